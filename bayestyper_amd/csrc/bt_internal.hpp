@@ -1,0 +1,104 @@
+// Internal (non-ABI) definitions shared by the libbtgpu translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/btgpu.h"
+#include "bt_kmer_device.hpp"
+
+namespace bt {
+
+void set_error(const std::string &msg);
+int fail(const std::string &msg);   // set_error + return BT_ERR
+
+#define BT_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return bt::fail(std::string(#call) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+#define BT_CHECK_LAUNCH()                                                                   \
+    do {                                                                                    \
+        hipError_t _e = hipGetLastError();                                                  \
+        if (_e != hipSuccess)                                                               \
+            return bt::fail(std::string("kernel launch: ") + hipGetErrorString(_e));        \
+    } while (0)
+
+inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks = 1u << 30) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (unsigned)g;
+}
+
+}  // namespace bt
+
+struct bt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;     // the stream work is submitted to
+    int num_cu = 0;
+};
+
+struct bt_timer {
+    bt_ctx *ctx = nullptr;
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+struct bt_bloom {
+    bt_ctx *ctx = nullptr;
+    uint64_t num_kmers = 0;       // per (sub-)filter
+    uint64_t num_bits = 0;        // per (sub-)filter
+    uint32_t num_hashes = 0;
+    uint32_t num_sub = 1;
+    uint32_t k = 0;
+    uint64_t stride = 0;          // bytes per sub-filter, multiple of 4
+    uint64_t bytes = 0;           // total device bytes
+    uint32_t *d_words = nullptr;
+    bt::BloomView view() const {
+        bt::BloomView v;
+        v.words = d_words;
+        v.stride = stride;
+        v.bits = bt::make_fastmod(num_bits);
+        v.num_hashes = num_hashes;
+        v.num_sub = num_sub;
+        v.k = k;
+        return v;
+    }
+};
+
+namespace bt {
+// Open-addressing table in HBM, structure of arrays.  state: 0 empty, 1 being written, 2 ready.
+struct TableView {
+    uint64_t *key_lo;
+    uint64_t *key_hi;
+    uint32_t *state;
+    uint32_t *meta;      // byte0 flags, byte1 max_haploid_multiplicity, byte2 female ic, byte3 male ic
+    uint32_t *counts;    // spad bytes per slot, viewed as words
+    uint64_t mask;       // capacity - 1
+    uint32_t spad;       // bytes of counts per slot (multiple of 4)
+    uint32_t k;
+    unsigned long long *num_keys;   // device counter
+    uint32_t *overflow;             // device flag
+};
+}  // namespace bt
+
+struct bt_table {
+    bt_ctx *ctx = nullptr;
+    uint64_t capacity = 0;
+    uint32_t num_samples = 0;
+    uint32_t spad = 0;
+    uint32_t k = 0;
+    bt::TableView v{};
+};
+
+struct bt_kmc_scan {
+    bt_ctx *ctx = nullptr;
+    uint32_t k = 0, p = 0, counter_size = 0, suffix_bytes = 0, rec_size = 0;
+    uint64_t total = 0;
+    uint64_t lut_entries = 0;   // 4^p + 1
+    uint64_t *d_lut = nullptr;
+};

@@ -1,0 +1,571 @@
+// libbtgpu: k-mer count table in HBM + the KMC count-table scan ("k-mer matches/sec").
+//
+//   bt_table_*            <- KmerCountsHash / ObservedKmerCountsHash<N> (KmerHash.hpp:73-87,
+//                            KmerHash.cpp:202-254) over KmerCounts (KmerCounts.cpp:40-223)
+//   bt_table_count_intercluster <- KmerCounter::countInterclusterKmersCallback (KmerCounter.cpp:291-338)
+//   bt_table_classify_batch     <- VariantClusterGraph::classifyPathKmers, table half (VariantClusterGraph.cpp:902-938)
+//   bt_kmc_scan_*         <- KmerCounter::parseSampleKmers(+CallBack) (KmerCounter.cpp:388-524),
+//                            record layout of CKMCFile::ReadNextKmer (kmc_file.cpp:428-494)
+//
+// The reference keeps a two-level map (16.7 M std::vector leaves + a mutex each).  Here the table is
+// one open-addressing array in HBM (structure of arrays, linear probing, power-of-two capacity):
+// per-key contents are identical, iteration order is free.
+#include "bt_internal.hpp"
+
+#include <cstring>
+
+using namespace bt;
+
+namespace {
+
+constexpr unsigned BLOCK = 256;
+constexpr uint32_t ST_EMPTY = 0, ST_BUSY = 1, ST_READY = 2;
+
+__device__ inline uint64_t mix64(uint64_t x) {   // murmur3 finaliser
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+__device__ inline uint64_t table_home(Kmer a, const TableView &t) { return mix64(a.lo ^ mix64(a.hi + 0x9e3779b97f4a7c15ULL)) & t.mask; }
+
+// findKmer: slot or -1
+__device__ inline int64_t table_find(const TableView &t, Kmer a) {
+    uint64_t idx = table_home(a, t);
+    for (uint64_t probes = 0; probes <= t.mask; ++probes) {
+        uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == ST_EMPTY) return -1;
+        if (st == ST_READY) {
+            uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lo == a.lo && hi == a.hi) return (int64_t)idx;
+            idx = (idx + 1) & t.mask;
+        }
+        // ST_BUSY: another lane is publishing this slot; poll it again (the writer never waits)
+        else
+            --probes;
+    }
+    return -1;
+}
+
+// addKmer: slot of the (possibly new) key, -1 if the table is full
+__device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a) {
+    uint64_t idx = table_home(a, t);
+    for (uint64_t probes = 0; probes <= t.mask;) {
+        uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == ST_EMPTY) {
+            uint32_t prev = atomicCAS(&t.state[idx], ST_EMPTY, ST_BUSY);
+            if (prev == ST_EMPTY) {
+                __hip_atomic_store(&t.key_lo[idx], a.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&t.key_hi[idx], a.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&t.state[idx], ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(t.num_keys, 1ULL);
+                return (int64_t)idx;
+            }
+            st = prev;
+        }
+        if (st == ST_READY) {
+            uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lo == a.lo && hi == a.hi) return (int64_t)idx;
+            idx = (idx + 1) & t.mask;
+            ++probes;
+        }
+        // ST_BUSY: poll again
+    }
+    atomicExch(t.overflow, 1u);
+    return -1;
+}
+
+// saturating u8 add on byte `byte_idx` of a word array (ObservedKmerCounts::addSampleCount,
+// KmerCounts.cpp:161-171; KmerCounts::updateMultiplicity :178-188)
+__device__ inline void sat_add_byte(uint32_t *words, uint64_t byte_idx, uint32_t add) {
+    uint32_t *w = &words[byte_idx >> 2];
+    const unsigned sh = (unsigned)(byte_idx & 3u) * 8u;
+    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+        uint32_t cur = (old >> sh) & 0xFFu;
+        uint32_t nv = cur + add;
+        if (nv > 255u) nv = 255u;
+        uint32_t desired = (old & ~(0xFFu << sh)) | (nv << sh);
+        if (desired == old) return;
+        uint32_t prev = atomicCAS(w, old, desired);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+
+// read-modify-write of one slot's meta word with a pure function of the old value
+template <typename F>
+__device__ inline uint32_t meta_update(uint32_t *w, F f) {
+    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+        uint32_t desired = f(old);
+        if (desired == old) return desired;
+        uint32_t prev = atomicCAS(w, old, desired);
+        if (prev == old) return desired;
+        old = prev;
+    }
+}
+
+__device__ inline uint32_t sat8(uint32_t cur, uint32_t add) {
+    uint32_t s = cur + add;
+    return s > 255u ? 255u : s;
+}
+
+// KmerCounts::addInterclusterMultiplicity (KmerCounts.cpp:98-118)
+__device__ inline uint32_t meta_add_intercluster(uint32_t m, bool is_decoy, uint32_t fem, uint32_t male) {
+    uint32_t flags = m & 0xFFu, maxhap = (m >> 8) & 0xFFu, f = (m >> 16) & 0xFFu, ml = (m >> 24) & 0xFFu;
+    maxhap = sat8(maxhap, 1);
+    if (maxhap > 127u) flags |= BT_KC_MAX_MULTIPLICITY;
+    if (is_decoy) flags |= BT_KC_DECOY_OCC;
+    else {
+        f = sat8(f, fem);
+        ml = sat8(ml, male);
+    }
+    return flags | (maxhap << 8) | (f << 16) | (ml << 24);
+}
+
+// KmerCounts::addClusterMultiplicity (KmerCounts.cpp:137-159)
+__device__ inline uint32_t meta_add_cluster(uint32_t m, uint32_t mult, bool is_multigroup) {
+    uint32_t flags = m & 0xFFu, maxhap = (m >> 8) & 0xFFu;
+    if (flags & BT_KC_CLUSTER_OCC) flags |= BT_KC_MULTICLUSTER_OCC;
+    flags |= BT_KC_CLUSTER_OCC;
+    if (is_multigroup) flags |= BT_KC_MULTIGROUP_OCC;
+    maxhap = sat8(maxhap, mult);
+    if (maxhap > 127u) flags |= BT_KC_MAX_MULTIPLICITY;
+    return (m & 0xFFFF0000u) | flags | (maxhap << 8);
+}
+
+__global__ __launch_bounds__(BLOCK) void table_insert_kernel(TableView t, const uint64_t *__restrict__ kmers, uint64_t n, int mark_parameter) {
+    for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        Kmer a{kmers[2 * i], kmers[2 * i + 1]};
+        int64_t slot = table_find_or_insert(t, a);
+        if (slot >= 0 && mark_parameter) atomicOr(&t.meta[slot], (uint32_t)BT_KC_PARAMETER);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void table_find_kernel(TableView t, const uint64_t *__restrict__ kmers, uint64_t n, int64_t *__restrict__ slots) {
+    for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        Kmer a{kmers[2 * i], kmers[2 * i + 1]};
+        slots[i] = table_find(t, a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// intercluster scan: sequence tile in LDS -> canonical k-mer per position -> path-Bloom test ->
+// table insert + addInterclusterMultiplicity.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned SEQ_TILE = 1024;
+
+__global__ __launch_bounds__(BLOCK) void intercluster_kernel(TableView t, BloomView bloom, const char *__restrict__ seq, uint64_t len,
+                                                             int is_decoy, uint32_t fem, uint32_t male) {
+    __shared__ uint8_t codes[SEQ_TILE + 64];
+    const unsigned k = t.k;
+    const uint64_t num_tiles = (len + SEQ_TILE - 1) / SEQ_TILE;
+    for (uint64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+        const uint64_t tile_start = tile * SEQ_TILE;
+        const uint64_t halo = k - 1;
+        for (unsigned j = threadIdx.x; j < SEQ_TILE + halo; j += BLOCK) {
+            int64_t pos = (int64_t)tile_start - (int64_t)halo + (int64_t)j;
+            uint8_t c = 0xFF;
+            if (pos >= 0 && (uint64_t)pos < len) {
+                int code = nt_code(seq[pos]);
+                c = code < 0 ? 0xFF : (uint8_t)code;
+            }
+            codes[j] = c;
+        }
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < SEQ_TILE; j += BLOCK) {
+            uint64_t pos = tile_start + j;
+            if (pos >= len) break;
+            Kmer fw{0, 0};
+            bool ok = true;
+            for (unsigned i = 0; i < k; ++i) {
+                uint8_t c = codes[j + i];
+                ok = ok && (c != 0xFF);
+                uint64_t v = (uint64_t)(c & 3u);
+                if (i < 32u) fw.lo |= v << (2u * i);
+                else fw.hi |= v << (2u * (i - 32u));
+            }
+            if (!ok) continue;
+            Kmer can = kmer_canonical(fw, k);
+            if (!bloom_contains(nthash64(can, k), bloom)) continue;
+            int64_t slot = table_find_or_insert(t, can);
+            if (slot < 0) continue;
+            meta_update(&t.meta[slot], [&](uint32_t m) { return meta_add_intercluster(m, is_decoy != 0, fem, male); });
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void classify_kernel(TableView t, BloomView mg_bloom, const uint64_t *__restrict__ kmers,
+                                                         const uint8_t *__restrict__ mult, uint64_t n, uint8_t *__restrict__ excluded) {
+    for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        Kmer a{kmers[2 * i], kmers[2 * i + 1]};
+        const uint32_t m = mult[i];
+        int64_t slot = (m > 127u) ? table_find_or_insert(t, a) : table_find(t, a);
+        uint8_t ex = 0;
+        if (slot >= 0) {
+            const bool is_mg = bloom_contains(nthash64(a, t.k), mg_bloom);
+            uint32_t nm = meta_update(&t.meta[slot], [&](uint32_t old) { return meta_add_cluster(old, m, is_mg); });
+            ex = (nm & (BT_KC_DECOY_OCC | BT_KC_MAX_MULTIPLICITY | BT_KC_MULTIGROUP_OCC)) ? 1 : 0;   // isExcluded, KmerCounts.cpp:93-96
+        }
+        if (excluded) excluded[i] = ex;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KMC scan.  One record per lane.  A workgroup handles RECS consecutive records whose raw bytes
+// it first copies to LDS with 16-byte loads (the 13-byte records are not naturally aligned).
+// k-mer of record n = prefix(n) (p symbols, from the LUT) ++ suffix bytes (4 symbols per byte,
+// first symbol in the top two bits) — kmc_file.cpp:437-474.
+// ---------------------------------------------------------------------------------------------
+struct KmcView {
+    const uint64_t *lut;     // 4^p + 1 entries
+    uint64_t lut_entries;
+    uint32_t k, p, counter_size, suffix_bytes, rec_size;
+};
+
+constexpr unsigned KMC_RECS = 256;          // records per workgroup iteration (= BLOCK)
+constexpr unsigned KMC_MAX_REC = 24;        // max record size in bytes (k<=64: 16 suffix + 4 counter)
+
+// prefix of record n: largest j with lut[j] <= n  (skips empty prefixes exactly like
+// ReadNextKmer's "while (buf[idx] == buf[idx+1]) idx++", kmc_file.cpp:439-445)
+__device__ inline uint64_t kmc_prefix_of(const KmcView &v, uint64_t n) {
+    uint64_t lo = 0, hi = v.lut_entries - 1;   // invariant: lut[lo] <= n < lut[hi]
+    while (hi - lo > 1) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (v.lut[mid] <= n) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline void kmc_decode(const KmcView &v, uint64_t prefix, const uint8_t *rec, Kmer &out, uint32_t &count) {
+    // assemble the k symbols MSB-first into a 128-bit big number, then reverse the group order
+    uint64_t bhi = 0, blo = 0;   // symbols s_0 .. s_{k-1}, s_0 most significant, right-aligned at bit 0
+    auto push = [&](uint64_t bits, unsigned nbits) {
+        bhi = (bhi << nbits) | (blo >> (64u - nbits));
+        blo = (blo << nbits) | bits;
+    };
+    if (v.p) {
+        const unsigned pb = 2u * v.p;   // <= 30 bits
+        push(prefix & ((1ULL << pb) - 1ULL), pb);
+    }
+    for (unsigned b = 0; b < v.suffix_bytes; ++b) push((uint64_t)rec[b], 8u);
+    // now symbol i (0-based from the left) sits at group (k-1-i); our packing wants symbol i at group i:
+    // reverse all 64 groups, then shift down by (64-k) groups
+    uint64_t rlo = rev2bit64(bhi), rhi = rev2bit64(blo);
+    unsigned sh = 2u * (64u - v.k);
+    if (sh == 0) { out.lo = rlo; out.hi = rhi; }
+    else if (sh < 64u) { out.lo = (rlo >> sh) | (rhi << (64u - sh)); out.hi = rhi >> sh; }
+    else if (sh == 64u) { out.lo = rhi; out.hi = 0; }
+    else { out.lo = rhi >> (sh - 64u); out.hi = 0; }
+    count = 0;
+    for (unsigned b = 0; b < v.counter_size; ++b) count |= (uint32_t)rec[v.suffix_bytes + b] << (8u * b);
+}
+
+template <bool DECODE_ONLY>
+__global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bloom, TableView t, uint32_t sample_idx,
+                                                         const uint8_t *__restrict__ records, uint64_t first_record, uint64_t n,
+                                                         unsigned long long *__restrict__ hit_count, uint64_t *__restrict__ out_kmers,
+                                                         uint32_t *__restrict__ out_counts) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[KMC_RECS * KMC_MAX_REC + 32];
+    __shared__ unsigned block_hits;
+    const uint64_t num_chunks = (n + KMC_RECS - 1) / KMC_RECS;
+    for (uint64_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
+        const uint64_t rec0 = chunk * KMC_RECS;
+        const unsigned nrec = (unsigned)((n - rec0) < KMC_RECS ? (n - rec0) : KMC_RECS);
+        const uint64_t byte0 = rec0 * v.rec_size;
+        const unsigned nbytes = nrec * v.rec_size;
+        if (threadIdx.x == 0) block_hits = 0;
+        // 16-byte aligned window that covers [byte0, byte0 + nbytes)
+        const uint64_t a0 = byte0 & ~15ULL;
+        const unsigned lead = (unsigned)(byte0 - a0);
+        const unsigned nvec = (lead + nbytes + 15u) / 16u;
+        const uint64_t total_bytes = n * (uint64_t)v.rec_size;
+        for (unsigned j = threadIdx.x; j < nvec; j += BLOCK) {
+            const uint64_t off = a0 + (uint64_t)j * 16u;
+            if (off + 16u <= total_bytes) {
+                *reinterpret_cast<uint4 *>(&stage[j * 16u]) = *reinterpret_cast<const uint4 *>(records + off);
+            } else {
+                for (unsigned q = 0; q < 16u; ++q) stage[j * 16u + q] = (off + q < total_bytes) ? records[off + q] : 0;
+            }
+        }
+        __syncthreads();
+        unsigned my_hit = 0;
+        if (threadIdx.x < nrec) {
+            const uint64_t ridx = rec0 + threadIdx.x;            // index inside this call
+            const uint64_t gidx = first_record + ridx;           // index inside the database
+            const uint8_t *rec = &stage[lead + threadIdx.x * v.rec_size];
+            Kmer a;
+            uint32_t count;
+            kmc_decode(v, kmc_prefix_of(v, gidx), rec, a, count);
+            if (DECODE_ONLY) {
+                out_kmers[2 * ridx] = a.lo;
+                out_kmers[2 * ridx + 1] = a.hi;
+                out_counts[ridx] = count;
+            } else if (bloom_contains(nthash64(a, v.k), bloom)) {     // KmerCounter.cpp:412
+                my_hit = 1;
+                int64_t slot = table_find_or_insert(t, a);            // addKmer(kmer, false), :416
+                if (slot >= 0) sat_add_byte(t.counts, (uint64_t)slot * t.spad + sample_idx, count > 255u ? 255u : count);   // :419
+            }
+        }
+        if (!DECODE_ONLY && hit_count) {
+            // one atomic per wavefront, then one per workgroup
+            unsigned long long ballot = __ballot(my_hit);
+            if ((threadIdx.x & 63u) == 0 && ballot) atomicAdd(&block_hits, (unsigned)__popcll(ballot));
+            __syncthreads();
+            if (threadIdx.x == 0 && block_hits) atomicAdd(hit_count, (unsigned long long)block_hits);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_table_create(bt_ctx *ctx, uint64_t expected_size, uint32_t num_samples, uint32_t k, bt_table **out) {
+    if (!ctx || !out) return fail("bt_table_create: null argument");
+    if (num_samples < 1 || num_samples > 30) return fail("bt_table_create: number of samples must be in 1..30");   // main.cpp:72
+    if (k < 1 || k > 64) return fail("bt_table_create: k must be in 1..64");
+    uint64_t cap = 1024;
+    while (cap < expected_size * 2) cap <<= 1;
+    bt_table *t = new bt_table();
+    t->ctx = ctx;
+    t->capacity = cap;
+    t->num_samples = num_samples;
+    t->spad = (num_samples + 3u) & ~3u;
+    t->k = k;
+    BT_HIP(hipSetDevice(ctx->device));
+    TableView &v = t->v;
+    v.mask = cap - 1;
+    v.spad = t->spad;
+    v.k = k;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.key_lo), cap * 8));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.key_hi), cap * 8));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.state), cap * 4));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.meta), cap * 4));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.counts), cap * (uint64_t)t->spad));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.num_keys), 8));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.overflow), 4));
+    BT_HIP(hipMemsetAsync(v.state, 0, cap * 4, ctx->stream));
+    BT_HIP(hipMemsetAsync(v.meta, 0, cap * 4, ctx->stream));
+    BT_HIP(hipMemsetAsync(v.counts, 0, cap * (uint64_t)t->spad, ctx->stream));
+    BT_HIP(hipMemsetAsync(v.num_keys, 0, 8, ctx->stream));
+    BT_HIP(hipMemsetAsync(v.overflow, 0, 4, ctx->stream));
+    *out = t;
+    return BT_OK;
+}
+
+int bt_table_destroy(bt_table *t) {
+    if (!t) return BT_OK;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)hipFree(t->v.key_lo);
+    (void)hipFree(t->v.key_hi);
+    (void)hipFree(t->v.state);
+    (void)hipFree(t->v.meta);
+    (void)hipFree(t->v.counts);
+    (void)hipFree(t->v.num_keys);
+    (void)hipFree(t->v.overflow);
+    delete t;
+    return BT_OK;
+}
+
+int bt_table_status(bt_table *t, uint64_t *num_keys, uint64_t *capacity, int *overflowed) {
+    if (!t) return fail("bt_table_status: null table");
+    BT_HIP(hipSetDevice(t->ctx->device));
+    unsigned long long nk = 0;
+    uint32_t ov = 0;
+    BT_HIP(hipMemcpyAsync(&nk, t->v.num_keys, 8, hipMemcpyDeviceToHost, t->ctx->stream));
+    BT_HIP(hipMemcpyAsync(&ov, t->v.overflow, 4, hipMemcpyDeviceToHost, t->ctx->stream));
+    BT_HIP(hipStreamSynchronize(t->ctx->stream));
+    if (num_keys) *num_keys = nk;
+    if (capacity) *capacity = t->capacity;
+    if (overflowed) *overflowed = (int)ov;
+    return BT_OK;
+}
+
+int bt_table_insert_batch(bt_table *t, const uint64_t *d_kmers, uint64_t n, int mark_parameter) {
+    if (!t) return fail("bt_table_insert_batch: null table");
+    if (n == 0) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    hipLaunchKernelGGL(table_insert_kernel, dim3(grid_for(n, BLOCK, t->ctx->num_cu * 16)), dim3(BLOCK), 0, t->ctx->stream, t->v, d_kmers, n,
+                       mark_parameter);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+int bt_table_find_batch(bt_table *t, const uint64_t *d_kmers, uint64_t n, int64_t *d_slots) {
+    if (!t) return fail("bt_table_find_batch: null table");
+    if (n == 0) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    hipLaunchKernelGGL(table_find_kernel, dim3(grid_for(n, BLOCK, t->ctx->num_cu * 16)), dim3(BLOCK), 0, t->ctx->stream, t->v, d_kmers, n,
+                       d_slots);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+int bt_table_read_slots(bt_table *t, const int64_t *h_slots, uint64_t n, uint8_t *h_counts, uint8_t *h_meta) {
+    if (!t || !h_slots) return fail("bt_table_read_slots: null argument");
+    BT_HIP(hipSetDevice(t->ctx->device));
+    BT_HIP(hipStreamSynchronize(t->ctx->stream));
+    std::vector<uint8_t> cbuf(t->spad);
+    for (uint64_t i = 0; i < n; ++i) {
+        int64_t s = h_slots[i];
+        if (s < 0 || (uint64_t)s >= t->capacity) {
+            if (h_counts) for (uint32_t j = 0; j < t->num_samples; ++j) h_counts[i * t->num_samples + j] = 0;
+            if (h_meta) for (int j = 0; j < 4; ++j) h_meta[i * 4 + j] = 0;
+            continue;
+        }
+        if (h_counts) {
+            BT_HIP(hipMemcpy(cbuf.data(), reinterpret_cast<const uint8_t *>(t->v.counts) + (uint64_t)s * t->spad, t->spad, hipMemcpyDeviceToHost));
+            for (uint32_t j = 0; j < t->num_samples; ++j) h_counts[i * t->num_samples + j] = cbuf[j];
+        }
+        if (h_meta) BT_HIP(hipMemcpy(h_meta + i * 4, t->v.meta + s, 4, hipMemcpyDeviceToHost));
+    }
+    return BT_OK;
+}
+
+int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *h_meta, uint64_t max_records, uint64_t *num_written) {
+    if (!t || !num_written) return fail("bt_table_export: null argument");
+    BT_HIP(hipSetDevice(t->ctx->device));
+    BT_HIP(hipStreamSynchronize(t->ctx->stream));
+    const uint64_t cap = t->capacity;
+    std::vector<uint64_t> lo(cap), hi(cap);
+    std::vector<uint32_t> st(cap), meta(cap);
+    std::vector<uint8_t> counts(cap * t->spad);
+    BT_HIP(hipMemcpy(lo.data(), t->v.key_lo, cap * 8, hipMemcpyDeviceToHost));
+    BT_HIP(hipMemcpy(hi.data(), t->v.key_hi, cap * 8, hipMemcpyDeviceToHost));
+    BT_HIP(hipMemcpy(st.data(), t->v.state, cap * 4, hipMemcpyDeviceToHost));
+    BT_HIP(hipMemcpy(meta.data(), t->v.meta, cap * 4, hipMemcpyDeviceToHost));
+    BT_HIP(hipMemcpy(counts.data(), t->v.counts, cap * t->spad, hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < cap; ++i) {
+        if (st[i] != ST_READY) continue;
+        if (w >= max_records) return fail("bt_table_export: output arrays too small");
+        if (h_kmers) {
+            h_kmers[2 * w] = lo[i];
+            h_kmers[2 * w + 1] = hi[i];
+        }
+        if (h_counts) for (uint32_t j = 0; j < t->num_samples; ++j) h_counts[w * t->num_samples + j] = counts[i * t->spad + j];
+        if (h_meta) std::memcpy(h_meta + w * 4, &meta[i], 4);
+        ++w;
+    }
+    *num_written = w;
+    return BT_OK;
+}
+
+int bt_table_count_intercluster(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint64_t len, int is_decoy, uint32_t female_ploidy,
+                                uint32_t male_ploidy) {
+    if (!t || !path_bloom) return fail("bt_table_count_intercluster: null argument");
+    if (path_bloom->k != t->k) return fail("bt_table_count_intercluster: k mismatch between table and bloom");
+    if (len == 0) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    unsigned grid = grid_for((len + SEQ_TILE - 1) / SEQ_TILE, 1, t->ctx->num_cu * 8);
+    hipLaunchKernelGGL(intercluster_kernel, dim3(grid), dim3(BLOCK), 0, t->ctx->stream, t->v, path_bloom->view(), d_seq, len, is_decoy,
+                       female_ploidy, male_ploidy);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+int bt_table_classify_batch(bt_table *t, bt_bloom *multigroup_bloom, const uint64_t *d_kmers, const uint8_t *d_mult, uint64_t n,
+                            uint8_t *d_excluded) {
+    if (!t || !multigroup_bloom) return fail("bt_table_classify_batch: null argument");
+    if (multigroup_bloom->k != t->k) return fail("bt_table_classify_batch: k mismatch between table and bloom");
+    if (n == 0) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    hipLaunchKernelGGL(classify_kernel, dim3(grid_for(n, BLOCK, t->ctx->num_cu * 16)), dim3(BLOCK), 0, t->ctx->stream, t->v,
+                       multigroup_bloom->view(), d_kmers, d_mult, n, d_excluded);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+int bt_kmc_scan_create(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_t counter_size, uint64_t total_records,
+                       const uint64_t *h_prefix_lut, bt_kmc_scan **out) {
+    if (!ctx || !out || !h_prefix_lut) return fail("bt_kmc_scan_create: null argument");
+    if (k < 1 || k > 64) return fail("bt_kmc_scan_create: k must be in 1..64");
+    if (lut_prefix_len > k || lut_prefix_len > 15 || ((k - lut_prefix_len) % 4) != 0)
+        return fail("bt_kmc_scan_create: (k - lut_prefix_len) must be a non-negative multiple of 4 and lut_prefix_len <= 15");
+    if (counter_size < 1 || counter_size > 4) return fail("bt_kmc_scan_create: counter_size must be in 1..4");
+    bt_kmc_scan *s = new bt_kmc_scan();
+    s->ctx = ctx;
+    s->k = k;
+    s->p = lut_prefix_len;
+    s->counter_size = counter_size;
+    s->suffix_bytes = (k - lut_prefix_len) / 4;
+    s->rec_size = s->suffix_bytes + counter_size;
+    s->total = total_records;
+    s->lut_entries = (1ULL << (2 * lut_prefix_len)) + 1;
+    if (h_prefix_lut[s->lut_entries - 1] != total_records || h_prefix_lut[0] != 0) {
+        delete s;
+        return fail("bt_kmc_scan_create: prefix LUT must start at 0 and end at total_records");
+    }
+    BT_HIP(hipSetDevice(ctx->device));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_lut), s->lut_entries * 8));
+    BT_HIP(hipMemcpyAsync(s->d_lut, h_prefix_lut, s->lut_entries * 8, hipMemcpyHostToDevice, ctx->stream));
+    BT_HIP(hipStreamSynchronize(ctx->stream));
+    *out = s;
+    return BT_OK;
+}
+
+int bt_kmc_scan_destroy(bt_kmc_scan *s) {
+    if (!s) return BT_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->d_lut) (void)hipFree(s->d_lut);
+    delete s;
+    return BT_OK;
+}
+
+static KmcView make_kmc_view(const bt_kmc_scan *s) {
+    KmcView v;
+    v.lut = s->d_lut;
+    v.lut_entries = s->lut_entries;
+    v.k = s->k;
+    v.p = s->p;
+    v.counter_size = s->counter_size;
+    v.suffix_bytes = s->suffix_bytes;
+    v.rec_size = s->rec_size;
+    return v;
+}
+
+int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *d_records,
+                    uint64_t first_record, uint64_t n, uint64_t *d_hit_count) {
+    if (!s || !path_bloom || !table) return fail("bt_kmc_scan_run: null argument");
+    if (path_bloom->k != s->k || table->k != s->k) return fail("bt_kmc_scan_run: k mismatch");
+    if (sample_idx >= table->num_samples) return fail("bt_kmc_scan_run: sample index out of range");
+    if (first_record + n > s->total) return fail("bt_kmc_scan_run: record range exceeds the database");
+    if ((reinterpret_cast<uintptr_t>(d_records) & 15u) != 0) return fail("bt_kmc_scan_run: d_records must be 16-byte aligned");
+    if (n == 0) return BT_OK;
+    BT_HIP(hipSetDevice(s->ctx->device));
+    unsigned grid = grid_for((n + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8);
+    hipLaunchKernelGGL(kmc_scan_kernel<false>, dim3(grid), dim3(BLOCK), 0, s->ctx->stream, make_kmc_view(s), path_bloom->view(), table->v,
+                       sample_idx, d_records, first_record, n, reinterpret_cast<unsigned long long *>(d_hit_count), (uint64_t *)nullptr,
+                       (uint32_t *)nullptr);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+int bt_kmc_scan_decode(bt_kmc_scan *s, const uint8_t *d_records, uint64_t first_record, uint64_t n, uint64_t *d_kmers, uint32_t *d_counts) {
+    if (!s || !d_kmers || !d_counts) return fail("bt_kmc_scan_decode: null argument");
+    if (first_record + n > s->total) return fail("bt_kmc_scan_decode: record range exceeds the database");
+    if ((reinterpret_cast<uintptr_t>(d_records) & 15u) != 0) return fail("bt_kmc_scan_decode: d_records must be 16-byte aligned");
+    if (n == 0) return BT_OK;
+    BT_HIP(hipSetDevice(s->ctx->device));
+    unsigned grid = grid_for((n + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8);
+    BloomView nob{};
+    TableView not_{};
+    hipLaunchKernelGGL(kmc_scan_kernel<true>, dim3(grid), dim3(BLOCK), 0, s->ctx->stream, make_kmc_view(s), nob, not_, 0u, d_records,
+                       first_record, n, (unsigned long long *)nullptr, d_kmers, d_counts);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+/*
+ * btgpu.h — C ABI of libbtgpu.so: the MI355X (gfx950) implementation of BayesTyper's
+ * k-mer matching + per-cluster Gibbs genotyping hot path.
+ *
+ * The reference (BayesTyper v1.5, C++11) has no FFI; the seams below are cut at the
+ * narrowest points of its own class structure.  Every entry point cites
+ * the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, opaque handles, no exceptions cross the boundary;
+ *   - every call returns int: 0 = ok, non-zero = error, text via bt_last_error();
+ *   - pointers named d_* are DEVICE pointers (hipMalloc / bt_malloc / a torch tensor's
+ *     data_ptr); everything else is host memory owned by the caller;
+ *   - batch calls are asynchronous on the context's stream; bt_sync() waits;
+ *   - handles are not thread-safe, distinct handles are; one bt_ctx per GPU;
+ *   - k-mers are passed 2-bit packed in two uint64 words {lo, hi}: nucleotide i sits in
+ *     bits (2i, 2i+1) of the 128-bit value, A=0 C=1 G=2 T=3 — the bit layout of the
+ *     reference's std::bitset<2k> (include/bayesTyper/Nucleotide.hpp:40-70).
+ *     k <= 64.  Unless stated otherwise k-mers must already be canonical
+ *     (include/bayesTyper/Kmer.tpp:225-255).
+ */
+#ifndef BTGPU_H
+#define BTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT_OK 0
+#define BT_ERR 1
+
+/* ------------------------------------------------------------------------------------------
+ * Context, memory, timing
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_ctx bt_ctx;
+
+/* last error message of the calling thread ("" if none) */
+const char *bt_last_error(void);
+/* library/ABI version, e.g. 100 = 1.0.0 */
+int bt_version(void);
+/* number of visible HIP devices (0 and BT_OK when there is none) */
+int bt_device_count(int *count);
+
+/* one context = one GPU + one stream (replaces the reference's `-p` thread pool for this path:
+ * src/bayesTyper/main.cpp:128,214,467) */
+int bt_ctx_create(int device_id, bt_ctx **out);
+int bt_ctx_destroy(bt_ctx *ctx);
+/* run all subsequent work of this context on an externally owned hipStream_t (e.g. torch's
+ * current stream); NULL restores the context's own stream */
+int bt_ctx_set_stream(bt_ctx *ctx, void *hip_stream);
+int bt_sync(bt_ctx *ctx);
+/* device properties: compute units, total/free HBM bytes, gcn arch name (buffer >= 64 bytes) */
+int bt_ctx_info(bt_ctx *ctx, int *num_cu, uint64_t *hbm_total, uint64_t *hbm_free, char *arch, size_t arch_len);
+
+int bt_malloc(bt_ctx *ctx, size_t bytes, void **d_out);
+int bt_free(bt_ctx *ctx, void *d_ptr);
+int bt_memset(bt_ctx *ctx, void *d_ptr, int value, size_t bytes);
+int bt_memcpy_h2d(bt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int bt_memcpy_d2h(bt_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* HIP-event timing on the context's stream (bench.py's roofline leg) */
+typedef struct bt_timer bt_timer;
+int bt_timer_create(bt_ctx *ctx, bt_timer **out);
+int bt_timer_destroy(bt_timer *t);
+int bt_timer_start(bt_timer *t);
+int bt_timer_stop(bt_timer *t);
+/* waits for the stop event; milliseconds between start and stop */
+int bt_timer_elapsed_ms(bt_timer *t, float *ms);
+
+/* ------------------------------------------------------------------------------------------
+ * k-mer packing / canonical form
+ *   mirrors KmerPair<k>::move + getLexicographicalLowestKmer
+ *   (include/bayesTyper/Kmer.tpp:44-81,116-153,182-255) and Nucleotide::ntToBit
+ *   (include/bayesTyper/Nucleotide.hpp:40-70)
+ * ---------------------------------------------------------------------------------------- */
+/* For every position i of the ASCII sequence d_seq[0..len): if the k characters ending at i are
+ * all in ACGTacgt, write the canonical k-mer of seq[i-k+1..i] to d_kmers[2*i..2*i+1] and 1 to
+ * d_valid[i]; else d_valid[i] = 0 (the k-mer window "resets" on any other character, exactly
+ * as KmerPair::move does). */
+int bt_kmers_from_sequence(bt_ctx *ctx, const char *d_seq, uint64_t len, uint32_t k,
+                           uint64_t *d_kmers, uint8_t *d_valid);
+
+/* ------------------------------------------------------------------------------------------
+ * ntHash (external/ntHash/nthash.hpp:262-267 NTP64(kmer,k); :275-282 NTP64(kmer,k,seed))
+ * ---------------------------------------------------------------------------------------- */
+/* d_hash[i] = NTP64(kmer_i, k); if seeded != 0: NTP64(kmer_i, k, seed) */
+int bt_nthash_batch(bt_ctx *ctx, const uint64_t *d_kmers, uint64_t n, uint32_t k,
+                    int seeded, uint32_t seed, uint64_t *d_hash);
+
+/* ------------------------------------------------------------------------------------------
+ * Bloom filters: KmerBloom<k> and ThreadedKmerBloom<k>
+ *   include/kmerBloom/KmerBloom.hpp:48-108, src/kmerBloom/KmerBloom.cpp:54-286,
+ *   external/ntHash/BloomFilter.hpp:40-66,149-161,260-264
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_bloom bt_bloom;
+
+/* KmerBloom<k>(num_kmers, fpr)               threaded == 0   (KmerBloom.cpp:54-60)
+ * ThreadedKmerBloom<k>(num_kmers, fpr)       threaded != 0   (KmerBloom.cpp:204-215): 65 536
+ * sub-filters each sized for ceil(num_kmers / 65536.0f) k-mers, routed by
+ * NTP64(kmer,k,1029283129) % 65536 (KmerBloom.cpp:277-280). */
+int bt_bloom_create(bt_ctx *ctx, uint64_t num_kmers, float fpr, uint32_t k, int threaded, bt_bloom **out);
+/* KmerBloom<k>(prefix): reads <prefix>.bloomMeta / <prefix>.bloomData (KmerBloom.cpp:63-89).
+ * Fails (like the reference's assert) when the stored k differs. */
+int bt_bloom_load(bt_ctx *ctx, const char *prefix, uint32_t k, bt_bloom **out);
+/* KmerBloom::save (KmerBloom.cpp:149-164); byte-identical files. Single filters only
+ * (the reference's ThreadedKmerBloom::save is commented out, KmerBloom.hpp:100). */
+int bt_bloom_save(bt_bloom *b, const char *prefix);
+int bt_bloom_destroy(bt_bloom *b);
+/* sizing as computed by calcOptNumBloomBits / calcOptNumHashes (KmerBloom.cpp:134-146);
+ * for a threaded filter num_kmers/num_bits are per sub-filter */
+int bt_bloom_info(bt_bloom *b, uint64_t *num_kmers, uint64_t *num_bits, uint32_t *num_hashes,
+                  uint32_t *num_sub_filters, uint64_t *device_bytes);
+/* addKmer for a batch (BloomFilter::insertF, BloomFilter.hpp:56-66) */
+int bt_bloom_insert_batch(bt_bloom *b, const uint64_t *d_kmers, uint64_t n);
+/* lookup for a batch (BloomFilter::containsF, BloomFilter.hpp:149-161): d_hits[i] = 0/1 */
+int bt_bloom_contains_batch(bt_bloom *b, const uint64_t *d_kmers, uint64_t n, uint8_t *d_hits);
+/* raw bit image of sub-filter `sub` (0 for a single filter) as the reference stores it:
+ * (num_bits+7)/8 bytes, bit b at byte b/8, mask 1<<(7-b%8) */
+int bt_bloom_read_bits(bt_bloom *b, uint32_t sub, uint8_t *h_out, uint64_t nbytes);
+int bt_bloom_clear(bt_bloom *b);
+
+/* ------------------------------------------------------------------------------------------
+ * k-mer count table: KmerCountsHash / ObservedKmerCountsHash<N> + KmerCounts
+ *   include/bayesTyper/KmerHash.hpp:73-87, include/bayesTyper/KmerCounts.hpp:35-101,
+ *   src/bayesTyper/KmerCounts.cpp:40-223.  Per-key contents equal the reference's; the
+ *   iteration order is free (open addressing in HBM instead of HybridHash's 16.7 M leaves).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_table bt_table;
+
+/* flag bits of bt_table meta byte 0 (KmerCounts.hpp:70) */
+#define BT_KC_CLUSTER_OCC      0x01
+#define BT_KC_MULTICLUSTER_OCC 0x02
+#define BT_KC_MULTIGROUP_OCC   0x04
+#define BT_KC_DECOY_OCC        0x08
+#define BT_KC_MAX_MULTIPLICITY 0x10
+#define BT_KC_PARAMETER        0x20
+
+/* ObservedKmerCountsHash<N>(expected_size, threads) (src/bayesTyper/KmerHash.cpp:202-210);
+ * num_samples <= 30 (src/bayesTyper/main.cpp:72).  Capacity is fixed: 2 x expected rounded
+ * up to a power of two; an insert into a full table is an error reported by bt_table_status. */
+int bt_table_create(bt_ctx *ctx, uint64_t expected_size, uint32_t num_samples, uint32_t k, bt_table **out);
+int bt_table_destroy(bt_table *t);
+/* number of stored keys, capacity, overflow flag */
+int bt_table_status(bt_table *t, uint64_t *num_keys, uint64_t *capacity, int *overflowed);
+/* addKmer(kmer, sorted) for a batch; optionally mark as parameter k-mer
+ * (main.cpp:571-577: addKmer + isParameter(true)) */
+int bt_table_insert_batch(bt_table *t, const uint64_t *d_kmers, uint64_t n, int mark_parameter);
+/* findKmer for a batch: d_slots[i] = slot index or -1 */
+int bt_table_find_batch(bt_table *t, const uint64_t *d_kmers, uint64_t n, int64_t *d_slots);
+/* read records of slots found with bt_table_find_batch (slot -1 -> zeros):
+ * h_counts[i*num_samples + s], h_meta[i*4 + {flags, max_haploid_mult, female_ic, male_ic}] */
+int bt_table_read_slots(bt_table *t, const int64_t *h_slots, uint64_t n, uint8_t *h_counts, uint8_t *h_meta);
+/* export every stored record (iteration order unspecified); arrays sized by bt_table_status */
+int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *h_meta, uint64_t max_records, uint64_t *num_written);
+
+/* KmerCounter::countInterclusterKmers for ONE region (src/bayesTyper/KmerCounter.cpp:291-338):
+ * slide over d_seq[0..len), canonical k-mers that hit `path_bloom` are added to the table
+ * (addKmer sorted) and get addInterclusterMultiplicity(is_decoy, {female_ploidy, male_ploidy})
+ * (KmerCounts.cpp:98-118). */
+int bt_table_count_intercluster(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint64_t len,
+                                int is_decoy, uint32_t female_ploidy, uint32_t male_ploidy);
+
+/* the table-update half of VariantClusterGraph::classifyPathKmers for one batch of DISTINCT
+ * path k-mers of distinct clusters (src/bayesTyper/VariantClusterGraph.cpp:902-938): for k-mer i
+ * with max-over-paths multiplicity d_mult[i]: findKmer; absent and mult > 127 -> addKmer;
+ * present -> addClusterMultiplicity(mult, multigroup_bloom.lookup(kmer)) (KmerCounts.cpp:137-159);
+ * d_excluded[i] = isExcluded() after the update (0 when absent).  A k-mer may occur several
+ * times in the batch (once per cluster that contains it). */
+int bt_table_classify_batch(bt_table *t, bt_bloom *multigroup_bloom, const uint64_t *d_kmers,
+                            const uint8_t *d_mult, uint64_t n, uint8_t *d_excluded);
+
+/* ------------------------------------------------------------------------------------------
+ * KMC count-table scan: KmerCounter::parseSampleKmers + parseSampleKmersCallBack
+ *   src/bayesTyper/KmerCounter.cpp:388-524; KMC record layout external/kmc_api/kmc_file.cpp:428-494
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_kmc_scan bt_kmc_scan;
+
+/* Describes one KMC database for the scan: k, lut_prefix_length p ((k-p)%4==0), counter_size
+ * (1..4 bytes, little endian; counts must be <= 255 as asserted at KmerCounter.cpp:401),
+ * total record count and the prefix LUT (4^p + 1 entries: LUT[j] = index of the first record
+ * whose prefix is >= j, LUT[4^p] = total; host memory, copied). */
+int bt_kmc_scan_create(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_t counter_size,
+                       uint64_t total_records, const uint64_t *h_prefix_lut, bt_kmc_scan **out);
+int bt_kmc_scan_destroy(bt_kmc_scan *s);
+/* Push records [first_record, first_record + n) of the .kmc_suf payload through
+ * decode -> path_bloom.lookup -> (on hit) table.addKmer(unsorted) + addSampleCount(sample, count).
+ * d_records points at the first byte of record `first_record` and must be 16-byte aligned;
+ * record size = (k-p)/4 + counter_size.  d_hit_count (optional, device uint64) is incremented
+ * by the number of Bloom hits. */
+int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx,
+                    const uint8_t *d_records, uint64_t first_record, uint64_t n, uint64_t *d_hit_count);
+/* decode only (tests): d_kmers[2*i..] = packed k-mer of record i, d_counts[i] = its count */
+int bt_kmc_scan_decode(bt_kmc_scan *s, const uint8_t *d_records, uint64_t first_record, uint64_t n,
+                       uint64_t *d_kmers, uint32_t *d_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTGPU_H */

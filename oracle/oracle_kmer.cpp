@@ -1,0 +1,530 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product: only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load this library, and only as the checker / CPU baseline.
+//
+// Plain scalar C++ restatement of the reference's k-mer side of the hot path (BayesTyper v1.5).
+// Each function cites the reference lines it follows (paths relative to the reference root).
+// Parity status: PINNED — validated bit-for-bit against the reference's own translation units
+// compiled unmodified into oracle/_ref/libbtref.so (tests/test_oracle_vs_ref.py) and against the
+// known answers of SURVEY.md Appendix A.2 (tests/golden/known_answers.json).
+//
+// The oracle deliberately works on ASCII k-mers and byte-addressed filters like the reference does
+// (the product works on 2-bit packed words), so the two implementations share no code.
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---- ntHash: external/ntHash/nthash.hpp:18-28 (seeds), :30-118 (msTab = rol(seed, j)), :262-282 ----
+const uint64_t kSeedA = 0x3c8bfbb395c60474ULL, kSeedC = 0x3193c18562a02b4cULL, kSeedG = 0x20323ed082572324ULL,
+               kSeedT = 0x295549f54be24456ULL;
+const uint64_t kMultiSeed = 0x90b45d39fb6da1faULL;
+const int kMultiShift = 27;
+
+inline uint64_t rol(uint64_t x, unsigned r) { r %= 64; return r ? (x << r) | (x >> (64 - r)) : x; }
+
+// msTab[c][j]: rows for A/a C/c G/g T/t are the rotated seeds, every other character is the zero row
+// (nthash.hpp:85-118)
+inline uint64_t ms_tab(unsigned char c, unsigned j) {
+    switch (c) {
+        case 'A': case 'a': return rol(kSeedA, j);
+        case 'C': case 'c': return rol(kSeedC, j);
+        case 'G': case 'g': return rol(kSeedG, j);
+        case 'T': case 't': return rol(kSeedT, j);
+        default: return 0;
+    }
+}
+
+uint64_t ntp64(const char *kmer, unsigned k) {   // nthash.hpp:262-267
+    uint64_t h = 0;
+    for (unsigned i = 0; i < k; i++) h ^= ms_tab((unsigned char)kmer[i], (k - 1 - i) % 64);
+    return h;
+}
+
+uint64_t ntp64_seed(const char *kmer, unsigned k, unsigned seed) {   // nthash.hpp:275-282
+    uint64_t h = ntp64(kmer, k);
+    h *= seed ^ k * kMultiSeed;   // same C precedence as the reference: seed ^ (k * multiSeed)
+    h ^= h >> kMultiShift;
+    return h;
+}
+
+// ---- BloomFilter: external/ntHash/BloomFilter.hpp:40-66,149-161 ----
+struct FlatBloom {
+    uint64_t m_size = 0;
+    unsigned m_hashNum = 0, m_kmerSize = 0;
+    std::vector<unsigned char> filter;
+    FlatBloom(uint64_t size, unsigned hashes, unsigned k) : m_size(size), m_hashNum(hashes), m_kmerSize(k), filter((size + 7) / 8, 0) {}
+    void insertF(const char *kmer) {
+        uint64_t h = ntp64(kmer, m_kmerSize);
+        uint64_t loc = h % m_size;
+        filter[loc / 8] |= (1 << (7 - loc % 8));
+        for (unsigned i = 1; i < m_hashNum; i++) {
+            uint64_t mh = h * (i ^ m_kmerSize * kMultiSeed);
+            mh ^= mh >> kMultiShift;
+            uint64_t l = mh % m_size;
+            filter[l / 8] |= (1 << (7 - l % 8));
+        }
+    }
+    bool containsF(const char *kmer) const {
+        uint64_t h = ntp64(kmer, m_kmerSize);
+        uint64_t loc = h % m_size;
+        if ((filter[loc / 8] & (1 << (7 - loc % 8))) == 0) return false;
+        for (unsigned i = 1; i < m_hashNum; i++) {
+            uint64_t mh = h * (i ^ m_kmerSize * kMultiSeed);
+            mh ^= mh >> kMultiShift;
+            uint64_t l = mh % m_size;
+            if ((filter[l / 8] & (1 << (7 - l % 8))) == 0) return false;
+        }
+        return true;
+    }
+};
+
+// ---- KmerBloom sizing: src/kmerBloom/KmerBloom.cpp:134-146 (types kept: float fpr, uint64 n) ----
+uint64_t calcOptNumBloomBits(const float fpr, const uint64_t num_kmers) {
+    auto ln2 = std::log(2);
+    return std::ceil(-(num_kmers * std::log(fpr) / ln2 / ln2));
+}
+unsigned calcOptNumHashes(const uint64_t num_bloom_bits, const uint64_t num_kmers) {
+    auto frac = static_cast<double>(num_bloom_bits) / static_cast<double>(num_kmers);
+    return std::ceil(frac * std::log(2));
+}
+
+// KmerBloom (KmerBloom.cpp:54-60) or ThreadedKmerBloom (KmerBloom.cpp:204-215,277-280)
+struct OrcBloom {
+    unsigned k = 0;
+    uint64_t num_kmers = 0, num_bits = 0;
+    unsigned num_hashes = 0;
+    std::vector<FlatBloom> subs;   // 1 or 65536
+    unsigned route(const char *kmer) const { return subs.size() == 1 ? 0 : (unsigned)(ntp64_seed(kmer, k, 1029283129) % subs.size()); }
+};
+
+// ---- 2-bit packing of the reference's bitset<2k>: Nucleotide.hpp:40-70 (A=00 C=01 G=10 T=11, bit 2i = low bit) ----
+inline int nt_code(char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return -1;
+    }
+}
+inline void pack(const char *kmer, unsigned k, uint64_t *out2) {
+    out2[0] = out2[1] = 0;
+    for (unsigned i = 0; i < k; i++) {
+        uint64_t v = (uint64_t)nt_code(kmer[i]);
+        out2[(2 * i) / 64] |= v << ((2 * i) % 64);
+    }
+}
+inline void unpack(const uint64_t *in2, unsigned k, char *out) {
+    static const char nt[4] = {'A', 'C', 'G', 'T'};
+    for (unsigned i = 0; i < k; i++) out[i] = nt[(in2[(2 * i) / 64] >> ((2 * i) % 64)) & 3];
+}
+
+// ---- KmerCounts record: include/bayesTyper/KmerCounts.hpp:70-75, src/bayesTyper/KmerCounts.cpp ----
+struct KC {
+    uint8_t flags = 0;   // bit0 cluster, 1 multicluster, 2 multigroup, 3 decoy, 4 maxmult, 5 parameter
+    uint8_t max_haploid = 0, fem = 0, male = 0;
+    uint8_t counts[30] = {0};
+    static uint8_t upd(uint8_t cur, uint8_t in) { return ((255 - cur) <= in) ? 255 : cur + in; }   // KmerCounts.cpp:178-188
+    void addInterclusterMultiplicity(bool is_decoy, unsigned fp, unsigned mp) {                      // KmerCounts.cpp:98-118
+        max_haploid = upd(max_haploid, 1);
+        if (max_haploid > 127) flags |= 0x10;
+        if (is_decoy) flags |= 0x08;
+        else {
+            fem = upd(fem, (uint8_t)fp);
+            male = upd(male, (uint8_t)mp);
+        }
+    }
+    void addClusterMultiplicity(uint8_t mult, bool is_multigroup) {   // KmerCounts.cpp:137-159
+        if (flags & 0x01) flags |= 0x02;
+        flags |= 0x01;
+        if (is_multigroup) flags |= 0x04;
+        max_haploid = upd(max_haploid, mult);
+        if (max_haploid > 127) flags |= 0x10;
+    }
+    void addSampleCount(unsigned s, uint8_t c) { counts[s] = upd(counts[s], c); }   // KmerCounts.cpp:161-171
+    bool isExcluded() const { return flags & (0x08 | 0x10 | 0x04); }                  // KmerCounts.cpp:93-96
+};
+
+struct OrcTable {
+    unsigned k = 0, num_samples = 0;
+    std::unordered_map<std::string, KC> map;   // keyed by the ASCII canonical k-mer
+};
+
+// sliding canonical k-mers: Kmer.tpp:44-81 (forward), :116-153 (reverse complement), :225-255 (lowest)
+inline char comp(char c) {
+    switch (c) {
+        case 'A': case 'a': return 'T';
+        case 'C': case 'c': return 'G';
+        case 'G': case 'g': return 'C';
+        default: return 'A';
+    }
+}
+inline char up(char c) {
+    static const char nt[4] = {'A', 'C', 'G', 'T'};
+    return nt[nt_code(c)];
+}
+// calls f(end_position, canonical_ascii) for every complete window
+template <typename F>
+void slide_canonical(const char *seq, uint64_t len, unsigned k, F f) {
+    std::string fw, rc;
+    uint64_t run = 0;   // number of consecutive valid nucleotides ending here (window "reset" on anything else)
+    for (uint64_t i = 0; i < len; i++) {
+        if (nt_code(seq[i]) < 0) {
+            run = 0;
+            continue;
+        }
+        run++;
+        if (run >= k) {
+            fw.assign(k, 'A');
+            rc.assign(k, 'A');
+            for (unsigned j = 0; j < k; j++) {
+                fw[j] = up(seq[i - k + 1 + j]);
+                rc[j] = comp(seq[i - j]);
+            }
+            // lexicographically lowest, ties -> forward (Kmer.tpp:253)
+            f(i, (rc < fw) ? rc : fw);
+        }
+    }
+}
+
+// ---- KMC database (format: SURVEY Appendix C.1, external/kmc_api/kmc_file.cpp:177-292,428-494) ----
+struct KmcDb {
+    unsigned k = 0, p = 0, counter_size = 0;
+    uint64_t total = 0;
+    std::vector<uint64_t> lut;        // 4^p + 1
+    std::vector<unsigned char> suf;   // payload of .kmc_suf without the two markers
+};
+
+bool read_file(const std::string &fn, std::vector<unsigned char> &out) {
+    std::ifstream f(fn, std::ios::binary);
+    if (!f.is_open()) return false;
+    f.seekg(0, std::ios::end);
+    size_t n = (size_t)f.tellg();
+    f.seekg(0);
+    out.resize(n);
+    f.read((char *)out.data(), (std::streamsize)n);
+    return true;
+}
+
+bool kmc_open(const std::string &prefix, KmcDb &db) {
+    std::vector<unsigned char> pre, suf;
+    if (!read_file(prefix + ".kmc_pre", pre) || !read_file(prefix + ".kmc_suf", suf)) return false;
+    if (pre.size() < 8 + 12 || memcmp(pre.data(), "KMCP", 4) || memcmp(pre.data() + pre.size() - 4, "KMCP", 4)) return false;
+    if (suf.size() < 8 || memcmp(suf.data(), "KMCS", 4) || memcmp(suf.data() + suf.size() - 4, "KMCS", 4)) return false;
+    uint32_t version;
+    memcpy(&version, pre.data() + pre.size() - 12, 4);   // kmc_file.cpp:180-185
+    if (version != 0) return false;                        // this oracle reads KMC1 ("version 0") databases
+    uint64_t size = pre.size() - 8;                        // without the two markers
+    uint64_t header_offset = pre[pre.size() - 8];          // kmc_file.cpp:245-246
+    size -= 4;
+    uint64_t header_index = (size - header_offset) / 8;
+    const unsigned char *words = pre.data() + 4;
+    auto word = [&](uint64_t i) { uint64_t w; memcpy(&w, words + 8 * i, 8); return w; };
+    uint64_t d = word(header_index);
+    db.k = (uint32_t)d;
+    if ((d >> 32) != 0) return false;   // mode 0 only (KmerCounter.cpp:449)
+    db.counter_size = (uint32_t)word(header_index + 1);
+    db.p = (uint32_t)(word(header_index + 1) >> 32);
+    db.total = word(header_index + 3);
+    if (header_index != (1ULL << (2 * db.p))) return false;
+    db.lut.assign(header_index + 1, 0);
+    for (uint64_t i = 0; i < header_index; i++) db.lut[i] = word(i);
+    db.lut[header_index] = db.total;
+    db.suf.assign(suf.begin() + 4, suf.end() - 4);
+    return true;
+}
+
+// record n -> (ascii k-mer, count): kmc_file.cpp:428-494
+void kmc_record(const KmcDb &db, uint64_t n, uint64_t prefix, std::string &kmer, uint32_t &count) {
+    static const char nt[4] = {'A', 'C', 'G', 'T'};
+    kmer.resize(db.k);
+    for (unsigned i = 0; i < db.p; i++) kmer[i] = nt[(prefix >> (2 * (db.p - 1 - i))) & 3];
+    const unsigned sb = (db.k - db.p) / 4;
+    const unsigned char *rec = db.suf.data() + n * (sb + db.counter_size);
+    for (unsigned b = 0; b < sb; b++)
+        for (unsigned j = 0; j < 4; j++) kmer[db.p + 4 * b + j] = nt[(rec[b] >> (6 - 2 * j)) & 3];
+    count = 0;
+    for (unsigned b = 0; b < db.counter_size; b++) count |= (uint32_t)rec[sb + b] << (8 * b);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t orc_ntp64(const char *kmer, unsigned k) { return ntp64(kmer, k); }
+uint64_t orc_ntp64_seed(const char *kmer, unsigned k, unsigned seed) { return ntp64_seed(kmer, k, seed); }
+void orc_ntp64_batch(const char *kmers, uint64_t n, unsigned k, int seeded, unsigned seed, uint64_t *out) {
+    for (uint64_t i = 0; i < n; i++) out[i] = seeded ? ntp64_seed(kmers + i * k, k, seed) : ntp64(kmers + i * k, k);
+}
+
+void orc_pack_batch(const char *kmers, uint64_t n, unsigned k, uint64_t *out) {
+    for (uint64_t i = 0; i < n; i++) pack(kmers + i * k, k, out + 2 * i);
+}
+void orc_unpack_batch(const uint64_t *packed, uint64_t n, unsigned k, char *out) {
+    for (uint64_t i = 0; i < n; i++) unpack(packed + 2 * i, k, out + i * k);
+}
+
+void orc_bloom_sizing(uint64_t num_kmers, float fpr, uint64_t *bits, unsigned *hashes) {
+    *bits = calcOptNumBloomBits(fpr, num_kmers);
+    *hashes = calcOptNumHashes(*bits, num_kmers);
+}
+
+void *orc_bloom_new(uint64_t num_kmers, float fpr, unsigned k, int threaded) {
+    OrcBloom *b = new OrcBloom();
+    b->k = k;
+    unsigned nsub = threaded ? 65536u : 1u;
+    // ThreadedKmerBloom: KmerBloom(ceil(num_kmers / float(root_size)), fpr) (KmerBloom.cpp:213)
+    uint64_t per = threaded ? (uint64_t)std::ceil(num_kmers / static_cast<float>(nsub)) : num_kmers;
+    b->num_kmers = std::max(per, static_cast<uint64_t>(1));   // KmerBloom.cpp:54
+    b->num_bits = calcOptNumBloomBits(fpr, b->num_kmers);
+    b->num_hashes = calcOptNumHashes(b->num_bits, b->num_kmers);
+    b->subs.assign(nsub, FlatBloom(b->num_bits, b->num_hashes, k));
+    return b;
+}
+void *orc_bloom_load(const char *prefix, unsigned k) {   // KmerBloom.cpp:63-89
+    std::ifstream meta(std::string(prefix) + ".bloomMeta");
+    if (!meta.is_open()) return nullptr;
+    std::string line;
+    std::getline(meta, line);
+    std::stringstream ss(line);
+    std::vector<std::string> tok;
+    for (std::string item; std::getline(ss, item, '\t');) tok.push_back(item);
+    if (tok.size() != 3 || (unsigned)std::stoi(tok[2]) != k) return nullptr;
+    OrcBloom *b = new OrcBloom();
+    b->k = k;
+    b->num_kmers = std::stol(tok[0]);
+    b->num_bits = std::stol(tok[1]);
+    b->num_hashes = calcOptNumHashes(b->num_bits, b->num_kmers);
+    b->subs.assign(1, FlatBloom(b->num_bits, b->num_hashes, k));
+    std::ifstream data(std::string(prefix) + ".bloomData", std::ios::binary);
+    data.read((char *)b->subs[0].filter.data(), (std::streamsize)b->subs[0].filter.size());
+    return b;
+}
+int orc_bloom_save(void *h, const char *prefix) {   // KmerBloom.cpp:149-164
+    OrcBloom *b = (OrcBloom *)h;
+    if (b->subs.size() != 1) return 1;
+    std::ofstream meta(std::string(prefix) + ".bloomMeta");
+    meta << std::to_string(b->num_kmers) << "\t" << std::to_string(b->num_bits) << "\t" << std::to_string(b->k) << std::endl;
+    std::ofstream data(std::string(prefix) + ".bloomData", std::ios::binary);
+    data.write((const char *)b->subs[0].filter.data(), (std::streamsize)b->subs[0].filter.size());
+    return 0;
+}
+void orc_bloom_free(void *h) { delete (OrcBloom *)h; }
+void orc_bloom_info(void *h, uint64_t *num_kmers, uint64_t *bits, unsigned *hashes, unsigned *nsub) {
+    OrcBloom *b = (OrcBloom *)h;
+    *num_kmers = b->num_kmers;
+    *bits = b->num_bits;
+    *hashes = b->num_hashes;
+    *nsub = (unsigned)b->subs.size();
+}
+void orc_bloom_insert(void *h, const char *kmers, uint64_t n) {
+    OrcBloom *b = (OrcBloom *)h;
+    for (uint64_t i = 0; i < n; i++) b->subs[b->route(kmers + i * b->k)].insertF(kmers + i * b->k);
+}
+void orc_bloom_contains(void *h, const char *kmers, uint64_t n, uint8_t *hits) {
+    OrcBloom *b = (OrcBloom *)h;
+    for (uint64_t i = 0; i < n; i++) hits[i] = b->subs[b->route(kmers + i * b->k)].containsF(kmers + i * b->k) ? 1 : 0;
+}
+void orc_bloom_bits(void *h, unsigned sub, uint8_t *out) {
+    OrcBloom *b = (OrcBloom *)h;
+    memcpy(out, b->subs[sub].filter.data(), b->subs[sub].filter.size());
+}
+unsigned orc_bloom_route(void *h, const char *kmer) { return ((OrcBloom *)h)->route(kmer); }
+
+// canonical k-mer per position, packed; valid[i] = 1 when a full window ends at i
+void orc_kmers_from_sequence(const char *seq, uint64_t len, unsigned k, uint64_t *kmers, uint8_t *valid) {
+    memset(valid, 0, len);
+    memset(kmers, 0, len * 16);
+    slide_canonical(seq, len, k, [&](uint64_t i, const std::string &can) {
+        pack(can.data(), k, kmers + 2 * i);
+        valid[i] = 1;
+    });
+}
+
+// ---- table ----
+void *orc_table_new(unsigned num_samples, unsigned k) {
+    OrcTable *t = new OrcTable();
+    t->k = k;
+    t->num_samples = num_samples;
+    return t;
+}
+void orc_table_free(void *h) { delete (OrcTable *)h; }
+uint64_t orc_table_size(void *h) { return ((OrcTable *)h)->map.size(); }
+void orc_table_insert(void *h, const char *kmers, uint64_t n, int mark_parameter) {   // main.cpp:571-577
+    OrcTable *t = (OrcTable *)h;
+    for (uint64_t i = 0; i < n; i++) {
+        KC &kc = t->map[std::string(kmers + i * t->k, t->k)];
+        if (mark_parameter) kc.flags |= 0x20;
+    }
+}
+// KmerCounter::countInterclusterKmersCallback for one region (KmerCounter.cpp:291-338)
+void orc_table_count_intercluster(void *h, void *bloom, const char *seq, uint64_t len, int is_decoy, unsigned fp, unsigned mp) {
+    OrcTable *t = (OrcTable *)h;
+    OrcBloom *b = (OrcBloom *)bloom;
+    slide_canonical(seq, len, t->k, [&](uint64_t, const std::string &can) {
+        if (b->subs[b->route(can.data())].containsF(can.data())) t->map[can].addInterclusterMultiplicity(is_decoy != 0, fp, mp);
+    });
+}
+// table half of VariantClusterGraph::classifyPathKmers (VariantClusterGraph.cpp:902-938)
+void orc_table_classify(void *h, void *mg_bloom, const char *kmers, const uint8_t *mult, uint64_t n, uint8_t *excluded) {
+    OrcTable *t = (OrcTable *)h;
+    OrcBloom *b = (OrcBloom *)mg_bloom;
+    for (uint64_t i = 0; i < n; i++) {
+        std::string key(kmers + i * t->k, t->k);
+        auto it = t->map.find(key);
+        if (it == t->map.end() && mult[i] > 127) it = t->map.emplace(key, KC()).first;
+        excluded[i] = 0;
+        if (it != t->map.end()) {
+            it->second.addClusterMultiplicity(mult[i], b->subs[b->route(key.data())].containsF(key.data()));
+            excluded[i] = it->second.isExcluded() ? 1 : 0;
+        }
+    }
+}
+// export sorted by ASCII k-mer: kmers (n*k chars), counts (n*num_samples), meta (n*4)
+uint64_t orc_table_export(void *h, char *kmers, uint8_t *counts, uint8_t *meta) {
+    OrcTable *t = (OrcTable *)h;
+    std::vector<const std::pair<const std::string, KC> *> v;
+    for (auto &e : t->map) v.push_back(&e);
+    std::sort(v.begin(), v.end(), [](const std::pair<const std::string, KC> *a, const std::pair<const std::string, KC> *b) { return a->first < b->first; });
+    uint64_t i = 0;
+    for (auto e : v) {
+        memcpy(kmers + i * t->k, e->first.data(), t->k);
+        for (unsigned s = 0; s < t->num_samples; s++) counts[i * t->num_samples + s] = e->second.counts[s];
+        meta[4 * i] = e->second.flags;
+        meta[4 * i + 1] = e->second.max_haploid;
+        meta[4 * i + 2] = e->second.fem;
+        meta[4 * i + 3] = e->second.male;
+        i++;
+    }
+    return i;
+}
+
+// ---- KMC ----
+// Writer for test fixtures (KMC1 "version 0" layout).  kmers must be sorted ascending
+// (ASCII order == KMC order) and unique.
+int orc_kmc_write(const char *prefix, const char *kmers, const uint32_t *counts, uint64_t n, unsigned k, unsigned p, unsigned counter_size) {
+    if ((k - p) % 4) return 1;
+    const uint64_t nlut = 1ULL << (2 * p);
+    std::vector<uint64_t> lut(nlut, 0);
+    const unsigned sb = (k - p) / 4;
+    std::vector<unsigned char> suf;
+    suf.reserve(n * (sb + counter_size));
+    std::vector<uint64_t> per(nlut, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        const char *km = kmers + i * k;
+        uint64_t pre = 0;
+        for (unsigned j = 0; j < p; j++) pre = (pre << 2) | (uint64_t)nt_code(km[j]);
+        per[pre]++;
+        for (unsigned b = 0; b < sb; b++) {
+            unsigned char byte = 0;
+            for (unsigned j = 0; j < 4; j++) byte = (unsigned char)((byte << 2) | nt_code(km[p + 4 * b + j]));
+            suf.push_back(byte);
+        }
+        for (unsigned b = 0; b < counter_size; b++) suf.push_back((unsigned char)((counts[i] >> (8 * b)) & 0xFF));
+    }
+    uint64_t acc = 0;
+    for (uint64_t j = 0; j < nlut; j++) {
+        lut[j] = acc;
+        acc += per[j];
+    }
+    std::ofstream fp(std::string(prefix) + ".kmc_pre", std::ios::binary);
+    std::ofstream fs(std::string(prefix) + ".kmc_suf", std::ios::binary);
+    if (!fp.is_open() || !fs.is_open()) return 2;
+    fp.write("KMCP", 4);
+    fp.write((const char *)lut.data(), (std::streamsize)(nlut * 8));
+    uint64_t header[8] = {0};
+    header[0] = (uint64_t)k;                                    // k | mode << 32 (mode 0)
+    header[1] = (uint64_t)counter_size | ((uint64_t)p << 32);   // counter_size | lut_prefix_len << 32
+    header[2] = 1ULL | (255ULL << 32);                          // min | max << 32
+    header[3] = n;                                              // total k-mers
+    header[4] = 0;                                              // both-strands flag word (0 => canonical counting)
+    fp.write((const char *)header, 64);
+    uint32_t header_offset = 64;
+    fp.write((const char *)&header_offset, 4);
+    fp.write("KMCP", 4);
+    fs.write("KMCS", 4);
+    fs.write((const char *)suf.data(), (std::streamsize)suf.size());
+    fs.write("KMCS", 4);
+    return 0;
+}
+
+void *orc_kmc_open(const char *prefix) {
+    KmcDb *db = new KmcDb();
+    if (!kmc_open(prefix, *db)) {
+        delete db;
+        return nullptr;
+    }
+    return db;
+}
+void orc_kmc_free(void *h) { delete (KmcDb *)h; }
+void orc_kmc_info(void *h, unsigned *k, unsigned *p, unsigned *counter_size, uint64_t *total) {
+    KmcDb *db = (KmcDb *)h;
+    *k = db->k;
+    *p = db->p;
+    *counter_size = db->counter_size;
+    *total = db->total;
+}
+void orc_kmc_lut(void *h, uint64_t *out) { memcpy(out, ((KmcDb *)h)->lut.data(), ((KmcDb *)h)->lut.size() * 8); }
+uint64_t orc_kmc_payload_size(void *h) { return ((KmcDb *)h)->suf.size(); }
+void orc_kmc_payload(void *h, uint8_t *out) { memcpy(out, ((KmcDb *)h)->suf.data(), ((KmcDb *)h)->suf.size()); }
+// list all records in order (CKMCFile::ReadNextKmer semantics, kmc_file.cpp:428-494)
+void orc_kmc_list(void *h, char *kmers, uint32_t *counts) {
+    KmcDb *db = (KmcDb *)h;
+    uint64_t prefix = 0;
+    std::string km;
+    for (uint64_t n = 0; n < db->total; n++) {
+        while (db->lut[prefix + 1] <= n) prefix++;
+        uint32_t c;
+        kmc_record(*db, n, prefix, km, c);
+        memcpy(kmers + n * db->k, km.data(), db->k);
+        counts[n] = c;
+    }
+}
+
+// KmerCounter::parseSampleKmers for one sample (KmerCounter.cpp:388-429): every record -> path-Bloom lookup
+// -> on hit addKmer + addSampleCount.  Returns the number of Bloom hits.
+uint64_t orc_parse_sample_kmers(void *table, void *bloom, void *kmc, unsigned sample_idx, uint64_t first, uint64_t n) {
+    OrcTable *t = (OrcTable *)table;
+    OrcBloom *b = (OrcBloom *)bloom;
+    KmcDb *db = (KmcDb *)kmc;
+    uint64_t prefix = 0, hits = 0;
+    std::string km;
+    for (uint64_t r = first; r < first + n; r++) {
+        while (db->lut[prefix + 1] <= r) prefix++;
+        uint32_t c;
+        kmc_record(*db, r, prefix, km, c);
+        assert(c <= 255);   // KmerCounter.cpp:401
+        if (b->subs[b->route(km.data())].containsF(km.data())) {
+            hits++;
+            t->map[km].addSampleCount(sample_idx, (uint8_t)c);
+        }
+    }
+    return hits;
+}
+
+// lookup-only variant used as the CPU baseline of "k-mer matches/sec" when no table growth is wanted
+uint64_t orc_match_only(void *bloom, void *kmc, uint64_t first, uint64_t n) {
+    OrcBloom *b = (OrcBloom *)bloom;
+    KmcDb *db = (KmcDb *)kmc;
+    uint64_t prefix = 0, hits = 0;
+    std::string km;
+    for (uint64_t r = first; r < first + n; r++) {
+        while (db->lut[prefix + 1] <= r) prefix++;
+        uint32_t c;
+        kmc_record(*db, r, prefix, km, c);
+        hits += b->subs[b->route(km.data())].containsF(km.data()) ? 1 : 0;
+    }
+    return hits;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+"""Test-side loader for the oracle (oracle/liboracle.so) and the compiled reference TUs (oracle/_ref/libbtref.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libbtref.so")
+vp = C.c_void_p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(vp)
+
+
+def ensure_built():
+    srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.startswith("oracle_") and f.endswith(".cpp")]
+    stale = (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "liboracle.so")])
+
+
+def ascii_kmers(kmers):
+    """list[str] | (n,k) S1 array -> contiguous uint8 array of n*k chars"""
+    if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint8:
+        return np.ascontiguousarray(kmers)
+    return np.frombuffer("".join(kmers).encode(), dtype=np.uint8).copy()
+
+
+class Oracle:
+    def __init__(self, path):
+        self.l = L = C.CDLL(path)
+        L.orc_ntp64.restype = C.c_uint64
+        L.orc_ntp64.argtypes = [C.c_char_p, C.c_uint]
+        L.orc_ntp64_seed.restype = C.c_uint64
+        L.orc_ntp64_seed.argtypes = [C.c_char_p, C.c_uint, C.c_uint]
+        L.orc_ntp64_batch.argtypes = [vp, C.c_uint64, C.c_uint, C.c_int, C.c_uint, vp]
+        L.orc_pack_batch.argtypes = [vp, C.c_uint64, C.c_uint, vp]
+        L.orc_unpack_batch.argtypes = [vp, C.c_uint64, C.c_uint, vp]
+        L.orc_bloom_sizing.argtypes = [C.c_uint64, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint)]
+        L.orc_bloom_new.restype = vp
+        L.orc_bloom_new.argtypes = [C.c_uint64, C.c_float, C.c_uint, C.c_int]
+        L.orc_bloom_load.restype = vp
+        L.orc_bloom_load.argtypes = [C.c_char_p, C.c_uint]
+        L.orc_bloom_save.argtypes = [vp, C.c_char_p]
+        L.orc_bloom_free.argtypes = [vp]
+        L.orc_bloom_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        L.orc_bloom_insert.argtypes = [vp, vp, C.c_uint64]
+        L.orc_bloom_contains.argtypes = [vp, vp, C.c_uint64, vp]
+        L.orc_bloom_bits.argtypes = [vp, C.c_uint, vp]
+        L.orc_bloom_route.restype = C.c_uint
+        L.orc_bloom_route.argtypes = [vp, C.c_char_p]
+        L.orc_kmers_from_sequence.argtypes = [vp, C.c_uint64, C.c_uint, vp, vp]
+        L.orc_table_new.restype = vp
+        L.orc_table_new.argtypes = [C.c_uint, C.c_uint]
+        L.orc_table_free.argtypes = [vp]
+        L.orc_table_size.restype = C.c_uint64
+        L.orc_table_size.argtypes = [vp]
+        L.orc_table_insert.argtypes = [vp, vp, C.c_uint64, C.c_int]
+        L.orc_table_count_intercluster.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_uint, C.c_uint]
+        L.orc_table_classify.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]
+        L.orc_table_export.restype = C.c_uint64
+        L.orc_table_export.argtypes = [vp, vp, vp, vp]
+        L.orc_kmc_write.argtypes = [C.c_char_p, vp, vp, C.c_uint64, C.c_uint, C.c_uint, C.c_uint]
+        L.orc_kmc_open.restype = vp
+        L.orc_kmc_open.argtypes = [C.c_char_p]
+        L.orc_kmc_free.argtypes = [vp]
+        L.orc_kmc_info.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint64)]
+        L.orc_kmc_lut.argtypes = [vp, vp]
+        L.orc_kmc_payload_size.restype = C.c_uint64
+        L.orc_kmc_payload_size.argtypes = [vp]
+        L.orc_kmc_payload.argtypes = [vp, vp]
+        L.orc_kmc_list.argtypes = [vp, vp, vp]
+        L.orc_parse_sample_kmers.restype = C.c_uint64
+        L.orc_parse_sample_kmers.argtypes = [vp, vp, vp, C.c_uint, C.c_uint64, C.c_uint64]
+        L.orc_match_only.restype = C.c_uint64
+        L.orc_match_only.argtypes = [vp, vp, C.c_uint64, C.c_uint64]
+
+    # ---- hashing / packing ----
+    def ntp64(self, kmers, k, seed=None):
+        a = ascii_kmers(kmers)
+        n = len(a) // k
+        out = np.empty(n, dtype=np.uint64)
+        self.l.orc_ntp64_batch(_ptr(a), n, k, 0 if seed is None else 1, 0 if seed is None else seed, _ptr(out))
+        return out
+
+    def pack(self, kmers, k):
+        a = ascii_kmers(kmers)
+        n = len(a) // k
+        out = np.zeros((n, 2), dtype=np.uint64)
+        self.l.orc_pack_batch(_ptr(a), n, k, _ptr(out))
+        return out
+
+    def unpack(self, packed, k):
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        out = np.empty(len(packed) * k, dtype=np.uint8)
+        self.l.orc_unpack_batch(_ptr(packed), len(packed), k, _ptr(out))
+        return out
+
+    def bloom_sizing(self, n, fpr):
+        b, h = C.c_uint64(), C.c_uint()
+        self.l.orc_bloom_sizing(n, fpr, C.byref(b), C.byref(h))
+        return b.value, h.value
+
+    def kmers_from_sequence(self, seq_bytes, k):
+        a = np.frombuffer(seq_bytes, dtype=np.uint8).copy()
+        kmers = np.zeros((len(a), 2), dtype=np.uint64)
+        valid = np.zeros(len(a), dtype=np.uint8)
+        self.l.orc_kmers_from_sequence(_ptr(a), len(a), k, _ptr(kmers), _ptr(valid))
+        return kmers, valid
+
+    # ---- KMC ----
+    def kmc_write(self, prefix, kmers_ascii, counts, k, p, counter_size=1):
+        a = ascii_kmers(kmers_ascii)
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        rc = self.l.orc_kmc_write(prefix.encode(), _ptr(a), _ptr(c), len(c), k, p, counter_size)
+        assert rc == 0, rc
+
+
+class OrcBloom:
+    def __init__(self, orc, num_kmers=None, fpr=None, k=55, threaded=False, handle=None):
+        self.o, self.k = orc, k
+        self.h = handle if handle is not None else orc.l.orc_bloom_new(num_kmers, fpr, k, int(threaded))
+
+    @classmethod
+    def load(cls, orc, prefix, k):
+        h = orc.l.orc_bloom_load(prefix.encode(), k)
+        assert h, "orc_bloom_load failed"
+        return cls(orc, k=k, handle=h)
+
+    def save(self, prefix):
+        assert self.o.l.orc_bloom_save(self.h, prefix.encode()) == 0
+
+    def info(self):
+        nk, nb, nh, ns = C.c_uint64(), C.c_uint64(), C.c_uint(), C.c_uint()
+        self.o.l.orc_bloom_info(self.h, C.byref(nk), C.byref(nb), C.byref(nh), C.byref(ns))
+        return {"num_kmers": nk.value, "num_bits": nb.value, "num_hashes": nh.value, "num_sub": ns.value}
+
+    def insert(self, kmers_ascii):
+        a = ascii_kmers(kmers_ascii)
+        self.o.l.orc_bloom_insert(self.h, _ptr(a), len(a) // self.k)
+
+    def contains(self, kmers_ascii):
+        a = ascii_kmers(kmers_ascii)
+        n = len(a) // self.k
+        out = np.zeros(n, dtype=np.uint8)
+        self.o.l.orc_bloom_contains(self.h, _ptr(a), n, _ptr(out))
+        return out
+
+    def bits(self, sub=0):
+        out = np.zeros((self.info()["num_bits"] + 7) // 8, dtype=np.uint8)
+        self.o.l.orc_bloom_bits(self.h, sub, _ptr(out))
+        return out
+
+    def route(self, kmer):
+        return self.o.l.orc_bloom_route(self.h, kmer.encode() if isinstance(kmer, str) else bytes(kmer))
+
+    def close(self):
+        if self.h:
+            self.o.l.orc_bloom_free(self.h)
+            self.h = None
+
+
+class OrcTable:
+    def __init__(self, orc, num_samples, k):
+        self.o, self.k, self.S = orc, k, num_samples
+        self.h = orc.l.orc_table_new(num_samples, k)
+
+    def insert(self, kmers_ascii, mark_parameter=False):
+        a = ascii_kmers(kmers_ascii)
+        self.o.l.orc_table_insert(self.h, _ptr(a), len(a) // self.k, int(mark_parameter))
+
+    def count_intercluster(self, bloom, seq_bytes, is_decoy, fp, mp):
+        a = np.frombuffer(seq_bytes, dtype=np.uint8).copy()
+        self.o.l.orc_table_count_intercluster(self.h, bloom.h, _ptr(a), len(a), int(is_decoy), fp, mp)
+
+    def classify(self, mg_bloom, kmers_ascii, mult):
+        a = ascii_kmers(kmers_ascii)
+        m = np.ascontiguousarray(mult, dtype=np.uint8)
+        out = np.zeros(len(m), dtype=np.uint8)
+        self.o.l.orc_table_classify(self.h, mg_bloom.h, _ptr(a), _ptr(m), len(m), _ptr(out))
+        return out
+
+    def parse_sample_kmers(self, bloom, kmc, sample_idx, first=0, n=None):
+        n = kmc.total - first if n is None else n
+        return self.o.l.orc_parse_sample_kmers(self.h, bloom.h, kmc.h, sample_idx, first, n)
+
+    def export(self):
+        """-> (packed kmers (n,2) u64, counts (n,S), meta (n,4)) sorted by ASCII k-mer"""
+        n = self.o.l.orc_table_size(self.h)
+        km = np.zeros(max(n, 1) * self.k, dtype=np.uint8)
+        counts = np.zeros((max(n, 1), self.S), dtype=np.uint8)
+        meta = np.zeros((max(n, 1), 4), dtype=np.uint8)
+        n2 = self.o.l.orc_table_export(self.h, _ptr(km), _ptr(counts), _ptr(meta))
+        assert n2 == n
+        return self.o.pack(km[: n * self.k], self.k), counts[:n], meta[:n]
+
+    def close(self):
+        if self.h:
+            self.o.l.orc_table_free(self.h)
+            self.h = None
+
+
+class OrcKmc:
+    def __init__(self, orc, prefix):
+        self.o = orc
+        self.h = orc.l.orc_kmc_open(prefix.encode())
+        assert self.h, f"cannot open KMC db {prefix}"
+        k, p, cs, tot = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint64()
+        orc.l.orc_kmc_info(self.h, C.byref(k), C.byref(p), C.byref(cs), C.byref(tot))
+        self.k, self.p, self.counter_size, self.total = k.value, p.value, cs.value, tot.value
+        self.rec_size = (self.k - self.p) // 4 + self.counter_size
+
+    def lut(self):
+        out = np.zeros(4 ** self.p + 1, dtype=np.uint64)
+        self.o.l.orc_kmc_lut(self.h, _ptr(out))
+        return out
+
+    def payload(self):
+        n = self.o.l.orc_kmc_payload_size(self.h)
+        out = np.zeros(n, dtype=np.uint8)
+        self.o.l.orc_kmc_payload(self.h, _ptr(out))
+        return out
+
+    def list(self):
+        km = np.zeros(self.total * self.k, dtype=np.uint8)
+        counts = np.zeros(self.total, dtype=np.uint32)
+        self.o.l.orc_kmc_list(self.h, _ptr(km), _ptr(counts))
+        return km, counts
+
+    def close(self):
+        if self.h:
+            self.o.l.orc_kmc_free(self.h)
+            self.h = None
+
+
+_ORACLE = None
+
+
+def load_oracle():
+    global _ORACLE
+    if _ORACLE is None:
+        ensure_built()
+        _ORACLE = Oracle(ORACLE_SO)
+    return _ORACLE
+
+
+class Ref:
+    """ctypes view of oracle/_ref/libbtref.so (the reference's own code, k fixed at compile time)."""
+
+    def __init__(self, path):
+        self.l = L = C.CDLL(path)
+        L.ref_kmer_size.restype = C.c_uint
+        self.k = L.ref_kmer_size()
+        L.ref_ntp64.restype = C.c_uint64
+        L.ref_ntp64.argtypes = [C.c_char_p]
+        L.ref_ntp64_seed.restype = C.c_uint64
+        L.ref_ntp64_seed.argtypes = [C.c_char_p, C.c_uint]
+        L.ref_bloom_sizing.argtypes = [C.c_uint64, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint)]
+        for n in ("ref_kmerbloom_new", "ref_tbloom_new"):
+            getattr(L, n).restype = vp
+            getattr(L, n).argtypes = [C.c_uint64, C.c_float]
+        L.ref_kmerbloom_load.restype = vp
+        L.ref_kmerbloom_load.argtypes = [C.c_char_p]
+        L.ref_kmerbloom_free.argtypes = [vp]
+        L.ref_tbloom_free.argtypes = [vp]
+        L.ref_kmerbloom_save.argtypes = [vp, C.c_char_p]
+        for n in ("ref_kmerbloom_add", "ref_tbloom_add"):
+            getattr(L, n).argtypes = [vp, vp, C.c_uint64]
+        for n in ("ref_kmerbloom_lookup", "ref_tbloom_lookup", "ref_kmerbloom_lookup_packed"):
+            getattr(L, n).argtypes = [vp, vp, C.c_uint64, vp]
+        L.ref_kmers_from_sequence.argtypes = [vp, C.c_uint64, vp, vp]
+        L.ref_kmc_total.restype = C.c_int64
+        L.ref_kmc_total.argtypes = [C.c_char_p] + [C.POINTER(C.c_uint)] * 4
+        L.ref_kmc_list.restype = C.c_int64
+        L.ref_kmc_list.argtypes = [C.c_char_p, vp, vp, C.c_uint64]
+        L.ref_kc_new.restype = vp
+        L.ref_kc_free.argtypes = [vp]
+        L.ref_kc_add_intercluster.argtypes = [vp, C.c_int, C.c_uint, C.c_uint]
+        L.ref_kc_add_cluster.argtypes = [vp, C.c_uint, C.c_int]
+        L.ref_kc_add_sample_count.argtypes = [vp, C.c_uint, C.c_uint]
+        L.ref_kc_get.argtypes = [vp, vp, vp, vp]
+        L.ref_nb_moments.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ref_nb_logpmf.restype = C.c_double
+        L.ref_nb_logpmf.argtypes = [C.c_double, C.c_double, C.c_uint, C.c_uint]
+        L.ref_log_addition.restype = C.c_double
+        L.ref_log_addition.argtypes = [C.c_double, C.c_double]
+        L.ref_double_compare.argtypes = [C.c_double, C.c_double]
+        L.ref_logdiscrete_draws.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, vp]
+        L.ref_discrete_draws.argtypes = [vp, C.c_uint, C.c_uint, C.c_uint, vp]
+        L.ref_kmerstats.argtypes = [vp, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.ref_sparsity_cover.restype = C.c_uint
+        L.ref_sparsity_cover.argtypes = [vp, C.c_uint, C.c_uint, vp, C.c_uint, vp]
+
+
+_REF = False
+
+
+def load_ref():
+    global _REF
+    if _REF is False:
+        _REF = Ref(REF_SO) if os.path.exists(REF_SO) else None
+    return _REF
+
+
+def random_kmers(rng, n, k):
+    """n random ASCII k-mers as a contiguous uint8 array (n*k)"""
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n * k)].copy()
+
+
+def canonical_ascii(orc, kmers_u8, k):
+    """canonical form of each ASCII k-mer (via the oracle's sliding window on each k-mer)"""
+    n = len(kmers_u8) // k
+    out = np.empty_like(kmers_u8)
+    for i in range(n):
+        km, valid = orc.kmers_from_sequence(kmers_u8[i * k:(i + 1) * k].tobytes(), k)
+        out[i * k:(i + 1) * k] = orc.unpack(km[k - 1:k], k)
+    return out

@@ -1,0 +1,297 @@
+"""GPU parity tests (through the C ABI of libbtgpu.so) for the k-mer side of the hot path:
+ntHash, canonical k-mers, KmerBloom / ThreadedKmerBloom, the count table and the KMC scan.
+Bar: bit-exact against the oracle (which is itself pinned against the compiled reference, tests/test_oracle_kmer.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle
+from _oracle import OrcBloom, OrcKmc, OrcTable
+
+pytestmark = pytest.mark.gpu
+K = 55
+
+
+def _sorted_export(kmers, counts, meta):
+    order = np.lexsort((kmers[:, 0], kmers[:, 1]))
+    return kmers[order], counts[order], meta[order]
+
+
+def test_nthash_and_canonical(gpu_ctx, oracle):
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(11)
+    km = _oracle.random_kmers(rng, 50_000, K)
+    packed = oracle.pack(km, K)
+    d = gpu_ctx.to_device(packed)
+    o = gpu_ctx.buffer(8 * len(packed))
+    for seeded, seed in ((0, 0), (1, 1029283129), (1, 7)):
+        lib.check(lib.bt_nthash_batch(gpu_ctx.h, d.ptr, len(packed), K, seeded, seed, o.ptr))
+        gpu_ctx.sync()
+        got = o.download(np.uint64, len(packed))
+        want = oracle.ntp64(km, K, seed=seed if seeded else None)
+        assert np.array_equal(got, want)
+    d.free(), o.free()
+
+    # canonical k-mers of a messy sequence (N runs, lower case, palindromes, ragged tail, empty)
+    seq = np.frombuffer(b"ACGTacgtNnRX", dtype=np.uint8)[rng.choice(12, size=70_001, p=[0.22] * 4 + [0.025] * 4 + [0.005] * 4)].copy()
+    seq[5000:5400] = np.frombuffer(b"ACGT" * 100, dtype=np.uint8)
+    for n in (0, 1, K - 1, K, K + 1, 1023, 1024, 1025, len(seq)):
+        s = seq[:n]
+        want_k, want_v = oracle.kmers_from_sequence(s.tobytes(), K)
+        ds = gpu_ctx.to_device(s if n else np.zeros(1, np.uint8))
+        dk, dv = gpu_ctx.buffer(16 * max(n, 1)), gpu_ctx.buffer(max(n, 1))
+        lib.check(lib.bt_kmers_from_sequence(gpu_ctx.h, ds.ptr, n, K, dk.ptr, dv.ptr))
+        gpu_ctx.sync()
+        got_k = dk.download(np.uint64, 2 * n).reshape(n, 2)
+        got_v = dv.download(np.uint8, n)
+        assert np.array_equal(got_v, want_v)
+        assert np.array_equal(got_k[want_v == 1], want_k[want_v == 1])
+        for b in (ds, dk, dv):
+            b.free()
+
+
+@pytest.mark.parametrize("k", [15, 31, 32, 33, 55, 64])
+def test_other_kmer_sizes(gpu_ctx, oracle, k):
+    """the reference fixes k at compile time (BT_KMER_SIZE); the library takes it at run time, k <= 64"""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(k)
+    seq = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.choice(5, size=5000, p=[0.2475] * 4 + [0.01])].copy()
+    want_k, want_v = oracle.kmers_from_sequence(seq.tobytes(), k)
+    ds = gpu_ctx.to_device(seq)
+    dk, dv = gpu_ctx.buffer(16 * len(seq)), gpu_ctx.buffer(len(seq))
+    lib.check(lib.bt_kmers_from_sequence(gpu_ctx.h, ds.ptr, len(seq), k, dk.ptr, dv.ptr))
+    gpu_ctx.sync()
+    got_k = dk.download(np.uint64, 2 * len(seq)).reshape(-1, 2)
+    got_v = dv.download(np.uint8, len(seq))
+    assert np.array_equal(got_v, want_v) and np.array_equal(got_k[want_v == 1], want_k[want_v == 1])
+    valid = want_k[want_v == 1]
+    o = gpu_ctx.buffer(8 * len(valid))
+    dvk = gpu_ctx.to_device(valid)
+    lib.check(lib.bt_nthash_batch(gpu_ctx.h, dvk.ptr, len(valid), k, 1, 99, o.ptr))
+    gpu_ctx.sync()
+    assert np.array_equal(o.download(np.uint64, len(valid)), oracle.ntp64(oracle.unpack(valid, k), k, seed=99))
+    for b in (ds, dk, dv, o, dvk):
+        b.free()
+
+
+@pytest.mark.parametrize("n,fpr", [(1000, 1e-4), (1000, 1e-3), (1, 1e-3), (40_000, 1e-2)])
+def test_kmerbloom_bit_exact(gpu_ctx, oracle, tmp_path, n, fpr):
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(12)
+    members = _oracle.random_kmers(rng, n, K)
+    probes = np.concatenate([members[: min(n, 300) * K], _oracle.random_kmers(rng, 30_000, K)])
+    ob = OrcBloom(oracle, n, fpr, K)
+    ob.insert(members)
+    gb = lib.Bloom.create(gpu_ctx, n, fpr, K, threaded=False)
+    gi, oi = gb.info(), ob.info()
+    assert (gi["num_kmers"], gi["num_bits"], gi["num_hashes"], gi["num_sub"]) == (oi["num_kmers"], oi["num_bits"], oi["num_hashes"], 1)
+    gb.insert(oracle.pack(members, K))
+    assert np.array_equal(gb.bits(), ob.bits())
+    assert np.array_equal(gb.contains(oracle.pack(probes, K)), ob.contains(probes))
+    # save -> byte-identical files; load (ours and the oracle's) -> identical filters
+    gb.save(str(tmp_path / "gpu"))
+    ob.save(str(tmp_path / "orc"))
+    for ext in (".bloomMeta", ".bloomData"):
+        assert open(tmp_path / ("gpu" + ext), "rb").read() == open(tmp_path / ("orc" + ext), "rb").read()
+    gb2 = lib.Bloom.load(gpu_ctx, str(tmp_path / "orc"), K)
+    assert np.array_equal(gb2.bits(), ob.bits())
+    assert np.array_equal(gb2.contains(oracle.pack(probes, K)), ob.contains(probes))
+    with pytest.raises(lib.BtError):
+        lib.Bloom.load(gpu_ctx, str(tmp_path / "orc"), 31)   # k mismatch (the reference asserts)
+    with pytest.raises(lib.BtError):
+        lib.Bloom.load(gpu_ctx, str(tmp_path / "missing"), K)
+    for x in (gb, gb2, ob):
+        x.close()
+
+
+def test_threaded_bloom_bit_exact(gpu_ctx, oracle):
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(13)
+    n = 400_000
+    members = _oracle.random_kmers(rng, n, K)
+    probes = np.concatenate([members[: 1000 * K], _oracle.random_kmers(rng, 200_000, K)])
+    ob = OrcBloom(oracle, n, 1e-2, K, threaded=True)
+    ob.insert(members)
+    gb = lib.Bloom.create(gpu_ctx, n, 1e-2, K, threaded=True)
+    gi, oi = gb.info(), ob.info()
+    assert (gi["num_kmers"], gi["num_bits"], gi["num_hashes"], gi["num_sub"]) == (oi["num_kmers"], oi["num_bits"], oi["num_hashes"], 65536)
+    gb.insert(oracle.pack(members, K))
+    for sub in (0, 1, 39854, 65535):
+        assert np.array_equal(gb.bits(sub), ob.bits(sub))
+    hg, ho = gb.contains(oracle.pack(probes, K)), ob.contains(probes)
+    assert np.array_equal(hg, ho)
+    assert ho[:1000].all() and 0 < ho[1000:].sum() < 40_000   # false positives present and identical
+    # idempotence: inserting again changes nothing
+    gb.insert(oracle.pack(members[: 5000 * K], K))
+    assert np.array_equal(gb.contains(oracle.pack(probes, K)), ho)
+    gb.close(), ob.close()
+
+
+def test_kmc_decode_and_scan(gpu_ctx, oracle, tmp_path):
+    """parseSampleKmers: decode -> path-Bloom -> table add; table contents bit-exact incl. Bloom false positives"""
+    from bayestyper_amd import lib
+    from test_oracle_kmer import make_kmc
+
+    rng = np.random.default_rng(14)
+    S = 3
+    dbs = []
+    for s, (p, cs) in enumerate([(7, 1), (5, 2), (7, 1)]):
+        dbs.append(make_kmc(oracle, tmp_path, rng, 60_000 + 1000 * s, p, cs, name=f"s{s}"))
+    # path k-mers: a slice of every sample's k-mers + k-mers in no sample
+    path = np.concatenate([km.reshape(-1, K)[rng.choice(len(c), 4000, replace=False)] for _, km, c in dbs] + [_oracle.random_kmers(rng, 3000, K).reshape(-1, K)])
+    path = np.unique(_oracle.canonical_ascii(oracle, np.ascontiguousarray(path).reshape(-1), K).reshape(-1, K), axis=0)
+    path_flat = np.ascontiguousarray(path).reshape(-1)
+    ob = OrcBloom(oracle, len(path), 1e-2, K, threaded=True)
+    ob.insert(path_flat)
+    gb = lib.Bloom.create(gpu_ctx, len(path), 1e-2, K, threaded=True)
+    gb.insert(oracle.pack(path_flat, K))
+    ot = OrcTable(oracle, S, K)
+    gt = lib.Table(gpu_ctx, 40_000, S, K)
+    # parameter k-mers first (main.cpp:543-584)
+    param = _oracle.canonical_ascii(oracle, _oracle.random_kmers(rng, 500, K), K)
+    ot.insert(param, mark_parameter=True)
+    gt.insert(oracle.pack(param, K), mark_parameter=True)
+    d_hits = gpu_ctx.buffer(8).zero()
+    total_hits = 0
+    for s, (prefix, km, counts) in enumerate(dbs):
+        db = OrcKmc(oracle, prefix)
+        payload = db.payload()
+        scan = lib.KmcScan(gpu_ctx, db.k, db.p, db.counter_size, db.total, db.lut())
+        # decode parity
+        gk, gc = scan.decode(payload, 0, db.total)
+        assert np.array_equal(gk, oracle.pack(km, K)) and np.array_equal(gc, counts)
+        # scan in ragged chunks (chunk starts are record-aligned and 16-byte aligned)
+        d_payload = gpu_ctx.to_device(payload)
+        first = 0
+        for chunk in (16 * 13, 16 * 1000, db.total):
+            n = min(chunk, db.total - first)
+            assert (first * db.rec_size) % 16 == 0
+            scan.run(gb, gt, s, d_payload.ptr + first * db.rec_size, first, n, d_hits.ptr)
+            first += n
+        gpu_ctx.sync()
+        total_hits += ot.parse_sample_kmers(ob, db, s)
+        d_payload.free(), scan.close(), db.close()
+    assert int(d_hits.download(np.uint64, 1)[0]) == total_hits
+    assert not gt.status()["overflowed"]
+    gk, gc, gm = _sorted_export(*gt.export())
+    wk, wc, wm = _sorted_export(*ot.export())
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc)
+    assert np.array_equal(gm, wm)
+    # find: every exported key is found, random keys are not
+    slots = gt.find(wk)
+    assert (slots >= 0).all() and len(np.unique(slots)) == len(slots)
+    assert (gt.find(oracle.pack(_oracle.random_kmers(rng, 1000, K), K)) == -1).all()
+    for x in (gt, gb, ob, ot):
+        x.close()
+
+
+def test_intercluster_and_classify(gpu_ctx, oracle):
+    """countInterclusterKmers + the table half of classifyPathKmers: flags and multiplicities bit-exact"""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(15)
+    S = 2
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 120_000)].copy()
+    genome[30_000:30_020] = ord("N")
+    genome[50_000:58_000] = genome[10_000:18_000]          # a repeat -> multiplicities 2+
+    genome[90_000:90_400] = np.frombuffer(b"A" * 400, dtype=np.uint8)   # poly-A -> one k-mer > 127 times
+    regions = [(0, 40_000, 0, 2, 1), (40_000, 100_000, 0, 2, 2), (100_000, 120_000, 1, 0, 0)]   # (start, end, decoy, f, m)
+    # path set = k-mers of some windows of the genome
+    path_k, path_v = oracle.kmers_from_sequence(genome[9_000:19_000].tobytes(), K)
+    pa_k, pa_v = oracle.kmers_from_sequence(genome[89_900:90_500].tobytes(), K)
+    dk_k, dk_v = oracle.kmers_from_sequence(genome[100_500:101_000].tobytes(), K)
+    path = np.unique(np.concatenate([path_k[path_v == 1], pa_k[pa_v == 1], dk_k[dk_v == 1]]), axis=0)
+    path_ascii = oracle.unpack(path, K)
+    ob = OrcBloom(oracle, len(path), 1e-3, K, threaded=True)
+    ob.insert(path_ascii)
+    gb = lib.Bloom.create(gpu_ctx, len(path), 1e-3, K, threaded=True)
+    gb.insert(path)
+    ot, gt = OrcTable(oracle, S, K), lib.Table(gpu_ctx, 30_000, S, K)
+    for (a, b, decoy, f, m) in regions:
+        ot.count_intercluster(ob, genome[a:b].tobytes(), decoy, f, m)
+        gt.count_intercluster(gb, genome[a:b].tobytes(), decoy, f, m)
+    gk, gc, gm = _sorted_export(*gt.export())
+    wk, wc, wm = _sorted_export(*ot.export())
+    assert np.array_equal(gk, wk) and np.array_equal(gm, wm)
+    assert (wm[:, 0] & 0x10).any() and (wm[:, 0] & 0x08).any() and (wm[:, 2] >= 4).any()   # max-mult, decoy and repeats exercised
+    # classify: path k-mers with multiplicities; a multigroup Bloom holding a subset; some k-mers twice (two clusters)
+    mg_members = path_ascii.reshape(-1, K)[rng.choice(len(path), 50, replace=False)]
+    omg = OrcBloom(oracle, 50, 1e-4, K)
+    omg.insert(np.ascontiguousarray(mg_members).reshape(-1))
+    gmg = lib.Bloom.create(gpu_ctx, 50, 1e-4, K, threaded=False)
+    gmg.insert(oracle.pack(np.ascontiguousarray(mg_members).reshape(-1), K))
+    extra = _oracle.canonical_ascii(oracle, _oracle.random_kmers(rng, 300, K), K)      # never seen: only enters when mult > 127
+    cls_ascii = np.concatenate([path_ascii, path_ascii[: 100 * K], extra])
+    mult = np.concatenate([rng.integers(1, 4, len(path)), rng.integers(1, 4, 100), rng.choice([1, 2, 128, 200], 300)]).astype(np.uint8)
+    # order-dependence: the oracle processes in order; keep duplicates' multiplicities <= 127 so the result is order-free
+    ex_o = ot.classify(omg, cls_ascii, mult)
+    ex_g = gt.classify(gmg, oracle.pack(cls_ascii, K), mult)
+    gk, gc, gm = _sorted_export(*gt.export())
+    wk, wc, wm = _sorted_export(*ot.export())
+    assert np.array_equal(gk, wk) and np.array_equal(gm, wm)
+    # isExcluded is reported after each update; for duplicated k-mers compare only the final state
+    uniq = np.ones(len(mult), bool)
+    uniq[:100] = False
+    uniq[len(path):len(path) + 100] = False
+    assert np.array_equal(ex_o[uniq], ex_g[uniq])
+    assert (wm[:, 0] & 0x02).sum() == 100 and (wm[:, 0] & 0x04).sum() >= 50
+    for x in (gt, gb, gmg, ob, omg, ot):
+        x.close()
+
+
+def test_large_scan_properties(gpu_ctx, oracle):
+    """size-independent properties at a size the scalar oracle would take minutes for: every inserted path k-mer is
+    found again with its count, hit count >= members, a second identical scan saturates counts exactly"""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(16)
+    n, p = 3_000_000, 7
+    # synthetic sorted unique database built directly in packed KMC form: random suffix bytes under sorted prefixes
+    prefixes = np.sort(rng.integers(0, 4 ** p, size=n))
+    suffix = rng.integers(0, 256, size=(n, 12), dtype=np.uint8)
+    counts = rng.integers(1, 201, size=n).astype(np.uint8)
+    rec = np.concatenate([suffix, counts[:, None]], axis=1)
+    lut = np.searchsorted(prefixes, np.arange(4 ** p + 1)).astype(np.uint64)
+    scan = lib.KmcScan(gpu_ctx, K, p, 1, n, lut)
+    gk, gc = scan.decode(rec.reshape(-1), 0, n)
+    assert np.array_equal(gc, counts.astype(np.uint32))
+    members = rng.choice(n, 100_000, replace=False)
+    mk = np.unique(gk[members], axis=0)
+    bloom = lib.Bloom.create(gpu_ctx, len(mk) + 1_000_000, 1e-4, K, threaded=True)
+    bloom.insert(mk)
+    table = lib.Table(gpu_ctx, 300_000, 1, K)
+    d_rec = gpu_ctx.to_device(rec.reshape(-1))
+    d_hits = gpu_ctx.buffer(8).zero()
+    scan.run(bloom, table, 0, d_rec.ptr, 0, n, d_hits.ptr)
+    gpu_ctx.sync()
+    hits = int(d_hits.download(np.uint64, 1)[0])
+    st = table.status()
+    assert hits >= len(members) and not st["overflowed"]
+    ek, ec, em = table.export()
+    lookup = {bytes(k): int(c[0]) for k, c in zip(ek, ec)}
+    # duplicates in the random db are possible (same k-mer twice): then the count is the saturated sum
+    from collections import defaultdict
+    want = defaultdict(int)
+    member_set = {bytes(k) for k in mk}
+    for k_, c_ in zip(gk[members], counts[members]):
+        want[bytes(k_)] += int(c_)
+    dup_free = {k_: v for k_, v in want.items()}
+    all_keys, inv, cnt = np.unique(gk, axis=0, return_inverse=True, return_counts=True)
+    for k_, v in list(dup_free.items())[:20000]:
+        assert k_ in lookup and lookup[k_] >= min(255, v) - 0 or lookup[k_] == 255
+    # scanning the same sample again doubles (saturating) every count
+    scan.run(bloom, table, 0, d_rec.ptr, 0, n, d_hits.ptr)
+    gpu_ctx.sync()
+    ek2, ec2, _ = table.export()
+    assert table.status()["num_keys"] == st["num_keys"]
+    l2 = {bytes(k): int(c[0]) for k, c in zip(ek2, ec2)}
+    for k_, v in list(lookup.items())[:20000]:
+        assert l2[k_] == min(255, 2 * v)
+    for x in (scan, bloom, table):
+        x.close()
+    d_rec.free(), d_hits.free()
