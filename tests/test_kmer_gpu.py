@@ -140,7 +140,7 @@ def test_kmc_decode_and_scan(gpu_ctx, oracle, tmp_path):
     rng = np.random.default_rng(14)
     S = 3
     dbs = []
-    for s, (p, cs) in enumerate([(7, 1), (5, 2), (7, 1)]):
+    for s, (p, cs) in enumerate([(7, 1), (3, 2), (7, 1)]):
         dbs.append(make_kmc(oracle, tmp_path, rng, 60_000 + 1000 * s, p, cs, name=f"s{s}"))
     # path k-mers: a slice of every sample's k-mers + k-mers in no sample
     path = np.concatenate([km.reshape(-1, K)[rng.choice(len(c), 4000, replace=False)] for _, km, c in dbs] + [_oracle.random_kmers(rng, 3000, K).reshape(-1, K)])
@@ -239,7 +239,7 @@ def test_intercluster_and_classify(gpu_ctx, oracle):
     uniq[:100] = False
     uniq[len(path):len(path) + 100] = False
     assert np.array_equal(ex_o[uniq], ex_g[uniq])
-    assert (wm[:, 0] & 0x02).sum() == 100 and (wm[:, 0] & 0x04).sum() >= 50
+    assert ((wm[:, 0] & 0x02) != 0).sum() == 100 and ((wm[:, 0] & 0x04) != 0).sum() >= 50
     for x in (gt, gb, gmg, ob, omg, ot):
         x.close()
 
