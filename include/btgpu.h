@@ -196,6 +196,130 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
 int bt_kmc_scan_decode(bt_kmc_scan *s, const uint8_t *d_records, uint64_t first_record, uint64_t n,
                        uint64_t *d_kmers, uint32_t *d_counts);
 
+/* ------------------------------------------------------------------------------------------
+ * Count model LUTs: CountDistribution (src/bayesTyper/CountDistribution.cpp:215-265)
+ * ---------------------------------------------------------------------------------------- */
+/* layout of the two caches the sampler reads through calcCountLogProb(sample, bias=0, multiplicity, count):
+ *   genomic[(s*256 + multiplicity)*256 + count]   (CountDistribution.cpp:215-234; row multiplicity 0 is never read)
+ *   noise[s*256 + count]                          (CountDistribution.cpp:236-253)
+ * The host computes them in fp64 exactly as the reference does; the device only gathers. */
+
+/* ------------------------------------------------------------------------------------------
+ * Gibbs genotyping of variant-cluster groups:
+ *   VariantClusterGroup::{initGenotyper, shuffleBranchOrdering, estimateGenotypes, getNoiseCounts,
+ *   clearGenotyperCache, resetGroup, collectGenotypes} (include/bayesTyper/VariantClusterGroup.hpp:125-134)
+ *   driven as InferenceEngine does (src/bayesTyper/InferenceEngine.cpp:60-133,278-333).
+ *
+ * Input = the per-cluster tensor bundle VariantClusterGraph::getHaplotypeCandidates produces
+ * (VariantClusterHaplotypes, include/bayesTyper/VariantClusterHaplotypes.hpp:52-109), flattened.
+ * All arrays are HOST memory and are copied by bt_gibbs_create.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_gibbs_params {
+    uint32_t num_samples;                  /* S <= 30 */
+    uint32_t seed;                         /* --random-seed */
+    uint32_t num_chains;                   /* --number-of-gibbs-chains (20) */
+    uint32_t burn_in;                      /* --gibbs-burn-in (100) */
+    uint32_t num_iterations;               /* --gibbs-samples (250) */
+    float kmer_subsampling_rate;           /* --kmer-subsampling-rate (0.1f) */
+    uint32_t max_haplotype_variant_kmers;  /* --max-haplotype-variant-kmers (500) */
+    uint32_t noise_seeding;                /* 0: genotyper seed = seed+(i+1)          (InferenceEngine.cpp:294)
+                                              1: genotyper seed = seed+(i+1)*(c+1)    (InferenceEngine.cpp:70) */
+    const uint8_t *gender;                 /* [S] 0 = female, 1 = male (Utils::Gender) */
+} bt_gibbs_params;
+
+typedef struct bt_gibbs_batch {
+    uint32_t num_groups;     /* G */
+    uint32_t num_clusters;   /* C = total number of group vertices */
+    /* ---- per group ---- */
+    const uint32_t *group_index;         /* [G] index i of the group in the unit's sorted group vector (seeds, Appendix B) */
+    const uint32_t *group_cluster_off;   /* [G+1] vertices of group g are clusters [off[g], off[g+1]) in vertex order */
+    const uint8_t *group_ploidy;         /* [G*S] chromosome ploidy per sample: 0 Null, 1 Haploid, 2 Diploid */
+    const uint32_t *group_source_off;    /* [G+1] -> group_sources */
+    const uint32_t *group_sources;       /* source vertices (local vertex ids), VariantClusterGroup.hpp:86 */
+    const uint32_t *group_num_shared;    /* [G] number of multicluster k-mer records shared by the group's clusters */
+    /* ---- per cluster (vertex) ---- */
+    const uint32_t *cluster_idx;         /* [C] variant_cluster_idx (seed offset, nested-cluster identity) */
+    const uint32_t *edge_off;            /* [C+1] out_edges CSR -> edges */
+    const uint32_t *edges;               /* local vertex ids */
+    const uint32_t *num_haplotypes;      /* [C] H */
+    const uint32_t *num_variants;        /* [C] V */
+    const uint32_t *kmer_off;            /* [C+1] k-mer rows of cluster c: [kmer_off[c], kmer_off[c+1]) */
+    const uint8_t *hap_kmer_mult;        /* haplotype_kmer_multiplicities, row-major K x H per cluster, clusters concatenated */
+    /* ---- per k-mer row (R = kmer_off[C]) ---- */
+    const uint8_t *kmer_has_counts;      /* [R] KmerInfo::counts != nullptr */
+    const uint8_t *kmer_counts;          /* [R*S] getSampleCount(s) */
+    const uint8_t *kmer_ic_mult;         /* [R*2] getInterclusterMultiplicity(Female), (Male) */
+    const int32_t *kmer_shared;          /* [R] -1, or index (< group_num_shared) of the shared record of a multicluster k-mer */
+    const uint32_t *kv_off;              /* [R+1] variant_haplotype_indices CSR -> kv_var, kv_bits */
+    const uint16_t *kv_var;              /* [NNZ] variant index */
+    const uint32_t *kv_bits;             /* haplotype bitsets, ceil(H/32) words per entry, entries in kv order */
+    /* ---- index lists ---- */
+    const uint32_t *unique_off;          /* [C+1] -> unique_idx */
+    const uint32_t *unique_idx;          /* unique_kmer_indices (row ids local to the cluster), first-seen order */
+    const uint32_t *multi_off;           /* [C+1] -> multi_idx */
+    const uint32_t *multi_idx;           /* multicluster_kmer_indices */
+    /* ---- haplotypes / variants ---- */
+    const uint16_t *hap_allele;          /* variant_allele_indices, row-major H x V per cluster, clusters concatenated */
+    const uint32_t *hapnest_off;         /* [sum(H)+1] nested_variant_cluster_indices CSR per haplotype (sorted) */
+    const uint32_t *hapnest_idx;
+    const uint16_t *var_num_alleles;     /* [sum(V)] numberOfAlleles() incl. the missing allele */
+    const uint8_t *var_has_dependency;   /* [sum(V)] */
+    /* ---- nested_variant_cluster_dependency (VariantClusterHaplotypes.hpp:97) ---- */
+    const uint32_t *nestdep_off;         /* [C+1] -> nestdep_cluster / nestdep_var_off */
+    const uint32_t *nestdep_cluster;     /* child variant_cluster_idx */
+    const uint32_t *nestdep_var_off;     /* [ND+1] -> nestdep_var */
+    const uint16_t *nestdep_var;         /* variant indices, sorted descending (VariantClusterGraph.cpp:1130) */
+} bt_gibbs_batch;
+
+typedef struct bt_gibbs bt_gibbs;
+
+int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *batch, bt_gibbs **out);
+int bt_gibbs_destroy(bt_gibbs *g);
+/* upload the count-model LUTs (see above); must be called before the first sweep and after every noise update */
+int bt_gibbs_set_lut(bt_gibbs *g, const double *h_genomic /* [S*256*256] */, const double *h_noise /* [S*256] */);
+int bt_gibbs_set_noise_lut(bt_gibbs *g, const double *h_noise /* [S*256] */);
+/* initGenotyper (constructing the genotypers on first use) + shuffleBranchOrdering for every group,
+ * with the seeds of chain `chain_idx` (InferenceEngine.cpp:292-295 / :60-75) */
+int bt_gibbs_init_chain(bt_gibbs *g, uint32_t chain_idx);
+/* estimateGenotypes(count_distribution, ploidy, collect_samples) `num_sweeps` times for every group */
+int bt_gibbs_sweep(bt_gibbs *g, uint32_t num_sweeps, int collect_samples);
+/* the whole default-mode schedule for every group: for each chain init_chain, burn_in sweeps without and
+ * num_iterations sweeps with collection (InferenceEngine.cpp:292-306), in one launch */
+int bt_gibbs_run(bt_gibbs *g);
+/* getNoiseCounts of every group accumulated into a [S*256] histogram on the device, then clearGenotyperCache
+ * (InferenceEngine.cpp:90-92); d_hist is zeroed first when zero_first != 0 */
+int bt_gibbs_noise_counts(bt_gibbs *g, uint64_t *d_hist, int zero_first);
+/* resetGroup for every group (InferenceEngine.cpp:100-113): genotypers are rebuilt by the next init_chain */
+int bt_gibbs_reset_groups(bt_gibbs *g);
+
+/* Results (collectGenotypes input): per cluster the diplotype sampling frequencies
+ * (VariantClusterGenotyper.hpp:112) and the allele k-mer statistics (:104).
+ * sizes: number of distinct sampled diplotypes over all clusters; number of (cluster, sample, allele) cells */
+int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t *num_allele_cells);
+/* h_dip_off[C+1]; entry e: haplotypes (h_dip_h1[e] <= h_dip_h2[e], 0xFFFF = none), h_dip_freq[e*S + s];
+ * allele cells in the order cluster, sample, variant, allele: h_stats[cell*12 + stat*4 + {count, fraction, mean, M2}]
+ * for stat in {count_stats, fraction_stats, mean_stats} (KmerStats.cpp:107-121); h_cell_off[C+1] */
+int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, uint16_t *h_dip_h2, uint32_t *h_dip_freq,
+                          uint64_t *h_cell_off, double *h_stats);
+/* diagnostics: the diplotype drawn for (cluster, sample) in each of the first `max_sweeps` sweeps after this call:
+ * h_trace[(sweep*C + c)*S + s] = h1 | h2 << 16.  Pass max_sweeps = 0 to switch tracing off. */
+int bt_gibbs_trace_enable(bt_gibbs *g, uint32_t max_sweeps);
+int bt_gibbs_trace_fetch(bt_gibbs *g, uint32_t *h_trace, uint64_t max_words, uint64_t *num_sweeps_recorded);
+/* device bytes held by this batch (state + inputs) */
+int bt_gibbs_device_bytes(bt_gibbs *g, uint64_t *bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Diagnostics: host-side entry points of the libstdc++-compatible primitives the sampler relies on
+ * (SURVEY Appendix B.2).  They run the same __host__ __device__ code the kernels use.
+ * ---------------------------------------------------------------------------------------- */
+/* replay a sequence of operations on the unordered_set<uint> emulation: op[i] = 0 insert, 1 erase, 2 clear;
+ * afterwards writes the iteration order to h_order (capacity universe) and its length to *n */
+int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *values, uint64_t num_ops, uint32_t *h_order, uint32_t *n);
+/* draws from the device random-number stack seeded like std::mt19937(seed): kind 0 raw u32, 1 generate_canonical<double,53>,
+ * 2 gamma(shape=a, scale=b) with one persistent distribution object, 3 uniform_int(0, a), 4 bernoulli(float a),
+ * 5 std::shuffle of 0..a-1 (h_out gets the permutation as doubles, n ignored) */
+int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint64_t n, double *h_out);
+
 #ifdef __cplusplus
 }
 #endif

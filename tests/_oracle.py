@@ -321,3 +321,115 @@ def canonical_ascii(orc, kmers_u8, k):
         km, valid = orc.kmers_from_sequence(kmers_u8[i * k:(i + 1) * k].tobytes(), k)
         out[i * k:(i + 1) * k] = orc.unpack(km[k - 1:k], k)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gibbs oracle (oracle/oracle_gibbs.cpp)
+# ---------------------------------------------------------------------------------------------------------------
+def _gibbs_sigs(L):
+    if getattr(L, "_gibbs_sigs_done", False):
+        return
+    d, u, u64 = C.c_double, C.c_uint, C.c_uint64
+    L.orc_build_luts.argtypes = [u, vp, vp, vp, vp, vp]
+    L.orc_build_noise_lut.argtypes = [u, vp, vp]
+    L.orc_nb_moments.argtypes = [d, d, C.POINTER(d), C.POINTER(d)]
+    L.orc_nb_logpmf.restype = d
+    L.orc_nb_logpmf.argtypes = [d, d, u, u]
+    L.orc_log_addition.restype = d
+    L.orc_log_addition.argtypes = [d, d]
+    L.orc_double_compare.argtypes = [d, d]
+    L.orc_logdiscrete_draws.argtypes = [vp, u, u, u, vp]
+    L.orc_discrete_draws.argtypes = [vp, u, u, u, vp]
+    L.orc_kmerstats.argtypes = [vp, u, C.POINTER(u), C.POINTER(d), C.POINTER(d), C.POINTER(d)]
+    L.orc_sparsity_cover.restype = u
+    L.orc_sparsity_cover.argtypes = [vp, u, u, vp, u, vp]
+    L.orc_rng.argtypes = [u, C.c_int, vp, vp, u64, vp]
+    L.orc_uset_replay.argtypes = [u, vp, vp, u64, vp, C.POINTER(C.c_uint32)]
+    L.orc_gibbs_create.restype = vp
+    L.orc_gibbs_create.argtypes = [vp, vp, vp, vp]
+    L.orc_gibbs_free.argtypes = [vp]
+    L.orc_gibbs_set_noise_lut.argtypes = [vp, vp]
+    L.orc_gibbs_trace_enable.argtypes = [vp, C.c_uint32]
+    L.orc_gibbs_run.argtypes = [vp, u]
+    L.orc_gibbs_init_chain.argtypes = [vp, C.c_uint32]
+    L.orc_gibbs_sweep.argtypes = [vp, C.c_uint32, C.c_int]
+    L.orc_gibbs_noise_counts.argtypes = [vp, vp, C.c_int]
+    L.orc_gibbs_reset_groups.argtypes = [vp]
+    L.orc_gibbs_result_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.orc_gibbs_result_fetch.argtypes = [vp] * 7
+    L.orc_gibbs_trace_fetch.restype = u64
+    L.orc_gibbs_trace_fetch.argtypes = [vp, C.c_uint32, vp, u64]
+    L._gibbs_sigs_done = True
+
+
+def build_luts(orc, S, mean=15.0, var=30.0, noise_rate=0.05):
+    """CountDistribution LUTs for S samples with identical NB(mean,var) per copy and the given noise rate(s)"""
+    _gibbs_sigs(orc.l)
+    p, size = C.c_double(), C.c_double()
+    orc.l.orc_nb_moments(mean, var, C.byref(p), C.byref(size))
+    ps = np.full(S, p.value)
+    sz = np.full(S, size.value)
+    nr = np.full(S, noise_rate, dtype=np.float64) if np.isscalar(noise_rate) else np.asarray(noise_rate, np.float64)
+    g = np.zeros(S * 65536, np.float64)
+    n = np.zeros(S * 256, np.float64)
+    orc.l.orc_build_luts(S, _ptr(ps), _ptr(sz), _ptr(nr), _ptr(g), _ptr(n))
+    return g, n
+
+
+class OrcGibbs:
+    def __init__(self, orc, flat, lut_g, lut_n, **kw):
+        from bayestyper_amd import synth
+
+        _gibbs_sigs(orc.l)
+        self.o, self.flat = orc, flat
+        self.S, self.C = flat["S"], flat["num_clusters"]
+        self.params, self.batch, self._keep = synth.to_ctypes(flat, **kw)
+        self._keep += [lut_g, lut_n]
+        self.h = orc.l.orc_gibbs_create(C.addressof(self.params), C.addressof(self.batch), _ptr(lut_g), _ptr(lut_n))
+
+    def run(self, threads=1):
+        self.o.l.orc_gibbs_run(self.h, threads)
+
+    def trace_enable(self, n):
+        self.o.l.orc_gibbs_trace_enable(self.h, n)
+
+    def trace(self, group, n_vertices, max_sweeps):
+        buf = np.zeros(max_sweeps * n_vertices * self.S, np.uint32)
+        n = self.o.l.orc_gibbs_trace_fetch(self.h, group, _ptr(buf), len(buf))
+        return buf[:n].reshape(-1, n_vertices, self.S)
+
+    def init_chain(self, c):
+        self.o.l.orc_gibbs_init_chain(self.h, c)
+
+    def sweep(self, n, collect):
+        self.o.l.orc_gibbs_sweep(self.h, n, int(collect))
+
+    def noise_counts(self, zero_first=True):
+        hist = np.zeros(self.S * 256, np.uint64)
+        self.o.l.orc_gibbs_noise_counts(self.h, _ptr(hist), int(zero_first))
+        return hist
+
+    def set_noise_lut(self, lut_n):
+        self._keep.append(lut_n)
+        self.o.l.orc_gibbs_set_noise_lut(self.h, _ptr(lut_n))
+
+    def reset_groups(self):
+        self.o.l.orc_gibbs_reset_groups(self.h)
+
+    def results(self):
+        nd, nc = C.c_uint64(), C.c_uint64()
+        self.o.l.orc_gibbs_result_sizes(self.h, C.byref(nd), C.byref(nc))
+        nd, nc = nd.value, nc.value
+        dip_off = np.zeros(self.C + 1, np.uint64)
+        cell_off = np.zeros(self.C + 1, np.uint64)
+        h1, h2 = np.zeros(max(nd, 1), np.uint16), np.zeros(max(nd, 1), np.uint16)
+        freq = np.zeros(max(nd, 1) * self.S, np.uint32)
+        stats = np.zeros(max(nc, 1) * 12, np.float64)
+        self.o.l.orc_gibbs_result_fetch(self.h, _ptr(dip_off), _ptr(h1), _ptr(h2), _ptr(freq), _ptr(cell_off), _ptr(stats))
+        return {"dip_off": dip_off, "h1": h1[:nd], "h2": h2[:nd], "freq": freq[: nd * self.S].reshape(nd, self.S), "cell_off": cell_off,
+                "stats": stats[: nc * 12].reshape(nc, 3, 4)}
+
+    def close(self):
+        if self.h:
+            self.o.l.orc_gibbs_free(self.h)
+            self.h = None
