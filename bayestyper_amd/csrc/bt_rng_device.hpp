@@ -1,0 +1,290 @@
+// libstdc++-compatible random-number stack and unordered_set<uint> iteration-order emulation for the Gibbs
+// kernels.  The reference draws every random decision from std::mt19937 through
+// libstdc++'s distribution classes and iterates std::unordered_set<uint>; posteriors within 1e-4 require the
+// same draw STREAM, so these are re-implemented here from the published algorithms:
+//
+//   mt19937                          Matsumoto & Nishimura 1998 (state 624 x u32, tempering constants of [rand.predef])
+//   generate_canonical<double,53>    two 32-bit draws: (x0 + x1 * 2^32) / 2^64, clamped below 1   (bits/random.tcc:3362-3373)
+//   uniform_int_distribution         Lemire's nearly-divisionless method on a 32-bit engine         (bits/uniform_int_dist.h:246-268)
+//   bernoulli_distribution           canonical() < p                                                (bits/random.h:3635-3643)
+//   normal_distribution              Marsaglia polar with a saved second variate                    (bits/random.tcc:1804-1835)
+//   gamma_distribution               Marsaglia-Tsang over that normal; the normal's saved variate survives param() (bits/random.tcc:2337-2396)
+//   std::shuffle                     two swap positions per draw                                    (bits/stl_algo.h:3706-3790)
+//   std::unordered_set<unsigned>     _Hashtable: identity hash, prime bucket counts 13,29,59,..., insert-at-bucket-begin,
+//                                    rehash re-threading in list order, clear() keeps the bucket array (bits/hashtable.h)
+//
+// All state lives in caller-provided memory (HBM on the device); every function is __host__ __device__ so the same
+// code is exercised on the CPU through the bt_diag_* entry points.  Build with -ffp-contract=off: the reference's
+// x86-64 build has no fused multiply-add, and the draw stream depends on individually rounded operations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace bt {
+
+#define BT_HD __host__ __device__ inline
+
+// ------------------------------------------------------------------------------------------------------------
+// mt19937: st[0..623] state words, st[624] position
+// ------------------------------------------------------------------------------------------------------------
+constexpr unsigned MT_N = 624, MT_M = 397, MT_WORDS = 625;
+
+BT_HD void mt_seed(uint32_t *st, uint32_t seed) {
+    uint32_t x = seed;
+    st[0] = x;
+    for (unsigned i = 1; i < MT_N; ++i) {
+        x = 1812433253u * (x ^ (x >> 30)) + i;
+        st[i] = x;
+    }
+    st[MT_N] = MT_N;
+}
+
+BT_HD void mt_refill(uint32_t *st) {
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
+    for (unsigned k = 0; k < MT_N - MT_M; ++k) {
+        uint32_t y = (st[k] & UPPER) | (st[k + 1] & LOWER);
+        st[k] = st[k + MT_M] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+    }
+    for (unsigned k = MT_N - MT_M; k < MT_N - 1; ++k) {
+        uint32_t y = (st[k] & UPPER) | (st[k + 1] & LOWER);
+        st[k] = st[k + MT_M - MT_N] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+    }
+    uint32_t y = (st[MT_N - 1] & UPPER) | (st[0] & LOWER);
+    st[MT_N - 1] = st[MT_M - 1] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+    st[MT_N] = 0;
+}
+
+BT_HD uint32_t mt_next(uint32_t *st) {
+    uint32_t p = st[MT_N];
+    if (p >= MT_N) {
+        mt_refill(st);
+        p = 0;
+    }
+    uint32_t z = st[p];
+    st[MT_N] = p + 1;
+    z ^= (z >> 11);
+    z ^= (z << 7) & 0x9d2c5680u;
+    z ^= (z << 15) & 0xefc60000u;
+    z ^= (z >> 18);
+    return z;
+}
+
+// generate_canonical<double, 53>(mt19937)
+BT_HD double rng_canonical(uint32_t *st) {
+    double sum = (double)mt_next(st);
+    sum += (double)mt_next(st) * 4294967296.0;
+    double ret = sum / 18446744073709551616.0;
+    if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;   // nextafter(1, 0)
+    return ret;
+}
+
+// uniform_int_distribution<>(0, b) for b < 2^32 - 1: range = b + 1
+BT_HD uint32_t rng_uniform_int(uint32_t *st, uint32_t range) {
+    uint64_t product = (uint64_t)mt_next(st) * (uint64_t)range;
+    uint32_t low = (uint32_t)product;
+    if (low < range) {
+        uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+            product = (uint64_t)mt_next(st) * (uint64_t)range;
+            low = (uint32_t)product;
+        }
+    }
+    return (uint32_t)(product >> 32);
+}
+
+BT_HD bool rng_bernoulli(uint32_t *st, double p) { return rng_canonical(st) < p; }
+
+// std::shuffle over a uint32 array in caller memory
+BT_HD void rng_shuffle_u32(uint32_t *st, uint32_t *a, uint32_t n) {
+    if (n == 0) return;
+    const uint64_t urngrange = 0xFFFFFFFFull;
+    if (urngrange / n >= n) {
+        uint32_t i = 1;
+        if ((n % 2u) == 0) {
+            uint32_t j = rng_uniform_int(st, 2);
+            uint32_t t = a[i]; a[i] = a[j]; a[j] = t;
+            ++i;
+        }
+        while (i != n) {
+            const uint32_t swap_range = i + 1;
+            const uint32_t b1 = swap_range + 1;
+            uint32_t x = rng_uniform_int(st, swap_range * b1);
+            uint32_t p0 = x / b1, p1 = x % b1;
+            uint32_t t = a[i]; a[i] = a[p0]; a[p0] = t;
+            ++i;
+            t = a[i]; a[i] = a[p1]; a[p1] = t;
+            ++i;
+        }
+        return;
+    }
+    for (uint32_t i = 1; i < n; ++i) {
+        uint32_t j = rng_uniform_int(st, i + 1);
+        uint32_t t = a[i]; a[i] = a[j]; a[j] = t;
+    }
+}
+
+// normal_distribution<double>(0,1) + gamma_distribution<double>; `nd` holds {saved value, saved_available flag}
+struct NormalState {
+    double saved;
+    uint32_t available;
+};
+
+BT_HD double rng_normal(uint32_t *st, NormalState *nd) {
+    double ret;
+    if (nd->available) {
+        nd->available = 0;
+        ret = nd->saved;
+    } else {
+        double x, y, r2;
+        do {
+            x = 2.0 * rng_canonical(st) - 1.0;
+            y = 2.0 * rng_canonical(st) - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = sqrt(-2 * log(r2) / r2);
+        nd->saved = x * mult;
+        nd->available = 1;
+        ret = y * mult;
+    }
+    ret = ret * 1.0 + 0.0;
+    return ret;
+}
+
+BT_HD double rng_gamma(uint32_t *st, NormalState *nd, double alpha, double beta) {
+    const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
+    const double a1 = malpha - 1.0 / 3.0;
+    const double a2 = 1.0 / sqrt(9.0 * a1);
+    double u, v, n;
+    do {
+        do {
+            n = rng_normal(st, nd);
+            v = 1.0 + a2 * n;
+        } while (v <= 0.0);
+        v = v * v * v;
+        u = rng_canonical(st);
+    } while (u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v)))));
+    if (alpha == malpha) return a1 * v * beta;
+    do u = rng_canonical(st);
+    while (u == 0.0);
+    return pow(u, 1.0 / alpha) * a1 * v * beta;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// std::unordered_set<unsigned> order emulation.  Elements are 0..universe-1; `next` (one word per element) may be
+// shared by several sets as long as an element is in at most one of them at a time.
+// hdr: [0] bucket count B, [1] head (before_begin.next), [2] size, [3] next_resize
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t US_NONE = 0xFFFFFFFFu, US_BEFORE = 0xFFFFFFFEu;
+
+struct USet {
+    uint32_t *hdr;    // 4 words
+    uint32_t *bkt;    // capacity >= uset_bucket_capacity(universe)
+    uint32_t *next;   // universe words
+};
+
+BT_HD uint32_t uset_next_bucket_count(uint32_t min_needed) {   // next entry of libstdc++'s growth chain that is >= min_needed
+    const uint32_t chain[15] = {13, 29, 59, 127, 257, 541, 1109, 2357, 5087, 10273, 20753, 42043, 85229, 172933, 351061};
+    for (int i = 0; i < 15; ++i)
+        if (chain[i] >= min_needed) return chain[i];
+    return 351061;
+}
+// bucket array capacity needed for a set that may hold up to `universe` elements
+BT_HD uint32_t uset_bucket_capacity(uint32_t universe) {
+    uint32_t b = 13;
+    while (b < universe) b = uset_next_bucket_count(2 * b);
+    return b;
+}
+
+BT_HD void uset_init(USet s) {
+    s.hdr[0] = 1;
+    s.hdr[1] = US_NONE;
+    s.hdr[2] = 0;
+    s.hdr[3] = 0;
+    s.bkt[0] = US_NONE;
+}
+BT_HD uint32_t uset_nxt(USet s, uint32_t node) { return node == US_BEFORE ? s.hdr[1] : s.next[node]; }
+BT_HD void uset_set_nxt(USet s, uint32_t node, uint32_t v) {
+    if (node == US_BEFORE) s.hdr[1] = v;
+    else s.next[node] = v;
+}
+BT_HD void uset_rehash(USet s, uint32_t newB) {
+    for (uint32_t i = 0; i < newB; ++i) s.bkt[i] = US_NONE;
+    uint32_t p = s.hdr[1];
+    s.hdr[1] = US_NONE;
+    uint32_t bbegin_bkt = 0;
+    while (p != US_NONE) {
+        uint32_t nx = s.next[p];
+        uint32_t b = p % newB;
+        if (s.bkt[b] == US_NONE) {
+            s.next[p] = s.hdr[1];
+            s.hdr[1] = p;
+            s.bkt[b] = US_BEFORE;
+            if (s.next[p] != US_NONE) s.bkt[bbegin_bkt] = p;
+            bbegin_bkt = b;
+        } else {
+            uint32_t prev = s.bkt[b];
+            s.next[p] = uset_nxt(s, prev);
+            uset_set_nxt(s, prev, p);
+        }
+        p = nx;
+    }
+    s.hdr[0] = newB;
+    s.hdr[3] = newB;   // floor(B * max_load_factor 1.0)
+}
+// insert an element that is not in the set
+BT_HD void uset_insert(USet s, uint32_t e) {
+    uint32_t B = s.hdr[0], size = s.hdr[2];
+    if (size + 1 > s.hdr[3]) {
+        uint32_t min_bkts = size + 1;
+        if (s.hdr[3] == 0 && min_bkts < 11) min_bkts = 11;
+        if (min_bkts >= B) {
+            uint32_t want = min_bkts + 1 > 2 * B ? min_bkts + 1 : 2 * B;
+            uset_rehash(s, uset_next_bucket_count(want));
+            B = s.hdr[0];
+        } else
+            s.hdr[3] = B;
+    }
+    uint32_t b = e % B;
+    if (s.bkt[b] != US_NONE) {
+        uint32_t prev = s.bkt[b];
+        s.next[e] = uset_nxt(s, prev);
+        uset_set_nxt(s, prev, e);
+    } else {
+        s.next[e] = s.hdr[1];
+        s.hdr[1] = e;
+        if (s.next[e] != US_NONE) s.bkt[s.next[e] % B] = e;
+        s.bkt[b] = US_BEFORE;
+    }
+    s.hdr[2] = size + 1;
+}
+// erase an element that is in the set
+BT_HD void uset_erase(USet s, uint32_t e) {
+    const uint32_t B = s.hdr[0];
+    const uint32_t b = e % B;
+    uint32_t prev = s.bkt[b];
+    while (uset_nxt(s, prev) != e) prev = uset_nxt(s, prev);
+    const uint32_t nn = s.next[e];
+    if (prev == s.bkt[b]) {
+        if (nn == US_NONE || (nn % B) != b) {
+            if (nn != US_NONE) s.bkt[nn % B] = s.bkt[b];
+            if (s.bkt[b] == US_BEFORE) s.hdr[1] = nn;
+            s.bkt[b] = US_NONE;
+        }
+    } else if (nn != US_NONE) {
+        uint32_t nb = nn % B;
+        if (nb != b) s.bkt[nb] = prev;
+    }
+    uset_set_nxt(s, prev, nn);
+    s.hdr[2] -= 1;
+}
+BT_HD void uset_clear(USet s) {
+    const uint32_t B = s.hdr[0];
+    for (uint32_t i = 0; i < B; ++i) s.bkt[i] = US_NONE;
+    s.hdr[1] = US_NONE;
+    s.hdr[2] = 0;
+}
+BT_HD uint32_t uset_begin(USet s) { return s.hdr[1]; }
+BT_HD uint32_t uset_size(USet s) { return s.hdr[2]; }
+
+}  // namespace bt

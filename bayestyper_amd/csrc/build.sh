@@ -8,7 +8,7 @@ objs=()
 for s in "${srcs[@]}"; do
   o="${s%.hip}.o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ -n "$(find "$here" "$here/../../include" -name '*.h*' -newer "$o" 2>/dev/null | head -1)" ]; then
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$s" -o "$o"
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@" -c "$s" -o "$o"
   fi
   objs+=("$o")
 done

@@ -326,3 +326,111 @@ class KmcScan:
         if self.h:
             bt_kmc_scan_destroy(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gibbs genotyping (bt_gibbs_*)
+# ---------------------------------------------------------------------------------------------------------------
+bt_gibbs_create = _sig("bt_gibbs_create", [vp, vp, vp, C.POINTER(vp)])
+bt_gibbs_destroy = _sig("bt_gibbs_destroy", [vp])
+bt_gibbs_set_lut = _sig("bt_gibbs_set_lut", [vp, vp, vp])
+bt_gibbs_set_noise_lut = _sig("bt_gibbs_set_noise_lut", [vp, vp])
+bt_gibbs_init_chain = _sig("bt_gibbs_init_chain", [vp, C.c_uint32])
+bt_gibbs_sweep = _sig("bt_gibbs_sweep", [vp, C.c_uint32, C.c_int])
+bt_gibbs_run = _sig("bt_gibbs_run", [vp])
+bt_gibbs_noise_counts = _sig("bt_gibbs_noise_counts", [vp, vp, C.c_int])
+bt_gibbs_reset_groups = _sig("bt_gibbs_reset_groups", [vp])
+bt_gibbs_result_sizes = _sig("bt_gibbs_result_sizes", [vp, u64p, u64p])
+bt_gibbs_result_fetch = _sig("bt_gibbs_result_fetch", [vp] * 7)
+bt_gibbs_trace_enable = _sig("bt_gibbs_trace_enable", [vp, C.c_uint32])
+bt_gibbs_trace_fetch = _sig("bt_gibbs_trace_fetch", [vp, vp, C.c_uint64, u64p])
+bt_gibbs_device_bytes = _sig("bt_gibbs_device_bytes", [vp, u64p])
+bt_diag_uset_replay = _sig("bt_diag_uset_replay", [C.c_uint32, vp, vp, C.c_uint64, vp, u32p])
+bt_diag_rng = _sig("bt_diag_rng", [C.c_uint32, C.c_int, vp, vp, C.c_uint64, vp])
+
+
+class Gibbs:
+    """A batch of variant-cluster groups on one GPU (bt_gibbs_*).  `flat` is a dict as produced by bayestyper_amd.synth."""
+
+    def __init__(self, ctx, flat, lut_g, lut_n, **kw):
+        from . import synth
+
+        self.ctx, self.flat = ctx, flat
+        self.S, self.C, self.G = flat["S"], flat["num_clusters"], flat["num_groups"]
+        self.params, self.batch, self._keep = synth.to_ctypes(flat, **kw)
+        h = vp()
+        check(bt_gibbs_create(ctx.h, C.addressof(self.params), C.addressof(self.batch), C.byref(h)))
+        self.h = h.value
+        if lut_g is not None:
+            self.set_lut(lut_g, lut_n)
+
+    def set_lut(self, lut_g, lut_n):
+        lut_g, lut_n = np.ascontiguousarray(lut_g, np.float64), np.ascontiguousarray(lut_n, np.float64)
+        check(bt_gibbs_set_lut(self.h, _np_ptr(lut_g), _np_ptr(lut_n)))
+
+    def set_noise_lut(self, lut_n):
+        lut_n = np.ascontiguousarray(lut_n, np.float64)
+        check(bt_gibbs_set_noise_lut(self.h, _np_ptr(lut_n)))
+
+    def run(self):
+        check(bt_gibbs_run(self.h))
+
+    def init_chain(self, c):
+        check(bt_gibbs_init_chain(self.h, c))
+
+    def sweep(self, n, collect):
+        check(bt_gibbs_sweep(self.h, n, int(collect)))
+
+    def noise_counts(self, zero_first=True):
+        d = self.ctx.buffer(self.S * 256 * 8)
+        check(bt_gibbs_noise_counts(self.h, d.ptr, int(zero_first)))
+        self.ctx.sync()
+        out = d.download(np.uint64, self.S * 256)
+        d.free()
+        return out
+
+    def reset_groups(self):
+        check(bt_gibbs_reset_groups(self.h))
+
+    def device_bytes(self):
+        b = C.c_uint64()
+        check(bt_gibbs_device_bytes(self.h, C.byref(b)))
+        return b.value
+
+    def trace_enable(self, n):
+        check(bt_gibbs_trace_enable(self.h, n))
+        self._trace_n = n
+
+    def trace(self):
+        """-> list per group of arrays [sweeps][vertex][S]"""
+        goff = self.flat["group_cluster_off"]
+        nv = (goff[1:] - goff[:-1]).astype(np.int64)
+        total = int((nv * self._trace_n * self.S).sum())
+        buf = np.zeros(max(total, 1), np.uint32)
+        n0 = C.c_uint64()
+        check(bt_gibbs_trace_fetch(self.h, _np_ptr(buf), len(buf), C.byref(n0)))
+        out, off = [], 0
+        for g in range(self.G):
+            w = int(nv[g]) * self._trace_n * self.S
+            out.append(buf[off:off + w].reshape(self._trace_n, int(nv[g]), self.S))
+            off += w
+        return out
+
+    def results(self):
+        self.ctx.sync()
+        nd, nc = C.c_uint64(), C.c_uint64()
+        check(bt_gibbs_result_sizes(self.h, C.byref(nd), C.byref(nc)))
+        nd, nc = nd.value, nc.value
+        dip_off = np.zeros(self.C + 1, np.uint64)
+        cell_off = np.zeros(self.C + 1, np.uint64)
+        h1, h2 = np.zeros(max(nd, 1), np.uint16), np.zeros(max(nd, 1), np.uint16)
+        freq = np.zeros(max(nd, 1) * self.S, np.uint32)
+        stats = np.zeros(max(nc, 1) * 12, np.float64)
+        check(bt_gibbs_result_fetch(self.h, _np_ptr(dip_off), _np_ptr(h1), _np_ptr(h2), _np_ptr(freq), _np_ptr(cell_off), _np_ptr(stats)))
+        return {"dip_off": dip_off, "h1": h1[:nd], "h2": h2[:nd], "freq": freq[: nd * self.S].reshape(nd, self.S), "cell_off": cell_off,
+                "stats": stats[: nc * 12].reshape(nc, 3, 4)}
+
+    def close(self):
+        if self.h:
+            bt_gibbs_destroy(self.h)
+            self.h = None

@@ -1,0 +1,142 @@
+"""GPU parity tests for the Gibbs genotyping path (through the C ABI) against the oracle on identical inputs and seed.
+Bar (BASELINE.json north_star): genotype posteriors within 1e-4.  The draw streams are reproduced exactly, so the integer
+diplotype sampling frequencies are expected to be identical; the tests assert the 1e-4 bar and report exact equality."""
+import numpy as np
+import pytest
+
+import _oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4   # posterior tolerance stated by north_star
+
+
+def run_both(gpu_ctx, oracle, flat, trace=0, **kw):
+    from bayestyper_amd import lib
+
+    S = flat["S"]
+    lut_g, lut_n = _oracle.build_luts(oracle, S)
+    og = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, **kw)
+    gg = lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, **kw)
+    if trace:
+        og.trace_enable(trace)
+        gg.trace_enable(trace)
+    og.run(8)
+    gg.run()
+    gpu_ctx.sync()
+    ro, rg = og.results(), gg.results()
+    tr = None
+    if trace:
+        goff = flat["group_cluster_off"]
+        tg = gg.trace()
+        tr = [(og.trace(g, int(goff[g + 1] - goff[g]), trace), tg[g]) for g in range(flat["num_groups"])]
+    og.close()
+    gg.close()
+    return ro, rg, tr
+
+
+def posteriors(r, c, S):
+    """{(h1,h2): freq/total} per sample for cluster c"""
+    e0, e1 = int(r["dip_off"][c]), int(r["dip_off"][c + 1])
+    tot = r["freq"][e0:e1].sum(axis=0).astype(np.float64)
+    return {(int(r["h1"][e]), int(r["h2"][e])): r["freq"][e] / np.maximum(tot, 1) for e in range(e0, e1)}, tot
+
+
+def assert_parity(flat, ro, rg, n_collect):
+    S = flat["S"]
+    exact = 0
+    for c in range(flat["num_clusters"]):
+        po, to = posteriors(ro, c, S)
+        pg, tg = posteriors(rg, c, S)
+        assert (to == n_collect).all() and (tg == n_collect).all()
+        keys = set(po) | set(pg)
+        worst = max(np.abs(po.get(k, np.zeros(S)) - pg.get(k, np.zeros(S))).max() for k in keys)
+        assert worst <= TOL, f"cluster {c}: diplotype posterior differs by {worst}"
+        exact += int(worst == 0)
+    # allele k-mer statistics (NAK/FAK/MAC inputs): counts exact, means to 1e-9 relative
+    so, sg = ro["stats"], rg["stats"]
+    assert so.shape == sg.shape
+    assert np.array_equal(so[:, :, 0], sg[:, :, 0])
+    assert np.allclose(so[:, :, 1:3], sg[:, :, 1:3], rtol=1e-9, atol=1e-12)
+    return exact
+
+
+@pytest.mark.parametrize("shape,n,S", [("A", 64, 3), ("A", 50, 10), ("B", 16, 3), ("A", 30, 1)])
+def test_single_cluster_groups(gpu_ctx, oracle, shape, n, S):
+    from bayestyper_amd import synth
+
+    flat = synth.make_batch(shape, n, S, seed=1000 + S)
+    kw = dict(seed=42, chains=4, burn=20, iters=50)
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=40, **kw)
+    for g, (to, tg) in enumerate(tr):
+        assert np.array_equal(to, tg[: len(to)]), f"group {g}: diplotype trace diverges at sweep {np.argwhere((to != tg[:len(to)]).any(axis=(1, 2)))[:1]}"
+    exact = assert_parity(flat, ro, rg, 4 * 50)
+    assert exact == flat["num_clusters"]
+
+
+def test_default_schedule_shape_A(gpu_ctx, oracle):
+    """the reference's default schedule: 20 chains x (100 burn-in + 250 collected) (main.cpp:389-391)"""
+    from bayestyper_amd import synth
+
+    flat = synth.make_batch("A", 24, 10, seed=77)
+    ro, rg, _ = run_both(gpu_ctx, oracle, flat)
+    assert_parity(flat, ro, rg, 20 * 250)
+
+
+def test_nested_groups_with_multicluster_kmers(gpu_ctx, oracle):
+    from bayestyper_amd import synth
+
+    flat = synth.make_batch("C", 6, 3, seed=5)
+    kw = dict(seed=7, chains=3, burn=15, iters=40)
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=30, **kw)
+    for g, (to, tg) in enumerate(tr):
+        assert np.array_equal(to, tg[: len(to)]), f"group {g}"
+    assert_parity(flat, ro, rg, 3 * 40)
+
+
+def test_ploidy_gender_and_ragged_inputs(gpu_ctx, oracle):
+    """haploid / absent chromosomes (male X/Y), male intercluster multiplicities, a group with a single k-mer-less sample"""
+    from bayestyper_amd import synth
+
+    rng = np.random.default_rng(3)
+    groups = [synth.group_shape_A(rng, i) for i in range(12)] + [synth.GroupSpec([synth.make_cluster(rng, 2, 4, 20, ic_kmers=6)], [100 + i]) for i in range(6)]
+    S = 4
+    ploidy = np.full((len(groups), S), 2, np.uint8)
+    ploidy[::3, 1] = 1
+    ploidy[1::3, 2] = 0
+    ploidy[5] = 0
+    flat = synth.flatten(groups, S, rng, ploidy=ploidy, gender=[0, 1, 1, 0])
+    kw = dict(seed=99, chains=3, burn=10, iters=30)
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=20, **kw)
+    for g, (to, tg) in enumerate(tr):
+        assert np.array_equal(to, tg[: len(to)]), f"group {g}"
+    assert_parity(flat, ro, rg, 3 * 30)
+
+
+def test_stepwise_driving_and_noise_counts(gpu_ctx, oracle):
+    """init_chain / sweep / noise_counts driven step by step as the noise drivers do (InferenceEngine.cpp:60-98)"""
+    from bayestyper_amd import lib, synth
+
+    flat = synth.make_batch("A", 40, 3, seed=11)
+    S = 3
+    lut_g, lut_n = _oracle.build_luts(oracle, S)
+    kw = dict(seed=5, chains=2, burn=5, iters=10, noise_seeding=1)
+    og = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, **kw)
+    gg = lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, **kw)
+    for chain in range(2):
+        og.init_chain(chain)
+        gg.init_chain(chain)
+        for it in range(8):
+            og.sweep(1, it >= 4)
+            gg.sweep(1, it >= 4)
+            ho, hg = og.noise_counts(), gg.noise_counts()
+            assert np.array_equal(ho, hg) and ho.sum() > 0
+            if it == 3:   # a noise-rate update in the middle of the chain
+                _, ln2 = _oracle.build_luts(oracle, S, noise_rate=0.2)
+                og.set_noise_lut(ln2)
+                gg.set_noise_lut(ln2)
+        if chain == 0:    # estimateNoise deletes the genotypers after every chain
+            og.reset_groups()
+            gg.reset_groups()
+    ro, rg = og.results(), gg.results()
+    assert_parity(flat, ro, rg, 4)
+    og.close(), gg.close()
