@@ -64,6 +64,12 @@ int bt_ctx_set_stream(bt_ctx *ctx, void *hip_stream) {
     return BT_OK;
 }
 
+int bt_ctx_use_default_stream(bt_ctx *ctx) {
+    if (!ctx) return bt::fail("bt_ctx_use_default_stream: null ctx");
+    ctx->stream = nullptr;
+    return BT_OK;
+}
+
 int bt_sync(bt_ctx *ctx) {
     if (!ctx) return bt::fail("bt_sync: null ctx");
     BT_HIP(hipSetDevice(ctx->device));

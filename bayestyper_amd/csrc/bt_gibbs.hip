@@ -177,6 +177,31 @@ __global__ __launch_bounds__(GIBBS_BLOCK) void gibbs_kernel(const GroupDev *__re
     }
 }
 
+// per (cluster, sample): most frequently sampled diplotype and its frequency -> the compact posterior summary that is
+// gathered to rank 0; ties resolve to the smallest (h1, h2)
+__global__ __launch_bounds__(256) void summary_kernel(const ClusterDev *__restrict__ clusters, uint32_t num_clusters, uint32_t S, uint32_t *__restrict__ out) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= num_clusters) return;
+    const ClusterDev *d = &clusters[c];
+    for (uint32_t s = 0; s < S; ++s) {
+        uint32_t best_key = 0xFFFFFFFFu, best = 0;
+        for (uint32_t slot = 0; slot < d->dip_cap; ++slot) {
+            const uint32_t tag = d->dip_keys[slot];
+            if (!tag) continue;
+            const uint32_t key = tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u;
+            const uint32_t f = d->dip_freq[(size_t)slot * S + s];
+            const uint32_t kk = (key << 16) | (key >> 16);   // order by (h1, h2)
+            const uint32_t bk = (best_key << 16) | (best_key >> 16);
+            if (f > best || (f == best && f > 0 && kk < bk)) {
+                best = f;
+                best_key = key;
+            }
+        }
+        out[((size_t)c * S + s) * 2] = best_key;
+        out[((size_t)c * S + s) * 2 + 1] = best;
+    }
+}
+
 struct PoolPlan {
     uint64_t size = 0;
     uint64_t take(uint64_t bytes, uint64_t align = 8) {
@@ -610,6 +635,14 @@ int bt_gibbs_noise_counts(bt_gibbs *g, uint64_t *d_hist, int zero_first) {
 int bt_gibbs_reset_groups(bt_gibbs *g) {
     if (!g) return fail("bt_gibbs_reset_groups: null handle");
     return launch(g, OP_RESET, 0, 0, nullptr);
+}
+
+int bt_gibbs_posterior_summary(bt_gibbs *g, uint32_t *d_out) {
+    if (!g || !d_out) return fail("bt_gibbs_posterior_summary: null argument");
+    BT_HIP(hipSetDevice(g->ctx->device));
+    hipLaunchKernelGGL(summary_kernel, dim3((g->C + 255) / 256), dim3(256), 0, g->ctx->stream, g->d_clusters, g->C, g->S, d_out);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
 }
 
 int bt_gibbs_device_bytes(bt_gibbs *g, uint64_t *bytes) {

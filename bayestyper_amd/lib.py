@@ -32,6 +32,7 @@ bt_device_count = _sig("bt_device_count", [C.POINTER(C.c_int)])
 bt_ctx_create = _sig("bt_ctx_create", [C.c_int, C.POINTER(vp)])
 bt_ctx_destroy = _sig("bt_ctx_destroy", [vp])
 bt_ctx_set_stream = _sig("bt_ctx_set_stream", [vp, vp])
+bt_ctx_use_default_stream = _sig("bt_ctx_use_default_stream", [vp])
 bt_sync = _sig("bt_sync", [vp])
 bt_ctx_info = _sig("bt_ctx_info", [vp, C.POINTER(C.c_int), u64p, u64p, C.c_char_p, C.c_size_t])
 bt_malloc = _sig("bt_malloc", [vp, C.c_size_t, C.POINTER(vp)])
@@ -125,7 +126,11 @@ class Ctx:
         check(bt_sync(self.h))
 
     def set_stream(self, stream_ptr):
-        check(bt_ctx_set_stream(self.h, stream_ptr))
+        """hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream); 0 = the device's default stream"""
+        if not stream_ptr:
+            check(bt_ctx_use_default_stream(self.h))
+        else:
+            check(bt_ctx_set_stream(self.h, stream_ptr))
 
     def info(self):
         cu, tot, free = C.c_int(), C.c_uint64(), C.c_uint64()
@@ -344,6 +349,7 @@ bt_gibbs_result_sizes = _sig("bt_gibbs_result_sizes", [vp, u64p, u64p])
 bt_gibbs_result_fetch = _sig("bt_gibbs_result_fetch", [vp] * 7)
 bt_gibbs_trace_enable = _sig("bt_gibbs_trace_enable", [vp, C.c_uint32])
 bt_gibbs_trace_fetch = _sig("bt_gibbs_trace_fetch", [vp, vp, C.c_uint64, u64p])
+bt_gibbs_posterior_summary = _sig("bt_gibbs_posterior_summary", [vp, vp])
 bt_gibbs_device_bytes = _sig("bt_gibbs_device_bytes", [vp, u64p])
 bt_diag_uset_replay = _sig("bt_diag_uset_replay", [C.c_uint32, vp, vp, C.c_uint64, vp, u32p])
 bt_diag_rng = _sig("bt_diag_rng", [C.c_uint32, C.c_int, vp, vp, C.c_uint64, vp])

@@ -379,3 +379,68 @@ def to_ctypes(flat, seed=42, chains=20, burn=100, iters=250, rate=0.1, max_hvk=5
         keep.append(a)
         setattr(b, n, a.ctypes.data)
     return p, b, keep
+
+
+_PER_ITEM = ("group_ploidy", "group_sources", "group_num_shared", "cluster_idx", "edges", "num_haplotypes", "num_variants", "hap_kmer_mult",
+             "kmer_has_counts", "kmer_counts", "kmer_ic_mult", "kmer_shared", "kv_var", "kv_bits", "unique_idx", "multi_idx", "hap_allele",
+             "hapnest_idx", "var_num_alleles", "var_has_dependency", "nestdep_cluster", "nestdep_var")
+
+
+def concat(flats):
+    """concatenate flat batches (same S, same gender) into one; group_index is renumbered 0..G-1"""
+    out = dict(flats[0])
+    for k in _PER_ITEM:
+        out[k] = np.ascontiguousarray(np.concatenate([f[k] for f in flats]))
+    for k in _OFFSET_OF:
+        parts, base = [], np.uint64(0)
+        for f in flats:
+            o = f[k].astype(np.uint64)
+            parts.append(o[:-1] + base)
+            base = base + o[-1]
+        out[k] = np.concatenate(parts + [np.asarray([base], np.uint64)]).astype(np.uint32)
+    out["num_groups"] = int(sum(f["num_groups"] for f in flats))
+    out["num_clusters"] = int(sum(f["num_clusters"] for f in flats))
+    out["group_index"] = np.arange(out["num_groups"], dtype=np.uint32)
+    return out
+
+
+def make_mixture(n_groups, S, seed, fractions=None, templates=4):
+    """WGS-like mixture of group shapes, ordered by number of variants descending like the reference
+    sorts groups (main.cpp:247).  Shape D (H=256) needs >= 8 samples' worth of haplotype candidates and is left out
+    below that (--max-number-of-sample-haplotypes 32 caps H at 32*S)."""
+    if fractions is None:
+        fractions = {"A": 0.90, "B": 0.08, "C": 0.015, "D": 0.005} if S >= 8 else {"A": 0.90, "B": 0.085, "C": 0.015}
+    rng = np.random.default_rng(seed)
+    flats, counts = [], {}
+    for shape in ("D", "C", "B", "A"):
+        if shape not in fractions:
+            continue
+        n = int(round(n_groups * fractions[shape]))
+        if n == 0:
+            continue
+        counts[shape] = n
+        t = min(templates, n)
+        if shape == "C":
+            cid = 0
+            groups = []
+            for _ in range(t):
+                g = SHAPES[shape](rng, cid)
+                cid += 3
+                groups.append(g)
+            tmpl = flatten(groups, S, rng)
+        else:
+            tmpl = flatten([SHAPES[shape](rng, i) for i in range(t)], S, rng)
+        reps = (n + t - 1) // t
+        flats.append(replicate(tmpl, reps, rng))
+    out = concat(flats)
+    out["mixture"] = {k: int(v) for k, v in counts.items()}
+    return out
+
+
+def algorithmic_bytes_per_chain(flat, subsampling_rate=0.1):
+    """HBM floor of the Gibbs path per (cluster, chain) = inputs once + state in/out once:
+    K*H (M) + K*(S+4) (counts, flags, ic) + K_sub*4 (subset) + 2*(H*13 + S*4) (state in/out) + 2*2*2496 (two mt19937 in/out)"""
+    S = flat["S"]
+    H = flat["num_haplotypes"].astype(np.float64)
+    K = (flat["kmer_off"][1:].astype(np.float64) - flat["kmer_off"][:-1].astype(np.float64))
+    return float((K * H + K * (S + 4) + subsampling_rate * K * 4 + 2 * (H * 13 + S * 4) + 2 * 2 * 2496).sum())

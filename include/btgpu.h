@@ -51,6 +51,9 @@ int bt_ctx_destroy(bt_ctx *ctx);
 /* run all subsequent work of this context on an externally owned hipStream_t (e.g. torch's
  * current stream); NULL restores the context's own stream */
 int bt_ctx_set_stream(bt_ctx *ctx, void *hip_stream);
+/* run all subsequent work on the device's default (null) stream — what torch.cuda.current_stream() is unless the
+ * caller switched streams; the default stream's handle is 0, which bt_ctx_set_stream reads as "own stream" */
+int bt_ctx_use_default_stream(bt_ctx *ctx);
 int bt_sync(bt_ctx *ctx);
 /* device properties: compute units, total/free HBM bytes, gcn arch name (buffer >= 64 bytes) */
 int bt_ctx_info(bt_ctx *ctx, int *num_cu, uint64_t *hbm_total, uint64_t *hbm_free, char *arch, size_t arch_len);
@@ -301,6 +304,9 @@ int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t
  * for stat in {count_stats, fraction_stats, mean_stats} (KmerStats.cpp:107-121); h_cell_off[C+1] */
 int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, uint16_t *h_dip_h2, uint32_t *h_dip_freq,
                           uint64_t *h_cell_off, double *h_stats);
+/* compact posterior summary on the DEVICE (input of the cross-GPU gather to rank 0): for cluster c, sample s
+ * d_out[(c*S+s)*2] = h1 | h2<<16 of the most frequently sampled diplotype, d_out[(c*S+s)*2+1] = its frequency */
+int bt_gibbs_posterior_summary(bt_gibbs *g, uint32_t *d_out);
 /* diagnostics: the diplotype drawn for (cluster, sample) in each of the first `max_sweeps` sweeps after this call:
  * h_trace[(sweep*C + c)*S + s] = h1 | h2 << 16.  Pass max_sweeps = 0 to switch tracing off. */
 int bt_gibbs_trace_enable(bt_gibbs *g, uint32_t max_sweeps);
