@@ -6,73 +6,81 @@
 //   bt_gibbs_noise_counts<- VariantClusterGroup::getNoiseCounts + clearGenotyperCache (InferenceEngine.cpp:90-92)
 //
 // Parallelisation: variant-cluster groups are the reference's unit of independence (one std::thread works a group at a
-// time).  Here one LANE owns one group for a whole launch: the sweep is a strictly sequential chain of dependent random
-// draws (samples within a sweep, sweeps within a chain, chains within a genotyper), so the parallel axis is the group
-// index, and a launch carries 10^5-10^6 groups.  All state is in HBM (ClusterDev); workgroups are one wavefront wide so
-// that divergence between groups costs only within a wave and small batches still spread over all 256 CUs.
-#include "bt_gibbs_device.hpp"
+// time).  Here one LANE owns one group for a whole launch: a sweep is a strictly sequential chain of dependent random
+// draws (samples within a sweep, sweeps within a chain, chains within a genotyper), so the parallel axis is the group.
+// Groups are sorted by shape and cut into TILES of 64; a tile is one wavefront's worth of lane-interleaved HBM
+// (bt_gibbs_tile.hpp) so that the wave's memory traffic coalesces.  One workgroup = one wavefront = one tile.
+#include "bt_gibbs_tile.hpp"
 #include "bt_internal.hpp"
 
 #include <algorithm>
 #include <cstring>
+#include <numeric>
 
 using namespace bt;
 
 namespace {
 
-constexpr unsigned GIBBS_BLOCK = 64;
-
-enum GibbsOp { OP_RUN = 0, OP_INIT_CHAIN = 1, OP_SWEEP = 2, OP_NOISE = 3, OP_RESET = 4 };
+enum GibbsOp { OP_RUN = 0, OP_INIT_CHAIN = 1, OP_SWEEP = 2, OP_NOISE = 3, OP_RESET = 4, OP_SETUP = 5 };
 
 struct TraceCfg {
     uint32_t max_sweeps;   // 0 = off
-    uint32_t *counter;     // [G] sweeps recorded per group
+    uint32_t *counter;     // [ntiles*64] sweeps recorded per group
+    uint32_t *buf;         // tile blocks of [max_sweeps][nvm][S][64]
 };
 
-__device__ inline void group_init_chain(const GroupDev *g, ClusterDev *cl, const GParams &P, uint32_t chain) {
-    const uint32_t gseed = P.noise_seeding ? P.seed + (g->index + 1u) * (chain + 1u) : P.seed + (g->index + 1u);
-    for (uint32_t v = 0; v < g->nvert; ++v) {
-        ClusterDev *c = &cl[g->c0 + v];
-        if (!c->sc[SC_CONSTRUCTED]) genotyper_construct(c, P, gseed + c->cid);   // VariantClusterGroup.cpp:179-182
+__device__ inline void group_init_chain(const Tile &t, const GParams &P, uint32_t chain, uint32_t nvert, uint32_t nsrc, uint32_t gindex) {
+    const uint32_t gseed = P.noise_seeding ? P.seed + (gindex + 1u) * (chain + 1u) : P.seed + (gindex + 1u);
+    for (uint32_t v = 0; v < nvert; ++v) {
+        const Vx c = make_vx(t, v);
+        if (!c.sc()[SC_CONSTRUCTED]) genotyper_construct(c, P, gseed + c.cid);   // VariantClusterGroup.cpp:179-182
         genotyper_reset(c, P);
     }
     // shuffleBranchOrdering (VariantClusterGroup.cpp:208-218)
-    mt_seed(g->brng, P.seed + (g->index + 1u) * (chain + 1u));
-    rng_shuffle_u32(g->brng, g->sources, g->nsrc);
-    for (uint32_t v = 0; v < g->nvert; ++v) rng_shuffle_u32(g->brng, cl[g->c0 + v].edges, cl[g->c0 + v].ne);
+    uint32_t *brng = reinterpret_cast<uint32_t *>(t.base + t.d->off[A_BRNG]) + (size_t)t.lane * MT_PAD;
+    mt_seed(brng, P.seed + (gindex + 1u) * (chain + 1u));
+    rng_shuffle_u32(brng, t.arr<uint32_t>(A_SOURCES), nsrc);
+    for (uint32_t v = 0; v < nvert; ++v) {
+        const Vx c = make_vx(t, v);
+        rng_shuffle_u32(brng, c.edges(), vx_ne(c));
+    }
 }
 
 // VariantClusterGenotyper::updateNestedVariantClusterInfo (VariantClusterGenotyper.cpp:140-206): child's info := parent's info, updated
-__device__ inline void prepare_nested(const ClusterDev *c, const ClusterDev *cc, const GParams &P) {
+__device__ inline void prepare_nested(const Vx &c, const Vx &cc, const GParams &P) {
+    const uint32_t nd_n = vx_nd(c);
+    const TileDesc &d = c.d();
+    SPtr<uint32_t, LANES> ndcl = c.a<uint32_t>(A_NDCL, d.NDm > 1 ? d.NDm : 1), ndvo = c.a<uint32_t>(A_NDVOFF, d.NDm + 1);
+    SPtr<uint16_t, LANES> ndv = c.a<uint16_t>(A_NDVAR, d.NDVm > 1 ? d.NDVm : 1);
     for (uint32_t s = 0; s < P.S; ++s) {
-        uint8_t ploidy = c->nest_ploidy[s];
-        uint32_t n = c->nest_n[s];
+        uint8_t ploidy = c.nest_ploidy()[s];
+        uint32_t n = c.nest_n()[s];
         for (uint32_t j = 0; j < n; ++j)
-            for (int q = 0; q < 4; ++q) cc->nest_stats[((size_t)s * 2 + j) * 4 + q] = c->nest_stats[((size_t)s * 2 + j) * 4 + q];
+            for (int q = 0; q < 4; ++q) cc.nest_stats(s, j)[q] = (double)c.nest_stats(s, j)[q];
         for (uint32_t which = 0; which < 2; ++which) {
-            const uint16_t h = c->dip[2 * s + which];
+            const uint16_t h = c.dip()[2 * s + which];
             if (h == NOHAP) continue;
             // binary_search(nested_variant_cluster_indices of h, child cluster idx)
             bool found = false;
-            uint32_t lo = c->hapnest_off[h], hi = c->hapnest_off[h + 1];
+            uint32_t lo = c.hn_off(h), hi = c.hn_off(h + 1);
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                const uint32_t val = c->hapnest_idx[mid];
-                if (val == cc->cid) {
+                const uint32_t val = c.hn_idx(mid);
+                if (val == cc.cid) {
                     found = true;
                     break;
                 }
-                if (val < cc->cid) lo = mid + 1;
+                if (val < cc.cid) lo = mid + 1;
                 else hi = mid;
             }
             if (found) continue;
             ploidy = ploidy == 2 ? 1 : 0;   // updateNestedPloidy
             uint32_t variant_idx = 0xFFFFFFFFu;
-            for (uint32_t d = 0; d < c->nd_n; ++d) {
-                if (c->nd_cluster[d] != cc->cid) continue;
-                for (uint32_t i = c->nd_var_off[d]; i < c->nd_var_off[d + 1]; ++i) {
-                    const uint32_t nv = c->nd_var[i];
-                    const uint32_t a = c->hap_allele[(size_t)h * c->V + nv];
+            for (uint32_t dd = 0; dd < nd_n; ++dd) {
+                if (ndcl[dd] != cc.cid) continue;
+                for (uint32_t i = ndvo[dd], i1 = ndvo[dd + 1]; i < i1; ++i) {
+                    const uint32_t nv = ndv[i];
+                    const uint32_t a = c.hap_allele(h, nv);
                     if (!is_missing(c, nv, a)) {
                         variant_idx = nv;
                         break;
@@ -81,49 +89,52 @@ __device__ inline void prepare_nested(const ClusterDev *c, const ClusterDev *cc,
                 break;
             }
             if (variant_idx != 0xFFFFFFFFu && n < 2) {
-                const double *src = ksc_slot(c, s, which, variant_idx);
-                for (int q = 0; q < 4; ++q) cc->nest_stats[((size_t)s * 2 + n) * 4 + q] = src[q];
+                for (int q = 0; q < 4; ++q) cc.nest_stats(s, n)[q] = (double)c.ksc(s, which, variant_idx)[q];
                 ++n;
             }
         }
-        cc->nest_ploidy[s] = ploidy;
-        cc->nest_n[s] = (uint8_t)n;
+        cc.nest_ploidy()[s] = ploidy;
+        cc.nest_n()[s] = (uint8_t)n;
     }
 }
 
-__device__ inline void visit_vertex(const GroupDev *g, ClusterDev *cl, const GParams &P, uint32_t v, bool collect, uint32_t *trace_row) {
-    const ClusterDev *c = &cl[g->c0 + v];
-    sample_diplotypes(c, P, collect, trace_row ? trace_row + (size_t)v * P.S : nullptr);
+__device__ inline void visit_vertex(const Tile &t, const GParams &P, uint32_t v, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+    const Vx c = make_vx(t, v);
+    sample_diplotypes(c, P, collect, trace_row + (size_t)v * P.S, tracing);
     sample_haplotype_frequencies(c);
 }
 
 // VariantClusterGroup::estimateGenotypes + runGibbsSample (VariantClusterGroup.cpp:220-250), recursion unrolled on an explicit stack
-__device__ inline void group_sweep(const GroupDev *g, ClusterDev *cl, const GParams &P, bool collect, uint32_t *trace_row) {
-    if (trace_row)
-        for (uint32_t i = 0; i < g->nvert * P.S; ++i) trace_row[i] = 0xFFFFFFFFu;
-    for (uint32_t si = 0; si < g->nsrc; ++si) {
-        const uint32_t sv = g->sources[si];
-        const ClusterDev *root = &cl[g->c0 + sv];
-        for (uint32_t s = 0; s < P.S; ++s) {
-            root->nest_ploidy[s] = g->ploidy[s];
-            root->nest_n[s] = 0;
+__device__ inline void group_sweep(const Tile &t, const GParams &P, bool collect, uint32_t nvert, uint32_t nsrc, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+    if (tracing)
+        for (uint32_t i = 0; i < t.d->nvm * P.S; ++i) trace_row[i] = 0xFFFFFFFFu;
+    SPtr<uint32_t, LANES> sources = t.arr<uint32_t>(A_SOURCES), stack = t.arr<uint32_t>(A_STACK);
+    SPtr<uint8_t, LANES> gploidy = t.arr<uint8_t>(A_PLOIDY);
+    for (uint32_t si = 0; si < nsrc; ++si) {
+        const uint32_t sv = sources[si];
+        {
+            const Vx root = make_vx(t, sv);
+            for (uint32_t s = 0; s < P.S; ++s) {
+                root.nest_ploidy()[s] = gploidy[s];
+                root.nest_n()[s] = 0;
+            }
         }
-        visit_vertex(g, cl, P, sv, collect, trace_row);
-        uint32_t sp = 0;
-        g->stack[0] = sv;
-        g->stack[1] = 0;
-        sp = 1;
+        visit_vertex(t, P, sv, collect, trace_row, tracing);
+        if (nvert == 1) continue;
+        stack[0] = sv;
+        stack[1] = 0;
+        uint32_t sp = 1;
         while (sp > 0) {
-            const uint32_t v = g->stack[2 * (sp - 1)];
-            const uint32_t i = g->stack[2 * (sp - 1) + 1];
-            const ClusterDev *c = &cl[g->c0 + v];
-            if (i < c->ne) {
-                g->stack[2 * (sp - 1) + 1] = i + 1;
-                const uint32_t t = c->edges[i];
-                prepare_nested(c, &cl[g->c0 + t], P);
-                visit_vertex(g, cl, P, t, collect, trace_row);
-                g->stack[2 * sp] = t;
-                g->stack[2 * sp + 1] = 0;
+            const uint32_t v = stack[2 * (sp - 1)];
+            const uint32_t i = stack[2 * (sp - 1) + 1];
+            const Vx c = make_vx(t, v);
+            if (i < vx_ne(c)) {
+                stack[2 * (sp - 1) + 1] = i + 1;
+                const uint32_t tv = c.edges()[i];
+                prepare_nested(c, make_vx(t, tv), P);
+                visit_vertex(t, P, tv, collect, trace_row, tracing);
+                stack[2 * sp] = tv;
+                stack[2 * sp + 1] = 0;
                 ++sp;
             } else
                 --sp;
@@ -131,40 +142,63 @@ __device__ inline void group_sweep(const GroupDev *g, ClusterDev *cl, const GPar
     }
 }
 
-__device__ inline uint32_t *trace_row_for(const GroupDev *g, const GParams &P, const TraceCfg &tr, uint32_t gi) {
-    if (!tr.max_sweeps || !g->trace) return nullptr;
-    const uint32_t n = tr.counter[gi];
-    if (n >= tr.max_sweeps) return nullptr;
-    tr.counter[gi] = n + 1;
-    return g->trace + (size_t)n * g->nvert * P.S;
+struct TraceRow {
+    SPtr<uint32_t, LANES> row;
+    bool on;
+};
+__device__ inline TraceRow trace_row_for(const Tile &t, const GParams &P, const TraceCfg &tr, uint32_t tile) {
+    TraceRow r{SPtr<uint32_t, LANES>{nullptr}, false};
+    if (!tr.max_sweeps) return r;
+    uint32_t *cnt = &tr.counter[(size_t)tile * LANES + t.lane];
+    const uint32_t n = *cnt;
+    if (n >= tr.max_sweeps) return r;
+    *cnt = n + 1;
+    r.row = SPtr<uint32_t, LANES>{tr.buf + t.d->trace_base + (size_t)n * t.d->nvm * P.S * LANES + t.lane};
+    r.on = true;
+    return r;
 }
 
-__global__ __launch_bounds__(GIBBS_BLOCK) void gibbs_kernel(const GroupDev *__restrict__ groups, ClusterDev *__restrict__ clusters, uint32_t num_groups,
-                                                            GParams P, int op, uint32_t arg0, uint32_t arg1, unsigned long long *__restrict__ hist, TraceCfg tr) {
-    const uint32_t gi = blockIdx.x * GIBBS_BLOCK + threadIdx.x;
-    if (gi >= num_groups) return;
-    const GroupDev *g = &groups[gi];
+__global__ __launch_bounds__(LANES) void gibbs_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, GParams P, int op, uint32_t arg0, uint32_t arg1,
+                                                       unsigned long long *__restrict__ hist, TraceCfg tr) {
+    const uint32_t tile = blockIdx.x;
+    Tile t;
+    t.d = &tiles[tile];
+    t.base = pool + t.d->base;
+    t.lane = threadIdx.x;
+    SPtr<uint32_t, LANES> gd = t.arr<uint32_t>(A_GDIMS);
+    if (!gd[3]) return;   // padding lane of the last tile
+    const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
     if (op == OP_RUN) {
         for (uint32_t chain = 0; chain < P.num_chains; ++chain) {
-            group_init_chain(g, clusters, P, chain);
-            for (uint32_t i = 0; i < P.burn_in; ++i) group_sweep(g, clusters, P, false, trace_row_for(g, P, tr, gi));
-            for (uint32_t i = 0; i < P.num_iterations; ++i) group_sweep(g, clusters, P, true, trace_row_for(g, P, tr, gi));
+            group_init_chain(t, P, chain, nvert, nsrc, gindex);
+            for (uint32_t i = 0; i < P.burn_in; ++i) {
+                const TraceRow r = trace_row_for(t, P, tr, tile);
+                group_sweep(t, P, false, nvert, nsrc, r.row, r.on);
+            }
+            for (uint32_t i = 0; i < P.num_iterations; ++i) {
+                const TraceRow r = trace_row_for(t, P, tr, tile);
+                group_sweep(t, P, true, nvert, nsrc, r.row, r.on);
+            }
         }
     } else if (op == OP_INIT_CHAIN) {
-        group_init_chain(g, clusters, P, arg0);
+        group_init_chain(t, P, arg0, nvert, nsrc, gindex);
     } else if (op == OP_SWEEP) {
-        for (uint32_t i = 0; i < arg0; ++i) group_sweep(g, clusters, P, arg1 != 0, trace_row_for(g, P, tr, gi));
+        for (uint32_t i = 0; i < arg0; ++i) {
+            const TraceRow r = trace_row_for(t, P, tr, tile);
+            group_sweep(t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
+        }
     } else if (op == OP_NOISE) {
         // VariantClusterGenotyper::getNoiseCounts (:757-779) for every vertex, then clearCache
-        for (uint32_t v = 0; v < g->nvert; ++v) {
-            const ClusterDev *c = &clusters[g->c0 + v];
-            const uint32_t nsu = c->sc[SC_NSUB_U];
+        for (uint32_t v = 0; v < nvert; ++v) {
+            const Vx c = make_vx(t, v);
+            const uint32_t nsu = c.sc()[SC_NSUB_U];
+            SPtr<uint32_t, LANES> usub = c.usub();
             for (uint32_t s = 0; s < P.S; ++s) {
-                const uint16_t h1 = c->dip[2 * s], h2 = c->dip[2 * s + 1];
+                const uint16_t h1 = c.dip()[2 * s], h2 = c.dip()[2 * s + 1];
                 for (uint32_t i = 0; i < nsu; ++i) {
-                    const uint32_t k = c->usub[i];
+                    const uint32_t k = usub[i];
                     if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) {
-                        const uint32_t cnt = c->has_counts[k] ? c->counts[(size_t)k * P.S + s] : 0;
+                        const uint32_t cnt = c.has_counts(k) ? c.count(k, s) : 0;
                         atomicAdd(&hist[s * 256u + cnt], 1ULL);
                     }
                 }
@@ -173,23 +207,42 @@ __global__ __launch_bounds__(GIBBS_BLOCK) void gibbs_kernel(const GroupDev *__re
         }
     } else if (op == OP_RESET) {
         // VariantClusterGroup::resetGroup: genotypers are deleted; the shared KmerCounts multiplicities are NOT reset
-        for (uint32_t v = 0; v < g->nvert; ++v) clusters[g->c0 + v].sc[SC_CONSTRUCTED] = 0;
+        for (uint32_t v = 0; v < nvert; ++v) make_vx(t, v).sc()[SC_CONSTRUCTED] = 0;
+    } else if (op == OP_SETUP) {
+        // mutable copies of the group structure (shuffled in place chain after chain, never restored)
+        SPtr<uint32_t, LANES> s0 = t.arr<uint32_t>(A_SOURCES0), s1 = t.arr<uint32_t>(A_SOURCES);
+        for (uint32_t i = 0; i < nsrc; ++i) s1[i] = s0[i];
+        for (uint32_t v = 0; v < nvert; ++v) {
+            const Vx c = make_vx(t, v);
+            SPtr<uint32_t, LANES> e0 = c.a<uint32_t>(A_EDGES0, t.d->NEm > 1 ? t.d->NEm : 1), e1 = c.edges();
+            for (uint32_t i = 0, n = vx_ne(c); i < n; ++i) e1[i] = e0[i];
+        }
     }
 }
 
 // per (cluster, sample): most frequently sampled diplotype and its frequency -> the compact posterior summary that is
-// gathered to rank 0; ties resolve to the smallest (h1, h2)
-__global__ __launch_bounds__(256) void summary_kernel(const ClusterDev *__restrict__ clusters, uint32_t num_clusters, uint32_t S, uint32_t *__restrict__ out) {
+// gathered to rank 0; ties resolve to the smallest (h1, h2).  One lane per cluster.
+struct ClusterLoc {
+    uint32_t tile, lane, v, pad;
+};
+__global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const ClusterLoc *__restrict__ loc,
+                                                      uint32_t num_clusters, uint32_t S, uint32_t *__restrict__ out) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= num_clusters) return;
-    const ClusterDev *d = &clusters[c];
+    Tile t;
+    t.d = &tiles[loc[c].tile];
+    t.base = pool + t.d->base;
+    t.lane = loc[c].lane;
+    const Vx x = make_vx(t, loc[c].v);
+    SPtr<uint32_t, LANES> keys = x.dip_keys(), freq = x.dip_freq();
+    const uint32_t cap = t.d->dip_cap;
     for (uint32_t s = 0; s < S; ++s) {
         uint32_t best_key = 0xFFFFFFFFu, best = 0;
-        for (uint32_t slot = 0; slot < d->dip_cap; ++slot) {
-            const uint32_t tag = d->dip_keys[slot];
+        for (uint32_t slot = 0; slot < cap; ++slot) {
+            const uint32_t tag = keys[slot];
             if (!tag) continue;
             const uint32_t key = tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u;
-            const uint32_t f = d->dip_freq[(size_t)slot * S + s];
+            const uint32_t f = freq[(size_t)slot * S + s];
             const uint32_t kk = (key << 16) | (key >> 16);   // order by (h1, h2)
             const uint32_t bk = (best_key << 16) | (best_key >> 16);
             if (f > best || (f == best && f > 0 && kk < bk)) {
@@ -202,23 +255,17 @@ __global__ __launch_bounds__(256) void summary_kernel(const ClusterDev *__restri
     }
 }
 
-struct PoolPlan {
-    uint64_t size = 0;
-    uint64_t take(uint64_t bytes, uint64_t align = 8) {
-        size = (size + align - 1) / align * align;
-        uint64_t off = size;
-        size += bytes;
-        return off;
-    }
+// ---- host-side tile builder -------------------------------------------------------------------------------------
+struct TilePlan {
+    TileDesc d;
+    uint64_t in_bytes;      // the input arrays occupy [0, in_bytes) of the tile
+    uint64_t total_bytes;
 };
 
 template <typename T>
-int upload(bt_ctx *ctx, const T *h, uint64_t n, T **d, uint64_t *total) {
-    const uint64_t bytes = std::max<uint64_t>(n, 1) * sizeof(T);
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(d), bytes));
-    if (n) BT_HIP(hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    *total += bytes;
-    return BT_OK;
+inline void put(std::vector<uint8_t> &img, const TileDesc &d, int arr, size_t idx, uint32_t lane, T value) {
+    T *p = reinterpret_cast<T *>(img.data() + d.off[arr]) + idx * LANES + lane;
+    *p = value;
 }
 
 }  // namespace
@@ -226,24 +273,23 @@ int upload(bt_ctx *ctx, const T *h, uint64_t n, T **d, uint64_t *total) {
 struct bt_gibbs {
     bt_ctx *ctx = nullptr;
     GParams P{};
-    uint32_t G = 0, C = 0, S = 0;
-    std::vector<void *> allocs;          // every device allocation, freed in destroy
+    uint32_t G = 0, C = 0, S = 0, ntiles = 0;
+    std::vector<void *> allocs;
     uint64_t device_bytes = 0;
-    GroupDev *d_groups = nullptr;
-    ClusterDev *d_clusters = nullptr;
+    TileDesc *d_tiles = nullptr;
     uint8_t *d_pool = nullptr;
     uint64_t pool_bytes = 0;
+    ClusterLoc *d_loc = nullptr;
     double *d_lut_g = nullptr, *d_lut_n = nullptr;
     bool lut_set = false;
-    // host copies needed to fetch results
-    std::vector<ClusterDev> h_clusters;
-    std::vector<uint32_t> h_A;           // alleles per cluster
+    std::vector<TileDesc> tiles;
+    std::vector<ClusterLoc> loc;           // per cluster (batch order)
+    std::vector<uint32_t> h_A;             // alleles per cluster
+    std::vector<uint32_t> group_tile, group_lane, group_nvert;
     // trace
     uint32_t trace_sweeps = 0;
     uint32_t *d_trace = nullptr, *d_trace_counter = nullptr;
-    std::vector<uint64_t> trace_off;     // per group word offset
     uint64_t trace_words = 0;
-    std::vector<uint32_t> h_nvert;
 };
 
 namespace {
@@ -251,12 +297,23 @@ namespace {
 int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hist) {
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     BT_HIP(hipSetDevice(g->ctx->device));
-    TraceCfg tr{g->trace_sweeps, g->d_trace_counter};
-    hipLaunchKernelGGL(gibbs_kernel, dim3((g->G + GIBBS_BLOCK - 1) / GIBBS_BLOCK), dim3(GIBBS_BLOCK), 0, g->ctx->stream, g->d_groups, g->d_clusters, g->G,
-                       g->P, op, a0, a1, hist, tr);
+    TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
+    hipLaunchKernelGGL(gibbs_kernel, dim3(g->ntiles), dim3(LANES), 0, g->ctx->stream, g->d_tiles, g->d_pool, g->P, op, a0, a1, hist, tr);
     BT_CHECK_LAUNCH();
     return BT_OK;
 }
+
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// element sizes per array, in TileArr order
+const uint32_t kElemSize[A_COUNT] = {
+    /*A_M*/ 1, /*HASC*/ 1, /*COUNTS*/ 1, /*IC*/ 1, /*SHARED*/ 4, /*KVOFF*/ 4, /*KVVAR*/ 2, /*KVBITS*/ 4, /*HAPAL*/ 2, /*HNOFF*/ 4, /*HNIDX*/ 4, /*VARNA*/ 2,
+    /*VARDEP*/ 1, /*ALBASE*/ 4, /*NDCL*/ 4, /*NDVOFF*/ 4, /*NDVAR*/ 2, /*UNIQ0*/ 4, /*MULTI0*/ 4, /*EDGES0*/ 4, /*VDIMS*/ 4, /*VDIMS2*/ 4, /*GDIMS*/ 4,
+    /*SOURCES0*/ 4, /*PLOIDY*/ 1,
+    /*MT*/ 4, /*FNDSAVED*/ 8, /*SPARSITY*/ 8, /*UNIQ*/ 4, /*MULTI*/ 4, /*USUB*/ 4, /*MSUB*/ 4, /*SMM*/ 1, /*DIP*/ 2, /*FREQ*/ 8, /*OBS*/ 4, /*NZ*/ 1,
+    /*ZHDR*/ 4, /*ZBKT*/ 4, /*PHDR*/ 4, /*PBKT*/ 4, /*UNEXT*/ 4, /*HVCOUNT*/ 4, /*UCACHE*/ 8, /*UCTAG*/ 4, /*CUM*/ 8, /*NZLIST*/ 2, /*SIMPLEX*/ 8,
+    /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*SC*/ 4,
+    /*EDGES*/ 4, /*COVER*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1};
 
 }  // namespace
 
@@ -294,17 +351,19 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             return _rc;          \
         }                        \
     } while (0)
-#define UP(field, T, n)                                                 \
-    T *d_##field = nullptr;                                             \
-    BT_TRY(upload<T>(ctx, B->field, (n), &d_##field, &g->device_bytes)); \
-    g->allocs.push_back(d_##field)
+#define BT_TRYHIP(x)                                                     \
+    do {                                                                 \
+        hipError_t _e = (x);                                             \
+        if (_e != hipSuccess) {                                          \
+            bt_gibbs_destroy(g);                                         \
+            return fail(std::string(#x) + ": " + hipGetErrorString(_e)); \
+        }                                                                \
+    } while (0)
 
-    // ---- sizes of the flat input arrays ----
-    const uint64_t R = B->kmer_off[C];
-    const uint64_t NNZ = B->kv_off[R];
-    uint64_t sumH = 0, sumV = 0, multBytes = 0, kvWords = 0, hapvar = 0, nShared = 0;
+    // ---- prefix sums over the flat batch ----
     std::vector<uint64_t> mult_off(C + 1, 0), kvb_off(C + 1, 0), hapvar_off(C + 1, 0);
     std::vector<uint32_t> hap_base(C + 1, 0), var_base(C + 1, 0);
+    g->h_A.assign(C, 0);
     for (uint32_t c = 0; c < C; ++c) {
         const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], K = B->kmer_off[c + 1] - B->kmer_off[c];
         if (H < 1 || H >= 65535 || V < 1) {
@@ -317,132 +376,163 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         hapvar_off[c + 1] = hapvar_off[c] + (uint64_t)H * V;
         hap_base[c + 1] = hap_base[c] + H;
         var_base[c + 1] = var_base[c] + V;
-    }
-    sumH = hap_base[C];
-    sumV = var_base[C];
-    multBytes = mult_off[C];
-    kvWords = kvb_off[C];
-    hapvar = hapvar_off[C];
-    for (uint32_t gi = 0; gi < G; ++gi) nShared += B->group_num_shared[gi];
-    const uint64_t nEdges = B->edge_off[C], nSrc = B->group_source_off[G];
-    const uint64_t nND = B->nestdep_off[C];
-
-    UP(hap_kmer_mult, uint8_t, multBytes);
-    UP(kmer_has_counts, uint8_t, R);
-    UP(kmer_counts, uint8_t, R * S);
-    UP(kmer_ic_mult, uint8_t, R * 2);
-    UP(kmer_shared, int32_t, R);
-    UP(kv_off, uint32_t, R + 1);
-    UP(kv_var, uint16_t, NNZ);
-    UP(kv_bits, uint32_t, kvWords);
-    UP(hap_allele, uint16_t, hapvar);
-    UP(hapnest_off, uint32_t, sumH + 1);
-    UP(hapnest_idx, uint32_t, B->hapnest_off[sumH]);
-    UP(var_num_alleles, uint16_t, sumV);
-    UP(var_has_dependency, uint8_t, sumV);
-    UP(nestdep_cluster, uint32_t, nND);
-    UP(nestdep_var_off, uint32_t, nND + 1);
-    UP(nestdep_var, uint16_t, B->nestdep_var_off[nND]);
-    UP(group_ploidy, uint8_t, (uint64_t)G * S);
-    UP(unique_idx, uint32_t, B->unique_off[C]);
-    UP(multi_idx, uint32_t, B->multi_off[C]);
-
-    // ---- plan the state pool ----
-    PoolPlan plan;
-    std::vector<ClusterDev> &hc = g->h_clusters;
-    hc.assign(C, ClusterDev{});
-    g->h_A.assign(C, 0);
-    struct Offs {
-        uint64_t allele_base, prng, fprng, fnd, uniq, multi, usub, msub, smm, dip, freq, obs, nz, zhdr, zbkt, phdr, pbkt, unext, hvcount, ucache, ucache_tag,
-            cum, nzlist, simplex, ksc, ksc_upd, dip_keys, dip_freq, astats, nest_ploidy, nest_n, nest_stats, sc, edges, cover_rows;
-    };
-    std::vector<Offs> offs(C);
-    const uint64_t collect_total = (uint64_t)std::max<uint32_t>(params->num_chains, 1) * std::max<uint32_t>(params->num_iterations, 1) * S;
-    for (uint32_t c = 0; c < C; ++c) {
-        ClusterDev &d = hc[c];
-        Offs &o = offs[c];
-        d.H = B->num_haplotypes[c];
-        d.V = B->num_variants[c];
-        d.K = B->kmer_off[c + 1] - B->kmer_off[c];
-        d.HW = (d.H + 31) / 32;
-        d.nu = B->unique_off[c + 1] - B->unique_off[c];
-        d.nm = B->multi_off[c + 1] - B->multi_off[c];
-        d.cid = B->cluster_idx[c];
-        d.D2 = d.H * (d.H + 1) / 2;
-        d.Dc = d.D2 + d.H;
-        d.nd_n = B->nestdep_off[c + 1] - B->nestdep_off[c];
-        d.ne = B->edge_off[c + 1] - B->edge_off[c];
-        d.kv_e0 = B->kv_off[B->kmer_off[c]];
         uint32_t A = 0;
-        for (uint32_t v = 0; v < d.V; ++v) A += B->var_num_alleles[var_base[c] + v];
-        d.A = A;
+        for (uint32_t v = 0; v < V; ++v) A += B->var_num_alleles[var_base[c] + v];
         g->h_A[c] = A;
-        // unique log-prob cache: dense when small, else direct-mapped
-        const uint64_t dense = (uint64_t)S * d.Dc;
-        uint64_t cache_entries;
+    }
+
+    // ---- order groups by shape (vertices, haplotypes, k-mers: descending) and cut into tiles of 64 ----
+    struct GShape {
+        uint32_t nv, Hmax, Kmax, g;
+    };
+    std::vector<GShape> shapes(G);
+    for (uint32_t gi = 0; gi < G; ++gi) {
+        GShape s{B->group_cluster_off[gi + 1] - B->group_cluster_off[gi], 0, 0, gi};
+        for (uint32_t c = B->group_cluster_off[gi]; c < B->group_cluster_off[gi + 1]; ++c) {
+            s.Hmax = std::max(s.Hmax, B->num_haplotypes[c]);
+            s.Kmax = std::max(s.Kmax, B->kmer_off[c + 1] - B->kmer_off[c]);
+        }
+        shapes[gi] = s;
+    }
+    std::stable_sort(shapes.begin(), shapes.end(), [](const GShape &a, const GShape &b) {
+        if (a.nv != b.nv) return a.nv > b.nv;
+        if (a.Hmax != b.Hmax) return a.Hmax > b.Hmax;
+        return a.Kmax > b.Kmax;
+    });
+    const uint32_t ntiles = (G + LANES - 1) / LANES;
+    g->ntiles = ntiles;
+    g->group_tile.assign(G, 0);
+    g->group_lane.assign(G, 0);
+    g->group_nvert.assign(G, 0);
+    g->loc.assign(C, ClusterLoc{0, 0, 0, 0});
+    const uint64_t collect_total = (uint64_t)std::max<uint32_t>(params->num_chains, 1) * std::max<uint32_t>(params->num_iterations, 1) * S;
+
+    std::vector<TilePlan> plans(ntiles);
+    uint64_t pool = 0;
+    for (uint32_t ti = 0; ti < ntiles; ++ti) {
+        TileDesc d{};
+        d.S = S;
+        d.first_group = ti * LANES;
+        d.num_lanes = std::min<uint32_t>(LANES, G - ti * LANES);
+        uint32_t Am = 1, NSHm = 0;
+        for (uint32_t l = 0; l < d.num_lanes; ++l) {
+            const uint32_t gi = shapes[ti * LANES + l].g;
+            const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
+            d.nvm = std::max(d.nvm, c1 - c0);
+            NSHm = std::max(NSHm, B->group_num_shared[gi]);
+            for (uint32_t c = c0; c < c1; ++c) {
+                const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], K = B->kmer_off[c + 1] - B->kmer_off[c];
+                d.Hm = std::max(d.Hm, H);
+                d.Vm = std::max(d.Vm, V);
+                d.Km = std::max(d.Km, K);
+                d.NUm = std::max(d.NUm, B->unique_off[c + 1] - B->unique_off[c]);
+                d.NMm = std::max(d.NMm, B->multi_off[c + 1] - B->multi_off[c]);
+                d.NNZm = std::max(d.NNZm, B->kv_off[B->kmer_off[c + 1]] - B->kv_off[B->kmer_off[c]]);
+                d.HNm = std::max(d.HNm, B->hapnest_off[hap_base[c + 1]] - B->hapnest_off[hap_base[c]]);
+                d.NDm = std::max(d.NDm, B->nestdep_off[c + 1] - B->nestdep_off[c]);
+                d.NDVm = std::max(d.NDVm, B->nestdep_var_off[B->nestdep_off[c + 1]] - B->nestdep_var_off[B->nestdep_off[c]]);
+                d.NEm = std::max(d.NEm, B->edge_off[c + 1] - B->edge_off[c]);
+                Am = std::max(Am, g->h_A[c]);
+            }
+        }
+        d.HWm = (d.Hm + 31) / 32;
+        d.NSHm = NSHm;
+        d.Am = Am;
+        d.Bcap = uset_bucket_capacity(d.Hm);
+        d.D2m = d.Hm * (d.Hm + 1) / 2;
+        d.Dcm = d.D2m + d.Hm;
+        const uint64_t dense = (uint64_t)S * d.Dcm;
         if (dense <= 8192) {
             d.cache_mode = 0;
-            cache_entries = dense;
-            d.cache_mask = 0;
+            d.cache_entries = (uint32_t)dense;
         } else {
             d.cache_mode = 1;
-            cache_entries = 16384;
-            d.cache_mask = (uint32_t)cache_entries - 1;
+            d.cache_entries = 16384;
         }
-        const uint64_t Dtot = (uint64_t)d.Dc + 1;
         uint64_t cap = 4;
-        while (cap < 2 * std::min<uint64_t>(Dtot, collect_total)) cap <<= 1;
+        while (cap < 2 * std::min<uint64_t>((uint64_t)d.Dcm + 1, collect_total)) cap <<= 1;
         d.dip_cap = (uint32_t)cap;
-        const uint32_t bcap = uset_bucket_capacity(d.H);
-        o.allele_base = plan.take((uint64_t)(d.V + 1) * 4, 4);
-        o.prng = plan.take(MT_WORDS * 4, 4);
-        o.fprng = plan.take(MT_WORDS * 4, 4);
-        o.fnd = plan.take(sizeof(NormalState), 8);
-        o.uniq = plan.take((uint64_t)d.nu * 4, 4);
-        o.multi = plan.take((uint64_t)d.nm * 4, 4);
-        o.usub = plan.take((uint64_t)d.nu * 4, 4);
-        o.msub = plan.take((uint64_t)d.nm * 4, 4);
-        o.smm = plan.take((uint64_t)d.nm * S, 1);
-        o.dip = plan.take((uint64_t)S * 4, 2);
-        o.freq = plan.take((uint64_t)d.H * 8, 8);
-        o.obs = plan.take((uint64_t)d.H * 4, 4);
-        o.nz = plan.take(d.H, 1);
-        o.zhdr = plan.take(16, 4);
-        o.zbkt = plan.take((uint64_t)bcap * 4, 4);
-        o.phdr = plan.take(16, 4);
-        o.pbkt = plan.take((uint64_t)bcap * 4, 4);
-        o.unext = plan.take((uint64_t)d.H * 4, 4);
-        o.hvcount = plan.take((uint64_t)d.H * d.V * 4, 4);
-        o.ucache = plan.take(cache_entries * 8, 8);
-        o.ucache_tag = plan.take(d.cache_mode == 1 ? cache_entries * 4 : 4, 4);
-        o.cum = plan.take((uint64_t)std::max<uint32_t>(d.D2, 1) * 8, 8);
-        o.nzlist = plan.take((uint64_t)d.H * 2, 2);
-        o.simplex = plan.take((uint64_t)(d.H + 1) * 8, 8);
-        o.ksc = plan.take((uint64_t)S * 2 * d.V * 4 * 8, 8);
-        o.ksc_upd = plan.take(S, 1);
-        o.dip_keys = plan.take(cap * 4, 4);
-        o.dip_freq = plan.take(cap * S * 4, 4);
-        o.astats = plan.take((uint64_t)S * A * 12 * 8, 8);
-        o.nest_ploidy = plan.take(S, 1);
-        o.nest_n = plan.take(S, 1);
-        o.nest_stats = plan.take((uint64_t)S * 2 * 4 * 8, 8);
-        o.sc = plan.take(SC_COUNT * 4, 4);
-        o.edges = plan.take((uint64_t)d.ne * 4, 4);
-        o.cover_rows = plan.take(d.K, 1);
+        d.scache_p = std::min<uint32_t>(2 * S, d.Hm);
+        d.scache_len = d.Hm + 1;
+        d.scache_n = 2 * S * d.scache_p;
+        if ((uint64_t)d.scache_n * d.scache_len > 4096) d.scache_n = 0;
+        // lengths (elements per lane) of every array
+        const uint64_t nv = d.nvm;
+        uint64_t len[A_COUNT];
+        len[A_M] = nv * d.Km * d.Hm;
+        len[A_HASC] = nv * d.Km;
+        len[A_COUNTS] = nv * d.Km * S;
+        len[A_IC] = nv * d.Km * 2;
+        len[A_SHARED] = nv * d.Km;
+        len[A_KVOFF] = nv * (d.Km + 1);
+        len[A_KVVAR] = nv * d.NNZm;
+        len[A_KVBITS] = nv * (uint64_t)d.NNZm * d.HWm;
+        len[A_HAPAL] = nv * d.Hm * d.Vm;
+        len[A_HNOFF] = nv * (d.Hm + 1);
+        len[A_HNIDX] = nv * d.HNm;
+        len[A_VARNA] = nv * d.Vm;
+        len[A_VARDEP] = nv * d.Vm;
+        len[A_ALBASE] = nv * (d.Vm + 1);
+        len[A_NDCL] = nv * std::max<uint32_t>(d.NDm, 1);
+        len[A_NDVOFF] = nv * (d.NDm + 1);
+        len[A_NDVAR] = nv * std::max<uint32_t>(d.NDVm, 1);
+        len[A_UNIQ0] = nv * d.NUm;
+        len[A_MULTI0] = nv * d.NMm;
+        len[A_EDGES0] = nv * std::max<uint32_t>(d.NEm, 1);
+        len[A_VDIMS] = nv * 8;
+        len[A_VDIMS2] = nv * 2;
+        len[A_GDIMS] = 4;
+        len[A_SOURCES0] = nv;
+        len[A_PLOIDY] = S;
+        len[A_MT] = nv * 2 * MT_PAD;
+        len[A_FNDSAVED] = nv;
+        len[A_SPARSITY] = nv;
+        len[A_UNIQ] = len[A_USUB] = nv * d.NUm;
+        len[A_MULTI] = len[A_MSUB] = nv * d.NMm;
+        len[A_SMM] = nv * d.NMm * S;
+        len[A_DIP] = nv * 2 * S;
+        len[A_FREQ] = nv * d.Hm;
+        len[A_OBS] = nv * d.Hm;
+        len[A_NZ] = nv * d.Hm;
+        len[A_ZHDR] = len[A_PHDR] = nv * 4;
+        len[A_ZBKT] = len[A_PBKT] = nv * d.Bcap;
+        len[A_UNEXT] = nv * d.Hm;
+        len[A_HVCOUNT] = nv * d.Hm * d.Vm;
+        len[A_UCACHE] = nv * d.cache_entries;
+        len[A_UCTAG] = nv * (d.cache_mode == 1 ? d.cache_entries : 1);
+        len[A_CUM] = nv * std::max<uint32_t>(d.D2m, 1);
+        len[A_NZLIST] = nv * d.Hm;
+        len[A_SIMPLEX] = nv * (d.Hm + 1);
+        len[A_SCACHE] = nv * (uint64_t)std::max<uint32_t>(d.scache_n, 1) * std::max<uint32_t>(d.scache_n ? d.scache_len : 1, 1);
+        len[A_SCLEN] = nv * std::max<uint32_t>(d.scache_n, 1);
+        len[A_KSC] = nv * S * 2 * d.Vm * 4;
+        len[A_KSCUPD] = nv * S;
+        len[A_DIPKEYS] = nv * d.dip_cap;
+        len[A_DIPFREQ] = nv * (uint64_t)d.dip_cap * S;
+        len[A_ASTATS] = nv * (uint64_t)S * d.Am * 12;
+        len[A_NESTPL] = len[A_NESTN] = nv * S;
+        len[A_NESTST] = nv * S * 8;
+        len[A_SC] = nv * SC_COUNT;
+        len[A_EDGES] = nv * std::max<uint32_t>(d.NEm, 1);
+        len[A_COVER] = nv * d.Km;
+        len[A_SOURCES] = nv;
+        len[A_STACK] = 2 * (nv + 1);
+        len[A_BRNG] = MT_PAD;
+        len[A_SHMULT] = (uint64_t)std::max<uint32_t>(d.NSHm, 1) * S;
+        uint64_t off = 0, in_bytes = 0;
+        for (int a = 0; a < A_COUNT; ++a) {
+            off = align_up(off, 256);
+            d.off[a] = off;
+            off += len[a] * LANES * kElemSize[a];
+            if (a == A_PLOIDY) in_bytes = align_up(off, 256);
+        }
+        d.base = pool;
+        plans[ti].d = d;
+        plans[ti].in_bytes = in_bytes;
+        plans[ti].total_bytes = align_up(off, 256);
+        pool += plans[ti].total_bytes;
     }
-    struct GOffs {
-        uint64_t sources, stack, brng, shared;
-    };
-    std::vector<GOffs> goffs(G);
-    for (uint32_t gi = 0; gi < G; ++gi) {
-        const uint32_t nv = B->group_cluster_off[gi + 1] - B->group_cluster_off[gi];
-        const uint32_t ns = B->group_source_off[gi + 1] - B->group_source_off[gi];
-        goffs[gi].sources = plan.take((uint64_t)ns * 4, 4);
-        goffs[gi].stack = plan.take((uint64_t)(nv + 1) * 2 * 4, 4);
-        goffs[gi].brng = plan.take(MT_WORDS * 4, 4);
-        goffs[gi].shared = plan.take((uint64_t)B->group_num_shared[gi] * S, 1);
-    }
-    g->pool_bytes = plan.size + 64;
+    g->pool_bytes = pool + 256;
     {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->d_pool), g->pool_bytes);
         if (e != hipSuccess) {
@@ -452,129 +542,105 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     }
     g->allocs.push_back(g->d_pool);
     g->device_bytes += g->pool_bytes;
-    BT_TRY(hipMemsetAsync(g->d_pool, 0, g->pool_bytes, ctx->stream) == hipSuccess ? BT_OK : fail("bt_gibbs_create: memset failed"));
+    BT_TRYHIP(hipMemsetAsync(g->d_pool, 0, g->pool_bytes, ctx->stream));
 
-    // ---- host image of the mutable, non-zero-initialised parts of the pool ----
-    // (index lists, edges, sources, allele_base); built in one staging buffer and copied over the zeroed pool
-    std::vector<uint8_t> stage(g->pool_bytes, 0);
-    for (uint32_t c = 0; c < C; ++c) {
-        const ClusterDev &d = hc[c];
-        const Offs &o = offs[c];
-        uint32_t *ab = reinterpret_cast<uint32_t *>(stage.data() + o.allele_base);
-        uint32_t acc = 0;
-        for (uint32_t v = 0; v < d.V; ++v) {
-            ab[v] = acc;
-            acc += B->var_num_alleles[var_base[c] + v];
+    // ---- build and upload the input image of every tile ----
+    std::vector<uint8_t> img;
+    g->tiles.resize(ntiles);
+    for (uint32_t ti = 0; ti < ntiles; ++ti) {
+        const TileDesc &d = plans[ti].d;
+        g->tiles[ti] = d;
+        img.assign(plans[ti].in_bytes, 0);
+        for (uint32_t l = 0; l < d.num_lanes; ++l) {
+            const uint32_t gi = shapes[ti * LANES + l].g;
+            const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
+            g->group_tile[gi] = ti;
+            g->group_lane[gi] = l;
+            g->group_nvert[gi] = c1 - c0;
+            const uint32_t nsrc = B->group_source_off[gi + 1] - B->group_source_off[gi];
+            put<uint32_t>(img, d, A_GDIMS, 0, l, c1 - c0);
+            put<uint32_t>(img, d, A_GDIMS, 1, l, nsrc);
+            put<uint32_t>(img, d, A_GDIMS, 2, l, B->group_index[gi]);
+            put<uint32_t>(img, d, A_GDIMS, 3, l, 1u);
+            for (uint32_t i = 0; i < nsrc; ++i) put<uint32_t>(img, d, A_SOURCES0, i, l, B->group_sources[B->group_source_off[gi] + i]);
+            for (uint32_t s = 0; s < S; ++s) put<uint8_t>(img, d, A_PLOIDY, s, l, B->group_ploidy[(size_t)gi * S + s]);
+            for (uint32_t c = c0; c < c1; ++c) {
+                const size_t v = c - c0;
+                g->loc[c] = ClusterLoc{ti, l, (uint32_t)v, 0};
+                const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], r0 = B->kmer_off[c], K = B->kmer_off[c + 1] - r0;
+                const uint32_t nu = B->unique_off[c + 1] - B->unique_off[c], nm = B->multi_off[c + 1] - B->multi_off[c];
+                const uint32_t nd = B->nestdep_off[c + 1] - B->nestdep_off[c], ne = B->edge_off[c + 1] - B->edge_off[c];
+                const uint32_t dims[8] = {H, V, K, nu, nm, nd, ne, B->cluster_idx[c]};
+                for (int q = 0; q < 8; ++q) put<uint32_t>(img, d, A_VDIMS, v * 8 + q, l, dims[q]);
+                put<uint32_t>(img, d, A_VDIMS2, v * 2, l, g->h_A[c]);
+                const uint8_t *M = B->hap_kmer_mult + mult_off[c];
+                const uint32_t HW = (H + 31) / 32;
+                const uint32_t e0 = B->kv_off[r0];
+                for (uint32_t k = 0; k < K; ++k) {
+                    const size_t r = (size_t)r0 + k;
+                    for (uint32_t h = 0; h < H; ++h) put<uint8_t>(img, d, A_M, (v * d.Km + k) * d.Hm + h, l, M[(size_t)k * H + h]);
+                    put<uint8_t>(img, d, A_HASC, v * d.Km + k, l, B->kmer_has_counts[r]);
+                    for (uint32_t s = 0; s < S; ++s) put<uint8_t>(img, d, A_COUNTS, (v * d.Km + k) * S + s, l, B->kmer_counts[r * S + s]);
+                    put<uint8_t>(img, d, A_IC, (v * d.Km + k) * 2, l, B->kmer_ic_mult[2 * r]);
+                    put<uint8_t>(img, d, A_IC, (v * d.Km + k) * 2 + 1, l, B->kmer_ic_mult[2 * r + 1]);
+                    put<int32_t>(img, d, A_SHARED, v * d.Km + k, l, B->kmer_shared[r]);
+                    put<uint32_t>(img, d, A_KVOFF, v * (d.Km + 1) + k, l, B->kv_off[r] - e0);
+                }
+                put<uint32_t>(img, d, A_KVOFF, v * (d.Km + 1) + K, l, B->kv_off[(size_t)r0 + K] - e0);
+                const uint32_t nnz = B->kv_off[(size_t)r0 + K] - e0;
+                for (uint32_t e = 0; e < nnz; ++e) {
+                    put<uint16_t>(img, d, A_KVVAR, v * d.NNZm + e, l, B->kv_var[e0 + e]);
+                    for (uint32_t w = 0; w < HW; ++w) put<uint32_t>(img, d, A_KVBITS, (v * d.NNZm + e) * d.HWm + w, l, B->kv_bits[kvb_off[c] + (uint64_t)e * HW + w]);
+                }
+                const uint32_t hn0 = B->hapnest_off[hap_base[c]];
+                for (uint32_t h = 0; h < H; ++h) {
+                    for (uint32_t vv = 0; vv < V; ++vv) put<uint16_t>(img, d, A_HAPAL, (v * d.Hm + h) * d.Vm + vv, l, B->hap_allele[hapvar_off[c] + (size_t)h * V + vv]);
+                    put<uint32_t>(img, d, A_HNOFF, v * (d.Hm + 1) + h, l, B->hapnest_off[hap_base[c] + h] - hn0);
+                }
+                put<uint32_t>(img, d, A_HNOFF, v * (d.Hm + 1) + H, l, B->hapnest_off[hap_base[c] + H] - hn0);
+                for (uint32_t i = 0, n = B->hapnest_off[hap_base[c] + H] - hn0; i < n; ++i) put<uint32_t>(img, d, A_HNIDX, v * d.HNm + i, l, B->hapnest_idx[hn0 + i]);
+                uint32_t acc = 0;
+                for (uint32_t vv = 0; vv < V; ++vv) {
+                    put<uint16_t>(img, d, A_VARNA, v * d.Vm + vv, l, B->var_num_alleles[var_base[c] + vv]);
+                    put<uint8_t>(img, d, A_VARDEP, v * d.Vm + vv, l, B->var_has_dependency[var_base[c] + vv]);
+                    put<uint32_t>(img, d, A_ALBASE, v * (d.Vm + 1) + vv, l, acc);
+                    acc += B->var_num_alleles[var_base[c] + vv];
+                }
+                put<uint32_t>(img, d, A_ALBASE, v * (d.Vm + 1) + V, l, acc);
+                const uint32_t nd0 = B->nestdep_off[c];
+                const uint32_t ndv0 = B->nestdep_var_off[nd0];
+                for (uint32_t i = 0; i < nd; ++i) {
+                    put<uint32_t>(img, d, A_NDCL, v * std::max<uint32_t>(d.NDm, 1) + i, l, B->nestdep_cluster[nd0 + i]);
+                    put<uint32_t>(img, d, A_NDVOFF, v * (d.NDm + 1) + i, l, B->nestdep_var_off[nd0 + i] - ndv0);
+                }
+                put<uint32_t>(img, d, A_NDVOFF, v * (d.NDm + 1) + nd, l, B->nestdep_var_off[nd0 + nd] - ndv0);
+                for (uint32_t i = 0, n = B->nestdep_var_off[nd0 + nd] - ndv0; i < n; ++i)
+                    put<uint16_t>(img, d, A_NDVAR, v * std::max<uint32_t>(d.NDVm, 1) + i, l, B->nestdep_var[ndv0 + i]);
+                for (uint32_t i = 0; i < nu; ++i) put<uint32_t>(img, d, A_UNIQ0, v * d.NUm + i, l, B->unique_idx[B->unique_off[c] + i]);
+                for (uint32_t i = 0; i < nm; ++i) put<uint32_t>(img, d, A_MULTI0, v * d.NMm + i, l, B->multi_idx[B->multi_off[c] + i]);
+                for (uint32_t i = 0; i < ne; ++i) put<uint32_t>(img, d, A_EDGES0, v * std::max<uint32_t>(d.NEm, 1) + i, l, B->edges[B->edge_off[c] + i]);
+            }
         }
-        ab[d.V] = acc;
-        std::memcpy(stage.data() + o.uniq, B->unique_idx + B->unique_off[c], (size_t)d.nu * 4);
-        std::memcpy(stage.data() + o.multi, B->multi_idx + B->multi_off[c], (size_t)d.nm * 4);
-        std::memcpy(stage.data() + o.edges, B->edges + B->edge_off[c], (size_t)d.ne * 4);
+        BT_TRYHIP(hipMemcpyAsync(g->d_pool + d.base, img.data(), plans[ti].in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        BT_TRYHIP(hipStreamSynchronize(ctx->stream));   // img is reused
     }
-    for (uint32_t gi = 0; gi < G; ++gi) {
-        const uint32_t ns = B->group_source_off[gi + 1] - B->group_source_off[gi];
-        std::memcpy(stage.data() + goffs[gi].sources, B->group_sources + B->group_source_off[gi], (size_t)ns * 4);
-    }
-    BT_TRY(hipMemcpyAsync(g->d_pool, stage.data(), g->pool_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? BT_OK
-                                                                                                                        : fail("bt_gibbs_create: pool upload failed"));
-    BT_TRY(hipStreamSynchronize(ctx->stream) == hipSuccess ? BT_OK : fail("bt_gibbs_create: sync failed"));
-
-    // ---- device records ----
-    std::vector<GroupDev> hg(G);
-    for (uint32_t gi = 0; gi < G; ++gi) {
-        GroupDev &gd = hg[gi];
-        gd.index = B->group_index[gi];
-        gd.c0 = B->group_cluster_off[gi];
-        gd.nvert = B->group_cluster_off[gi + 1] - gd.c0;
-        gd.nsrc = B->group_source_off[gi + 1] - B->group_source_off[gi];
-        gd.nshared = B->group_num_shared[gi];
-        gd.sources = reinterpret_cast<uint32_t *>(g->d_pool + goffs[gi].sources);
-        gd.ploidy = d_group_ploidy + (uint64_t)gi * S;
-        gd.stack = reinterpret_cast<uint32_t *>(g->d_pool + goffs[gi].stack);
-        gd.brng = reinterpret_cast<uint32_t *>(g->d_pool + goffs[gi].brng);
-        gd.trace = nullptr;
-        uint8_t *shared = g->d_pool + goffs[gi].shared;
-        for (uint32_t c = gd.c0; c < gd.c0 + gd.nvert; ++c) {
-            ClusterDev &d = hc[c];
-            const Offs &o = offs[c];
-            const uint64_t r0 = B->kmer_off[c];
-            uint8_t *P0 = g->d_pool;
-            d.M = d_hap_kmer_mult + mult_off[c];
-            d.has_counts = d_kmer_has_counts + r0;
-            d.counts = d_kmer_counts + r0 * S;
-            d.ic = d_kmer_ic_mult + r0 * 2;
-            d.shared_idx = d_kmer_shared + r0;
-            d.kv_off = d_kv_off + r0;
-            d.kv_var = d_kv_var;
-            d.kv_bits = d_kv_bits + kvb_off[c];
-            d.hap_allele = d_hap_allele + hapvar_off[c];
-            d.hapnest_off = d_hapnest_off + hap_base[c];
-            d.hapnest_idx = d_hapnest_idx;
-            d.var_na = d_var_num_alleles + var_base[c];
-            d.var_dep = d_var_has_dependency + var_base[c];
-            d.allele_base = reinterpret_cast<uint32_t *>(P0 + o.allele_base);
-            d.nd_cluster = d_nestdep_cluster + B->nestdep_off[c];
-            d.nd_var_off = d_nestdep_var_off + B->nestdep_off[c];
-            d.nd_var = d_nestdep_var;
-            d.uniq0 = d_unique_idx + B->unique_off[c];
-            d.multi0 = d_multi_idx + B->multi_off[c];
-            d.shared_mult = shared;
-            d.prng = reinterpret_cast<uint32_t *>(P0 + o.prng);
-            d.fprng = reinterpret_cast<uint32_t *>(P0 + o.fprng);
-            d.fnd = reinterpret_cast<NormalState *>(P0 + o.fnd);
-            d.uniq = reinterpret_cast<uint32_t *>(P0 + o.uniq);
-            d.multi = reinterpret_cast<uint32_t *>(P0 + o.multi);
-            d.usub = reinterpret_cast<uint32_t *>(P0 + o.usub);
-            d.msub = reinterpret_cast<uint32_t *>(P0 + o.msub);
-            d.smm = P0 + o.smm;
-            d.dip = reinterpret_cast<uint16_t *>(P0 + o.dip);
-            d.freq = reinterpret_cast<double *>(P0 + o.freq);
-            d.obs = reinterpret_cast<uint32_t *>(P0 + o.obs);
-            d.nz = P0 + o.nz;
-            d.zhdr = reinterpret_cast<uint32_t *>(P0 + o.zhdr);
-            d.zbkt = reinterpret_cast<uint32_t *>(P0 + o.zbkt);
-            d.phdr = reinterpret_cast<uint32_t *>(P0 + o.phdr);
-            d.pbkt = reinterpret_cast<uint32_t *>(P0 + o.pbkt);
-            d.unext = reinterpret_cast<uint32_t *>(P0 + o.unext);
-            d.hvcount = reinterpret_cast<uint32_t *>(P0 + o.hvcount);
-            d.ucache = reinterpret_cast<double *>(P0 + o.ucache);
-            d.ucache_tag = reinterpret_cast<uint32_t *>(P0 + o.ucache_tag);
-            d.cum = reinterpret_cast<double *>(P0 + o.cum);
-            d.nzlist = reinterpret_cast<uint16_t *>(P0 + o.nzlist);
-            d.simplex = reinterpret_cast<double *>(P0 + o.simplex);
-            d.ksc = reinterpret_cast<double *>(P0 + o.ksc);
-            d.ksc_upd = P0 + o.ksc_upd;
-            d.dip_keys = reinterpret_cast<uint32_t *>(P0 + o.dip_keys);
-            d.dip_freq = reinterpret_cast<uint32_t *>(P0 + o.dip_freq);
-            d.astats = reinterpret_cast<double *>(P0 + o.astats);
-            d.nest_ploidy = P0 + o.nest_ploidy;
-            d.nest_n = P0 + o.nest_n;
-            d.nest_stats = reinterpret_cast<double *>(P0 + o.nest_stats);
-            d.sc = reinterpret_cast<uint32_t *>(P0 + o.sc);
-            d.edges = reinterpret_cast<uint32_t *>(P0 + o.edges);
-            d.cover_rows = P0 + o.cover_rows;
-        }
-    }
-    g->h_nvert.resize(G);
-    for (uint32_t gi = 0; gi < G; ++gi) g->h_nvert[gi] = hg[gi].nvert;
-    BT_TRY(upload<GroupDev>(ctx, hg.data(), G, &g->d_groups, &g->device_bytes));
-    g->allocs.push_back(g->d_groups);
-    BT_TRY(upload<ClusterDev>(ctx, hc.data(), C, &g->d_clusters, &g->device_bytes));
-    g->allocs.push_back(g->d_clusters);
-    // LUT buffers
-    BT_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_lut_g), (size_t)S * 65536 * 8) == hipSuccess ? BT_OK : fail("bt_gibbs_create: LUT alloc failed"));
+    BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_tiles), (size_t)ntiles * sizeof(TileDesc)));
+    g->allocs.push_back(g->d_tiles);
+    BT_TRYHIP(hipMemcpyAsync(g->d_tiles, g->tiles.data(), (size_t)ntiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+    BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_loc), (size_t)C * sizeof(ClusterLoc)));
+    g->allocs.push_back(g->d_loc);
+    BT_TRYHIP(hipMemcpyAsync(g->d_loc, g->loc.data(), (size_t)C * sizeof(ClusterLoc), hipMemcpyHostToDevice, ctx->stream));
+    BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_lut_g), (size_t)S * 65536 * 8));
     g->allocs.push_back(g->d_lut_g);
-    BT_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_lut_n), (size_t)S * 256 * 8) == hipSuccess ? BT_OK : fail("bt_gibbs_create: LUT alloc failed"));
+    BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_lut_n), (size_t)S * 256 * 8));
     g->allocs.push_back(g->d_lut_n);
-    g->device_bytes += (uint64_t)S * (65536 + 256) * 8;
+    g->device_bytes += (uint64_t)S * (65536 + 256) * 8 + (uint64_t)ntiles * sizeof(TileDesc) + (uint64_t)C * sizeof(ClusterLoc);
     g->P.lut_g = g->d_lut_g;
     g->P.lut_n = g->d_lut_n;
-    BT_TRY(hipStreamSynchronize(ctx->stream) == hipSuccess ? BT_OK : fail("bt_gibbs_create: sync failed"));
-#undef UP
+    BT_TRY(launch(g, OP_SETUP, 0, 0, nullptr));
+    BT_TRYHIP(hipStreamSynchronize(ctx->stream));
 #undef BT_TRY
-    (void)nEdges;
-    (void)nSrc;
-    (void)nShared;
+#undef BT_TRYHIP
     *out = g;
     return BT_OK;
 }
@@ -640,7 +706,7 @@ int bt_gibbs_reset_groups(bt_gibbs *g) {
 int bt_gibbs_posterior_summary(bt_gibbs *g, uint32_t *d_out) {
     if (!g || !d_out) return fail("bt_gibbs_posterior_summary: null argument");
     BT_HIP(hipSetDevice(g->ctx->device));
-    hipLaunchKernelGGL(summary_kernel, dim3((g->C + 255) / 256), dim3(256), 0, g->ctx->stream, g->d_clusters, g->C, g->S, d_out);
+    hipLaunchKernelGGL(summary_kernel, dim3((g->C + 255) / 256), dim3(256), 0, g->ctx->stream, g->d_tiles, g->d_pool, g->d_loc, g->C, g->S, d_out);
     BT_CHECK_LAUNCH();
     return BT_OK;
 }
@@ -651,33 +717,35 @@ int bt_gibbs_device_bytes(bt_gibbs *g, uint64_t *bytes) {
     return BT_OK;
 }
 
-static int fetch_scalars(bt_gibbs *g, std::vector<uint32_t> &sc) {
-    // the scalar blocks are scattered in the pool: copy them one by one (diagnostic path, C small) or the whole pool when large
-    sc.assign((size_t)g->C * SC_COUNT, 0);
-    BT_HIP(hipSetDevice(g->ctx->device));
-    BT_HIP(hipStreamSynchronize(g->ctx->stream));
-    if (g->C > 4096) {
-        std::vector<uint8_t> pool(g->pool_bytes);
-        BT_HIP(hipMemcpy(pool.data(), g->d_pool, g->pool_bytes, hipMemcpyDeviceToHost));
-        for (uint32_t c = 0; c < g->C; ++c)
-            std::memcpy(&sc[(size_t)c * SC_COUNT], pool.data() + (reinterpret_cast<uint8_t *>(g->h_clusters[c].sc) - g->d_pool), SC_COUNT * 4);
-    } else {
-        for (uint32_t c = 0; c < g->C; ++c) BT_HIP(hipMemcpy(&sc[(size_t)c * SC_COUNT], g->h_clusters[c].sc, SC_COUNT * 4, hipMemcpyDeviceToHost));
-    }
+}  // extern "C"
+
+// copy one array of one tile to the host (all vertices, all lanes)
+template <typename T>
+static int fetch_array(bt_gibbs *g, uint32_t ti, int arr, uint64_t elems_per_lane, std::vector<T> &out) {
+    out.resize(elems_per_lane * LANES);
+    BT_HIP(hipMemcpy(out.data(), g->d_pool + g->tiles[ti].base + g->tiles[ti].off[arr], out.size() * sizeof(T), hipMemcpyDeviceToHost));
     return BT_OK;
 }
 
+extern "C" {
+
 int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t *num_allele_cells) {
     if (!g) return fail("bt_gibbs_result_sizes: null handle");
-    std::vector<uint32_t> sc;
-    int rc = fetch_scalars(g, sc);
-    if (rc != BT_OK) return rc;
+    BT_HIP(hipSetDevice(g->ctx->device));
+    BT_HIP(hipStreamSynchronize(g->ctx->stream));
     uint64_t nd = 0, nc = 0;
-    for (uint32_t c = 0; c < g->C; ++c) {
-        if (sc[(size_t)c * SC_COUNT + SC_DIP_OVERFLOW]) return fail("bt_gibbs: diplotype frequency table overflowed");
-        nd += sc[(size_t)c * SC_COUNT + SC_DIP_ENTRIES];
-        nc += (uint64_t)g->h_A[c] * g->S;
+    std::vector<uint32_t> sc;
+    for (uint32_t ti = 0; ti < g->ntiles; ++ti) {
+        const TileDesc &d = g->tiles[ti];
+        int rc = fetch_array<uint32_t>(g, ti, A_SC, (uint64_t)d.nvm * SC_COUNT, sc);
+        if (rc != BT_OK) return rc;
+        for (uint32_t l = 0; l < d.num_lanes; ++l)
+            for (uint32_t v = 0; v < d.nvm; ++v) {
+                if (sc[((size_t)v * SC_COUNT + SC_DIP_OVERFLOW) * LANES + l]) return fail("bt_gibbs: diplotype frequency table overflowed");
+                nd += sc[((size_t)v * SC_COUNT + SC_DIP_ENTRIES) * LANES + l];
+            }
     }
+    for (uint32_t c = 0; c < g->C; ++c) nc += (uint64_t)g->h_A[c] * g->S;
     if (num_diplotype_entries) *num_diplotype_entries = nd;
     if (num_allele_cells) *num_allele_cells = nc;
     return BT_OK;
@@ -688,42 +756,74 @@ int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, 
     if (!g || !h_dip_off || !h_cell_off) return fail("bt_gibbs_result_fetch: null argument");
     BT_HIP(hipSetDevice(g->ctx->device));
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
-    std::vector<uint8_t> pool(g->pool_bytes);
-    BT_HIP(hipMemcpy(pool.data(), g->d_pool, g->pool_bytes, hipMemcpyDeviceToHost));
     const uint32_t S = g->S;
-    uint64_t e = 0, cell = 0;
-    std::vector<std::pair<uint32_t, uint32_t>> order;   // (key, slot)
-    for (uint32_t c = 0; c < g->C; ++c) {
-        const ClusterDev &d = g->h_clusters[c];
-        const uint32_t *keys = reinterpret_cast<const uint32_t *>(pool.data() + (reinterpret_cast<uint8_t *>(d.dip_keys) - g->d_pool));
-        const uint32_t *freq = reinterpret_cast<const uint32_t *>(pool.data() + (reinterpret_cast<uint8_t *>(d.dip_freq) - g->d_pool));
-        const double *astats = reinterpret_cast<const double *>(pool.data() + (reinterpret_cast<uint8_t *>(d.astats) - g->d_pool));
-        h_dip_off[c] = e;
-        h_cell_off[c] = cell;
-        order.clear();
-        for (uint32_t slot = 0; slot < d.dip_cap; ++slot) {
-            const uint32_t tag = keys[slot];
-            if (!tag) continue;
-            const uint32_t key = tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u;
-            order.emplace_back(key, slot);
+    // clusters grouped by tile so that every tile array is fetched once
+    std::vector<uint32_t> order(g->C);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g->loc[a].tile < g->loc[b].tile; });
+    std::vector<uint32_t> keys, freq;
+    std::vector<double> ast;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ents(g->C);   // per cluster: (key, slot) sorted by (h1, h2)
+    uint32_t cur_tile = 0xFFFFFFFFu;
+    for (uint32_t oi = 0; oi < g->C; ++oi) {
+        const uint32_t c = order[oi];
+        const ClusterLoc &L = g->loc[c];
+        const TileDesc &d = g->tiles[L.tile];
+        if (L.tile != cur_tile) {
+            int rc = fetch_array<uint32_t>(g, L.tile, A_DIPKEYS, (uint64_t)d.nvm * d.dip_cap, keys);
+            if (rc != BT_OK) return rc;
+            cur_tile = L.tile;
         }
-        // entries sorted by (h1, h2)
-        std::sort(order.begin(), order.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
+        auto &e = ents[c];
+        for (uint32_t slot = 0; slot < d.dip_cap; ++slot) {
+            const uint32_t tag = keys[((size_t)L.v * d.dip_cap + slot) * LANES + L.lane];
+            if (!tag) continue;
+            e.emplace_back(tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u, slot);
+        }
+        std::sort(e.begin(), e.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
             const uint32_t a1 = a.first & 0xFFFF, a2 = a.first >> 16, b1 = b.first & 0xFFFF, b2 = b.first >> 16;
             return a1 != b1 ? a1 < b1 : a2 < b2;
         });
-        for (auto &kv : order) {
+    }
+    uint64_t e_acc = 0, cell_acc = 0;
+    for (uint32_t c = 0; c < g->C; ++c) {
+        h_dip_off[c] = e_acc;
+        h_cell_off[c] = cell_acc;
+        e_acc += ents[c].size();
+        cell_acc += (uint64_t)S * g->h_A[c];
+    }
+    h_dip_off[g->C] = e_acc;
+    h_cell_off[g->C] = cell_acc;
+    cur_tile = 0xFFFFFFFFu;
+    for (uint32_t oi = 0; oi < g->C; ++oi) {
+        const uint32_t c = order[oi];
+        const ClusterLoc &L = g->loc[c];
+        const TileDesc &d = g->tiles[L.tile];
+        if (L.tile != cur_tile) {
+            int rc = fetch_array<uint32_t>(g, L.tile, A_DIPFREQ, (uint64_t)d.nvm * d.dip_cap * S, freq);
+            if (rc != BT_OK) return rc;
+            if (h_stats) {
+                rc = fetch_array<double>(g, L.tile, A_ASTATS, (uint64_t)d.nvm * S * d.Am * 12, ast);
+                if (rc != BT_OK) return rc;
+            }
+            cur_tile = L.tile;
+        }
+        uint64_t e = h_dip_off[c];
+        for (auto &kv : ents[c]) {
             if (h_dip_h1) h_dip_h1[e] = (uint16_t)(kv.first & 0xFFFF);
             if (h_dip_h2) h_dip_h2[e] = (uint16_t)(kv.first >> 16);
             if (h_dip_freq)
-                for (uint32_t s = 0; s < S; ++s) h_dip_freq[e * S + s] = freq[(size_t)kv.second * S + s];
+                for (uint32_t s = 0; s < S; ++s) h_dip_freq[e * S + s] = freq[(((size_t)L.v * d.dip_cap + kv.second) * S + s) * LANES + L.lane];
             ++e;
         }
-        if (h_stats) std::memcpy(h_stats + cell * 12, astats, (size_t)S * d.A * 12 * 8);
-        cell += (uint64_t)S * d.A;
+        if (h_stats) {
+            const uint32_t A = g->h_A[c];
+            for (uint32_t s = 0; s < S; ++s)
+                for (uint32_t a = 0; a < A; ++a)
+                    for (uint32_t q = 0; q < 12; ++q)
+                        h_stats[(h_cell_off[c] + (uint64_t)s * A + a) * 12 + q] = ast[((((size_t)L.v * S + s) * d.Am + a) * 12 + q) * LANES + L.lane];
+        }
     }
-    h_dip_off[g->C] = e;
-    h_cell_off[g->C] = cell;
     return BT_OK;
 }
 
@@ -740,32 +840,44 @@ int bt_gibbs_trace_enable(bt_gibbs *g, uint32_t max_sweeps) {
         g->d_trace_counter = nullptr;
     }
     g->trace_sweeps = max_sweeps;
-    std::vector<GroupDev> hg(g->G);
-    BT_HIP(hipMemcpy(hg.data(), g->d_groups, (size_t)g->G * sizeof(GroupDev), hipMemcpyDeviceToHost));
-    g->trace_off.assign(g->G + 1, 0);
-    for (uint32_t gi = 0; gi < g->G; ++gi) g->trace_off[gi + 1] = g->trace_off[gi] + (uint64_t)max_sweeps * g->h_nvert[gi] * g->S;
-    g->trace_words = g->trace_off[g->G];
-    if (max_sweeps) {
-        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_trace), std::max<uint64_t>(g->trace_words, 1) * 4));
-        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_trace_counter), (size_t)g->G * 4));
-        BT_HIP(hipMemset(g->d_trace, 0xFF, std::max<uint64_t>(g->trace_words, 1) * 4));
-        BT_HIP(hipMemset(g->d_trace_counter, 0, (size_t)g->G * 4));
+    uint64_t words = 0;
+    for (uint32_t ti = 0; ti < g->ntiles; ++ti) {
+        g->tiles[ti].trace_base = words;
+        words += (uint64_t)max_sweeps * g->tiles[ti].nvm * g->S * LANES;
     }
-    for (uint32_t gi = 0; gi < g->G; ++gi) hg[gi].trace = max_sweeps ? g->d_trace + g->trace_off[gi] : nullptr;
-    BT_HIP(hipMemcpy(g->d_groups, hg.data(), (size_t)g->G * sizeof(GroupDev), hipMemcpyHostToDevice));
+    g->trace_words = words;
+    BT_HIP(hipMemcpy(g->d_tiles, g->tiles.data(), (size_t)g->ntiles * sizeof(TileDesc), hipMemcpyHostToDevice));
+    if (max_sweeps) {
+        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_trace), std::max<uint64_t>(words, 1) * 4));
+        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_trace_counter), (size_t)g->ntiles * LANES * 4));
+        BT_HIP(hipMemset(g->d_trace, 0xFF, std::max<uint64_t>(words, 1) * 4));
+        BT_HIP(hipMemset(g->d_trace_counter, 0, (size_t)g->ntiles * LANES * 4));
+    }
     return BT_OK;
 }
 
+// h_trace: groups in batch order; group gi contributes [max_sweeps][nvert(gi)][S] words
 int bt_gibbs_trace_fetch(bt_gibbs *g, uint32_t *h_trace, uint64_t max_words, uint64_t *num_sweeps_recorded) {
     if (!g || !h_trace) return fail("bt_gibbs_trace_fetch: null argument");
     if (!g->d_trace) return fail("bt_gibbs_trace_fetch: tracing is off");
-    if (max_words < g->trace_words) return fail("bt_gibbs_trace_fetch: buffer too small");
+    uint64_t need = 0;
+    for (uint32_t gi = 0; gi < g->G; ++gi) need += (uint64_t)g->trace_sweeps * g->group_nvert[gi] * g->S;
+    if (max_words < need) return fail("bt_gibbs_trace_fetch: buffer too small");
     BT_HIP(hipSetDevice(g->ctx->device));
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
-    BT_HIP(hipMemcpy(h_trace, g->d_trace, g->trace_words * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> raw(g->trace_words);
+    BT_HIP(hipMemcpy(raw.data(), g->d_trace, g->trace_words * 4, hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for (uint32_t gi = 0; gi < g->G; ++gi) {
+        const TileDesc &d = g->tiles[g->group_tile[gi]];
+        const uint32_t l = g->group_lane[gi], nv = g->group_nvert[gi];
+        for (uint32_t sw = 0; sw < g->trace_sweeps; ++sw)
+            for (uint32_t v = 0; v < nv; ++v)
+                for (uint32_t s = 0; s < g->S; ++s) h_trace[w++] = raw[d.trace_base + (((uint64_t)sw * d.nvm + v) * g->S + s) * LANES + l];
+    }
     if (num_sweeps_recorded) {
         uint32_t n0 = 0;
-        BT_HIP(hipMemcpy(&n0, g->d_trace_counter, 4, hipMemcpyDeviceToHost));
+        BT_HIP(hipMemcpy(&n0, g->d_trace_counter + (size_t)g->group_tile[0] * LANES + g->group_lane[0], 4, hipMemcpyDeviceToHost));
         *num_sweeps_recorded = n0;
     }
     return BT_OK;
@@ -778,7 +890,7 @@ int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *v
     if (!ops || !values || !h_order || !n) return fail("bt_diag_uset_replay: null argument");
     std::vector<uint32_t> hdr(4), bkt(uset_bucket_capacity(universe)), next(std::max<uint32_t>(universe, 1));
     std::vector<uint8_t> present(universe, 0);
-    USet s{hdr.data(), bkt.data(), next.data()};
+    USet s{SPtr<uint32_t, 1>{hdr.data()}, SPtr<uint32_t, 1>{bkt.data()}, SPtr<uint32_t, 1>{next.data()}};
     uset_init(s);
     for (uint64_t i = 0; i < num_ops; ++i) {
         if (ops[i] == 2) {
@@ -806,7 +918,9 @@ int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint6
     if (!h_out) return fail("bt_diag_rng: null argument");
     std::vector<uint32_t> st(MT_WORDS);
     mt_seed(st.data(), seed);
-    NormalState nd{0, 0};
+    double saved = 0;
+    uint32_t avail = 0;
+    NormalState nd{&saved, &avail};
     switch (kind) {
         case 0:
             for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)mt_next(st.data());
@@ -815,7 +929,7 @@ int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint6
             for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_canonical(st.data());
             break;
         case 2:
-            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_gamma(st.data(), &nd, a[i], b[i]);
+            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_gamma(st.data(), nd, a[i], b[i]);
             break;
         case 3:
             for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)rng_uniform_int(st.data(), (uint32_t)a[i] + 1u);

@@ -1,0 +1,823 @@
+// Device-side Gibbs genotyper: one variant-cluster group per lane, 64 groups per wavefront ("tile"), gfx950.
+//
+// Reference behaviour restated (not copied); every function cites what it mirrors:
+//   VariantClusterGenotyper   src/bayesTyper/VariantClusterGenotyper.cpp:59-206,569-785
+//   VariantClusterHaplotypes  src/bayesTyper/VariantClusterHaplotypes.cpp:45-372
+//   (Sparse)FrequencyDistribution / HaplotypeFrequencyDistribution
+//                             src/bayesTyper/FrequencyDistribution.cpp:43-303, HaplotypeFrequencyDistribution.cpp:79-138
+//   SparsityEstimator         src/bayesTyper/SparsityEstimator.cpp:41-87
+//   LogDiscreteSampler        src/bayesTyper/DiscreteSampler.cpp:100-125, Utils::logAddition Utils.hpp:105-124
+//   KmerStats                 src/bayesTyper/KmerStats.cpp:51-121
+//   VariantClusterGroup       src/bayesTyper/VariantClusterGroup.cpp:171-250
+//
+// HBM layout.  The sampler is a chain of dependent random draws per group, so the parallel axis is the group: a lane owns
+// a group for a whole launch.  64 groups of similar shape form a TILE handled by one wavefront.  Every array of a tile is
+// lane-interleaved: element i of vertex v of lane l sits at  off_X + ((v*LEN_X + i)*64 + l)*sizeof(T), with off_X / LEN_X
+// tile-uniform (scalar registers) — a wave-uniform index is ONE coalesced transaction instead of 64 scattered ones, and
+// there is no per-lane pointer to chase.  Arrays are padded to the tile's maximum dimensions; each lane keeps its true
+// dimensions.  Only the mt19937 states are per-lane contiguous (their position drifts between lanes).
+#pragma once
+#include "bt_rng_device.hpp"
+
+namespace bt {
+
+constexpr unsigned LANES = 64;
+constexpr uint16_t NOHAP = 0xFFFF;
+constexpr double BT_LN2 = 0.693147180559945309417232121458176568;
+constexpr double BT_DBL_EPS = 2.220446049250313080847263336181640625e-16;
+constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
+
+// scalar slots per vertex (A_SC)
+enum { SC_USE_MULTI = 0, SC_NSUB_U, SC_NSUB_M, SC_HAP_COUNT, SC_CONSTRUCTED, SC_DIP_ENTRIES, SC_DIP_OVERFLOW, SC_IS_SPARSE, SC_FND_AVAIL, SC_COUNT };
+
+// arrays of a tile.  [V] = per vertex (index v*LEN + i), [G] = per group
+enum TileArr {
+    // ---- inputs ----
+    A_M = 0,        // u8  [V] Km*Hm      haplotype_kmer_multiplicities, index k*Hm + h
+    A_HASC,         // u8  [V] Km
+    A_COUNTS,       // u8  [V] Km*S
+    A_IC,           // u8  [V] Km*2
+    A_SHARED,       // i32 [V] Km
+    A_KVOFF,        // u32 [V] Km+1       CSR offsets (0-based within the vertex)
+    A_KVVAR,        // u16 [V] NNZm
+    A_KVBITS,       // u32 [V] NNZm*HWm
+    A_HAPAL,        // u16 [V] Hm*Vm      index h*Vm + v
+    A_HNOFF,        // u32 [V] Hm+1
+    A_HNIDX,        // u32 [V] HNm
+    A_VARNA,        // u16 [V] Vm
+    A_VARDEP,       // u8  [V] Vm
+    A_ALBASE,       // u32 [V] Vm+1
+    A_NDCL,         // u32 [V] NDm
+    A_NDVOFF,       // u32 [V] NDm+1
+    A_NDVAR,        // u16 [V] NDVm
+    A_UNIQ0,        // u32 [V] NUm
+    A_MULTI0,       // u32 [V] NMm
+    A_EDGES0,       // u32 [V] NEm
+    A_VDIMS,        // u32 [V] 8: H, V, K, nu, nm, nd, ne, cid
+    A_VDIMS2,       // u32 [V] 2: A (alleles), reserved
+    A_GDIMS,        // u32 [G] 4: nvert, nsrc, group index, valid
+    A_SOURCES0,     // u32 [G] nvm
+    A_PLOIDY,       // u8  [G] S
+    // ---- state ----
+    A_MT,           // u32 [V] 2 generators, per-lane contiguous (MT_PAD words each)
+    A_FNDSAVED,     // f64 [V] 1
+    A_SPARSITY,     // f64 [V] 1
+    A_UNIQ, A_MULTI, A_USUB, A_MSUB,   // u32 [V]
+    A_SMM,          // u8  [V] NMm*S
+    A_DIP,          // u16 [V] 2*S
+    A_FREQ,         // f64 [V] Hm
+    A_OBS,          // u32 [V] Hm
+    A_NZ,           // u8  [V] Hm
+    A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_UNEXT,   // u32 [V] 4, Bcap, 4, Bcap, Hm
+    A_HVCOUNT,      // u32 [V] Hm*Vm
+    A_UCACHE,       // f64 [V] cache_entries
+    A_UCTAG,        // u32 [V] cache_entries (mode 1) or 1
+    A_CUM,          // f64 [V] max(D2m,1)
+    A_NZLIST,       // u16 [V] Hm
+    A_SIMPLEX,      // f64 [V] Hm+1
+    A_SCACHE,       // f64 [V] scache_n*scache_len   cached simplex probability vectors
+    A_SCLEN,        // u32 [V] scache_n              their lengths (0 = not computed)
+    A_KSC,          // f64 [V] S*2*Vm*4
+    A_KSCUPD,       // u8  [V] S
+    A_DIPKEYS,      // u32 [V] dip_cap
+    A_DIPFREQ,      // u32 [V] dip_cap*S
+    A_ASTATS,       // f64 [V] S*Am*12
+    A_NESTPL, A_NESTN,   // u8 [V] S
+    A_NESTST,       // f64 [V] S*2*4
+    A_SC,           // u32 [V] SC_COUNT
+    A_EDGES,        // u32 [V] NEm
+    A_COVER,        // u8  [V] Km
+    A_SOURCES,      // u32 [G] nvm
+    A_STACK,        // u32 [G] 2*(nvm+1)
+    A_BRNG,         // u32 [G] per-lane contiguous MT_PAD
+    A_SHMULT,       // u8  [G] NSHm*S
+    A_COUNT
+};
+
+struct TileDesc {
+    uint32_t S, nvm, Hm, Vm, Km, HWm, NUm, NMm, NNZm, HNm, NDm, NDVm, NEm, NSHm, Am, Bcap, D2m, Dcm, cache_mode, cache_entries, dip_cap, scache_n, scache_len,
+        scache_p, num_lanes, first_group;
+    uint64_t base;            // byte offset of this tile in the pool
+    uint64_t trace_base;      // word offset of this tile's trace block ([sweep][vertex][S][64])
+    uint64_t off[A_COUNT];    // byte offsets of the arrays from the tile base
+};
+
+struct GParams {
+    uint32_t S, seed, num_chains, burn_in, num_iterations, max_hvk, noise_seeding;
+    double rate;                // (double)(float)kmer_subsampling_rate, as bernoulli_distribution stores it
+    uint8_t gender[32];
+    const double *lut_g;        // [S][256][256]
+    const double *lut_n;        // [S][256]
+};
+
+// ---- lane view of a tile / of one vertex of the lane's group ------------------------------------------------------
+struct Tile {
+    uint8_t *base;
+    const TileDesc *d;
+    uint32_t lane;
+    template <typename T>
+    __device__ inline SPtr<T, LANES> arr(int a, size_t first = 0) const {
+        return SPtr<T, LANES>{reinterpret_cast<T *>(base + d->off[a]) + first * LANES + lane};
+    }
+};
+
+struct Vx {   // vertex context: tile + vertex index + the lane's true dimensions of that vertex
+    Tile t;
+    uint32_t v, H, V, K, nu, nm, cid;
+    __device__ inline const TileDesc &d() const { return *t.d; }
+    template <typename T>
+    __device__ inline SPtr<T, LANES> a(int arr, size_t len) const { return t.arr<T>(arr, (size_t)v * len); }
+    // inputs
+    __device__ inline uint8_t M(uint32_t k, uint32_t h) const { return a<uint8_t>(A_M, (size_t)d().Km * d().Hm)[(size_t)k * d().Hm + h]; }
+    __device__ inline uint8_t has_counts(uint32_t k) const { return a<uint8_t>(A_HASC, d().Km)[k]; }
+    __device__ inline uint8_t count(uint32_t k, uint32_t s) const { return a<uint8_t>(A_COUNTS, (size_t)d().Km * d().S)[(size_t)k * d().S + s]; }
+    __device__ inline uint8_t ic(uint32_t k, uint32_t g) const { return a<uint8_t>(A_IC, (size_t)d().Km * 2)[2 * k + g]; }
+    __device__ inline int32_t shared_idx(uint32_t k) const { return a<int32_t>(A_SHARED, d().Km)[k]; }
+    __device__ inline uint32_t kv_off(uint32_t k) const { return a<uint32_t>(A_KVOFF, d().Km + 1)[k]; }
+    __device__ inline uint16_t kv_var(uint32_t e) const { return a<uint16_t>(A_KVVAR, d().NNZm)[e]; }
+    __device__ inline bool kv_bit(uint32_t e, uint32_t h) const { return (a<uint32_t>(A_KVBITS, (size_t)d().NNZm * d().HWm)[(size_t)e * d().HWm + (h >> 5)] >> (h & 31u)) & 1u; }
+    __device__ inline uint16_t hap_allele(uint32_t h, uint32_t var) const { return a<uint16_t>(A_HAPAL, (size_t)d().Hm * d().Vm)[(size_t)h * d().Vm + var]; }
+    __device__ inline uint32_t hn_off(uint32_t h) const { return a<uint32_t>(A_HNOFF, d().Hm + 1)[h]; }
+    __device__ inline uint32_t hn_idx(uint32_t i) const { return a<uint32_t>(A_HNIDX, d().HNm)[i]; }
+    __device__ inline uint16_t var_na(uint32_t var) const { return a<uint16_t>(A_VARNA, d().Vm)[var]; }
+    __device__ inline uint8_t var_dep(uint32_t var) const { return a<uint8_t>(A_VARDEP, d().Vm)[var]; }
+    __device__ inline uint32_t allele_base(uint32_t var) const { return a<uint32_t>(A_ALBASE, d().Vm + 1)[var]; }
+    // state
+    __device__ inline uint32_t *mt(uint32_t g) const { return reinterpret_cast<uint32_t *>(t.base + d().off[A_MT]) + (((size_t)v * 2 + g) * LANES + t.lane) * MT_PAD; }
+    __device__ inline SPtr<uint32_t, LANES> sc() const { return a<uint32_t>(A_SC, SC_COUNT); }
+    __device__ inline SPtr<uint32_t, LANES> uniq() const { return a<uint32_t>(A_UNIQ, d().NUm); }
+    __device__ inline SPtr<uint32_t, LANES> multi() const { return a<uint32_t>(A_MULTI, d().NMm); }
+    __device__ inline SPtr<uint32_t, LANES> usub() const { return a<uint32_t>(A_USUB, d().NUm); }
+    __device__ inline SPtr<uint32_t, LANES> msub() const { return a<uint32_t>(A_MSUB, d().NMm); }
+    __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (size_t)d().NMm * d().S); }
+    __device__ inline SPtr<uint16_t, LANES> dip() const { return a<uint16_t>(A_DIP, 2 * d().S); }
+    __device__ inline SPtr<double, LANES> freq() const { return a<double>(A_FREQ, d().Hm); }
+    __device__ inline SPtr<uint32_t, LANES> obs() const { return a<uint32_t>(A_OBS, d().Hm); }
+    __device__ inline SPtr<uint8_t, LANES> nz() const { return a<uint8_t>(A_NZ, d().Hm); }
+    __device__ inline SPtr<uint32_t, LANES> unext() const { return a<uint32_t>(A_UNEXT, d().Hm); }
+    __device__ inline USetT<LANES> zero_set() const { return USetT<LANES>{a<uint32_t>(A_ZHDR, 4), a<uint32_t>(A_ZBKT, d().Bcap), unext()}; }
+    __device__ inline USetT<LANES> plus_set() const { return USetT<LANES>{a<uint32_t>(A_PHDR, 4), a<uint32_t>(A_PBKT, d().Bcap), unext()}; }
+    __device__ inline SPtr<uint32_t, LANES> hvcount() const { return a<uint32_t>(A_HVCOUNT, (size_t)d().Hm * d().Vm); }
+    __device__ inline SPtr<double, LANES> ucache() const { return a<double>(A_UCACHE, d().cache_entries); }
+    __device__ inline SPtr<uint32_t, LANES> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
+    __device__ inline SPtr<double, LANES> cum() const { return a<double>(A_CUM, d().D2m > 1 ? d().D2m : 1); }
+    __device__ inline SPtr<uint16_t, LANES> nzlist() const { return a<uint16_t>(A_NZLIST, d().Hm); }
+    __device__ inline SPtr<double, LANES> simplex() const { return a<double>(A_SIMPLEX, d().Hm + 1); }
+    __device__ inline SPtr<double, LANES> scache() const { return a<double>(A_SCACHE, (size_t)(d().scache_n ? d().scache_n : 1) * (d().scache_len ? d().scache_len : 1)); }
+    __device__ inline SPtr<uint32_t, LANES> sclen() const { return a<uint32_t>(A_SCLEN, d().scache_n > 1 ? d().scache_n : 1); }
+    __device__ inline SPtr<double, LANES> ksc(uint32_t s, uint32_t which, uint32_t var) const {
+        return a<double>(A_KSC, (size_t)d().S * 2 * d().Vm * 4) + (((size_t)s * 2 + which) * d().Vm + var) * 4;
+    }
+    __device__ inline SPtr<uint8_t, LANES> ksc_upd() const { return a<uint8_t>(A_KSCUPD, d().S); }
+    __device__ inline SPtr<uint32_t, LANES> dip_keys() const { return a<uint32_t>(A_DIPKEYS, d().dip_cap); }
+    __device__ inline SPtr<uint32_t, LANES> dip_freq() const { return a<uint32_t>(A_DIPFREQ, (size_t)d().dip_cap * d().S); }
+    __device__ inline SPtr<double, LANES> astats(uint32_t s, uint32_t var, uint32_t al) const {
+        return a<double>(A_ASTATS, (size_t)d().S * d().Am * 12) + ((size_t)s * d().Am + allele_base(var) + al) * 12;
+    }
+    __device__ inline SPtr<uint8_t, LANES> nest_ploidy() const { return a<uint8_t>(A_NESTPL, d().S); }
+    __device__ inline SPtr<uint8_t, LANES> nest_n() const { return a<uint8_t>(A_NESTN, d().S); }
+    __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (size_t)d().S * 8) + ((size_t)s * 2 + j) * 4; }
+    __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
+    __device__ inline SPtr<uint8_t, LANES> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
+    __device__ inline double &fnd_saved() const { return a<double>(A_FNDSAVED, 1)[0]; }
+    __device__ inline double &sparsity() const { return a<double>(A_SPARSITY, 1)[0]; }
+    __device__ inline NormalState fnd() const { return NormalState{&fnd_saved(), &sc()[SC_FND_AVAIL]}; }
+    __device__ inline SPtr<uint8_t, LANES> shared_mult() const { return t.arr<uint8_t>(A_SHMULT); }
+};
+
+__device__ inline Vx make_vx(const Tile &t, uint32_t v) {
+    Vx x;
+    x.t = t;
+    x.v = v;
+    SPtr<uint32_t, LANES> dm = t.arr<uint32_t>(A_VDIMS, (size_t)v * 8);
+    x.H = dm[0];
+    x.V = dm[1];
+    x.K = dm[2];
+    x.nu = dm[3];
+    x.nm = dm[4];
+    x.cid = dm[7];
+    return x;
+}
+__device__ inline uint32_t vx_nd(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, (size_t)c.v * 8)[5]; }
+__device__ inline uint32_t vx_ne(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, (size_t)c.v * 8)[6]; }
+
+// ---- Utils::logAddition (Utils.hpp:105-124) ----
+__device__ inline double log_addition(double a, double b) {
+    if (a < b) return b + log1p(exp(a - b));
+    return a + log1p(exp(b - a));
+}
+
+// ---- KmerStats (KmerStats.cpp:51-63): ks = {count, fraction, mean, M2} ----
+template <typename P>
+__device__ inline void ks_reset(P ks) { ks[0] = 0; ks[1] = 0; ks[2] = 0; ks[3] = 0; }
+template <typename P>
+__device__ inline void ks_add(P ks, double value) {
+    const double count = ks[0] + 1.0;
+    ks[0] = count;
+    // !doubleCompare(value, 0): value == 0 <=> equal (Utils.hpp:81-87 with b = 0)
+    double fr = ks[1];
+    fr += ((value == 0.0 ? 0.0 : 1.0) - fr) / count;
+    ks[1] = fr;
+    double mean = ks[2];
+    const double delta = value - mean;
+    mean += delta / count;
+    ks[2] = mean;
+    ks[3] += delta * (value - mean);
+}
+// AlleleKmerStats::addKmerStats (KmerStats.cpp:114-121): cell = [3][4]
+template <typename P, typename Q>
+__device__ inline void aks_add(P cell, Q ks) {
+    const double cnt = ks[0];
+    ks_add(cell, cnt);                        // count_stats    <- (getCount(), true)
+    if (cnt != 0.0) {
+        ks_add(cell + 4, (double)ks[1]);      // fraction_stats <- getFraction()  (skipped when count == 0)
+        ks_add(cell + 8, (double)ks[2]);      // mean_stats     <- getMean()
+    }
+}
+
+__device__ inline double count_log_prob(const GParams &P, uint32_t s, uint8_t mult, uint8_t count) {   // CountDistribution.cpp:255-265
+    if (mult == 0) return P.lut_n[s * 256u + count];
+    return P.lut_g[((size_t)s * 256u + mult) * 256u + count];
+}
+
+// ---- VariantClusterHaplotypes multiplicity getters (VariantClusterHaplotypes.cpp:45-108), uchar arithmetic ----
+__device__ inline uint8_t dip_mult(const Vx &c, uint32_t k, uint16_t h1, uint16_t h2) {
+    uint8_t m = 0;
+    if (h1 != NOHAP) m = (uint8_t)(m + c.M(k, h1));
+    if (h2 != NOHAP) m = (uint8_t)(m + c.M(k, h2));
+    return m;
+}
+__device__ inline uint8_t unique_mult(const Vx &c, uint32_t k, uint16_t h1, uint16_t h2, uint8_t gender) {
+    uint8_t m = dip_mult(c, k, h1, h2);
+    if (c.has_counts(k)) m = (uint8_t)(m + c.ic(k, gender));
+    return m;
+}
+__device__ inline uint8_t multi_mult(const Vx &c, const GParams &P, uint32_t k, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t s) {
+    const uint8_t icm = c.ic(k, P.gender[s]);
+    if (c.count(k, s) == 0) return (uint8_t)(dip_mult(c, k, h1, h2) + icm);
+    const uint8_t shared = c.shared_mult()[(size_t)c.shared_idx(k) * P.S + s];
+    return (uint8_t)(shared - dip_mult(c, k, p1, p2) + dip_mult(c, k, h1, h2) + icm);
+}
+
+// ---- FrequencyDistribution::reset / SparseFrequencyDistribution::reset (FrequencyDistribution.cpp:49-54,104-115) ----
+__device__ inline void freq_reset(const Vx &c) {
+    const double f = 1 / (double)c.H;
+    SPtr<uint32_t, LANES> obs = c.obs();
+    SPtr<double, LANES> freq = c.freq();
+    SPtr<uint8_t, LANES> nz = c.nz();
+    for (uint32_t h = 0; h < c.H; ++h) {
+        obs[h] = 0;
+        freq[h] = f;
+        nz[h] = 1;
+    }
+    if (c.sc()[SC_IS_SPARSE]) {
+        uset_clear(c.plus_set());
+        USetT<LANES> z = c.zero_set();
+        uset_clear(z);
+        for (uint32_t h = 0; h < c.H; ++h) uset_insert(z, h);
+    }
+}
+
+// ---- SparsityEstimator::estimateMinimumColumnCover (SparsityEstimator.cpp:41-87), unweighted ----
+// returns the cover size; uses `rng` (freshly seeded by the caller), cover_rows, obs (column sums), nzlist
+__device__ inline uint32_t sparsity_cover(const Vx &c, uint32_t *rng) {
+    SPtr<uint8_t, LANES> rows = c.cover_rows();
+    SPtr<uint32_t, LANES> obs = c.obs();
+    SPtr<uint16_t, LANES> nzl = c.nzlist();
+    uint32_t remaining = 0;
+    for (uint32_t k = 0; k < c.K; ++k) {
+        const uint8_t r = c.has_counts(k) ? 1 : 0;
+        rows[k] = r;
+        remaining += r;
+    }
+    uint32_t cover = 0;
+    while (remaining > 0) {
+        for (uint32_t h = 0; h < c.H; ++h) obs[h] = 0;
+        for (uint32_t k = 0; k < c.K; ++k)
+            if (rows[k])
+                for (uint32_t h = 0; h < c.H; ++h) obs[h] += c.M(k, h);
+        uint32_t best = 0;
+        for (uint32_t h = 0; h < c.H; ++h) {
+            const uint32_t o = obs[h];
+            best = o > best ? o : best;
+        }
+        if (best == 0) break;   // the reference asserts max_row_cover > 0
+        uint32_t m = 0;
+        for (uint32_t h = 0; h < c.H; ++h)
+            if (obs[h] == best) nzl[m++] = (uint16_t)h;
+        // DiscreteSampler with outcomes 1,1,...: cum = 1..m; sample = upper_bound(cum, canonical * m) (DiscreteSampler.cpp:61-87)
+        const double x = rng_canonical(rng) * (double)m;
+        uint32_t pick = 0;
+        if (m > 1) {
+            while (pick < m && !((double)(pick + 1) > x)) ++pick;
+            if (pick >= m) pick = m - 1;
+        }
+        const uint32_t col = nzl[pick];
+        ++cover;
+        for (uint32_t k = 0; k < c.K; ++k)
+            if (rows[k] && c.M(k, col) != 0) {
+                rows[k] = 0;
+                --remaining;
+            }
+    }
+    return cover;
+}
+
+// ---- VariantClusterGenotyper ctor (VariantClusterGenotyper.cpp:59-106) ----
+__device__ inline void genotyper_construct(const Vx &c, const GParams &P, uint32_t prng_seed) {
+    const TileDesc &d = c.d();
+    mt_seed(c.mt(0), prng_seed);
+    SPtr<uint32_t, LANES> sc = c.sc();
+    for (uint32_t i = 0; i < SC_COUNT; ++i) sc[i] = 0;
+    // a (re)built genotyper starts from the k-mer index lists in first-seen order (they are shuffled in place per chain)
+    {
+        SPtr<uint32_t, LANES> u0 = c.a<uint32_t>(A_UNIQ0, d.NUm), u = c.uniq(), m0 = c.a<uint32_t>(A_MULTI0, d.NMm), m = c.multi();
+        for (uint32_t i = 0; i < c.nu; ++i) u[i] = u0[i];
+        for (uint32_t i = 0; i < c.nm; ++i) m[i] = m0[i];
+    }
+    SPtr<uint16_t, LANES> dip = c.dip();
+    SPtr<uint8_t, LANES> upd = c.ksc_upd();
+    for (uint32_t s = 0; s < P.S; ++s) {
+        dip[2 * s] = NOHAP;
+        dip[2 * s + 1] = NOHAP;
+        upd[s] = 1;
+    }
+    {
+        const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, (size_t)c.v * 2)[0];
+        SPtr<double, LANES> as = c.a<double>(A_ASTATS, (size_t)d.S * d.Am * 12);
+        for (size_t s = 0; s < P.S; ++s)
+            for (size_t i = 0; i < (size_t)A * 12; ++i) as[s * d.Am * 12 + i] = 0;
+        SPtr<double, LANES> k = c.a<double>(A_KSC, (size_t)d.S * 2 * d.Vm * 4);
+        for (size_t i = 0; i < (size_t)P.S * 2 * d.Vm * 4; ++i) k[i] = 0;
+        SPtr<uint32_t, LANES> dk = c.dip_keys(), df = c.dip_freq();
+        for (uint32_t i = 0; i < d.dip_cap; ++i) dk[i] = 0;
+        for (size_t i = 0; i < (size_t)d.dip_cap * P.S; ++i) df[i] = 0;
+        SPtr<uint32_t, LANES> sl = c.sclen();
+        for (uint32_t i = 0; i < d.scache_n; ++i) sl[i] = 0;
+    }
+    // SparsityEstimator(prng_seed), then (Sparse)FrequencyDistribution(.., prng_seed) with a fresh generator
+    uint32_t *fr = c.mt(1);
+    mt_seed(fr, prng_seed);
+    const uint32_t cover = sparsity_cover(c, fr);
+    mt_seed(fr, prng_seed);
+    c.fnd_saved() = 0;
+    sc[SC_FND_AVAIL] = 0;
+    sc[SC_IS_SPARSE] = cover > 0 ? 1u : 0u;   // HaplotypeFrequencyDistribution.cpp:79-89
+    if (cover > 0) {
+        const double sp = (double)cover / (double)c.H;
+        const double cap = 1 - BT_DBL_EPS * 100;
+        c.sparsity() = sp < cap ? sp : cap;    // FrequencyDistribution.cpp:98
+        uset_init(c.zero_set());
+        uset_init(c.plus_set());
+    }
+    freq_reset(c);
+    sc[SC_CONSTRUCTED] = 1;
+}
+
+__device__ inline void cache_clear(const Vx &c, const GParams &P) {   // VariantClusterGenotyper::clearCache (:131-138)
+    const TileDesc &d = c.d();
+    if (d.cache_mode == 0) {
+        SPtr<double, LANES> uc = c.ucache();
+        const uint32_t Dc = c.H * (c.H + 1) / 2 + c.H;
+        for (uint32_t s = 0; s < P.S; ++s)
+            for (uint32_t i = 0; i < Dc; ++i) uc[(size_t)s * d.Dcm + i] = __longlong_as_double(0x7ff8000000000000LL);
+    } else if (d.cache_mode == 1) {
+        SPtr<uint32_t, LANES> tg = c.uctag();
+        for (uint32_t i = 0; i < d.cache_entries; ++i) tg[i] = 0;
+    }
+}
+
+// ---- VariantClusterHaplotypes::sampleKmerSubset (+ isMaxHaplotypeVariantKmer) (VariantClusterHaplotypes.cpp:110-177) ----
+__device__ inline bool is_max_hv_kmer(const Vx &c, uint32_t k, uint32_t maxk) {
+    bool is_max = true;
+    SPtr<uint32_t, LANES> hv = c.hvcount();
+    const uint32_t Vm = c.d().Vm;
+    for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
+        const uint32_t var = c.kv_var(e);
+        for (uint32_t h = 0; h < c.H; ++h) {
+            if (c.kv_bit(e, h)) {
+                const uint32_t cnt = hv[(size_t)h * Vm + var];
+                if (cnt < maxk) {
+                    hv[(size_t)h * Vm + var] = cnt + 1;
+                    is_max = false;
+                }
+            }
+        }
+    }
+    return is_max;
+}
+__device__ inline void sample_kmer_subset(const Vx &c, const GParams &P) {
+    const uint32_t Vm = c.d().Vm;
+    SPtr<uint32_t, LANES> hv = c.hvcount();
+    for (uint32_t h = 0; h < c.H; ++h)
+        for (uint32_t v = 0; v < c.V; ++v) hv[(size_t)h * Vm + v] = 0;
+    uint32_t nsu = 0, nsm = 0;
+    uint32_t *rng = c.mt(0);
+    SPtr<uint32_t, LANES> uniq = c.uniq(), usub = c.usub(), multi = c.multi(), msub = c.msub();
+    rng_shuffle_u32(rng, uniq, c.nu);
+    for (uint32_t i = 0; i < c.nu; ++i) {
+        const uint32_t k = uniq[i];
+        if (rng_bernoulli(rng, P.rate))
+            if (!is_max_hv_kmer(c, k, P.max_hvk)) usub[nsu++] = k;
+    }
+    rng_shuffle_u32(rng, multi, c.nm);
+    for (uint32_t i = 0; i < c.nm; ++i) {
+        const uint32_t k = multi[i];
+        if (rng_bernoulli(rng, P.rate))
+            if (!is_max_hv_kmer(c, k, P.max_hvk)) msub[nsm++] = k;
+    }
+    SPtr<uint32_t, LANES> sc = c.sc();
+    sc[SC_NSUB_U] = nsu;
+    sc[SC_NSUB_M] = nsm;
+    SPtr<uint8_t, LANES> smm = c.smm();
+    for (size_t i = 0; i < (size_t)nsm * P.S; ++i) smm[i] = 0;
+    SPtr<uint8_t, LANES> upd = c.ksc_upd();
+    for (uint32_t s = 0; s < P.S; ++s) upd[s] = 1;
+}
+
+// ---- VariantClusterGenotyper::reset (VariantClusterGenotyper.cpp:113-129) ----
+__device__ inline void genotyper_reset(const Vx &c, const GParams &P) {
+    c.sc()[SC_USE_MULTI] = 0;
+    sample_kmer_subset(c, P);
+    cache_clear(c, P);
+    freq_reset(c);   // HaplotypeFrequencyDistribution::reset (counts are 0 here, as the reference asserts)
+}
+
+__device__ inline uint32_t dip_index(const Vx &c, uint16_t h1, uint16_t h2) {
+    if (h2 == NOHAP) return c.H * (c.H + 1) / 2 + h1;
+    return (uint32_t)h1 * c.H - ((uint32_t)h1 * ((uint32_t)h1 - 1u)) / 2u + ((uint32_t)h2 - (uint32_t)h1);
+}
+
+// unique part of calcDiplotypeLogProb with its per-(sample, diplotype) cache (VariantClusterGenotyper.cpp:619-643).
+// The cached value is a pure function of (sample, diplotype, k-mer subset), so a dense table, a direct-mapped table
+// or no table at all give bit-identical sums (same summation order).
+__device__ inline double unique_log_prob(const Vx &c, const GParams &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t nsub_u) {
+    const TileDesc &d = c.d();
+    const uint32_t idx = dip_index(c, h1, h2);
+    uint32_t slot = 0;
+    SPtr<double, LANES> uc = c.ucache();
+    if (d.cache_mode == 0) {
+        const double v = uc[(size_t)s * d.Dcm + idx];
+        if (v == v) return v;
+    } else if (d.cache_mode == 1) {
+        const uint32_t key = s * d.Dcm + idx + 1u;
+        slot = (key * 2654435761u) & (d.cache_entries - 1u);
+        if (c.uctag()[slot] == key) return uc[slot];
+    }
+    double acc = 0;
+    const uint8_t gender = P.gender[s];
+    SPtr<uint32_t, LANES> usub = c.usub();
+    for (uint32_t i = 0; i < nsub_u; ++i) {
+        const uint32_t k = usub[i];
+        const uint8_t m = unique_mult(c, k, h1, h2, gender);
+        const uint8_t cnt = c.has_counts(k) ? c.count(k, s) : 0;
+        acc += count_log_prob(P, s, m, cnt);
+    }
+    if (d.cache_mode == 0) uc[(size_t)s * d.Dcm + idx] = acc;
+    else if (d.cache_mode == 1) {
+        c.uctag()[slot] = s * d.Dcm + idx + 1u;
+        uc[slot] = acc;
+    }
+    return acc;
+}
+
+// multicluster part (VariantClusterGenotyper.cpp:647-661).  The reference keeps a second cache that it patches
+// incrementally (:569-595); the patched value equals this direct sum up to floating-point re-association.
+__device__ inline double multi_log_prob(const Vx &c, const GParams &P, uint32_t s, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t nsub_m) {
+    double acc = 0;
+    SPtr<uint32_t, LANES> msub = c.msub();
+    for (uint32_t i = 0; i < nsub_m; ++i) {
+        const uint32_t k = msub[i];
+        const uint8_t m = multi_mult(c, P, k, h1, h2, p1, p2, s);
+        acc += count_log_prob(P, s, m, c.count(k, s));
+    }
+    return acc;
+}
+
+// ---- HaplotypeFrequencyDistribution::incrementCount (HaplotypeFrequencyDistribution.cpp:113-125) ----
+__device__ inline void hfd_increment(const Vx &c, uint16_t h, bool is_sparse, uint32_t &hap_count) {
+    if (h == NOHAP) return;   // num_missing_count is only read by an assert in the reference
+    hap_count += 1;
+    SPtr<uint32_t, LANES> obs = c.obs();
+    const uint32_t o = obs[h];
+    if (is_sparse && o == 0) {   // SparseFrequencyDistribution::incrementObservationCount (:198-207)
+        // the reference inserts into plus, then erases from zero; the sets share their `next` words here, so leave
+        // the zero list first (the resulting containers are identical)
+        uset_erase(c.zero_set(), h);
+        uset_insert(c.plus_set(), h);
+    }
+    obs[h] = o + 1;
+}
+
+// ---- diplotype_sampling_frequencies (VariantClusterGenotyper.cpp:692-696) as an open-addressing table ----
+__device__ inline void dip_table_add(const Vx &c, const GParams &P, uint16_t h1, uint16_t h2, uint32_t s) {
+    const uint32_t key = ((uint32_t)h1 | ((uint32_t)h2 << 16));
+    // stored tag: key + 1 (0 = empty slot); the null diplotype (NOHAP, NOHAP) would wrap to 0 and is stored as 0xFFFFFFFF,
+    // which no other key + 1 can equal because haplotype indices are < 0xFFFE
+    const uint32_t want = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : key + 1u;
+    const uint32_t cap = c.d().dip_cap, mask = cap - 1u;
+    SPtr<uint32_t, LANES> keys = c.dip_keys(), freq = c.dip_freq();
+    uint32_t slot = (key * 2654435761u) & mask;
+    for (uint32_t probes = 0; probes < cap; ++probes) {
+        const uint32_t tag = keys[slot];
+        if (tag == 0) {
+            keys[slot] = want;
+            c.sc()[SC_DIP_ENTRIES] += 1;
+            freq[(size_t)slot * P.S + s] += 1;
+            return;
+        }
+        if (tag == want) {
+            freq[(size_t)slot * P.S + s] += 1;
+            return;
+        }
+        slot = (slot + 1u) & mask;
+    }
+    c.sc()[SC_DIP_OVERFLOW] = 1;
+}
+
+// ---- VariantClusterHaplotypes::updateMulticlusterKmerMultiplicities (VariantClusterHaplotypes.cpp:197-233) ----
+__device__ inline void update_multicluster_multiplicities(const Vx &c, const GParams &P, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t s, uint32_t nsub_m) {
+    if (h1 != p1 || h2 != p2) c.ksc_upd()[s] = 1;
+    if (c.nm == 0) return;
+    SPtr<uint8_t, LANES> shm = c.shared_mult();
+    if (h1 != p1 || h2 != p2) {
+        SPtr<uint32_t, LANES> multi = c.multi();
+        for (uint32_t i = 0; i < c.nm; ++i) {
+            const uint32_t k = multi[i];
+            const uint8_t cur = dip_mult(c, k, h1, h2), pre = dip_mult(c, k, p1, p2);
+            if (cur != pre) {
+                const size_t at = (size_t)c.shared_idx(k) * P.S + s;
+                uint8_t m = shm[at];
+                m = (uint8_t)(m - pre);
+                m = (uint8_t)(m + cur);
+                shm[at] = m;
+            }
+        }
+    }
+    SPtr<uint32_t, LANES> msub = c.msub();
+    SPtr<uint8_t, LANES> smm = c.smm();
+    for (uint32_t sub = 0; sub < nsub_m; ++sub) {
+        const uint32_t k = msub[sub];
+        const uint8_t shared = shm[(size_t)c.shared_idx(k) * P.S + s];
+        if (dip_mult(c, k, h1, h2) > 0 && c.count(k, s) > 0 && shared != smm[(size_t)sub * P.S + s]) c.ksc_upd()[s] = 1;
+        smm[(size_t)sub * P.S + s] = shared;
+    }
+}
+
+// ---- updateKmerStatsCache / updateAlleleKmerStats (VariantClusterHaplotypes.cpp:235-372) ----
+__device__ inline void update_kmer_stats_cache(const Vx &c, const GParams &P, uint32_t k, uint16_t h1, uint16_t h2, uint32_t s, uint8_t mult) {
+    double kmer_count = 0;
+    if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
+    for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
+        const uint32_t var = c.kv_var(e);
+        if (c.kv_bit(e, h1)) ks_add(c.ksc(s, 0, var), kmer_count);
+        if (h2 != NOHAP && c.kv_bit(e, h2)) ks_add(c.ksc(s, 1, var), kmer_count);
+    }
+}
+__device__ inline bool is_missing(const Vx &c, uint32_t var, uint32_t a) { return c.var_dep(var) && a == (uint32_t)c.var_na(var) - 1u; }
+
+__device__ inline void add_haplotype_kmer_stats(const Vx &c, uint32_t s, uint32_t which, uint16_t h) {   // :332-358
+    uint32_t last_non_missing = 0xFFFFFFFFu;
+    for (uint32_t var = 0; var < c.V; ++var) {
+        const uint32_t a = c.hap_allele(h, var);
+        if (is_missing(c, var, a)) {
+            if (last_non_missing != 0xFFFFFFFFu) aks_add(c.astats(s, var, a), c.ksc(s, which, last_non_missing));
+        } else {
+            aks_add(c.astats(s, var, a), c.ksc(s, which, var));
+            last_non_missing = var;
+        }
+    }
+}
+
+__device__ inline void update_allele_kmer_stats(const Vx &c, const GParams &P, uint32_t nsub_u, uint32_t nsub_m) {   // :235-298
+    SPtr<uint16_t, LANES> dip = c.dip();
+    SPtr<uint8_t, LANES> upd = c.ksc_upd();
+    for (uint32_t s = 0; s < P.S; ++s) {
+        const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
+        if (upd[s]) {
+            upd[s] = 0;
+            for (uint32_t var = 0; var < c.V; ++var) {
+                ks_reset(c.ksc(s, 0, var));
+                ks_reset(c.ksc(s, 1, var));
+            }
+            if (h1 != NOHAP) {
+                SPtr<uint32_t, LANES> usub = c.usub(), msub = c.msub();
+                for (uint32_t i = 0; i < nsub_u; ++i) {
+                    const uint32_t k = usub[i];
+                    if (dip_mult(c, k, h1, h2) > 0) update_kmer_stats_cache(c, P, k, h1, h2, s, unique_mult(c, k, h1, h2, P.gender[s]));
+                }
+                for (uint32_t i = 0; i < nsub_m; ++i) {
+                    const uint32_t k = msub[i];
+                    if (dip_mult(c, k, h1, h2) > 0) update_kmer_stats_cache(c, P, k, h1, h2, s, multi_mult(c, P, k, h1, h2, h1, h2, s));
+                }
+            }
+        }
+        if (h1 != NOHAP) add_haplotype_kmer_stats(c, s, 0, h1);
+        if (h2 != NOHAP) add_haplotype_kmer_stats(c, s, 1, h2);
+        const uint32_t nn = c.nest_n()[s];
+        for (uint32_t j = 0; j < nn; ++j)   // addNestedHaplotypeKmerStats (:360-372)
+            for (uint32_t var = 0; var < c.V; ++var) aks_add(c.astats(s, var, (uint32_t)c.var_na(var) - 1u), c.nest_stats(s, j));
+    }
+}
+
+// ---- sampleDiplotypes / sampleDiplotype / calcDiplotypeLogProb (VariantClusterGenotyper.cpp:597-755) ----
+__device__ inline void sample_diplotypes(const Vx &c, const GParams &P, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+    SPtr<uint32_t, LANES> sc = c.sc();
+    const uint32_t nsub_u = sc[SC_NSUB_U], nsub_m = sc[SC_NSUB_M];
+    const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
+    uint32_t hap_count = sc[SC_HAP_COUNT];
+    SPtr<uint16_t, LANES> nzl = c.nzlist();
+    SPtr<double, LANES> freq = c.freq(), cum = c.cum();
+    SPtr<uint16_t, LANES> dip = c.dip();
+    uint32_t nnz = 0;
+    {
+        SPtr<uint8_t, LANES> nz = c.nz();
+        for (uint32_t h = 0; h < c.H; ++h)
+            if (nz[h]) nzl[nnz++] = (uint16_t)h;
+    }
+    for (uint32_t s = 0; s < P.S; ++s) {
+        const uint16_t p1 = dip[2 * s], p2 = dip[2 * s + 1];
+        const uint8_t ploidy = c.nest_ploidy()[s];
+        // candidates in the reference's order; cumulative log-sum-exp exactly as LogDiscreteSampler::addOutcome
+        uint32_t ncand = 0;
+        double run = 0;
+        if (ploidy == 2) {
+            for (uint32_t a = 0; a < nnz; ++a) {
+                const uint16_t ha = nzl[a];
+                const double lfa = log(freq[ha]);
+                for (uint32_t b = a; b < nnz; ++b) {
+                    const uint16_t hb = nzl[b];
+                    double lp = 0;
+                    if (a == b) lp += 2 * lfa;
+                    else lp += BT_LN2 + lfa + log(freq[hb]);
+                    lp += unique_log_prob(c, P, s, ha, hb, nsub_u);
+                    if (use_multi) lp += multi_log_prob(c, P, s, ha, hb, p1, p2, nsub_m);
+                    run = ncand == 0 ? lp : log_addition(lp, run);
+                    cum[ncand++] = run;
+                }
+            }
+        } else if (ploidy == 1) {
+            for (uint32_t a = 0; a < nnz; ++a) {
+                const uint16_t ha = nzl[a];
+                double lp = 0;
+                lp += log(freq[ha]);
+                lp += unique_log_prob(c, P, s, ha, NOHAP, nsub_u);
+                if (use_multi) lp += multi_log_prob(c, P, s, ha, NOHAP, p1, p2, nsub_m);
+                run = ncand == 0 ? lp : log_addition(lp, run);
+                cum[ncand++] = run;
+            }
+        } else {
+            ncand = 1;
+            run = 0;
+        }
+        // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome
+        const double u = log(rng_canonical(c.mt(0))) + run;
+        uint32_t pick = 0;
+        if (ncand > 1) {
+            uint32_t lo = 0, hi = ncand;   // upper_bound: first index with cum > u
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (u < cum[mid]) hi = mid;
+                else lo = mid + 1;
+            }
+            pick = lo < ncand ? lo : ncand - 1;
+        }
+        uint16_t h1 = NOHAP, h2 = NOHAP;
+        if (ploidy == 2) {
+            uint32_t a = 0, rem = pick;   // invert the (a, b >= a) enumeration
+            while (rem >= nnz - a) {
+                rem -= nnz - a;
+                ++a;
+            }
+            h1 = nzl[a];
+            h2 = nzl[a + rem];
+        } else if (ploidy == 1) {
+            h1 = nzl[pick];
+        }
+        dip[2 * s] = h1;
+        dip[2 * s + 1] = h2;
+        hfd_increment(c, h1, is_sparse, hap_count);
+        hfd_increment(c, h2, is_sparse, hap_count);
+        update_multicluster_multiplicities(c, P, h1, h2, p1, p2, s, nsub_m);
+        if (tracing) trace_row[s] = (uint32_t)h1 | ((uint32_t)h2 << 16);
+        if (collect) dip_table_add(c, P, h1, h2, s);
+    }
+    sc[SC_HAP_COUNT] = hap_count;
+    if (collect) update_allele_kmer_stats(c, P, nsub_u, nsub_m);
+    sc[SC_USE_MULTI] = nsub_m != 0 ? 1u : 0u;
+}
+
+// ---- SparseFrequencyDistribution::updateCachedSimplexProbVector (FrequencyDistribution.cpp:143-196) -> out[], returns length ----
+template <typename Q>
+__device__ inline uint32_t simplex_prob_vector(const Vx &c, Q out, uint32_t total_obs, uint32_t plus_size) {
+    const uint32_t Hn = c.H;
+    const double sparsity = c.sparsity();
+    const double lsp = log(sparsity), l1sp = log(1 - sparsity);
+    double prob_z_log = plus_size * lsp + (Hn - plus_size) * l1sp;
+    double prob_t_log = lgamma(plus_size * 1.0) - lgamma(total_obs + plus_size * 1.0);
+    double prob_eq_z_log = 0.0 + prob_z_log + prob_t_log;
+    double row_sum = prob_eq_z_log;
+    uint32_t n = 0;
+    out[n++] = row_sum;
+    double prev = row_sum;
+    for (uint32_t j = plus_size + 1; j < Hn + 1; ++j) {
+        const double cardinal = lgamma((double)(Hn - plus_size + 1)) - (lgamma((double)(j - plus_size + 1)) + lgamma((double)(Hn - j + 1)));
+        prob_z_log = j * lsp + (Hn - j) * l1sp;
+        prob_t_log = lgamma(j * 1.0) - lgamma(total_obs + j * 1.0);
+        prob_eq_z_log = cardinal + prob_z_log + prob_t_log;
+        row_sum += log(1 + exp(prob_eq_z_log - row_sum));
+        out[n++] = row_sum;
+        const double a = row_sum, b = prev;
+        const double mn = a < b ? a : b;
+        prev = row_sum;
+        if (a == b || fabs(a - b) < fabs(mn) * BT_DBL_EPS * 100) break;   // Utils::doubleCompare
+    }
+    for (uint32_t i = 0; i < n; ++i) out[i] = exp(out[i] - row_sum);
+    return n;
+}
+
+// ---- sampleHaplotypeFrequencies (VariantClusterGenotyper.cpp:781-785 -> HaplotypeFrequencyDistribution.cpp:127-138
+//      -> FrequencyDistribution.cpp:75-93 / 209-303) ----
+__device__ inline void sample_haplotype_frequencies(const Vx &c) {
+    const TileDesc &d = c.d();
+    SPtr<uint32_t, LANES> sc = c.sc();
+    const uint32_t n_obs = sc[SC_HAP_COUNT];
+    if (n_obs > 0) {
+        uint32_t *rng = c.mt(1);
+        const NormalState nd = c.fnd();
+        SPtr<uint32_t, LANES> obs = c.obs();
+        SPtr<double, LANES> freq = c.freq();
+        SPtr<uint8_t, LANES> nz = c.nz();
+        if (!sc[SC_IS_SPARSE]) {
+            double norm = 0;
+            for (uint32_t h = 0; h < c.H; ++h) {
+                const double f = rng_gamma(rng, nd, (double)(obs[h] + 1u), 1.0);
+                freq[h] = f;
+                norm += f;
+                obs[h] = 0;
+            }
+            for (uint32_t h = 0; h < c.H; ++h) freq[h] /= norm;
+        } else {
+            USetT<LANES> plus = c.plus_set(), zero = c.zero_set();
+            SPtr<uint32_t, LANES> unext = c.unext();
+            const uint32_t plus_size = uset_size(plus);
+            // cached_simplex_prob_vectors[sum_observation_counts][|plus| - 1] (FrequencyDistribution.cpp:211-229): the vector is a pure
+            // function of (n_obs, |plus|), so caching it or not is invisible; cached when the tile reserved room for it
+            uint32_t len;
+            SPtr<double, LANES> vec = c.simplex();
+            if (d.scache_n && n_obs <= 2 * d.S && plus_size <= d.scache_p) {
+                const uint32_t ci = (n_obs - 1) * d.scache_p + (plus_size - 1);
+                vec = c.scache() + (size_t)ci * d.scache_len;
+                len = c.sclen()[ci];
+                if (len == 0) {
+                    len = simplex_prob_vector(c, vec, n_obs, plus_size);
+                    c.sclen()[ci] = len;
+                }
+            } else
+                len = simplex_prob_vector(c, vec, n_obs, plus_size);
+            const double u = rng_canonical(rng);
+            uint32_t ub = 0;
+            while (ub < len && !(u < vec[ub])) ++ub;   // upper_bound over a non-decreasing vector
+            const uint32_t simplex_size = ub + plus_size;
+            double norm = 0;
+            for (uint32_t e = uset_begin(plus); e != US_NONE; e = unext[e]) {
+                const double f = rng_gamma(rng, nd, (double)obs[e] + 1.0, 1.0);
+                freq[e] = f;
+                norm += f;
+                nz[e] = 1;
+            }
+            while (uset_size(plus) < simplex_size) {
+                const uint32_t pos = rng_uniform_int(rng, uset_size(zero));   // uniform_int(0, |zero| - 1)
+                uint32_t e = uset_begin(zero);
+                for (uint32_t i = 0; i < pos; ++i) e = unext[e];
+                const double f = rng_gamma(rng, nd, 1.0, 1.0);
+                freq[e] = f;
+                norm += f;
+                nz[e] = 1;
+                // the two sets share the `next` words: leave the zero list before entering the plus list
+                uset_erase(zero, e);
+                uset_insert(plus, e);
+            }
+            for (uint32_t e = uset_begin(zero); e != US_NONE; e = unext[e]) {
+                freq[e] = 0;
+                nz[e] = 0;
+                obs[e] = 0;
+            }
+            // "for p in plus: freq /= norm; zero.insert(p); obs = 0" then plus.clear(): record the plus iteration order
+            // first (shared `next` words), clear plus, then insert into zero in that order — same final containers
+            SPtr<uint16_t, LANES> nzl = c.nzlist();
+            uint32_t np = 0;
+            for (uint32_t e = uset_begin(plus); e != US_NONE; e = unext[e]) nzl[np++] = (uint16_t)e;
+            uset_clear(plus);
+            for (uint32_t i = 0; i < np; ++i) {
+                const uint32_t e = nzl[i];
+                freq[e] /= norm;
+                uset_insert(zero, e);
+                obs[e] = 0;
+            }
+        }
+    }
+    sc[SC_HAP_COUNT] = 0;
+}
+
+}  // namespace bt

@@ -25,6 +25,16 @@ namespace bt {
 
 #define BT_HD __host__ __device__ inline
 
+// Pointer with an element stride: element i lives at p[i * STRIDE].  STRIDE = 1 is an ordinary array; STRIDE = 64 is the
+// lane-interleaved layout of the Gibbs tiles (element i of all 64 lanes of a wavefront adjacent in memory, so a wave-uniform
+// index is one coalesced transaction).
+template <typename T, unsigned STRIDE>
+struct SPtr {
+    T *p;
+    BT_HD T &operator[](size_t i) const { return p[i * STRIDE]; }
+    BT_HD SPtr<T, STRIDE> operator+(size_t i) const { return SPtr<T, STRIDE>{p + i * STRIDE}; }
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // mt19937: st[0..623] state words, st[624] position
 // ------------------------------------------------------------------------------------------------------------
@@ -37,32 +47,23 @@ BT_HD void mt_seed(uint32_t *st, uint32_t seed) {
         x = 1812433253u * (x ^ (x >> 30)) + i;
         st[i] = x;
     }
-    st[MT_N] = MT_N;
+    st[MT_N] = 0;   // position of the next word to generate
 }
 
-BT_HD void mt_refill(uint32_t *st) {
-    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
-    for (unsigned k = 0; k < MT_N - MT_M; ++k) {
-        uint32_t y = (st[k] & UPPER) | (st[k + 1] & LOWER);
-        st[k] = st[k + MT_M] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
-    }
-    for (unsigned k = MT_N - MT_M; k < MT_N - 1; ++k) {
-        uint32_t y = (st[k] & UPPER) | (st[k + 1] & LOWER);
-        st[k] = st[k + MT_M - MT_N] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
-    }
-    uint32_t y = (st[MT_N - 1] & UPPER) | (st[0] & LOWER);
-    st[MT_N - 1] = st[MT_M - 1] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
-    st[MT_N] = 0;
-}
-
+// One output word.  The textbook generator regenerates all 624 words at once and then reads them out; here word p is
+// regenerated in place right before it is read.  The recurrence x[k+624] = x[k+397] ^ twist(x[k], x[k+1]) touches, at
+// position p, only words that the block form has in the same old/new state (p+1 is still old, p+397 mod 624 is old for
+// p < 227 and already new afterwards), so the output stream is identical — and no lane ever runs a 624-step refill loop
+// while its wavefront neighbours wait.
 BT_HD uint32_t mt_next(uint32_t *st) {
-    uint32_t p = st[MT_N];
-    if (p >= MT_N) {
-        mt_refill(st);
-        p = 0;
-    }
-    uint32_t z = st[p];
-    st[MT_N] = p + 1;
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
+    const uint32_t p = st[MT_N];
+    const uint32_t p1 = p + 1 == MT_N ? 0 : p + 1;
+    const uint32_t pm = p + MT_M >= MT_N ? p + MT_M - MT_N : p + MT_M;
+    const uint32_t y = (st[p] & UPPER) | (st[p1] & LOWER);
+    uint32_t z = st[pm] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
+    st[p] = z;
+    st[MT_N] = p1;
     z ^= (z >> 11);
     z ^= (z << 7) & 0x9d2c5680u;
     z ^= (z << 15) & 0xefc60000u;
@@ -96,7 +97,8 @@ BT_HD uint32_t rng_uniform_int(uint32_t *st, uint32_t range) {
 BT_HD bool rng_bernoulli(uint32_t *st, double p) { return rng_canonical(st) < p; }
 
 // std::shuffle over a uint32 array in caller memory
-BT_HD void rng_shuffle_u32(uint32_t *st, uint32_t *a, uint32_t n) {
+template <typename Arr>
+BT_HD void rng_shuffle_u32(uint32_t *st, Arr a, uint32_t n) {
     if (n == 0) return;
     const uint64_t urngrange = 0xFFFFFFFFull;
     if (urngrange / n >= n) {
@@ -125,16 +127,16 @@ BT_HD void rng_shuffle_u32(uint32_t *st, uint32_t *a, uint32_t n) {
 }
 
 // normal_distribution<double>(0,1) + gamma_distribution<double>; `nd` holds {saved value, saved_available flag}
-struct NormalState {
-    double saved;
-    uint32_t available;
+struct NormalState {   // references to wherever the caller keeps the two fields
+    double *saved;
+    uint32_t *available;
 };
 
-BT_HD double rng_normal(uint32_t *st, NormalState *nd) {
+BT_HD double rng_normal(uint32_t *st, NormalState nd) {
     double ret;
-    if (nd->available) {
-        nd->available = 0;
-        ret = nd->saved;
+    if (*nd.available) {
+        *nd.available = 0;
+        ret = *nd.saved;
     } else {
         double x, y, r2;
         do {
@@ -143,15 +145,15 @@ BT_HD double rng_normal(uint32_t *st, NormalState *nd) {
             r2 = x * x + y * y;
         } while (r2 > 1.0 || r2 == 0.0);
         const double mult = sqrt(-2 * log(r2) / r2);
-        nd->saved = x * mult;
-        nd->available = 1;
+        *nd.saved = x * mult;
+        *nd.available = 1;
         ret = y * mult;
     }
     ret = ret * 1.0 + 0.0;
     return ret;
 }
 
-BT_HD double rng_gamma(uint32_t *st, NormalState *nd, double alpha, double beta) {
+BT_HD double rng_gamma(uint32_t *st, NormalState nd, double alpha, double beta) {
     const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
     const double a1 = malpha - 1.0 / 3.0;
     const double a2 = 1.0 / sqrt(9.0 * a1);
@@ -177,11 +179,13 @@ BT_HD double rng_gamma(uint32_t *st, NormalState *nd, double alpha, double beta)
 // ------------------------------------------------------------------------------------------------------------
 constexpr uint32_t US_NONE = 0xFFFFFFFFu, US_BEFORE = 0xFFFFFFFEu;
 
-struct USet {
-    uint32_t *hdr;    // 4 words
-    uint32_t *bkt;    // capacity >= uset_bucket_capacity(universe)
-    uint32_t *next;   // universe words
+template <unsigned STRIDE>
+struct USetT {
+    SPtr<uint32_t, STRIDE> hdr;    // 4 words
+    SPtr<uint32_t, STRIDE> bkt;    // capacity >= uset_bucket_capacity(universe)
+    SPtr<uint32_t, STRIDE> next;   // universe words
 };
+typedef USetT<1> USet;
 
 BT_HD uint32_t uset_next_bucket_count(uint32_t min_needed) {   // next entry of libstdc++'s growth chain that is >= min_needed
     const uint32_t chain[15] = {13, 29, 59, 127, 257, 541, 1109, 2357, 5087, 10273, 20753, 42043, 85229, 172933, 351061};
@@ -196,19 +200,23 @@ BT_HD uint32_t uset_bucket_capacity(uint32_t universe) {
     return b;
 }
 
-BT_HD void uset_init(USet s) {
+template <unsigned ST>
+BT_HD void uset_init(USetT<ST> s) {
     s.hdr[0] = 1;
     s.hdr[1] = US_NONE;
     s.hdr[2] = 0;
     s.hdr[3] = 0;
     s.bkt[0] = US_NONE;
 }
-BT_HD uint32_t uset_nxt(USet s, uint32_t node) { return node == US_BEFORE ? s.hdr[1] : s.next[node]; }
-BT_HD void uset_set_nxt(USet s, uint32_t node, uint32_t v) {
+template <unsigned ST>
+BT_HD uint32_t uset_nxt(USetT<ST> s, uint32_t node) { return node == US_BEFORE ? s.hdr[1] : s.next[node]; }
+template <unsigned ST>
+BT_HD void uset_set_nxt(USetT<ST> s, uint32_t node, uint32_t v) {
     if (node == US_BEFORE) s.hdr[1] = v;
     else s.next[node] = v;
 }
-BT_HD void uset_rehash(USet s, uint32_t newB) {
+template <unsigned ST>
+BT_HD void uset_rehash(USetT<ST> s, uint32_t newB) {
     for (uint32_t i = 0; i < newB; ++i) s.bkt[i] = US_NONE;
     uint32_t p = s.hdr[1];
     s.hdr[1] = US_NONE;
@@ -233,7 +241,8 @@ BT_HD void uset_rehash(USet s, uint32_t newB) {
     s.hdr[3] = newB;   // floor(B * max_load_factor 1.0)
 }
 // insert an element that is not in the set
-BT_HD void uset_insert(USet s, uint32_t e) {
+template <unsigned ST>
+BT_HD void uset_insert(USetT<ST> s, uint32_t e) {
     uint32_t B = s.hdr[0], size = s.hdr[2];
     if (size + 1 > s.hdr[3]) {
         uint32_t min_bkts = size + 1;
@@ -259,7 +268,8 @@ BT_HD void uset_insert(USet s, uint32_t e) {
     s.hdr[2] = size + 1;
 }
 // erase an element that is in the set
-BT_HD void uset_erase(USet s, uint32_t e) {
+template <unsigned ST>
+BT_HD void uset_erase(USetT<ST> s, uint32_t e) {
     const uint32_t B = s.hdr[0];
     const uint32_t b = e % B;
     uint32_t prev = s.bkt[b];
@@ -278,13 +288,16 @@ BT_HD void uset_erase(USet s, uint32_t e) {
     uset_set_nxt(s, prev, nn);
     s.hdr[2] -= 1;
 }
-BT_HD void uset_clear(USet s) {
+template <unsigned ST>
+BT_HD void uset_clear(USetT<ST> s) {
     const uint32_t B = s.hdr[0];
     for (uint32_t i = 0; i < B; ++i) s.bkt[i] = US_NONE;
     s.hdr[1] = US_NONE;
     s.hdr[2] = 0;
 }
-BT_HD uint32_t uset_begin(USet s) { return s.hdr[1]; }
-BT_HD uint32_t uset_size(USet s) { return s.hdr[2]; }
+template <unsigned ST>
+BT_HD uint32_t uset_begin(USetT<ST> s) { return s.hdr[1]; }
+template <unsigned ST>
+BT_HD uint32_t uset_size(USetT<ST> s) { return s.hdr[2]; }
 
 }  // namespace bt
