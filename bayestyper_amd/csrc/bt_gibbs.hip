@@ -14,6 +14,7 @@
 #include "bt_internal.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 
@@ -29,16 +30,20 @@ struct TraceCfg {
     uint32_t *buf;         // tile blocks of [max_sweeps][nvm][S][64]
 };
 
-__device__ inline void group_init_chain(const Tile &t, const GParams &P, uint32_t chain, uint32_t nvert, uint32_t nsrc, uint32_t gindex) {
+__device__ __noinline__ void group_init_chain(Env env, uint32_t chain, uint32_t nvert, uint32_t nsrc, uint32_t gindex) {
+    const Tile t = make_tile(env);
+    const GParams BT_CAS &P = env_params(env);
     const uint32_t gseed = P.noise_seeding ? P.seed + (gindex + 1u) * (chain + 1u) : P.seed + (gindex + 1u);
     for (uint32_t v = 0; v < nvert; ++v) {
         const Vx c = make_vx(t, v);
-        if (!c.sc()[SC_CONSTRUCTED]) genotyper_construct(c, P, gseed + c.cid);   // VariantClusterGroup.cpp:179-182
-        genotyper_reset(c, P);
+        if (!c.sc()[SC_CONSTRUCTED]) genotyper_construct(env, v, gseed + c.cid);   // VariantClusterGroup.cpp:179-182
+        genotyper_reset(env, v);
     }
     // shuffleBranchOrdering (VariantClusterGroup.cpp:208-218)
-    uint32_t *brng = reinterpret_cast<uint32_t *>(t.base + t.d->off[A_BRNG]) + (size_t)t.lane * MT_PAD;
-    mt_seed(brng, P.seed + (gindex + 1u) * (chain + 1u));
+    if (nvert == 1 && nsrc == 1) return;   // nothing to shuffle (a fresh generator is seeded per call, no state carries over)
+    uint32_t *bst = (uint32_t *)(t.base + t.d->off[A_BRNG]) + (size_t)t.lane * MT_PAD;
+    mt_seed(bst, P.seed + (gindex + 1u) * (chain + 1u));
+    Mt brng = mt_open(bst);
     rng_shuffle_u32(brng, t.arr<uint32_t>(A_SOURCES), nsrc);
     for (uint32_t v = 0; v < nvert; ++v) {
         const Vx c = make_vx(t, v);
@@ -47,9 +52,12 @@ __device__ inline void group_init_chain(const Tile &t, const GParams &P, uint32_
 }
 
 // VariantClusterGenotyper::updateNestedVariantClusterInfo (VariantClusterGenotyper.cpp:140-206): child's info := parent's info, updated
-__device__ inline void prepare_nested(const Vx &c, const Vx &cc, const GParams &P) {
+__device__ __noinline__ void prepare_nested(Env env, uint32_t v_parent, uint32_t v_child) {
+    const Tile t = make_tile(env);
+    const GParams BT_CAS &P = env_params(env);
+    const Vx c = make_vx(t, v_parent), cc = make_vx(t, v_child);
     const uint32_t nd_n = vx_nd(c);
-    const TileDesc &d = c.d();
+    const TileDesc BT_CAS &d = c.d();
     SPtr<uint32_t, LANES> ndcl = c.a<uint32_t>(A_NDCL, d.NDm > 1 ? d.NDm : 1), ndvo = c.a<uint32_t>(A_NDVOFF, d.NDm + 1);
     SPtr<uint16_t, LANES> ndv = c.a<uint16_t>(A_NDVAR, d.NDVm > 1 ? d.NDVm : 1);
     for (uint32_t s = 0; s < P.S; ++s) {
@@ -98,14 +106,17 @@ __device__ inline void prepare_nested(const Vx &c, const Vx &cc, const GParams &
     }
 }
 
-__device__ inline void visit_vertex(const Tile &t, const GParams &P, uint32_t v, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
-    const Vx c = make_vx(t, v);
-    sample_diplotypes(c, P, collect, trace_row + (size_t)v * P.S, tracing);
-    sample_haplotype_frequencies(c);
+__device__ inline void visit_vertex(const Env &env, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+    sample_diplotypes(env, v, collect, trace_row.off + v * P.S * LANES, tracing, (uint32_t *)trace_row.base);
+#ifndef ABL_NOFREQ
+    sample_haplotype_frequencies(env, v);
+#else
+    make_vx(t, v).sc()[SC_HAP_COUNT] = 0;
+#endif
 }
 
 // VariantClusterGroup::estimateGenotypes + runGibbsSample (VariantClusterGroup.cpp:220-250), recursion unrolled on an explicit stack
-__device__ inline void group_sweep(const Tile &t, const GParams &P, bool collect, uint32_t nvert, uint32_t nsrc, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+__device__ inline void group_sweep(const Env &env, const Tile &t, const GParams BT_CAS &P, bool collect, uint32_t nvert, uint32_t nsrc, SPtr<uint32_t, LANES> trace_row, bool tracing) {
     if (tracing)
         for (uint32_t i = 0; i < t.d->nvm * P.S; ++i) trace_row[i] = 0xFFFFFFFFu;
     SPtr<uint32_t, LANES> sources = t.arr<uint32_t>(A_SOURCES), stack = t.arr<uint32_t>(A_STACK);
@@ -119,7 +130,7 @@ __device__ inline void group_sweep(const Tile &t, const GParams &P, bool collect
                 root.nest_n()[s] = 0;
             }
         }
-        visit_vertex(t, P, sv, collect, trace_row, tracing);
+        visit_vertex(env, t, P, sv, collect, trace_row, tracing);
         if (nvert == 1) continue;
         stack[0] = sv;
         stack[1] = 0;
@@ -131,8 +142,8 @@ __device__ inline void group_sweep(const Tile &t, const GParams &P, bool collect
             if (i < vx_ne(c)) {
                 stack[2 * (sp - 1) + 1] = i + 1;
                 const uint32_t tv = c.edges()[i];
-                prepare_nested(c, make_vx(t, tv), P);
-                visit_vertex(t, P, tv, collect, trace_row, tracing);
+                prepare_nested(env, v, tv);
+                visit_vertex(env, t, P, tv, collect, trace_row, tracing);
                 stack[2 * sp] = tv;
                 stack[2 * sp + 1] = 0;
                 ++sp;
@@ -146,46 +157,51 @@ struct TraceRow {
     SPtr<uint32_t, LANES> row;
     bool on;
 };
-__device__ inline TraceRow trace_row_for(const Tile &t, const GParams &P, const TraceCfg &tr, uint32_t tile) {
-    TraceRow r{SPtr<uint32_t, LANES>{nullptr}, false};
+__device__ inline TraceRow trace_row_for(const Tile &t, const GParams BT_CAS &P, const TraceCfg &tr, uint32_t tile) {
+    TraceRow r{SPtr<uint32_t, LANES>{(uint32_t BT_GAS *)tr.buf, 0u}, false};
     if (!tr.max_sweeps) return r;
     uint32_t *cnt = &tr.counter[(size_t)tile * LANES + t.lane];
     const uint32_t n = *cnt;
     if (n >= tr.max_sweeps) return r;
     *cnt = n + 1;
-    r.row = SPtr<uint32_t, LANES>{tr.buf + t.d->trace_base + (size_t)n * t.d->nvm * P.S * LANES + t.lane};
+    r.row = SPtr<uint32_t, LANES>{(uint32_t BT_GAS *)tr.buf, (uint32_t)(t.d->trace_base + (size_t)n * t.d->nvm * P.S * LANES) + t.lane};
     r.on = true;
     return r;
 }
 
-__global__ __launch_bounds__(LANES) void gibbs_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, GParams P, int op, uint32_t arg0, uint32_t arg1,
-                                                       unsigned long long *__restrict__ hist, TraceCfg tr) {
+#ifndef GIBBS_WAVES
+#define GIBBS_WAVES 1
+#endif
+__global__ __launch_bounds__(LANES, GIBBS_WAVES) void gibbs_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg, int op,
+                                                       uint32_t arg0, uint32_t arg1, unsigned long long *__restrict__ hist, TraceCfg tr) {
     const uint32_t tile = blockIdx.x;
+    const Env env{tiles, pool, Pg};
+    const GParams BT_CAS &P = *(const GParams BT_CAS *)Pg;
     Tile t;
-    t.d = &tiles[tile];
-    t.base = pool + t.d->base;
+    t.d = (const TileDesc BT_CAS *)&tiles[tile];
+    t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = threadIdx.x;
     SPtr<uint32_t, LANES> gd = t.arr<uint32_t>(A_GDIMS);
     if (!gd[3]) return;   // padding lane of the last tile
     const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
     if (op == OP_RUN) {
         for (uint32_t chain = 0; chain < P.num_chains; ++chain) {
-            group_init_chain(t, P, chain, nvert, nsrc, gindex);
+            group_init_chain(env, chain, nvert, nsrc, gindex);
             for (uint32_t i = 0; i < P.burn_in; ++i) {
                 const TraceRow r = trace_row_for(t, P, tr, tile);
-                group_sweep(t, P, false, nvert, nsrc, r.row, r.on);
+                group_sweep(env, t, P, false, nvert, nsrc, r.row, r.on);
             }
             for (uint32_t i = 0; i < P.num_iterations; ++i) {
                 const TraceRow r = trace_row_for(t, P, tr, tile);
-                group_sweep(t, P, true, nvert, nsrc, r.row, r.on);
+                group_sweep(env, t, P, true, nvert, nsrc, r.row, r.on);
             }
         }
     } else if (op == OP_INIT_CHAIN) {
-        group_init_chain(t, P, arg0, nvert, nsrc, gindex);
+        group_init_chain(env, arg0, nvert, nsrc, gindex);
     } else if (op == OP_SWEEP) {
         for (uint32_t i = 0; i < arg0; ++i) {
             const TraceRow r = trace_row_for(t, P, tr, tile);
-            group_sweep(t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
+            group_sweep(env, t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
         }
     } else if (op == OP_NOISE) {
         // VariantClusterGenotyper::getNoiseCounts (:757-779) for every vertex, then clearCache
@@ -230,8 +246,8 @@ __global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= num_clusters) return;
     Tile t;
-    t.d = &tiles[loc[c].tile];
-    t.base = pool + t.d->base;
+    t.d = (const TileDesc BT_CAS *)&tiles[loc[c].tile];
+    t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = loc[c].lane;
     const Vx x = make_vx(t, loc[c].v);
     SPtr<uint32_t, LANES> keys = x.dip_keys(), freq = x.dip_freq();
@@ -280,7 +296,8 @@ struct bt_gibbs {
     uint8_t *d_pool = nullptr;
     uint64_t pool_bytes = 0;
     ClusterLoc *d_loc = nullptr;
-    double *d_lut_g = nullptr, *d_lut_n = nullptr;
+    double *d_lut_g = nullptr, *d_lut_n = nullptr, *d_lgamma = nullptr;
+    GParams *d_params = nullptr;
     bool lut_set = false;
     std::vector<TileDesc> tiles;
     std::vector<ClusterLoc> loc;           // per cluster (batch order)
@@ -298,7 +315,7 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     BT_HIP(hipSetDevice(g->ctx->device));
     TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
-    hipLaunchKernelGGL(gibbs_kernel, dim3(g->ntiles), dim3(LANES), 0, g->ctx->stream, g->d_tiles, g->d_pool, g->P, op, a0, a1, hist, tr);
+    hipLaunchKernelGGL(gibbs_kernel, dim3(g->ntiles), dim3(LANES), 0, g->ctx->stream, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr);
     BT_CHECK_LAUNCH();
     return BT_OK;
 }
@@ -635,8 +652,26 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_lut_n), (size_t)S * 256 * 8));
     g->allocs.push_back(g->d_lut_n);
     g->device_bytes += (uint64_t)S * (65536 + 256) * 8 + (uint64_t)ntiles * sizeof(TileDesc) + (uint64_t)C * sizeof(ClusterLoc);
-    g->P.lut_g = g->d_lut_g;
-    g->P.lut_n = g->d_lut_n;
+    g->P.lut_g = (const double BT_GAS *)g->d_lut_g;
+    g->P.lut_n = (const double BT_GAS *)g->d_lut_n;
+    {
+        // lgamma over the integers the simplex-size distribution touches (FrequencyDistribution.cpp:143-196): <= Hmax + 2S + 1
+        uint32_t Hmax = 0;
+        for (uint32_t c = 0; c < C; ++c) Hmax = std::max(Hmax, B->num_haplotypes[c]);
+        const uint32_t n = Hmax + 2 * S + 8;
+        std::vector<double> lg(n, 0.0);
+        for (uint32_t i = 1; i < n; ++i) lg[i] = std::lgamma((double)i);
+        BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_lgamma), (size_t)n * 8));
+        g->allocs.push_back(g->d_lgamma);
+        BT_TRYHIP(hipMemcpyAsync(g->d_lgamma, lg.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        BT_TRYHIP(hipStreamSynchronize(ctx->stream));
+        g->P.lgamma_int = (const double BT_GAS *)g->d_lgamma;
+        g->P.lgamma_n = n;
+        BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_params), sizeof(GParams)));
+        g->allocs.push_back(g->d_params);
+        BT_TRYHIP(hipMemcpyAsync(g->d_params, &g->P, sizeof(GParams), hipMemcpyHostToDevice, ctx->stream));
+        BT_TRYHIP(hipStreamSynchronize(ctx->stream));
+    }
     BT_TRY(launch(g, OP_SETUP, 0, 0, nullptr));
     BT_TRYHIP(hipStreamSynchronize(ctx->stream));
 #undef BT_TRY
@@ -890,7 +925,7 @@ int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *v
     if (!ops || !values || !h_order || !n) return fail("bt_diag_uset_replay: null argument");
     std::vector<uint32_t> hdr(4), bkt(uset_bucket_capacity(universe)), next(std::max<uint32_t>(universe, 1));
     std::vector<uint8_t> present(universe, 0);
-    USet s{SPtr<uint32_t, 1>{hdr.data()}, SPtr<uint32_t, 1>{bkt.data()}, SPtr<uint32_t, 1>{next.data()}};
+    USet s{sptr1(hdr.data()), sptr1(bkt.data()), sptr1(next.data())};
     uset_init(s);
     for (uint64_t i = 0; i < num_ops; ++i) {
         if (ops[i] == 2) {
@@ -916,31 +951,32 @@ int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *v
 
 int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint64_t n, double *h_out) {
     if (!h_out) return fail("bt_diag_rng: null argument");
-    std::vector<uint32_t> st(MT_WORDS);
-    mt_seed(st.data(), seed);
+    std::vector<uint32_t> stv(MT_WORDS);
+    mt_seed(stv.data(), seed);
+    Mt st = mt_open(stv.data());
     double saved = 0;
     uint32_t avail = 0;
-    NormalState nd{&saved, &avail};
+    NormalState nd{(double BT_GAS *)&saved, (uint32_t BT_GAS *)&avail};
     switch (kind) {
         case 0:
-            for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)mt_next(st.data());
+            for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)mt_next(st);
             break;
         case 1:
-            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_canonical(st.data());
+            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_canonical(st);
             break;
         case 2:
-            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_gamma(st.data(), nd, a[i], b[i]);
+            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_gamma(st, nd, a[i], b[i]);
             break;
         case 3:
-            for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)rng_uniform_int(st.data(), (uint32_t)a[i] + 1u);
+            for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)rng_uniform_int(st, (uint32_t)a[i] + 1u);
             break;
         case 4:
-            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_bernoulli(st.data(), (double)(float)a[0]) ? 1.0 : 0.0;
+            for (uint64_t i = 0; i < n; ++i) h_out[i] = rng_bernoulli(st, (double)(float)a[0]) ? 1.0 : 0.0;
             break;
         case 5: {
             std::vector<uint32_t> v((size_t)a[0]);
             for (size_t i = 0; i < v.size(); ++i) v[i] = (uint32_t)i;
-            rng_shuffle_u32(st.data(), v.data(), (uint32_t)v.size());
+            rng_shuffle_u32(st, sptr1(v.data()), (uint32_t)v.size());
             for (size_t i = 0; i < v.size(); ++i) h_out[i] = v[i];
             break;
         }

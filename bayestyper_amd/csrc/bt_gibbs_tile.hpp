@@ -106,50 +106,60 @@ struct GParams {
     uint32_t S, seed, num_chains, burn_in, num_iterations, max_hvk, noise_seeding;
     double rate;                // (double)(float)kmer_subsampling_rate, as bernoulli_distribution stores it
     uint8_t gender[32];
-    const double *lut_g;        // [S][256][256]
-    const double *lut_n;        // [S][256]
+    const double BT_GAS *lut_g;        // [S][256][256]
+    const double BT_GAS *lut_n;        // [S][256]
+    const double BT_GAS *lgamma_int;   // lgamma(n) for integer n in [0, lgamma_n): computed on the host (libm), gathered on the device
+    uint32_t lgamma_n, pad;
 };
 
 // ---- lane view of a tile / of one vertex of the lane's group ------------------------------------------------------
 struct Tile {
-    uint8_t *base;
-    const TileDesc *d;
+    uint8_t BT_GAS *base;
+    const TileDesc BT_CAS *d;
     uint32_t lane;
     template <typename T>
-    __device__ inline SPtr<T, LANES> arr(int a, size_t first = 0) const {
-        return SPtr<T, LANES>{reinterpret_cast<T *>(base + d->off[a]) + first * LANES + lane};
+    __device__ inline SPtr<T, LANES> arr(int a, uint32_t first = 0) const {
+        return SPtr<T, LANES>{(T BT_GAS *)(base + d->off[a]), first * LANES + lane};
     }
+};
+
+// the kernel's wave-uniform environment, re-derived inside every non-inlined function (arguments of a call are vector
+// registers to the compiler; readfirstlane turns them back into scalars)
+struct Env {
+    const TileDesc *tiles;
+    uint8_t *pool;
+    const struct GParams *P;
 };
 
 struct Vx {   // vertex context: tile + vertex index + the lane's true dimensions of that vertex
     Tile t;
     uint32_t v, H, V, K, nu, nm, cid;
-    __device__ inline const TileDesc &d() const { return *t.d; }
+    __device__ inline const TileDesc BT_CAS &d() const { return *t.d; }
     template <typename T>
-    __device__ inline SPtr<T, LANES> a(int arr, size_t len) const { return t.arr<T>(arr, (size_t)v * len); }
+    __device__ inline SPtr<T, LANES> a(int arr, uint32_t len) const { return t.arr<T>(arr, v * len); }
     // inputs
-    __device__ inline uint8_t M(uint32_t k, uint32_t h) const { return a<uint8_t>(A_M, (size_t)d().Km * d().Hm)[(size_t)k * d().Hm + h]; }
+    __device__ inline uint8_t M(uint32_t k, uint32_t h) const { return a<uint8_t>(A_M, (uint32_t)d().Km * d().Hm)[(uint32_t)k * d().Hm + h]; }
     __device__ inline uint8_t has_counts(uint32_t k) const { return a<uint8_t>(A_HASC, d().Km)[k]; }
-    __device__ inline uint8_t count(uint32_t k, uint32_t s) const { return a<uint8_t>(A_COUNTS, (size_t)d().Km * d().S)[(size_t)k * d().S + s]; }
-    __device__ inline uint8_t ic(uint32_t k, uint32_t g) const { return a<uint8_t>(A_IC, (size_t)d().Km * 2)[2 * k + g]; }
+    __device__ inline uint8_t count(uint32_t k, uint32_t s) const { return a<uint8_t>(A_COUNTS, (uint32_t)d().Km * d().S)[(uint32_t)k * d().S + s]; }
+    __device__ inline uint8_t ic(uint32_t k, uint32_t g) const { return a<uint8_t>(A_IC, (uint32_t)d().Km * 2)[2 * k + g]; }
     __device__ inline int32_t shared_idx(uint32_t k) const { return a<int32_t>(A_SHARED, d().Km)[k]; }
     __device__ inline uint32_t kv_off(uint32_t k) const { return a<uint32_t>(A_KVOFF, d().Km + 1)[k]; }
     __device__ inline uint16_t kv_var(uint32_t e) const { return a<uint16_t>(A_KVVAR, d().NNZm)[e]; }
-    __device__ inline bool kv_bit(uint32_t e, uint32_t h) const { return (a<uint32_t>(A_KVBITS, (size_t)d().NNZm * d().HWm)[(size_t)e * d().HWm + (h >> 5)] >> (h & 31u)) & 1u; }
-    __device__ inline uint16_t hap_allele(uint32_t h, uint32_t var) const { return a<uint16_t>(A_HAPAL, (size_t)d().Hm * d().Vm)[(size_t)h * d().Vm + var]; }
+    __device__ inline bool kv_bit(uint32_t e, uint32_t h) const { return (a<uint32_t>(A_KVBITS, (uint32_t)d().NNZm * d().HWm)[(uint32_t)e * d().HWm + (h >> 5)] >> (h & 31u)) & 1u; }
+    __device__ inline uint16_t hap_allele(uint32_t h, uint32_t var) const { return a<uint16_t>(A_HAPAL, (uint32_t)d().Hm * d().Vm)[(uint32_t)h * d().Vm + var]; }
     __device__ inline uint32_t hn_off(uint32_t h) const { return a<uint32_t>(A_HNOFF, d().Hm + 1)[h]; }
     __device__ inline uint32_t hn_idx(uint32_t i) const { return a<uint32_t>(A_HNIDX, d().HNm)[i]; }
     __device__ inline uint16_t var_na(uint32_t var) const { return a<uint16_t>(A_VARNA, d().Vm)[var]; }
     __device__ inline uint8_t var_dep(uint32_t var) const { return a<uint8_t>(A_VARDEP, d().Vm)[var]; }
     __device__ inline uint32_t allele_base(uint32_t var) const { return a<uint32_t>(A_ALBASE, d().Vm + 1)[var]; }
     // state
-    __device__ inline uint32_t *mt(uint32_t g) const { return reinterpret_cast<uint32_t *>(t.base + d().off[A_MT]) + (((size_t)v * 2 + g) * LANES + t.lane) * MT_PAD; }
+    __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)(v * 2 + g) * LANES + t.lane) * MT_PAD; }
     __device__ inline SPtr<uint32_t, LANES> sc() const { return a<uint32_t>(A_SC, SC_COUNT); }
     __device__ inline SPtr<uint32_t, LANES> uniq() const { return a<uint32_t>(A_UNIQ, d().NUm); }
     __device__ inline SPtr<uint32_t, LANES> multi() const { return a<uint32_t>(A_MULTI, d().NMm); }
     __device__ inline SPtr<uint32_t, LANES> usub() const { return a<uint32_t>(A_USUB, d().NUm); }
     __device__ inline SPtr<uint32_t, LANES> msub() const { return a<uint32_t>(A_MSUB, d().NMm); }
-    __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (size_t)d().NMm * d().S); }
+    __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (uint32_t)d().NMm * d().S); }
     __device__ inline SPtr<uint16_t, LANES> dip() const { return a<uint16_t>(A_DIP, 2 * d().S); }
     __device__ inline SPtr<double, LANES> freq() const { return a<double>(A_FREQ, d().Hm); }
     __device__ inline SPtr<uint32_t, LANES> obs() const { return a<uint32_t>(A_OBS, d().Hm); }
@@ -157,39 +167,50 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<uint32_t, LANES> unext() const { return a<uint32_t>(A_UNEXT, d().Hm); }
     __device__ inline USetT<LANES> zero_set() const { return USetT<LANES>{a<uint32_t>(A_ZHDR, 4), a<uint32_t>(A_ZBKT, d().Bcap), unext()}; }
     __device__ inline USetT<LANES> plus_set() const { return USetT<LANES>{a<uint32_t>(A_PHDR, 4), a<uint32_t>(A_PBKT, d().Bcap), unext()}; }
-    __device__ inline SPtr<uint32_t, LANES> hvcount() const { return a<uint32_t>(A_HVCOUNT, (size_t)d().Hm * d().Vm); }
+    __device__ inline SPtr<uint32_t, LANES> hvcount() const { return a<uint32_t>(A_HVCOUNT, (uint32_t)d().Hm * d().Vm); }
     __device__ inline SPtr<double, LANES> ucache() const { return a<double>(A_UCACHE, d().cache_entries); }
     __device__ inline SPtr<uint32_t, LANES> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
     __device__ inline SPtr<double, LANES> cum() const { return a<double>(A_CUM, d().D2m > 1 ? d().D2m : 1); }
     __device__ inline SPtr<uint16_t, LANES> nzlist() const { return a<uint16_t>(A_NZLIST, d().Hm); }
     __device__ inline SPtr<double, LANES> simplex() const { return a<double>(A_SIMPLEX, d().Hm + 1); }
-    __device__ inline SPtr<double, LANES> scache() const { return a<double>(A_SCACHE, (size_t)(d().scache_n ? d().scache_n : 1) * (d().scache_len ? d().scache_len : 1)); }
+    __device__ inline SPtr<double, LANES> scache() const { return a<double>(A_SCACHE, (uint32_t)(d().scache_n ? d().scache_n : 1) * (d().scache_len ? d().scache_len : 1)); }
     __device__ inline SPtr<uint32_t, LANES> sclen() const { return a<uint32_t>(A_SCLEN, d().scache_n > 1 ? d().scache_n : 1); }
     __device__ inline SPtr<double, LANES> ksc(uint32_t s, uint32_t which, uint32_t var) const {
-        return a<double>(A_KSC, (size_t)d().S * 2 * d().Vm * 4) + (((size_t)s * 2 + which) * d().Vm + var) * 4;
+        return a<double>(A_KSC, (uint32_t)d().S * 2 * d().Vm * 4) + (((uint32_t)s * 2 + which) * d().Vm + var) * 4;
     }
     __device__ inline SPtr<uint8_t, LANES> ksc_upd() const { return a<uint8_t>(A_KSCUPD, d().S); }
     __device__ inline SPtr<uint32_t, LANES> dip_keys() const { return a<uint32_t>(A_DIPKEYS, d().dip_cap); }
-    __device__ inline SPtr<uint32_t, LANES> dip_freq() const { return a<uint32_t>(A_DIPFREQ, (size_t)d().dip_cap * d().S); }
+    __device__ inline SPtr<uint32_t, LANES> dip_freq() const { return a<uint32_t>(A_DIPFREQ, (uint32_t)d().dip_cap * d().S); }
     __device__ inline SPtr<double, LANES> astats(uint32_t s, uint32_t var, uint32_t al) const {
-        return a<double>(A_ASTATS, (size_t)d().S * d().Am * 12) + ((size_t)s * d().Am + allele_base(var) + al) * 12;
+        return a<double>(A_ASTATS, (uint32_t)d().S * d().Am * 12) + ((uint32_t)s * d().Am + allele_base(var) + al) * 12;
     }
     __device__ inline SPtr<uint8_t, LANES> nest_ploidy() const { return a<uint8_t>(A_NESTPL, d().S); }
     __device__ inline SPtr<uint8_t, LANES> nest_n() const { return a<uint8_t>(A_NESTN, d().S); }
-    __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (size_t)d().S * 8) + ((size_t)s * 2 + j) * 4; }
+    __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
     __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
     __device__ inline SPtr<uint8_t, LANES> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
-    __device__ inline double &fnd_saved() const { return a<double>(A_FNDSAVED, 1)[0]; }
-    __device__ inline double &sparsity() const { return a<double>(A_SPARSITY, 1)[0]; }
+    __device__ inline double BT_GAS &fnd_saved() const { return a<double>(A_FNDSAVED, 1)[0]; }
+    __device__ inline double BT_GAS &sparsity() const { return a<double>(A_SPARSITY, 1)[0]; }
     __device__ inline NormalState fnd() const { return NormalState{&fnd_saved(), &sc()[SC_FND_AVAIL]}; }
     __device__ inline SPtr<uint8_t, LANES> shared_mult() const { return t.arr<uint8_t>(A_SHMULT); }
 };
+
+__device__ inline Tile make_tile(const Env &e_in) {
+    Tile t;
+    const TileDesc *tiles = uniform_ptr(e_in.tiles);
+    uint8_t *pool = uniform_ptr(e_in.pool);
+    t.d = (const TileDesc BT_CAS *)&tiles[blockIdx.x];
+    t.base = (uint8_t BT_GAS *)(pool + t.d->base);
+    t.lane = threadIdx.x;
+    return t;
+}
+__device__ inline const GParams BT_CAS &env_params(const Env &e) { return *(const GParams BT_CAS *)uniform_ptr(e.P); }
 
 __device__ inline Vx make_vx(const Tile &t, uint32_t v) {
     Vx x;
     x.t = t;
     x.v = v;
-    SPtr<uint32_t, LANES> dm = t.arr<uint32_t>(A_VDIMS, (size_t)v * 8);
+    SPtr<uint32_t, LANES> dm = t.arr<uint32_t>(A_VDIMS, v * 8);
     x.H = dm[0];
     x.V = dm[1];
     x.K = dm[2];
@@ -198,46 +219,59 @@ __device__ inline Vx make_vx(const Tile &t, uint32_t v) {
     x.cid = dm[7];
     return x;
 }
-__device__ inline uint32_t vx_nd(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, (size_t)c.v * 8)[5]; }
-__device__ inline uint32_t vx_ne(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, (size_t)c.v * 8)[6]; }
+__device__ inline uint32_t vx_nd(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, c.v * 8)[5]; }
+__device__ inline uint32_t vx_ne(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, c.v * 8)[6]; }
 
 // ---- Utils::logAddition (Utils.hpp:105-124) ----
 __device__ inline double log_addition(double a, double b) {
-    if (a < b) return b + log1p(exp(a - b));
-    return a + log1p(exp(b - a));
+    if (a < b) return b + bt_log1p(bt_exp(a - b));
+    return a + bt_log1p(bt_exp(b - a));
 }
 
 // ---- KmerStats (KmerStats.cpp:51-63): ks = {count, fraction, mean, M2} ----
+// Values are pulled into registers with independent loads, updated, and written back: one memory round trip per
+// KmerStats object instead of a dependent load/store chain per field.
+struct KS {
+    double c, f, m, m2;
+};
+template <typename P>
+__device__ inline KS ks_load(P p) { return KS{(double)p[0], (double)p[1], (double)p[2], (double)p[3]}; }
+template <typename P>
+__device__ inline void ks_store(P p, const KS &k) { p[0] = k.c; p[1] = k.f; p[2] = k.m; p[3] = k.m2; }
 template <typename P>
 __device__ inline void ks_reset(P ks) { ks[0] = 0; ks[1] = 0; ks[2] = 0; ks[3] = 0; }
+__device__ inline void ks_add_r(KS &k, double value) {
+    const double count = k.c + 1.0;
+    k.c = count;
+    // !doubleCompare(value, 0): value == 0 <=> equal (Utils.hpp:81-87 with b = 0)
+    k.f += ((value == 0.0 ? 0.0 : 1.0) - k.f) / count;
+    const double delta = value - k.m;
+    k.m += delta / count;
+    k.m2 += delta * (value - k.m);
+}
 template <typename P>
 __device__ inline void ks_add(P ks, double value) {
-    const double count = ks[0] + 1.0;
-    ks[0] = count;
-    // !doubleCompare(value, 0): value == 0 <=> equal (Utils.hpp:81-87 with b = 0)
-    double fr = ks[1];
-    fr += ((value == 0.0 ? 0.0 : 1.0) - fr) / count;
-    ks[1] = fr;
-    double mean = ks[2];
-    const double delta = value - mean;
-    mean += delta / count;
-    ks[2] = mean;
-    ks[3] += delta * (value - mean);
+    KS k = ks_load(ks);
+    ks_add_r(k, value);
+    ks_store(ks, k);
 }
 // AlleleKmerStats::addKmerStats (KmerStats.cpp:114-121): cell = [3][4]
-template <typename P, typename Q>
-__device__ inline void aks_add(P cell, Q ks) {
-    const double cnt = ks[0];
-    ks_add(cell, cnt);                        // count_stats    <- (getCount(), true)
-    if (cnt != 0.0) {
-        ks_add(cell + 4, (double)ks[1]);      // fraction_stats <- getFraction()  (skipped when count == 0)
-        ks_add(cell + 8, (double)ks[2]);      // mean_stats     <- getMean()
+template <typename P>
+__device__ inline void aks_add(P cell, const KS &src) {
+    KS a = ks_load(cell), b = ks_load(cell + 4), c = ks_load(cell + 8);
+    ks_add_r(a, src.c);                       // count_stats    <- (getCount(), true)
+    ks_store(cell, a);
+    if (src.c != 0.0) {
+        ks_add_r(b, src.f);                   // fraction_stats <- getFraction()  (skipped when count == 0)
+        ks_add_r(c, src.m);                   // mean_stats     <- getMean()
+        ks_store(cell + 4, b);
+        ks_store(cell + 8, c);
     }
 }
 
-__device__ inline double count_log_prob(const GParams &P, uint32_t s, uint8_t mult, uint8_t count) {   // CountDistribution.cpp:255-265
+__device__ inline double count_log_prob(const GParams BT_CAS &P, uint32_t s, uint8_t mult, uint8_t count) {   // CountDistribution.cpp:255-265
     if (mult == 0) return P.lut_n[s * 256u + count];
-    return P.lut_g[((size_t)s * 256u + mult) * 256u + count];
+    return P.lut_g[((uint32_t)s * 256u + mult) * 256u + count];
 }
 
 // ---- VariantClusterHaplotypes multiplicity getters (VariantClusterHaplotypes.cpp:45-108), uchar arithmetic ----
@@ -252,10 +286,10 @@ __device__ inline uint8_t unique_mult(const Vx &c, uint32_t k, uint16_t h1, uint
     if (c.has_counts(k)) m = (uint8_t)(m + c.ic(k, gender));
     return m;
 }
-__device__ inline uint8_t multi_mult(const Vx &c, const GParams &P, uint32_t k, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t s) {
+__device__ inline uint8_t multi_mult(const Vx &c, const GParams BT_CAS &P, uint32_t k, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t s) {
     const uint8_t icm = c.ic(k, P.gender[s]);
     if (c.count(k, s) == 0) return (uint8_t)(dip_mult(c, k, h1, h2) + icm);
-    const uint8_t shared = c.shared_mult()[(size_t)c.shared_idx(k) * P.S + s];
+    const uint8_t shared = c.shared_mult()[(uint32_t)c.shared_idx(k) * P.S + s];
     return (uint8_t)(shared - dip_mult(c, k, p1, p2) + dip_mult(c, k, h1, h2) + icm);
 }
 
@@ -280,7 +314,7 @@ __device__ inline void freq_reset(const Vx &c) {
 
 // ---- SparsityEstimator::estimateMinimumColumnCover (SparsityEstimator.cpp:41-87), unweighted ----
 // returns the cover size; uses `rng` (freshly seeded by the caller), cover_rows, obs (column sums), nzlist
-__device__ inline uint32_t sparsity_cover(const Vx &c, uint32_t *rng) {
+__device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
     SPtr<uint8_t, LANES> rows = c.cover_rows();
     SPtr<uint32_t, LANES> obs = c.obs();
     SPtr<uint16_t, LANES> nzl = c.nzlist();
@@ -324,8 +358,10 @@ __device__ inline uint32_t sparsity_cover(const Vx &c, uint32_t *rng) {
 }
 
 // ---- VariantClusterGenotyper ctor (VariantClusterGenotyper.cpp:59-106) ----
-__device__ inline void genotyper_construct(const Vx &c, const GParams &P, uint32_t prng_seed) {
-    const TileDesc &d = c.d();
+__device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t prng_seed) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    const TileDesc BT_CAS &d = c.d();
     mt_seed(c.mt(0), prng_seed);
     SPtr<uint32_t, LANES> sc = c.sc();
     for (uint32_t i = 0; i < SC_COUNT; ++i) sc[i] = 0;
@@ -343,22 +379,26 @@ __device__ inline void genotyper_construct(const Vx &c, const GParams &P, uint32
         upd[s] = 1;
     }
     {
-        const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, (size_t)c.v * 2)[0];
-        SPtr<double, LANES> as = c.a<double>(A_ASTATS, (size_t)d.S * d.Am * 12);
+        const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, c.v * 2)[0];
+        SPtr<double, LANES> as = c.a<double>(A_ASTATS, (uint32_t)d.S * d.Am * 12);
         for (size_t s = 0; s < P.S; ++s)
-            for (size_t i = 0; i < (size_t)A * 12; ++i) as[s * d.Am * 12 + i] = 0;
-        SPtr<double, LANES> k = c.a<double>(A_KSC, (size_t)d.S * 2 * d.Vm * 4);
-        for (size_t i = 0; i < (size_t)P.S * 2 * d.Vm * 4; ++i) k[i] = 0;
+            for (size_t i = 0; i < (uint32_t)A * 12; ++i) as[s * d.Am * 12 + i] = 0;
+        SPtr<double, LANES> k = c.a<double>(A_KSC, (uint32_t)d.S * 2 * d.Vm * 4);
+        for (size_t i = 0; i < (uint32_t)P.S * 2 * d.Vm * 4; ++i) k[i] = 0;
         SPtr<uint32_t, LANES> dk = c.dip_keys(), df = c.dip_freq();
         for (uint32_t i = 0; i < d.dip_cap; ++i) dk[i] = 0;
-        for (size_t i = 0; i < (size_t)d.dip_cap * P.S; ++i) df[i] = 0;
+        for (size_t i = 0; i < (uint32_t)d.dip_cap * P.S; ++i) df[i] = 0;
         SPtr<uint32_t, LANES> sl = c.sclen();
         for (uint32_t i = 0; i < d.scache_n; ++i) sl[i] = 0;
     }
     // SparsityEstimator(prng_seed), then (Sparse)FrequencyDistribution(.., prng_seed) with a fresh generator
     uint32_t *fr = c.mt(1);
     mt_seed(fr, prng_seed);
-    const uint32_t cover = sparsity_cover(c, fr);
+    uint32_t cover;
+    {
+        Mt m = mt_open(fr);
+        cover = sparsity_cover(c, m);
+    }
     mt_seed(fr, prng_seed);
     c.fnd_saved() = 0;
     sc[SC_FND_AVAIL] = 0;
@@ -374,13 +414,13 @@ __device__ inline void genotyper_construct(const Vx &c, const GParams &P, uint32
     sc[SC_CONSTRUCTED] = 1;
 }
 
-__device__ inline void cache_clear(const Vx &c, const GParams &P) {   // VariantClusterGenotyper::clearCache (:131-138)
-    const TileDesc &d = c.d();
+__device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P) {   // VariantClusterGenotyper::clearCache (:131-138)
+    const TileDesc BT_CAS &d = c.d();
     if (d.cache_mode == 0) {
         SPtr<double, LANES> uc = c.ucache();
         const uint32_t Dc = c.H * (c.H + 1) / 2 + c.H;
         for (uint32_t s = 0; s < P.S; ++s)
-            for (uint32_t i = 0; i < Dc; ++i) uc[(size_t)s * d.Dcm + i] = __longlong_as_double(0x7ff8000000000000LL);
+            for (uint32_t i = 0; i < Dc; ++i) uc[(uint32_t)s * d.Dcm + i] = __longlong_as_double(0x7ff8000000000000LL);
     } else if (d.cache_mode == 1) {
         SPtr<uint32_t, LANES> tg = c.uctag();
         for (uint32_t i = 0; i < d.cache_entries; ++i) tg[i] = 0;
@@ -396,9 +436,9 @@ __device__ inline bool is_max_hv_kmer(const Vx &c, uint32_t k, uint32_t maxk) {
         const uint32_t var = c.kv_var(e);
         for (uint32_t h = 0; h < c.H; ++h) {
             if (c.kv_bit(e, h)) {
-                const uint32_t cnt = hv[(size_t)h * Vm + var];
+                const uint32_t cnt = hv[(uint32_t)h * Vm + var];
                 if (cnt < maxk) {
-                    hv[(size_t)h * Vm + var] = cnt + 1;
+                    hv[(uint32_t)h * Vm + var] = cnt + 1;
                     is_max = false;
                 }
             }
@@ -406,13 +446,13 @@ __device__ inline bool is_max_hv_kmer(const Vx &c, uint32_t k, uint32_t maxk) {
     }
     return is_max;
 }
-__device__ inline void sample_kmer_subset(const Vx &c, const GParams &P) {
+__device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) {
     const uint32_t Vm = c.d().Vm;
     SPtr<uint32_t, LANES> hv = c.hvcount();
     for (uint32_t h = 0; h < c.H; ++h)
-        for (uint32_t v = 0; v < c.V; ++v) hv[(size_t)h * Vm + v] = 0;
+        for (uint32_t v = 0; v < c.V; ++v) hv[(uint32_t)h * Vm + v] = 0;
     uint32_t nsu = 0, nsm = 0;
-    uint32_t *rng = c.mt(0);
+    Mt rng = mt_open(c.mt(0));
     SPtr<uint32_t, LANES> uniq = c.uniq(), usub = c.usub(), multi = c.multi(), msub = c.msub();
     rng_shuffle_u32(rng, uniq, c.nu);
     for (uint32_t i = 0; i < c.nu; ++i) {
@@ -426,17 +466,20 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams &P) {
         if (rng_bernoulli(rng, P.rate))
             if (!is_max_hv_kmer(c, k, P.max_hvk)) msub[nsm++] = k;
     }
+    mt_close(rng);
     SPtr<uint32_t, LANES> sc = c.sc();
     sc[SC_NSUB_U] = nsu;
     sc[SC_NSUB_M] = nsm;
     SPtr<uint8_t, LANES> smm = c.smm();
-    for (size_t i = 0; i < (size_t)nsm * P.S; ++i) smm[i] = 0;
+    for (size_t i = 0; i < (uint32_t)nsm * P.S; ++i) smm[i] = 0;
     SPtr<uint8_t, LANES> upd = c.ksc_upd();
     for (uint32_t s = 0; s < P.S; ++s) upd[s] = 1;
 }
 
 // ---- VariantClusterGenotyper::reset (VariantClusterGenotyper.cpp:113-129) ----
-__device__ inline void genotyper_reset(const Vx &c, const GParams &P) {
+__device__ __noinline__ void genotyper_reset(Env env, uint32_t vtx) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
     c.sc()[SC_USE_MULTI] = 0;
     sample_kmer_subset(c, P);
     cache_clear(c, P);
@@ -451,13 +494,13 @@ __device__ inline uint32_t dip_index(const Vx &c, uint16_t h1, uint16_t h2) {
 // unique part of calcDiplotypeLogProb with its per-(sample, diplotype) cache (VariantClusterGenotyper.cpp:619-643).
 // The cached value is a pure function of (sample, diplotype, k-mer subset), so a dense table, a direct-mapped table
 // or no table at all give bit-identical sums (same summation order).
-__device__ inline double unique_log_prob(const Vx &c, const GParams &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t nsub_u) {
-    const TileDesc &d = c.d();
+__device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t nsub_u) {
+    const TileDesc BT_CAS &d = c.d();
     const uint32_t idx = dip_index(c, h1, h2);
     uint32_t slot = 0;
     SPtr<double, LANES> uc = c.ucache();
     if (d.cache_mode == 0) {
-        const double v = uc[(size_t)s * d.Dcm + idx];
+        const double v = uc[(uint32_t)s * d.Dcm + idx];
         if (v == v) return v;
     } else if (d.cache_mode == 1) {
         const uint32_t key = s * d.Dcm + idx + 1u;
@@ -473,7 +516,7 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams &P, uint32_t
         const uint8_t cnt = c.has_counts(k) ? c.count(k, s) : 0;
         acc += count_log_prob(P, s, m, cnt);
     }
-    if (d.cache_mode == 0) uc[(size_t)s * d.Dcm + idx] = acc;
+    if (d.cache_mode == 0) uc[(uint32_t)s * d.Dcm + idx] = acc;
     else if (d.cache_mode == 1) {
         c.uctag()[slot] = s * d.Dcm + idx + 1u;
         uc[slot] = acc;
@@ -483,7 +526,7 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams &P, uint32_t
 
 // multicluster part (VariantClusterGenotyper.cpp:647-661).  The reference keeps a second cache that it patches
 // incrementally (:569-595); the patched value equals this direct sum up to floating-point re-association.
-__device__ inline double multi_log_prob(const Vx &c, const GParams &P, uint32_t s, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t nsub_m) {
+__device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t nsub_m) {
     double acc = 0;
     SPtr<uint32_t, LANES> msub = c.msub();
     for (uint32_t i = 0; i < nsub_m; ++i) {
@@ -510,7 +553,7 @@ __device__ inline void hfd_increment(const Vx &c, uint16_t h, bool is_sparse, ui
 }
 
 // ---- diplotype_sampling_frequencies (VariantClusterGenotyper.cpp:692-696) as an open-addressing table ----
-__device__ inline void dip_table_add(const Vx &c, const GParams &P, uint16_t h1, uint16_t h2, uint32_t s) {
+__device__ inline void dip_table_add(const Vx &c, const GParams BT_CAS &P, uint16_t h1, uint16_t h2, uint32_t s) {
     const uint32_t key = ((uint32_t)h1 | ((uint32_t)h2 << 16));
     // stored tag: key + 1 (0 = empty slot); the null diplotype (NOHAP, NOHAP) would wrap to 0 and is stored as 0xFFFFFFFF,
     // which no other key + 1 can equal because haplotype indices are < 0xFFFE
@@ -523,11 +566,11 @@ __device__ inline void dip_table_add(const Vx &c, const GParams &P, uint16_t h1,
         if (tag == 0) {
             keys[slot] = want;
             c.sc()[SC_DIP_ENTRIES] += 1;
-            freq[(size_t)slot * P.S + s] += 1;
+            freq[(uint32_t)slot * P.S + s] += 1;
             return;
         }
         if (tag == want) {
-            freq[(size_t)slot * P.S + s] += 1;
+            freq[(uint32_t)slot * P.S + s] += 1;
             return;
         }
         slot = (slot + 1u) & mask;
@@ -536,7 +579,7 @@ __device__ inline void dip_table_add(const Vx &c, const GParams &P, uint16_t h1,
 }
 
 // ---- VariantClusterHaplotypes::updateMulticlusterKmerMultiplicities (VariantClusterHaplotypes.cpp:197-233) ----
-__device__ inline void update_multicluster_multiplicities(const Vx &c, const GParams &P, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t s, uint32_t nsub_m) {
+__device__ inline void update_multicluster_multiplicities(const Vx &c, const GParams BT_CAS &P, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t s, uint32_t nsub_m) {
     if (h1 != p1 || h2 != p2) c.ksc_upd()[s] = 1;
     if (c.nm == 0) return;
     SPtr<uint8_t, LANES> shm = c.shared_mult();
@@ -546,7 +589,7 @@ __device__ inline void update_multicluster_multiplicities(const Vx &c, const GPa
             const uint32_t k = multi[i];
             const uint8_t cur = dip_mult(c, k, h1, h2), pre = dip_mult(c, k, p1, p2);
             if (cur != pre) {
-                const size_t at = (size_t)c.shared_idx(k) * P.S + s;
+                const size_t at = (uint32_t)c.shared_idx(k) * P.S + s;
                 uint8_t m = shm[at];
                 m = (uint8_t)(m - pre);
                 m = (uint8_t)(m + cur);
@@ -558,14 +601,14 @@ __device__ inline void update_multicluster_multiplicities(const Vx &c, const GPa
     SPtr<uint8_t, LANES> smm = c.smm();
     for (uint32_t sub = 0; sub < nsub_m; ++sub) {
         const uint32_t k = msub[sub];
-        const uint8_t shared = shm[(size_t)c.shared_idx(k) * P.S + s];
-        if (dip_mult(c, k, h1, h2) > 0 && c.count(k, s) > 0 && shared != smm[(size_t)sub * P.S + s]) c.ksc_upd()[s] = 1;
-        smm[(size_t)sub * P.S + s] = shared;
+        const uint8_t shared = shm[(uint32_t)c.shared_idx(k) * P.S + s];
+        if (dip_mult(c, k, h1, h2) > 0 && c.count(k, s) > 0 && shared != smm[(uint32_t)sub * P.S + s]) c.ksc_upd()[s] = 1;
+        smm[(uint32_t)sub * P.S + s] = shared;
     }
 }
 
 // ---- updateKmerStatsCache / updateAlleleKmerStats (VariantClusterHaplotypes.cpp:235-372) ----
-__device__ inline void update_kmer_stats_cache(const Vx &c, const GParams &P, uint32_t k, uint16_t h1, uint16_t h2, uint32_t s, uint8_t mult) {
+__device__ inline void update_kmer_stats_cache(const Vx &c, const GParams BT_CAS &P, uint32_t k, uint16_t h1, uint16_t h2, uint32_t s, uint8_t mult) {
     double kmer_count = 0;
     if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
     for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
@@ -581,15 +624,17 @@ __device__ inline void add_haplotype_kmer_stats(const Vx &c, uint32_t s, uint32_
     for (uint32_t var = 0; var < c.V; ++var) {
         const uint32_t a = c.hap_allele(h, var);
         if (is_missing(c, var, a)) {
-            if (last_non_missing != 0xFFFFFFFFu) aks_add(c.astats(s, var, a), c.ksc(s, which, last_non_missing));
+            if (last_non_missing != 0xFFFFFFFFu) aks_add(c.astats(s, var, a), ks_load(c.ksc(s, which, last_non_missing)));
         } else {
-            aks_add(c.astats(s, var, a), c.ksc(s, which, var));
+            aks_add(c.astats(s, var, a), ks_load(c.ksc(s, which, var)));
             last_non_missing = var;
         }
     }
 }
 
-__device__ inline void update_allele_kmer_stats(const Vx &c, const GParams &P, uint32_t nsub_u, uint32_t nsub_m) {   // :235-298
+__device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {   // :235-298
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
     SPtr<uint16_t, LANES> dip = c.dip();
     SPtr<uint8_t, LANES> upd = c.ksc_upd();
     for (uint32_t s = 0; s < P.S; ++s) {
@@ -616,16 +661,20 @@ __device__ inline void update_allele_kmer_stats(const Vx &c, const GParams &P, u
         if (h2 != NOHAP) add_haplotype_kmer_stats(c, s, 1, h2);
         const uint32_t nn = c.nest_n()[s];
         for (uint32_t j = 0; j < nn; ++j)   // addNestedHaplotypeKmerStats (:360-372)
-            for (uint32_t var = 0; var < c.V; ++var) aks_add(c.astats(s, var, (uint32_t)c.var_na(var) - 1u), c.nest_stats(s, j));
+            for (uint32_t var = 0; var < c.V; ++var) aks_add(c.astats(s, var, (uint32_t)c.var_na(var) - 1u), ks_load(c.nest_stats(s, j)));
     }
 }
 
 // ---- sampleDiplotypes / sampleDiplotype / calcDiplotypeLogProb (VariantClusterGenotyper.cpp:597-755) ----
-__device__ inline void sample_diplotypes(const Vx &c, const GParams &P, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+__device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool collect, uint32_t trace_word, bool tracing, uint32_t *trace_buf) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    const SPtr<uint32_t, LANES> trace_row{(uint32_t BT_GAS *)uniform_ptr(trace_buf), trace_word};
     SPtr<uint32_t, LANES> sc = c.sc();
     const uint32_t nsub_u = sc[SC_NSUB_U], nsub_m = sc[SC_NSUB_M];
     const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
     uint32_t hap_count = sc[SC_HAP_COUNT];
+    Mt rng = mt_open(c.mt(0));
     SPtr<uint16_t, LANES> nzl = c.nzlist();
     SPtr<double, LANES> freq = c.freq(), cum = c.cum();
     SPtr<uint16_t, LANES> dip = c.dip();
@@ -644,12 +693,12 @@ __device__ inline void sample_diplotypes(const Vx &c, const GParams &P, bool col
         if (ploidy == 2) {
             for (uint32_t a = 0; a < nnz; ++a) {
                 const uint16_t ha = nzl[a];
-                const double lfa = log(freq[ha]);
+                const double lfa = bt_log(freq[ha]);
                 for (uint32_t b = a; b < nnz; ++b) {
                     const uint16_t hb = nzl[b];
                     double lp = 0;
                     if (a == b) lp += 2 * lfa;
-                    else lp += BT_LN2 + lfa + log(freq[hb]);
+                    else lp += BT_LN2 + lfa + bt_log(freq[hb]);
                     lp += unique_log_prob(c, P, s, ha, hb, nsub_u);
                     if (use_multi) lp += multi_log_prob(c, P, s, ha, hb, p1, p2, nsub_m);
                     run = ncand == 0 ? lp : log_addition(lp, run);
@@ -660,7 +709,7 @@ __device__ inline void sample_diplotypes(const Vx &c, const GParams &P, bool col
             for (uint32_t a = 0; a < nnz; ++a) {
                 const uint16_t ha = nzl[a];
                 double lp = 0;
-                lp += log(freq[ha]);
+                lp += bt_log(freq[ha]);
                 lp += unique_log_prob(c, P, s, ha, NOHAP, nsub_u);
                 if (use_multi) lp += multi_log_prob(c, P, s, ha, NOHAP, p1, p2, nsub_m);
                 run = ncand == 0 ? lp : log_addition(lp, run);
@@ -671,7 +720,7 @@ __device__ inline void sample_diplotypes(const Vx &c, const GParams &P, bool col
             run = 0;
         }
         // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome
-        const double u = log(rng_canonical(c.mt(0))) + run;
+        const double u = bt_log(rng_canonical(rng)) + run;
         uint32_t pick = 0;
         if (ncand > 1) {
             uint32_t lo = 0, hi = ncand;   // upper_bound: first index with cum > u
@@ -702,48 +751,55 @@ __device__ inline void sample_diplotypes(const Vx &c, const GParams &P, bool col
         if (tracing) trace_row[s] = (uint32_t)h1 | ((uint32_t)h2 << 16);
         if (collect) dip_table_add(c, P, h1, h2, s);
     }
+    mt_close(rng);
     sc[SC_HAP_COUNT] = hap_count;
-    if (collect) update_allele_kmer_stats(c, P, nsub_u, nsub_m);
+#ifndef ABL_NOSTATS
+    if (collect) update_allele_kmer_stats(env, vtx, nsub_u, nsub_m);
+#endif
     sc[SC_USE_MULTI] = nsub_m != 0 ? 1u : 0u;
 }
 
 // ---- SparseFrequencyDistribution::updateCachedSimplexProbVector (FrequencyDistribution.cpp:143-196) -> out[], returns length ----
+// Every lgamma argument in that formula is a positive integer (<= H + 2S + 1): the values come from a host-computed table.
 template <typename Q>
-__device__ inline uint32_t simplex_prob_vector(const Vx &c, Q out, uint32_t total_obs, uint32_t plus_size) {
+__device__ inline uint32_t simplex_prob_vector(const Vx &c, const GParams BT_CAS &P, Q out, uint32_t total_obs, uint32_t plus_size) {
     const uint32_t Hn = c.H;
+    const double BT_GAS *lg = P.lgamma_int;
     const double sparsity = c.sparsity();
-    const double lsp = log(sparsity), l1sp = log(1 - sparsity);
+    const double lsp = bt_log(sparsity), l1sp = bt_log(1 - sparsity);
     double prob_z_log = plus_size * lsp + (Hn - plus_size) * l1sp;
-    double prob_t_log = lgamma(plus_size * 1.0) - lgamma(total_obs + plus_size * 1.0);
+    double prob_t_log = lg[plus_size] - lg[total_obs + plus_size];
     double prob_eq_z_log = 0.0 + prob_z_log + prob_t_log;
     double row_sum = prob_eq_z_log;
     uint32_t n = 0;
     out[n++] = row_sum;
     double prev = row_sum;
     for (uint32_t j = plus_size + 1; j < Hn + 1; ++j) {
-        const double cardinal = lgamma((double)(Hn - plus_size + 1)) - (lgamma((double)(j - plus_size + 1)) + lgamma((double)(Hn - j + 1)));
+        const double cardinal = lg[Hn - plus_size + 1] - (lg[j - plus_size + 1] + lg[Hn - j + 1]);
         prob_z_log = j * lsp + (Hn - j) * l1sp;
-        prob_t_log = lgamma(j * 1.0) - lgamma(total_obs + j * 1.0);
+        prob_t_log = lg[j] - lg[total_obs + j];
         prob_eq_z_log = cardinal + prob_z_log + prob_t_log;
-        row_sum += log(1 + exp(prob_eq_z_log - row_sum));
+        row_sum += bt_log(1 + bt_exp(prob_eq_z_log - row_sum));
         out[n++] = row_sum;
         const double a = row_sum, b = prev;
         const double mn = a < b ? a : b;
         prev = row_sum;
         if (a == b || fabs(a - b) < fabs(mn) * BT_DBL_EPS * 100) break;   // Utils::doubleCompare
     }
-    for (uint32_t i = 0; i < n; ++i) out[i] = exp(out[i] - row_sum);
+    for (uint32_t i = 0; i < n; ++i) out[i] = bt_exp((double)out[i] - row_sum);
     return n;
 }
 
 // ---- sampleHaplotypeFrequencies (VariantClusterGenotyper.cpp:781-785 -> HaplotypeFrequencyDistribution.cpp:127-138
 //      -> FrequencyDistribution.cpp:75-93 / 209-303) ----
-__device__ inline void sample_haplotype_frequencies(const Vx &c) {
-    const TileDesc &d = c.d();
+__device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    const TileDesc BT_CAS &d = c.d();
     SPtr<uint32_t, LANES> sc = c.sc();
     const uint32_t n_obs = sc[SC_HAP_COUNT];
     if (n_obs > 0) {
-        uint32_t *rng = c.mt(1);
+        Mt rng = mt_open(c.mt(1));
         const NormalState nd = c.fnd();
         SPtr<uint32_t, LANES> obs = c.obs();
         SPtr<double, LANES> freq = c.freq();
@@ -767,14 +823,14 @@ __device__ inline void sample_haplotype_frequencies(const Vx &c) {
             SPtr<double, LANES> vec = c.simplex();
             if (d.scache_n && n_obs <= 2 * d.S && plus_size <= d.scache_p) {
                 const uint32_t ci = (n_obs - 1) * d.scache_p + (plus_size - 1);
-                vec = c.scache() + (size_t)ci * d.scache_len;
+                vec = c.scache() + (uint32_t)ci * d.scache_len;
                 len = c.sclen()[ci];
                 if (len == 0) {
-                    len = simplex_prob_vector(c, vec, n_obs, plus_size);
+                    len = simplex_prob_vector(c, P, vec, n_obs, plus_size);
                     c.sclen()[ci] = len;
                 }
             } else
-                len = simplex_prob_vector(c, vec, n_obs, plus_size);
+                len = simplex_prob_vector(c, P, vec, n_obs, plus_size);
             const double u = rng_canonical(rng);
             uint32_t ub = 0;
             while (ub < len && !(u < vec[ub])) ++ub;   // upper_bound over a non-decreasing vector
@@ -816,6 +872,7 @@ __device__ inline void sample_haplotype_frequencies(const Vx &c) {
                 obs[e] = 0;
             }
         }
+        mt_close(rng);
     }
     sc[SC_HAP_COUNT] = 0;
 }

@@ -25,15 +25,53 @@ namespace bt {
 
 #define BT_HD __host__ __device__ inline
 
+// fp64 transcendental functions.  On the device they are out-of-line: ocml's double-precision log/exp/log1p/pow need many
+// registers; keeping them as separate functions keeps the samplers' own allocation small enough for 2-4 waves per SIMD.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BT_MATH __host__ __device__ __noinline__
+#else
+#define BT_MATH __host__ __device__ inline
+#endif
+BT_MATH double bt_log(double x) { return log(x); }
+BT_MATH double bt_exp(double x) { return exp(x); }
+BT_MATH double bt_log1p(double x) { return log1p(x); }
+BT_MATH double bt_pow(double x, double y) { return pow(x, y); }
+
 // Pointer with an element stride: element i lives at p[i * STRIDE].  STRIDE = 1 is an ordinary array; STRIDE = 64 is the
 // lane-interleaved layout of the Gibbs tiles (element i of all 64 lanes of a wavefront adjacent in memory, so a wave-uniform
 // index is one coalesced transaction).
+// Represented as a (wave-uniform) base pointer plus a 32-bit element offset, so that on the device an access is
+// "scalar base + one vector offset register" instead of a 64-bit per-lane pointer pair; on the device the base is
+// typed as a GLOBAL-address-space pointer so that the compiler emits global_* rather than flat_* instructions.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BT_GAS __attribute__((address_space(1)))
+#define BT_CAS __attribute__((address_space(4)))   // read-only ("constant") global memory: eligible for scalar loads
+#else
+#define BT_GAS
+#define BT_CAS
+#endif
 template <typename T, unsigned STRIDE>
 struct SPtr {
-    T *p;
-    BT_HD T &operator[](size_t i) const { return p[i * STRIDE]; }
-    BT_HD SPtr<T, STRIDE> operator+(size_t i) const { return SPtr<T, STRIDE>{p + i * STRIDE}; }
+    T BT_GAS *base;
+    uint32_t off;
+    BT_HD T BT_GAS &operator[](uint32_t i) const { return base[off + i * STRIDE]; }
+    BT_HD SPtr<T, STRIDE> operator+(uint32_t i) const { return SPtr<T, STRIDE>{base, off + i * STRIDE}; }
 };
+template <typename T>
+BT_HD SPtr<T, 1> sptr1(T *p) { return SPtr<T, 1>{(T BT_GAS *)p, 0u}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+// tell the compiler that a pointer handed through a non-inlined call is wave-uniform (it then lives in scalar registers and
+// loads through it can be scalar / use the scalar-base addressing mode)
+template <typename T>
+__device__ inline T *uniform_ptr(T *p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T *)(((uint64_t)hi << 32) | lo);
+}
+#else
+template <typename T>
+__host__ __device__ inline T *uniform_ptr(T *p) { return p; }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // mt19937: st[0..623] state words, st[624] position
@@ -55,33 +93,65 @@ BT_HD void mt_seed(uint32_t *st, uint32_t seed) {
 // position p, only words that the block form has in the same old/new state (p+1 is still old, p+397 mod 624 is old for
 // p < 227 and already new afterwards), so the output stream is identical — and no lane ever runs a 624-step refill loop
 // while its wavefront neighbours wait.
-BT_HD uint32_t mt_next(uint32_t *st) {
-    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAG = 0x9908b0dfu;
-    const uint32_t p = st[MT_N];
-    const uint32_t p1 = p + 1 == MT_N ? 0 : p + 1;
-    const uint32_t pm = p + MT_M >= MT_N ? p + MT_M - MT_N : p + MT_M;
-    const uint32_t y = (st[p] & UPPER) | (st[p1] & LOWER);
-    uint32_t z = st[pm] ^ (y >> 1) ^ ((y & 1u) ? MAG : 0u);
-    st[p] = z;
-    st[MT_N] = p1;
+// A generator in use: state words in memory + the position held in a register for the duration of a call sequence
+// (mt_open loads it, mt_close writes it back).  With the position in a register the three state loads of a draw have
+// independent addresses, i.e. ONE memory round trip per draw instead of a dependent chain of four.
+struct Mt {
+    uint32_t BT_GAS *st;
+    uint32_t pos;
+};
+BT_HD Mt mt_open(uint32_t *st) { return Mt{(uint32_t BT_GAS *)st, ((uint32_t BT_GAS *)st)[MT_N]}; }
+BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
+
+BT_HD uint32_t mt_temper(uint32_t z) {
     z ^= (z >> 11);
     z ^= (z << 7) & 0x9d2c5680u;
     z ^= (z << 15) & 0xefc60000u;
     z ^= (z >> 18);
     return z;
 }
+BT_HD uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {   // new word from (st[p], st[p+1], st[p+397])
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+BT_HD uint32_t mt_wrap(uint32_t i) { return i >= MT_N ? i - MT_N : i; }
 
-// generate_canonical<double, 53>(mt19937)
-BT_HD double rng_canonical(uint32_t *st) {
-    double sum = (double)mt_next(st);
-    sum += (double)mt_next(st) * 4294967296.0;
+BT_HD uint32_t mt_next(Mt &m) {
+#ifdef ABL_MT
+    uint32_t x = m.st[0]; x ^= x << 13; x ^= x >> 17; x ^= x << 5; m.st[0] = x; return x;
+#endif
+    const uint32_t p = m.pos, p1 = mt_wrap(p + 1), pm = mt_wrap(p + MT_M);
+    const uint32_t z = mt_twist(m.st[p], m.st[p1], m.st[pm]);
+    m.st[p] = z;
+    m.pos = p1;
+    return mt_temper(z);
+}
+
+// generate_canonical<double, 53>(mt19937): two draws fused so that all five state loads are issued together
+// (draw 2 reads st[p+1] as it was BEFORE draw 1 replaced st[p]; draw 1 does not modify st[p+1])
+BT_HD double rng_canonical(Mt &m) {
+#ifdef ABL_MT
+    double s0 = (double)mt_next(m); s0 += (double)mt_next(m) * 4294967296.0; double r0 = s0 / 18446744073709551616.0; return r0 >= 1.0 ? 0.99999999999999988897769753748434595763683319091796875 : r0;
+#endif
+    const uint32_t p = m.pos, p1 = mt_wrap(p + 1), p2 = mt_wrap(p + 2), pm = mt_wrap(p + MT_M), pm1 = mt_wrap(p + MT_M + 1);
+    const uint32_t a = m.st[p], b = m.st[p1], c = m.st[p2], d = m.st[pm];
+    // st[pm1] may be the word draw 1 has just replaced (only when p + 398 wraps onto p, impossible: 398 < 624) — always an independent word
+    const uint32_t e = m.st[pm1];
+    const uint32_t z0 = mt_twist(a, b, d);
+    // draw 2 needs st[p+398]: if that index equals p (never) it would need z0
+    const uint32_t z1 = mt_twist(b, c, e);
+    m.st[p] = z0;
+    m.st[p1] = z1;
+    m.pos = p2;
+    double sum = (double)mt_temper(z0);
+    sum += (double)mt_temper(z1) * 4294967296.0;
     double ret = sum / 18446744073709551616.0;
     if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;   // nextafter(1, 0)
     return ret;
 }
 
 // uniform_int_distribution<>(0, b) for b < 2^32 - 1: range = b + 1
-BT_HD uint32_t rng_uniform_int(uint32_t *st, uint32_t range) {
+BT_HD uint32_t rng_uniform_int(Mt &st, uint32_t range) {
     uint64_t product = (uint64_t)mt_next(st) * (uint64_t)range;
     uint32_t low = (uint32_t)product;
     if (low < range) {
@@ -94,11 +164,11 @@ BT_HD uint32_t rng_uniform_int(uint32_t *st, uint32_t range) {
     return (uint32_t)(product >> 32);
 }
 
-BT_HD bool rng_bernoulli(uint32_t *st, double p) { return rng_canonical(st) < p; }
+BT_HD bool rng_bernoulli(Mt &st, double p) { return rng_canonical(st) < p; }
 
 // std::shuffle over a uint32 array in caller memory
 template <typename Arr>
-BT_HD void rng_shuffle_u32(uint32_t *st, Arr a, uint32_t n) {
+BT_HD void rng_shuffle_u32(Mt &st, Arr a, uint32_t n) {
     if (n == 0) return;
     const uint64_t urngrange = 0xFFFFFFFFull;
     if (urngrange / n >= n) {
@@ -128,11 +198,11 @@ BT_HD void rng_shuffle_u32(uint32_t *st, Arr a, uint32_t n) {
 
 // normal_distribution<double>(0,1) + gamma_distribution<double>; `nd` holds {saved value, saved_available flag}
 struct NormalState {   // references to wherever the caller keeps the two fields
-    double *saved;
-    uint32_t *available;
+    double BT_GAS *saved;
+    uint32_t BT_GAS *available;
 };
 
-BT_HD double rng_normal(uint32_t *st, NormalState nd) {
+BT_HD double rng_normal(Mt &st, NormalState nd) {
     double ret;
     if (*nd.available) {
         *nd.available = 0;
@@ -144,7 +214,7 @@ BT_HD double rng_normal(uint32_t *st, NormalState nd) {
             y = 2.0 * rng_canonical(st) - 1.0;
             r2 = x * x + y * y;
         } while (r2 > 1.0 || r2 == 0.0);
-        const double mult = sqrt(-2 * log(r2) / r2);
+        const double mult = sqrt(-2 * bt_log(r2) / r2);
         *nd.saved = x * mult;
         *nd.available = 1;
         ret = y * mult;
@@ -153,7 +223,7 @@ BT_HD double rng_normal(uint32_t *st, NormalState nd) {
     return ret;
 }
 
-BT_HD double rng_gamma(uint32_t *st, NormalState nd, double alpha, double beta) {
+BT_HD double rng_gamma(Mt &st, NormalState nd, double alpha, double beta) {
     const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
     const double a1 = malpha - 1.0 / 3.0;
     const double a2 = 1.0 / sqrt(9.0 * a1);
@@ -165,11 +235,11 @@ BT_HD double rng_gamma(uint32_t *st, NormalState nd, double alpha, double beta) 
         } while (v <= 0.0);
         v = v * v * v;
         u = rng_canonical(st);
-    } while (u > 1.0 - 0.0331 * n * n * n * n && (log(u) > (0.5 * n * n + a1 * (1.0 - v + log(v)))));
+    } while (u > 1.0 - 0.0331 * n * n * n * n && (bt_log(u) > (0.5 * n * n + a1 * (1.0 - v + bt_log(v)))));
     if (alpha == malpha) return a1 * v * beta;
     do u = rng_canonical(st);
     while (u == 0.0);
-    return pow(u, 1.0 / alpha) * a1 * v * beta;
+    return bt_pow(u, 1.0 / alpha) * a1 * v * beta;
 }
 
 // ------------------------------------------------------------------------------------------------------------
