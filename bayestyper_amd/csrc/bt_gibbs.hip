@@ -196,6 +196,7 @@ __global__ __launch_bounds__(LANES, GIBBS_WAVES) void gibbs_kernel(const TileDes
                 group_sweep(env, t, P, true, nvert, nsrc, r.row, r.on);
             }
         }
+        for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
     } else if (op == OP_INIT_CHAIN) {
         group_init_chain(env, arg0, nvert, nsrc, gindex);
     } else if (op == OP_SWEEP) {
@@ -203,6 +204,8 @@ __global__ __launch_bounds__(LANES, GIBBS_WAVES) void gibbs_kernel(const TileDes
             const TraceRow r = trace_row_for(t, P, tr, tile);
             group_sweep(env, t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
         }
+        if (arg1 != 0)
+            for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
     } else if (op == OP_NOISE) {
         // VariantClusterGenotyper::getNoiseCounts (:757-779) for every vertex, then clearCache
         for (uint32_t v = 0; v < nvert; ++v) {
@@ -330,7 +333,7 @@ const uint32_t kElemSize[A_COUNT] = {
     /*MT*/ 4, /*FNDSAVED*/ 8, /*SPARSITY*/ 8, /*UNIQ*/ 4, /*MULTI*/ 4, /*USUB*/ 4, /*MSUB*/ 4, /*SMM*/ 1, /*DIP*/ 2, /*FREQ*/ 8, /*OBS*/ 4, /*NZ*/ 1,
     /*ZHDR*/ 4, /*ZBKT*/ 4, /*PHDR*/ 4, /*PBKT*/ 4, /*UNEXT*/ 4, /*HVCOUNT*/ 4, /*UCACHE*/ 8, /*UCTAG*/ 4, /*CUM*/ 8, /*NZLIST*/ 2, /*SIMPLEX*/ 8,
     /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*SC*/ 4,
-    /*EDGES*/ 4, /*COVER*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1};
+    /*EDGES*/ 4, /*COVER*/ 1, /*PEND*/ 4, /*PENDDIP*/ 2, /*PENDVALID*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1};
 
 }  // namespace
 
@@ -532,6 +535,9 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_SC] = nv * SC_COUNT;
         len[A_EDGES] = nv * std::max<uint32_t>(d.NEm, 1);
         len[A_COVER] = nv * d.Km;
+        len[A_PEND] = nv * S;
+        len[A_PENDDIP] = nv * 2 * S;
+        len[A_PENDVALID] = nv * S;
         len[A_SOURCES] = nv;
         len[A_STACK] = 2 * (nv + 1);
         len[A_BRNG] = MT_PAD;

@@ -87,6 +87,9 @@ enum TileArr {
     A_SC,           // u32 [V] SC_COUNT
     A_EDGES,        // u32 [V] NEm
     A_COVER,        // u8  [V] Km
+    A_PEND,         // u32 [V] S    collected sweeps not yet materialised for the sample (run-length of identical contributions)
+    A_PENDDIP,      // u16 [V] 2*S  the diplotype those pending sweeps drew
+    A_PENDVALID,    // u8  [V] S
     A_SOURCES,      // u32 [G] nvm
     A_STACK,        // u32 [G] 2*(nvm+1)
     A_BRNG,         // u32 [G] per-lane contiguous MT_PAD
@@ -189,6 +192,9 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
     __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
     __device__ inline SPtr<uint8_t, LANES> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
+    __device__ inline SPtr<uint32_t, LANES> pend() const { return a<uint32_t>(A_PEND, d().S); }
+    __device__ inline SPtr<uint16_t, LANES> pend_dip() const { return a<uint16_t>(A_PENDDIP, 2 * d().S); }
+    __device__ inline SPtr<uint8_t, LANES> pend_valid() const { return a<uint8_t>(A_PENDVALID, d().S); }
     __device__ inline double BT_GAS &fnd_saved() const { return a<double>(A_FNDSAVED, 1)[0]; }
     __device__ inline double BT_GAS &sparsity() const { return a<double>(A_SPARSITY, 1)[0]; }
     __device__ inline NormalState fnd() const { return NormalState{&fnd_saved(), &sc()[SC_FND_AVAIL]}; }
@@ -377,6 +383,8 @@ __device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t
         dip[2 * s] = NOHAP;
         dip[2 * s + 1] = NOHAP;
         upd[s] = 1;
+        c.pend()[s] = 0;
+        c.pend_valid()[s] = 0;
     }
     {
         const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, c.v * 2)[0];
@@ -553,7 +561,7 @@ __device__ inline void hfd_increment(const Vx &c, uint16_t h, bool is_sparse, ui
 }
 
 // ---- diplotype_sampling_frequencies (VariantClusterGenotyper.cpp:692-696) as an open-addressing table ----
-__device__ inline void dip_table_add(const Vx &c, const GParams BT_CAS &P, uint16_t h1, uint16_t h2, uint32_t s) {
+__device__ inline void dip_table_add(const Vx &c, const GParams BT_CAS &P, uint16_t h1, uint16_t h2, uint32_t s, uint32_t times) {
     const uint32_t key = ((uint32_t)h1 | ((uint32_t)h2 << 16));
     // stored tag: key + 1 (0 = empty slot); the null diplotype (NOHAP, NOHAP) would wrap to 0 and is stored as 0xFFFFFFFF,
     // which no other key + 1 can equal because haplotype indices are < 0xFFFE
@@ -566,11 +574,11 @@ __device__ inline void dip_table_add(const Vx &c, const GParams BT_CAS &P, uint1
         if (tag == 0) {
             keys[slot] = want;
             c.sc()[SC_DIP_ENTRIES] += 1;
-            freq[(uint32_t)slot * P.S + s] += 1;
+            freq[(uint32_t)slot * P.S + s] += times;
             return;
         }
         if (tag == want) {
-            freq[(uint32_t)slot * P.S + s] += 1;
+            freq[(uint32_t)slot * P.S + s] += times;
             return;
         }
         slot = (slot + 1u) & mask;
@@ -632,14 +640,129 @@ __device__ inline void add_haplotype_kmer_stats(const Vx &c, uint32_t s, uint32_
     }
 }
 
-__device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {   // :235-298
+// r repetitions of KmerStats::addValue(value) on a register copy.  Once an accumulator has converged onto the value
+// (delta == 0 and the non-zero fraction saturated) every further addValue only increments the count, so the remaining
+// repetitions collapse into one exact addition.
+__device__ inline void ks_add_rep(KS &k, double value, uint32_t r) {
+    const double nzv = value == 0.0 ? 0.0 : 1.0;
+    for (uint32_t i = 0; i < r; ++i) {
+        if (k.m == value && k.f == nzv && k.c > 0.0) {
+            k.c += (double)(r - i);
+            return;
+        }
+        ks_add_r(k, value);
+    }
+}
+
+// the source KmerStats a haplotype contributes to variant `var` (add_haplotype_kmer_stats' missing-allele rule), or count < 0 for "skip"
+__device__ inline bool hap_source(const Vx &c, uint32_t s, uint32_t which, uint16_t h, uint32_t var, uint32_t &last_non_missing, uint32_t &allele, KS &src) {
+    allele = c.hap_allele(h, var);
+    if (is_missing(c, var, allele)) {
+        if (last_non_missing == 0xFFFFFFFFu) return false;
+        src = ks_load(c.ksc(s, which, last_non_missing));
+        return true;
+    }
+    src = ks_load(c.ksc(s, which, var));
+    last_non_missing = var;
+    return true;
+}
+
+// Materialise `r` identical collected sweeps of sample s that drew diplotype (h1, h2) while its k-mer-stats cache stayed
+// unchanged: diplotype_sampling_frequencies += r and, per allele cell, the reference's exact sequence of addKmerStats calls
+// replayed r times in registers (h1's contribution then h2's, interleaved when both hit the same cell).
+__device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t r) {
+    dip_table_add(c, P, h1, h2, s, r);
+    if (h1 == NOHAP) return;
+    uint32_t last1 = 0xFFFFFFFFu, last2 = 0xFFFFFFFFu;
+    for (uint32_t var = 0; var < c.V; ++var) {
+        uint32_t a1 = 0, a2 = 0;
+        KS s1{0, 0, 0, 0}, s2{0, 0, 0, 0};
+        const bool ok1 = hap_source(c, s, 0, h1, var, last1, a1, s1);
+        const bool ok2 = h2 != NOHAP && hap_source(c, s, 1, h2, var, last2, a2, s2);
+        if (ok1 && ok2 && a1 == a2) {
+            SPtr<double, LANES> cell = c.astats(s, var, a1);
+            KS a = ks_load(cell), b = ks_load(cell + 4), m = ks_load(cell + 8);
+            if (r == 1 || (s1.c == s2.c && s1.f == s2.f && s1.m == s2.m)) {
+                // identical sources (or a single sweep): 2r applications of the same value per statistic
+                for (uint32_t rep = 0; rep < (r == 1 ? 1u : 0u); ++rep) {
+                    ks_add_r(a, s1.c);
+                    if (s1.c != 0.0) { ks_add_r(b, s1.f); ks_add_r(m, s1.m); }
+                    ks_add_r(a, s2.c);
+                    if (s2.c != 0.0) { ks_add_r(b, s2.f); ks_add_r(m, s2.m); }
+                }
+                if (r > 1) {
+                    ks_add_rep(a, s1.c, 2 * r);
+                    if (s1.c != 0.0) { ks_add_rep(b, s1.f, 2 * r); ks_add_rep(m, s1.m, 2 * r); }
+                }
+            } else {
+                for (uint32_t rep = 0; rep < r; ++rep) {
+                    ks_add_r(a, s1.c);
+                    if (s1.c != 0.0) { ks_add_r(b, s1.f); ks_add_r(m, s1.m); }
+                    ks_add_r(a, s2.c);
+                    if (s2.c != 0.0) { ks_add_r(b, s2.f); ks_add_r(m, s2.m); }
+                }
+            }
+            ks_store(cell, a);
+            ks_store(cell + 4, b);
+            ks_store(cell + 8, m);
+        } else {
+            if (ok1) {
+                SPtr<double, LANES> cell = c.astats(s, var, a1);
+                KS a = ks_load(cell), b = ks_load(cell + 4), m = ks_load(cell + 8);
+                ks_add_rep(a, s1.c, r);
+                if (s1.c != 0.0) { ks_add_rep(b, s1.f, r); ks_add_rep(m, s1.m, r); }
+                ks_store(cell, a);
+                ks_store(cell + 4, b);
+                ks_store(cell + 8, m);
+            }
+            if (ok2) {
+                SPtr<double, LANES> cell = c.astats(s, var, a2);
+                KS a = ks_load(cell), b = ks_load(cell + 4), m = ks_load(cell + 8);
+                ks_add_rep(a, s2.c, r);
+                if (s2.c != 0.0) { ks_add_rep(b, s2.f, r); ks_add_rep(m, s2.m, r); }
+                ks_store(cell, a);
+                ks_store(cell + 4, b);
+                ks_store(cell + 8, m);
+            }
+        }
+    }
+}
+
+__device__ inline void flush_sample(const Vx &c, const GParams BT_CAS &P, uint32_t s) {
+    const uint32_t r = c.pend()[s];
+    if (r == 0) return;
+    c.pend()[s] = 0;
+    replay_collected(c, P, s, c.pend_dip()[2 * s], c.pend_dip()[2 * s + 1], r);
+}
+
+// materialise everything still pending (end of a launch: results may be read next)
+__device__ __noinline__ void flush_vertex(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
-    SPtr<uint16_t, LANES> dip = c.dip();
-    SPtr<uint8_t, LANES> upd = c.ksc_upd();
+    for (uint32_t s = 0; s < P.S; ++s) flush_sample(c, P, s);
+}
+
+// One collected sweep of a vertex: diplotype_sampling_frequencies (VariantClusterGenotyper.cpp:692-696) and
+// updateAlleleKmerStats (VariantClusterHaplotypes.cpp:235-298).  A sample whose diplotype and k-mer-stats cache are the
+// same as in the previous collected sweep contributes exactly the same updates again; those are counted (pend) and
+// replayed later instead of being read-modify-written in HBM every sweep.
+__device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    SPtr<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
+    SPtr<uint8_t, LANES> upd = c.ksc_upd(), pvalid = c.pend_valid();
     for (uint32_t s = 0; s < P.S; ++s) {
         const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
-        if (upd[s]) {
+        const uint8_t u = upd[s];
+        const uint32_t nn = c.nest_n()[s];
+#ifndef ABL_NODEFER
+        if (pvalid[s] && !u && nn == 0 && pdip[2 * s] == h1 && pdip[2 * s + 1] == h2) {
+            c.pend()[s] += 1;
+            continue;
+        }
+        flush_sample(c, P, s);
+#endif
+        if (u) {
             upd[s] = 0;
             for (uint32_t var = 0; var < c.V; ++var) {
                 ks_reset(c.ksc(s, 0, var));
@@ -657,11 +780,12 @@ __device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uin
                 }
             }
         }
-        if (h1 != NOHAP) add_haplotype_kmer_stats(c, s, 0, h1);
-        if (h2 != NOHAP) add_haplotype_kmer_stats(c, s, 1, h2);
-        const uint32_t nn = c.nest_n()[s];
+        replay_collected(c, P, s, h1, h2, 1);
         for (uint32_t j = 0; j < nn; ++j)   // addNestedHaplotypeKmerStats (:360-372)
             for (uint32_t var = 0; var < c.V; ++var) aks_add(c.astats(s, var, (uint32_t)c.var_na(var) - 1u), ks_load(c.nest_stats(s, j)));
+        pvalid[s] = nn == 0 ? 1 : 0;
+        pdip[2 * s] = h1;
+        pdip[2 * s + 1] = h2;
     }
 }
 
@@ -749,7 +873,6 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         hfd_increment(c, h2, is_sparse, hap_count);
         update_multicluster_multiplicities(c, P, h1, h2, p1, p2, s, nsub_m);
         if (tracing) trace_row[s] = (uint32_t)h1 | ((uint32_t)h2 << 16);
-        if (collect) dip_table_add(c, P, h1, h2, s);
     }
     mt_close(rng);
     sc[SC_HAP_COUNT] = hap_count;
