@@ -87,6 +87,11 @@ enum TileArr {
     A_SC,           // u32 [V] SC_COUNT
     A_EDGES,        // u32 [V] NEm
     A_COVER,        // u8  [V] Km
+    A_MCACHE,       // f64 [V] cache_entries  multicluster log-prob sums per (sample, diplotype)
+    A_MCTAG,        // u32 [V] cache_entries  key + 1 (0 = empty)
+    A_MCGEN,        // u32 [V] cache_entries  generation of the sample at fill time
+    A_MGEN,         // u32 [V] S              current generation per sample (bumped when the other clusters' contribution changes)
+    A_OTH,          // u8  [V] NMm*S          other clusters' multiplicity per subset k-mer at the current generation
     A_PEND,         // u32 [V] S    collected sweeps not yet materialised for the sample (run-length of identical contributions)
     A_PENDDIP,      // u16 [V] 2*S  the diplotype those pending sweeps drew
     A_PENDVALID,    // u8  [V] S
@@ -192,6 +197,11 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
     __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
     __device__ inline SPtr<uint8_t, LANES> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
+    __device__ inline SPtr<double, LANES> mcache() const { return a<double>(A_MCACHE, d().cache_entries); }
+    __device__ inline SPtr<uint32_t, LANES> mctag() const { return a<uint32_t>(A_MCTAG, d().cache_entries); }
+    __device__ inline SPtr<uint32_t, LANES> mcgen() const { return a<uint32_t>(A_MCGEN, d().cache_entries); }
+    __device__ inline SPtr<uint32_t, LANES> mgen() const { return a<uint32_t>(A_MGEN, d().S); }
+    __device__ inline SPtr<uint8_t, LANES> oth() const { return a<uint8_t>(A_OTH, d().NMm * d().S); }
     __device__ inline SPtr<uint32_t, LANES> pend() const { return a<uint32_t>(A_PEND, d().S); }
     __device__ inline SPtr<uint16_t, LANES> pend_dip() const { return a<uint16_t>(A_PENDDIP, 2 * d().S); }
     __device__ inline SPtr<uint8_t, LANES> pend_valid() const { return a<uint8_t>(A_PENDVALID, d().S); }
@@ -478,8 +488,12 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
     SPtr<uint32_t, LANES> sc = c.sc();
     sc[SC_NSUB_U] = nsu;
     sc[SC_NSUB_M] = nsm;
-    SPtr<uint8_t, LANES> smm = c.smm();
-    for (size_t i = 0; i < (uint32_t)nsm * P.S; ++i) smm[i] = 0;
+    SPtr<uint8_t, LANES> smm = c.smm(), oth = c.oth();
+    for (uint32_t i = 0; i < nsm * P.S; ++i) {
+        smm[i] = 0;
+        oth[i] = 0;
+    }
+    for (uint32_t s = 0; s < P.S; ++s) c.mgen()[s] += 1;   // a new k-mer subset invalidates the multicluster cache
     SPtr<uint8_t, LANES> upd = c.ksc_upd();
     for (uint32_t s = 0; s < P.S; ++s) upd[s] = 1;
 }
@@ -532,9 +546,33 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
     return acc;
 }
 
-// multicluster part (VariantClusterGenotyper.cpp:647-661).  The reference keeps a second cache that it patches
-// incrementally (:569-595); the patched value equals this direct sum up to floating-point re-association.
-__device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t nsub_m) {
+// multicluster part (VariantClusterGenotyper.cpp:647-661).  For a candidate d the k-mer multiplicity is
+// (shared - M[current diplotype]) + M[d] + intercluster, i.e. "what the OTHER clusters currently contribute" + own candidate.
+// The reference caches the sum per (sample, diplotype) and patches it when another cluster moved (:569-595); here the cache
+// is generation-stamped per sample: multi_refresh() compares the other clusters' contribution of every subset k-mer with a
+// snapshot and bumps the sample's generation when anything moved, which invalidates that sample's entries in O(1).  A hit
+// returns exactly the direct sum a miss would compute.
+__device__ inline void multi_refresh(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t p1, uint16_t p2, uint32_t nsub_m) {
+    SPtr<uint32_t, LANES> msub = c.msub();
+    SPtr<uint8_t, LANES> oth = c.oth(), shm = c.shared_mult();
+    bool moved = false;
+    for (uint32_t sub = 0; sub < nsub_m; ++sub) {
+        const uint32_t k = msub[sub];
+        uint8_t o = 0;
+        if (c.count(k, s) != 0) o = (uint8_t)(shm[(uint32_t)c.shared_idx(k) * P.S + s] - dip_mult(c, k, p1, p2));
+        if (o != oth[sub * P.S + s]) {
+            oth[sub * P.S + s] = o;
+            moved = true;
+        }
+    }
+    if (moved) c.mgen()[s] += 1;
+}
+__device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t nsub_m, uint32_t gen) {
+    const TileDesc BT_CAS &d = c.d();
+    const uint32_t idx = dip_index(c, h1, h2);
+    const uint32_t key = s * d.Dcm + idx + 1u;
+    const uint32_t slot = d.cache_mode == 0 ? s * d.Dcm + idx : ((key * 2654435761u) & (d.cache_entries - 1u));
+    if (c.mctag()[slot] == key && c.mcgen()[slot] == gen) return c.mcache()[slot];
     double acc = 0;
     SPtr<uint32_t, LANES> msub = c.msub();
     for (uint32_t i = 0; i < nsub_m; ++i) {
@@ -542,6 +580,9 @@ __device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, ui
         const uint8_t m = multi_mult(c, P, k, h1, h2, p1, p2, s);
         acc += count_log_prob(P, s, m, c.count(k, s));
     }
+    c.mctag()[slot] = key;
+    c.mcgen()[slot] = gen;
+    c.mcache()[slot] = acc;
     return acc;
 }
 
@@ -811,6 +852,11 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
     for (uint32_t s = 0; s < P.S; ++s) {
         const uint16_t p1 = dip[2 * s], p2 = dip[2 * s + 1];
         const uint8_t ploidy = c.nest_ploidy()[s];
+        uint32_t gen = 0;
+        if (use_multi && nsub_m) {
+            multi_refresh(c, P, s, p1, p2, nsub_m);
+            gen = c.mgen()[s];
+        }
         // candidates in the reference's order; cumulative log-sum-exp exactly as LogDiscreteSampler::addOutcome
         uint32_t ncand = 0;
         double run = 0;
@@ -824,7 +870,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                     if (a == b) lp += 2 * lfa;
                     else lp += BT_LN2 + lfa + bt_log(freq[hb]);
                     lp += unique_log_prob(c, P, s, ha, hb, nsub_u);
-                    if (use_multi) lp += multi_log_prob(c, P, s, ha, hb, p1, p2, nsub_m);
+                    if (use_multi) lp += multi_log_prob(c, P, s, ha, hb, p1, p2, nsub_m, gen);
                     run = ncand == 0 ? lp : log_addition(lp, run);
                     cum[ncand++] = run;
                 }
@@ -835,7 +881,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                 double lp = 0;
                 lp += bt_log(freq[ha]);
                 lp += unique_log_prob(c, P, s, ha, NOHAP, nsub_u);
-                if (use_multi) lp += multi_log_prob(c, P, s, ha, NOHAP, p1, p2, nsub_m);
+                if (use_multi) lp += multi_log_prob(c, P, s, ha, NOHAP, p1, p2, nsub_m, gen);
                 run = ncand == 0 ? lp : log_addition(lp, run);
                 cum[ncand++] = run;
             }
