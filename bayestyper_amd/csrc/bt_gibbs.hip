@@ -36,8 +36,15 @@ __device__ __noinline__ void group_init_chain(Env env, uint32_t chain, uint32_t 
     const uint32_t gseed = P.noise_seeding ? P.seed + (gindex + 1u) * (chain + 1u) : P.seed + (gindex + 1u);
     for (uint32_t v = 0; v < nvert; ++v) {
         const Vx c = make_vx(t, v);
-        if (!c.sc()[SC_CONSTRUCTED]) genotyper_construct(env, v, gseed + c.cid);   // VariantClusterGroup.cpp:179-182
-        genotyper_reset(env, v);
+        Env ev = env;
+        const bool swap = env.resident == 0xFFFFFFFFu && t.d->hot_bytes != 0;
+        if (swap) {
+            hot_swap(env, v, true);
+            ev.resident = v;
+        }
+        if (!make_vx(make_tile(ev), v).sc()[SC_CONSTRUCTED]) genotyper_construct(ev, v, gseed + c.cid);   // VariantClusterGroup.cpp:179-182
+        genotyper_reset(ev, v);
+        if (swap) hot_swap(env, v, false);
     }
     // shuffleBranchOrdering (VariantClusterGroup.cpp:208-218)
     if (nvert == 1 && nsrc == 1) return;   // nothing to shuffle (a fresh generator is seeded per call, no state carries over)
@@ -53,6 +60,7 @@ __device__ __noinline__ void group_init_chain(Env env, uint32_t chain, uint32_t 
 
 // VariantClusterGenotyper::updateNestedVariantClusterInfo (VariantClusterGenotyper.cpp:140-206): child's info := parent's info, updated
 __device__ __noinline__ void prepare_nested(Env env, uint32_t v_parent, uint32_t v_child) {
+    env.resident = 0xFFFFFFFFu;   // between visits every vertex's hot arrays are in HBM
     const Tile t = make_tile(env);
     const GParams BT_CAS &P = env_params(env);
     const Vx c = make_vx(t, v_parent), cc = make_vx(t, v_child);
@@ -106,13 +114,16 @@ __device__ __noinline__ void prepare_nested(Env env, uint32_t v_parent, uint32_t
     }
 }
 
-__device__ inline void visit_vertex(const Env &env, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+__device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+    Env env = env_in;
+    const bool swap = env.resident == 0xFFFFFFFFu && t.d->hot_bytes != 0;
+    if (swap) {
+        hot_swap(env, v, true);
+        env.resident = v;
+    }
     sample_diplotypes(env, v, collect, trace_row.off + v * P.S * LANES, tracing, (uint32_t *)trace_row.base);
-#ifndef ABL_NOFREQ
     sample_haplotype_frequencies(env, v);
-#else
-    make_vx(t, v).sc()[SC_HAP_COUNT] = 0;
-#endif
+    if (swap) hot_swap(env, v, false);
 }
 
 // VariantClusterGroup::estimateGenotypes + runGibbsSample (VariantClusterGroup.cpp:220-250), recursion unrolled on an explicit stack
@@ -173,17 +184,27 @@ __device__ inline TraceRow trace_row_for(const Tile &t, const GParams BT_CAS &P,
 #define GIBBS_WAVES 1
 #endif
 __global__ __launch_bounds__(LANES, GIBBS_WAVES) void gibbs_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg, int op,
-                                                       uint32_t arg0, uint32_t arg1, unsigned long long *__restrict__ hist, TraceCfg tr) {
-    const uint32_t tile = blockIdx.x;
-    const Env env{tiles, pool, Pg};
+                                                       uint32_t arg0, uint32_t arg1, unsigned long long *__restrict__ hist, TraceCfg tr, const uint32_t *__restrict__ tile_list) {
+    const uint32_t tile = tile_list ? tile_list[blockIdx.x] : blockIdx.x;
+    Env env{tiles, pool, Pg, tile_list, 0xFFFFFFFFu};
     const GParams BT_CAS &P = *(const GParams BT_CAS *)Pg;
     Tile t;
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = threadIdx.x;
+    t.hot = nullptr;
+    t.resident = 0xFFFFFFFFu;
     SPtr<uint32_t, LANES> gd = t.arr<uint32_t>(A_GDIMS);
     if (!gd[3]) return;   // padding lane of the last tile
     const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
+    // groups of ONE cluster keep that cluster's hot arrays in LDS for the whole launch; larger groups swap per vertex visit
+    const bool whole = t.d->nvm == 1 && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN);
+    if (whole) {
+        hot_swap(env, 0, true);
+        env.resident = 0;
+        t.resident = 0;
+        t.hot = lds_block();
+    }
     if (op == OP_RUN) {
         for (uint32_t chain = 0; chain < P.num_chains; ++chain) {
             group_init_chain(env, chain, nvert, nsrc, gindex);
@@ -196,7 +217,7 @@ __global__ __launch_bounds__(LANES, GIBBS_WAVES) void gibbs_kernel(const TileDes
                 group_sweep(env, t, P, true, nvert, nsrc, r.row, r.on);
             }
         }
-        for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
+        for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);   // hot arrays: LDS when resident, else HBM (both valid)
     } else if (op == OP_INIT_CHAIN) {
         group_init_chain(env, arg0, nvert, nsrc, gindex);
     } else if (op == OP_SWEEP) {
@@ -237,6 +258,7 @@ __global__ __launch_bounds__(LANES, GIBBS_WAVES) void gibbs_kernel(const TileDes
             for (uint32_t i = 0, n = vx_ne(c); i < n; ++i) e1[i] = e0[i];
         }
     }
+    if (whole) hot_swap(env, 0, false);
 }
 
 // per (cluster, sample): most frequently sampled diplotype and its frequency -> the compact posterior summary that is
@@ -252,6 +274,8 @@ __global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict
     t.d = (const TileDesc BT_CAS *)&tiles[loc[c].tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = loc[c].lane;
+    t.hot = nullptr;
+    t.resident = 0xFFFFFFFFu;
     const Vx x = make_vx(t, loc[c].v);
     SPtr<uint32_t, LANES> keys = x.dip_keys(), freq = x.dip_freq();
     const uint32_t cap = t.d->dip_cap;
@@ -307,6 +331,7 @@ struct bt_gibbs {
     std::vector<uint32_t> h_A;             // alleles per cluster
     std::vector<uint32_t> group_tile, group_lane, group_nvert;
     // trace
+    uint32_t lds_bytes = 0;               // dynamic LDS per workgroup (max hot_bytes over the tiles)
     uint32_t trace_sweeps = 0;
     uint32_t *d_trace = nullptr, *d_trace_counter = nullptr;
     uint64_t trace_words = 0;
@@ -318,12 +343,17 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     BT_HIP(hipSetDevice(g->ctx->device));
     TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
-    hipLaunchKernelGGL(gibbs_kernel, dim3(g->ntiles), dim3(LANES), 0, g->ctx->stream, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr);
+    hipLaunchKernelGGL(gibbs_kernel, dim3(g->ntiles), dim3(LANES), g->lds_bytes, g->ctx->stream, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
+                       (const uint32_t *)nullptr);
     BT_CHECK_LAUNCH();
     return BT_OK;
 }
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+#ifndef BT_HOT_BUDGET
+#define BT_HOT_BUDGET 32768
+#endif
+constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
 
 // element sizes per array, in TileArr order
 const uint32_t kElemSize[A_COUNT] = {
@@ -551,6 +581,25 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             d.off[a] = off;
             off += len[a] * LANES * kElemSize[a];
             if (a == A_PLOIDY) in_bytes = align_up(off, 256);
+        }
+        {
+            // hot arrays (bt_gibbs_tile.hpp: Vx::harr users) -> offsets inside the wavefront's LDS block
+            for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
+            const int hot_arrs[] = {A_SC, A_DIP, A_NESTPL, A_NESTN, A_KSCUPD, A_MGEN, A_PEND, A_PENDDIP, A_PENDVALID, A_FREQ, A_OBS, A_NZ, A_NZLIST,
+                                    A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_CUM};
+            uint32_t ho = 0;
+            for (int a : hot_arrs) {
+                if (a == A_CUM && d.D2m > 64) continue;
+                const uint64_t per_vertex = len[a] / nv;   // elements per lane and vertex
+                d.hoff[a] = ho;
+                ho = (uint32_t)align_up(ho + per_vertex * LANES * kElemSize[a], 16);
+            }
+            d.hot_bytes = ho;
+            if (ho > kHotBudget) {
+                for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
+                d.hot_bytes = 0;
+            }
+            g->lds_bytes = std::max(g->lds_bytes, d.hot_bytes);
         }
         d.base = pool;
         plans[ti].d = d;
@@ -965,7 +1014,7 @@ int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint6
     Mt st = mt_open(stv.data());
     double saved = 0;
     uint32_t avail = 0;
-    NormalState nd{(double BT_GAS *)&saved, (uint32_t BT_GAS *)&avail};
+    NormalState nd{(double BT_GAS *)&saved, &avail};
     switch (kind) {
         case 0:
             for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)mt_next(st);

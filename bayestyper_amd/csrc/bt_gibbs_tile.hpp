@@ -108,7 +108,10 @@ struct TileDesc {
     uint64_t base;            // byte offset of this tile in the pool
     uint64_t trace_base;      // word offset of this tile's trace block ([sweep][vertex][S][64])
     uint64_t off[A_COUNT];    // byte offsets of the arrays from the tile base
+    uint32_t hoff[A_COUNT];   // byte offset inside the wavefront's LDS block of the arrays kept resident there (NOHOT otherwise)
+    uint32_t hot_bytes, hot_pad;
 };
+constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 
 struct GParams {
     uint32_t S, seed, num_chains, burn_in, num_iterations, max_hvk, noise_seeding;
@@ -125,6 +128,15 @@ struct Tile {
     uint8_t BT_GAS *base;
     const TileDesc BT_CAS *d;
     uint32_t lane;
+    uint8_t *hot;        // this wavefront's LDS block (generic pointer) or nullptr
+    uint32_t resident;   // vertex whose hot arrays currently live in LDS (0xFFFFFFFF: none)
+    // hot-capable array: LDS when the vertex is resident, HBM otherwise; one code path through generic pointers
+    template <typename T>
+    __device__ inline SPtrF<T, LANES> harr(int a, uint32_t v, uint32_t len) const {
+        const uint32_t ho = d->hoff[a];
+        if (hot != nullptr && ho != NOHOT && v == resident) return SPtrF<T, LANES>{(T *)(hot + ho), lane};
+        return SPtrF<T, LANES>{(T *)(uint8_t *)(base + d->off[a]), v * len * LANES + lane};
+    }
     template <typename T>
     __device__ inline SPtr<T, LANES> arr(int a, uint32_t first = 0) const {
         return SPtr<T, LANES>{(T BT_GAS *)(base + d->off[a]), first * LANES + lane};
@@ -137,6 +149,8 @@ struct Env {
     const TileDesc *tiles;
     uint8_t *pool;
     const struct GParams *P;
+    const uint32_t *tile_list;   // block -> tile index (nullptr: identity)
+    uint32_t resident;           // vertex resident in LDS, 0xFFFFFFFF = none
 };
 
 struct Vx {   // vertex context: tile + vertex index + the lane's true dimensions of that vertex
@@ -162,62 +176,70 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint32_t allele_base(uint32_t var) const { return a<uint32_t>(A_ALBASE, d().Vm + 1)[var]; }
     // state
     __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)(v * 2 + g) * LANES + t.lane) * MT_PAD; }
-    __device__ inline SPtr<uint32_t, LANES> sc() const { return a<uint32_t>(A_SC, SC_COUNT); }
+    __device__ inline SPtrF<uint32_t, LANES> sc() const { return t.harr<uint32_t>(A_SC, v, SC_COUNT); }
     __device__ inline SPtr<uint32_t, LANES> uniq() const { return a<uint32_t>(A_UNIQ, d().NUm); }
     __device__ inline SPtr<uint32_t, LANES> multi() const { return a<uint32_t>(A_MULTI, d().NMm); }
     __device__ inline SPtr<uint32_t, LANES> usub() const { return a<uint32_t>(A_USUB, d().NUm); }
     __device__ inline SPtr<uint32_t, LANES> msub() const { return a<uint32_t>(A_MSUB, d().NMm); }
     __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (uint32_t)d().NMm * d().S); }
-    __device__ inline SPtr<uint16_t, LANES> dip() const { return a<uint16_t>(A_DIP, 2 * d().S); }
-    __device__ inline SPtr<double, LANES> freq() const { return a<double>(A_FREQ, d().Hm); }
-    __device__ inline SPtr<uint32_t, LANES> obs() const { return a<uint32_t>(A_OBS, d().Hm); }
-    __device__ inline SPtr<uint8_t, LANES> nz() const { return a<uint8_t>(A_NZ, d().Hm); }
-    __device__ inline SPtr<uint32_t, LANES> unext() const { return a<uint32_t>(A_UNEXT, d().Hm); }
-    __device__ inline USetT<LANES> zero_set() const { return USetT<LANES>{a<uint32_t>(A_ZHDR, 4), a<uint32_t>(A_ZBKT, d().Bcap), unext()}; }
-    __device__ inline USetT<LANES> plus_set() const { return USetT<LANES>{a<uint32_t>(A_PHDR, 4), a<uint32_t>(A_PBKT, d().Bcap), unext()}; }
+    __device__ inline SPtrF<uint16_t, LANES> dip() const { return t.harr<uint16_t>(A_DIP, v, 2 * d().S); }
+    __device__ inline SPtrF<double, LANES> freq() const { return t.harr<double>(A_FREQ, v, d().Hm); }
+    __device__ inline SPtrF<uint32_t, LANES> obs() const { return t.harr<uint32_t>(A_OBS, v, d().Hm); }
+    __device__ inline SPtrF<uint8_t, LANES> nz() const { return t.harr<uint8_t>(A_NZ, v, d().Hm); }
+    __device__ inline SPtrF<uint32_t, LANES> unext() const { return t.harr<uint32_t>(A_UNEXT, v, d().Hm); }
+    typedef USetP<SPtrF<uint32_t, LANES>> HSet;
+    __device__ inline HSet zero_set() const { return HSet{t.harr<uint32_t>(A_ZHDR, v, 4), t.harr<uint32_t>(A_ZBKT, v, d().Bcap), unext()}; }
+    __device__ inline HSet plus_set() const { return HSet{t.harr<uint32_t>(A_PHDR, v, 4), t.harr<uint32_t>(A_PBKT, v, d().Bcap), unext()}; }
     __device__ inline SPtr<uint32_t, LANES> hvcount() const { return a<uint32_t>(A_HVCOUNT, (uint32_t)d().Hm * d().Vm); }
     __device__ inline SPtr<double, LANES> ucache() const { return a<double>(A_UCACHE, d().cache_entries); }
     __device__ inline SPtr<uint32_t, LANES> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
-    __device__ inline SPtr<double, LANES> cum() const { return a<double>(A_CUM, d().D2m > 1 ? d().D2m : 1); }
-    __device__ inline SPtr<uint16_t, LANES> nzlist() const { return a<uint16_t>(A_NZLIST, d().Hm); }
+    __device__ inline SPtrF<double, LANES> cum() const { return t.harr<double>(A_CUM, v, (d().D2m > 1 ? d().D2m : 1)); }
+    __device__ inline SPtrF<uint16_t, LANES> nzlist() const { return t.harr<uint16_t>(A_NZLIST, v, d().Hm); }
     __device__ inline SPtr<double, LANES> simplex() const { return a<double>(A_SIMPLEX, d().Hm + 1); }
     __device__ inline SPtr<double, LANES> scache() const { return a<double>(A_SCACHE, (uint32_t)(d().scache_n ? d().scache_n : 1) * (d().scache_len ? d().scache_len : 1)); }
     __device__ inline SPtr<uint32_t, LANES> sclen() const { return a<uint32_t>(A_SCLEN, d().scache_n > 1 ? d().scache_n : 1); }
     __device__ inline SPtr<double, LANES> ksc(uint32_t s, uint32_t which, uint32_t var) const {
         return a<double>(A_KSC, (uint32_t)d().S * 2 * d().Vm * 4) + (((uint32_t)s * 2 + which) * d().Vm + var) * 4;
     }
-    __device__ inline SPtr<uint8_t, LANES> ksc_upd() const { return a<uint8_t>(A_KSCUPD, d().S); }
+    __device__ inline SPtrF<uint8_t, LANES> ksc_upd() const { return t.harr<uint8_t>(A_KSCUPD, v, d().S); }
     __device__ inline SPtr<uint32_t, LANES> dip_keys() const { return a<uint32_t>(A_DIPKEYS, d().dip_cap); }
     __device__ inline SPtr<uint32_t, LANES> dip_freq() const { return a<uint32_t>(A_DIPFREQ, (uint32_t)d().dip_cap * d().S); }
     __device__ inline SPtr<double, LANES> astats(uint32_t s, uint32_t var, uint32_t al) const {
         return a<double>(A_ASTATS, (uint32_t)d().S * d().Am * 12) + ((uint32_t)s * d().Am + allele_base(var) + al) * 12;
     }
-    __device__ inline SPtr<uint8_t, LANES> nest_ploidy() const { return a<uint8_t>(A_NESTPL, d().S); }
-    __device__ inline SPtr<uint8_t, LANES> nest_n() const { return a<uint8_t>(A_NESTN, d().S); }
+    __device__ inline SPtrF<uint8_t, LANES> nest_ploidy() const { return t.harr<uint8_t>(A_NESTPL, v, d().S); }
+    __device__ inline SPtrF<uint8_t, LANES> nest_n() const { return t.harr<uint8_t>(A_NESTN, v, d().S); }
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
     __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
     __device__ inline SPtr<uint8_t, LANES> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
     __device__ inline SPtr<double, LANES> mcache() const { return a<double>(A_MCACHE, d().cache_entries); }
     __device__ inline SPtr<uint32_t, LANES> mctag() const { return a<uint32_t>(A_MCTAG, d().cache_entries); }
     __device__ inline SPtr<uint32_t, LANES> mcgen() const { return a<uint32_t>(A_MCGEN, d().cache_entries); }
-    __device__ inline SPtr<uint32_t, LANES> mgen() const { return a<uint32_t>(A_MGEN, d().S); }
+    __device__ inline SPtrF<uint32_t, LANES> mgen() const { return t.harr<uint32_t>(A_MGEN, v, d().S); }
     __device__ inline SPtr<uint8_t, LANES> oth() const { return a<uint8_t>(A_OTH, d().NMm * d().S); }
-    __device__ inline SPtr<uint32_t, LANES> pend() const { return a<uint32_t>(A_PEND, d().S); }
-    __device__ inline SPtr<uint16_t, LANES> pend_dip() const { return a<uint16_t>(A_PENDDIP, 2 * d().S); }
-    __device__ inline SPtr<uint8_t, LANES> pend_valid() const { return a<uint8_t>(A_PENDVALID, d().S); }
+    __device__ inline SPtrF<uint32_t, LANES> pend() const { return t.harr<uint32_t>(A_PEND, v, d().S); }
+    __device__ inline SPtrF<uint16_t, LANES> pend_dip() const { return t.harr<uint16_t>(A_PENDDIP, v, 2 * d().S); }
+    __device__ inline SPtrF<uint8_t, LANES> pend_valid() const { return t.harr<uint8_t>(A_PENDVALID, v, d().S); }
     __device__ inline double BT_GAS &fnd_saved() const { return a<double>(A_FNDSAVED, 1)[0]; }
     __device__ inline double BT_GAS &sparsity() const { return a<double>(A_SPARSITY, 1)[0]; }
-    __device__ inline NormalState fnd() const { return NormalState{&fnd_saved(), &sc()[SC_FND_AVAIL]}; }
+    __device__ inline NormalState fnd() const { return NormalState{&fnd_saved(), &sc()[SC_FND_AVAIL]}; }   // `available` may live in LDS
     __device__ inline SPtr<uint8_t, LANES> shared_mult() const { return t.arr<uint8_t>(A_SHMULT); }
 };
+
+extern __shared__ __attribute__((aligned(16))) uint8_t bt_lds_raw[];
+__device__ inline uint8_t *lds_block() { return (uint8_t *)bt_lds_raw; }
 
 __device__ inline Tile make_tile(const Env &e_in) {
     Tile t;
     const TileDesc *tiles = uniform_ptr(e_in.tiles);
     uint8_t *pool = uniform_ptr(e_in.pool);
-    t.d = (const TileDesc BT_CAS *)&tiles[blockIdx.x];
+    const uint32_t *list = uniform_ptr(e_in.tile_list);
+    const uint32_t tile = list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x;
+    t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = threadIdx.x;
+    t.resident = e_in.resident;   // per lane: lanes of a tile may be at different vertices of their groups
+    t.hot = (t.resident != 0xFFFFFFFFu && t.d->hot_bytes) ? lds_block() : nullptr;
     return t;
 }
 __device__ inline const GParams BT_CAS &env_params(const Env &e) { return *(const GParams BT_CAS *)uniform_ptr(e.P); }
@@ -237,6 +259,44 @@ __device__ inline Vx make_vx(const Tile &t, uint32_t v) {
 }
 __device__ inline uint32_t vx_nd(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, c.v * 8)[5]; }
 __device__ inline uint32_t vx_ne(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, c.v * 8)[6]; }
+
+// ---- LDS residency of a vertex's hot arrays ----------------------------------------------------------------------
+template <typename T>
+__device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len, bool to_lds) {
+    const uint32_t ho = t.d->hoff[arr];
+    if (ho == NOHOT) return;
+    T *l = (T *)(lds_block() + ho) + t.lane;
+    T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + v * len * LANES + t.lane;
+    if (to_lds)
+        for (uint32_t i = 0; i < len; ++i) l[i * LANES] = g[i * LANES];
+    else
+        for (uint32_t i = 0; i < len; ++i) g[i * LANES] = l[i * LANES];
+}
+// move every hot array of vertex v between HBM and the wavefront's LDS block (lane-wise, coalesced)
+__device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
+    env.resident = 0xFFFFFFFFu;
+    const Tile t = make_tile(env);
+    const TileDesc BT_CAS &d = *t.d;
+    if (!d.hot_bytes) return;
+    hot_copy<uint32_t>(t, A_SC, v, SC_COUNT, to_lds);
+    hot_copy<uint16_t>(t, A_DIP, v, 2 * d.S, to_lds);
+    hot_copy<uint8_t>(t, A_NESTPL, v, d.S, to_lds);
+    hot_copy<uint8_t>(t, A_NESTN, v, d.S, to_lds);
+    hot_copy<uint8_t>(t, A_KSCUPD, v, d.S, to_lds);
+    hot_copy<uint32_t>(t, A_MGEN, v, d.S, to_lds);
+    hot_copy<uint32_t>(t, A_PEND, v, d.S, to_lds);
+    hot_copy<uint16_t>(t, A_PENDDIP, v, 2 * d.S, to_lds);
+    hot_copy<uint8_t>(t, A_PENDVALID, v, d.S, to_lds);
+    hot_copy<double>(t, A_FREQ, v, d.Hm, to_lds);
+    hot_copy<uint32_t>(t, A_OBS, v, d.Hm, to_lds);
+    hot_copy<uint8_t>(t, A_NZ, v, d.Hm, to_lds);
+    hot_copy<uint32_t>(t, A_UNEXT, v, d.Hm, to_lds);
+    hot_copy<uint32_t>(t, A_ZHDR, v, 4, to_lds);
+    hot_copy<uint32_t>(t, A_ZBKT, v, d.Bcap, to_lds);
+    hot_copy<uint32_t>(t, A_PHDR, v, 4, to_lds);
+    hot_copy<uint32_t>(t, A_PBKT, v, d.Bcap, to_lds);
+    // A_NZLIST and A_CUM are per-call scratch: resident in LDS but never copied
+}
 
 // ---- Utils::logAddition (Utils.hpp:105-124) ----
 __device__ inline double log_addition(double a, double b) {
@@ -312,9 +372,9 @@ __device__ inline uint8_t multi_mult(const Vx &c, const GParams BT_CAS &P, uint3
 // ---- FrequencyDistribution::reset / SparseFrequencyDistribution::reset (FrequencyDistribution.cpp:49-54,104-115) ----
 __device__ inline void freq_reset(const Vx &c) {
     const double f = 1 / (double)c.H;
-    SPtr<uint32_t, LANES> obs = c.obs();
-    SPtr<double, LANES> freq = c.freq();
-    SPtr<uint8_t, LANES> nz = c.nz();
+    SPtrF<uint32_t, LANES> obs = c.obs();
+    SPtrF<double, LANES> freq = c.freq();
+    SPtrF<uint8_t, LANES> nz = c.nz();
     for (uint32_t h = 0; h < c.H; ++h) {
         obs[h] = 0;
         freq[h] = f;
@@ -322,7 +382,7 @@ __device__ inline void freq_reset(const Vx &c) {
     }
     if (c.sc()[SC_IS_SPARSE]) {
         uset_clear(c.plus_set());
-        USetT<LANES> z = c.zero_set();
+        Vx::HSet z = c.zero_set();
         uset_clear(z);
         for (uint32_t h = 0; h < c.H; ++h) uset_insert(z, h);
     }
@@ -332,8 +392,8 @@ __device__ inline void freq_reset(const Vx &c) {
 // returns the cover size; uses `rng` (freshly seeded by the caller), cover_rows, obs (column sums), nzlist
 __device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
     SPtr<uint8_t, LANES> rows = c.cover_rows();
-    SPtr<uint32_t, LANES> obs = c.obs();
-    SPtr<uint16_t, LANES> nzl = c.nzlist();
+    SPtrF<uint32_t, LANES> obs = c.obs();
+    SPtrF<uint16_t, LANES> nzl = c.nzlist();
     uint32_t remaining = 0;
     for (uint32_t k = 0; k < c.K; ++k) {
         const uint8_t r = c.has_counts(k) ? 1 : 0;
@@ -379,7 +439,7 @@ __device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t
     const GParams BT_CAS &P = env_params(env);
     const TileDesc BT_CAS &d = c.d();
     mt_seed(c.mt(0), prng_seed);
-    SPtr<uint32_t, LANES> sc = c.sc();
+    SPtrF<uint32_t, LANES> sc = c.sc();
     for (uint32_t i = 0; i < SC_COUNT; ++i) sc[i] = 0;
     // a (re)built genotyper starts from the k-mer index lists in first-seen order (they are shuffled in place per chain)
     {
@@ -387,8 +447,8 @@ __device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t
         for (uint32_t i = 0; i < c.nu; ++i) u[i] = u0[i];
         for (uint32_t i = 0; i < c.nm; ++i) m[i] = m0[i];
     }
-    SPtr<uint16_t, LANES> dip = c.dip();
-    SPtr<uint8_t, LANES> upd = c.ksc_upd();
+    SPtrF<uint16_t, LANES> dip = c.dip();
+    SPtrF<uint8_t, LANES> upd = c.ksc_upd();
     for (uint32_t s = 0; s < P.S; ++s) {
         dip[2 * s] = NOHAP;
         dip[2 * s + 1] = NOHAP;
@@ -485,7 +545,7 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
             if (!is_max_hv_kmer(c, k, P.max_hvk)) msub[nsm++] = k;
     }
     mt_close(rng);
-    SPtr<uint32_t, LANES> sc = c.sc();
+    SPtrF<uint32_t, LANES> sc = c.sc();
     sc[SC_NSUB_U] = nsu;
     sc[SC_NSUB_M] = nsm;
     SPtr<uint8_t, LANES> smm = c.smm(), oth = c.oth();
@@ -494,7 +554,7 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
         oth[i] = 0;
     }
     for (uint32_t s = 0; s < P.S; ++s) c.mgen()[s] += 1;   // a new k-mer subset invalidates the multicluster cache
-    SPtr<uint8_t, LANES> upd = c.ksc_upd();
+    SPtrF<uint8_t, LANES> upd = c.ksc_upd();
     for (uint32_t s = 0; s < P.S; ++s) upd[s] = 1;
 }
 
@@ -590,7 +650,7 @@ __device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, ui
 __device__ inline void hfd_increment(const Vx &c, uint16_t h, bool is_sparse, uint32_t &hap_count) {
     if (h == NOHAP) return;   // num_missing_count is only read by an assert in the reference
     hap_count += 1;
-    SPtr<uint32_t, LANES> obs = c.obs();
+    SPtrF<uint32_t, LANES> obs = c.obs();
     const uint32_t o = obs[h];
     if (is_sparse && o == 0) {   // SparseFrequencyDistribution::incrementObservationCount (:198-207)
         // the reference inserts into plus, then erases from zero; the sets share their `next` words here, so leave
@@ -790,8 +850,8 @@ __device__ __noinline__ void flush_vertex(Env env, uint32_t vtx) {
 __device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
-    SPtr<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
-    SPtr<uint8_t, LANES> upd = c.ksc_upd(), pvalid = c.pend_valid();
+    SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
+    SPtrF<uint8_t, LANES> upd = c.ksc_upd(), pvalid = c.pend_valid();
     for (uint32_t s = 0; s < P.S; ++s) {
         const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
         const uint8_t u = upd[s];
@@ -835,17 +895,17 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const SPtr<uint32_t, LANES> trace_row{(uint32_t BT_GAS *)uniform_ptr(trace_buf), trace_word};
-    SPtr<uint32_t, LANES> sc = c.sc();
+    SPtrF<uint32_t, LANES> sc = c.sc();
     const uint32_t nsub_u = sc[SC_NSUB_U], nsub_m = sc[SC_NSUB_M];
     const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
     uint32_t hap_count = sc[SC_HAP_COUNT];
     Mt rng = mt_open(c.mt(0));
-    SPtr<uint16_t, LANES> nzl = c.nzlist();
-    SPtr<double, LANES> freq = c.freq(), cum = c.cum();
-    SPtr<uint16_t, LANES> dip = c.dip();
+    SPtrF<uint16_t, LANES> nzl = c.nzlist();
+    SPtrF<double, LANES> freq = c.freq(), cum = c.cum();
+    SPtrF<uint16_t, LANES> dip = c.dip();
     uint32_t nnz = 0;
     {
-        SPtr<uint8_t, LANES> nz = c.nz();
+        SPtrF<uint8_t, LANES> nz = c.nz();
         for (uint32_t h = 0; h < c.H; ++h)
             if (nz[h]) nzl[nnz++] = (uint16_t)h;
     }
@@ -965,14 +1025,14 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const TileDesc BT_CAS &d = c.d();
-    SPtr<uint32_t, LANES> sc = c.sc();
+    SPtrF<uint32_t, LANES> sc = c.sc();
     const uint32_t n_obs = sc[SC_HAP_COUNT];
     if (n_obs > 0) {
         Mt rng = mt_open(c.mt(1));
         const NormalState nd = c.fnd();
-        SPtr<uint32_t, LANES> obs = c.obs();
-        SPtr<double, LANES> freq = c.freq();
-        SPtr<uint8_t, LANES> nz = c.nz();
+        SPtrF<uint32_t, LANES> obs = c.obs();
+        SPtrF<double, LANES> freq = c.freq();
+        SPtrF<uint8_t, LANES> nz = c.nz();
         if (!sc[SC_IS_SPARSE]) {
             double norm = 0;
             for (uint32_t h = 0; h < c.H; ++h) {
@@ -983,8 +1043,8 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
             }
             for (uint32_t h = 0; h < c.H; ++h) freq[h] /= norm;
         } else {
-            USetT<LANES> plus = c.plus_set(), zero = c.zero_set();
-            SPtr<uint32_t, LANES> unext = c.unext();
+            Vx::HSet plus = c.plus_set(), zero = c.zero_set();
+            SPtrF<uint32_t, LANES> unext = c.unext();
             const uint32_t plus_size = uset_size(plus);
             // cached_simplex_prob_vectors[sum_observation_counts][|plus| - 1] (FrequencyDistribution.cpp:211-229): the vector is a pure
             // function of (n_obs, |plus|), so caching it or not is invisible; cached when the tile reserved room for it
@@ -1030,7 +1090,7 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
             }
             // "for p in plus: freq /= norm; zero.insert(p); obs = 0" then plus.clear(): record the plus iteration order
             // first (shared `next` words), clear plus, then insert into zero in that order — same final containers
-            SPtr<uint16_t, LANES> nzl = c.nzlist();
+            SPtrF<uint16_t, LANES> nzl = c.nzlist();
             uint32_t np = 0;
             for (uint32_t e = uset_begin(plus); e != US_NONE; e = unext[e]) nzl[np++] = (uint16_t)e;
             uset_clear(plus);

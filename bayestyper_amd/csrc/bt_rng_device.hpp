@@ -59,6 +59,14 @@ struct SPtr {
 };
 template <typename T>
 BT_HD SPtr<T, 1> sptr1(T *p) { return SPtr<T, 1>{(T BT_GAS *)p, 0u}; }
+// same, with a generic ("flat") base pointer: may point into LDS as well as into HBM
+template <typename T, unsigned STRIDE>
+struct SPtrF {
+    T *base;
+    uint32_t off;
+    BT_HD T &operator[](uint32_t i) const { return base[off + i * STRIDE]; }
+    BT_HD SPtrF<T, STRIDE> operator+(uint32_t i) const { return SPtrF<T, STRIDE>{base, off + i * STRIDE}; }
+};
 #if defined(__HIP_DEVICE_COMPILE__)
 // tell the compiler that a pointer handed through a non-inlined call is wave-uniform (it then lives in scalar registers and
 // loads through it can be scalar / use the scalar-base addressing mode)
@@ -199,7 +207,7 @@ BT_HD void rng_shuffle_u32(Mt &st, Arr a, uint32_t n) {
 // normal_distribution<double>(0,1) + gamma_distribution<double>; `nd` holds {saved value, saved_available flag}
 struct NormalState {   // references to wherever the caller keeps the two fields
     double BT_GAS *saved;
-    uint32_t BT_GAS *available;
+    uint32_t *available;   // generic: may point into LDS
 };
 
 BT_HD double rng_normal(Mt &st, NormalState nd) {
@@ -249,13 +257,13 @@ BT_HD double rng_gamma(Mt &st, NormalState nd, double alpha, double beta) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr uint32_t US_NONE = 0xFFFFFFFFu, US_BEFORE = 0xFFFFFFFEu;
 
-template <unsigned STRIDE>
-struct USetT {
-    SPtr<uint32_t, STRIDE> hdr;    // 4 words
-    SPtr<uint32_t, STRIDE> bkt;    // capacity >= uset_bucket_capacity(universe)
-    SPtr<uint32_t, STRIDE> next;   // universe words
+template <class PT>   // PT: any pointer-like with operator[](uint32_t) -> uint32_t&
+struct USetP {
+    PT hdr;    // 4 words
+    PT bkt;    // capacity >= uset_bucket_capacity(universe)
+    PT next;   // universe words
 };
-typedef USetT<1> USet;
+typedef USetP<SPtr<uint32_t, 1>> USet;
 
 BT_HD uint32_t uset_next_bucket_count(uint32_t min_needed) {   // next entry of libstdc++'s growth chain that is >= min_needed
     const uint32_t chain[15] = {13, 29, 59, 127, 257, 541, 1109, 2357, 5087, 10273, 20753, 42043, 85229, 172933, 351061};
@@ -270,23 +278,23 @@ BT_HD uint32_t uset_bucket_capacity(uint32_t universe) {
     return b;
 }
 
-template <unsigned ST>
-BT_HD void uset_init(USetT<ST> s) {
+template <class PT>
+BT_HD void uset_init(USetP<PT> s) {
     s.hdr[0] = 1;
     s.hdr[1] = US_NONE;
     s.hdr[2] = 0;
     s.hdr[3] = 0;
     s.bkt[0] = US_NONE;
 }
-template <unsigned ST>
-BT_HD uint32_t uset_nxt(USetT<ST> s, uint32_t node) { return node == US_BEFORE ? s.hdr[1] : s.next[node]; }
-template <unsigned ST>
-BT_HD void uset_set_nxt(USetT<ST> s, uint32_t node, uint32_t v) {
+template <class PT>
+BT_HD uint32_t uset_nxt(USetP<PT> s, uint32_t node) { return node == US_BEFORE ? s.hdr[1] : s.next[node]; }
+template <class PT>
+BT_HD void uset_set_nxt(USetP<PT> s, uint32_t node, uint32_t v) {
     if (node == US_BEFORE) s.hdr[1] = v;
     else s.next[node] = v;
 }
-template <unsigned ST>
-BT_HD void uset_rehash(USetT<ST> s, uint32_t newB) {
+template <class PT>
+BT_HD void uset_rehash(USetP<PT> s, uint32_t newB) {
     for (uint32_t i = 0; i < newB; ++i) s.bkt[i] = US_NONE;
     uint32_t p = s.hdr[1];
     s.hdr[1] = US_NONE;
@@ -311,8 +319,8 @@ BT_HD void uset_rehash(USetT<ST> s, uint32_t newB) {
     s.hdr[3] = newB;   // floor(B * max_load_factor 1.0)
 }
 // insert an element that is not in the set
-template <unsigned ST>
-BT_HD void uset_insert(USetT<ST> s, uint32_t e) {
+template <class PT>
+BT_HD void uset_insert(USetP<PT> s, uint32_t e) {
     uint32_t B = s.hdr[0], size = s.hdr[2];
     if (size + 1 > s.hdr[3]) {
         uint32_t min_bkts = size + 1;
@@ -338,8 +346,8 @@ BT_HD void uset_insert(USetT<ST> s, uint32_t e) {
     s.hdr[2] = size + 1;
 }
 // erase an element that is in the set
-template <unsigned ST>
-BT_HD void uset_erase(USetT<ST> s, uint32_t e) {
+template <class PT>
+BT_HD void uset_erase(USetP<PT> s, uint32_t e) {
     const uint32_t B = s.hdr[0];
     const uint32_t b = e % B;
     uint32_t prev = s.bkt[b];
@@ -358,16 +366,16 @@ BT_HD void uset_erase(USetT<ST> s, uint32_t e) {
     uset_set_nxt(s, prev, nn);
     s.hdr[2] -= 1;
 }
-template <unsigned ST>
-BT_HD void uset_clear(USetT<ST> s) {
+template <class PT>
+BT_HD void uset_clear(USetP<PT> s) {
     const uint32_t B = s.hdr[0];
     for (uint32_t i = 0; i < B; ++i) s.bkt[i] = US_NONE;
     s.hdr[1] = US_NONE;
     s.hdr[2] = 0;
 }
-template <unsigned ST>
-BT_HD uint32_t uset_begin(USetT<ST> s) { return s.hdr[1]; }
-template <unsigned ST>
-BT_HD uint32_t uset_size(USetT<ST> s) { return s.hdr[2]; }
+template <class PT>
+BT_HD uint32_t uset_begin(USetP<PT> s) { return s.hdr[1]; }
+template <class PT>
+BT_HD uint32_t uset_size(USetP<PT> s) { return s.hdr[2]; }
 
 }  // namespace bt
