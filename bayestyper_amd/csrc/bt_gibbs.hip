@@ -331,7 +331,12 @@ struct bt_gibbs {
     std::vector<uint32_t> h_A;             // alleles per cluster
     std::vector<uint32_t> group_tile, group_lane, group_nvert;
     // trace
-    uint32_t lds_bytes = 0;               // dynamic LDS per workgroup (max hot_bytes over the tiles)
+    // tiles are launched in two classes so that a few LDS-hungry tiles do not cap the occupancy of all the others
+    uint32_t lds_light = 0, lds_heavy = 0;   // dynamic LDS per workgroup of each class (max hot_bytes over its tiles)
+    std::vector<uint32_t> light_tiles, heavy_tiles;
+    uint32_t *d_light = nullptr, *d_heavy = nullptr;
+    hipStream_t heavy_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t trace_sweeps = 0;
     uint32_t *d_trace = nullptr, *d_trace_counter = nullptr;
     uint64_t trace_words = 0;
@@ -343,17 +348,33 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     BT_HIP(hipSetDevice(g->ctx->device));
     TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
-    hipLaunchKernelGGL(gibbs_kernel, dim3(g->ntiles), dim3(LANES), g->lds_bytes, g->ctx->stream, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
-                       (const uint32_t *)nullptr);
-    BT_CHECK_LAUNCH();
+    const bool both = !g->heavy_tiles.empty() && !g->light_tiles.empty();
+    if (!g->heavy_tiles.empty()) {
+        hipStream_t hs = both ? g->heavy_stream : g->ctx->stream;
+        if (both) {
+            BT_HIP(hipEventRecord(g->ev_fork, g->ctx->stream));
+            BT_HIP(hipStreamWaitEvent(hs, g->ev_fork, 0));
+        }
+        hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)g->heavy_tiles.size()), dim3(LANES), g->lds_heavy, hs, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
+                           (const uint32_t *)g->d_heavy);
+        BT_CHECK_LAUNCH();
+        if (both) BT_HIP(hipEventRecord(g->ev_join, hs));
+    }
+    if (!g->light_tiles.empty()) {
+        hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)g->light_tiles.size()), dim3(LANES), g->lds_light, g->ctx->stream, g->d_tiles, g->d_pool, g->d_params, op, a0, a1,
+                           hist, tr, (const uint32_t *)g->d_light);
+        BT_CHECK_LAUNCH();
+    }
+    if (both) BT_HIP(hipStreamWaitEvent(g->ctx->stream, g->ev_join, 0));
     return BT_OK;
 }
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 #ifndef BT_HOT_BUDGET
-#define BT_HOT_BUDGET 32768
+#define BT_HOT_BUDGET 155648
 #endif
 constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
+constexpr uint32_t kLightLds = 24576;            // tiles above this go to the "heavy" launch class
 
 // element sizes per array, in TileArr order
 const uint32_t kElemSize[A_COUNT] = {
@@ -363,7 +384,7 @@ const uint32_t kElemSize[A_COUNT] = {
     /*MT*/ 4, /*FNDSAVED*/ 8, /*SPARSITY*/ 8, /*UNIQ*/ 4, /*MULTI*/ 4, /*USUB*/ 4, /*MSUB*/ 4, /*SMM*/ 1, /*DIP*/ 2, /*FREQ*/ 8, /*OBS*/ 4, /*NZ*/ 1,
     /*ZHDR*/ 4, /*ZBKT*/ 4, /*PHDR*/ 4, /*PBKT*/ 4, /*UNEXT*/ 4, /*HVCOUNT*/ 4, /*UCACHE*/ 8, /*UCTAG*/ 4, /*CUM*/ 8, /*NZLIST*/ 2, /*SIMPLEX*/ 8,
     /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*SC*/ 4,
-    /*EDGES*/ 4, /*COVER*/ 1, /*MCACHE*/ 8, /*MCTAG*/ 4, /*MCGEN*/ 4, /*MGEN*/ 4, /*OTH*/ 1, /*PEND*/ 4, /*PENDDIP*/ 2, /*PENDVALID*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1};
+    /*EDGES*/ 4, /*COVER*/ 1, /*MCACHE*/ 8, /*MCTAG*/ 4, /*MCGEN*/ 4, /*MGEN*/ 4, /*OTH*/ 1, /*LOGF*/ 8, /*PEND*/ 4, /*PENDDIP*/ 2, /*PENDVALID*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1};
 
 }  // namespace
 
@@ -568,6 +589,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_MCACHE] = len[A_MCTAG] = len[A_MCGEN] = nv * (d.NMm ? d.cache_entries : 1);
         len[A_MGEN] = nv * S;
         len[A_OTH] = nv * std::max<uint32_t>(d.NMm, 1) * S;
+        len[A_LOGF] = nv * d.Hm;
         len[A_PEND] = nv * S;
         len[A_PENDDIP] = nv * 2 * S;
         len[A_PENDVALID] = nv * S;
@@ -585,11 +607,11 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         {
             // hot arrays (bt_gibbs_tile.hpp: Vx::harr users) -> offsets inside the wavefront's LDS block
             for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
-            const int hot_arrs[] = {A_SC, A_DIP, A_NESTPL, A_NESTN, A_KSCUPD, A_MGEN, A_PEND, A_PENDDIP, A_PENDVALID, A_FREQ, A_OBS, A_NZ, A_NZLIST,
+            const int hot_arrs[] = {A_SC, A_DIP, A_NESTPL, A_NESTN, A_KSCUPD, A_MGEN, A_PEND, A_PENDDIP, A_PENDVALID, A_FREQ, A_LOGF, A_OBS, A_NZ, A_NZLIST,
                                     A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_CUM};
             uint32_t ho = 0;
             for (int a : hot_arrs) {
-                if (a == A_CUM && d.D2m > 64) continue;
+                if (a == A_CUM && d.D2m > 16) continue;
                 const uint64_t per_vertex = len[a] / nv;   // elements per lane and vertex
                 d.hoff[a] = ho;
                 ho = (uint32_t)align_up(ho + per_vertex * LANES * kElemSize[a], 16);
@@ -599,7 +621,6 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
                 d.hot_bytes = 0;
             }
-            g->lds_bytes = std::max(g->lds_bytes, d.hot_bytes);
         }
         d.base = pool;
         plans[ti].d = d;
@@ -730,6 +751,31 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         BT_TRYHIP(hipMemcpyAsync(g->d_params, &g->P, sizeof(GParams), hipMemcpyHostToDevice, ctx->stream));
         BT_TRYHIP(hipStreamSynchronize(ctx->stream));
     }
+    for (uint32_t ti = 0; ti < ntiles; ++ti) {
+        const uint32_t hb = g->tiles[ti].hot_bytes;
+        if (hb > kLightLds) {
+            g->heavy_tiles.push_back(ti);
+            g->lds_heavy = std::max(g->lds_heavy, hb);
+        } else {
+            g->light_tiles.push_back(ti);
+            g->lds_light = std::max(g->lds_light, hb);
+        }
+    }
+    if (!g->heavy_tiles.empty()) {
+        BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_heavy), g->heavy_tiles.size() * 4));
+        g->allocs.push_back(g->d_heavy);
+        BT_TRYHIP(hipMemcpyAsync(g->d_heavy, g->heavy_tiles.data(), g->heavy_tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
+        BT_TRYHIP(hipStreamCreateWithFlags(&g->heavy_stream, hipStreamNonBlocking));
+        BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        BT_TRYHIP(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
+    }
+    if (!g->light_tiles.empty()) {
+        BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_light), g->light_tiles.size() * 4));
+        g->allocs.push_back(g->d_light);
+        BT_TRYHIP(hipMemcpyAsync(g->d_light, g->light_tiles.data(), g->light_tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    BT_TRYHIP(hipStreamSynchronize(ctx->stream));
     BT_TRY(launch(g, OP_SETUP, 0, 0, nullptr));
     BT_TRYHIP(hipStreamSynchronize(ctx->stream));
 #undef BT_TRY
@@ -746,6 +792,12 @@ int bt_gibbs_destroy(bt_gibbs *g) {
         if (p) (void)hipFree(p);
     if (g->d_trace) (void)hipFree(g->d_trace);
     if (g->d_trace_counter) (void)hipFree(g->d_trace_counter);
+    if (g->heavy_stream) {
+        (void)hipStreamSynchronize(g->heavy_stream);
+        (void)hipStreamDestroy(g->heavy_stream);
+    }
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     delete g;
     return BT_OK;
 }
@@ -1006,6 +1058,18 @@ int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *v
     *n = j;
     return BT_OK;
 }
+
+#ifdef BT_PROF
+int bt_diag_prof(unsigned long long *h_out16, int reset) {
+    BT_HIP(hipDeviceSynchronize());
+    BT_HIP(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_bt_prof), 16 * 8));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, 16 * 8));
+    }
+    return BT_OK;
+}
+#endif
 
 int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint64_t n, double *h_out) {
     if (!h_out) return fail("bt_diag_rng: null argument");

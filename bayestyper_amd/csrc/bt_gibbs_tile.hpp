@@ -92,6 +92,7 @@ enum TileArr {
     A_MCGEN,        // u32 [V] cache_entries  generation of the sample at fill time
     A_MGEN,         // u32 [V] S              current generation per sample (bumped when the other clusters' contribution changes)
     A_OTH,          // u8  [V] NMm*S          other clusters' multiplicity per subset k-mer at the current generation
+    A_LOGF,         // f64 [V] Hm             log(frequency) of the non-zero haplotypes (pure function of A_FREQ, refreshed with it)
     A_PEND,         // u32 [V] S    collected sweeps not yet materialised for the sample (run-length of identical contributions)
     A_PENDDIP,      // u16 [V] 2*S  the diplotype those pending sweeps drew
     A_PENDVALID,    // u8  [V] S
@@ -184,6 +185,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (uint32_t)d().NMm * d().S); }
     __device__ inline SPtrF<uint16_t, LANES> dip() const { return t.harr<uint16_t>(A_DIP, v, 2 * d().S); }
     __device__ inline SPtrF<double, LANES> freq() const { return t.harr<double>(A_FREQ, v, d().Hm); }
+    __device__ inline SPtrF<double, LANES> logf() const { return t.harr<double>(A_LOGF, v, d().Hm); }
     __device__ inline SPtrF<uint32_t, LANES> obs() const { return t.harr<uint32_t>(A_OBS, v, d().Hm); }
     __device__ inline SPtrF<uint8_t, LANES> nz() const { return t.harr<uint8_t>(A_NZ, v, d().Hm); }
     __device__ inline SPtrF<uint32_t, LANES> unext() const { return t.harr<uint32_t>(A_UNEXT, v, d().Hm); }
@@ -288,6 +290,7 @@ __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
     hot_copy<uint16_t>(t, A_PENDDIP, v, 2 * d.S, to_lds);
     hot_copy<uint8_t>(t, A_PENDVALID, v, d.S, to_lds);
     hot_copy<double>(t, A_FREQ, v, d.Hm, to_lds);
+    hot_copy<double>(t, A_LOGF, v, d.Hm, to_lds);
     hot_copy<uint32_t>(t, A_OBS, v, d.Hm, to_lds);
     hot_copy<uint8_t>(t, A_NZ, v, d.Hm, to_lds);
     hot_copy<uint32_t>(t, A_UNEXT, v, d.Hm, to_lds);
@@ -297,6 +300,21 @@ __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
     hot_copy<uint32_t>(t, A_PBKT, v, d.Bcap, to_lds);
     // A_NZLIST and A_CUM are per-call scratch: resident in LDS but never copied
 }
+
+// ---- optional per-phase cycle accounting (build with -DBT_PROF; read with bt_diag_prof) ----
+#ifdef BT_PROF
+__device__ unsigned long long g_bt_prof[16];
+#define PROF_DECL unsigned long long _pt = __builtin_readcyclecounter()
+#define PROF(sec)                                                            \
+    do {                                                                     \
+        const unsigned long long _now = __builtin_readcyclecounter();        \
+        if (threadIdx.x == 0) atomicAdd(&g_bt_prof[sec], _now - _pt);        \
+        _pt = _now;                                                          \
+    } while (0)
+#else
+#define PROF_DECL
+#define PROF(sec)
+#endif
 
 // ---- Utils::logAddition (Utils.hpp:105-124) ----
 __device__ inline double log_addition(double a, double b) {
@@ -372,12 +390,14 @@ __device__ inline uint8_t multi_mult(const Vx &c, const GParams BT_CAS &P, uint3
 // ---- FrequencyDistribution::reset / SparseFrequencyDistribution::reset (FrequencyDistribution.cpp:49-54,104-115) ----
 __device__ inline void freq_reset(const Vx &c) {
     const double f = 1 / (double)c.H;
+    const double lf = bt_log(f);
     SPtrF<uint32_t, LANES> obs = c.obs();
-    SPtrF<double, LANES> freq = c.freq();
+    SPtrF<double, LANES> freq = c.freq(), logf = c.logf();
     SPtrF<uint8_t, LANES> nz = c.nz();
     for (uint32_t h = 0; h < c.H; ++h) {
         obs[h] = 0;
         freq[h] = f;
+        logf[h] = lf;
         nz[h] = 1;
     }
     if (c.sc()[SC_IS_SPARSE]) {
@@ -899,9 +919,10 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
     const uint32_t nsub_u = sc[SC_NSUB_U], nsub_m = sc[SC_NSUB_M];
     const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
     uint32_t hap_count = sc[SC_HAP_COUNT];
+    PROF_DECL;
     Mt rng = mt_open(c.mt(0));
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
-    SPtrF<double, LANES> freq = c.freq(), cum = c.cum();
+    SPtrF<double, LANES> logf = c.logf(), cum = c.cum();
     SPtrF<uint16_t, LANES> dip = c.dip();
     uint32_t nnz = 0;
     {
@@ -909,6 +930,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         for (uint32_t h = 0; h < c.H; ++h)
             if (nz[h]) nzl[nnz++] = (uint16_t)h;
     }
+    PROF(0);
     for (uint32_t s = 0; s < P.S; ++s) {
         const uint16_t p1 = dip[2 * s], p2 = dip[2 * s + 1];
         const uint8_t ploidy = c.nest_ploidy()[s];
@@ -917,18 +939,19 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             multi_refresh(c, P, s, p1, p2, nsub_m);
             gen = c.mgen()[s];
         }
+        PROF(1);
         // candidates in the reference's order; cumulative log-sum-exp exactly as LogDiscreteSampler::addOutcome
         uint32_t ncand = 0;
         double run = 0;
         if (ploidy == 2) {
             for (uint32_t a = 0; a < nnz; ++a) {
                 const uint16_t ha = nzl[a];
-                const double lfa = bt_log(freq[ha]);
+                const double lfa = logf[ha];   // == log(freq[ha]) (VariantClusterGenotyper.cpp:603-616 computes it per candidate)
                 for (uint32_t b = a; b < nnz; ++b) {
                     const uint16_t hb = nzl[b];
                     double lp = 0;
                     if (a == b) lp += 2 * lfa;
-                    else lp += BT_LN2 + lfa + bt_log(freq[hb]);
+                    else lp += BT_LN2 + lfa + logf[hb];
                     lp += unique_log_prob(c, P, s, ha, hb, nsub_u);
                     if (use_multi) lp += multi_log_prob(c, P, s, ha, hb, p1, p2, nsub_m, gen);
                     run = ncand == 0 ? lp : log_addition(lp, run);
@@ -939,7 +962,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             for (uint32_t a = 0; a < nnz; ++a) {
                 const uint16_t ha = nzl[a];
                 double lp = 0;
-                lp += bt_log(freq[ha]);
+                lp += logf[ha];
                 lp += unique_log_prob(c, P, s, ha, NOHAP, nsub_u);
                 if (use_multi) lp += multi_log_prob(c, P, s, ha, NOHAP, p1, p2, nsub_m, gen);
                 run = ncand == 0 ? lp : log_addition(lp, run);
@@ -949,6 +972,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             ncand = 1;
             run = 0;
         }
+        PROF(2);
         // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome
         const double u = bt_log(rng_canonical(rng)) + run;
         uint32_t pick = 0;
@@ -973,11 +997,14 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         } else if (ploidy == 1) {
             h1 = nzl[pick];
         }
+        PROF(3);
         dip[2 * s] = h1;
         dip[2 * s + 1] = h2;
         hfd_increment(c, h1, is_sparse, hap_count);
         hfd_increment(c, h2, is_sparse, hap_count);
+        PROF(4);
         update_multicluster_multiplicities(c, P, h1, h2, p1, p2, s, nsub_m);
+        PROF(5);
         if (tracing) trace_row[s] = (uint32_t)h1 | ((uint32_t)h2 << 16);
     }
     mt_close(rng);
@@ -985,6 +1012,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
 #ifndef ABL_NOSTATS
     if (collect) update_allele_kmer_stats(env, vtx, nsub_u, nsub_m);
 #endif
+    PROF(6);
     sc[SC_USE_MULTI] = nsub_m != 0 ? 1u : 0u;
 }
 
@@ -1027,6 +1055,7 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
     const TileDesc BT_CAS &d = c.d();
     SPtrF<uint32_t, LANES> sc = c.sc();
     const uint32_t n_obs = sc[SC_HAP_COUNT];
+    PROF_DECL;
     if (n_obs > 0) {
         Mt rng = mt_open(c.mt(1));
         const NormalState nd = c.fnd();
@@ -1041,7 +1070,12 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
                 norm += f;
                 obs[h] = 0;
             }
-            for (uint32_t h = 0; h < c.H; ++h) freq[h] /= norm;
+            SPtrF<double, LANES> logf = c.logf();
+            for (uint32_t h = 0; h < c.H; ++h) {
+                const double f = freq[h] / norm;
+                freq[h] = f;
+                logf[h] = bt_log(f);
+            }
         } else {
             Vx::HSet plus = c.plus_set(), zero = c.zero_set();
             SPtrF<uint32_t, LANES> unext = c.unext();
@@ -1096,13 +1130,16 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
             uset_clear(plus);
             for (uint32_t i = 0; i < np; ++i) {
                 const uint32_t e = nzl[i];
-                freq[e] /= norm;
+                const double f = freq[e] / norm;
+                freq[e] = f;
+                c.logf()[e] = bt_log(f);
                 uset_insert(zero, e);
                 obs[e] = 0;
             }
         }
         mt_close(rng);
     }
+    PROF(7);
     sc[SC_HAP_COUNT] = 0;
 }
 
