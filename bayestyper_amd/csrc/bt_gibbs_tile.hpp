@@ -92,6 +92,13 @@ enum TileArr {
     A_MCGEN,        // u32 [V] cache_entries  generation of the sample at fill time
     A_MGEN,         // u32 [V] S              current generation per sample (bumped when the other clusters' contribution changes)
     A_OTH,          // u8  [V] NMm*S          other clusters' multiplicity per subset k-mer at the current generation
+    A_SUBM,         // u8  [V] NUm*Hm         multiplicity rows of the unique subset k-mers, in subset order (compact copy of A_M rows)
+    A_SUBCNT,       // u8  [V] NUm*S          their observed counts (0 when the k-mer has no count record)
+    A_SUBIC,        // u8  [V] NUm*2          their intercluster multiplicities (0 when no count record)
+    A_SKVOFF,       // u32 [V] NUm+1          variant_haplotype_indices CSR of the unique subset k-mers, in subset order
+    A_SKVVAR,       // u16 [V] NNZm
+    A_SKVBITS,      // u32 [V] NNZm*HWm
+    A_KSCTMP,       // f64 [V] 2*Vm*4         scratch accumulators of one sample's k-mer-stats cache rebuild
     A_LOGF,         // f64 [V] Hm             log(frequency) of the non-zero haplotypes (pure function of A_FREQ, refreshed with it)
     A_PEND,         // u32 [V] S    collected sweeps not yet materialised for the sample (run-length of identical contributions)
     A_PENDDIP,      // u16 [V] 2*S  the diplotype those pending sweeps drew
@@ -185,6 +192,13 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (uint32_t)d().NMm * d().S); }
     __device__ inline SPtrF<uint16_t, LANES> dip() const { return t.harr<uint16_t>(A_DIP, v, 2 * d().S); }
     __device__ inline SPtrF<double, LANES> freq() const { return t.harr<double>(A_FREQ, v, d().Hm); }
+    __device__ inline SPtr<uint8_t, LANES> subm() const { return a<uint8_t>(A_SUBM, d().NUm * d().Hm); }
+    __device__ inline SPtr<uint8_t, LANES> subcnt() const { return a<uint8_t>(A_SUBCNT, d().NUm * d().S); }
+    __device__ inline SPtr<uint8_t, LANES> subic() const { return a<uint8_t>(A_SUBIC, d().NUm * 2); }
+    __device__ inline SPtr<uint32_t, LANES> skv_off() const { return a<uint32_t>(A_SKVOFF, d().NUm + 1); }
+    __device__ inline SPtr<uint16_t, LANES> skv_var() const { return a<uint16_t>(A_SKVVAR, d().NNZm > 1 ? d().NNZm : 1); }
+    __device__ inline SPtr<uint32_t, LANES> skv_bits() const { return a<uint32_t>(A_SKVBITS, (d().NNZm > 1 ? d().NNZm : 1) * d().HWm); }
+    __device__ inline SPtrF<double, LANES> ksc_tmp() const { return t.harr<double>(A_KSCTMP, v, 2 * d().Vm * 4); }
     __device__ inline SPtrF<double, LANES> logf() const { return t.harr<double>(A_LOGF, v, d().Hm); }
     __device__ inline SPtrF<uint32_t, LANES> obs() const { return t.harr<uint32_t>(A_OBS, v, d().Hm); }
     __device__ inline SPtrF<uint8_t, LANES> nz() const { return t.harr<uint8_t>(A_NZ, v, d().Hm); }
@@ -565,6 +579,30 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
             if (!is_max_hv_kmer(c, k, P.max_hvk)) msub[nsm++] = k;
     }
     mt_close(rng);
+    {
+        // compact, subset-ordered copies of what calcDiplotypeLogProb reads per unique subset k-mer: the per-candidate sum then
+        // walks plain arrays (index i, no k-mer indirection), so its loads are independent and coalesce across the wavefront
+        const uint32_t Hm = c.d().Hm;
+        SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+        SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits();
+        SPtr<uint16_t, LANES> sv = c.skv_var();
+        const uint32_t HWm = c.d().HWm, HW = (c.H + 31) / 32;
+        uint32_t ne = 0;
+        for (uint32_t i = 0; i < nsu; ++i) {
+            const uint32_t k = usub[i];
+            so[i] = ne;
+            for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e, ++ne) {
+                sv[ne] = c.kv_var(e);
+                for (uint32_t w = 0; w < HW; ++w) sb[ne * HWm + w] = c.a<uint32_t>(A_KVBITS, c.d().NNZm * HWm)[e * HWm + w];
+            }
+            so[i + 1] = ne;
+            const bool hc = c.has_counts(k) != 0;
+            for (uint32_t h = 0; h < c.H; ++h) sm[i * Hm + h] = c.M(k, h);
+            for (uint32_t ss = 0; ss < P.S; ++ss) scn[i * P.S + ss] = hc ? c.count(k, ss) : (uint8_t)0;
+            sic[2 * i] = hc ? c.ic(k, 0) : (uint8_t)0;
+            sic[2 * i + 1] = hc ? c.ic(k, 1) : (uint8_t)0;
+        }
+    }
     SPtrF<uint32_t, LANES> sc = c.sc();
     sc[SC_NSUB_U] = nsu;
     sc[SC_NSUB_M] = nsm;
@@ -611,12 +649,33 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
     }
     double acc = 0;
     const uint8_t gender = P.gender[s];
-    SPtr<uint32_t, LANES> usub = c.usub();
-    for (uint32_t i = 0; i < nsub_u; ++i) {
-        const uint32_t k = usub[i];
-        const uint8_t m = unique_mult(c, k, h1, h2, gender);
-        const uint8_t cnt = c.has_counts(k) ? c.count(k, s) : 0;
-        acc += count_log_prob(P, s, m, cnt);
+    {
+        const uint32_t Hm = d.Hm, S = P.S;
+        SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+        const bool two = h2 != NOHAP;
+        uint32_t i = 0;
+        // eight k-mers per step: all loads of a step are issued before the first table lookup; the sum itself stays in subset order
+        for (; i + 8 <= nsub_u; i += 8) {
+            uint8_t m[8], cn[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint8_t mm = sm[(i + q) * Hm + h1];
+                if (two) mm = (uint8_t)(mm + sm[(i + q) * Hm + h2]);
+                m[q] = (uint8_t)(mm + sic[2 * (i + q) + gender]);
+                cn[q] = scn[(i + q) * S + s];
+            }
+            double lp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) lp[q] = count_log_prob(P, s, m[q], cn[q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += lp[q];
+        }
+        for (; i < nsub_u; ++i) {
+            uint8_t mm = sm[i * Hm + h1];
+            if (two) mm = (uint8_t)(mm + sm[i * Hm + h2]);
+            const uint8_t m = (uint8_t)(mm + sic[2 * i + gender]);
+            acc += count_log_prob(P, s, m, scn[i * S + s]);
+        }
     }
     if (d.cache_mode == 0) uc[(uint32_t)s * d.Dcm + idx] = acc;
     else if (d.cache_mode == 1) {
@@ -885,20 +944,47 @@ __device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uin
 #endif
         if (u) {
             upd[s] = 0;
-            for (uint32_t var = 0; var < c.V; ++var) {
-                ks_reset(c.ksc(s, 0, var));
-                ks_reset(c.ksc(s, 1, var));
-            }
+            // rebuild kmer_stats_cache[s] (VariantClusterHaplotypes.cpp:247-277) in scratch accumulators (LDS when the vertex is
+            // resident), walking the compact subset arrays; same k-mer order, same arithmetic, one write-back at the end
+            SPtrF<double, LANES> tmp = c.ksc_tmp();
+            const uint32_t Vm = c.d().Vm, Hm = c.d().Hm, HWm = c.d().HWm;
+            for (uint32_t i = 0; i < 2 * Vm * 4; ++i) tmp[i] = 0;
             if (h1 != NOHAP) {
-                SPtr<uint32_t, LANES> usub = c.usub(), msub = c.msub();
+                const bool two = h2 != NOHAP;
+                const uint8_t g = P.gender[s];
+                SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+                SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits();
+                SPtr<uint16_t, LANES> sv = c.skv_var();
                 for (uint32_t i = 0; i < nsub_u; ++i) {
-                    const uint32_t k = usub[i];
-                    if (dip_mult(c, k, h1, h2) > 0) update_kmer_stats_cache(c, P, k, h1, h2, s, unique_mult(c, k, h1, h2, P.gender[s]));
+                    uint8_t dm = sm[i * Hm + h1];
+                    if (two) dm = (uint8_t)(dm + sm[i * Hm + h2]);
+                    const uint32_t e0 = so[i], e1 = so[i + 1];
+                    if (dm == 0) continue;
+                    const uint8_t mult = (uint8_t)(dm + sic[2 * i + g]);
+                    const double kmer_count = scn[i * P.S + s] / (double)mult;
+                    for (uint32_t e = e0; e < e1; ++e) {
+                        const uint32_t var = sv[e];
+                        if ((sb[e * HWm + (h1 >> 5)] >> (h1 & 31u)) & 1u) ks_add(tmp + (0 * Vm + var) * 4, kmer_count);
+                        if (two && ((sb[e * HWm + (h2 >> 5)] >> (h2 & 31u)) & 1u)) ks_add(tmp + (1 * Vm + var) * 4, kmer_count);
+                    }
                 }
+                SPtr<uint32_t, LANES> msub = c.msub();
                 for (uint32_t i = 0; i < nsub_m; ++i) {
                     const uint32_t k = msub[i];
-                    if (dip_mult(c, k, h1, h2) > 0) update_kmer_stats_cache(c, P, k, h1, h2, s, multi_mult(c, P, k, h1, h2, h1, h2, s));
+                    if (dip_mult(c, k, h1, h2) == 0) continue;
+                    const uint8_t mult = multi_mult(c, P, k, h1, h2, h1, h2, s);
+                    double kmer_count = 0;
+                    if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
+                    for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
+                        const uint32_t var = c.kv_var(e);
+                        if (c.kv_bit(e, h1)) ks_add(tmp + (0 * Vm + var) * 4, kmer_count);
+                        if (two && c.kv_bit(e, h2)) ks_add(tmp + (1 * Vm + var) * 4, kmer_count);
+                    }
                 }
+            }
+            for (uint32_t var = 0; var < c.V; ++var) {
+                ks_store(c.ksc(s, 0, var), ks_load(tmp + (0 * Vm + var) * 4));
+                ks_store(c.ksc(s, 1, var), ks_load(tmp + (1 * Vm + var) * 4));
             }
         }
         replay_collected(c, P, s, h1, h2, 1);
