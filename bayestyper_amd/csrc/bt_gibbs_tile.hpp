@@ -28,7 +28,7 @@ constexpr double BT_DBL_EPS = 2.220446049250313080847263336181640625e-16;
 constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
 
 // scalar slots per vertex (A_SC)
-enum { SC_USE_MULTI = 0, SC_NSUB_U, SC_NSUB_M, SC_HAP_COUNT, SC_CONSTRUCTED, SC_DIP_ENTRIES, SC_DIP_OVERFLOW, SC_IS_SPARSE, SC_FND_AVAIL, SC_COUNT };
+enum { SC_USE_MULTI = 0, SC_NSUB_U, SC_NSUB_M, SC_HAP_COUNT, SC_CONSTRUCTED, SC_DIP_ENTRIES, SC_DIP_OVERFLOW, SC_IS_SPARSE, SC_FND_AVAIL, SC_UC_DIRTY, SC_COUNT };
 
 // arrays of a tile.  [V] = per vertex (index v*LEN + i), [G] = per group
 enum TileArr {
@@ -117,7 +117,7 @@ struct TileDesc {
     uint64_t trace_base;      // word offset of this tile's trace block ([sweep][vertex][S][64])
     uint64_t off[A_COUNT];    // byte offsets of the arrays from the tile base
     uint32_t hoff[A_COUNT];   // byte offset inside the wavefront's LDS block of the arrays kept resident there (NOHOT otherwise)
-    uint32_t hot_bytes, hot_pad;
+    uint32_t hot_bytes, split;   // split: wavefronts working on this tile (1, 2, 4 or 8), see tile_lane()
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 
@@ -242,6 +242,12 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<uint8_t, LANES> shared_mult() const { return t.arr<uint8_t>(A_SHMULT); }
 };
 
+// A tile is worked on by `split` wavefronts (TileDesc::split, chosen per tile by the host): wavefront w owns the 64/split
+// consecutive group lanes starting at w * 64/split and runs with only that many active threads; wavefronts of the workgroup
+// beyond `split` exit at once.  The memory layout (HBM pool and LDS hot arrays, both interleaved over 64 group lanes) does not
+// depend on the split: it only trades SIMD width for more wavefronts that each wait on fewer diverging lanes.
+__device__ inline uint32_t tile_lane(uint32_t split) { return (threadIdx.x >> 6) * (64u / split) + (threadIdx.x & 63u); }
+__device__ inline bool tile_thread_active(uint32_t split) { return (threadIdx.x >> 6) < split && (threadIdx.x & 63u) < 64u / split; }
 extern __shared__ __attribute__((aligned(16))) uint8_t bt_lds_raw[];
 __device__ inline uint8_t *lds_block() { return (uint8_t *)bt_lds_raw; }
 
@@ -253,7 +259,7 @@ __device__ inline Tile make_tile(const Env &e_in) {
     const uint32_t tile = list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x;
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
-    t.lane = threadIdx.x;
+    t.lane = tile_lane(t.d->split);
     t.resident = e_in.resident;   // per lane: lanes of a tile may be at different vertices of their groups
     t.hot = (t.resident != 0xFFFFFFFFu && t.d->hot_bytes) ? lds_block() : nullptr;
     return t;
@@ -319,15 +325,22 @@ __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
 #ifdef BT_PROF
 __device__ unsigned long long g_bt_prof[16];
 #define PROF_DECL unsigned long long _pt = __builtin_readcyclecounter()
+#define PROF_DECL2 _pt = __builtin_readcyclecounter()
 #define PROF(sec)                                                            \
     do {                                                                     \
         const unsigned long long _now = __builtin_readcyclecounter();        \
         if (threadIdx.x == 0) atomicAdd(&g_bt_prof[sec], _now - _pt);        \
         _pt = _now;                                                          \
     } while (0)
+#define PROF_CNT(slot, n)                                                    \
+    do {                                                                     \
+        if (threadIdx.x == 0) atomicAdd(&g_bt_prof[slot], (unsigned long long)(n)); \
+    } while (0)
 #else
 #define PROF_DECL
+#define PROF_DECL2
 #define PROF(sec)
+#define PROF_CNT(slot, n)
 #endif
 
 // ---- Utils::logAddition (Utils.hpp:105-124) ----
@@ -529,10 +542,7 @@ __device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t
 __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P) {   // VariantClusterGenotyper::clearCache (:131-138)
     const TileDesc BT_CAS &d = c.d();
     if (d.cache_mode == 0) {
-        SPtr<double, LANES> uc = c.ucache();
-        const uint32_t Dc = c.H * (c.H + 1) / 2 + c.H;
-        for (uint32_t s = 0; s < P.S; ++s)
-            for (uint32_t i = 0; i < Dc; ++i) uc[(uint32_t)s * d.Dcm + i] = __longlong_as_double(0x7ff8000000000000LL);
+        c.sc()[SC_UC_DIRTY] = 1;   // dense table: rebuilt as a whole at the next visit (fill_unique_cache)
     } else if (d.cache_mode == 1) {
         SPtr<uint32_t, LANES> tg = c.uctag();
         for (uint32_t i = 0; i < d.cache_entries; ++i) tg[i] = 0;
@@ -543,16 +553,32 @@ __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P) {   // 
 __device__ inline bool is_max_hv_kmer(const Vx &c, uint32_t k, uint32_t maxk) {
     bool is_max = true;
     SPtr<uint32_t, LANES> hv = c.hvcount();
-    const uint32_t Vm = c.d().Vm;
+    const uint32_t Vm = c.d().Vm, HWm = c.d().HWm, HW = (c.H + 31) / 32;
+    SPtr<uint32_t, LANES> bits = c.a<uint32_t>(A_KVBITS, (uint32_t)c.d().NNZm * HWm);
     for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
         const uint32_t var = c.kv_var(e);
-        for (uint32_t h = 0; h < c.H; ++h) {
-            if (c.kv_bit(e, h)) {
-                const uint32_t cnt = hv[(uint32_t)h * Vm + var];
-                if (cnt < maxk) {
-                    hv[(uint32_t)h * Vm + var] = cnt + 1;
-                    is_max = false;
+        for (uint32_t w = 0; w < HW; ++w) {
+            uint32_t word = bits[e * HWm + w];
+            // the counters of distinct haplotypes are independent: four are read before any is written back
+            while (word) {
+                uint32_t h[4], cnt[4], n = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h[q] = 0;
+                    if (word) {
+                        h[q] = w * 32 + (uint32_t)__builtin_ctz(word);
+                        word &= word - 1;
+                        n = q + 1;
+                    }
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cnt[q] = hv[h[q] * Vm + var];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((uint32_t)q < n && cnt[q] < maxk) {
+                        hv[h[q] * Vm + var] = cnt[q] + 1;
+                        is_max = false;
+                    }
             }
         }
     }
@@ -566,18 +592,28 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
     uint32_t nsu = 0, nsm = 0;
     Mt rng = mt_open(c.mt(0));
     SPtr<uint32_t, LANES> uniq = c.uniq(), usub = c.usub(), multi = c.multi(), msub = c.msub();
+    PROF_DECL;
+    // The generator is consumed exactly as the reference does (shuffle, one Bernoulli draw per k-mer; unique list, then the
+    // multicluster list), but the isMaxHaplotypeVariantKmer filter — which draws nothing — runs afterwards over the selected
+    // k-mers only, in the same order: every lane then works on ITS j-th selected k-mer instead of the wave stepping through
+    // all k-mers with the ~10 % of lanes that selected that one.
     rng_shuffle_u32(rng, uniq, c.nu);
-    for (uint32_t i = 0; i < c.nu; ++i) {
-        const uint32_t k = uniq[i];
-        if (rng_bernoulli(rng, P.rate))
-            if (!is_max_hv_kmer(c, k, P.max_hvk)) usub[nsu++] = k;
-    }
+    PROF(8);
+    uint32_t nu_sel = 0, nm_sel = 0;
+    for (uint32_t i = 0; i < c.nu; ++i)
+        if (rng_bernoulli(rng, P.rate)) usub[nu_sel++] = uniq[i];
     rng_shuffle_u32(rng, multi, c.nm);
-    for (uint32_t i = 0; i < c.nm; ++i) {
-        const uint32_t k = multi[i];
-        if (rng_bernoulli(rng, P.rate))
-            if (!is_max_hv_kmer(c, k, P.max_hvk)) msub[nsm++] = k;
+    for (uint32_t i = 0; i < c.nm; ++i)
+        if (rng_bernoulli(rng, P.rate)) msub[nm_sel++] = multi[i];
+    for (uint32_t i = 0; i < nu_sel; ++i) {
+        const uint32_t k = usub[i];
+        if (!is_max_hv_kmer(c, k, P.max_hvk)) usub[nsu++] = k;
     }
+    for (uint32_t i = 0; i < nm_sel; ++i) {
+        const uint32_t k = msub[i];
+        if (!is_max_hv_kmer(c, k, P.max_hvk)) msub[nsm++] = k;
+    }
+    PROF(9);
     mt_close(rng);
     {
         // compact, subset-ordered copies of what calcDiplotypeLogProb reads per unique subset k-mer: the per-candidate sum then
@@ -603,6 +639,8 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
             sic[2 * i + 1] = hc ? c.ic(k, 1) : (uint8_t)0;
         }
     }
+    PROF(10);
+    PROF_CNT(11, nsu);
     SPtrF<uint32_t, LANES> sc = c.sc();
     sc[SC_NSUB_U] = nsu;
     sc[SC_NSUB_M] = nsm;
@@ -683,6 +721,50 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
         uc[slot] = acc;
     }
     return acc;
+}
+
+// Dense-table tiles (cache_mode 0) do not fill the unique-part cache on demand: a miss would stall the 63 other lanes of the
+// wave for a whole pass over the k-mer subset, and over a chain nearly every (sample, diplotype) entry gets requested by some
+// sweep anyway.  Instead the whole table is computed once per cache epoch (chain start / clearCache) with all lanes busy.
+// Every entry is the same sum in the same (subset) order as the on-demand evaluation, so values are bit-identical.
+// Four candidates sharing the first haplotype are evaluated per pass: 11 loads per k-mer for 4 sums instead of 20.
+__device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    const TileDesc BT_CAS &d = c.d();
+    const uint32_t nsub = c.sc()[SC_NSUB_U];
+    const uint32_t Hm = d.Hm, S = P.S, H = c.H;
+    SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+    SPtr<double, LANES> uc = c.ucache();
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint8_t gender = P.gender[s];
+        const uint32_t row = s * d.Dcm;
+        // a == H is the haploid row: candidates (b, none)
+        for (uint32_t a = 0; a <= H; ++a) {
+            const bool hap = a == H;
+            for (uint32_t b0 = hap ? 0 : a; b0 < H; b0 += 4) {
+                uint32_t hb[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) hb[q] = b0 + q < H ? b0 + q : H - 1;
+                double acc[4] = {0, 0, 0, 0};
+                for (uint32_t i = 0; i < nsub; ++i) {
+                    const uint8_t ma = hap ? (uint8_t)0 : (uint8_t)sm[i * Hm + a];
+                    const uint8_t icn = sic[2 * i + gender], cn = scn[i * S + s];
+                    uint8_t m[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) m[q] = (uint8_t)((uint8_t)(ma + (uint8_t)sm[i * Hm + hb[q]]) + icn);
+                    double lp[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) lp[q] = count_log_prob(P, s, m[q], cn);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) acc[q] += lp[q];
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q)
+                    if (b0 + q < H) uc[row + (hap ? H * (H + 1) / 2 + b0 + q : dip_index(c, (uint16_t)a, (uint16_t)(b0 + q)))] = acc[q];
+            }
+        }
+    }
 }
 
 // multicluster part (VariantClusterGenotyper.cpp:647-661).  For a candidate d the k-mer multiplicity is
@@ -1006,6 +1088,11 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
     const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
     uint32_t hap_count = sc[SC_HAP_COUNT];
     PROF_DECL;
+    if (sc[SC_UC_DIRTY]) {
+        fill_unique_cache(env, vtx);
+        sc[SC_UC_DIRTY] = 0;
+    }
+    PROF(12);
     Mt rng = mt_open(c.mt(0));
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
     SPtrF<double, LANES> logf = c.logf(), cum = c.cum();

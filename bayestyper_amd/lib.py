@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbtgpu.so")
+LIB_PATH = os.environ.get("BTGPU_LIB", os.path.join(_HERE, "libbtgpu.so"))   # BTGPU_LIB: alternative build of the same library (tuning experiments)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
