@@ -398,6 +398,15 @@ class Gibbs:
     def reset_groups(self):
         check(bt_gibbs_reset_groups(self.h))
 
+    def posterior_summary(self):
+        """bt_gibbs_posterior_summary -> uint32 [C, S, 2] on the host (the device buffer is what a multi-GPU run gathers)"""
+        buf = DeviceBuffer(self.ctx, self.C * self.S * 2 * 4)
+        check(bt_gibbs_posterior_summary(self.h, buf.ptr))
+        self.ctx.sync()
+        out = buf.download(np.uint32, self.C * self.S * 2).reshape(self.C, self.S, 2)
+        buf.free()
+        return out
+
     def device_bytes(self):
         b = C.c_uint64()
         check(bt_gibbs_device_bytes(self.h, C.byref(b)))

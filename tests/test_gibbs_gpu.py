@@ -140,3 +140,36 @@ def test_stepwise_driving_and_noise_counts(gpu_ctx, oracle):
     ro, rg = og.results(), gg.results()
     assert_parity(flat, ro, rg, 4)
     og.close(), gg.close()
+
+
+def test_sharded_run_equals_unsharded_and_summary_definition(gpu_ctx, oracle):
+    """Multi-GPU path by construction: the groups of a batch split over two 'ranks' (run one after the other on this GPU), each
+    keeping its global group indices, give exactly the unsharded posterior summaries; bt_gibbs_posterior_summary agrees with its
+    host-side statement applied to the fetched results (and, through it, with the oracle)."""
+    from bayestyper_amd import lib, shard, synth
+
+    S = 2
+    flat = synth.concat([synth.make_batch("A", 70, S, seed=5, templates=3), synth.make_batch("B", 9, S, seed=6, templates=2), synth.make_batch("C", 3, S, seed=7)])
+    flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
+    lut_g, lut_n = _oracle.build_luts(oracle, S)
+    kw = dict(seed=42, chains=2, burn=10, iters=30)
+
+    def gpu_summary(f):
+        g = lib.Gibbs(gpu_ctx, f, lut_g, lut_n, **kw)
+        g.run()
+        summ, res = g.posterior_summary(), g.results()
+        g.close()
+        return summ, res
+
+    full, res = gpu_summary(flat)
+    assert np.array_equal(full, shard.summary_from_results(res, flat["num_clusters"], S))
+    og = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, **kw)
+    og.run(8)
+    assert np.array_equal(full, shard.summary_from_results(og.results(), flat["num_clusters"], S))
+    og.close()
+    parts = shard.assign_groups(shard.group_cost(flat), 2)
+    merged = np.zeros_like(full)
+    for ids in parts:
+        summ, _ = gpu_summary(shard.take_groups(flat, ids))
+        merged[shard.cluster_ids_of(flat, ids)] = summ
+    assert np.array_equal(merged, full)
