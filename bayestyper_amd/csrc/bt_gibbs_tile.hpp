@@ -25,6 +25,9 @@ constexpr unsigned LANES = 64;
 constexpr uint16_t NOHAP = 0xFFFF;
 constexpr double BT_LN2 = 0.693147180559945309417232121458176568;
 constexpr double BT_DBL_EPS = 2.220446049250313080847263336181640625e-16;
+#ifndef BT_LINEAR_DRAW_MIN
+#define BT_LINEAR_DRAW_MIN 4u   // candidate sets up to this size always use the reference's chain of logAddition calls
+#endif
 constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
 
 // scalar slots per vertex (A_SC)
@@ -107,6 +110,10 @@ enum TileArr {
     A_STACK,        // u32 [G] 2*(nvm+1)
     A_BRNG,         // u32 [G] per-lane contiguous MT_PAD
     A_SHMULT,       // u8  [G] NSHm*S
+    A_MSUBM,        // u8  [V] NMm*Hm         multiplicity rows of the multicluster subset k-mers, in subset order
+    A_MSUBC,        // u8  [V] NMm*S          their observed counts
+    A_MSUBIC,       // u8  [V] NMm*2          their intercluster multiplicities
+    A_MSUBSH,       // u32 [V] NMm            their slot in the group's shared-multiplicity table
     A_COUNT
 };
 
@@ -233,6 +240,10 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<uint32_t, LANES> mcgen() const { return a<uint32_t>(A_MCGEN, d().cache_entries); }
     __device__ inline SPtrF<uint32_t, LANES> mgen() const { return t.harr<uint32_t>(A_MGEN, v, d().S); }
     __device__ inline SPtr<uint8_t, LANES> oth() const { return a<uint8_t>(A_OTH, d().NMm * d().S); }
+    __device__ inline SPtr<uint8_t, LANES> msubm() const { return a<uint8_t>(A_MSUBM, (d().NMm > 1 ? d().NMm : 1) * d().Hm); }
+    __device__ inline SPtr<uint8_t, LANES> msubc() const { return a<uint8_t>(A_MSUBC, (d().NMm > 1 ? d().NMm : 1) * d().S); }
+    __device__ inline SPtr<uint8_t, LANES> msubic() const { return a<uint8_t>(A_MSUBIC, (d().NMm > 1 ? d().NMm : 1) * 2); }
+    __device__ inline SPtr<uint32_t, LANES> msubsh() const { return a<uint32_t>(A_MSUBSH, d().NMm > 1 ? d().NMm : 1); }
     __device__ inline SPtrF<uint32_t, LANES> pend() const { return t.harr<uint32_t>(A_PEND, v, d().S); }
     __device__ inline SPtrF<uint16_t, LANES> pend_dip() const { return t.harr<uint16_t>(A_PENDDIP, v, 2 * d().S); }
     __device__ inline SPtrF<uint8_t, LANES> pend_valid() const { return t.harr<uint8_t>(A_PENDVALID, v, d().S); }
@@ -289,10 +300,27 @@ __device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len
     if (ho == NOHOT) return;
     T *l = (T *)(lds_block() + ho) + t.lane;
     T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + v * len * LANES + t.lane;
-    if (to_lds)
-        for (uint32_t i = 0; i < len; ++i) l[i * LANES] = g[i * LANES];
-    else
-        for (uint32_t i = 0; i < len; ++i) g[i * LANES] = l[i * LANES];
+    // eight elements in flight per step (the copy is latency-bound: one wavefront, dependent address arithmetic otherwise)
+    uint32_t i = 0;
+    if (to_lds) {
+        for (; i + 8 <= len; i += 8) {
+            T tmp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tmp[q] = g[(i + q) * LANES];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) l[(i + q) * LANES] = tmp[q];
+        }
+        for (; i < len; ++i) l[i * LANES] = g[i * LANES];
+    } else {
+        for (; i + 8 <= len; i += 8) {
+            T tmp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tmp[q] = l[(i + q) * LANES];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g[(i + q) * LANES] = tmp[q];
+        }
+        for (; i < len; ++i) g[i * LANES] = l[i * LANES];
+    }
 }
 // move every hot array of vertex v between HBM and the wavefront's LDS block (lane-wise, coalesced)
 __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
@@ -639,6 +667,20 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
             sic[2 * i + 1] = hc ? c.ic(k, 1) : (uint8_t)0;
         }
     }
+    {
+        // the same for the multicluster subset k-mers (multi_refresh / multi_log_prob / updateMulticlusterDiplotypeLogProb inputs)
+        const uint32_t Hm = c.d().Hm;
+        SPtr<uint8_t, LANES> mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
+        SPtr<uint32_t, LANES> msh = c.msubsh();
+        for (uint32_t i = 0; i < nsm; ++i) {
+            const uint32_t k = msub[i];
+            for (uint32_t h = 0; h < c.H; ++h) mm[i * Hm + h] = c.M(k, h);
+            for (uint32_t ss = 0; ss < P.S; ++ss) mcn[i * P.S + ss] = c.count(k, ss);
+            mic[2 * i] = c.ic(k, 0);
+            mic[2 * i + 1] = c.ic(k, 1);
+            msh[i] = (uint32_t)c.shared_idx(k);
+        }
+    }
     PROF(10);
     PROF_CNT(11, nsu);
     SPtrF<uint32_t, LANES> sc = c.sc();
@@ -747,7 +789,30 @@ __device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) hb[q] = b0 + q < H ? b0 + q : H - 1;
                 double acc[4] = {0, 0, 0, 0};
-                for (uint32_t i = 0; i < nsub; ++i) {
+                uint32_t i = 0;
+                // four k-mers x four candidates per step: all 28 operand loads, then the 16 table lookups, then the additions
+                // (each candidate's sum still runs in subset order)
+                for (; i + 4 <= nsub; i += 4) {
+                    uint8_t m[4][4], cn[4];
+#pragma unroll
+                    for (uint32_t r = 0; r < 4; ++r) {
+                        const uint8_t ma = hap ? (uint8_t)0 : (uint8_t)sm[(i + r) * Hm + a];
+                        const uint8_t icn = sic[2 * (i + r) + gender];
+                        cn[r] = scn[(i + r) * S + s];
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q) m[r][q] = (uint8_t)((uint8_t)(ma + (uint8_t)sm[(i + r) * Hm + hb[q]]) + icn);
+                    }
+                    double lp[4][4];
+#pragma unroll
+                    for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q) lp[r][q] = count_log_prob(P, s, m[r][q], cn[r]);
+#pragma unroll
+                    for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q) acc[q] += lp[r][q];
+                }
+                for (; i < nsub; ++i) {
                     const uint8_t ma = hap ? (uint8_t)0 : (uint8_t)sm[i * Hm + a];
                     const uint8_t icn = sic[2 * i + gender], cn = scn[i * S + s];
                     uint8_t m[4];
@@ -773,14 +838,20 @@ __device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
 // is generation-stamped per sample: multi_refresh() compares the other clusters' contribution of every subset k-mer with a
 // snapshot and bumps the sample's generation when anything moved, which invalidates that sample's entries in O(1).  A hit
 // returns exactly the direct sum a miss would compute.
+__device__ inline uint8_t msub_dip_mult(SPtr<uint8_t, LANES> mm, uint32_t Hm, uint32_t i, uint16_t h1, uint16_t h2) {
+    uint8_t m = 0;
+    if (h1 != NOHAP) m = (uint8_t)(m + mm[i * Hm + h1]);
+    if (h2 != NOHAP) m = (uint8_t)(m + mm[i * Hm + h2]);
+    return m;
+}
 __device__ inline void multi_refresh(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t p1, uint16_t p2, uint32_t nsub_m) {
-    SPtr<uint32_t, LANES> msub = c.msub();
-    SPtr<uint8_t, LANES> oth = c.oth(), shm = c.shared_mult();
+    SPtr<uint8_t, LANES> oth = c.oth(), shm = c.shared_mult(), mm = c.msubm(), mcn = c.msubc();
+    SPtr<uint32_t, LANES> msh = c.msubsh();
+    const uint32_t Hm = c.d().Hm;
     bool moved = false;
     for (uint32_t sub = 0; sub < nsub_m; ++sub) {
-        const uint32_t k = msub[sub];
         uint8_t o = 0;
-        if (c.count(k, s) != 0) o = (uint8_t)(shm[(uint32_t)c.shared_idx(k) * P.S + s] - dip_mult(c, k, p1, p2));
+        if (mcn[sub * P.S + s] != 0) o = (uint8_t)(shm[(uint32_t)msh[sub] * P.S + s] - msub_dip_mult(mm, Hm, sub, p1, p2));
         if (o != oth[sub * P.S + s]) {
             oth[sub * P.S + s] = o;
             moved = true;
@@ -788,6 +859,9 @@ __device__ inline void multi_refresh(const Vx &c, const GParams BT_CAS &P, uint3
     }
     if (moved) c.mgen()[s] += 1;
 }
+// For one candidate: sum over the multicluster subset k-mers of log P(count | oth + M[h1] + M[h2] + intercluster) — the value of
+// getMulticlusterKmerMultiplicity for the candidate (VariantClusterHaplotypes.cpp:82-108) is exactly oth + own + intercluster,
+// in uchar arithmetic, with oth as refreshed by multi_refresh for the current generation.
 __device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t nsub_m, uint32_t gen) {
     const TileDesc BT_CAS &d = c.d();
     const uint32_t idx = dip_index(c, h1, h2);
@@ -795,16 +869,44 @@ __device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, ui
     const uint32_t slot = d.cache_mode == 0 ? s * d.Dcm + idx : ((key * 2654435761u) & (d.cache_entries - 1u));
     if (c.mctag()[slot] == key && c.mcgen()[slot] == gen) return c.mcache()[slot];
     double acc = 0;
-    SPtr<uint32_t, LANES> msub = c.msub();
+    SPtr<uint8_t, LANES> oth = c.oth(), mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
+    const uint32_t Hm = d.Hm;
+    const uint8_t gender = P.gender[s];
     for (uint32_t i = 0; i < nsub_m; ++i) {
-        const uint32_t k = msub[i];
-        const uint8_t m = multi_mult(c, P, k, h1, h2, p1, p2, s);
-        acc += count_log_prob(P, s, m, c.count(k, s));
+        const uint8_t m = (uint8_t)((uint8_t)(oth[i * P.S + s] + msub_dip_mult(mm, Hm, i, h1, h2)) + mic[2 * i + gender]);
+        acc += count_log_prob(P, s, m, mcn[i * P.S + s]);
     }
     c.mctag()[slot] = key;
     c.mcgen()[slot] = gen;
     c.mcache()[slot] = acc;
     return acc;
+}
+// The misses of a block of 8 candidates, evaluated together: per subset k-mer the shared operands (oth, intercluster, count) are
+// read once and the candidates' multiplicity rows and table lookups are independent loads.  Sums stay in subset order.
+__device__ inline void multi_log_prob_block(const Vx &c, const GParams BT_CAS &P, uint32_t s, const uint16_t (&ha)[8], const uint16_t (&hb)[8], const bool (&need)[8],
+                                            uint32_t nsub_m, double (&out)[8]) {
+    SPtr<uint8_t, LANES> oth = c.oth(), mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
+    const uint32_t Hm = c.d().Hm;
+    const uint8_t gender = P.gender[s];
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0;
+    for (uint32_t i = 0; i < nsub_m; ++i) {
+        const uint8_t o = (uint8_t)(oth[i * P.S + s]), icn = mic[2 * i + gender], cn = mcn[i * P.S + s];
+        uint8_t m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint16_t a = need[q] ? ha[q] : (uint16_t)0, b = need[q] ? hb[q] : NOHAP;   // safe addresses for unused slots
+            m[q] = (uint8_t)((uint8_t)(o + msub_dip_mult(mm, Hm, i, a, b)) + icn);
+        }
+        double lp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lp[q] = count_log_prob(P, s, m[q], cn);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += lp[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[q] = acc[q];
 }
 
 // ---- HaplotypeFrequencyDistribution::incrementCount (HaplotypeFrequencyDistribution.cpp:113-125) ----
@@ -867,12 +969,12 @@ __device__ inline void update_multicluster_multiplicities(const Vx &c, const GPa
             }
         }
     }
-    SPtr<uint32_t, LANES> msub = c.msub();
-    SPtr<uint8_t, LANES> smm = c.smm();
+    SPtr<uint8_t, LANES> smm = c.smm(), mm = c.msubm(), mcn = c.msubc();
+    SPtr<uint32_t, LANES> msh = c.msubsh();
+    const uint32_t Hm = c.d().Hm;
     for (uint32_t sub = 0; sub < nsub_m; ++sub) {
-        const uint32_t k = msub[sub];
-        const uint8_t shared = shm[(uint32_t)c.shared_idx(k) * P.S + s];
-        if (dip_mult(c, k, h1, h2) > 0 && c.count(k, s) > 0 && shared != smm[(uint32_t)sub * P.S + s]) c.ksc_upd()[s] = 1;
+        const uint8_t shared = shm[(uint32_t)msh[sub] * P.S + s];
+        if (msub_dip_mult(mm, Hm, sub, h1, h2) > 0 && mcn[sub * P.S + s] > 0 && shared != smm[(uint32_t)sub * P.S + s]) c.ksc_upd()[s] = 1;
         smm[(uint32_t)sub * P.S + s] = shared;
     }
 }
@@ -1113,50 +1215,143 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             gen = c.mgen()[s];
         }
         PROF(1);
-        // candidates in the reference's order; cumulative log-sum-exp exactly as LogDiscreteSampler::addOutcome
-        uint32_t ncand = 0;
-        double run = 0;
-        if (ploidy == 2) {
-            for (uint32_t a = 0; a < nnz; ++a) {
-                const uint16_t ha = nzl[a];
-                const double lfa = logf[ha];   // == log(freq[ha]) (VariantClusterGenotyper.cpp:603-616 computes it per candidate)
-                for (uint32_t b = a; b < nnz; ++b) {
-                    const uint16_t hb = nzl[b];
-                    double lp = 0;
-                    if (a == b) lp += 2 * lfa;
-                    else lp += BT_LN2 + lfa + logf[hb];
-                    lp += unique_log_prob(c, P, s, ha, hb, nsub_u);
-                    if (use_multi) lp += multi_log_prob(c, P, s, ha, hb, p1, p2, nsub_m, gen);
-                    run = ncand == 0 ? lp : log_addition(lp, run);
-                    cum[ncand++] = run;
+        // Candidates in the reference's order.  The reference builds the cumulative log-sums with a chain of logAddition calls
+        // (LogDiscreteSampler::addOutcome, DiscreteSampler.cpp:104-118) and picks upper_bound(cum, log(U) + cum.back()).
+        // Small candidate sets do exactly that.  Larger sets take the same decision from linear-domain running sums of
+        // exp(lp - max) against U * total (one exp per candidate instead of a dependent exp + log1p pair), and verify it: the
+        // two formulations can only disagree when U * total lies within the accumulated rounding error of a boundary, so
+        // whenever the threshold is closer than `margin` (>= 16x the worst-case bound) to either boundary of
+        // the picked interval — about once in 10^5..10^6 draws — the reference's chain is evaluated after all.
+        const uint32_t total = ploidy == 2 ? nnz * (nnz + 1) / 2 : (ploidy == 1 ? nnz : 0u);
+        const bool chain_only = total <= BT_LINEAR_DRAW_MIN;
+        double lpmax = 0;
+        // lp of every candidate -> cum[0..total), in order; returns through lpmax the maximum
+        // Evaluated in blocks of 8: the cache words of a whole block are requested first (independent loads, one memory round trip
+        // per block instead of one per candidate), then the block is finished in order.
+        auto eval_candidates = [&]() {
+            const bool dipl = ploidy == 2;
+            const TileDesc BT_CAS &dd = c.d();
+            SPtr<double, LANES> uc = c.ucache(), mc = c.mcache();
+            SPtr<uint32_t, LANES> uct = c.uctag(), mct = c.mctag(), mcg = c.mcgen();
+            const bool multi = use_multi && nsub_m != 0;
+            uint32_t a = 0, b = 0, n = 0;   // enumeration state (diploid: b >= a)
+            for (uint32_t base = 0; base < total; base += 8) {
+                const uint32_t nb = total - base < 8 ? total - base : 8;
+                uint16_t ha[8], hb[8];
+                uint32_t uslot[8], ukey[8];
+                double uval[8], mval[8], la[8], lb[8];
+                uint32_t utag[8], mtag[8], mgn[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) {
+                    if (q < nb) {
+                        ha[q] = nzl[a];
+                        hb[q] = dipl ? (uint16_t)nzl[b] : NOHAP;
+                        if (dipl) {
+                            if (++b == nnz) {
+                                ++a;
+                                b = a;
+                            }
+                        } else
+                            ++a;
+                        const uint32_t idx = dip_index(c, ha[q], hb[q]);
+                        ukey[q] = s * dd.Dcm + idx + 1u;
+                        uslot[q] = dd.cache_mode == 0 ? s * dd.Dcm + idx : ((ukey[q] * 2654435761u) & (dd.cache_entries - 1u));
+                        uval[q] = dd.cache_mode != 2 ? (double)uc[uslot[q]] : 0.0;
+                        utag[q] = dd.cache_mode == 1 ? (uint32_t)uct[uslot[q]] : 0u;
+                        if (multi) {
+                            mtag[q] = mct[uslot[q]];
+                            mgn[q] = mcg[uslot[q]];
+                            mval[q] = mc[uslot[q]];
+                        }
+                        la[q] = logf[ha[q]];   // == log(freq[h]) (VariantClusterGenotyper.cpp:603-616 computes it per candidate)
+                        lb[q] = dipl ? (double)logf[hb[q]] : 0.0;
+                    }
+                }
+                if (multi) {
+                    bool need[8], any = false;
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q) {
+                        need[q] = q < nb && !(mtag[q] == ukey[q] && mgn[q] == gen);
+                        any = any || need[q];
+                    }
+                    if (any) {
+                        double fresh[8];
+                        multi_log_prob_block(c, P, s, ha, hb, need, nsub_m, fresh);
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q)
+                            if (need[q]) {
+                                mval[q] = fresh[q];
+                                mct[uslot[q]] = ukey[q];
+                                mcg[uslot[q]] = gen;
+                                mc[uslot[q]] = fresh[q];
+                            }
+                    }
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) {
+                    if (q < nb) {
+                        double lp = 0;
+                        if (!dipl) lp += la[q];
+                        else if (ha[q] == hb[q]) lp += 2 * la[q];
+                        else lp += BT_LN2 + la[q] + lb[q];
+                        // dense tables are complete (fill_unique_cache); hashed tables fill on demand
+                        const bool uhit = dd.cache_mode == 0 || (dd.cache_mode == 1 && utag[q] == ukey[q]);
+                        lp += uhit ? uval[q] : unique_log_prob(c, P, s, ha[q], hb[q], nsub_u);
+                        if (multi) lp += mval[q];
+                        lpmax = (n == 0 || lp > lpmax) ? lp : lpmax;
+                        cum[n++] = lp;
+                    }
                 }
             }
-        } else if (ploidy == 1) {
-            for (uint32_t a = 0; a < nnz; ++a) {
-                const uint16_t ha = nzl[a];
-                double lp = 0;
-                lp += logf[ha];
-                lp += unique_log_prob(c, P, s, ha, NOHAP, nsub_u);
-                if (use_multi) lp += multi_log_prob(c, P, s, ha, NOHAP, p1, p2, nsub_m, gen);
-                run = ncand == 0 ? lp : log_addition(lp, run);
-                cum[ncand++] = run;
+        };
+        // the reference's decision on cum[] holding the lp values: chain, then upper_bound (first index with cum > u)
+        auto chain_pick = [&](double u01) -> uint32_t {
+            if (total == 0) return 0u;
+            double run = cum[0];
+            for (uint32_t i = 1; i < total; ++i) {
+                run = log_addition((double)cum[i], run);
+                cum[i] = run;
             }
-        } else {
-            ncand = 1;
-            run = 0;
-        }
-        PROF(2);
-        // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome
-        const double u = bt_log(rng_canonical(rng)) + run;
-        uint32_t pick = 0;
-        if (ncand > 1) {
-            uint32_t lo = 0, hi = ncand;   // upper_bound: first index with cum > u
+            const double u = bt_log(u01) + run;
+            uint32_t lo = 0, hi = total;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (u < cum[mid]) hi = mid;
                 else lo = mid + 1;
             }
-            pick = lo < ncand ? lo : ncand - 1;
+            return lo < total ? lo : total - 1;
+        };
+        eval_candidates();
+        PROF(2);
+        // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome
+        const double u01 = rng_canonical(rng);
+        uint32_t pick = 0;
+        if (chain_only) {
+            if (total == 0) (void)bt_log(u01);
+            pick = chain_pick(u01);
+        } else {
+            double acc = 0;
+            for (uint32_t i = 0; i < total; ++i) {
+                acc += bt_exp((double)cum[i] - lpmax);
+                cum[i] = acc;
+            }
+            const double thr = u01 * acc;
+            uint32_t lo = 0, hi = total;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (thr < cum[mid]) hi = mid;
+                else lo = mid + 1;
+            }
+            const double amax = fabs(lpmax) > 1.0 ? fabs(lpmax) : 1.0;
+            double margin = 64.0 * (double)total * amax * BT_DBL_EPS;
+            margin = (margin > 1e-6 ? margin : 1e-6) * acc;
+            const bool safe = lo < total && (double)cum[lo] - thr > margin && (lo == 0 || thr - (double)cum[lo - 1] > margin);
+            if (safe) pick = lo;
+            else {
+                PROF_CNT(14, 1000000);   // shows up as 1.0 per fallback in the "nested" column of scratch/prof_phases.py
+                eval_candidates();
+                pick = chain_pick(u01);
+            }
         }
         uint16_t h1 = NOHAP, h2 = NOHAP;
         if (ploidy == 2) {
