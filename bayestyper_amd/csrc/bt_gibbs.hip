@@ -643,7 +643,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 ho = (uint32_t)align_up(ho + per_vertex * LANES * kElemSize[a], 16);
             }
             d.hot_bytes = ho;
-            if (ho > kHotBudget) {
+            if (ho > kHotBudget || (d.nvm > 1 && getenv("BT_GIBBS_NOHOT_MULTI"))) {
                 for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
                 d.hot_bytes = 0;
             }

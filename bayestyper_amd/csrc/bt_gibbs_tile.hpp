@@ -295,29 +295,31 @@ __device__ inline uint32_t vx_ne(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS
 
 // ---- LDS residency of a vertex's hot arrays ----------------------------------------------------------------------
 template <typename T>
-__device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len, bool to_lds) {
+__device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len, bool to_lds, uint32_t live = 0xFFFFFFFFu) {
     const uint32_t ho = t.d->hoff[arr];
     if (ho == NOHOT) return;
-    T *l = (T *)(lds_block() + ho) + t.lane;
+    T BT_LAS *l = (T BT_LAS *)(bt_lds_raw + ho) + t.lane;   // explicit LDS pointer: the copies of different arrays can overlap (no aliasing with HBM)
     T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + v * len * LANES + t.lane;
-    // eight elements in flight per step (the copy is latency-bound: one wavefront, dependent address arithmetic otherwise)
+    // eight elements in flight per step (the copy is latency-bound: one wavefront, one memory round trip per step)
     uint32_t i = 0;
+    len = live < len ? live : len;   // (the vertex stride above used the full row count)
+    constexpr int U = 8;
     if (to_lds) {
-        for (; i + 8 <= len; i += 8) {
-            T tmp[8];
+        for (; i + U <= len; i += U) {
+            T tmp[U];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) tmp[q] = g[(i + q) * LANES];
+            for (int q = 0; q < U; ++q) tmp[q] = g[(i + q) * LANES];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) l[(i + q) * LANES] = tmp[q];
+            for (int q = 0; q < U; ++q) l[(i + q) * LANES] = tmp[q];
         }
         for (; i < len; ++i) l[i * LANES] = g[i * LANES];
     } else {
-        for (; i + 8 <= len; i += 8) {
-            T tmp[8];
+        for (; i + U <= len; i += U) {
+            T tmp[U];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) tmp[q] = l[(i + q) * LANES];
+            for (int q = 0; q < U; ++q) tmp[q] = l[(i + q) * LANES];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) g[(i + q) * LANES] = tmp[q];
+            for (int q = 0; q < U; ++q) g[(i + q) * LANES] = tmp[q];
         }
         for (; i < len; ++i) g[i * LANES] = l[i * LANES];
     }
@@ -337,11 +339,13 @@ __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
     hot_copy<uint32_t>(t, A_PEND, v, d.S, to_lds);
     hot_copy<uint16_t>(t, A_PENDDIP, v, 2 * d.S, to_lds);
     hot_copy<uint8_t>(t, A_PENDVALID, v, d.S, to_lds);
-    hot_copy<double>(t, A_FREQ, v, d.Hm, to_lds);
-    hot_copy<double>(t, A_LOGF, v, d.Hm, to_lds);
-    hot_copy<uint32_t>(t, A_OBS, v, d.Hm, to_lds);
-    hot_copy<uint8_t>(t, A_NZ, v, d.Hm, to_lds);
-    hot_copy<uint32_t>(t, A_UNEXT, v, d.Hm, to_lds);
+    // per-haplotype arrays: only this lane's H entries are live (rows are Hm apart; the tail is never read)
+    const uint32_t H = t.arr<uint32_t>(A_VDIMS, v * 8)[0];
+    hot_copy<double>(t, A_FREQ, v, d.Hm, to_lds, H);
+    hot_copy<double>(t, A_LOGF, v, d.Hm, to_lds, H);
+    hot_copy<uint32_t>(t, A_OBS, v, d.Hm, to_lds, H);
+    hot_copy<uint8_t>(t, A_NZ, v, d.Hm, to_lds, H);
+    hot_copy<uint32_t>(t, A_UNEXT, v, d.Hm, to_lds, H);
     hot_copy<uint32_t>(t, A_ZHDR, v, 4, to_lds);
     hot_copy<uint32_t>(t, A_ZBKT, v, d.Bcap, to_lds);
     hot_copy<uint32_t>(t, A_PHDR, v, 4, to_lds);
@@ -469,26 +473,44 @@ __device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
     SPtr<uint8_t, LANES> rows = c.cover_rows();
     SPtrF<uint32_t, LANES> obs = c.obs();
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
+    const uint32_t Hm = c.d().Hm, H = c.H;
+    SPtr<uint8_t, LANES> M = c.a<uint8_t>(A_M, (uint32_t)c.d().Km * Hm);
+    // The reference recomputes the column sums of the still-uncovered rows in every round; the sums are integers, so keeping
+    // them up to date (add every row once, subtract it when it gets covered) gives the same values with one pass per row.
+    auto row_apply = [&](uint32_t k, bool add) {
+        uint32_t h = 0;
+        for (; h + 8 <= H; h += 8) {
+            uint32_t m[8], o[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = M[k * Hm + h + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = obs[h + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) obs[h + q] = add ? o[q] + m[q] : o[q] - m[q];
+        }
+        for (; h < H; ++h) {
+            const uint32_t m = M[k * Hm + h];
+            obs[h] = add ? obs[h] + m : obs[h] - m;
+        }
+    };
     uint32_t remaining = 0;
+    for (uint32_t h = 0; h < H; ++h) obs[h] = 0;
     for (uint32_t k = 0; k < c.K; ++k) {
         const uint8_t r = c.has_counts(k) ? 1 : 0;
         rows[k] = r;
         remaining += r;
+        if (r) row_apply(k, true);
     }
     uint32_t cover = 0;
     while (remaining > 0) {
-        for (uint32_t h = 0; h < c.H; ++h) obs[h] = 0;
-        for (uint32_t k = 0; k < c.K; ++k)
-            if (rows[k])
-                for (uint32_t h = 0; h < c.H; ++h) obs[h] += c.M(k, h);
         uint32_t best = 0;
-        for (uint32_t h = 0; h < c.H; ++h) {
+        for (uint32_t h = 0; h < H; ++h) {
             const uint32_t o = obs[h];
             best = o > best ? o : best;
         }
         if (best == 0) break;   // the reference asserts max_row_cover > 0
         uint32_t m = 0;
-        for (uint32_t h = 0; h < c.H; ++h)
+        for (uint32_t h = 0; h < H; ++h)
             if (obs[h] == best) nzl[m++] = (uint16_t)h;
         // DiscreteSampler with outcomes 1,1,...: cum = 1..m; sample = upper_bound(cum, canonical * m) (DiscreteSampler.cpp:61-87)
         const double x = rng_canonical(rng) * (double)m;
@@ -500,9 +522,10 @@ __device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
         const uint32_t col = nzl[pick];
         ++cover;
         for (uint32_t k = 0; k < c.K; ++k)
-            if (rows[k] && c.M(k, col) != 0) {
+            if (rows[k] && M[k * Hm + col] != 0) {
                 rows[k] = 0;
                 --remaining;
+                row_apply(k, false);
             }
     }
     return cover;

@@ -46,9 +46,11 @@ BT_MATH double bt_pow(double x, double y) { return pow(x, y); }
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BT_GAS __attribute__((address_space(1)))
 #define BT_CAS __attribute__((address_space(4)))   // read-only ("constant") global memory: eligible for scalar loads
+#define BT_LAS __attribute__((address_space(3)))   // LDS
 #else
 #define BT_GAS
 #define BT_CAS
+#define BT_LAS
 #endif
 template <typename T, unsigned STRIDE>
 struct SPtr {
