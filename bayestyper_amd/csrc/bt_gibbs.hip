@@ -485,7 +485,32 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         if (a.Hmax != b.Hmax) return a.Hmax > b.Hmax;
         return a.Kmax > b.Kmax;
     });
-    const uint32_t ntiles = (G + LANES - 1) / LANES;
+    // Tiles hold up to 64 groups (one per lane).  The few most expensive groups of a batch (nested groups, clusters with many
+    // haplotypes) run thousands of sequential sweeps each and would otherwise occupy a handful of wavefronts while the rest of
+    // the chip idles after the cheap groups finish: they are cut into narrower tiles (fewer groups per wavefront => less
+    // divergence per step and more compute units working on the tail).  Cheap groups always fill 64-lane tiles.
+    std::vector<uint32_t> tile_start;
+    {
+        uint32_t n_tail = 0;
+        while (n_tail < G && (shapes[n_tail].nv > 1 || shapes[n_tail].Hmax >= 16)) ++n_tail;   // sorted: expensive groups first
+        uint32_t width = LANES;
+        while (width > 16 && (uint64_t)n_tail * 2 <= (uint64_t)width * 256) width /= 2;         // aim at >= one tile per 2 CUs
+        if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {   // tuning override
+            const int v = atoi(e);
+            if (v == 8 || v == 16 || v == 32 || v == 64) width = (uint32_t)v;
+        }
+        uint32_t at = 0;
+        while (at < n_tail) {
+            tile_start.push_back(at);
+            at += std::min<uint32_t>(width, n_tail - at);
+        }
+        while (at < G) {
+            tile_start.push_back(at);
+            at += std::min<uint32_t>(LANES, G - at);
+        }
+        tile_start.push_back(G);
+    }
+    const uint32_t ntiles = (uint32_t)tile_start.size() - 1;
     g->ntiles = ntiles;
     g->group_tile.assign(G, 0);
     g->group_lane.assign(G, 0);
@@ -498,11 +523,11 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     for (uint32_t ti = 0; ti < ntiles; ++ti) {
         TileDesc d{};
         d.S = S;
-        d.first_group = ti * LANES;
-        d.num_lanes = std::min<uint32_t>(LANES, G - ti * LANES);
+        d.first_group = tile_start[ti];
+        d.num_lanes = tile_start[ti + 1] - tile_start[ti];
         uint32_t Am = 1, NSHm = 0;
         for (uint32_t l = 0; l < d.num_lanes; ++l) {
-            const uint32_t gi = shapes[ti * LANES + l].g;
+            const uint32_t gi = shapes[tile_start[ti] + l].g;
             const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
             d.nvm = std::max(d.nvm, c1 - c0);
             NSHm = std::max(NSHm, B->group_num_shared[gi]);
@@ -681,7 +706,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         g->tiles[ti] = d;
         img.assign(plans[ti].in_bytes, 0);
         for (uint32_t l = 0; l < d.num_lanes; ++l) {
-            const uint32_t gi = shapes[ti * LANES + l].g;
+            const uint32_t gi = shapes[tile_start[ti] + l].g;
             const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
             g->group_tile[gi] = ti;
             g->group_lane[gi] = l;
