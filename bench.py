@@ -209,6 +209,17 @@ def main():
         gibbs_bytes = synth.algorithmic_bytes_per_chain(flat) * gibbs.params.num_chains     # one launch = all chains of all clusters
         gibbs_gbs = gibbs_bytes / (gibbs_avg_ms * 1e-3) / 1e9
         kmc_gbs = R * KMER_MATCH_BYTES_PER_RECORD / (kmc_avg_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC passes of the same command (profiles/, collected with rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs; counters cannot be read from inside this process).  Only reported for the default workload.
+        traffic, traffic_kmc, traffic_src = None, None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        default_workload = (args.groups, args.samples, args.records) == (150_000, 1, 200_000_000)
+        if default_workload and os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc = json.load(fh)
+            traffic = pmc["gibbs_kernel_bytes_per_step"]["total"]
+            traffic_kmc = pmc["kmc_scan_kernel_bytes_per_launch"]["fetch_raw"] + pmc["kmc_scan_kernel_bytes_per_launch"]["write"]
+            traffic_src = "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, uncorrected; Infinity-Cache hits are counted)"
         out = {
             "metric": "variant-cluster Gibbs iterations/sec + k-mer matches/sec at 1/2/4/8 MI355X",
             "value": total_cluster_sweeps / elapsed,
@@ -229,10 +240,12 @@ def main():
                        "groups_per_gpu": G, "clusters_per_gpu": C, "samples": S, "kmc_records_per_gpu": R, "sharding": "groups and KMC byte ranges per rank; "
                        "gather of posterior summaries to rank 0"},
             "roofline": {"kernel": "gibbs_kernel", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gibbs_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": gibbs_avg_ms,
-                         "note": "latency/issue-bound sequential sampler: the HBM floor (inputs + state once per chain, SURVEY 8d) is tiny by construction"},
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
+                         "note": "latency/issue-bound sequential sampler (one lane per variant-cluster group): the HBM floor (inputs + state once per chain, "
+                                 "SURVEY 8d) is tiny by construction; avg_launch_ms spans the two concurrent launches (light / heavy tiles) of one schedule; "
+                                 "measured traffic is dominated by the per-draw mt19937 state updates of 150k groups"},
             "roofline_kmer_match": {"kernel": "kmc_scan_kernel", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kmc_avg_ms, "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD,
+                                    "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": traffic_kmc, "avg_launch_ms": kmc_avg_ms, "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD,
                                     "bloom_hits": hits, "table_keys": st["num_keys"]},
             "cpu_baseline": cpu,
             "gibbs_device_bytes": gibbs.device_bytes(),

@@ -50,6 +50,12 @@ def _worker(rank, world, port, out_path):
     mine = shard.take_groups(flat, parts[rank])
     local = _run_oracle(mine, S)
     full = shard.gather_summaries(local, shard.cluster_ids_of(flat, parts[rank]), flat["num_clusters"], rank, world)
+    # the noise drivers' only exchange: sum of the per-rank noise-count histograms
+    import torch
+
+    hist = torch.full((S, 256), rank + 1, dtype=torch.int64)
+    shard.allreduce_noise_counts(hist)
+    assert int(hist[0, 0]) == sum(range(1, world + 1))
     if rank == 0:
         np.save(out_path, full)
     dist.barrier()
