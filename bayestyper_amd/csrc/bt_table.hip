@@ -161,6 +161,45 @@ __global__ __launch_bounds__(BLOCK) void table_find_kernel(TableView t, const ui
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned SEQ_TILE = 1024;
 
+// calculateKmerStats (KmerHash.cpp:256-340): class tallies + exact integer moments of the parameter k-mers' counts per
+// (sample, intercluster multiplicity).  Per-workgroup LDS accumulation of the tallies; the (s, m) bins go straight to global
+// atomics (parameter k-mers are a ~1e-3 fraction of the table and concentrate on a handful of bins per sample).
+__global__ __launch_bounds__(BLOCK) void kmer_stats_kernel(TableView t, uint64_t capacity, uint32_t S, uint32_t gender_mask, unsigned long long *__restrict__ acc) {
+    __shared__ unsigned int tally[7];
+    if (threadIdx.x < 7) tally[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long *n = acc + 7, *sum = n + (size_t)S * 256, *sumsq = sum + (size_t)S * 256, *nonzero = sumsq + (size_t)S * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        if (t.state[i] != ST_READY) continue;
+        const uint32_t meta = t.meta[i];
+        const uint32_t flags = meta & 0xffu;
+        atomicAdd(&tally[0], 1u);
+        if (flags & BT_KC_CLUSTER_OCC) {
+            if (flags & (BT_KC_DECOY_OCC | BT_KC_MAX_MULTIPLICITY | BT_KC_MULTIGROUP_OCC)) {   // isExcluded (KmerCounts.cpp:93-96)
+                if (flags & BT_KC_DECOY_OCC) atomicAdd(&tally[3], 1u);
+                else if (flags & BT_KC_MAX_MULTIPLICITY) atomicAdd(&tally[4], 1u);
+                else atomicAdd(&tally[5], 1u);
+            } else if (flags & BT_KC_MULTICLUSTER_OCC) atomicAdd(&tally[2], 1u);
+            else atomicAdd(&tally[1], 1u);
+        } else {
+            atomicAdd(&tally[6], 1u);
+            if (flags & BT_KC_PARAMETER) {
+                const uint8_t *cnt = reinterpret_cast<const uint8_t *>(t.counts) + i * t.spad;
+                for (uint32_t s = 0; s < S; ++s) {
+                    const uint32_t m = (gender_mask >> s) & 1u ? (meta >> 24) & 0xffu : (meta >> 16) & 0xffu;   // male : female
+                    const unsigned long long c = cnt[s];
+                    atomicAdd(&n[s * 256 + m], 1ull);
+                    atomicAdd(&sum[s * 256 + m], c);
+                    atomicAdd(&sumsq[s * 256 + m], c * c);
+                    if (c) atomicAdd(&nonzero[s * 256 + m], 1ull);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 7 && tally[threadIdx.x]) atomicAdd(&acc[threadIdx.x], (unsigned long long)tally[threadIdx.x]);
+}
+
 __global__ __launch_bounds__(BLOCK) void intercluster_kernel(TableView t, BloomView bloom, const char *__restrict__ seq, uint64_t len,
                                                              int is_decoy, uint32_t fem, uint32_t male) {
     __shared__ uint8_t codes[SEQ_TILE + 64];
@@ -459,6 +498,34 @@ int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *
         ++w;
     }
     *num_written = w;
+    return BT_OK;
+}
+
+int bt_table_kmer_stats(bt_table *t, const uint8_t *h_gender, uint64_t *h_class_counts, uint64_t *h_n, uint64_t *h_nonzero, uint64_t *h_sum, uint64_t *h_sumsq) {
+    if (!t || !h_gender || !h_class_counts || !h_n || !h_nonzero || !h_sum || !h_sumsq) return fail("bt_table_kmer_stats: null argument");
+    BT_HIP(hipSetDevice(t->ctx->device));
+    const uint32_t S = t->num_samples;
+    const size_t words = 7 + (size_t)4 * S * 256;
+    unsigned long long *d_acc = nullptr;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_acc), words * 8));
+    BT_HIP(hipMemsetAsync(d_acc, 0, words * 8, t->ctx->stream));
+    uint32_t gmask = 0;
+    for (uint32_t s = 0; s < S; ++s) gmask |= (uint32_t)(h_gender[s] & 1u) << s;
+    const unsigned grid = grid_for(t->capacity, BLOCK, t->ctx->num_cu * 8);
+    hipLaunchKernelGGL(kmer_stats_kernel, dim3(grid), dim3(BLOCK), 0, t->ctx->stream, t->v, t->capacity, S, gmask, d_acc);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(t->ctx->stream);
+    std::vector<unsigned long long> h(words);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d_acc, words * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_acc);
+    if (e != hipSuccess) return fail(std::string("bt_table_kmer_stats: ") + hipGetErrorString(e));
+    for (int i = 0; i < 7; ++i) h_class_counts[i] = h[i];
+    for (size_t i = 0; i < (size_t)S * 256; ++i) {
+        h_n[i] = h[7 + i];
+        h_sum[i] = h[7 + (size_t)S * 256 + i];
+        h_sumsq[i] = h[7 + (size_t)2 * S * 256 + i];
+        h_nonzero[i] = h[7 + (size_t)3 * S * 256 + i];
+    }
     return BT_OK;
 }
 

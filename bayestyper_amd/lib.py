@@ -63,6 +63,7 @@ bt_table_insert_batch = _sig("bt_table_insert_batch", [vp, vp, C.c_uint64, C.c_i
 bt_table_find_batch = _sig("bt_table_find_batch", [vp, vp, C.c_uint64, vp])
 bt_table_read_slots = _sig("bt_table_read_slots", [vp, vp, C.c_uint64, vp, vp])
 bt_table_export = _sig("bt_table_export", [vp, vp, vp, vp, C.c_uint64, u64p])
+bt_table_kmer_stats = _sig("bt_table_kmer_stats", [vp, vp, vp, vp, vp, vp, vp])
 bt_table_count_intercluster = _sig("bt_table_count_intercluster", [vp, vp, vp, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32])
 bt_table_classify_batch = _sig("bt_table_classify_batch", [vp, vp, vp, vp, C.c_uint64, vp])
 bt_kmc_scan_create = _sig("bt_kmc_scan_create", [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.POINTER(vp)])
@@ -283,6 +284,14 @@ class Table:
         for b in (d, m, o):
             b.free()
         return out
+
+    def kmer_stats(self, gender):
+        """bt_table_kmer_stats -> (class_counts[7], dict of exact integer moments n / nonzero / sum / sumsq, each [S, 256])"""
+        g = np.ascontiguousarray(gender, dtype=np.uint8)
+        cls = np.zeros(7, np.uint64)
+        mom = {k: np.zeros((self.num_samples, 256), np.uint64) for k in ("n", "nonzero", "sum", "sumsq")}
+        check(bt_table_kmer_stats(self.h, _np_ptr(g), _np_ptr(cls), _np_ptr(mom["n"]), _np_ptr(mom["nonzero"]), _np_ptr(mom["sum"]), _np_ptr(mom["sumsq"])))
+        return cls, mom
 
     def export(self):
         """-> (kmers (n,2) u64, counts (n,S) u8, meta (n,4) u8) sorted by (hi, lo)"""

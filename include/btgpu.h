@@ -159,6 +159,16 @@ int bt_table_read_slots(bt_table *t, const int64_t *h_slots, uint64_t n, uint8_t
 /* export every stored record (iteration order unspecified); arrays sized by bt_table_status */
 int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *h_meta, uint64_t max_records, uint64_t *num_written);
 
+/* ObservedKmerCountsHash<N>::calculateKmerStats (src/bayesTyper/KmerHash.cpp:256-340): one pass over the table.
+ * h_class_counts[7] = {total, unique, multicluster, decoy, max_multiplicity, multigroup, non_cluster} exactly as the reference
+ * tallies them (:268-321).  For every PARAMETER k-mer without cluster occurrence and every sample s the observed count c enters
+ * the bin (s, m = interclusterMultiplicity(gender[s])): the device accumulates the exact integer moments
+ *   h_n[s*256+m] += 1, h_nonzero[s*256+m] += (c != 0), h_sum[s*256+m] += c, h_sumsq[s*256+m] += c*c
+ * (order-independent, unlike the reference's running Welford update; KmerStats count / fraction / mean / variance follow from them on the host:
+ * KmerStats.cpp:51-63,107-121).  gender[s]: 0 female, 1 male (Utils::Gender). */
+int bt_table_kmer_stats(bt_table *t, const uint8_t *h_gender, uint64_t *h_class_counts, uint64_t *h_n, uint64_t *h_nonzero, uint64_t *h_sum,
+                        uint64_t *h_sumsq);
+
 /* KmerCounter::countInterclusterKmers for ONE region (src/bayesTyper/KmerCounter.cpp:291-338):
  * slide over d_seq[0..len), canonical k-mers that hit `path_bloom` are added to the table
  * (addKmer sorted) and get addInterclusterMultiplicity(is_decoy, {female_ploidy, male_ploidy})

@@ -390,6 +390,40 @@ void orc_table_classify(void *h, void *mg_bloom, const char *kmers, const uint8_
         }
     }
 }
+// ObservedKmerCountsHash<N>::calculateKmerStats (KmerHash.cpp:256-340) with KmerStats::addValue (KmerStats.cpp:51-63) as the
+// reference runs it: a running Welford update per (sample, intercluster multiplicity) in table iteration order.
+// class_counts[7] = {total, unique, multicluster, decoy, max_multiplicity, multigroup, non_cluster};
+// stats[(s*256+m)*4 + {count, fraction, mean, M2}]
+void orc_table_kmer_stats(void *h, const uint8_t *gender, uint64_t *class_counts, double *stats) {
+    OrcTable *t = (OrcTable *)h;
+    for (int i = 0; i < 7; i++) class_counts[i] = 0;
+    for (size_t i = 0; i < (size_t)t->num_samples * 256 * 4; i++) stats[i] = 0;
+    for (auto &e : t->map) {
+        const KC &kc = e.second;
+        class_counts[0]++;
+        if (kc.flags & 0x01) {
+            if (kc.isExcluded()) {
+                if (kc.flags & 0x08) class_counts[3]++;
+                else if (kc.flags & 0x10) class_counts[4]++;
+                else class_counts[5]++;
+            } else if (kc.flags & 0x02) class_counts[2]++;
+            else class_counts[1]++;
+        } else {
+            class_counts[6]++;
+            if (kc.flags & 0x20) {
+                for (unsigned s = 0; s < t->num_samples; s++) {
+                    double *ks = stats + ((size_t)s * 256 + (gender[s] ? kc.male : kc.fem)) * 4;
+                    const double value = kc.counts[s];
+                    ks[0] += 1;
+                    ks[1] += ((value != 0 ? 1.0 : 0.0) - ks[1]) / ks[0];
+                    const double delta = value - ks[2];
+                    ks[2] += delta / ks[0];
+                    ks[3] += delta * (value - ks[2]);
+                }
+            }
+        }
+    }
+}
 // export sorted by ASCII k-mer: kmers (n*k chars), counts (n*num_samples), meta (n*4)
 uint64_t orc_table_export(void *h, char *kmers, uint8_t *counts, uint8_t *meta) {
     OrcTable *t = (OrcTable *)h;

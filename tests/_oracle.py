@@ -66,6 +66,8 @@ class Oracle:
         L.orc_table_classify.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]
         L.orc_table_export.restype = C.c_uint64
         L.orc_table_export.argtypes = [vp, vp, vp, vp]
+        L.orc_table_kmer_stats.restype = None
+        L.orc_table_kmer_stats.argtypes = [vp, vp, vp, vp]
         L.orc_kmc_write.argtypes = [C.c_char_p, vp, vp, C.c_uint64, C.c_uint, C.c_uint, C.c_uint]
         L.orc_kmc_open.restype = vp
         L.orc_kmc_open.argtypes = [C.c_char_p]
@@ -189,6 +191,14 @@ class OrcTable:
     def parse_sample_kmers(self, bloom, kmc, sample_idx, first=0, n=None):
         n = kmc.total - first if n is None else n
         return self.o.l.orc_parse_sample_kmers(self.h, bloom.h, kmc.h, sample_idx, first, n)
+
+    def kmer_stats(self, gender):
+        """calculateKmerStats -> (class_counts[7], stats[S,256,4] = count, fraction, mean, M2 of the running Welford update)"""
+        g = np.ascontiguousarray(gender, dtype=np.uint8)
+        cls = np.zeros(7, np.uint64)
+        st = np.zeros((self.S, 256, 4), np.float64)
+        self.o.l.orc_table_kmer_stats(self.h, _ptr(g), _ptr(cls), _ptr(st))
+        return cls, st
 
     def export(self):
         """-> (packed kmers (n,2) u64, counts (n,S), meta (n,4)) sorted by ASCII k-mer"""

@@ -295,3 +295,65 @@ def test_large_scan_properties(gpu_ctx, oracle):
     for x in (scan, bloom, table):
         x.close()
     d_rec.free(), d_hits.free()
+
+
+def test_calculate_kmer_stats(gpu_ctx, oracle, tmp_path):
+    """ObservedKmerCountsHash::calculateKmerStats: class tallies exact; the (sample, intercluster multiplicity) statistics of the
+    parameter k-mers — exact integer moments on the device — agree with the reference's running Welford update to 1e-12."""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(21)
+    S, gender = 3, np.array([0, 1, 1], np.uint8)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 60_000)].copy()
+    genome[20_000:24_000] = genome[5_000:9_000]            # repeat -> intercluster multiplicity 2x
+    win_k, win_v = oracle.kmers_from_sequence(genome[4_000:26_000].tobytes(), K)
+    members = np.unique(win_k[win_v == 1], axis=0)
+    mem_ascii = oracle.unpack(members, K)
+    ob = OrcBloom(oracle, len(members), 1e-3, K, threaded=True)
+    ob.insert(mem_ascii)
+    gb = lib.Bloom.create(gpu_ctx, len(members), 1e-3, K, threaded=True)
+    gb.insert(members)
+    ot, gt = OrcTable(oracle, S, K), lib.Table(gpu_ctx, 60_000, S, K)
+    # parameter k-mers (main.cpp:571-577), then intercluster multiplicities, then sample counts from a KMC database, then a few
+    # cluster occurrences (parameter k-mers never get one in the reference: pick the classified ones from the non-parameter half)
+    par = mem_ascii.reshape(-1, K)[::2]
+    ot.insert(np.ascontiguousarray(par).reshape(-1), mark_parameter=True)
+    gt.insert(oracle.pack(np.ascontiguousarray(par).reshape(-1), K), mark_parameter=True)
+    for (a, b, decoy, f, m) in [(0, 30_000, 0, 2, 1), (30_000, 60_000, 0, 2, 2)]:
+        ot.count_intercluster(ob, genome[a:b].tobytes(), decoy, f, m)
+        gt.count_intercluster(gb, genome[a:b].tobytes(), decoy, f, m)
+    for s in range(S):
+        cnt = rng.integers(0, 40, len(members)).astype(np.uint32)
+        cnt[rng.random(len(members)) < 0.1] = 0
+        keep = cnt > 0
+        pref = str(tmp_path / f"db{s}")
+        oracle.kmc_write(pref, np.ascontiguousarray(mem_ascii.reshape(-1, K)[keep]).reshape(-1), cnt[keep], K, 3, 1)
+        db = OrcKmc(oracle, pref)
+        ot.parse_sample_kmers(ob, db, s)
+        sc = lib.KmcScan(gpu_ctx, db.k, db.p, db.counter_size, db.total, db.lut())
+        buf = gpu_ctx.to_device(db.payload())
+        sc.run(gb, gt, s, buf.ptr, 0, db.total)
+        gpu_ctx.sync()
+        sc.close()
+        buf.free()
+        db.close()
+    nonpar = mem_ascii.reshape(-1, K)[1::2][:500]
+    mult = rng.choice([1, 2, 130], 500).astype(np.uint8)
+    omg = OrcBloom(oracle, 10, 1e-4, K)
+    gmg = lib.Bloom.create(gpu_ctx, 10, 1e-4, K, threaded=False)
+    ot.classify(omg, np.ascontiguousarray(nonpar).reshape(-1), mult)
+    gt.classify(gmg, oracle.pack(np.ascontiguousarray(nonpar).reshape(-1), K), mult)
+    cls_o, st_o = ot.kmer_stats(gender)
+    cls_g, mom = gt.kmer_stats(gender)
+    assert np.array_equal(cls_o, cls_g) and cls_o[1] > 0 and cls_o[4] > 0 and cls_o[6] > 0
+    n = mom["n"].astype(np.float64)
+    assert np.array_equal(st_o[:, :, 0], n) and n.sum() == S * len(par) and (n > 0).sum() >= 2 * S
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = np.where(n > 0, mom["sum"] / n, 0.0)
+        frac = np.where(n > 0, mom["nonzero"] / n, 0.0)
+        m2 = np.where(n > 0, mom["sumsq"] - mom["sum"].astype(np.float64) ** 2 / np.maximum(n, 1), 0.0)
+    assert np.allclose(st_o[:, :, 1], frac, rtol=1e-12, atol=1e-12)
+    assert np.allclose(st_o[:, :, 2], mean, rtol=1e-12, atol=1e-12)
+    assert np.allclose(st_o[:, :, 3], m2, rtol=1e-9, atol=1e-7)
+    for x in (gt, gb, gmg, ob, omg, ot):
+        x.close()
