@@ -1,0 +1,855 @@
+// libbtgpu — path k-mer enumeration over variant-cluster graphs.
+//   bt_paths_count_kmers  <- VariantClusterGraph::countPathKmers (VariantClusterGraph.cpp:800-846) + KmerCounter.cpp:252-289
+//   bt_paths_classify     <- VariantClusterGraph::classifyPathKmers (:848-939)
+//   bt_paths_candidates   <- VariantClusterGraph::getHaplotypeCandidates + updateVariantPathIndices (:941-1184)
+//
+// The reference walks every best path nucleotide by nucleotide three times, filling per-cluster unordered_maps.  Here every
+// best path of every cluster is laid out once as a TEXT in HBM (segments of vertex sequences; a separator before every
+// disconnected vertex and after every path so that no k-mer window spans them), the canonical k-mer of every window is
+// enumerated once by the sequence kernel, and the maps become two open-addressing indexes built with atomics:
+//   A: (cluster, k-mer)       -> first text position (atomicMin), max-over-paths multiplicity
+//   B: (k-mer, path)          -> multiplicity on that path
+// "first-seen order" of the reference's row numbering is the order of first text positions, recovered with a prefix sum.
+// Integer / byte work, HBM random access; no MFMA.
+#include "bt_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+using namespace bt;
+
+namespace {
+
+constexpr unsigned BLOCK = 256;
+constexpr uint32_t ST_EMPTY = 0, ST_BUSY = 1, ST_READY = 2;
+constexpr uint32_t NOPATH = 0xFFFFFFFFu;
+
+struct Seg {          // one included vertex of one path
+    uint64_t dst;     // first text position of its nucleotides
+    uint64_t src;     // first nucleotide in the vertex sequence array
+    uint32_t len;
+    uint32_t nt0;     // num_nucleotides of the path before this vertex
+    uint32_t gpath;   // global path id
+    uint32_t pad;
+};
+
+struct IndexA {       // (cluster, k-mer) -> first position, max multiplicity, list id
+    uint64_t *lo, *hi;
+    uint32_t *cluster, *state, *maxmult, *list_id;
+    unsigned long long *first;
+    uint64_t mask;
+};
+struct IndexB {       // (k-mer, global path) -> count
+    uint64_t *lo, *hi;
+    uint32_t *gpath, *state, *count, *slot_a;
+    uint64_t mask;
+};
+
+__device__ inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+// find-or-insert: returns the slot of (lo, hi, tag); tag = cluster (A) or global path (B)
+__device__ inline uint64_t index_insert(uint64_t *klo, uint64_t *khi, uint32_t *ktag, uint32_t *state, uint64_t mask, uint64_t lo, uint64_t hi, uint32_t tag) {
+    uint64_t idx = mix64(lo ^ mix64(hi + 0x9e3779b97f4a7c15ULL * (tag + 1u))) & mask;
+    while (true) {
+        uint32_t st = __hip_atomic_load(&state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == ST_EMPTY) {
+            const uint32_t prev = atomicCAS(&state[idx], ST_EMPTY, ST_BUSY);
+            if (prev == ST_EMPTY) {
+                __hip_atomic_store(&klo[idx], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&khi[idx], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ktag[idx], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&state[idx], ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return idx;
+            }
+            st = prev;
+        }
+        if (st == ST_READY) {
+            if (__hip_atomic_load(&klo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == lo &&
+                __hip_atomic_load(&khi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == hi &&
+                __hip_atomic_load(&ktag[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag)
+                return idx;
+            idx = (idx + 1) & mask;
+        }
+        // ST_BUSY: the writer publishes without waiting; poll again
+    }
+}
+
+// ---- text layout: every position inside a segment gets its nucleotide (ASCII), its global path and its nucleotide index ----
+__global__ __launch_bounds__(BLOCK) void text_kernel(const Seg *__restrict__ segs, uint64_t nseg, const uint8_t *__restrict__ seq, uint64_t L,
+                                                      char *__restrict__ text, uint32_t *__restrict__ pos_path, uint32_t *__restrict__ pos_nt) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK) {
+        // last segment with dst <= pos
+        uint64_t lo = 0, hi = nseg;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (segs[mid].dst <= pos) lo = mid + 1;
+            else hi = mid;
+        }
+        char ch = 'N';
+        uint32_t gp = NOPATH, nt = 0;
+        if (lo > 0) {
+            const Seg s = segs[lo - 1];
+            if (pos - s.dst < s.len) {
+                const uint32_t o = (uint32_t)(pos - s.dst);
+                ch = "ACGT"[seq[s.src + o] & 3u];
+                gp = s.gpath;
+                nt = s.nt0 + o;
+            }
+        }
+        text[pos] = ch;
+        pos_path[pos] = gp;
+        pos_nt[pos] = nt;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void bloom_insert_valid_kernel(BloomView bloom, const uint64_t *__restrict__ kmers, const uint8_t *__restrict__ valid, uint64_t L) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK)
+        if (valid[pos]) bloom_insert(nthash64(Kmer{kmers[2 * pos], kmers[2 * pos + 1]}, bloom.k), bloom);
+}
+
+// ---- index build ----
+__global__ __launch_bounds__(BLOCK) void index_kernel(IndexA A, IndexB B, const uint64_t *__restrict__ kmers, const uint8_t *__restrict__ valid,
+                                                       const uint32_t *__restrict__ pos_path, const uint32_t *__restrict__ path_cluster, uint64_t L,
+                                                       uint32_t *__restrict__ pos_slot_a) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK) {
+        if (!valid[pos]) continue;
+        const uint64_t lo = kmers[2 * pos], hi = kmers[2 * pos + 1];
+        const uint32_t gp = pos_path[pos], c = path_cluster[gp];
+        const uint64_t a = index_insert(A.lo, A.hi, A.cluster, A.state, A.mask, lo, hi, c);
+        atomicMin(&A.first[a], (unsigned long long)pos);
+        pos_slot_a[pos] = (uint32_t)a;
+        const uint64_t b = index_insert(B.lo, B.hi, B.gpath, B.state, B.mask, lo, hi, gp);
+        B.slot_a[b] = (uint32_t)a;   // every inserter of this entry writes the same value
+        atomicAdd(&B.count[b], 1u);
+    }
+}
+// max over paths of the saturating per-path multiplicity (VariantClusterGraph.cpp:887-910)
+__global__ __launch_bounds__(BLOCK) void maxmult_kernel(IndexA A, IndexB B) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i <= B.mask; i += (uint64_t)gridDim.x * BLOCK) {
+        if (B.state[i] != ST_READY) continue;
+        const uint32_t cnt = B.count[i] > 255u ? 255u : B.count[i];
+        atomicMax(&A.maxmult[B.slot_a[i]], cnt);
+    }
+}
+// dense list of the distinct (cluster, k-mer) entries: order is irrelevant (the table update commutes)
+__global__ __launch_bounds__(BLOCK) void list_kernel(IndexA A, uint64_t *__restrict__ list_kmers, uint8_t *__restrict__ list_mult, uint32_t *__restrict__ list_cluster,
+                                                      unsigned long long *__restrict__ cursor) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i <= A.mask; i += (uint64_t)gridDim.x * BLOCK) {
+        if (A.state[i] != ST_READY) continue;
+        const unsigned long long j = atomicAdd(cursor, 1ULL);
+        list_kmers[2 * j] = A.lo[i];
+        list_kmers[2 * j + 1] = A.hi[i];
+        list_mult[j] = (uint8_t)A.maxmult[i];
+        list_cluster[j] = A.cluster[i];
+        A.list_id[i] = (uint32_t)j;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void classify_tally_kernel(const uint32_t *__restrict__ list_cluster, const uint8_t *__restrict__ excluded, uint64_t n,
+                                                                uint32_t *__restrict__ num_path_kmers, uint32_t *__restrict__ has_excluded) {
+    for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (uint64_t)gridDim.x * BLOCK) {
+        atomicAdd(&num_path_kmers[list_cluster[j]], 1u);
+        if (excluded[j]) atomicOr(&has_excluded[list_cluster[j]], 1u);
+    }
+}
+
+// ---- candidates ----
+// per distinct (cluster, k-mer): table record -> excluded?, multicluster?; list_flags[j]: bit0 in table, bit1 excluded, bit2 multicluster
+__global__ __launch_bounds__(BLOCK) void record_kernel(TableView t, const int64_t *__restrict__ slots, uint64_t n, uint8_t *__restrict__ list_flags) {
+    for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (uint64_t)gridDim.x * BLOCK) {
+        uint8_t f = 0;
+        if (slots[j] >= 0) {
+            const uint32_t flags = t.meta[slots[j]] & 0xffu;
+            f = 1;
+            if (flags & (BT_KC_DECOY_OCC | BT_KC_MAX_MULTIPLICITY | BT_KC_MULTIGROUP_OCC)) f |= 2;   // isExcluded (KmerCounts.cpp:93-96)
+            if (flags & BT_KC_MULTICLUSTER_OCC) f |= 4;
+        }
+        list_flags[j] = f;
+    }
+}
+// 1 at the first text position of every non-excluded distinct (cluster, k-mer): its prefix sum is the reference's row numbering
+__global__ __launch_bounds__(BLOCK) void first_flag_kernel(IndexA A, const uint8_t *__restrict__ valid, const uint32_t *__restrict__ pos_slot_a,
+                                                            const uint8_t *__restrict__ list_flags, uint64_t L, uint32_t *__restrict__ flag) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK) {
+        uint32_t f = 0;
+        if (valid[pos]) {
+            const uint32_t a = pos_slot_a[pos];
+            f = (A.first[a] == pos && !(list_flags[A.list_id[a]] & 2)) ? 1u : 0u;
+        }
+        flag[pos] = f;
+    }
+}
+// block-wise exclusive scan: 1024 elements per workgroup (4 per lane); block totals to `sums`
+__global__ __launch_bounds__(BLOCK) void scan_block_kernel(const uint32_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ out, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t part[BLOCK];
+    const uint64_t base = (uint64_t)blockIdx.x * (BLOCK * 4) + (uint64_t)threadIdx.x * 4;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q] = base + q < n ? in[base + q] : 0u;
+        s += v[q];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (unsigned off = 1; off < BLOCK; off <<= 1) {   // Hillis-Steele over the 256 lane totals
+        const uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (base + q < n) out[base + q] = run;
+        run += v[q];
+    }
+    if (threadIdx.x == BLOCK - 1) sums[blockIdx.x] = part[BLOCK - 1];
+}
+__global__ __launch_bounds__(BLOCK) void scan_add_kernel(uint32_t *__restrict__ out, uint64_t n, const uint32_t *__restrict__ block_off) {
+    const uint64_t base = (uint64_t)blockIdx.x * (BLOCK * 4) + (uint64_t)threadIdx.x * 4;
+    const uint32_t add = block_off[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (base + q < n) out[base + q] += add;
+}
+// per row: key, table record
+__global__ __launch_bounds__(BLOCK) void rows_kernel(IndexA A, TableView t, const uint8_t *__restrict__ valid, const uint32_t *__restrict__ pos_slot_a,
+                                                      const uint32_t *__restrict__ flag, const uint32_t *__restrict__ row_of_pos, const int64_t *__restrict__ slots,
+                                                      const uint8_t *__restrict__ list_flags, uint64_t L, uint32_t S, uint32_t *__restrict__ a_row,
+                                                      uint64_t *__restrict__ row_key, uint8_t *__restrict__ row_flags, uint8_t *__restrict__ row_counts,
+                                                      uint8_t *__restrict__ row_ic) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK) {
+        if (!flag[pos]) continue;
+        const uint32_t a = pos_slot_a[pos], row = row_of_pos[pos], j = A.list_id[a];
+        a_row[a] = row;
+        row_key[2 * (uint64_t)row] = A.lo[a];
+        row_key[2 * (uint64_t)row + 1] = A.hi[a];
+        row_flags[row] = list_flags[j];
+        const int64_t slot = slots[j];
+        for (uint32_t s = 0; s < S; ++s) row_counts[(uint64_t)row * S + s] = slot >= 0 ? reinterpret_cast<const uint8_t *>(t.counts)[(uint64_t)slot * t.spad + s] : (uint8_t)0;
+        const uint32_t meta = slot >= 0 ? t.meta[slot] : 0u;
+        row_ic[2 * (uint64_t)row] = (uint8_t)((meta >> 16) & 0xffu);
+        row_ic[2 * (uint64_t)row + 1] = (uint8_t)((meta >> 24) & 0xffu);
+    }
+}
+// haplotype_kmer_multiplicities(row, path) = multiplicity of the k-mer on that path (one writer per cell)
+__global__ __launch_bounds__(BLOCK) void mult_kernel(IndexA A, IndexB B, const uint8_t *__restrict__ list_flags, const uint32_t *__restrict__ a_row,
+                                                      const uint32_t *__restrict__ path_cluster, const uint32_t *__restrict__ path_local,
+                                                      const uint32_t *__restrict__ cluster_row0, const uint64_t *__restrict__ cluster_mult0,
+                                                      const uint32_t *__restrict__ cluster_h, uint8_t *__restrict__ mult, uint32_t *__restrict__ over127) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i <= B.mask; i += (uint64_t)gridDim.x * BLOCK) {
+        if (B.state[i] != ST_READY) continue;
+        const uint32_t a = B.slot_a[i];
+        if (list_flags[A.list_id[a]] & 2) continue;
+        const uint32_t gp = B.gpath[i], c = path_cluster[gp];
+        const uint32_t local_row = a_row[a] - cluster_row0[c];
+        if (B.count[i] > 127u) atomicOr(over127, 1u);   // the reference asserts <= 127 (VariantClusterGraph.cpp:1060)
+        mult[cluster_mult0[c] + (uint64_t)local_row * cluster_h[c] + path_local[gp]] = (uint8_t)B.count[i];
+    }
+}
+// updateVariantPathIndices: one (row, variant, path) triple per window and running variant that covers its last nucleotide
+struct Interval {
+    uint32_t first, second;
+    uint16_t variant, pad;
+};
+__global__ __launch_bounds__(BLOCK) void triples_kernel(IndexA A, const uint8_t *__restrict__ valid, const uint32_t *__restrict__ pos_slot_a,
+                                                         const uint8_t *__restrict__ list_flags, const uint32_t *__restrict__ a_row, const uint32_t *__restrict__ pos_path,
+                                                         const uint32_t *__restrict__ pos_nt, const uint32_t *__restrict__ path_local,
+                                                         const uint32_t *__restrict__ iv_off, const Interval *__restrict__ iv, uint64_t L,
+                                                         unsigned long long *__restrict__ cursor, uint64_t *__restrict__ out /* null: count only */) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK) {
+        if (!valid[pos]) continue;
+        const uint32_t a = pos_slot_a[pos];
+        if (list_flags[A.list_id[a]] & 2) continue;
+        const uint32_t gp = pos_path[pos], nt = pos_nt[pos];
+        for (uint32_t e = iv_off[gp]; e < iv_off[gp + 1]; ++e) {
+            if (iv[e].first <= nt && nt < iv[e].second) {
+                const unsigned long long j = atomicAdd(cursor, 1ULL);
+                if (out) out[j] = ((uint64_t)a_row[a] << 32) | ((uint64_t)iv[e].variant << 16) | path_local[gp];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void gather_u32_kernel(const uint32_t *__restrict__ in, const uint64_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+
+template <typename T>
+int dev_alloc(T **p, uint64_t n, std::vector<void *> &owned) {
+    *p = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<uint64_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(std::string("bt_paths: device allocation of ") + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+    owned.push_back(*p);
+    return BT_OK;
+}
+
+uint64_t pow2_at_least(uint64_t n) {
+    uint64_t c = 16;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+}  // namespace
+
+struct bt_paths {
+    bt_ctx *ctx = nullptr;
+    uint32_t k = 0, C = 0;
+    // host copies of what the host-side half needs
+    std::vector<uint32_t> vertex_off, num_paths, vertex_nested, refvar_off, var_off;
+    std::vector<uint64_t> seq_off, path_off;
+    std::vector<uint16_t> vertex_variant, vertex_allele, refvar, var_num_alleles;
+    std::vector<uint8_t> vertex_flags, path_vertices, var_has_dependency;
+    std::vector<uint32_t> path_cluster, path_local, cluster_path0;   // global path ids
+    uint64_t num_gpaths = 0, L = 0, num_valid = 0;
+    std::vector<void *> owned;
+    // device
+    uint8_t *d_seq = nullptr;
+    char *d_text = nullptr;
+    uint32_t *d_pos_path = nullptr, *d_pos_nt = nullptr, *d_pos_slot_a = nullptr;
+    uint64_t *d_kmers = nullptr;
+    uint8_t *d_valid = nullptr;
+    uint32_t *d_path_cluster = nullptr, *d_path_local = nullptr, *d_iv_off = nullptr;
+    Interval *d_iv = nullptr;
+    IndexA A{};
+    IndexB B{};
+    bool indexed = false;
+    uint64_t n_list = 0;
+    uint64_t *d_list_kmers = nullptr;
+    uint8_t *d_list_mult = nullptr, *d_list_excluded = nullptr, *d_list_flags = nullptr;
+    uint32_t *d_list_cluster = nullptr;
+    int64_t *d_list_slots = nullptr;
+    std::vector<uint64_t> cluster_text0;   // first text position of each cluster (+ L at the end)
+    // candidates result (host)
+    bool have_candidates = false;
+    uint32_t S = 0;
+    std::vector<uint32_t> kmer_off, kv_off, unique_off, unique_idx, multi_off, multi_idx, hapnest_off, hapnest_idx, nestdep_off, nestdep_cluster, nestdep_var_off, kv_bits;
+    std::vector<uint8_t> mult, has_counts, counts, ic;
+    std::vector<uint64_t> key;
+    std::vector<uint16_t> kv_var, hap_allele, nestdep_var;
+};
+
+namespace {
+
+// Host half of getHaplotypeCandidates for one path: running-variant intervals in path-nucleotide coordinates
+// (VariantClusterGraph.cpp:984-1011), haplotype allele indices (:990-996,1095-1102), nested cluster list (:1013-1017,1093)
+void walk_path_host(const bt_paths &p, uint32_t c, uint32_t lp, std::vector<Interval> &iv, std::vector<uint16_t> &alleles, std::vector<uint32_t> &nested) {
+    const uint32_t v0 = p.vertex_off[c], nv = p.vertex_off[c + 1] - v0, V = p.var_off[c + 1] - p.var_off[c];
+    const uint8_t *row = p.path_vertices.data() + p.path_off[c] + (uint64_t)lp * nv;
+    alleles.assign(V, 0xFFFF);
+    nested.clear();
+    std::map<std::pair<uint16_t, uint16_t>, size_t> open;   // (variant, allele) -> index into iv of its current interval
+    uint32_t nn = 0;
+    for (uint32_t vi = 0; vi < nv; ++vi) {
+        if (!row[vi]) continue;
+        const uint32_t v = v0 + vi;
+        const uint32_t len = (uint32_t)(p.seq_off[v + 1] - p.seq_off[v]);
+        if (p.vertex_variant[v] != 0xFFFF) {
+            if (!(p.vertex_flags[v] & 1)) alleles[p.vertex_variant[v]] = p.vertex_allele[v];
+            const auto key = std::make_pair(p.vertex_variant[v], p.vertex_allele[v]);
+            auto it = open.find(key);
+            // the reference's emplace keeps an existing entry only while it is still alive, i.e. ends exactly at nn + k - 1
+            if (it == open.end() || iv[it->second].second != nn + p.k - 1) {
+                iv.push_back(Interval{nn + ((p.vertex_flags[v] >> 1) & 1u), nn + p.k - 1, p.vertex_variant[v], 0});
+                open[key] = iv.size() - 1;
+                it = open.find(key);
+            }
+            iv[it->second].second += len;
+        }
+        for (uint32_t r = p.refvar_off[v]; r < p.refvar_off[v + 1]; ++r) {
+            auto it = open.find(std::make_pair(p.refvar[r], (uint16_t)0));
+            if (it != open.end() && iv[it->second].second == nn + p.k - 1) iv[it->second].second += len;
+        }
+        if (p.vertex_nested[v] != 0xFFFFFFFFu) nested.push_back(p.vertex_nested[v]);
+        nn += len;
+    }
+    std::sort(nested.begin(), nested.end());
+    for (uint32_t var = 0; var < V; ++var)
+        if (alleles[var] == 0xFFFF) alleles[var] = (uint16_t)(p.var_num_alleles[p.var_off[c] + var] - 1);
+}
+
+int build_index(bt_paths *p) {
+    if (p->indexed) return BT_OK;
+    const uint64_t cap = pow2_at_least(2 * std::max<uint64_t>(p->num_valid, 8));
+    IndexA &A = p->A;
+    IndexB &B = p->B;
+#define TRY(x)                         \
+    do {                               \
+        const int _rc = (x);           \
+        if (_rc != BT_OK) return _rc;  \
+    } while (0)
+    TRY(dev_alloc(&A.lo, cap, p->owned));
+    TRY(dev_alloc(&A.hi, cap, p->owned));
+    TRY(dev_alloc(&A.cluster, cap, p->owned));
+    TRY(dev_alloc(&A.state, cap, p->owned));
+    TRY(dev_alloc(&A.maxmult, cap, p->owned));
+    TRY(dev_alloc(&A.list_id, cap, p->owned));
+    TRY(dev_alloc(&A.first, cap, p->owned));
+    A.mask = cap - 1;
+    TRY(dev_alloc(&B.lo, cap, p->owned));
+    TRY(dev_alloc(&B.hi, cap, p->owned));
+    TRY(dev_alloc(&B.gpath, cap, p->owned));
+    TRY(dev_alloc(&B.state, cap, p->owned));
+    TRY(dev_alloc(&B.count, cap, p->owned));
+    TRY(dev_alloc(&B.slot_a, cap, p->owned));
+    B.mask = cap - 1;
+    TRY(dev_alloc(&p->d_pos_slot_a, p->L, p->owned));
+    hipStream_t st = p->ctx->stream;
+    BT_HIP(hipMemsetAsync(A.state, 0, cap * 4, st));
+    BT_HIP(hipMemsetAsync(A.maxmult, 0, cap * 4, st));
+    BT_HIP(hipMemsetAsync(A.first, 0xFF, cap * 8, st));
+    BT_HIP(hipMemsetAsync(B.state, 0, cap * 4, st));
+    BT_HIP(hipMemsetAsync(B.count, 0, cap * 4, st));
+    const unsigned maxb = p->ctx->num_cu * 16;
+    hipLaunchKernelGGL(index_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, A, B, p->d_kmers, p->d_valid, p->d_pos_path, p->d_path_cluster, p->L,
+                       p->d_pos_slot_a);
+    BT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(maxmult_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, A, B);
+    BT_CHECK_LAUNCH();
+    // dense list of the distinct (cluster, k-mer) entries
+    unsigned long long *d_cursor = nullptr;
+    TRY(dev_alloc(&d_cursor, 1, p->owned));
+    BT_HIP(hipMemsetAsync(d_cursor, 0, 8, st));
+    TRY(dev_alloc(&p->d_list_kmers, 2 * p->num_valid, p->owned));
+    TRY(dev_alloc(&p->d_list_mult, p->num_valid, p->owned));
+    TRY(dev_alloc(&p->d_list_cluster, p->num_valid, p->owned));
+    TRY(dev_alloc(&p->d_list_excluded, p->num_valid, p->owned));
+    TRY(dev_alloc(&p->d_list_flags, p->num_valid, p->owned));
+    TRY(dev_alloc(&p->d_list_slots, p->num_valid, p->owned));
+    hipLaunchKernelGGL(list_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, A, p->d_list_kmers, p->d_list_mult, p->d_list_cluster, d_cursor);
+    BT_CHECK_LAUNCH();
+    unsigned long long n = 0;
+    BT_HIP(hipMemcpyAsync(&n, d_cursor, 8, hipMemcpyDeviceToHost, st));
+    BT_HIP(hipStreamSynchronize(st));
+    p->n_list = n;
+    p->indexed = true;
+    return BT_OK;
+#undef TRY
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_paths_create(bt_ctx *ctx, const bt_paths_batch *b, uint32_t k, bt_paths **out, uint64_t *h_num_kmer_occurrences) {
+    if (!ctx || !b || !out) return fail("bt_paths_create: null argument");
+    if (k < 1 || k > 64) return fail("bt_paths_create: k must be in 1..64");
+    if (b->num_clusters == 0) return fail("bt_paths_create: empty batch");
+    BT_HIP(hipSetDevice(ctx->device));
+    bt_paths *p = new bt_paths();
+    p->ctx = ctx;
+    p->k = k;
+    p->C = b->num_clusters;
+    const uint32_t C = p->C, NV = b->vertex_off[C];
+    p->vertex_off.assign(b->vertex_off, b->vertex_off + C + 1);
+    p->num_paths.assign(b->num_paths, b->num_paths + C);
+    p->seq_off.assign(b->seq_off, b->seq_off + NV + 1);
+    p->vertex_variant.assign(b->vertex_variant, b->vertex_variant + NV);
+    p->vertex_allele.assign(b->vertex_allele, b->vertex_allele + NV);
+    p->vertex_flags.assign(b->vertex_flags, b->vertex_flags + NV);
+    p->vertex_nested.assign(b->vertex_nested, b->vertex_nested + NV);
+    p->refvar_off.assign(b->refvar_off, b->refvar_off + NV + 1);
+    p->refvar.assign(b->refvar, b->refvar + p->refvar_off[NV]);
+    p->path_off.assign(b->path_off, b->path_off + C + 1);
+    p->path_vertices.assign(b->path_vertices, b->path_vertices + p->path_off[C]);
+    p->var_off.assign(b->var_off, b->var_off + C + 1);
+    p->var_num_alleles.assign(b->var_num_alleles, b->var_num_alleles + p->var_off[C]);
+    p->var_has_dependency.assign(b->var_has_dependency, b->var_has_dependency + p->var_off[C]);
+    // ---- segments: text layout of every path ----
+    std::vector<Seg> segs;
+    std::vector<uint32_t> iv_off(1, 0);
+    std::vector<Interval> iv;
+    uint64_t at = 0;
+    p->cluster_path0.assign(C + 1, 0);
+    std::vector<uint16_t> alleles;
+    std::vector<uint32_t> nested;
+    for (uint32_t c = 0; c < C; ++c) {
+        const uint32_t v0 = p->vertex_off[c], nv = p->vertex_off[c + 1] - v0;
+        if (p->path_off[c + 1] - p->path_off[c] != (uint64_t)p->num_paths[c] * nv) {
+            delete p;
+            return fail("bt_paths_create: path_off does not match num_paths x vertices");
+        }
+        p->cluster_text0.push_back(at);
+        p->cluster_path0[c] = (uint32_t)p->path_cluster.size();
+        for (uint32_t lp = 0; lp < p->num_paths[c]; ++lp) {
+            const uint32_t gp = (uint32_t)p->path_cluster.size();
+            p->path_cluster.push_back(c);
+            p->path_local.push_back(lp);
+            const uint8_t *row = p->path_vertices.data() + p->path_off[c] + (uint64_t)lp * nv;
+            uint32_t nn = 0;
+            for (uint32_t vi = 0; vi < nv; ++vi) {
+                if (!row[vi]) continue;
+                const uint32_t v = v0 + vi;
+                const uint32_t len = (uint32_t)(p->seq_off[v + 1] - p->seq_off[v]);
+                if (p->vertex_flags[v] & 1) ++at;   // kmer_pair.reset(): one separator position
+                if (len) segs.push_back(Seg{at, p->seq_off[v], len, nn, gp, 0});
+                at += len;
+                nn += len;
+            }
+            ++at;   // separator between paths
+            walk_path_host(*p, c, lp, iv, alleles, nested);
+            iv_off.push_back((uint32_t)iv.size());
+        }
+    }
+    p->cluster_path0[C] = (uint32_t)p->path_cluster.size();
+    p->cluster_text0.push_back(at);
+    p->num_gpaths = p->path_cluster.size();
+    p->L = at;
+    if (p->L >= (1ull << 32)) {
+        delete p;
+        return fail("bt_paths_create: more than 2^32 path nucleotides in one batch (split the unit)");
+    }
+    // ---- upload, build the text, enumerate the k-mers ----
+    Seg *d_segs = nullptr;
+    int rc = BT_OK;
+    auto up = [&](auto **dst, const auto &vec) {
+        if (rc != BT_OK) return;
+        rc = dev_alloc(dst, vec.size(), p->owned);
+        if (rc == BT_OK && !vec.empty() && hipMemcpy(*dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice) != hipSuccess) rc = fail("bt_paths_create: upload failed");
+    };
+    std::vector<uint8_t> seq(b->seq, b->seq + p->seq_off[NV]);
+    up(&p->d_seq, seq);
+    up(&d_segs, segs);
+    up(&p->d_path_cluster, p->path_cluster);
+    up(&p->d_path_local, p->path_local);
+    up(&p->d_iv_off, iv_off);
+    up(&p->d_iv, iv);
+    if (rc == BT_OK) rc = dev_alloc(&p->d_text, p->L, p->owned);
+    if (rc == BT_OK) rc = dev_alloc(&p->d_pos_path, p->L, p->owned);
+    if (rc == BT_OK) rc = dev_alloc(&p->d_pos_nt, p->L, p->owned);
+    if (rc == BT_OK) rc = dev_alloc(&p->d_kmers, 2 * p->L, p->owned);
+    if (rc == BT_OK) rc = dev_alloc(&p->d_valid, p->L, p->owned);
+    if (rc != BT_OK) {
+        bt_paths_destroy(p);
+        return rc;
+    }
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(text_kernel, dim3(grid_for(p->L, BLOCK, ctx->num_cu * 16)), dim3(BLOCK), 0, st, d_segs, (uint64_t)segs.size(), p->d_seq, p->L, p->d_text,
+                       p->d_pos_path, p->d_pos_nt);
+    if (hipGetLastError() != hipSuccess || bt_kmers_from_sequence(ctx, p->d_text, p->L, k, p->d_kmers, p->d_valid) != BT_OK) {
+        bt_paths_destroy(p);
+        return fail("bt_paths_create: k-mer enumeration failed");
+    }
+    // number of windows
+    std::vector<uint8_t> hv(p->L);
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(hv.data(), p->d_valid, p->L, hipMemcpyDeviceToHost) != hipSuccess) {
+        bt_paths_destroy(p);
+        return fail("bt_paths_create: device error");
+    }
+    p->num_valid = std::accumulate(hv.begin(), hv.end(), (uint64_t)0);
+    if (h_num_kmer_occurrences) *h_num_kmer_occurrences = p->num_valid;
+    *out = p;
+    return BT_OK;
+}
+
+int bt_paths_destroy(bt_paths *p) {
+    if (!p) return BT_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (void *q : p->owned) (void)hipFree(q);
+    delete p;
+    return BT_OK;
+}
+
+int bt_paths_count_kmers(bt_paths *p, bt_bloom *path_bloom) {
+    if (!p || !path_bloom) return fail("bt_paths_count_kmers: null argument");
+    if (path_bloom->k != p->k) return fail("bt_paths_count_kmers: k mismatch");
+    BT_HIP(hipSetDevice(p->ctx->device));
+    hipLaunchKernelGGL(bloom_insert_valid_kernel, dim3(grid_for(p->L, BLOCK, p->ctx->num_cu * 16)), dim3(BLOCK), 0, p->ctx->stream, path_bloom->view(), p->d_kmers,
+                       p->d_valid, p->L);
+    BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+int bt_paths_classify(bt_paths *p, bt_table *table, bt_bloom *multigroup_bloom, uint32_t *h_num_path_kmers, uint8_t *h_has_excluded) {
+    if (!p || !table || !multigroup_bloom) return fail("bt_paths_classify: null argument");
+    if (table->k != p->k) return fail("bt_paths_classify: k mismatch");
+    BT_HIP(hipSetDevice(p->ctx->device));
+    int rc = build_index(p);
+    if (rc != BT_OK) return rc;
+    rc = bt_table_classify_batch(table, multigroup_bloom, p->d_list_kmers, p->d_list_mult, p->n_list, p->d_list_excluded);
+    if (rc != BT_OK) return rc;
+    uint32_t *d_n = nullptr, *d_ex = nullptr;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_n), (size_t)p->C * 4));
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_ex), (size_t)p->C * 4));
+    hipStream_t st = p->ctx->stream;
+    (void)hipMemsetAsync(d_n, 0, (size_t)p->C * 4, st);
+    (void)hipMemsetAsync(d_ex, 0, (size_t)p->C * 4, st);
+    hipLaunchKernelGGL(classify_tally_kernel, dim3(grid_for(p->n_list, BLOCK, p->ctx->num_cu * 16)), dim3(BLOCK), 0, st, p->d_list_cluster, p->d_list_excluded,
+                       p->n_list, d_n, d_ex);
+    std::vector<uint32_t> n(p->C), ex(p->C);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(n.data(), d_n, (size_t)p->C * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ex.data(), d_ex, (size_t)p->C * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_n);
+    (void)hipFree(d_ex);
+    if (e != hipSuccess) return fail(std::string("bt_paths_classify: ") + hipGetErrorString(e));
+    for (uint32_t c = 0; c < p->C; ++c) {
+        if (h_num_path_kmers) h_num_path_kmers[c] = n[c];
+        if (h_has_excluded) h_has_excluded[c] = ex[c] ? 1 : 0;
+    }
+    return BT_OK;
+}
+
+int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes *sizes) {
+    if (!p || !table || !sizes) return fail("bt_paths_candidates: null argument");
+    if (table->k != p->k) return fail("bt_paths_candidates: k mismatch");
+    BT_HIP(hipSetDevice(p->ctx->device));
+    int rc = build_index(p);
+    if (rc != BT_OK) return rc;
+    hipStream_t st = p->ctx->stream;
+    const unsigned maxb = p->ctx->num_cu * 16;
+    const uint32_t C = p->C, S = table->num_samples;
+    p->S = S;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() {
+        for (void *q : tmp) (void)hipFree(q);
+    };
+#define TRYC(x)                  \
+    do {                         \
+        const int _rc = (x);     \
+        if (_rc != BT_OK) {      \
+            cleanup();           \
+            return _rc;          \
+        }                        \
+    } while (0)
+#define HIPC(call)                                                                      \
+    do {                                                                                \
+        hipError_t _e = (call);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            cleanup();                                                                  \
+            return bt::fail(std::string(#call) + ": " + hipGetErrorString(_e));         \
+        }                                                                               \
+    } while (0)
+    // 1. table records of the distinct (cluster, k-mer) entries
+    TRYC(bt_table_find_batch(table, p->d_list_kmers, p->n_list, p->d_list_slots));
+    hipLaunchKernelGGL(record_kernel, dim3(grid_for(p->n_list, BLOCK, maxb)), dim3(BLOCK), 0, st, table->v, p->d_list_slots, p->n_list, p->d_list_flags);
+    // 2. row numbering = prefix sum over first-occurrence flags in text order
+    uint32_t *d_flag = nullptr, *d_rowpos = nullptr, *d_sums = nullptr, *d_a_row = nullptr;
+    const uint64_t nblk = (p->L + BLOCK * 4 - 1) / (BLOCK * 4);
+    TRYC(dev_alloc(&d_flag, p->L, tmp));
+    TRYC(dev_alloc(&d_rowpos, p->L + 1, tmp));
+    TRYC(dev_alloc(&d_sums, nblk, tmp));
+    TRYC(dev_alloc(&d_a_row, p->A.mask + 1, tmp));
+    hipLaunchKernelGGL(first_flag_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, p->A, p->d_valid, p->d_pos_slot_a, p->d_list_flags, p->L, d_flag);
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, d_flag, p->L, d_rowpos, d_sums);
+    std::vector<uint32_t> sums(nblk);
+    HIPC(hipMemcpyAsync(sums.data(), d_sums, nblk * 4, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    uint64_t total_rows = 0;
+    for (uint64_t i = 0; i < nblk; ++i) {
+        const uint32_t v = sums[i];
+        sums[i] = (uint32_t)total_rows;
+        total_rows += v;
+    }
+    if (total_rows >= (1ull << 32)) {
+        cleanup();
+        return fail("bt_paths_candidates: more than 2^32 k-mer rows in one batch");
+    }
+    HIPC(hipMemcpyAsync(d_sums, sums.data(), nblk * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, d_rowpos, p->L, d_sums);
+    // kmer_off[c] = rows before the cluster's first text position
+    p->kmer_off.assign(C + 1, 0);
+    {
+        // rows before the first text position of every cluster (d_rowpos has L + 1 entries: the last one is the total)
+        uint64_t *d_idx = nullptr;
+        uint32_t *d_out = nullptr;
+        TRYC(dev_alloc(&d_idx, C, tmp));
+        TRYC(dev_alloc(&d_out, C, tmp));
+        HIPC(hipMemcpyAsync(d_rowpos + p->L, &total_rows, 4, hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(d_idx, p->cluster_text0.data(), (size_t)C * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_u32_kernel, dim3((C + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_rowpos, d_idx, C, d_out);
+        HIPC(hipMemcpyAsync(p->kmer_off.data(), d_out, (size_t)C * 4, hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+    }
+    p->kmer_off[C] = (uint32_t)total_rows;
+    const uint64_t R = total_rows;
+    // 3. per row: key + table record
+    uint64_t *d_row_key = nullptr;
+    uint8_t *d_row_flags = nullptr, *d_row_counts = nullptr, *d_row_ic = nullptr;
+    TRYC(dev_alloc(&d_row_key, 2 * R, tmp));
+    TRYC(dev_alloc(&d_row_flags, R, tmp));
+    TRYC(dev_alloc(&d_row_counts, R * S, tmp));
+    TRYC(dev_alloc(&d_row_ic, 2 * R, tmp));
+    hipLaunchKernelGGL(rows_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, p->A, table->v, p->d_valid, p->d_pos_slot_a, d_flag, d_rowpos, p->d_list_slots,
+                       p->d_list_flags, p->L, S, d_a_row, d_row_key, d_row_flags, d_row_counts, d_row_ic);
+    // 4. multiplicity matrix
+    std::vector<uint64_t> mult0(C + 1, 0);
+    for (uint32_t c = 0; c < C; ++c) mult0[c + 1] = mult0[c] + (uint64_t)(p->kmer_off[c + 1] - p->kmer_off[c]) * p->num_paths[c];
+    uint8_t *d_mult = nullptr;
+    uint32_t *d_row0 = nullptr, *d_h = nullptr, *d_over = nullptr;
+    uint64_t *d_mult0 = nullptr;
+    TRYC(dev_alloc(&d_mult, mult0[C], tmp));
+    TRYC(dev_alloc(&d_row0, C + 1, tmp));
+    TRYC(dev_alloc(&d_h, C, tmp));
+    TRYC(dev_alloc(&d_mult0, C + 1, tmp));
+    TRYC(dev_alloc(&d_over, 1, tmp));
+    HIPC(hipMemsetAsync(d_mult, 0, std::max<uint64_t>(mult0[C], 1), st));
+    HIPC(hipMemsetAsync(d_over, 0, 4, st));
+    HIPC(hipMemcpyAsync(d_row0, p->kmer_off.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(d_h, p->num_paths.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(d_mult0, mult0.data(), (size_t)(C + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mult_kernel, dim3(grid_for(p->B.mask + 1, BLOCK, maxb)), dim3(BLOCK), 0, st, p->A, p->B, p->d_list_flags, d_a_row, p->d_path_cluster,
+                       p->d_path_local, d_row0, d_mult0, d_h, d_mult, d_over);
+    // 5. (row, variant, path) triples
+    unsigned long long *d_cursor = nullptr;
+    TRYC(dev_alloc(&d_cursor, 1, tmp));
+    HIPC(hipMemsetAsync(d_cursor, 0, 8, st));
+    hipLaunchKernelGGL(triples_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, p->A, p->d_valid, p->d_pos_slot_a, p->d_list_flags, d_a_row, p->d_pos_path,
+                       p->d_pos_nt, p->d_path_local, p->d_iv_off, p->d_iv, p->L, d_cursor, (uint64_t *)nullptr);
+    unsigned long long ntrip = 0;
+    HIPC(hipMemcpyAsync(&ntrip, d_cursor, 8, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    uint64_t *d_trip = nullptr;
+    TRYC(dev_alloc(&d_trip, ntrip, tmp));
+    HIPC(hipMemsetAsync(d_cursor, 0, 8, st));
+    hipLaunchKernelGGL(triples_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, p->A, p->d_valid, p->d_pos_slot_a, p->d_list_flags, d_a_row, p->d_pos_path,
+                       p->d_pos_nt, p->d_path_local, p->d_iv_off, p->d_iv, p->L, d_cursor, d_trip);
+    HIPC(hipGetLastError());
+    // 6. fetch and assemble on the host
+    std::vector<uint64_t> trip(ntrip);
+    std::vector<uint8_t> row_flags(R);
+    uint32_t over = 0;
+    p->key.resize(2 * R);
+    p->counts.resize(R * S);
+    p->ic.resize(2 * R);
+    p->mult.resize(mult0[C]);
+    HIPC(hipStreamSynchronize(st));
+    if (ntrip) HIPC(hipMemcpy(trip.data(), d_trip, ntrip * 8, hipMemcpyDeviceToHost));
+    if (R) {
+        HIPC(hipMemcpy(row_flags.data(), d_row_flags, R, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(p->key.data(), d_row_key, 2 * R * 8, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(p->counts.data(), d_row_counts, R * S, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(p->ic.data(), d_row_ic, 2 * R, hipMemcpyDeviceToHost));
+    }
+    if (mult0[C]) HIPC(hipMemcpy(p->mult.data(), d_mult, mult0[C], hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(&over, d_over, 4, hipMemcpyDeviceToHost));
+    cleanup();
+#undef TRYC
+#undef HIPC
+    if (over) return fail("bt_paths_candidates: a path k-mer occurs more than 127 times on one haplotype (the reference asserts <= 127)");
+    p->has_counts.resize(R);
+    for (uint64_t r = 0; r < R; ++r) p->has_counts[r] = row_flags[r] & 1;
+    // unique / multicluster row lists, in row (= first-seen) order
+    p->unique_off.assign(1, 0);
+    p->multi_off.assign(1, 0);
+    p->unique_idx.clear();
+    p->multi_idx.clear();
+    for (uint32_t c = 0; c < C; ++c) {
+        for (uint32_t r = p->kmer_off[c]; r < p->kmer_off[c + 1]; ++r) (row_flags[r] & 4 ? p->multi_idx : p->unique_idx).push_back(r - p->kmer_off[c]);
+        p->unique_off.push_back((uint32_t)p->unique_idx.size());
+        p->multi_off.push_back((uint32_t)p->multi_idx.size());
+    }
+    // variant_haplotype_indices: triples sorted by (row, variant); entries of a row ordered by variant
+    std::sort(trip.begin(), trip.end());
+    std::vector<uint32_t> row_cluster(R);
+    for (uint32_t c = 0; c < C; ++c)
+        for (uint32_t r = p->kmer_off[c]; r < p->kmer_off[c + 1]; ++r) row_cluster[r] = c;
+    p->kv_off.assign(R + 1, 0);
+    p->kv_var.clear();
+    p->kv_bits.clear();
+    uint64_t ti = 0;
+    for (uint64_t r = 0; r < R; ++r) {
+        const uint32_t HW = (p->num_paths[row_cluster[r]] + 31) / 32;
+        while (ti < ntrip && (trip[ti] >> 32) == r) {
+            const uint16_t var = (uint16_t)((trip[ti] >> 16) & 0xffff);
+            p->kv_var.push_back(var);
+            const size_t w0 = p->kv_bits.size();
+            p->kv_bits.resize(w0 + HW, 0);
+            while (ti < ntrip && (trip[ti] >> 32) == r && (uint16_t)((trip[ti] >> 16) & 0xffff) == var) {
+                const uint32_t path = (uint32_t)(trip[ti] & 0xffff);
+                p->kv_bits[w0 + (path >> 5)] |= 1u << (path & 31);
+                ++ti;
+            }
+        }
+        p->kv_off[r + 1] = (uint32_t)p->kv_var.size();
+    }
+    // haplotypes and the nested dependency map (host: O(paths x vertices))
+    p->hap_allele.clear();
+    p->hapnest_off.assign(1, 0);
+    p->hapnest_idx.clear();
+    p->nestdep_off.assign(1, 0);
+    p->nestdep_cluster.clear();
+    p->nestdep_var_off.assign(1, 0);
+    p->nestdep_var.clear();
+    std::vector<Interval> iv_dummy;
+    std::vector<uint16_t> alleles;
+    std::vector<uint32_t> nested;
+    for (uint32_t c = 0; c < C; ++c) {
+        for (uint32_t lp = 0; lp < p->num_paths[c]; ++lp) {
+            iv_dummy.clear();
+            walk_path_host(*p, c, lp, iv_dummy, alleles, nested);
+            p->hap_allele.insert(p->hap_allele.end(), alleles.begin(), alleles.end());
+            p->hapnest_idx.insert(p->hapnest_idx.end(), nested.begin(), nested.end());
+            p->hapnest_off.push_back((uint32_t)p->hapnest_idx.size());
+        }
+        std::map<uint32_t, std::vector<uint16_t>> dep;   // VariantClusterGraph.cpp:1112-1132
+        for (uint32_t v = p->vertex_off[c]; v < p->vertex_off[c + 1]; ++v) {
+            if (p->vertex_nested[v] == 0xFFFFFFFFu) continue;
+            auto &lst = dep[p->vertex_nested[v]];
+            if (p->vertex_variant[v] != 0xFFFF) lst.push_back(p->vertex_variant[v]);
+            for (uint32_t r = p->refvar_off[v]; r < p->refvar_off[v + 1]; ++r) lst.push_back(p->refvar[r]);
+            std::sort(lst.begin(), lst.end(), std::greater<uint16_t>());
+        }
+        for (auto &e : dep) {
+            p->nestdep_cluster.push_back(e.first);
+            p->nestdep_var.insert(p->nestdep_var.end(), e.second.begin(), e.second.end());
+            p->nestdep_var_off.push_back((uint32_t)p->nestdep_var.size());
+        }
+        p->nestdep_off.push_back((uint32_t)p->nestdep_cluster.size());
+    }
+    p->have_candidates = true;
+    sizes->rows = R;
+    sizes->mult_bytes = p->mult.size();
+    sizes->nnz = p->kv_var.size();
+    sizes->kv_words = p->kv_bits.size();
+    sizes->num_unique = p->unique_idx.size();
+    sizes->num_multi = p->multi_idx.size();
+    sizes->hap_allele = p->hap_allele.size();
+    sizes->num_haplotypes = p->num_gpaths;
+    sizes->hapnest = p->hapnest_idx.size();
+    sizes->nestdep = p->nestdep_cluster.size();
+    sizes->nestdep_var = p->nestdep_var.size();
+    return BT_OK;
+}
+
+int bt_paths_candidates_fetch(bt_paths *p, bt_paths_candidates_out *o) {
+    if (!p || !o) return fail("bt_paths_candidates_fetch: null argument");
+    if (!p->have_candidates) return fail("bt_paths_candidates_fetch: bt_paths_candidates has not run");
+    auto cp = [](const auto &v, auto *dst) {
+        if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+    };
+    cp(p->kmer_off, o->kmer_off);
+    cp(p->mult, o->hap_kmer_mult);
+    cp(p->key, o->kmer_key);
+    cp(p->has_counts, o->kmer_has_counts);
+    cp(p->counts, o->kmer_counts);
+    cp(p->ic, o->kmer_ic_mult);
+    cp(p->kv_off, o->kv_off);
+    cp(p->kv_var, o->kv_var);
+    cp(p->kv_bits, o->kv_bits);
+    cp(p->unique_off, o->unique_off);
+    cp(p->unique_idx, o->unique_idx);
+    cp(p->multi_off, o->multi_off);
+    cp(p->multi_idx, o->multi_idx);
+    cp(p->hap_allele, o->hap_allele);
+    cp(p->hapnest_off, o->hapnest_off);
+    cp(p->hapnest_idx, o->hapnest_idx);
+    cp(p->nestdep_off, o->nestdep_off);
+    cp(p->nestdep_cluster, o->nestdep_cluster);
+    cp(p->nestdep_var_off, o->nestdep_var_off);
+    cp(p->nestdep_var, o->nestdep_var);
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -63,6 +63,12 @@ bt_table_insert_batch = _sig("bt_table_insert_batch", [vp, vp, C.c_uint64, C.c_i
 bt_table_find_batch = _sig("bt_table_find_batch", [vp, vp, C.c_uint64, vp])
 bt_table_read_slots = _sig("bt_table_read_slots", [vp, vp, C.c_uint64, vp, vp])
 bt_table_export = _sig("bt_table_export", [vp, vp, vp, vp, C.c_uint64, u64p])
+bt_paths_create = _sig("bt_paths_create", [vp, vp, C.c_uint32, C.POINTER(vp), u64p])
+bt_paths_destroy = _sig("bt_paths_destroy", [vp])
+bt_paths_count_kmers = _sig("bt_paths_count_kmers", [vp, vp])
+bt_paths_classify = _sig("bt_paths_classify", [vp, vp, vp, vp, vp])
+bt_paths_candidates = _sig("bt_paths_candidates", [vp, vp, vp])
+bt_paths_candidates_fetch = _sig("bt_paths_candidates_fetch", [vp, vp])
 bt_table_kmer_stats = _sig("bt_table_kmer_stats", [vp, vp, vp, vp, vp, vp, vp])
 bt_table_count_intercluster = _sig("bt_table_count_intercluster", [vp, vp, vp, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32])
 bt_table_classify_batch = _sig("bt_table_classify_batch", [vp, vp, vp, vp, C.c_uint64, vp])
@@ -308,6 +314,63 @@ class Table:
     def close(self):
         if self.h:
             bt_table_destroy(self.h)
+            self.h = None
+
+
+CAND_FIELDS = [("kmer_off", np.uint32), ("hap_kmer_mult", np.uint8), ("kmer_key", np.uint64), ("kmer_has_counts", np.uint8), ("kmer_counts", np.uint8),
+               ("kmer_ic_mult", np.uint8), ("kv_off", np.uint32), ("kv_var", np.uint16), ("kv_bits", np.uint32), ("unique_off", np.uint32),
+               ("unique_idx", np.uint32), ("multi_off", np.uint32), ("multi_idx", np.uint32), ("hap_allele", np.uint16), ("hapnest_off", np.uint32),
+               ("hapnest_idx", np.uint32), ("nestdep_off", np.uint32), ("nestdep_cluster", np.uint32), ("nestdep_var_off", np.uint32), ("nestdep_var", np.uint16)]
+
+
+class _CandOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n, _ in CAND_FIELDS]
+
+
+class _CandSizes(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rows", "mult_bytes", "nnz", "kv_words", "num_unique", "num_multi", "hap_allele", "num_haplotypes", "hapnest",
+                                          "nestdep", "nestdep_var")]
+
+
+class Paths:
+    """Path k-mer enumeration over flattened variant-cluster graphs (bt_paths_*; input: synth_graphs.flatten-style dict)"""
+
+    def __init__(self, ctx, flat, k):
+        from . import synth_graphs
+
+        self.ctx, self.C, self.k = ctx, flat["num_clusters"], k
+        batch, self._keep = synth_graphs.to_ctypes(flat)
+        h, n = vp(), C.c_uint64()
+        check(bt_paths_create(ctx.h, C.byref(batch), k, C.byref(h), C.byref(n)))
+        self.h, self.num_windows = h.value, n.value
+
+    def count_kmers(self, bloom):
+        check(bt_paths_count_kmers(self.h, bloom.h))
+
+    def classify(self, table, mg_bloom):
+        n = np.zeros(self.C, np.uint32)
+        ex = np.zeros(self.C, np.uint8)
+        check(bt_paths_classify(self.h, table.h, mg_bloom.h, _np_ptr(n), _np_ptr(ex)))
+        return n, ex
+
+    def candidates(self, table):
+        sz = _CandSizes()
+        check(bt_paths_candidates(self.h, table.h, C.byref(sz)))
+        S = table.num_samples
+        n = {"kmer_off": self.C + 1, "hap_kmer_mult": sz.mult_bytes, "kmer_key": sz.rows * 2, "kmer_has_counts": sz.rows, "kmer_counts": sz.rows * S,
+             "kmer_ic_mult": sz.rows * 2, "kv_off": sz.rows + 1, "kv_var": sz.nnz, "kv_bits": sz.kv_words, "unique_off": self.C + 1, "unique_idx": sz.num_unique,
+             "multi_off": self.C + 1, "multi_idx": sz.num_multi, "hap_allele": sz.hap_allele, "hapnest_off": sz.num_haplotypes + 1, "hapnest_idx": sz.hapnest,
+             "nestdep_off": self.C + 1, "nestdep_cluster": sz.nestdep, "nestdep_var_off": sz.nestdep + 1, "nestdep_var": sz.nestdep_var}
+        arrs = {name: np.zeros(max(int(n[name]), 1), dt) for name, dt in CAND_FIELDS}
+        out = _CandOut()
+        for name, _ in CAND_FIELDS:
+            setattr(out, name, arrs[name].ctypes.data)
+        check(bt_paths_candidates_fetch(self.h, C.byref(out)))
+        return {name: arrs[name][: int(n[name])] for name, _ in CAND_FIELDS}
+
+    def close(self):
+        if self.h:
+            bt_paths_destroy(self.h)
             self.h = None
 
 

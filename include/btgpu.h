@@ -210,6 +210,85 @@ int bt_kmc_scan_decode(bt_kmc_scan *s, const uint8_t *d_records, uint64_t first_
                        uint64_t *d_kmers, uint32_t *d_counts);
 
 /* ------------------------------------------------------------------------------------------
+ * Path k-mer enumeration over variant-cluster graphs:
+ *   VariantClusterGraph::{countPathKmers, classifyPathKmers, getHaplotypeCandidates, updateVariantPathIndices}
+ *   (src/bayesTyper/VariantClusterGraph.cpp:800-1184), driven per unit by KmerCounter::{countPathKmers, classifyPathKmers}
+ *   (src/bayesTyper/KmerCounter.cpp:252-289,526-555) and VariantClusterGroup::initGenotyper.
+ * Input: the graphs as VariantClusterGraph holds them after findSamplePaths — vertices in topological (vertex-index) order
+ * with the fields of VariantClusterGraphVertex (include/bayesTyper/VariantClusterGraphVertex.hpp:43-73) and the best-path
+ * bitmaps best_paths_indices (P x |V|).  Output of the last stage: the VariantClusterHaplotypes bundle of every cluster in the
+ * flattened form bt_gibbs_batch takes.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_paths_batch {
+    uint32_t num_clusters;             /* C */
+    const uint32_t *vertex_off;        /* [C+1] vertices of cluster c, in vertex-index order */
+    const uint32_t *num_paths;         /* [C] number of best paths (= haplotype candidates H) */
+    /* ---- per vertex (NV = vertex_off[C]) ---- */
+    const uint64_t *seq_off;           /* [NV+1] nucleotides of vertex v: seq[seq_off[v] .. seq_off[v+1]) */
+    const uint8_t *seq;                /* one 2-bit code per byte (A 0, C 1, G 2, T 3: Nucleotide.hpp:40-70) */
+    const uint16_t *vertex_variant;    /* variant_allele_idx.first, 0xFFFF = none */
+    const uint16_t *vertex_allele;     /* variant_allele_idx.second */
+    const uint8_t *vertex_flags;       /* bit 0 is_disconnected, bit 1 is_first_nucleotides_redundant */
+    const uint32_t *vertex_nested;     /* nested_variant_cluster_index, 0xFFFFFFFF = none */
+    const uint32_t *refvar_off;        /* [NV+1] -> refvar */
+    const uint16_t *refvar;            /* reference_variant_indices */
+    /* ---- per cluster ---- */
+    const uint64_t *path_off;          /* [C+1] -> path_vertices; cluster c: num_paths[c] rows of (vertex_off[c+1]-vertex_off[c]) bytes */
+    const uint8_t *path_vertices;      /* best_paths_indices, row-major (path, vertex), 0/1 */
+    const uint32_t *var_off;           /* [C+1] -> per-variant arrays (variant_cluster_info) */
+    const uint16_t *var_num_alleles;   /* numberOfAlleles(), incl. the missing allele of variants with has_dependency */
+    const uint8_t *var_has_dependency;
+} bt_paths_batch;
+
+typedef struct bt_paths bt_paths;
+
+/* uploads the graphs, lays every best path out as one text (k-mer windows never span a disconnected vertex or two paths) and
+ * enumerates the canonical k-mer of every window once; *h_num_kmer_occurrences (optional) = number of full windows */
+int bt_paths_create(bt_ctx *ctx, const bt_paths_batch *batch, uint32_t k, bt_paths **out, uint64_t *h_num_kmer_occurrences);
+int bt_paths_destroy(bt_paths *p);
+/* VariantClusterGraph::countPathKmers + KmerCounter::countPathKmersCallback (KmerCounter.cpp:252-289): every path k-mer is
+ * added to the path Bloom filter (the reference first collects them in an unordered_set; insertion is idempotent) */
+int bt_paths_count_kmers(bt_paths *p, bt_bloom *path_bloom);
+/* VariantClusterGraph::classifyPathKmers for every cluster (VariantClusterGraph.cpp:848-939): per distinct path k-mer of a
+ * cluster the maximum over its paths of the (saturating) per-path multiplicity -> table update as bt_table_classify_batch.
+ * h_num_path_kmers[c] = distinct k-mers of cluster c (num_path_kmers), h_has_excluded[c] = has_excluded_kmers. */
+int bt_paths_classify(bt_paths *p, bt_table *table, bt_bloom *multigroup_bloom, uint32_t *h_num_path_kmers, uint8_t *h_has_excluded);
+
+/* host arrays receiving getHaplotypeCandidates' result for all clusters; sizes from bt_paths_candidates (R rows, NNZ incidence
+ * entries, ...).  Field meaning as in bt_gibbs_batch; row ids in unique_idx / multi_idx are local to the cluster. */
+typedef struct bt_paths_candidates_out {
+    uint32_t *kmer_off;          /* [C+1] */
+    uint8_t *hap_kmer_mult;      /* sum_c K_c * H_c */
+    uint64_t *kmer_key;          /* [R*2] packed canonical k-mer of the row (identifies shared records of multicluster k-mers) */
+    uint8_t *kmer_has_counts;    /* [R] the k-mer has a record in the table */
+    uint8_t *kmer_counts;        /* [R*S] */
+    uint8_t *kmer_ic_mult;       /* [R*2] */
+    uint32_t *kv_off;            /* [R+1] */
+    uint16_t *kv_var;            /* [NNZ] entries of a row sorted by variant index (the reference's order is an unordered_map's) */
+    uint32_t *kv_bits;           /* ceil(H/32) words per entry */
+    uint32_t *unique_off;        /* [C+1] */
+    uint32_t *unique_idx;
+    uint32_t *multi_off;         /* [C+1] */
+    uint32_t *multi_idx;
+    uint16_t *hap_allele;        /* sum_c H_c * V_c */
+    uint32_t *hapnest_off;       /* [sum_c H_c + 1] */
+    uint32_t *hapnest_idx;
+    uint32_t *nestdep_off;       /* [C+1] */
+    uint32_t *nestdep_cluster;
+    uint32_t *nestdep_var_off;   /* [ND+1] */
+    uint16_t *nestdep_var;
+} bt_paths_candidates_out;
+
+typedef struct bt_paths_candidates_sizes {
+    uint64_t rows, mult_bytes, nnz, kv_words, num_unique, num_multi, hap_allele, num_haplotypes, hapnest, nestdep, nestdep_var;
+} bt_paths_candidates_sizes;
+
+/* VariantClusterGraph::getHaplotypeCandidates for every cluster (VariantClusterGraph.cpp:941-1135) against the classified
+ * table: computes the bundle on the device + host and reports its sizes; bt_paths_candidates_fetch copies it out. */
+int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes *sizes);
+int bt_paths_candidates_fetch(bt_paths *p, bt_paths_candidates_out *out);
+
+/* ------------------------------------------------------------------------------------------
  * Count model LUTs: CountDistribution (src/bayesTyper/CountDistribution.cpp:215-265)
  * ---------------------------------------------------------------------------------------- */
 /* layout of the two caches the sampler reads through calcCountLogProb(sample, bias=0, multiplicity, count):

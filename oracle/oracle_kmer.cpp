@@ -19,7 +19,9 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <functional>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -559,6 +561,259 @@ uint64_t orc_match_only(void *bloom, void *kmc, uint64_t first, uint64_t n) {
         hits += b->subs[b->route(km.data())].containsF(km.data()) ? 1 : 0;
     }
     return hits;
+}
+
+
+// =====================================================================================================================
+// Path k-mer enumeration over variant-cluster graphs (VariantClusterGraph.cpp:800-1184), restated on the flattened graph
+// arrays of include/btgpu.h's bt_paths_batch (plain arrays here; the oracle includes no product header).
+// =====================================================================================================================
+struct OrcGraphs {
+    unsigned k;
+    uint32_t C;
+    const uint32_t *vertex_off, *num_paths;
+    const uint64_t *seq_off;
+    const uint8_t *seq;
+    const uint16_t *vvar, *vall;
+    const uint8_t *vflags;
+    const uint32_t *vnested, *refvar_off;
+    const uint16_t *refvar;
+    const uint64_t *path_off;
+    const uint8_t *paths;
+    const uint32_t *var_off;
+    const uint16_t *var_na;
+    const uint8_t *var_dep;
+};
+void *orc_graphs_new(unsigned k, uint32_t C, const uint32_t *vertex_off, const uint32_t *num_paths, const uint64_t *seq_off, const uint8_t *seq,
+                     const uint16_t *vvar, const uint16_t *vall, const uint8_t *vflags, const uint32_t *vnested, const uint32_t *refvar_off,
+                     const uint16_t *refvar, const uint64_t *path_off, const uint8_t *paths, const uint32_t *var_off, const uint16_t *var_na,
+                     const uint8_t *var_dep) {
+    return new OrcGraphs{k, C, vertex_off, num_paths, seq_off, seq, vvar, vall, vflags, vnested, refvar_off, refvar, path_off, paths, var_off, var_na, var_dep};
+}
+void orc_graphs_free(void *h) { delete (OrcGraphs *)h; }
+
+}  // extern "C" (closed around the template below)
+// walks path `p` of cluster `c` nucleotide by nucleotide like the three reference loops do; f_vertex(v) is called when a path
+// vertex is entered (before its nucleotides), f_kmer(canonical_ascii) for every completed window; f_nt() after every nucleotide
+template <typename FV, typename FK, typename FN>
+static void walk_path(const OrcGraphs &g, uint32_t c, uint32_t p, FV f_vertex, FK f_kmer, FN f_nt) {
+    static const char nt[4] = {'A', 'C', 'G', 'T'};
+    const uint32_t v0 = g.vertex_off[c], nv = g.vertex_off[c + 1] - v0;
+    const uint8_t *row = g.paths + g.path_off[c] + (uint64_t)p * nv;
+    std::string window;   // KmerPair: the last <= k nucleotides since the last reset (Kmer.tpp:182-255)
+    for (uint32_t vi = 0; vi < nv; vi++) {
+        if (!row[vi]) continue;
+        const uint32_t v = v0 + vi;
+        f_vertex(v);
+        if (g.vflags[v] & 1) window.clear();   // is_disconnected -> kmer_pair.reset()
+        for (uint64_t i = g.seq_off[v]; i < g.seq_off[v + 1]; i++) {
+            window.push_back(nt[g.seq[i] & 3]);
+            if (window.size() > g.k) window.erase(0, 1);
+            if (window.size() == g.k) {
+                std::string rc(g.k, 'A');
+                for (unsigned j = 0; j < g.k; j++) rc[j] = comp(window[g.k - 1 - j]);
+                f_kmer((rc < window) ? rc : window);
+            }
+            f_nt();
+        }
+    }
+}
+
+extern "C" {
+// VariantClusterGraph::countPathKmers (:800-846) for all clusters + KmerCounter::countPathKmersCallback (KmerCounter.cpp:252-289):
+// the set of path k-mers goes into the path Bloom filter.  Returns the number of k-mer windows.
+uint64_t orc_paths_count_kmers(void *gh, void *bloom) {
+    const OrcGraphs &g = *(OrcGraphs *)gh;
+    OrcBloom *b = (OrcBloom *)bloom;
+    uint64_t windows = 0;
+    std::unordered_set<std::string> path_kmers;
+    for (uint32_t c = 0; c < g.C; c++)
+        for (uint32_t p = 0; p < g.num_paths[c]; p++)
+            walk_path(g, c, p, [](uint32_t) {}, [&](const std::string &km) { path_kmers.insert(km); windows++; }, [] {});
+    if (b)
+        for (auto &km : path_kmers) b->subs[b->route(km.data())].insertF(km.data());
+    return windows;
+}
+
+// VariantClusterGraph::classifyPathKmers (:848-939) for every cluster, clusters in index order
+void orc_paths_classify(void *gh, void *table, void *mg_bloom, uint32_t *num_path_kmers, uint8_t *has_excluded) {
+    const OrcGraphs &g = *(OrcGraphs *)gh;
+    OrcTable *t = (OrcTable *)table;
+    OrcBloom *b = (OrcBloom *)mg_bloom;
+    for (uint32_t c = 0; c < g.C; c++) {
+        const uint32_t P = g.num_paths[c];
+        std::unordered_map<std::string, std::vector<uint8_t>> mult;
+        for (uint32_t p = 0; p < P; p++)
+            walk_path(g, c, p, [](uint32_t) {}, [&](const std::string &km) {
+                auto it = mult.emplace(km, std::vector<uint8_t>(P, 0)).first;
+                if (it->second[p] < 255) it->second[p]++;
+            }, [] {});
+        num_path_kmers[c] = (uint32_t)mult.size();
+        has_excluded[c] = 0;
+        for (auto &e : mult) {
+            const uint8_t mx = *std::max_element(e.second.begin(), e.second.end());
+            auto it = t->map.find(e.first);
+            if (it == t->map.end() && mx > 127) it = t->map.emplace(e.first, KC()).first;
+            if (it != t->map.end()) {
+                it->second.addClusterMultiplicity(mx, b->subs[b->route(e.first.data())].containsF(e.first.data()));
+                if (it->second.isExcluded()) has_excluded[c] = 1;
+            }
+        }
+    }
+}
+
+// VariantClusterGraph::getHaplotypeCandidates (:941-1135) + updateVariantPathIndices (:1137-1184) for every cluster.
+// Results are kept in the handle and copied out by orc_paths_candidates_fetch (same arrays as bt_paths_candidates_out).
+struct OrcCandidates {
+    std::vector<uint32_t> kmer_off, kv_off, unique_off, unique_idx, multi_off, multi_idx, hapnest_off, hapnest_idx, nestdep_off, nestdep_cluster, nestdep_var_off,
+        kv_bits;
+    std::vector<uint8_t> mult, has_counts, counts, ic;
+    std::vector<uint64_t> key;
+    std::vector<uint16_t> kv_var, hap_allele, nestdep_var;
+};
+void *orc_paths_candidates(void *gh, void *table, uint64_t *sizes /* 11 values, order of bt_paths_candidates_sizes */) {
+    const OrcGraphs &g = *(OrcGraphs *)gh;
+    OrcTable *t = (OrcTable *)table;
+    const unsigned S = t->num_samples;
+    OrcCandidates *o = new OrcCandidates();
+    o->kmer_off.push_back(0);
+    o->kv_off.push_back(0);
+    o->unique_off.push_back(0);
+    o->multi_off.push_back(0);
+    o->hapnest_off.push_back(0);
+    o->nestdep_off.push_back(0);
+    o->nestdep_var_off.push_back(0);
+    uint64_t num_hap = 0;
+    for (uint32_t c = 0; c < g.C; c++) {
+        const uint32_t P = g.num_paths[c], V = g.var_off[c + 1] - g.var_off[c], HW = (P + 31) / 32;
+        const uint32_t v0 = g.vertex_off[c], nv = g.vertex_off[c + 1] - v0;
+        std::unordered_map<std::string, uint32_t> row_of;
+        std::vector<std::string> row_key;
+        std::vector<std::vector<uint8_t>> M;                                    // rows x P
+        std::vector<std::vector<std::pair<uint16_t, std::vector<uint32_t>>>> kv;   // per row: (variant, bitset words)
+        std::vector<uint32_t> uniq, multi;
+        for (uint32_t p = 0; p < P; p++) {
+            std::vector<uint16_t> alleles(V, 0xFFFF);
+            std::vector<uint32_t> nested;
+            uint32_t num_nucleotides = 0;
+            std::map<std::pair<uint16_t, uint16_t>, std::pair<uint32_t, uint32_t>> running;   // (variant, allele) -> [first, second)
+            walk_path(
+                g, c, p,
+                [&](uint32_t v) {
+                    if (g.vvar[v] != 0xFFFF) {
+                        if (!(g.vflags[v] & 1)) alleles[g.vvar[v]] = g.vall[v];
+                        auto it = running.emplace(std::make_pair(g.vvar[v], g.vall[v]),
+                                                  std::make_pair(num_nucleotides + ((g.vflags[v] >> 1) & 1u), num_nucleotides + g.k - 1)).first;
+                        it->second.second += (uint32_t)(g.seq_off[v + 1] - g.seq_off[v]);
+                    }
+                    for (uint32_t r = g.refvar_off[v]; r < g.refvar_off[v + 1]; r++) {
+                        auto it = running.find(std::make_pair(g.refvar[r], (uint16_t)0));
+                        if (it != running.end()) it->second.second += (uint32_t)(g.seq_off[v + 1] - g.seq_off[v]);
+                    }
+                    if (g.vnested[v] != 0xFFFFFFFFu) nested.push_back(g.vnested[v]);
+                },
+                [&](const std::string &km) {
+                    auto kc = t->map.find(km);
+                    bool is_multi = false;
+                    if (kc != t->map.end()) {
+                        if (kc->second.isExcluded()) return;
+                        is_multi = kc->second.flags & 0x02;
+                    }
+                    auto ins = row_of.emplace(km, (uint32_t)row_of.size());
+                    const uint32_t row = ins.first->second;
+                    if (ins.second) {
+                        row_key.push_back(km);
+                        M.emplace_back(P, 0);
+                        kv.emplace_back();
+                        (is_multi ? multi : uniq).push_back(row);
+                    }
+                    M[row][p]++;
+                    // updateVariantPathIndices: every running variant whose interval covers this nucleotide
+                    for (auto it = running.begin(); it != running.end();) {
+                        if (it->second.second <= num_nucleotides) {
+                            it = running.erase(it);
+                            continue;
+                        }
+                        if (it->second.first <= num_nucleotides) {
+                            auto &lst = kv[row];
+                            auto e = std::find_if(lst.begin(), lst.end(), [&](const std::pair<uint16_t, std::vector<uint32_t>> &x) { return x.first == it->first.first; });
+                            if (e == lst.end()) {
+                                lst.emplace_back(it->first.first, std::vector<uint32_t>(HW, 0));
+                                e = lst.end() - 1;
+                            }
+                            e->second[p >> 5] |= 1u << (p & 31);
+                        }
+                        ++it;
+                    }
+                },
+                [&] { num_nucleotides++; });
+            std::sort(nested.begin(), nested.end());
+            for (uint32_t var = 0; var < V; var++)
+                if (alleles[var] == 0xFFFF) alleles[var] = (uint16_t)(g.var_na[g.var_off[c] + var] - 1);   // missing allele (:1095-1102)
+            o->hap_allele.insert(o->hap_allele.end(), alleles.begin(), alleles.end());
+            o->hapnest_idx.insert(o->hapnest_idx.end(), nested.begin(), nested.end());
+            o->hapnest_off.push_back((uint32_t)o->hapnest_idx.size());
+            num_hap++;
+        }
+        const uint32_t K = (uint32_t)row_key.size();
+        for (uint32_t r = 0; r < K; r++) {
+            o->mult.insert(o->mult.end(), M[r].begin(), M[r].end());
+            uint64_t pk[2];
+            pack(row_key[r].data(), g.k, pk);
+            o->key.push_back(pk[0]);
+            o->key.push_back(pk[1]);
+            auto kc = t->map.find(row_key[r]);
+            o->has_counts.push_back(kc != t->map.end());
+            for (unsigned s = 0; s < S; s++) o->counts.push_back(kc != t->map.end() ? kc->second.counts[s] : 0);
+            o->ic.push_back(kc != t->map.end() ? kc->second.fem : 0);
+            o->ic.push_back(kc != t->map.end() ? kc->second.male : 0);
+            std::sort(kv[r].begin(), kv[r].end(), [](const std::pair<uint16_t, std::vector<uint32_t>> &a, const std::pair<uint16_t, std::vector<uint32_t>> &b) { return a.first < b.first; });
+            for (auto &e : kv[r]) {
+                o->kv_var.push_back(e.first);
+                o->kv_bits.insert(o->kv_bits.end(), e.second.begin(), e.second.end());
+            }
+            o->kv_off.push_back((uint32_t)o->kv_var.size());
+        }
+        o->kmer_off.push_back(o->kmer_off.back() + K);
+        o->unique_idx.insert(o->unique_idx.end(), uniq.begin(), uniq.end());
+        o->unique_off.push_back((uint32_t)o->unique_idx.size());
+        o->multi_idx.insert(o->multi_idx.end(), multi.begin(), multi.end());
+        o->multi_off.push_back((uint32_t)o->multi_idx.size());
+        // nested_variant_cluster_dependency (:1112-1132); std::map iteration = ascending child index here, the reference's
+        // unordered_map order is irrelevant downstream (lookups by key)
+        std::map<uint32_t, std::vector<uint16_t>> dep;
+        for (uint32_t vi = 0; vi < nv; vi++) {
+            const uint32_t v = v0 + vi;
+            if (g.vnested[v] == 0xFFFFFFFFu) continue;
+            auto &lst = dep[g.vnested[v]];
+            if (g.vvar[v] != 0xFFFF) lst.push_back(g.vvar[v]);
+            for (uint32_t r = g.refvar_off[v]; r < g.refvar_off[v + 1]; r++) lst.push_back(g.refvar[r]);
+            std::sort(lst.begin(), lst.end(), std::greater<uint16_t>());
+        }
+        for (auto &e : dep) {
+            o->nestdep_cluster.push_back(e.first);
+            o->nestdep_var.insert(o->nestdep_var.end(), e.second.begin(), e.second.end());
+            o->nestdep_var_off.push_back((uint32_t)o->nestdep_var.size());
+        }
+        o->nestdep_off.push_back((uint32_t)o->nestdep_cluster.size());
+    }
+    const uint64_t sz[11] = {o->kmer_off.back(), o->mult.size(), o->kv_var.size(), o->kv_bits.size(), o->unique_idx.size(), o->multi_idx.size(),
+                             o->hap_allele.size(), num_hap, o->hapnest_idx.size(), o->nestdep_cluster.size(), o->nestdep_var.size()};
+    memcpy(sizes, sz, sizeof(sz));
+    return o;
+}
+void orc_paths_candidates_fetch(void *h, uint32_t *kmer_off, uint8_t *mult, uint64_t *key, uint8_t *has_counts, uint8_t *counts, uint8_t *ic, uint32_t *kv_off,
+                                uint16_t *kv_var, uint32_t *kv_bits, uint32_t *unique_off, uint32_t *unique_idx, uint32_t *multi_off, uint32_t *multi_idx,
+                                uint16_t *hap_allele, uint32_t *hapnest_off, uint32_t *hapnest_idx, uint32_t *nestdep_off, uint32_t *nestdep_cluster,
+                                uint32_t *nestdep_var_off, uint16_t *nestdep_var) {
+    OrcCandidates *o = (OrcCandidates *)h;
+    auto cp = [](auto &v, auto *dst) { if (!v.empty()) memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+    cp(o->kmer_off, kmer_off); cp(o->mult, mult); cp(o->key, key); cp(o->has_counts, has_counts); cp(o->counts, counts); cp(o->ic, ic);
+    cp(o->kv_off, kv_off); cp(o->kv_var, kv_var); cp(o->kv_bits, kv_bits); cp(o->unique_off, unique_off); cp(o->unique_idx, unique_idx);
+    cp(o->multi_off, multi_off); cp(o->multi_idx, multi_idx); cp(o->hap_allele, hap_allele); cp(o->hapnest_off, hapnest_off);
+    cp(o->hapnest_idx, hapnest_idx); cp(o->nestdep_off, nestdep_off); cp(o->nestdep_cluster, nestdep_cluster); cp(o->nestdep_var_off, nestdep_var_off);
+    cp(o->nestdep_var, nestdep_var);
+    delete o;
 }
 
 }  // extern "C"

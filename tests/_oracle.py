@@ -66,6 +66,15 @@ class Oracle:
         L.orc_table_classify.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]
         L.orc_table_export.restype = C.c_uint64
         L.orc_table_export.argtypes = [vp, vp, vp, vp]
+        L.orc_graphs_new.restype = vp
+        L.orc_graphs_new.argtypes = [C.c_uint, C.c_uint32] + [vp] * 15
+        L.orc_graphs_free.argtypes = [vp]
+        L.orc_paths_count_kmers.restype = C.c_uint64
+        L.orc_paths_count_kmers.argtypes = [vp, vp]
+        L.orc_paths_classify.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_paths_candidates.restype = vp
+        L.orc_paths_candidates.argtypes = [vp, vp, vp]
+        L.orc_paths_candidates_fetch.argtypes = [vp] * 21
         L.orc_table_kmer_stats.restype = None
         L.orc_table_kmer_stats.argtypes = [vp, vp, vp, vp]
         L.orc_kmc_write.argtypes = [C.c_char_p, vp, vp, C.c_uint64, C.c_uint, C.c_uint, C.c_uint]
@@ -213,6 +222,55 @@ class OrcTable:
     def close(self):
         if self.h:
             self.o.l.orc_table_free(self.h)
+            self.h = None
+
+
+CAND_FIELDS = [("kmer_off", np.uint32), ("hap_kmer_mult", np.uint8), ("kmer_key", np.uint64), ("kmer_has_counts", np.uint8), ("kmer_counts", np.uint8),
+               ("kmer_ic_mult", np.uint8), ("kv_off", np.uint32), ("kv_var", np.uint16), ("kv_bits", np.uint32), ("unique_off", np.uint32),
+               ("unique_idx", np.uint32), ("multi_off", np.uint32), ("multi_idx", np.uint32), ("hap_allele", np.uint16), ("hapnest_off", np.uint32),
+               ("hapnest_idx", np.uint32), ("nestdep_off", np.uint32), ("nestdep_cluster", np.uint32), ("nestdep_var_off", np.uint32), ("nestdep_var", np.uint16)]
+
+
+def candidates_arrays(sizes, C_, S):
+    """host arrays of bt_paths_candidates_out for the sizes (rows, mult_bytes, nnz, kv_words, num_unique, num_multi, hap_allele,
+    num_haplotypes, hapnest, nestdep, nestdep_var)"""
+    rows, mult, nnz, kvw, nu, nm, ha, nh, hn, nd, ndv = [int(x) for x in sizes]
+    n = {"kmer_off": C_ + 1, "hap_kmer_mult": mult, "kmer_key": rows * 2, "kmer_has_counts": rows, "kmer_counts": rows * S, "kmer_ic_mult": rows * 2,
+         "kv_off": rows + 1, "kv_var": nnz, "kv_bits": kvw, "unique_off": C_ + 1, "unique_idx": nu, "multi_off": C_ + 1, "multi_idx": nm,
+         "hap_allele": ha, "hapnest_off": nh + 1, "hapnest_idx": hn, "nestdep_off": C_ + 1, "nestdep_cluster": nd, "nestdep_var_off": nd + 1,
+         "nestdep_var": ndv}
+    return {name: np.zeros(max(n[name], 1), dt) for name, dt in CAND_FIELDS}, n
+
+
+class OrcGraphs:
+    """flattened variant-cluster graphs (bayestyper_amd.synth_graphs.flatten) for the path-enumeration oracle"""
+
+    def __init__(self, orc, flat, k):
+        from bayestyper_amd import synth_graphs
+
+        self.o, self.f, self.k = orc, flat, k
+        self.keep = [np.ascontiguousarray(flat[n]) if np.asarray(flat[n]).size else np.zeros(1, np.asarray(flat[n]).dtype) for n in synth_graphs.FIELDS]
+        self.h = orc.l.orc_graphs_new(k, flat["num_clusters"], *[_ptr(a) for a in self.keep])
+
+    def count_kmers(self, bloom=None):
+        return self.o.l.orc_paths_count_kmers(self.h, bloom.h if bloom is not None else None)
+
+    def classify(self, table, mg_bloom):
+        n = np.zeros(self.f["num_clusters"], np.uint32)
+        ex = np.zeros(self.f["num_clusters"], np.uint8)
+        self.o.l.orc_paths_classify(self.h, table.h, mg_bloom.h, _ptr(n), _ptr(ex))
+        return n, ex
+
+    def candidates(self, table):
+        sizes = np.zeros(11, np.uint64)
+        h = self.o.l.orc_paths_candidates(self.h, table.h, _ptr(sizes))
+        arrs, n = candidates_arrays(sizes, self.f["num_clusters"], table.S)
+        self.o.l.orc_paths_candidates_fetch(h, *[_ptr(arrs[name]) for name, _ in CAND_FIELDS])
+        return {name: arrs[name][: n[name]] for name, _ in CAND_FIELDS}
+
+    def close(self):
+        if self.h:
+            self.o.l.orc_graphs_free(self.h)
             self.h = None
 
 

@@ -357,3 +357,75 @@ def test_calculate_kmer_stats(gpu_ctx, oracle, tmp_path):
     assert np.allclose(st_o[:, :, 3], m2, rtol=1e-9, atol=1e-7)
     for x in (gt, gb, gmg, ob, omg, ot):
         x.close()
+
+
+def _path_graphs(seed, n):
+    from bayestyper_amd import synth_graphs
+
+    rng = np.random.default_rng(seed)
+    gs = [synth_graphs.random_cluster(rng, K, int(rng.integers(1, 7)), int(rng.integers(2, 12)), nested_cluster=(500 + i) if i % 3 == 2 else None) for i in range(n)]
+    # two clusters sharing a stretch of sequence -> multicluster k-mers; one cluster with a long homopolymer -> a k-mer > 127 times
+    import copy
+
+    gs[1] = copy.deepcopy(gs[0])
+    gs[1].paths = synth_graphs.random_paths(gs[1], rng, 3)
+    big = synth_graphs.random_cluster(rng, K, 1, 2, chrom_len=1200)
+    big.seq[-1] = np.concatenate([big.seq[-1], np.zeros(300, np.uint8)])
+    gs.append(big)
+    return gs, synth_graphs.flatten(gs)
+
+
+def test_path_enumeration_classify_candidates(gpu_ctx, oracle):
+    """countPathKmers / classifyPathKmers / getHaplotypeCandidates over a batch of graphs (SNVs, indels, multi-allelic, nested cuts,
+    shared and >127x k-mers) against the oracle: Bloom image, table contents, and the whole VariantClusterHaplotypes bundle."""
+    from _oracle import OrcGraphs
+    from bayestyper_amd import lib
+
+    S = 2
+    gs, f = _path_graphs(31, 14)
+    og = OrcGraphs(oracle, f, K)
+    gp = lib.Paths(gpu_ctx, f, K)
+    # countPathKmers -> path Bloom (bit image identical)
+    ob = OrcBloom(oracle, 200_000, 1e-3, K, threaded=False)
+    gb = lib.Bloom.create(gpu_ctx, 200_000, 1e-3, K, threaded=False)
+    assert og.count_kmers(ob) == gp.num_windows
+    gp.count_kmers(gb)
+    gpu_ctx.sync()
+    assert np.array_equal(gb.bits(0), ob.bits(0))
+    # a count table holding part of the path k-mers with counts, some with intercluster multiplicity, one decoy region
+    ot, gt = OrcTable(oracle, S, K), lib.Table(gpu_ctx, 100_000, S, K)
+    rng = np.random.default_rng(5)
+    nt = np.frombuffer(b"ACGT", np.uint8)
+    text = np.concatenate([np.concatenate([nt[g.seq[v]] for v in range(len(g.seq))] + [np.frombuffer(b"N", np.uint8)]) for g in gs[:6]])
+    tb_o = OrcBloom(oracle, 200_000, 1e-3, K, threaded=True)
+    tb_g = lib.Bloom.create(gpu_ctx, 200_000, 1e-3, K, threaded=True)
+    km, va = oracle.kmers_from_sequence(text.tobytes(), K)
+    members = np.unique(km[va == 1], axis=0)
+    tb_o.insert(oracle.unpack(members, K))
+    tb_g.insert(members)
+    ot.count_intercluster(tb_o, text[: len(text) // 3].tobytes(), 0, 2, 1)
+    gt.count_intercluster(tb_g, text[: len(text) // 3].tobytes(), 0, 2, 1)
+    dec = text[len(text) // 3: len(text) // 3 + 200].tobytes()
+    ot.count_intercluster(tb_o, dec, 1, 0, 0)
+    gt.count_intercluster(tb_g, dec, 1, 0, 0)
+    # multigroup Bloom with a few of the path k-mers
+    mg_members = members[rng.choice(len(members), 30, replace=False)]
+    omg = OrcBloom(oracle, 30, 1e-4, K)
+    gmg = lib.Bloom.create(gpu_ctx, 30, 1e-4, K, threaded=False)
+    omg.insert(oracle.unpack(mg_members, K))
+    gmg.insert(mg_members)
+    n_o, ex_o = og.classify(ot, omg)
+    n_g, ex_g = gp.classify(gt, gmg)
+    assert np.array_equal(n_o, n_g) and np.array_equal(ex_o, ex_g) and ex_o.any() and not ex_o.all()
+    gk, gc, gm = _sorted_export(*gt.export())
+    wk, wc, wm = _sorted_export(*ot.export())
+    assert np.array_equal(gk, wk) and np.array_equal(gm, wm)
+    assert (wm[:, 0] & 0x02).any() and (wm[:, 0] & 0x10).any() and (wm[:, 0] & 0x04).any()   # multicluster, max-multiplicity, multigroup
+    # getHaplotypeCandidates
+    ro = og.candidates(ot)
+    rg = gp.candidates(gt)
+    for name in ro:
+        assert np.array_equal(ro[name], rg[name]), name
+    assert len(ro["multi_idx"]) > 0 and len(ro["hapnest_idx"]) > 0 and len(ro["nestdep_var"]) > 0 and ro["kmer_off"][-1] < n_o.sum()
+    for x in (gp, og, gb, ob, gt, ot, tb_o, tb_g, omg, gmg):
+        x.close()
