@@ -246,3 +246,43 @@ def to_ctypes(f):
         keep.append(a)
         setattr(b, n, a.ctypes.data)
     return b, keep
+
+
+def gibbs_batch_from_candidates(cand, f, groups, S, gender=None, ploidy=None, cluster_ids=None):
+    """The hand-over between the two halves of the path: getHaplotypeCandidates' bundle (bt_paths_candidates_fetch / the oracle's,
+    `cand`) for the graphs `f`, plus the group structure (`groups`: list of lists of cluster indices, every cluster a source of its
+    group — nested edges are not synthesised here), -> the dict layout of bt_gibbs_batch (synth.flatten's).  Multicluster k-mers of a
+    group share one record: kmer_shared numbers the distinct keys among the group's multicluster rows."""
+    order = [c for g in groups for c in g]
+    assert sorted(order) == list(range(f["num_clusters"])) and order == sorted(order), "groups must partition the clusters in order"
+    G = len(groups)
+    gender = np.zeros(S, np.uint8) if gender is None else np.asarray(gender, np.uint8)
+    ploidy = np.full((G, S), 2, np.uint8) if ploidy is None else np.asarray(ploidy, np.uint8).reshape(G, S)
+    R = int(cand["kmer_off"][-1])
+    shared = np.full(R, -1, np.int32)
+    num_shared = []
+    for g in groups:
+        keys = {}
+        for c in g:
+            r0 = int(cand["kmer_off"][c])
+            for r in cand["multi_idx"][cand["multi_off"][c]:cand["multi_off"][c + 1]]:
+                key = (int(cand["kmer_key"][2 * (r0 + r)]), int(cand["kmer_key"][2 * (r0 + r) + 1]))
+                shared[r0 + r] = keys.setdefault(key, len(keys))
+        num_shared.append(len(keys))
+    H = f["num_paths"].astype(np.uint32)
+    V = (f["var_off"][1:] - f["var_off"][:-1]).astype(np.uint32)
+    goff = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.uint32)
+    out = {
+        "S": S, "gender": gender, "num_groups": G, "num_clusters": f["num_clusters"],
+        "group_index": np.arange(G, dtype=np.uint32), "group_cluster_off": goff, "group_ploidy": np.ascontiguousarray(ploidy.reshape(-1)),
+        "group_source_off": goff.copy(), "group_sources": np.concatenate([np.arange(len(g), dtype=np.uint32) for g in groups]),
+        "group_num_shared": np.asarray(num_shared, np.uint32),
+        "cluster_idx": np.arange(f["num_clusters"], dtype=np.uint32) if cluster_ids is None else np.asarray(cluster_ids, np.uint32),
+        "edge_off": np.zeros(f["num_clusters"] + 1, np.uint32), "edges": np.zeros(0, np.uint32),
+        "num_haplotypes": H, "num_variants": V, "kmer_shared": shared,
+        "var_num_alleles": f["var_num_alleles"], "var_has_dependency": f["var_has_dependency"],
+    }
+    for name in ("kmer_off", "hap_kmer_mult", "kmer_has_counts", "kmer_counts", "kmer_ic_mult", "kv_off", "kv_var", "kv_bits", "unique_off", "unique_idx",
+                 "multi_off", "multi_idx", "hap_allele", "hapnest_off", "hapnest_idx", "nestdep_off", "nestdep_cluster", "nestdep_var_off", "nestdep_var"):
+        out[name] = cand[name]
+    return out

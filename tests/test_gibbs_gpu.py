@@ -173,3 +173,60 @@ def test_sharded_run_equals_unsharded_and_summary_definition(gpu_ctx, oracle):
         summ, _ = gpu_summary(shard.take_groups(flat, ids))
         merged[shard.cluster_ids_of(flat, ids)] = summ
     assert np.array_equal(merged, full)
+
+
+def test_graphs_to_genotypes_end_to_end(gpu_ctx, oracle):
+    """The whole hot path on one small unit, GPU side only through the C ABI: graphs + best paths -> path k-mers -> KMC scan into the
+    count table -> classifyPathKmers -> getHaplotypeCandidates -> Gibbs.  The oracle runs the same pipeline; the bundles and the
+    diplotype sampling frequencies must agree."""
+    import copy
+
+    from _oracle import OrcBloom, OrcGraphs, OrcKmc, OrcTable
+    from bayestyper_amd import lib, synth_graphs
+
+    K, S = 55, 2
+    rng = np.random.default_rng(77)
+    gs = [synth_graphs.random_cluster(rng, K, int(rng.integers(1, 4)), int(rng.integers(2, 6)), kinds=("snv", "ins", "del")) for _ in range(10)]
+    gs[1] = copy.deepcopy(gs[0])                      # a second cluster over the same sequence: multicluster k-mers inside one group
+    gs[1].paths = synth_graphs.random_paths(gs[1], rng, 2)
+    f = synth_graphs.flatten(gs)
+    groups = [[0, 1]] + [[c] for c in range(2, len(gs))]
+    og, gp = OrcGraphs(oracle, f, K), lib.Paths(gpu_ctx, f, K)
+    ob, gb = OrcBloom(oracle, 100_000, 1e-3, K, threaded=True), lib.Bloom.create(gpu_ctx, 100_000, 1e-3, K, threaded=True)
+    og.count_kmers(ob)
+    gp.count_kmers(gb)
+    # "reads": every path k-mer of the first path of each cluster gets NB-like counts in both samples -> KMC databases -> table
+    nt = np.frombuffer(b"ACGT", np.uint8)
+    hap_text = np.concatenate([np.concatenate([nt[g.seq[v]] for v in range(len(g.seq)) if g.paths[0, v]] + [np.frombuffer(b"N", np.uint8)]) for g in gs])
+    km, va = oracle.kmers_from_sequence(hap_text.tobytes(), K)
+    present = np.unique(km[va == 1], axis=0)
+    ot, gt = OrcTable(oracle, S, K), lib.Table(gpu_ctx, 50_000, S, K)
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as td:
+        for s in range(S):
+            cnt = rng.poisson(15, len(present)).astype(np.uint32) + 1
+            pref = os.path.join(td, f"s{s}")
+            oracle.kmc_write(pref, oracle.unpack(present, K), cnt, K, 3, 1)
+            db = OrcKmc(oracle, pref)
+            ot.parse_sample_kmers(ob, db, s)
+            sc = lib.KmcScan(gpu_ctx, db.k, db.p, db.counter_size, db.total, db.lut())
+            buf = gpu_ctx.to_device(db.payload())
+            sc.run(gb, gt, s, buf.ptr, 0, db.total)
+            gpu_ctx.sync()
+            sc.close(), buf.free(), db.close()
+    omg, gmg = OrcBloom(oracle, 10, 1e-4, K), lib.Bloom.create(gpu_ctx, 10, 1e-4, K, threaded=False)
+    n_o, ex_o = og.classify(ot, omg)
+    n_g, ex_g = gp.classify(gt, gmg)
+    assert np.array_equal(n_o, n_g) and np.array_equal(ex_o, ex_g)
+    co, cg = og.candidates(ot), gp.candidates(gt)
+    for name in co:
+        assert np.array_equal(co[name], cg[name]), name
+    assert len(co["multi_idx"]) > 0 and co["kmer_has_counts"].sum() > 0
+    flat = synth_graphs.gibbs_batch_from_candidates(cg, f, groups, S)
+    kw = dict(seed=3, chains=2, burn=10, iters=30)
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=15, **kw)
+    for g, (to, tg) in enumerate(tr):
+        assert np.array_equal(to, tg[: len(to)]), f"group {g}"
+    assert_parity(flat, ro, rg, 2 * 30)
+    for x in (og, gp, ob, gb, ot, gt, omg, gmg):
+        x.close()
