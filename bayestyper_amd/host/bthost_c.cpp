@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "CountDistribution.hpp"
+#include "Genotypes.hpp"
 
 using namespace bthost;
 
@@ -46,6 +47,54 @@ void bth_count_distribution_tables(void *h, double *genomic, double *noise, unsi
     auto *cd = (CountDistribution *)h;
     if (genomic) std::memcpy(genomic, cd->genomicTable().data(), (size_t)S * 65536 * 8);
     if (noise) std::memcpy(noise, cd->noiseTable().data(), (size_t)S * 256 * 8);
+}
+
+
+// getGenotypes for one cluster into flat arrays.  Strides: Amax alleles, Gmax = Amax*(Amax+1)/2 genotypes.
+//   gpp[(v*S+s)*Gmax + g], app[(v*S+s)*Amax + a], filters[(v*S+s)*Amax + a], estimate[(v*S+s)*2 + i] (0xFFFF none / unused),
+//   gq[v*S+s], total_count[v], alt_counts[v*Amax + a], alt_freq[v*Amax + a], acp[v*Amax + a], max_alt_acp[v], non_covered[v*Amax + a] (0/1)
+int bth_cluster_genotypes(unsigned S, unsigned H, unsigned V, const uint16_t *hap_allele, const uint16_t *var_num_alleles, const uint8_t *var_has_dependency,
+                          unsigned long long num_diplotypes, const uint16_t *h1, const uint16_t *h2, const uint32_t *freq, const double *stats, const uint8_t *ploidy,
+                          float min_gpp, float min_kmers, const float *min_fraction, unsigned Amax, float *gpp, float *app, uint16_t *filters, uint16_t *estimate,
+                          uint32_t *gq, uint32_t *total_count, uint32_t *alt_counts, float *alt_freq, float *acp, float *max_alt_acp, uint8_t *non_covered) {
+    try {
+        ClusterResults r;
+        r.S = S; r.H = H; r.V = V;
+        r.hap_allele = hap_allele; r.var_num_alleles = var_num_alleles; r.var_has_dependency = var_has_dependency;
+        r.num_diplotypes = num_diplotypes; r.h1 = h1; r.h2 = h2; r.freq = freq; r.stats = stats; r.ploidy = ploidy;
+        Filters f;
+        f.min_genotype_posterior = min_gpp;
+        f.min_number_of_kmers = min_kmers;
+        f.min_fraction_observed_kmers.assign(min_fraction, min_fraction + S);
+        const auto res = getGenotypes(r, f);
+        const unsigned Gmax = Amax * (Amax + 1) / 2;
+        for (unsigned v = 0; v < V; v++) {
+            const auto &g = res[v];
+            for (unsigned s = 0; s < S; s++) {
+                const auto &st = g.sample_stats[s];
+                const size_t vs = (size_t)v * S + s;
+                for (size_t i = 0; i < st.genotype_posteriors.size(); i++) gpp[vs * Gmax + i] = st.genotype_posteriors[i];
+                for (size_t i = 0; i < st.allele_posteriors.size(); i++) {
+                    app[vs * Amax + i] = st.allele_posteriors[i];
+                    filters[vs * Amax + i] = st.allele_filters[i];
+                }
+                estimate[vs * 2] = estimate[vs * 2 + 1] = 0xFFFF;
+                for (size_t i = 0; i < st.genotype_estimate.size(); i++) estimate[vs * 2 + i] = st.genotype_estimate[i];
+                gq[vs] = st.genotype_quality;
+            }
+            total_count[v] = g.variant_stats.total_count;
+            max_alt_acp[v] = g.variant_stats.max_alt_allele_call_probability;
+            for (size_t a = 0; a < g.variant_stats.alt_allele_counts.size(); a++) {
+                alt_counts[(size_t)v * Amax + a] = g.variant_stats.alt_allele_counts[a];
+                alt_freq[(size_t)v * Amax + a] = g.variant_stats.alt_allele_frequency[a];
+            }
+            for (size_t a = 0; a < g.variant_stats.allele_call_probabilities.size(); a++) acp[(size_t)v * Amax + a] = g.variant_stats.allele_call_probabilities[a];
+            for (uint16_t a : g.non_covered_alleles) non_covered[(size_t)v * Amax + a] = 1;
+        }
+        return 0;
+    } catch (...) {
+        return 1;
+    }
 }
 
 }  // extern "C"

@@ -1,0 +1,59 @@
+"""Genotype summaries (GPP / APP / GQ / filters / calls / AC, ACP) per cluster from the sampler's results:
+VariantClusterGenotyper::getGenotypes (src/bayesTyper/VariantClusterGenotyper.cpp:208-567) — ctypes front end of the C++ host
+layer's bthost::getGenotypes (bayestyper_amd/host/Genotypes.cpp).  `fn` defaults to libbthost's entry; the tests pass the oracle's
+restatement (same signature) to compare."""
+import ctypes as C
+
+import numpy as np
+
+OBSERVED_KMER_BETA = 0.275   # Filters.cpp:33
+
+
+def min_fraction_observed_kmers(genomic_means, disable=False):
+    """Filters::Filters (Filters.cpp:35-54): per sample 1 - exp(-(0.275f * mean)) as float, or 0 when disabled"""
+    m = np.asarray(genomic_means, np.float64)
+    return np.zeros(len(m), np.float32) if disable else (1 - np.exp(-(np.float32(OBSERVED_KMER_BETA).astype(np.float64) * m))).astype(np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cluster_genotypes(flat, res, c, ploidy, min_fraction, min_gpp=0.99, min_kmers=1.0, fn=None):
+    """flat: bt_gibbs_batch-style dict; res: Gibbs.results()/OrcGibbs.results(); c: cluster index; ploidy: [S] of the cluster's group"""
+    if fn is None:
+        from . import dll
+
+        fn = dll.bth_cluster_genotypes
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_float, C.c_float, C.c_void_p, C.c_uint] + [C.c_void_p] * 11
+    S = flat["S"]
+    H, V = int(flat["num_haplotypes"][c]), int(flat["num_variants"][c])
+    hv0 = int(np.sum(flat["num_haplotypes"][:c].astype(np.int64) * flat["num_variants"][:c].astype(np.int64)))
+    v0 = int(np.sum(flat["num_variants"][:c]))
+    hap_allele = np.ascontiguousarray(flat["hap_allele"][hv0:hv0 + H * V], np.uint16)
+    vna = np.ascontiguousarray(flat["var_num_alleles"][v0:v0 + V], np.uint16)
+    vdep = np.ascontiguousarray(flat["var_has_dependency"][v0:v0 + V], np.uint8)
+    e0, e1 = int(res["dip_off"][c]), int(res["dip_off"][c + 1])
+    h1 = np.ascontiguousarray(res["h1"][e0:e1], np.uint16)
+    h2 = np.ascontiguousarray(res["h2"][e0:e1], np.uint16)
+    freq = np.ascontiguousarray(res["freq"][e0:e1], np.uint32).reshape(-1)
+    stats = np.ascontiguousarray(res["stats"][int(res["cell_off"][c]):int(res["cell_off"][c + 1])], np.float64).reshape(-1)
+    ploidy = np.ascontiguousarray(ploidy, np.uint8)
+    mf = np.ascontiguousarray(min_fraction, np.float32)
+    Amax = int(vna.max())
+    Gmax = Amax * (Amax + 1) // 2
+    out = {"gpp": np.zeros((V, S, Gmax), np.float32), "app": np.zeros((V, S, Amax), np.float32), "filters": np.zeros((V, S, Amax), np.uint16),
+           "estimate": np.zeros((V, S, 2), np.uint16), "gq": np.zeros((V, S), np.uint32), "total_count": np.zeros(V, np.uint32),
+           "alt_counts": np.zeros((V, Amax), np.uint32), "alt_freq": np.zeros((V, Amax), np.float32), "acp": np.zeros((V, Amax), np.float32),
+           "max_alt_acp": np.zeros(V, np.float32), "non_covered": np.zeros((V, Amax), np.uint8)}
+    for a in (h1, h2, freq, stats):
+        if a.size == 0:
+            a.resize(1, refcheck=False)
+    rc = fn(S, H, V, _p(hap_allele), _p(vna), _p(vdep), e1 - e0, _p(h1), _p(h2), _p(freq), _p(stats), _p(ploidy), min_gpp, min_kmers, _p(mf), Amax,
+            *[_p(out[k]) for k in ("gpp", "app", "filters", "estimate", "gq", "total_count", "alt_counts", "alt_freq", "acp", "max_alt_acp", "non_covered")])
+    if rc != 0:
+        raise RuntimeError("cluster_genotypes failed")
+    out["num_alleles"] = vna
+    return out

@@ -1042,4 +1042,162 @@ uint64_t orc_gibbs_trace_fetch(void *h, uint32_t group, uint32_t *out, uint64_t 
     return n;
 }
 
+
+// ---- VariantClusterGenotyper::getGenotypes for one cluster (VariantClusterGenotyper.cpp:208-567), from the arrays
+// orc_gibbs_result_fetch returns.  Written along the reference's own structure: per-variant Genotypes objects with
+// SampleStats built while iterating the diplotype_sampling_frequencies map. ----
+namespace {
+struct PairHash {
+    size_t operator()(const std::pair<ushort, ushort> &p) const { return ((size_t)p.first << 16) ^ p.second; }
+};
+inline bool floatCompareO(const float a, const float b) { return ((a == b) or (std::abs(a - b) < std::abs(std::min(a, b)) * std::numeric_limits<float>::epsilon() * 100)); }
+inline bool floatLessO(const float a, const float b) { return ((a < b) and !(floatCompareO(a, b))); }
+}  // namespace
+int orc_cluster_genotypes(unsigned S, unsigned H, unsigned V, const uint16_t *hap_allele, const uint16_t *var_num_alleles, const uint8_t *var_has_dependency,
+                          unsigned long long num_diplotypes, const uint16_t *h1, const uint16_t *h2, const uint32_t *freq, const double *stats, const uint8_t *ploidy,
+                          float min_gpp, float min_kmers, const float *min_fraction, unsigned Amax, float *gpp, float *app, uint16_t *filters, uint16_t *estimate,
+                          uint32_t *gq, uint32_t *total_count, uint32_t *alt_counts, float *alt_freq, float *acp, float *max_alt_acp, uint8_t *non_covered) {
+    const unsigned Gmax = Amax * (Amax + 1) / 2;
+    std::unordered_map<std::pair<ushort, ushort>, std::vector<uint>, PairHash> diplotype_sampling_frequencies;
+    for (unsigned long long e = 0; e < num_diplotypes; e++) diplotype_sampling_frequencies.emplace(std::make_pair(h1[e], h2[e]), std::vector<uint>(freq + e * S, freq + (e + 1) * S));
+    uint allele_total = 0;
+    std::vector<uint> allele_first(V);
+    for (unsigned v = 0; v < V; v++) {
+        allele_first[v] = allele_total;
+        allele_total += var_num_alleles[v];
+    }
+    for (unsigned variant_idx = 0; variant_idx < V; variant_idx++) {
+        const ushort num_alleles = var_num_alleles[variant_idx];
+        auto haplotypeToAlleleIndex = [&](const ushort haplotype_idx) -> ushort {
+            if (haplotype_idx != 0xFFFF) return hap_allele[(size_t)haplotype_idx * V + variant_idx];
+            return num_alleles - 1;
+        };
+        {   // getNonCoveredAlleles
+            std::vector<bool> is_allele_covered(num_alleles, false);
+            for (unsigned h = 0; h < H; h++) is_allele_covered.at(hap_allele[(size_t)h * V + variant_idx]) = true;
+            if (var_has_dependency[variant_idx]) is_allele_covered.back() = true;
+            for (ushort a = 0; a < num_alleles; a++) non_covered[(size_t)variant_idx * Amax + a] = is_allele_covered[a] ? 0 : 1;
+        }
+        std::vector<std::vector<ushort>> estimates(S), sample_filters(S);
+        std::vector<std::vector<float>> sample_allele_post(S);
+        for (ushort sample_idx = 0; sample_idx < S; sample_idx++) {
+            const size_t vs = (size_t)variant_idx * S + sample_idx;
+            std::vector<float> genotype_posteriors, allele_posteriors;
+            if (ploidy[sample_idx] == 2) {
+                genotype_posteriors.assign((num_alleles * (num_alleles - 1)) / 2 + num_alleles, 0);
+                allele_posteriors.assign(num_alleles, 0);
+            } else if (ploidy[sample_idx] == 1) {
+                genotype_posteriors.assign(num_alleles, 0);
+                allele_posteriors.assign(num_alleles, 0);
+            }
+            std::vector<ushort> allele_filters(allele_posteriors.size(), 0);
+            uint num_iterations = 0;
+            std::pair<std::vector<std::pair<ushort, ushort>>, float> max_posterior_genotypes;
+            max_posterior_genotypes.second = 0;
+            for (auto &dsf : diplotype_sampling_frequencies) {
+                if (dsf.second.at(sample_idx) > 0) {
+                    std::pair<ushort, ushort> genotype_estimate(0xFFFF, 0xFFFF);
+                    auto genotype_idx = genotype_estimate.first;
+                    if (ploidy[sample_idx] == 2) {
+                        genotype_estimate.first = haplotypeToAlleleIndex(dsf.first.first);
+                        genotype_estimate.second = haplotypeToAlleleIndex(dsf.first.second);
+                        if (genotype_estimate.first > genotype_estimate.second) std::swap(genotype_estimate.first, genotype_estimate.second);
+                        genotype_idx = (genotype_estimate.second * (genotype_estimate.second + 1)) / 2 + genotype_estimate.first;
+                        genotype_posteriors.at(genotype_idx) += dsf.second.at(sample_idx);
+                        allele_posteriors.at(genotype_estimate.first) += dsf.second.at(sample_idx);
+                        if (genotype_estimate.first != genotype_estimate.second) allele_posteriors.at(genotype_estimate.second) += dsf.second.at(sample_idx);
+                    } else if (ploidy[sample_idx] == 1) {
+                        genotype_estimate.first = haplotypeToAlleleIndex(dsf.first.first);
+                        genotype_idx = genotype_estimate.first;
+                        genotype_posteriors.at(genotype_estimate.first) += dsf.second.at(sample_idx);
+                        allele_posteriors.at(genotype_estimate.first) += dsf.second.at(sample_idx);
+                    }
+                    num_iterations += dsf.second.at(sample_idx);
+                    if (ploidy[sample_idx] != 0) {
+                        if (floatCompareO(max_posterior_genotypes.second, genotype_posteriors.at(genotype_idx))) {
+                            max_posterior_genotypes.first.push_back(genotype_estimate);
+                        } else if (max_posterior_genotypes.second < genotype_posteriors.at(genotype_idx)) {
+                            max_posterior_genotypes.first.clear();
+                            max_posterior_genotypes.first.push_back(genotype_estimate);
+                            max_posterior_genotypes.second = genotype_posteriors.at(genotype_idx);
+                        }
+                    }
+                }
+            }
+            max_posterior_genotypes.second /= num_iterations;
+            for (auto &posterior : genotype_posteriors) posterior /= num_iterations;
+            for (auto &posterior : allele_posteriors) posterior /= num_iterations;
+            for (ushort allele_idx = 0; allele_idx < allele_posteriors.size(); allele_idx++) {
+                if (!floatCompareO(allele_posteriors.at(allele_idx), 0)) {
+                    const double *cell = stats + ((size_t)sample_idx * allele_total + allele_first[variant_idx] + allele_idx) * 12;
+                    const double count_mean = cell[2];      // count_stats.getMean().first
+                    if (floatLessO(count_mean, min_kmers)) allele_filters.at(allele_idx) += 1;
+                    if (!floatCompareO(count_mean, 0)) {
+                        const double fraction_mean = cell[6];   // fraction_stats.getMean().first
+                        if (floatLessO(fraction_mean, min_fraction[sample_idx])) allele_filters.at(allele_idx) += 2;
+                    }
+                }
+            }
+            uint genotype_quality;
+            if (floatCompareO(max_posterior_genotypes.second, 1)) genotype_quality = 99;
+            else if (floatCompareO(max_posterior_genotypes.second, 0)) genotype_quality = 0;
+            else genotype_quality = -10 * std::log10(1 - max_posterior_genotypes.second);
+            std::vector<ushort> genotype_estimate;
+            if (ploidy[sample_idx] == 2) {
+                genotype_estimate = std::vector<ushort>(2, 0xFFFF);
+                if (max_posterior_genotypes.first.size() == 1) {
+                    if (!floatLessO(max_posterior_genotypes.second, min_gpp)) {
+                        if ((allele_filters.at(max_posterior_genotypes.first.front().first) == 0) and (allele_filters.at(max_posterior_genotypes.first.front().second) == 0)) {
+                            genotype_estimate.front() = max_posterior_genotypes.first.front().first;
+                            genotype_estimate.back() = max_posterior_genotypes.first.front().second;
+                        }
+                    }
+                }
+            } else if (ploidy[sample_idx] == 1) {
+                genotype_estimate = std::vector<ushort>(1, 0xFFFF);
+                if ((max_posterior_genotypes.first.size() == 1) and !floatLessO(max_posterior_genotypes.second, min_gpp)) {
+                    if (allele_filters.at(max_posterior_genotypes.first.front().first) == 0) genotype_estimate.front() = max_posterior_genotypes.first.front().first;
+                }
+            }
+            for (size_t i = 0; i < genotype_posteriors.size(); i++) gpp[vs * Gmax + i] = genotype_posteriors[i];
+            for (size_t i = 0; i < allele_posteriors.size(); i++) {
+                app[vs * Amax + i] = allele_posteriors[i];
+                filters[vs * Amax + i] = allele_filters[i];
+            }
+            estimate[vs * 2] = estimate[vs * 2 + 1] = 0xFFFF;
+            for (size_t i = 0; i < genotype_estimate.size(); i++) estimate[vs * 2 + i] = genotype_estimate[i];
+            gq[vs] = genotype_quality;
+            estimates[sample_idx] = genotype_estimate;
+            sample_filters[sample_idx] = allele_filters;
+            sample_allele_post[sample_idx] = allele_posteriors;
+        }
+        // getGenotypeVariantStats
+        uint total = 0;
+        std::vector<uint> alt_allele_counts(num_alleles - 1, 0);
+        std::vector<float> allele_call_probabilities(num_alleles, 0);
+        for (ushort sample_idx = 0; sample_idx < S; sample_idx++) {
+            for (auto &allele_idx : estimates[sample_idx]) {
+                if (allele_idx != 0xFFFF) {
+                    total++;
+                    if (allele_idx > 0) alt_allele_counts.at(allele_idx - 1)++;
+                }
+            }
+            for (ushort allele_idx = 0; allele_idx < sample_allele_post[sample_idx].size(); allele_idx++)
+                if (sample_filters[sample_idx].at(allele_idx) == 0)
+                    allele_call_probabilities.at(allele_idx) = std::max(allele_call_probabilities.at(allele_idx), sample_allele_post[sample_idx].at(allele_idx));
+        }
+        float max_alt = 0;
+        const ushort num_alt = num_alleles - 1 - (var_has_dependency[variant_idx] ? 1 : 0);
+        for (ushort alt_allele_idx = 0; alt_allele_idx < num_alt; alt_allele_idx++) max_alt = std::max(max_alt, allele_call_probabilities.at(alt_allele_idx + 1));
+        total_count[variant_idx] = total;
+        max_alt_acp[variant_idx] = max_alt;
+        for (ushort a = 0; a + 1 < num_alleles; a++) {
+            alt_counts[(size_t)variant_idx * Amax + a] = alt_allele_counts[a];
+            alt_freq[(size_t)variant_idx * Amax + a] = total > 0 ? alt_allele_counts[a] / static_cast<float>(total) : 0.f;
+        }
+        for (ushort a = 0; a < num_alleles; a++) acp[(size_t)variant_idx * Amax + a] = allele_call_probabilities[a];
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -230,3 +230,32 @@ def test_graphs_to_genotypes_end_to_end(gpu_ctx, oracle):
     assert_parity(flat, ro, rg, 2 * 30)
     for x in (og, gp, ob, gb, ot, gt, omg, gmg):
         x.close()
+
+
+def test_genotype_posteriors_gpp_gq_calls(gpu_ctx, oracle):
+    """The contract in the reference's own output terms: per variant and sample GPP / APP within 1e-4 (they are expected identical),
+    GQ, allele filters, genotype calls and AC / ACP equal — GPU sampler + C++ host getGenotypes against oracle sampler + oracle getGenotypes."""
+    from bayestyper_amd import synth
+    from bayestyper_amd.host import genotypes
+
+    S = 3
+    rng = np.random.default_rng(8)
+    groups = [synth.group_shape_A(rng, i) for i in range(40)] + [synth.group_shape_B(rng, 100 + i) for i in range(8)] + [synth.group_shape_C(rng, 200 + 3 * i, root_H=8, root_kpa=60) for i in range(3)]
+    ploidy = np.full((len(groups), S), 2, np.uint8)
+    ploidy[::5, 1] = 1
+    ploidy[7, 2] = 0
+    flat = synth.flatten(groups, S, rng, ploidy=ploidy, gender=[0, 1, 1])
+    ro, rg, _ = run_both(gpu_ctx, oracle, flat, seed=21, chains=4, burn=20, iters=60)
+    mf = genotypes.min_fraction_observed_kmers([15.0] * S)
+    goff = flat["group_cluster_off"]
+    calls = 0
+    for g in range(flat["num_groups"]):
+        for c in range(goff[g], goff[g + 1]):
+            a = genotypes.cluster_genotypes(flat, rg, c, ploidy[g], mf)                                            # product: GPU results + host layer
+            b = genotypes.cluster_genotypes(flat, ro, c, ploidy[g], mf, fn=oracle.l.orc_cluster_genotypes)         # oracle end to end
+            assert np.abs(a["gpp"] - b["gpp"]).max() <= TOL and np.abs(a["app"] - b["app"]).max() <= TOL
+            for k in ("gq", "filters", "estimate", "total_count", "alt_counts", "non_covered"):
+                assert np.array_equal(a[k], b[k]), (c, k)
+            assert np.allclose(a["acp"], b["acp"], atol=TOL) and np.allclose(a["alt_freq"], b["alt_freq"], atol=TOL)
+            calls += int((a["estimate"][:, :, 0] != 0xFFFF).sum())
+    assert calls > 50
