@@ -161,6 +161,35 @@ __global__ __launch_bounds__(BLOCK) void classify_tally_kernel(const uint32_t *_
     }
 }
 
+// ---- countPathMultigroupKmers: D counts distinct (group, k-mer) pairs, E tracks per k-mer the first group seen and "another group too" ----
+__global__ __launch_bounds__(BLOCK) void multigroup_kernel(uint64_t *__restrict__ dlo, uint64_t *__restrict__ dhi, uint32_t *__restrict__ dtag, uint32_t *__restrict__ dstate,
+                                                            uint64_t *__restrict__ elo, uint64_t *__restrict__ ehi, uint32_t *__restrict__ etag, uint32_t *__restrict__ estate,
+                                                            uint32_t *__restrict__ egroup, uint32_t *__restrict__ emulti, uint64_t mask, const uint64_t *__restrict__ kmers,
+                                                            const uint8_t *__restrict__ valid, const uint32_t *__restrict__ pos_path, const uint32_t *__restrict__ path_cluster,
+                                                            const uint32_t *__restrict__ cluster_group, uint64_t L) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK) {
+        if (!valid[pos]) continue;
+        const uint64_t lo = kmers[2 * pos], hi = kmers[2 * pos + 1];
+        const uint32_t g = cluster_group[path_cluster[pos_path[pos]]];
+        index_insert(dlo, dhi, dtag, dstate, mask, lo, hi, g);
+        const uint64_t e = index_insert(elo, ehi, etag, estate, mask, lo, hi, 0u);
+        const uint32_t prev = atomicCAS(&egroup[e], 0xFFFFFFFFu, g);
+        if (prev != 0xFFFFFFFFu && prev != g) emulti[e] = 1u;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void multigroup_list_kernel(const uint64_t *__restrict__ elo, const uint64_t *__restrict__ ehi, const uint32_t *__restrict__ estate,
+                                                                 const uint32_t *__restrict__ emulti, const uint32_t *__restrict__ dstate, uint64_t mask,
+                                                                 uint64_t *__restrict__ out, unsigned long long *__restrict__ counters /* [0] multigroup, [1] (group,kmer) pairs */) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i <= mask; i += (uint64_t)gridDim.x * BLOCK) {
+        if (dstate[i] == ST_READY) atomicAdd(&counters[1], 1ULL);
+        if (estate[i] == ST_READY && emulti[i]) {
+            const unsigned long long j = atomicAdd(&counters[0], 1ULL);
+            out[2 * j] = elo[i];
+            out[2 * j + 1] = ehi[i];
+        }
+    }
+}
+
 // ---- candidates ----
 // per distinct (cluster, k-mer): table record -> excluded?, multicluster?; list_flags[j]: bit0 in table, bit1 excluded, bit2 multicluster
 __global__ __launch_bounds__(BLOCK) void record_kernel(TableView t, const int64_t *__restrict__ slots, uint64_t n, uint8_t *__restrict__ list_flags) {
@@ -568,6 +597,58 @@ int bt_paths_count_kmers(bt_paths *p, bt_bloom *path_bloom) {
                        p->d_valid, p->L);
     BT_CHECK_LAUNCH();
     return BT_OK;
+}
+
+int bt_paths_count_multigroup(bt_paths *p, const uint32_t *h_cluster_group, bt_bloom *path_bloom, bt_table *multigroup_table, uint64_t *h_num_path_kmers) {
+    if (!p || !h_cluster_group || !path_bloom || !multigroup_table) return fail("bt_paths_count_multigroup: null argument");
+    if (path_bloom->k != p->k || multigroup_table->k != p->k) return fail("bt_paths_count_multigroup: k mismatch");
+    BT_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t st = p->ctx->stream;
+    const uint64_t cap = pow2_at_least(2 * std::max<uint64_t>(p->num_valid, 8));
+    std::vector<void *> tmp;
+    auto cleanup = [&]() {
+        for (void *q : tmp) (void)hipFree(q);
+    };
+    uint64_t *dlo, *dhi, *elo, *ehi, *d_out;
+    uint32_t *dtag, *dstate, *etag, *estate, *egroup, *emulti, *d_cg;
+    unsigned long long *d_counters;
+    int rc = BT_OK;
+    auto A = [&](auto **q, uint64_t n) {
+        if (rc == BT_OK) rc = dev_alloc(q, n, tmp);
+    };
+    A(&dlo, cap); A(&dhi, cap); A(&dtag, cap); A(&dstate, cap);
+    A(&elo, cap); A(&ehi, cap); A(&etag, cap); A(&estate, cap); A(&egroup, cap); A(&emulti, cap);
+    A(&d_out, 2 * p->num_valid); A(&d_cg, p->C); A(&d_counters, 2);
+    if (rc != BT_OK) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemsetAsync(dstate, 0, cap * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(estate, 0, cap * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(egroup, 0xFF, cap * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(emulti, 0, cap * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_counters, 0, 16, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_cg, h_cluster_group, (size_t)p->C * 4, hipMemcpyHostToDevice, st);
+    const unsigned maxb = p->ctx->num_cu * 16;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(multigroup_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, dlo, dhi, dtag, dstate, elo, ehi, etag, estate, egroup, emulti, cap - 1,
+                           p->d_kmers, p->d_valid, p->d_pos_path, p->d_path_cluster, d_cg, p->L);
+        hipLaunchKernelGGL(multigroup_list_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, elo, ehi, estate, emulti, dstate, cap - 1, d_out, d_counters);
+        e = hipGetLastError();
+    }
+    unsigned long long counters[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(counters, d_counters, 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(std::string("bt_paths_count_multigroup: ") + hipGetErrorString(e));
+    }
+    rc = bt_table_insert_batch(multigroup_table, d_out, counters[0], 0);
+    if (rc == BT_OK) rc = bt_paths_count_kmers(p, path_bloom);
+    if (rc == BT_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail("bt_paths_count_multigroup: device error");
+    cleanup();
+    if (h_num_path_kmers) *h_num_path_kmers = counters[1];
+    return rc;
 }
 
 int bt_paths_classify(bt_paths *p, bt_table *table, bt_bloom *multigroup_bloom, uint32_t *h_num_path_kmers, uint8_t *h_has_excluded) {

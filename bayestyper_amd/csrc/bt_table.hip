@@ -12,7 +12,11 @@
 // per-key contents are identical, iteration order is free.
 #include "bt_internal.hpp"
 
+#include <algorithm>
 #include <cstring>
+#include <numeric>
+
+#include "bt_rng_device.hpp"
 
 using namespace bt;
 
@@ -160,6 +164,61 @@ __global__ __launch_bounds__(BLOCK) void table_find_kernel(TableView t, const ui
 // table insert + addInterclusterMultiplicity.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned SEQ_TILE = 1024;
+
+// ---- countInterclusterParameterKmers (KmerCounter.cpp:161-250) ----
+struct ParamRegion {
+    uint64_t start, len;     // relative to the span handed to the kernels
+    uint32_t seed;
+    uint32_t is_decoy;
+};
+__device__ inline int64_t region_of(const ParamRegion *__restrict__ regs, uint32_t R, uint64_t pos) {   // regions sorted by start, disjoint
+    uint32_t lo = 0, hi = R;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (regs[mid].start <= pos) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo == 0) return -1;
+    return pos - regs[lo - 1].start < regs[lo - 1].len ? (int64_t)(lo - 1) : -1;
+}
+// cand[pos] = 1 + region index parity is not needed: 1 when the window ending at pos lies inside one region and misses the path Bloom
+__global__ __launch_bounds__(BLOCK) void param_cand_kernel(BloomView bloom, const ParamRegion *__restrict__ regs, uint32_t R, const uint64_t *__restrict__ kmers,
+                                                            const uint8_t *__restrict__ valid, uint64_t n, uint32_t k, uint8_t *__restrict__ cand) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * BLOCK) {
+        uint8_t c = 0;
+        if (valid[pos]) {
+            const int64_t r = region_of(regs, R, pos);
+            if (r >= 0 && pos - regs[r].start + 1 >= k) {   // kmer_pair.reset() at the region start
+                const Kmer a{kmers[2 * pos], kmers[2 * pos + 1]};
+                c = bloom_contains(nthash64(a, bloom.k), bloom) ? 0 : 1;
+            }
+        }
+        cand[pos] = c;
+    }
+}
+// one lane per non-decoy region: the region's Bernoulli draws, in window order (the only sequential part)
+__global__ __launch_bounds__(64) void param_draw_kernel(const ParamRegion *__restrict__ regs, uint32_t r0, uint32_t r1, uint32_t *__restrict__ mt_states, double p,
+                                                         uint8_t *__restrict__ cand) {
+    const uint32_t r = r0 + blockIdx.x * 64 + threadIdx.x;
+    if (r >= r1 || regs[r].is_decoy) return;
+    uint32_t *st = mt_states + (size_t)(r - r0) * MT_WORDS;
+    mt_seed(st, regs[r].seed);
+    Mt rng = mt_open(st);
+    for (uint64_t pos = regs[r].start, e = regs[r].start + regs[r].len; pos < e; ++pos)
+        if (cand[pos]) cand[pos] = rng_bernoulli(rng, p) ? 2 : 0;   // 2 = accepted
+}
+__global__ __launch_bounds__(BLOCK) void param_insert_kernel(TableView t, const ParamRegion *__restrict__ regs, uint32_t R, const uint64_t *__restrict__ kmers,
+                                                              const uint8_t *__restrict__ cand, uint64_t n) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * BLOCK) {
+        const uint8_t c = cand[pos];
+        if (!c) continue;
+        const int64_t r = region_of(regs, R, pos);
+        const bool decoy = regs[r].is_decoy != 0;
+        if (!decoy && c != 2) continue;
+        const int64_t slot = table_find_or_insert(t, Kmer{kmers[2 * pos], kmers[2 * pos + 1]});
+        if (slot >= 0) atomicOr(&t.meta[slot], decoy ? (uint32_t)BT_KC_DECOY_OCC : (uint32_t)BT_KC_PARAMETER);
+    }
+}
 
 // calculateKmerStats (KmerHash.cpp:256-340): class tallies + exact integer moments of the parameter k-mers' counts per
 // (sample, intercluster multiplicity).  Per-workgroup LDS accumulation of the tallies; the (s, m) bins go straight to global
@@ -498,6 +557,72 @@ int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *
         ++w;
     }
     *num_written = w;
+    return BT_OK;
+}
+
+int bt_table_count_parameter_kmers(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint32_t num_regions, const uint64_t *h_start, const uint64_t *h_len,
+                                   const uint8_t *h_is_decoy, const uint32_t *h_seed, float fraction) {
+    if (!t || !path_bloom || !d_seq || !h_start || !h_len || !h_is_decoy || !h_seed) return fail("bt_table_count_parameter_kmers: null argument");
+    if (path_bloom->k != t->k) return fail("bt_table_count_parameter_kmers: k mismatch between table and bloom");
+    if (!(fraction > 0) || fraction > 1) return fail("bt_table_count_parameter_kmers: fraction must be in (0, 1]");   // KmerCounter.cpp:168-169
+    if (num_regions == 0) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    std::vector<uint32_t> order(num_regions);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h_start[a] < h_start[b]; });
+    const uint64_t span0 = h_start[order.front()];
+    uint64_t span1 = span0;
+    std::vector<ParamRegion> regs(num_regions);
+    for (uint32_t i = 0; i < num_regions; ++i) {
+        const uint32_t r = order[i];
+        if (i && h_start[r] < h_start[order[i - 1]] + h_len[order[i - 1]]) return fail("bt_table_count_parameter_kmers: regions overlap");
+        regs[i] = ParamRegion{h_start[r] - span0, h_len[r], h_seed[r], h_is_decoy[r] ? 1u : 0u};
+        span1 = std::max(span1, h_start[r] + h_len[r]);
+    }
+    const uint64_t n = span1 - span0;
+    if (n == 0) return BT_OK;
+    hipStream_t st = t->ctx->stream;
+    ParamRegion *d_regs = nullptr;
+    uint64_t *d_kmers = nullptr;
+    uint8_t *d_valid = nullptr, *d_cand = nullptr;
+    uint32_t *d_mt = nullptr;
+    const uint32_t batch = 1u << 16;   // regions drawing concurrently (625 state words each)
+    auto release = [&]() {
+        (void)hipFree(d_regs);
+        (void)hipFree(d_kmers);
+        (void)hipFree(d_valid);
+        (void)hipFree(d_cand);
+        (void)hipFree(d_mt);
+    };
+#define PK(call)                                                                                        \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            release();                                                                                  \
+            return fail(std::string("bt_table_count_parameter_kmers: ") + hipGetErrorString(_e));       \
+        }                                                                                               \
+    } while (0)
+    PK(hipMalloc(reinterpret_cast<void **>(&d_regs), (size_t)num_regions * sizeof(ParamRegion)));
+    PK(hipMalloc(reinterpret_cast<void **>(&d_kmers), n * 16));
+    PK(hipMalloc(reinterpret_cast<void **>(&d_valid), n));
+    PK(hipMalloc(reinterpret_cast<void **>(&d_cand), n));
+    PK(hipMalloc(reinterpret_cast<void **>(&d_mt), (size_t)std::min(batch, num_regions) * MT_WORDS * 4));
+    PK(hipMemcpyAsync(d_regs, regs.data(), (size_t)num_regions * sizeof(ParamRegion), hipMemcpyHostToDevice, st));
+    if (bt_kmers_from_sequence(t->ctx, d_seq + span0, n, t->k, d_kmers, d_valid) != BT_OK) {
+        release();
+        return BT_ERR;
+    }
+    const unsigned maxb = t->ctx->num_cu * 16;
+    hipLaunchKernelGGL(param_cand_kernel, dim3(grid_for(n, BLOCK, maxb)), dim3(BLOCK), 0, st, path_bloom->view(), d_regs, num_regions, d_kmers, d_valid, n, t->k, d_cand);
+    for (uint32_t r0 = 0; r0 < num_regions; r0 += batch) {
+        const uint32_t r1 = std::min(num_regions, r0 + batch);
+        hipLaunchKernelGGL(param_draw_kernel, dim3((r1 - r0 + 63) / 64), dim3(64), 0, st, d_regs, r0, r1, d_mt, (double)fraction, d_cand);
+    }
+    hipLaunchKernelGGL(param_insert_kernel, dim3(grid_for(n, BLOCK, maxb)), dim3(BLOCK), 0, st, t->v, d_regs, num_regions, d_kmers, d_cand, n);
+    PK(hipGetLastError());
+    PK(hipStreamSynchronize(st));
+#undef PK
+    release();
     return BT_OK;
 }
 

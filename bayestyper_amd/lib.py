@@ -66,9 +66,11 @@ bt_table_export = _sig("bt_table_export", [vp, vp, vp, vp, C.c_uint64, u64p])
 bt_paths_create = _sig("bt_paths_create", [vp, vp, C.c_uint32, C.POINTER(vp), u64p])
 bt_paths_destroy = _sig("bt_paths_destroy", [vp])
 bt_paths_count_kmers = _sig("bt_paths_count_kmers", [vp, vp])
+bt_paths_count_multigroup = _sig("bt_paths_count_multigroup", [vp, vp, vp, vp, u64p])
 bt_paths_classify = _sig("bt_paths_classify", [vp, vp, vp, vp, vp])
 bt_paths_candidates = _sig("bt_paths_candidates", [vp, vp, vp])
 bt_paths_candidates_fetch = _sig("bt_paths_candidates_fetch", [vp, vp])
+bt_table_count_parameter_kmers = _sig("bt_table_count_parameter_kmers", [vp, vp, vp, C.c_uint32, vp, vp, vp, vp, C.c_float])
 bt_table_kmer_stats = _sig("bt_table_kmer_stats", [vp, vp, vp, vp, vp, vp, vp])
 bt_table_count_intercluster = _sig("bt_table_count_intercluster", [vp, vp, vp, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32])
 bt_table_classify_batch = _sig("bt_table_classify_batch", [vp, vp, vp, vp, C.c_uint64, vp])
@@ -291,6 +293,14 @@ class Table:
             b.free()
         return out
 
+    def count_parameter_kmers(self, bloom, seq_bytes, starts, lens, decoy, seeds, fraction):
+        """bt_table_count_parameter_kmers over regions of one sequence (uploaded here)"""
+        d = self.ctx.to_device(np.frombuffer(seq_bytes, dtype=np.uint8))
+        a = [np.ascontiguousarray(starts, np.uint64), np.ascontiguousarray(lens, np.uint64), np.ascontiguousarray(decoy, np.uint8), np.ascontiguousarray(seeds, np.uint32)]
+        check(bt_table_count_parameter_kmers(self.h, bloom.h, d.ptr, len(a[0]), *[_np_ptr(x) for x in a], float(fraction)))
+        self.ctx.sync()
+        d.free()
+
     def kmer_stats(self, gender):
         """bt_table_kmer_stats -> (class_counts[7], dict of exact integer moments n / nonzero / sum / sumsq, each [S, 256])"""
         g = np.ascontiguousarray(gender, dtype=np.uint8)
@@ -346,6 +356,12 @@ class Paths:
 
     def count_kmers(self, bloom):
         check(bt_paths_count_kmers(self.h, bloom.h))
+
+    def count_multigroup(self, cluster_group, bloom, table):
+        cg = np.ascontiguousarray(cluster_group, np.uint32)
+        n = C.c_uint64()
+        check(bt_paths_count_multigroup(self.h, _np_ptr(cg), bloom.h, table.h, C.byref(n)))
+        return n.value
 
     def classify(self, table, mg_bloom):
         n = np.zeros(self.C, np.uint32)

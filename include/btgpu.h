@@ -176,6 +176,15 @@ int bt_table_kmer_stats(bt_table *t, const uint8_t *h_gender, uint64_t *h_class_
 int bt_table_count_intercluster(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint64_t len,
                                 int is_decoy, uint32_t female_ploidy, uint32_t male_ploidy);
 
+/* KmerCounter::countInterclusterParameterKmers (src/bayesTyper/KmerCounter.cpp:161-250) for a batch of disjoint intercluster
+ * regions of one device-resident sequence: region r = d_seq[h_start[r] .. h_start[r] + h_len[r]).  Every canonical k-mer of a
+ * region that is NOT in the path Bloom filter is, in window order, either recorded as decoy (h_is_decoy[r]) or accepted by a
+ * bernoulli_distribution(fraction) draw of mt19937(h_seed[r]) (h_seed[r] = prng_seed + intercluster_regions_idx, :176); accepted
+ * k-mers are inserted with BT_KC_PARAMETER, decoy ones with BT_KC_DECOY_OCC.  The table plays KmerHash<bool>: the reference's
+ * final value of a k-mer is PARAMETER && !DECOY_OCC (independent of the order regions are processed in). */
+int bt_table_count_parameter_kmers(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint32_t num_regions, const uint64_t *h_start,
+                                   const uint64_t *h_len, const uint8_t *h_is_decoy, const uint32_t *h_seed, float fraction);
+
 /* the table-update half of VariantClusterGraph::classifyPathKmers for one batch of DISTINCT
  * path k-mers of distinct clusters (src/bayesTyper/VariantClusterGraph.cpp:902-938): for k-mer i
  * with max-over-paths multiplicity d_mult[i]: findKmer; absent and mult > 127 -> addKmer;
@@ -249,6 +258,14 @@ int bt_paths_destroy(bt_paths *p);
 /* VariantClusterGraph::countPathKmers + KmerCounter::countPathKmersCallback (KmerCounter.cpp:252-289): every path k-mer is
  * added to the path Bloom filter (the reference first collects them in an unordered_set; insertion is idempotent) */
 int bt_paths_count_kmers(bt_paths *p, bt_bloom *path_bloom);
+/* KmerCounter::countPathMultigroupKmers (src/bayesTyper/KmerCounter.cpp:105-159) — cluster stage.  h_cluster_group[c] = index of
+ * the variant-cluster group of cluster c.  Every distinct path k-mer of a group is looked up in the path Bloom filter: present ->
+ * it goes into the multigroup table (KmerHash<bool>), absent -> it is added to the filter; *h_num_path_kmers = sum over groups of
+ * their distinct path k-mers (inference_unit->num_path_kmers).
+ * DEVIATION (documented in DESIGN.md): the reference's outcome depends on the order threads reach the filter — a Bloom false
+ * positive on a k-mer's first lookup also lands it in the multigroup table.  Here a k-mer is multigroup iff it occurs in at
+ * least two groups (the order-independent part); afterwards every path k-mer is in the filter, as in the reference. */
+int bt_paths_count_multigroup(bt_paths *p, const uint32_t *h_cluster_group, bt_bloom *path_bloom, bt_table *multigroup_table, uint64_t *h_num_path_kmers);
 /* VariantClusterGraph::classifyPathKmers for every cluster (VariantClusterGraph.cpp:848-939): per distinct path k-mer of a
  * cluster the maximum over its paths of the (saturating) per-path multiplicity -> table update as bt_table_classify_batch.
  * h_num_path_kmers[c] = distinct k-mers of cluster c (num_path_kmers), h_has_excluded[c] = has_excluded_kmers. */

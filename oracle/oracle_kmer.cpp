@@ -17,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <random>
 #include <sstream>
 #include <string>
 #include <functional>
@@ -377,6 +378,21 @@ void orc_table_count_intercluster(void *h, void *bloom, const char *seq, uint64_
         if (b->subs[b->route(can.data())].containsF(can.data())) t->map[can].addInterclusterMultiplicity(is_decoy != 0, fp, mp);
     });
 }
+// KmerCounter::countInterclusterParameterKmersCallback for ONE region (KmerCounter.cpp:161-231): seed = prng_seed + region index;
+// the table plays KmerHash<bool>: decoy -> value false (flag 0x08 here), accepted -> value true unless already present (flag 0x20)
+void orc_table_count_parameter_kmers(void *h, void *bloom, const char *seq, uint64_t len, int is_decoy, unsigned seed, float fraction) {
+    OrcTable *t = (OrcTable *)h;
+    OrcBloom *b = (OrcBloom *)bloom;
+    std::bernoulli_distribution bernoulli_dist(fraction);
+    std::mt19937 prng;
+    prng.seed(seed);
+    slide_canonical(seq, len, t->k, [&](uint64_t, const std::string &can) {
+        if (!b->subs[b->route(can.data())].containsF(can.data())) {
+            if (is_decoy) t->map[can].flags |= 0x08;
+            else if (bernoulli_dist(prng)) t->map[can].flags |= 0x20;
+        }
+    });
+}
 // table half of VariantClusterGraph::classifyPathKmers (VariantClusterGraph.cpp:902-938)
 void orc_table_classify(void *h, void *mg_bloom, const char *kmers, const uint8_t *mult, uint64_t n, uint8_t *excluded) {
     OrcTable *t = (OrcTable *)h;
@@ -633,6 +649,30 @@ uint64_t orc_paths_count_kmers(void *gh, void *bloom) {
     if (b)
         for (auto &km : path_kmers) b->subs[b->route(km.data())].insertF(km.data());
     return windows;
+}
+
+// KmerCounter::countPathMultigroupKmersCallback (KmerCounter.cpp:105-145), single thread: groups in index order; a path k-mer the
+// filter already reports goes into the multigroup table, otherwise it is added to the filter.  Returns num_path_kmers.
+uint64_t orc_paths_count_multigroup(void *gh, const uint32_t *cluster_group, void *bloom, void *table) {
+    const OrcGraphs &g = *(OrcGraphs *)gh;
+    OrcBloom *b = (OrcBloom *)bloom;
+    OrcTable *t = (OrcTable *)table;
+    uint32_t num_groups = 0;
+    for (uint32_t c = 0; c < g.C; c++) num_groups = std::max(num_groups, cluster_group[c] + 1);
+    uint64_t num_kmers = 0;
+    for (uint32_t grp = 0; grp < num_groups; grp++) {
+        std::unordered_set<std::string> group_kmers;
+        for (uint32_t c = 0; c < g.C; c++)
+            if (cluster_group[c] == grp)
+                for (uint32_t p = 0; p < g.num_paths[c]; p++) walk_path(g, c, p, [](uint32_t) {}, [&](const std::string &km) { group_kmers.insert(km); }, [] {});
+        num_kmers += group_kmers.size();
+        for (auto &km : group_kmers) {
+            FlatBloom &f = b->subs[b->route(km.data())];
+            if (f.containsF(km.data())) t->map[km];
+            else f.insertF(km.data());
+        }
+    }
+    return num_kmers;
 }
 
 // VariantClusterGraph::classifyPathKmers (:848-939) for every cluster, clusters in index order

@@ -64,6 +64,7 @@ class Oracle:
         L.orc_table_insert.argtypes = [vp, vp, C.c_uint64, C.c_int]
         L.orc_table_count_intercluster.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_uint, C.c_uint]
         L.orc_table_classify.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]
+        L.orc_table_count_parameter_kmers.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_uint, C.c_float]
         L.orc_table_export.restype = C.c_uint64
         L.orc_table_export.argtypes = [vp, vp, vp, vp]
         L.orc_graphs_new.restype = vp
@@ -72,6 +73,8 @@ class Oracle:
         L.orc_paths_count_kmers.restype = C.c_uint64
         L.orc_paths_count_kmers.argtypes = [vp, vp]
         L.orc_paths_classify.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_paths_count_multigroup.restype = C.c_uint64
+        L.orc_paths_count_multigroup.argtypes = [vp, vp, vp, vp]
         L.orc_paths_candidates.restype = vp
         L.orc_paths_candidates.argtypes = [vp, vp, vp]
         L.orc_paths_candidates_fetch.argtypes = [vp] * 21
@@ -190,6 +193,10 @@ class OrcTable:
         a = np.frombuffer(seq_bytes, dtype=np.uint8).copy()
         self.o.l.orc_table_count_intercluster(self.h, bloom.h, _ptr(a), len(a), int(is_decoy), fp, mp)
 
+    def count_parameter_kmers(self, bloom, seq_bytes, is_decoy, seed, fraction):
+        a = np.frombuffer(seq_bytes, dtype=np.uint8).copy()
+        self.o.l.orc_table_count_parameter_kmers(self.h, bloom.h, _ptr(a), len(a), int(is_decoy), int(seed), float(fraction))
+
     def classify(self, mg_bloom, kmers_ascii, mult):
         a = ascii_kmers(kmers_ascii)
         m = np.ascontiguousarray(mult, dtype=np.uint8)
@@ -254,6 +261,10 @@ class OrcGraphs:
 
     def count_kmers(self, bloom=None):
         return self.o.l.orc_paths_count_kmers(self.h, bloom.h if bloom is not None else None)
+
+    def count_multigroup(self, cluster_group, bloom, table):
+        cg = np.ascontiguousarray(cluster_group, np.uint32)
+        return self.o.l.orc_paths_count_multigroup(self.h, _ptr(cg), bloom.h, table.h)
 
     def classify(self, table, mg_bloom):
         n = np.zeros(self.f["num_clusters"], np.uint32)

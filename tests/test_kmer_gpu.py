@@ -429,3 +429,72 @@ def test_path_enumeration_classify_candidates(gpu_ctx, oracle):
     assert len(ro["multi_idx"]) > 0 and len(ro["hapnest_idx"]) > 0 and len(ro["nestdep_var"]) > 0 and ro["kmer_off"][-1] < n_o.sum()
     for x in (gp, og, gb, ob, gt, ot, tb_o, tb_g, omg, gmg):
         x.close()
+
+
+def test_intercluster_parameter_kmers(gpu_ctx, oracle):
+    """countInterclusterParameterKmers: per region the Bernoulli(fraction) stream of mt19937(seed + region index) over the non-path
+    k-mers in window order; decoy regions override.  Table flags bit-exact."""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(33)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 200_000)].copy()
+    genome[70_000:70_030] = ord("N")
+    genome[150_000:152_000] = genome[10_000:12_000]        # a repeat: the same k-mer drawn in two regions / in a decoy and a normal region
+    # regions: disjoint, unsorted, one of length < k, one empty-ish, two decoys (one overlapping the repeat)
+    regions = [(60_000, 25_000, 0), (0, 30_000, 0), (149_000, 5_000, 1), (30_050, 40, 0), (100_000, 20_000, 0), (190_000, 10_000, 1), (130_000, 54, 0)]
+    path_k, path_v = oracle.kmers_from_sequence(genome[5_000:8_000].tobytes(), K)
+    path = np.unique(path_k[path_v == 1], axis=0)
+    ob = OrcBloom(oracle, len(path), 1e-3, K, threaded=True)
+    ob.insert(oracle.unpack(path, K))
+    gb = lib.Bloom.create(gpu_ctx, len(path), 1e-3, K, threaded=True)
+    gb.insert(path)
+    for fraction in (0.05, 1.0):
+        ot, gt = OrcTable(oracle, 1, K), lib.Table(gpu_ctx, 400_000, 1, K)
+        seeds = [1234 + i for i in range(len(regions))]
+        for (a, n, d), sd in zip(regions, seeds):
+            ot.count_parameter_kmers(ob, genome[a:a + n].tobytes(), d, sd, fraction)
+        gt.count_parameter_kmers(gb, genome.tobytes(), [r[0] for r in regions], [r[1] for r in regions], [r[2] for r in regions], seeds, fraction)
+        gk, gc, gm = _sorted_export(*gt.export())
+        wk, wc, wm = _sorted_export(*ot.export())
+        assert np.array_equal(gk, wk) and np.array_equal(gm[:, 0], wm[:, 0])
+        par = (wm[:, 0] & 0x20) != 0
+        dec = (wm[:, 0] & 0x08) != 0
+        assert par.sum() > 100 and dec.sum() > 1000 and (par & dec).sum() > 0 if fraction == 1.0 else par.sum() > 100
+        if fraction < 1:
+            n_cand = sum(max(0, n - K + 1) for a, n, d in regions if not d)
+            assert 0.03 * n_cand < par.sum() < 0.07 * n_cand
+        ot.close(), gt.close()
+    ob.close(), gb.close()
+
+
+def test_path_multigroup_kmers(gpu_ctx, oracle):
+    """countPathMultigroupKmers: k-mers shared by two groups land in the multigroup table, k-mers shared inside one group do not;
+    num_path_kmers; the path Bloom afterwards holds every path k-mer.  (Filter sized so that no false positive occurs: the
+    reference's FP-induced entries are order-dependent and not reproduced, see include/btgpu.h.)"""
+    import copy
+
+    from _oracle import OrcGraphs
+    from bayestyper_amd import lib, synth_graphs
+
+    rng = np.random.default_rng(41)
+    gs = [synth_graphs.random_cluster(rng, K, int(rng.integers(1, 5)), int(rng.integers(2, 7))) for _ in range(12)]
+    gs[3] = copy.deepcopy(gs[2])     # same group as 2 -> shared k-mers are NOT multigroup
+    gs[3].paths = synth_graphs.random_paths(gs[3], rng, 3)
+    gs[9] = copy.deepcopy(gs[5])     # different group -> multigroup
+    gs[9].paths = synth_graphs.random_paths(gs[9], rng, 2)
+    f = synth_graphs.flatten(gs)
+    cluster_group = np.array([0, 1, 2, 2, 3, 4, 5, 5, 6, 7, 8, 9], np.uint32)
+    og, gp = OrcGraphs(oracle, f, K), lib.Paths(gpu_ctx, f, K)
+    ob, gb = OrcBloom(oracle, 1_000_000, 1e-7, K, threaded=True), lib.Bloom.create(gpu_ctx, 1_000_000, 1e-7, K, threaded=True)
+    ot, gt = OrcTable(oracle, 1, K), lib.Table(gpu_ctx, 50_000, 1, K)
+    n_o = og.count_multigroup(cluster_group, ob, ot)
+    n_g = gp.count_multigroup(cluster_group, gb, gt)
+    assert n_o == n_g and n_o > 0
+    gk, _, _ = _sorted_export(*gt.export())
+    wk, _, _ = _sorted_export(*ot.export())
+    assert len(wk) > 50 and np.array_equal(gk, wk)
+    # exactly the k-mers of clusters 5 and 9 that both contain
+    for sub in range(0, 65536, 4099):
+        assert np.array_equal(gb.bits(sub), ob.bits(sub))
+    for x in (og, gp, ob, gb, ot, gt):
+        x.close()
