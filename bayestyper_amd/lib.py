@@ -63,6 +63,11 @@ bt_table_insert_batch = _sig("bt_table_insert_batch", [vp, vp, C.c_uint64, C.c_i
 bt_table_find_batch = _sig("bt_table_find_batch", [vp, vp, C.c_uint64, vp])
 bt_table_read_slots = _sig("bt_table_read_slots", [vp, vp, C.c_uint64, vp, vp])
 bt_table_export = _sig("bt_table_export", [vp, vp, vp, vp, C.c_uint64, u64p])
+bt_find_paths_create = _sig("bt_find_paths_create", [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)])
+bt_find_paths_destroy = _sig("bt_find_paths_destroy", [vp])
+bt_find_paths_sample = _sig("bt_find_paths_sample", [vp, vp, vp])
+bt_find_paths_sizes = _sig("bt_find_paths_sizes", [vp, vp, u64p])
+bt_find_paths_fetch = _sig("bt_find_paths_fetch", [vp, vp])
 bt_paths_create = _sig("bt_paths_create", [vp, vp, C.c_uint32, C.POINTER(vp), u64p])
 bt_paths_destroy = _sig("bt_paths_destroy", [vp])
 bt_paths_count_kmers = _sig("bt_paths_count_kmers", [vp, vp])
@@ -387,6 +392,42 @@ class Paths:
     def close(self):
         if self.h:
             bt_paths_destroy(self.h)
+            self.h = None
+
+
+class FindPaths:
+    """Per-sample best-path search over flattened graphs (bt_find_paths_*)"""
+
+    def __init__(self, ctx, flat, k, max_haps, num_samples):
+        from . import synth_graphs
+
+        self.ctx, self.C = ctx, flat["num_clusters"]
+        self.nv = (flat["vertex_off"][1:] - flat["vertex_off"][:-1]).astype(np.int64)
+        batch, self._keep = synth_graphs.to_ctypes(flat)
+        h = vp()
+        check(bt_find_paths_create(ctx.h, C.byref(batch), k, max_haps, num_samples, C.byref(h)))
+        self.h = h.value
+
+    def sample(self, bloom, seeds):
+        sd = np.ascontiguousarray(seeds, np.uint32)
+        check(bt_find_paths_sample(self.h, bloom.h, _np_ptr(sd)))
+
+    def best_paths(self):
+        n = np.zeros(self.C, np.uint32)
+        tot = C.c_uint64()
+        check(bt_find_paths_sizes(self.h, _np_ptr(n), C.byref(tot)))
+        out = np.zeros(max(tot.value, 1), np.uint8)
+        check(bt_find_paths_fetch(self.h, _np_ptr(out)))
+        res, at = [], 0
+        for c in range(self.C):
+            m = int(n[c]) * int(self.nv[c])
+            res.append(out[at:at + m].reshape(int(n[c]), int(self.nv[c])).copy())
+            at += m
+        return res
+
+    def close(self):
+        if self.h:
+            bt_find_paths_destroy(self.h)
             self.h = None
 
 

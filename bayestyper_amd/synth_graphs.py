@@ -18,6 +18,7 @@ class Graph:
     def __init__(self):
         self.seq, self.var, self.allele, self.refvars, self.nested, self.disconnected, self.redundant = [], [], [], [], [], [], []
         self.out = []            # adjacency (vertex -> successors)
+        self.edges = []          # (source, target) in insertion order (boost::add_edge order: in_edges() iterates in this order)
         self.num_alleles, self.has_dep = [], []
 
     def new_vertex(self):
@@ -28,6 +29,7 @@ class Graph:
 
     def edge(self, a, b):
         self.out[a].append(b)
+        self.edges.append((a, b))
 
     def init_vertex(self, v, seq, va, refvars, nested, redundant):
         self.seq[v], self.var[v], self.allele[v] = np.asarray(seq, np.uint8), va[0], va[1]
@@ -188,15 +190,24 @@ def random_cluster(rng, k, num_variants, max_paths, chrom_len=None, nested_clust
 class PathsBatch(C.Structure):
     _fields_ = [("num_clusters", C.c_uint32)] + [(n, C.c_void_p) for n in (
         "vertex_off", "num_paths", "seq_off", "seq", "vertex_variant", "vertex_allele", "vertex_flags", "vertex_nested", "refvar_off", "refvar",
-        "path_off", "path_vertices", "var_off", "var_num_alleles", "var_has_dependency")]
+        "path_off", "path_vertices", "var_off", "var_num_alleles", "var_has_dependency", "in_off", "in_src")]
 
 
 def flatten(graphs):
     """list of Graph (with .paths) -> dict of numpy arrays named like bt_paths_batch's fields"""
     f = {"num_clusters": len(graphs)}
     vertex_off, num_paths, seq_off, seqs, vvar, vall, vfl, vnest, roff, rv, poff, pv, voff, vna, vdep = [0], [], [0], [], [], [], [], [], [0], [], [0], [], [0], [], []
+    in_off, in_src = [0], []
     for g in graphs:
         nv = len(g.seq)
+        ins = [[] for _ in range(nv)]
+        for a, b in g.edges:
+            ins[b].append(a)
+        for v in range(nv):
+            in_src.extend(ins[v])
+            in_off.append(len(in_src))
+        if getattr(g, "paths", None) is None:
+            g.paths = np.zeros((0, nv), np.uint8)
         vertex_off.append(vertex_off[-1] + nv)
         num_paths.append(g.paths.shape[0])
         for v in range(nv):
@@ -224,10 +235,12 @@ def flatten(graphs):
     f["refvar_off"] = np.asarray(roff, np.uint32)
     f["refvar"] = np.asarray(rv, np.uint16)
     f["path_off"] = np.asarray(poff, np.uint64)
-    f["path_vertices"] = np.ascontiguousarray(np.concatenate(pv).astype(np.uint8))
+    f["path_vertices"] = np.ascontiguousarray(np.concatenate(pv).astype(np.uint8)) if pv else np.zeros(0, np.uint8)
     f["var_off"] = np.asarray(voff, np.uint32)
     f["var_num_alleles"] = np.asarray(vna, np.uint16)
     f["var_has_dependency"] = np.asarray(vdep, np.uint8)
+    f["in_off"] = np.asarray(in_off, np.uint32)
+    f["in_src"] = np.asarray(in_src, np.uint32)
     return f
 
 

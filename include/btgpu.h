@@ -247,6 +247,9 @@ typedef struct bt_paths_batch {
     const uint32_t *var_off;           /* [C+1] -> per-variant arrays (variant_cluster_info) */
     const uint16_t *var_num_alleles;   /* numberOfAlleles(), incl. the missing allele of variants with has_dependency */
     const uint8_t *var_has_dependency;
+    /* ---- graph edges: only needed by bt_find_paths_* (may be NULL otherwise) ---- */
+    const uint32_t *in_off;            /* [NV+1] in-edges of vertex v -> in_src, in boost::in_edges order (edge insertion order) */
+    const uint32_t *in_src;            /* source vertex, local to the cluster (always < the target's local index) */
 } bt_paths_batch;
 
 typedef struct bt_paths bt_paths;
@@ -304,6 +307,23 @@ typedef struct bt_paths_candidates_sizes {
  * table: computes the bundle on the device + host and reports its sizes; bt_paths_candidates_fetch copies it out. */
 int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes *sizes);
 int bt_paths_candidates_fetch(bt_paths *p, bt_paths_candidates_out *out);
+
+/* ------------------------------------------------------------------------------------------
+ * Best-path search per sample: VariantClusterGraph::{findSamplePaths, mergePaths, isPathsRedundant, filterPaths, addPathIndices}
+ *   (src/bayesTyper/VariantClusterGraph.cpp:389-798) with VariantClusterGraphPath (src/bayesTyper/VariantClusterGraphPath.cpp:38-225),
+ *   driven per sample by KmerCounter::findVariantClusterPaths (src/bayesTyper/KmerCounter.cpp:59-103).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_find_paths bt_find_paths;
+/* state for the clusters of `batch` (num_paths / path_* fields ignored, in_off / in_src required): empty best_paths_indices */
+int bt_find_paths_create(bt_ctx *ctx, const bt_paths_batch *batch, uint32_t k, uint32_t max_sample_haplotypes, uint32_t num_samples, bt_find_paths **out);
+int bt_find_paths_destroy(bt_find_paths *f);
+/* one sample: findSamplePaths of every cluster against the sample's KmerBloom with mt19937(h_seeds[c]) — the reference's seed is
+ * prng_seed + (group_idx + 1) * (sample_idx + 1) + variant_cluster_idx (KmerCounter.cpp:65, VariantClusterGroup.cpp:142) — followed
+ * by addPathIndices into the accumulated best paths */
+int bt_find_paths_sample(bt_find_paths *f, bt_bloom *sample_bloom, const uint32_t *h_seeds);
+/* best_paths_indices so far: h_num_paths[c] rows of |V_c| bytes each, clusters concatenated (bt_paths_batch::path_vertices layout) */
+int bt_find_paths_sizes(bt_find_paths *f, uint32_t *h_num_paths, uint64_t *h_total_bytes);
+int bt_find_paths_fetch(bt_find_paths *f, uint8_t *h_path_vertices);
 
 /* ------------------------------------------------------------------------------------------
  * Count model LUTs: CountDistribution (src/bayesTyper/CountDistribution.cpp:215-265)

@@ -599,6 +599,7 @@ struct OrcGraphs {
     const uint32_t *var_off;
     const uint16_t *var_na;
     const uint8_t *var_dep;
+    const uint32_t *in_off = nullptr, *in_src = nullptr;   // in-edges per vertex (CSR over global vertices, local source indices, insertion order)
 };
 void *orc_graphs_new(unsigned k, uint32_t C, const uint32_t *vertex_off, const uint32_t *num_paths, const uint64_t *seq_off, const uint8_t *seq,
                      const uint16_t *vvar, const uint16_t *vall, const uint8_t *vflags, const uint32_t *vnested, const uint32_t *refvar_off,
@@ -607,6 +608,10 @@ void *orc_graphs_new(unsigned k, uint32_t C, const uint32_t *vertex_off, const u
     return new OrcGraphs{k, C, vertex_off, num_paths, seq_off, seq, vvar, vall, vflags, vnested, refvar_off, refvar, path_off, paths, var_off, var_na, var_dep};
 }
 void orc_graphs_free(void *h) { delete (OrcGraphs *)h; }
+void orc_graphs_set_edges(void *h, const uint32_t *in_off, const uint32_t *in_src) {
+    ((OrcGraphs *)h)->in_off = in_off;
+    ((OrcGraphs *)h)->in_src = in_src;
+}
 
 }  // extern "C" (closed around the template below)
 // walks path `p` of cluster `c` nucleotide by nucleotide like the three reference loops do; f_vertex(v) is called when a path
@@ -856,4 +861,263 @@ void orc_paths_candidates_fetch(void *h, uint32_t *kmer_off, uint8_t *mult, uint
     delete o;
 }
 
+
+}  // extern "C" (closed around the path-search classes)
+// =====================================================================================================================
+// VariantClusterGraph::findSamplePaths (VariantClusterGraph.cpp:389-798) with VariantClusterGraphPath
+// (VariantClusterGraphPath.cpp:38-225): the per-sample best-path search.  Restated object by object.
+// =====================================================================================================================
+namespace {
+constexpr uint8_t MIN_OBSERVED_KMERS = 2;     // VariantClusterGraphPath.cpp:36
+constexpr unsigned MIN_NUM_SAMPLE_PATHS = 1;  // VariantClusterGraph.cpp:60
+
+struct FPVertex {
+    uint32_t index;
+    uint8_t num_observed_kmers;
+};
+struct FPath {
+    std::vector<FPVertex> path;
+    std::string window;   // KmerPair: nucleotides since the last reset, at most k kept
+    uint32_t score_first = 0, score_second = 0;
+};
+struct FindCtx {
+    const OrcGraphs &g;
+    uint32_t c, v0, nv;
+    OrcBloom *bloom;
+    uint32_t len(uint32_t vi) const { return (uint32_t)(g.seq_off[v0 + vi + 1] - g.seq_off[v0 + vi]); }
+    uint8_t nt(uint32_t vi, uint32_t i) const { return g.seq[g.seq_off[v0 + vi] + i] & 3; }
+    bool disconnected(uint32_t vi) const { return g.vflags[v0 + vi] & 1; }
+    bool redundant(uint32_t vi) const { return g.vflags[v0 + vi] & 2; }
+};
+
+void update_score(const FindCtx &x, FPath &p, bool observed, uint32_t cur_sequence_length) {   // VariantClusterGraphPath.cpp:87-129
+    if (observed) {
+        p.score_first++;
+        auto rit = p.path.rbegin();
+        if ((cur_sequence_length > 1) or !x.redundant(rit->index)) {
+            if (rit->num_observed_kmers < MIN_OBSERVED_KMERS) rit->num_observed_kmers++;
+        }
+        rit++;
+        while (rit != p.path.rend()) {
+            if ((x.g.k <= cur_sequence_length) or (rit->num_observed_kmers == MIN_OBSERVED_KMERS)) break;
+            if (rit->num_observed_kmers < MIN_OBSERVED_KMERS) rit->num_observed_kmers++;
+            cur_sequence_length += x.len(rit->index);
+            rit++;
+        }
+    }
+    p.score_second++;
+}
+void add_vertex(const FindCtx &x, FPath &p, uint32_t vi) {   // VariantClusterGraphPath.cpp:46-85
+    static const char ntc[4] = {'A', 'C', 'G', 'T'};
+    p.path.push_back(FPVertex{vi, 0});
+    if (x.disconnected(vi)) {
+        if (x.len(vi) == 0) p.path.back().num_observed_kmers = MIN_OBSERVED_KMERS;
+        p.window.clear();
+    }
+    for (uint32_t i = 0; i < x.len(vi); i++) {
+        p.window.push_back(ntc[x.nt(vi, i)]);
+        if (p.window.size() > x.g.k) p.window.erase(0, 1);
+        if (p.window.size() == x.g.k) {
+            std::string rc(x.g.k, 'A');
+            for (unsigned j = 0; j < x.g.k; j++) rc[j] = comp(p.window[x.g.k - 1 - j]);
+            const std::string &low = (rc < p.window) ? rc : p.window;
+            update_score(x, p, x.bloom->subs[x.bloom->route(low.data())].containsF(low.data()), i + 1);
+        }
+    }
+}
+double kmer_score(const FPath &p) { return p.score_second > 0 ? p.score_first / static_cast<double>(p.score_second) : 1; }   // :136-148
+uint32_t vertex_score(const FindCtx &x, const FPath &p, const std::vector<bool> &covered, bool is_complete) {            // :150-188
+    uint32_t score = 0;
+    for (auto &v : p.path)
+        if ((v.num_observed_kmers == MIN_OBSERVED_KMERS) and !covered.at(v.index)) score++;
+    if (!is_complete) {
+        uint32_t cur = 0;
+        for (auto rit = p.path.rbegin(); rit != p.path.rend(); rit++) {
+            if (((x.g.k - 1) <= cur) or (rit->num_observed_kmers == MIN_OBSERVED_KMERS)) break;
+            if (!covered.at(rit->index)) score++;
+            cur += x.len(rit->index);
+        }
+    }
+    return score;
+}
+void update_covered(const FindCtx &x, const FPath &p, std::vector<bool> &covered, bool is_complete) {   // :190-225
+    for (auto &v : p.path)
+        if (v.num_observed_kmers == MIN_OBSERVED_KMERS) covered.at(v.index) = true;
+    if (!is_complete) {
+        uint32_t cur = 0;
+        for (auto rit = p.path.rbegin(); rit != p.path.rend(); rit++) {
+            if (((x.g.k - 1) <= cur) or (rit->num_observed_kmers == MIN_OBSERVED_KMERS)) break;
+            covered.at(rit->index) = true;
+            cur += x.len(rit->index);
+        }
+    }
+}
+// isPathsRedundant (VariantClusterGraph.cpp:525-626): the two vertex lists spell the same nucleotides and separators, read backwards
+template <typename P1, typename P2>
+bool paths_redundant(const FindCtx &x, const P1 &p1, const P2 &p2) {
+    // positions as (index into the path from the back, nucleotides still unread in that vertex)
+    long i1 = (long)p1.size() - 1, i2 = (long)p2.size() - 1;
+    uint32_t r1 = x.len(p1[i1].index), r2 = x.len(p2[i2].index);
+    bool d1 = false, d2 = false;
+    while (true) {
+        while (r1 == 0) {
+            if (x.disconnected(p1[i1].index)) d1 = true;
+            i1--;
+            if (i1 >= 0) r1 = x.len(p1[i1].index);
+            else break;
+        }
+        while (r2 == 0) {
+            if (x.disconnected(p2[i2].index)) d2 = true;
+            i2--;
+            if (i2 >= 0) r2 = x.len(p2[i2].index);
+            else break;
+        }
+        if (d1 != d2) return false;
+        d1 = false;
+        d2 = false;
+        if ((i1 < 0) or (i2 < 0)) break;
+        if (p1[i1].index == p2[i2].index and r1 == r2) {   // the same position of the same vertex: the rest of this vertex is shared
+            r1 = 0;
+            r2 = 0;
+        }
+        while ((r1 != 0) and (r2 != 0)) {
+            if (x.nt(p1[i1].index, r1 - 1) != x.nt(p2[i2].index, r2 - 1)) return false;
+            r1--;
+            r2--;
+        }
+    }
+    if ((i1 >= 0) or (i2 >= 0)) return false;
+    return true;
+}
+void merge_paths(const FindCtx &x, std::vector<FPath> &main_paths, const std::vector<FPath> &input_paths) {   // :474-523 (copies; the move is an optimisation)
+    const size_t main_size = main_paths.size();
+    for (auto &in : input_paths) {
+        bool is_redundant = false;
+        for (size_t m = 0; m < main_size; m++) {
+            if (paths_redundant(x, main_paths[m].path, in.path)) {
+                if (main_paths[m].path.size() < in.path.size()) main_paths[m] = in;
+                is_redundant = true;
+                break;
+            }
+        }
+        if (!is_redundant) main_paths.push_back(in);
+    }
+}
+bool double_compare(double a, double b) { return ((a == b) or (std::abs(a - b) < std::abs(std::min(a, b)) * std::numeric_limits<double>::epsilon() * 100)); }
+void filter_paths(const FindCtx &x, std::vector<FPath> &paths, uint32_t max_paths, bool is_complete) {   // :628-724
+    if (!((paths.size() > max_paths) or (is_complete and (paths.size() > MIN_NUM_SAMPLE_PATHS)))) return;
+    bool is_first_pass = true;
+    std::vector<bool> covered(x.nv, false);
+    size_t sorted_end = 0;
+    while (sorted_end != paths.size()) {
+        size_t best = sorted_end;
+        double best_kmer = kmer_score(paths[best]);
+        uint32_t best_vertex = vertex_score(x, paths[best], covered, is_complete);
+        for (size_t it = sorted_end + 1; it < paths.size(); it++) {
+            const double cur_kmer = kmer_score(paths[it]);
+            const uint32_t cur_vertex = vertex_score(x, paths[it], covered, is_complete);
+            if (is_first_pass) {
+                if (cur_vertex > 0) {
+                    if ((double_compare(cur_kmer, best_kmer) and (cur_vertex > best_vertex)) or (cur_kmer > best_kmer) or (best_vertex == 0)) {
+                        best = it;
+                        best_kmer = cur_kmer;
+                        best_vertex = cur_vertex;
+                    }
+                }
+            } else if (!is_complete or (cur_vertex == paths[it].path.size())) {
+                if (cur_kmer > best_kmer) {
+                    best = it;
+                    best_kmer = cur_kmer;
+                    best_vertex = cur_vertex;
+                }
+            }
+        }
+        if (is_first_pass) {
+            update_covered(x, paths[best], covered, is_complete);
+        } else if (is_complete and (sorted_end >= MIN_NUM_SAMPLE_PATHS) and (best_vertex < paths[best].path.size())) {
+            break;
+        }
+        if (sorted_end != best) std::swap(paths[sorted_end], paths[best]);
+        if (is_first_pass and (best_vertex == 0)) {
+            is_first_pass = false;
+            std::fill(covered.begin(), covered.end(), false);
+        } else {
+            sorted_end++;
+            if (sorted_end == max_paths) break;
+        }
+    }
+    paths.resize(sorted_end);
+}
+struct OrcFind {
+    std::vector<std::vector<std::vector<uint8_t>>> best;   // per cluster: rows of |V| flags
+};
+}  // namespace
+
+extern "C" {
+void *orc_find_new(void *gh) {
+    OrcFind *f = new OrcFind();
+    f->best.resize(((OrcGraphs *)gh)->C);
+    return f;
+}
+void orc_find_free(void *h) { delete (OrcFind *)h; }
+// one sample: findSamplePaths for every cluster with seeds[c] (= prng_seed + (group_idx+1)*(sample_idx+1) + variant_cluster_idx,
+// KmerCounter.cpp:59-69 + VariantClusterGroup.cpp:138-144), then addPathIndices
+void orc_find_sample_paths(void *fh, void *gh, void *bloom, const uint32_t *seeds, uint32_t max_sample_haplotypes) {
+    OrcFind *F = (OrcFind *)fh;
+    const OrcGraphs &g = *(OrcGraphs *)gh;
+    for (uint32_t c = 0; c < g.C; c++) {
+        FindCtx x{g, c, g.vertex_off[c], g.vertex_off[c + 1] - g.vertex_off[c], (OrcBloom *)bloom};
+        std::mt19937 prng(seeds[c]);
+        std::vector<std::vector<FPath>> vertex_paths(x.nv);
+        for (uint32_t vi = 0; vi < x.nv; vi++) {
+            auto &cur = vertex_paths[vi];
+            const uint32_t e0 = g.in_off[x.v0 + vi], e1 = g.in_off[x.v0 + vi + 1];
+            if (e0 == e1) cur.emplace_back();
+            else
+                for (uint32_t e = e0; e < e1; e++) merge_paths(x, cur, vertex_paths[g.in_src[e]]);
+            std::shuffle(cur.begin(), cur.end(), prng);
+            for (auto &p : cur) add_vertex(x, p, vi);
+            filter_paths(x, cur, max_sample_haplotypes, false);
+        }
+        auto &final_paths = vertex_paths[x.nv - 1];
+        filter_paths(x, final_paths, max_sample_haplotypes, true);
+        // addPathIndices (:726-798)
+        auto &best = F->best[c];
+        std::vector<bool> redundant(final_paths.size(), false);
+        for (auto &row : best) {
+            std::vector<FPVertex> cur_best;
+            for (uint32_t vi = 0; vi < x.nv; vi++)
+                if (row[vi]) cur_best.push_back(FPVertex{vi, 0});
+            for (size_t pi = 0; pi < final_paths.size(); pi++) {
+                if (redundant[pi]) continue;
+                if (paths_redundant(x, cur_best, final_paths[pi].path)) {
+                    if (cur_best.size() < final_paths[pi].path.size()) {
+                        std::fill(row.begin(), row.end(), 0);
+                        for (auto &v : final_paths[pi].path) row[v.index] = 1;
+                    }
+                    redundant[pi] = true;
+                    break;
+                }
+            }
+        }
+        for (size_t pi = 0; pi < final_paths.size(); pi++)
+            if (!redundant[pi]) {
+                std::vector<uint8_t> row(x.nv, 0);
+                for (auto &v : final_paths[pi].path) row[v.index] = 1;
+                best.push_back(row);
+            }
+    }
+}
+void orc_find_sizes(void *fh, uint32_t *num_paths) {
+    OrcFind *F = (OrcFind *)fh;
+    for (size_t c = 0; c < F->best.size(); c++) num_paths[c] = (uint32_t)F->best[c].size();
+}
+void orc_find_fetch(void *fh, uint8_t *out) {
+    OrcFind *F = (OrcFind *)fh;
+    for (auto &b : F->best)
+        for (auto &row : b) {
+            memcpy(out, row.data(), row.size());
+            out += row.size();
+        }
+}
 }  // extern "C"

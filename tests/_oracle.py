@@ -70,6 +70,13 @@ class Oracle:
         L.orc_graphs_new.restype = vp
         L.orc_graphs_new.argtypes = [C.c_uint, C.c_uint32] + [vp] * 15
         L.orc_graphs_free.argtypes = [vp]
+        L.orc_graphs_set_edges.argtypes = [vp, vp, vp]
+        L.orc_find_new.restype = vp
+        L.orc_find_new.argtypes = [vp]
+        L.orc_find_free.argtypes = [vp]
+        L.orc_find_sample_paths.argtypes = [vp, vp, vp, vp, C.c_uint32]
+        L.orc_find_sizes.argtypes = [vp, vp]
+        L.orc_find_fetch.argtypes = [vp, vp]
         L.orc_paths_count_kmers.restype = C.c_uint64
         L.orc_paths_count_kmers.argtypes = [vp, vp]
         L.orc_paths_classify.argtypes = [vp, vp, vp, vp, vp]
@@ -256,8 +263,29 @@ class OrcGraphs:
         from bayestyper_amd import synth_graphs
 
         self.o, self.f, self.k = orc, flat, k
-        self.keep = [np.ascontiguousarray(flat[n]) if np.asarray(flat[n]).size else np.zeros(1, np.asarray(flat[n]).dtype) for n in synth_graphs.FIELDS]
+        names = [n for n in synth_graphs.FIELDS if n not in ("in_off", "in_src")]
+        self.keep = [np.ascontiguousarray(flat[n]) if np.asarray(flat[n]).size else np.zeros(1, np.asarray(flat[n]).dtype) for n in names]
         self.h = orc.l.orc_graphs_new(k, flat["num_clusters"], *[_ptr(a) for a in self.keep])
+        self.edges = [np.ascontiguousarray(flat["in_off"], np.uint32), np.ascontiguousarray(np.concatenate([flat["in_src"], [0]]), np.uint32)]
+        orc.l.orc_graphs_set_edges(self.h, _ptr(self.edges[0]), _ptr(self.edges[1]))
+        self.find = None
+
+    def find_sample_paths(self, bloom, seeds, max_haps):
+        """one sample's findSamplePaths + addPathIndices for every cluster; returns the accumulated best paths (list of (P, |V|) arrays)"""
+        if self.find is None:
+            self.find = self.o.l.orc_find_new(self.h)
+        sd = np.ascontiguousarray(seeds, np.uint32)
+        self.o.l.orc_find_sample_paths(self.find, self.h, bloom.h, _ptr(sd), max_haps)
+        n = np.zeros(self.f["num_clusters"], np.uint32)
+        self.o.l.orc_find_sizes(self.find, _ptr(n))
+        nv = (self.f["vertex_off"][1:] - self.f["vertex_off"][:-1]).astype(np.int64)
+        out = np.zeros(max(int((n.astype(np.int64) * nv).sum()), 1), np.uint8)
+        self.o.l.orc_find_fetch(self.find, _ptr(out))
+        res, at = [], 0
+        for c in range(self.f["num_clusters"]):
+            res.append(out[at:at + int(n[c]) * int(nv[c])].reshape(int(n[c]), int(nv[c])).copy())
+            at += int(n[c]) * int(nv[c])
+        return res
 
     def count_kmers(self, bloom=None):
         return self.o.l.orc_paths_count_kmers(self.h, bloom.h if bloom is not None else None)
@@ -280,6 +308,9 @@ class OrcGraphs:
         return {name: arrs[name][: n[name]] for name, _ in CAND_FIELDS}
 
     def close(self):
+        if self.find:
+            self.o.l.orc_find_free(self.find)
+            self.find = None
         if self.h:
             self.o.l.orc_graphs_free(self.h)
             self.h = None

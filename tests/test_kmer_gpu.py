@@ -498,3 +498,42 @@ def test_path_multigroup_kmers(gpu_ctx, oracle):
         assert np.array_equal(gb.bits(sub), ob.bits(sub))
     for x in (og, gp, ob, gb, ot, gt):
         x.close()
+
+
+@pytest.mark.parametrize("max_haps,fpr", [(32, 1e-6), (3, 0.05), (2, 0.3)])
+def test_find_sample_paths(gpu_ctx, oracle, max_haps, fpr):
+    """findSamplePaths + addPathIndices for two samples: best_paths_indices identical to the oracle, with roomy and with binding
+    max_sample_haplotypes, exact and false-positive-rich sample Bloom filters, nested cuts, multi-allelic variants."""
+    from _oracle import OrcGraphs
+    from bayestyper_amd import lib, synth_graphs
+
+    rng = np.random.default_rng(52)
+    gs = [synth_graphs.random_cluster(rng, K, int(rng.integers(1, 8)), 3, nested_cluster=(700 + i) if i % 3 == 1 else None) for i in range(40)]
+    truth = [g.paths.copy() for g in gs]
+    for g in gs:
+        g.paths = None
+    f = synth_graphs.flatten(gs)
+    og = OrcGraphs(oracle, f, K)
+    gf = lib.FindPaths(gpu_ctx, f, K, max_haps, 2)
+    nt = np.frombuffer(b"ACGT", np.uint8)
+    for s in range(2):
+        # the sample's reads: two haplotypes per cluster (random best-path rows), 10 % of their k-mers unobserved
+        rows = [truth[i][rng.integers(len(truth[i]), size=2)] for i in range(len(gs))]
+        text = np.concatenate([np.concatenate([nt[g.seq[v]] for v in range(len(g.seq)) if rows[i][h, v]] + [np.frombuffer(b"N", np.uint8)])
+                               for i, g in enumerate(gs) for h in range(2)])
+        km, va = oracle.kmers_from_sequence(text.tobytes(), K)
+        mem = np.unique(km[va == 1], axis=0)
+        mem = mem[rng.random(len(mem)) > 0.1]
+        ob = OrcBloom(oracle, len(mem), fpr, K)
+        gb = lib.Bloom.create(gpu_ctx, len(mem), fpr, K, threaded=False)
+        ob.insert(oracle.unpack(mem, K))
+        gb.insert(mem)
+        seeds = (4242 + (np.arange(len(gs)) + 1) * (s + 1) + np.arange(len(gs))).astype(np.uint32)   # prng_seed + (group+1)*(sample+1) + cluster
+        bo = og.find_sample_paths(ob, seeds, max_haps)
+        gf.sample(gb, seeds)
+        bg = gf.best_paths()
+        for c in range(len(gs)):
+            assert bo[c].shape == bg[c].shape and np.array_equal(bo[c], bg[c]), (s, c)
+        ob.close(), gb.close()
+    assert sum(b.shape[0] for b in bo) > len(gs)
+    og.close(), gf.close()

@@ -84,3 +84,49 @@ def test_candidates_invariants(oracle):
     nested = [i for i, g in enumerate(gs) if any(n != synth_graphs.NONE32 for n in g.nested)]
     assert nested and len(res["nestdep_cluster"]) == len(nested) and len(res["hapnest_idx"]) > 0
     og.close(), ot.close(), mg.close()
+
+
+def test_find_sample_paths_recovers_the_sampled_haplotypes(oracle):
+    """findSamplePaths on a sample whose reads come from two known haplotypes (source-to-sink walks): with an (almost) exact
+    sample Bloom the two haplotypes are among the best paths, every best path is a source-to-sink walk, and a second sample
+    only adds paths that are not redundant with the existing ones."""
+    rng = np.random.default_rng(12)
+    gs = [synth_graphs.random_cluster(rng, K, int(rng.integers(1, 6)), 2, nested_cluster=(300 + i) if i % 4 == 3 else None) for i in range(12)]
+    truth = [g.paths.copy() for g in gs]
+    for g in gs:
+        g.paths = None
+    f = synth_graphs.flatten(gs)
+    og = OrcGraphs(oracle, f, K)
+    nt = np.frombuffer(b"ACGT", np.uint8)
+
+    def sample_bloom(which):
+        text = np.concatenate([np.concatenate([nt[g.seq[v]] for v in range(len(g.seq)) if truth[i][which[i] % len(truth[i]), v]] + [np.frombuffer(b"N", np.uint8)])
+                               for i, g in enumerate(gs)])
+        km, va = oracle.kmers_from_sequence(text.tobytes(), K)
+        mem = np.unique(km[va == 1], axis=0)
+        b = OrcBloom(oracle, 200_000, 1e-6, K)
+        b.insert(oracle.unpack(mem, K))
+        return b
+
+    both = [sample_bloom([0] * len(gs)), sample_bloom([1] * len(gs))]
+    union = OrcBloom(oracle, 200_000, 1e-6, K)
+    for which in ([0] * len(gs), [1] * len(gs)):
+        text = np.concatenate([np.concatenate([nt[g.seq[v]] for v in range(len(g.seq)) if truth[i][which[i] % len(truth[i]), v]] + [np.frombuffer(b"N", np.uint8)])
+                               for i, g in enumerate(gs)])
+        km, va = oracle.kmers_from_sequence(text.tobytes(), K)
+        union.insert(oracle.unpack(np.unique(km[va == 1], axis=0), K))
+    seeds = 1000 + np.arange(len(gs), dtype=np.uint32)
+    best = og.find_sample_paths(union, seeds, 32)
+    for i, g in enumerate(gs):
+        assert 1 <= best[i].shape[0] <= 32
+        rows = {r.tobytes() for r in best[i]}
+        # every best path is a walk: starts at vertex 0, ends at the sink, consecutive vertices are joined by an edge
+        for r in best[i]:
+            vs = np.nonzero(r)[0]
+            assert vs[0] == 0 and vs[-1] == len(g.seq) - 1 and all(b in g.out[a] for a, b in zip(vs[:-1], vs[1:]))
+        # the sampled haplotypes are found unless they spell the same sequence as another walk (then one representative is kept)
+        assert sum(t.tobytes() in rows for t in truth[i]) >= 1
+    n1 = [b.shape[0] for b in best]
+    best2 = og.find_sample_paths(both[0], seeds + 7, 32)     # second sample (one haplotype only): adds nothing new or few
+    assert all(b2.shape[0] >= a for b2, a in zip(best2, n1))
+    og.close()
