@@ -4,6 +4,7 @@
 
 #include "CountDistribution.hpp"
 #include "Genotypes.hpp"
+#include "VariantClusterGraph.hpp"
 
 using namespace bthost;
 
@@ -94,6 +95,69 @@ int bth_cluster_genotypes(unsigned S, unsigned H, unsigned V, const uint16_t *ha
         return 0;
     } catch (...) {
         return 1;
+    }
+}
+
+
+// One cluster's graph from flat variant arrays (tests: cross-check against the Python restatement in synth_graphs.py).
+//   variants: var_pos[nvar], var_nalt[nvar], var_redundant[nvar], var_dep[nvar]; alternative alleles concatenated: alt_ref_len[], alt_off[] (+1), alt_seq (ASCII)
+//   contained clusters: cont_lf[], cont_rf[], cont_idx[]
+void *bth_graph_build(unsigned k, const char *chrom, unsigned long long chrom_len, unsigned nvar, const uint32_t *var_pos, const uint32_t *var_nalt,
+                      const uint32_t *var_redundant, const uint8_t *var_dep, const uint32_t *alt_ref_len, const uint32_t *alt_off, const char *alt_seq, unsigned ncont,
+                      const uint32_t *cont_lf, const uint32_t *cont_rf, const uint32_t *cont_idx) {
+    try {
+        VariantCluster vc;
+        unsigned a = 0;
+        for (unsigned v = 0; v < nvar; v++) {
+            Variant var;
+            var.has_dependency = var_dep[v] != 0;
+            var.num_redundant_nucleotides = var_redundant[v];
+            for (unsigned i = 0; i < var_nalt[v]; i++, a++) var.alt_alleles.push_back(AlleleInfo{alt_ref_len[a], std::string(alt_seq + alt_off[a], alt_seq + alt_off[a + 1])});
+            vc.variants.emplace(var_pos[v], var);
+        }
+        for (unsigned i = 0; i < ncont; i++) vc.contained_clusters.push_back(ContainedCluster{cont_idx[i], cont_lf[i], cont_rf[i]});
+        return new VariantClusterGraph(vc, std::string(chrom, chrom + chrom_len), k);
+    } catch (...) {
+        return nullptr;
+    }
+}
+void bth_graph_free(void *h) { delete (VariantClusterGraph *)h; }
+// sizes: vertices, edges, total nucleotides, total reference_variant_indices
+void bth_graph_sizes(void *h, uint64_t *sizes) {
+    auto *g = (VariantClusterGraph *)h;
+    sizes[0] = g->vertices.size();
+    sizes[1] = g->edges.size();
+    sizes[2] = sizes[3] = 0;
+    for (auto &v : g->vertices) {
+        sizes[2] += v.sequence.size();
+        sizes[3] += v.reference_variant_indices.size();
+    }
+}
+void bth_graph_fetch(void *h, uint64_t *seq_off, uint8_t *seq, uint16_t *vvar, uint16_t *vall, uint8_t *vflags, uint32_t *vnested, uint32_t *refvar_off, uint16_t *refvar,
+                     uint32_t *edges, uint16_t *var_num_alleles, uint8_t *var_dep) {
+    auto *g = (VariantClusterGraph *)h;
+    uint64_t so = 0;
+    uint32_t ro = 0;
+    seq_off[0] = 0;
+    refvar_off[0] = 0;
+    for (size_t v = 0; v < g->vertices.size(); v++) {
+        auto &x = g->vertices[v];
+        for (uint8_t c : x.sequence) seq[so++] = c;
+        seq_off[v + 1] = so;
+        vvar[v] = x.variant;
+        vall[v] = x.allele;
+        vflags[v] = (uint8_t)((x.is_disconnected ? 1 : 0) | (x.is_first_nucleotides_redundant ? 2 : 0));
+        vnested[v] = x.nested_variant_cluster_index;
+        for (uint16_t r : x.reference_variant_indices) refvar[ro++] = r;
+        refvar_off[v + 1] = ro;
+    }
+    for (size_t e = 0; e < g->edges.size(); e++) {
+        edges[2 * e] = g->edges[e].first;
+        edges[2 * e + 1] = g->edges[e].second;
+    }
+    for (size_t v = 0; v < g->var_num_alleles.size(); v++) {
+        var_num_alleles[v] = g->var_num_alleles[v];
+        var_dep[v] = g->var_has_dependency[v];
     }
 }
 

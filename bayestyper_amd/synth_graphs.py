@@ -175,6 +175,7 @@ def random_cluster(rng, k, num_variants, max_paths, chrom_len=None, nested_clust
         pos += max_ref + gap
     assert pos + k < chrom_len
     g = build_graph(chrom, variants, k, contained)
+    g.chrom, g.variants, g.contained = chrom, variants, list(contained)   # kept for cross-checks against the C++ host constructor
     if contained:
         # the variants whose reference allele spans the cut get a missing allele (has_dependency), as VariantFileParser marks them
         for v in range(len(g.seq)):

@@ -1,0 +1,75 @@
+"""bthost::VariantClusterGraph (C++ host layer: VariantClusterGraph::VariantClusterGraph / addVertices / initVertex) against the Python
+restatement used to generate test graphs, plus the N-run splitting the Python side does not implement."""
+import ctypes as C
+
+import numpy as np
+
+from bayestyper_amd import synth_graphs
+from bayestyper_amd.host import dll
+
+K = 55
+NT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def _build(chrom_ascii, variants, contained):
+    dll.bth_graph_build.restype = C.c_void_p
+    dll.bth_graph_build.argtypes = [C.c_uint, C.c_char_p, C.c_ulonglong, C.c_uint] + [C.c_void_p] * 6 + [C.c_char_p, C.c_uint] + [C.c_void_p] * 3
+    dll.bth_graph_free.argtypes = [C.c_void_p]
+    dll.bth_graph_sizes.argtypes = [C.c_void_p, C.c_void_p]
+    dll.bth_graph_fetch.argtypes = [C.c_void_p] * 12
+    pos = np.array([v["pos"] for v in variants], np.uint32)
+    nalt = np.array([len(v["alts"]) for v in variants], np.uint32)
+    red = np.array([v.get("num_redundant", 0) for v in variants], np.uint32)
+    dep = np.array([1 if v.get("has_dependency") else 0 for v in variants], np.uint8)
+    ref_len = np.array([a[0] for v in variants for a in v["alts"]], np.uint32)
+    seqs = [NT[np.asarray(a[1], np.uint8)].tobytes() for v in variants for a in v["alts"]]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.uint32)
+    cl = np.array([c[0] for c in contained] + [0], np.uint32)
+    cr = np.array([c[1] for c in contained] + [0], np.uint32)
+    ci = np.array([c[2] for c in contained] + [0], np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    h = dll.bth_graph_build(K, chrom_ascii, len(chrom_ascii), len(variants), p(pos), p(nalt), p(red), p(dep), p(ref_len), p(off), b"".join(seqs), len(contained), p(cl), p(cr), p(ci))
+    assert h, "bth_graph_build failed"
+    sizes = np.zeros(4, np.uint64)
+    dll.bth_graph_sizes(h, p(sizes))
+    nv, ne, nnt, nref = [int(x) for x in sizes]
+    out = {"seq_off": np.zeros(nv + 1, np.uint64), "seq": np.zeros(max(nnt, 1), np.uint8), "var": np.zeros(nv, np.uint16), "allele": np.zeros(nv, np.uint16),
+           "flags": np.zeros(nv, np.uint8), "nested": np.zeros(nv, np.uint32), "refvar_off": np.zeros(nv + 1, np.uint32), "refvar": np.zeros(max(nref, 1), np.uint16),
+           "edges": np.zeros(max(2 * ne, 1), np.uint32), "num_alleles": np.zeros(len(variants), np.uint16), "dep": np.zeros(len(variants), np.uint8)}
+    dll.bth_graph_fetch(h, *[p(out[k]) for k in ("seq_off", "seq", "var", "allele", "flags", "nested", "refvar_off", "refvar", "edges", "num_alleles", "dep")])
+    dll.bth_graph_free(h)
+    out["seq"], out["refvar"], out["edges"] = out["seq"][:nnt], out["refvar"][:nref], out["edges"][: 2 * ne].reshape(-1, 2)
+    return out
+
+
+def test_cpp_graph_equals_python_restatement():
+    rng = np.random.default_rng(3)
+    for i in range(60):
+        g = synth_graphs.random_cluster(rng, K, int(rng.integers(1, 9)), 2, nested_cluster=(900 + i) if i % 3 else None)
+        out = _build(NT[g.chrom].tobytes(), g.variants, g.contained)
+        nv = len(g.seq)
+        assert len(out["var"]) == nv
+        assert np.array_equal(out["seq"], np.concatenate(g.seq)) and np.array_equal(out["seq_off"], np.concatenate([[0], np.cumsum([len(x) for x in g.seq])]))
+        assert np.array_equal(out["var"], np.array(g.var, np.uint16)) and np.array_equal(out["allele"], np.array(g.allele, np.uint16))
+        assert np.array_equal(out["flags"], np.array([(1 if g.disconnected[v] else 0) | (2 if g.redundant[v] else 0) for v in range(nv)], np.uint8))
+        assert np.array_equal(out["nested"], np.array(g.nested, np.uint32))
+        assert [list(out["refvar"][out["refvar_off"][v]:out["refvar_off"][v + 1]]) for v in range(nv)] == [list(r) for r in g.refvars]
+        assert [tuple(e) for e in out["edges"]] == g.edges
+        # numberOfAlleles before the generator's has_dependency post-processing: 1 + alts (+1 when the VCF parser marked a dependency)
+        assert np.array_equal(out["num_alleles"], np.array([1 + len(v["alts"]) for v in g.variants], np.uint16))
+
+
+def test_n_runs_split_vertices():
+    rng = np.random.default_rng(5)
+    g = synth_graphs.random_cluster(rng, K, 3, 2, kinds=("snv",))
+    base = _build(NT[g.chrom].tobytes(), g.variants, [])
+    chrom = NT[g.chrom].copy()
+    a = g.variants[0]["pos"] + 5                    # inside the reference stretch after the first SNV (gap permitting) or later flank
+    last = g.variants[-1]["pos"] + 10               # inside the right flank
+    chrom[last:last + 3] = ord("N")
+    out = _build(chrom.tobytes(), g.variants, [])
+    assert len(out["var"]) == len(base["var"]) + 1 and len(out["seq"]) == len(base["seq"]) - 3
+    split = int(np.nonzero(out["flags"] & 1)[0][0])
+    assert out["flags"][split] == 1 and out["nested"][split] == 0xFFFFFFFF and (out["var"][split], out["allele"][split]) == (out["var"][split - 1], out["allele"][split - 1])
+    assert [tuple(e) for e in out["edges"]][-1] == (split - 1, split)
+    del a
