@@ -61,7 +61,7 @@ __device__ __noinline__ void group_init_chain(Env env, uint32_t chain, uint32_t 
 
 // VariantClusterGenotyper::updateNestedVariantClusterInfo (VariantClusterGenotyper.cpp:140-206): child's info := parent's info, updated
 __device__ __noinline__ void prepare_nested(Env env, uint32_t v_parent, uint32_t v_child) {
-    env.resident = 0xFFFFFFFFu;   // between visits every vertex's hot arrays are in HBM
+    if (env.resident != RESIDENT_ALL) env.resident = 0xFFFFFFFFu;   // swap mode: between visits every vertex's hot arrays are in HBM
     const Tile t = make_tile(env);
     const GParams BT_CAS &P = env_params(env);
     const Vx c = make_vx(t, v_parent), cc = make_vx(t, v_child);
@@ -208,11 +208,12 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
     if (!gd[3]) return;   // padding lane of the last tile
     const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
     // groups of ONE cluster keep that cluster's hot arrays in LDS for the whole launch; larger groups swap per vertex visit
-    const bool whole = t.d->nvm == 1 && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN);
+    // (and so do multi-cluster groups of narrow tiles, whose LDS rows are interleaved over fewer lanes: TileDesc::lds_all)
+    const bool whole = (t.d->nvm == 1 || t.d->lds_all) && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN);
     if (whole) {
-        hot_swap(env, 0, true);
-        env.resident = 0;
-        t.resident = 0;
+        env.resident = RESIDENT_ALL;
+        for (uint32_t v = 0; v < nvert; ++v) hot_swap(env, v, true);
+        t.resident = RESIDENT_ALL;
         t.hot = lds_block();
     }
     if (op == OP_RUN) {
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
             for (uint32_t i = 0, n = vx_ne(c); i < n; ++i) e1[i] = e0[i];
         }
     }
-    if (whole) hot_swap(env, 0, false);
+    if (whole)
+        for (uint32_t v = 0; v < nvert; ++v) hot_swap(env, v, false);
 }
 
 // per (cluster, sample): most frequently sampled diplotype and its frequency -> the compact posterior summary that is
@@ -385,6 +387,8 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
 }
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+// dynamic LDS a workgroup of this tile needs: one block per vertex when all vertices are resident
+inline uint32_t tile_lds_bytes(const TileDesc &d) { return d.lds_all ? d.hot_bytes * d.nvm : d.hot_bytes; }
 #ifndef BT_HOT_BUDGET
 #define BT_HOT_BUDGET 155648
 #endif
@@ -660,22 +664,28 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
             const int hot_arrs[] = {A_SC, A_DIP, A_NESTPL, A_NESTN, A_KSCUPD, A_MGEN, A_PEND, A_PENDDIP, A_PENDVALID, A_FREQ, A_LOGF, A_OBS, A_NZ, A_NZLIST,
                                     A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_KSCTMP, A_CUM};
-            uint32_t ho = 0;
+            // LDS rows are interleaved over the tile's lanes only (16 / 32 / 64): a narrow tile needs a fraction of the LDS per vertex,
+            // which lets every vertex of a multi-cluster group stay resident instead of being swapped around each visit
+            d.lds_stride = 16;
+            while (d.lds_stride < d.num_lanes) d.lds_stride *= 2;
+            uint64_t ho = 0;
             for (int a : hot_arrs) {
                 if (a == A_CUM && d.D2m > 16) continue;
                 const uint64_t per_vertex = len[a] / nv;   // elements per lane and vertex
-                d.hoff[a] = ho;
-                ho = (uint32_t)align_up(ho + per_vertex * LANES * kElemSize[a], 16);
+                d.hoff[a] = (uint32_t)ho;
+                ho = align_up(ho + per_vertex * d.lds_stride * kElemSize[a], 16);
             }
-            d.hot_bytes = ho;
+            d.hot_bytes = (uint32_t)std::min<uint64_t>(ho, 0xFFFFFFFFu);
+            d.lds_all = d.nvm > 1 && ho * d.nvm <= kHotBudget && !getenv("BT_GIBBS_NO_LDS_ALL") ? 1u : 0u;
             if (ho > kHotBudget || (d.nvm > 1 && getenv("BT_GIBBS_NOHOT_MULTI"))) {
                 for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
                 d.hot_bytes = 0;
+                d.lds_all = 0;
             }
         }
         // Wavefronts per tile (measured on MI355X, 64-group tiles): two-haplotype clusters run best on one full wavefront;
         // tiles whose lanes diverge over tens of diplotype candidates gain 15-25 % from narrower wavefronts.
-        d.split = d.Hm < 6 ? 1u : (d.hot_bytes > kLightLds ? 2u : 4u);
+        d.split = d.Hm < 6 ? 1u : (tile_lds_bytes(d) > kLightLds ? 2u : 4u);
         if (const char *e = getenv("BT_GIBBS_SPLIT")) {   // tuning override
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8) d.split = (uint32_t)v;
@@ -810,7 +820,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         BT_TRYHIP(hipStreamSynchronize(ctx->stream));
     }
     for (uint32_t ti = 0; ti < ntiles; ++ti) {
-        const uint32_t hb = g->tiles[ti].hot_bytes;
+        const uint32_t hb = tile_lds_bytes(g->tiles[ti]);
         if (hb > kLightLds) {
             g->heavy_tiles.push_back(ti);
             g->lds_heavy = std::max(g->lds_heavy, hb);

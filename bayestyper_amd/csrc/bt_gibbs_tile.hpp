@@ -124,9 +124,11 @@ struct TileDesc {
     uint64_t trace_base;      // word offset of this tile's trace block ([sweep][vertex][S][64])
     uint64_t off[A_COUNT];    // byte offsets of the arrays from the tile base
     uint32_t hoff[A_COUNT];   // byte offset inside the wavefront's LDS block of the arrays kept resident there (NOHOT otherwise)
-    uint32_t hot_bytes, split;   // split: wavefronts working on this tile (1, 2, 4 or 8), see tile_lane()
+    uint32_t hot_bytes, split;   // hot_bytes: LDS bytes of ONE vertex's hot arrays; split: wavefronts working on this tile (1, 2, 4 or 8), see tile_lane()
+    uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (16/32/64); lds_all: every vertex has its own LDS block (no swaps)
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
+constexpr uint32_t RESIDENT_ALL = 0xFFFFFFFEu;   // Env/Tile::resident: every vertex of the group has its hot arrays in LDS
 
 struct GParams {
     uint32_t S, seed, num_chains, burn_in, num_iterations, max_hvk, noise_seeding;
@@ -149,7 +151,8 @@ struct Tile {
     template <typename T>
     __device__ inline SPtrF<T, LANES> harr(int a, uint32_t v, uint32_t len) const {
         const uint32_t ho = d->hoff[a];
-        if (hot != nullptr && ho != NOHOT && v == resident) return SPtrF<T, LANES>{(T *)(hot + ho), lane};
+        if (hot != nullptr && ho != NOHOT && (resident == RESIDENT_ALL || v == resident))
+            return SPtrF<T, LANES>{(T *)(hot + (resident == RESIDENT_ALL ? v * d->hot_bytes : 0u) + ho), lane, d->lds_stride};
         return SPtrF<T, LANES>{(T *)(uint8_t *)(base + d->off[a]), v * len * LANES + lane};
     }
     template <typename T>
@@ -295,10 +298,11 @@ __device__ inline uint32_t vx_ne(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS
 
 // ---- LDS residency of a vertex's hot arrays ----------------------------------------------------------------------
 template <typename T>
-__device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len, bool to_lds, uint32_t live = 0xFFFFFFFFu) {
+__device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len, bool to_lds, uint32_t lds_vertex_off, uint32_t live = 0xFFFFFFFFu) {
     const uint32_t ho = t.d->hoff[arr];
     if (ho == NOHOT) return;
-    T BT_LAS *l = (T BT_LAS *)(bt_lds_raw + ho) + t.lane;   // explicit LDS pointer: the copies of different arrays can overlap (no aliasing with HBM)
+    const uint32_t LS = t.d->lds_stride;
+    T BT_LAS *l = (T BT_LAS *)(bt_lds_raw + lds_vertex_off + ho) + t.lane;   // explicit LDS pointer: the copies of different arrays can overlap (no aliasing with HBM)
     T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + v * len * LANES + t.lane;
     // eight elements in flight per step (the copy is latency-bound: one wavefront, one memory round trip per step)
     uint32_t i = 0;
@@ -310,46 +314,53 @@ __device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len
 #pragma unroll
             for (int q = 0; q < U; ++q) tmp[q] = g[(i + q) * LANES];
 #pragma unroll
-            for (int q = 0; q < U; ++q) l[(i + q) * LANES] = tmp[q];
+            for (int q = 0; q < U; ++q) l[(i + q) * LS] = tmp[q];
         }
-        for (; i < len; ++i) l[i * LANES] = g[i * LANES];
+        for (; i < len; ++i) l[i * LS] = g[i * LANES];
     } else {
         for (; i + U <= len; i += U) {
             T tmp[U];
 #pragma unroll
-            for (int q = 0; q < U; ++q) tmp[q] = l[(i + q) * LANES];
+            for (int q = 0; q < U; ++q) tmp[q] = l[(i + q) * LS];
 #pragma unroll
             for (int q = 0; q < U; ++q) g[(i + q) * LANES] = tmp[q];
         }
-        for (; i < len; ++i) g[i * LANES] = l[i * LANES];
+        for (; i < len; ++i) g[i * LANES] = l[i * LS];
     }
+}
+__device__ inline uint32_t uniform_tile_hot_bytes(const Env &e) {
+    const TileDesc *tiles = uniform_ptr(e.tiles);
+    const uint32_t *list = uniform_ptr(e.tile_list);
+    const uint32_t tile = list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x;
+    return ((const TileDesc BT_CAS *)&tiles[tile])->hot_bytes;
 }
 // move every hot array of vertex v between HBM and the wavefront's LDS block (lane-wise, coalesced)
 __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
+    const uint32_t voff = env.resident == RESIDENT_ALL ? v * uniform_tile_hot_bytes(env) : 0u;
     env.resident = 0xFFFFFFFFu;
     const Tile t = make_tile(env);
     const TileDesc BT_CAS &d = *t.d;
     if (!d.hot_bytes) return;
-    hot_copy<uint32_t>(t, A_SC, v, SC_COUNT, to_lds);
-    hot_copy<uint16_t>(t, A_DIP, v, 2 * d.S, to_lds);
-    hot_copy<uint8_t>(t, A_NESTPL, v, d.S, to_lds);
-    hot_copy<uint8_t>(t, A_NESTN, v, d.S, to_lds);
-    hot_copy<uint8_t>(t, A_KSCUPD, v, d.S, to_lds);
-    hot_copy<uint32_t>(t, A_MGEN, v, d.S, to_lds);
-    hot_copy<uint32_t>(t, A_PEND, v, d.S, to_lds);
-    hot_copy<uint16_t>(t, A_PENDDIP, v, 2 * d.S, to_lds);
-    hot_copy<uint8_t>(t, A_PENDVALID, v, d.S, to_lds);
+    hot_copy<uint32_t>(t, A_SC, v, SC_COUNT, to_lds, voff);
+    hot_copy<uint16_t>(t, A_DIP, v, 2 * d.S, to_lds, voff);
+    hot_copy<uint8_t>(t, A_NESTPL, v, d.S, to_lds, voff);
+    hot_copy<uint8_t>(t, A_NESTN, v, d.S, to_lds, voff);
+    hot_copy<uint8_t>(t, A_KSCUPD, v, d.S, to_lds, voff);
+    hot_copy<uint32_t>(t, A_MGEN, v, d.S, to_lds, voff);
+    hot_copy<uint32_t>(t, A_PEND, v, d.S, to_lds, voff);
+    hot_copy<uint16_t>(t, A_PENDDIP, v, 2 * d.S, to_lds, voff);
+    hot_copy<uint8_t>(t, A_PENDVALID, v, d.S, to_lds, voff);
     // per-haplotype arrays: only this lane's H entries are live (rows are Hm apart; the tail is never read)
     const uint32_t H = t.arr<uint32_t>(A_VDIMS, v * 8)[0];
-    hot_copy<double>(t, A_FREQ, v, d.Hm, to_lds, H);
-    hot_copy<double>(t, A_LOGF, v, d.Hm, to_lds, H);
-    hot_copy<uint32_t>(t, A_OBS, v, d.Hm, to_lds, H);
-    hot_copy<uint8_t>(t, A_NZ, v, d.Hm, to_lds, H);
-    hot_copy<uint32_t>(t, A_UNEXT, v, d.Hm, to_lds, H);
-    hot_copy<uint32_t>(t, A_ZHDR, v, 4, to_lds);
-    hot_copy<uint32_t>(t, A_ZBKT, v, d.Bcap, to_lds);
-    hot_copy<uint32_t>(t, A_PHDR, v, 4, to_lds);
-    hot_copy<uint32_t>(t, A_PBKT, v, d.Bcap, to_lds);
+    hot_copy<double>(t, A_FREQ, v, d.Hm, to_lds, voff, H);
+    hot_copy<double>(t, A_LOGF, v, d.Hm, to_lds, voff, H);
+    hot_copy<uint32_t>(t, A_OBS, v, d.Hm, to_lds, voff, H);
+    hot_copy<uint8_t>(t, A_NZ, v, d.Hm, to_lds, voff, H);
+    hot_copy<uint32_t>(t, A_UNEXT, v, d.Hm, to_lds, voff, H);
+    hot_copy<uint32_t>(t, A_ZHDR, v, 4, to_lds, voff);
+    hot_copy<uint32_t>(t, A_ZBKT, v, d.Bcap, to_lds, voff);
+    hot_copy<uint32_t>(t, A_PHDR, v, 4, to_lds, voff);
+    hot_copy<uint32_t>(t, A_PBKT, v, d.Bcap, to_lds, voff);
     // A_NZLIST and A_CUM are per-call scratch: resident in LDS but never copied
 }
 

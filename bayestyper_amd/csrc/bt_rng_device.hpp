@@ -66,8 +66,9 @@ template <typename T, unsigned STRIDE>
 struct SPtrF {
     T *base;
     uint32_t off;
-    BT_HD T &operator[](uint32_t i) const { return base[off + i * STRIDE]; }
-    BT_HD SPtrF<T, STRIDE> operator+(uint32_t i) const { return SPtrF<T, STRIDE>{base, off + i * STRIDE}; }
+    uint32_t stride = STRIDE;   // run-time: LDS-resident arrays of narrow tiles are interleaved over fewer lanes than the HBM layout
+    BT_HD T &operator[](uint32_t i) const { return base[off + i * stride]; }
+    BT_HD SPtrF<T, STRIDE> operator+(uint32_t i) const { return SPtrF<T, STRIDE>{base, off + i * stride, stride}; }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 // tell the compiler that a pointer handed through a non-inlined call is wave-uniform (it then lives in scalar registers and
