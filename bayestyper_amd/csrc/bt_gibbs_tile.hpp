@@ -695,7 +695,19 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
             }
             so[i + 1] = ne;
             const bool hc = c.has_counts(k) != 0;
-            for (uint32_t h = 0; h < c.H; ++h) sm[i * Hm + h] = c.M(k, h);
+            {
+                // row copy, eight multiplicities in flight (loads and stores may alias as far as the compiler knows)
+                SPtr<uint8_t, LANES> Mrow = c.a<uint8_t>(A_M, (uint32_t)c.d().Km * Hm) + k * Hm;
+                uint32_t h = 0;
+                for (; h + 8 <= c.H; h += 8) {
+                    uint8_t t8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t8[q] = Mrow[h + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sm[i * Hm + h + q] = t8[q];
+                }
+                for (; h < c.H; ++h) sm[i * Hm + h] = Mrow[h];
+            }
             for (uint32_t ss = 0; ss < P.S; ++ss) scn[i * P.S + ss] = hc ? c.count(k, ss) : (uint8_t)0;
             sic[2 * i] = hc ? c.ic(k, 0) : (uint8_t)0;
             sic[2 * i + 1] = hc ? c.ic(k, 1) : (uint8_t)0;
