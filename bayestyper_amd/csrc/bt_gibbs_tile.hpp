@@ -905,28 +905,8 @@ __device__ inline void multi_refresh(const Vx &c, const GParams BT_CAS &P, uint3
     }
     if (moved) c.mgen()[s] += 1;
 }
-// For one candidate: sum over the multicluster subset k-mers of log P(count | oth + M[h1] + M[h2] + intercluster) — the value of
-// getMulticlusterKmerMultiplicity for the candidate (VariantClusterHaplotypes.cpp:82-108) is exactly oth + own + intercluster,
-// in uchar arithmetic, with oth as refreshed by multi_refresh for the current generation.
-__device__ inline double multi_log_prob(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t nsub_m, uint32_t gen) {
-    const TileDesc BT_CAS &d = c.d();
-    const uint32_t idx = dip_index(c, h1, h2);
-    const uint32_t key = s * d.Dcm + idx + 1u;
-    const uint32_t slot = d.cache_mode == 0 ? s * d.Dcm + idx : ((key * 2654435761u) & (d.cache_entries - 1u));
-    if (c.mctag()[slot] == key && c.mcgen()[slot] == gen) return c.mcache()[slot];
-    double acc = 0;
-    SPtr<uint8_t, LANES> oth = c.oth(), mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
-    const uint32_t Hm = d.Hm;
-    const uint8_t gender = P.gender[s];
-    for (uint32_t i = 0; i < nsub_m; ++i) {
-        const uint8_t m = (uint8_t)((uint8_t)(oth[i * P.S + s] + msub_dip_mult(mm, Hm, i, h1, h2)) + mic[2 * i + gender]);
-        acc += count_log_prob(P, s, m, mcn[i * P.S + s]);
-    }
-    c.mctag()[slot] = key;
-    c.mcgen()[slot] = gen;
-    c.mcache()[slot] = acc;
-    return acc;
-}
+// For a candidate the k-mer multiplicity getMulticlusterKmerMultiplicity returns (VariantClusterHaplotypes.cpp:82-108) is exactly
+// oth + M[h1] + M[h2] + intercluster in uchar arithmetic, with oth as refreshed by multi_refresh for the current generation.
 // The misses of a block of 8 candidates, evaluated together: per subset k-mer the shared operands (oth, intercluster, count) are
 // read once and the candidates' multiplicity rows and table lookups are independent loads.  Sums stay in subset order.
 __device__ inline void multi_log_prob_block(const Vx &c, const GParams BT_CAS &P, uint32_t s, const uint16_t (&ha)[8], const uint16_t (&hb)[8], const bool (&need)[8],

@@ -259,3 +259,29 @@ def test_genotype_posteriors_gpp_gq_calls(gpu_ctx, oracle):
             assert np.allclose(a["acp"], b["acp"], atol=TOL) and np.allclose(a["alt_freq"], b["alt_freq"], atol=TOL)
             calls += int((a["estimate"][:, :, 0] != 0xFFFF).sum())
     assert calls > 50
+
+
+def test_scale_properties_of_a_mixture_batch(gpu_ctx):
+    """Size-independent properties at a batch size the scalar oracle would need minutes for (20 000 groups of the bench's shape
+    mixture, full 20 x 350 schedule): every (cluster, sample) collects exactly chains x samples draws, a second run of the same batch
+    reproduces every frequency (the launch is deterministic), and the device-side posterior summary agrees with its host definition."""
+    from bayestyper_amd import lib, shard, synth
+    from bayestyper_amd.host import count_model
+
+    S = 1
+    flat = synth.make_mixture(20_000, S, seed=77)
+    lut_g, lut_n = count_model.build_luts(S, mean=15.0, var=30.0, noise_rate=0.05)
+    runs = []
+    for _ in range(2):
+        g = lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, seed=42)
+        g.run()
+        runs.append((g.results(), g.posterior_summary()))
+        g.close()
+    (r0, s0), (r1, s1) = runs
+    for k in ("dip_off", "h1", "h2", "freq"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.array_equal(r0["stats"], r1["stats"]) and np.array_equal(s0, s1)
+    total = np.add.reduceat(r0["freq"][:, 0].astype(np.int64), r0["dip_off"][:-1].astype(np.int64))
+    assert (total == 20 * 250).all()                                   # Null-ploidy samples would still record (none, none)
+    assert np.array_equal(s0, shard.summary_from_results(r0, flat["num_clusters"], S))
+    assert (s0[:, :, 1] > 0).all() and (s0[:, :, 1] <= 20 * 250).all()
