@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--hit-rate", type=float, default=0.02)
     ap.add_argument("--cpu-groups-per-core", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-paths", action="store_true", help="skip the graph-stage throughput figures")
+    ap.add_argument("--path-clusters", type=int, default=50_000)
     return ap.parse_args()
 
 
@@ -201,6 +203,44 @@ def main():
                          f"{cpu_s:.1f} s on {cores} threads (oracle/oracle_gibbs.cpp, one group per thread at a time)",
                "kmer_matches_per_sec_1core": kcpu}
 
+    # ------------------------------------------------------------------ graph stages (rank 0, outside the timed region): best-path search,
+    # path k-mer enumeration, classification, haplotype candidates on synthetic SNV/indel clusters — reported beside the headline metric
+    paths = None
+    if rank == 0 and not args.no_paths:
+        from bayestyper_amd import synth_graphs
+
+        prng = np.random.default_rng(11)
+        n_cl = args.path_clusters
+        gs = [synth_graphs.random_cluster(prng, K, int(prng.integers(1, 4)), int(prng.integers(2, 5)), kinds=("snv", "snv", "snv", "ins", "del")) for _ in range(n_cl)]
+        fg = synth_graphs.flatten(gs)
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn()
+            ctx.sync()
+            return r, time.perf_counter() - t
+
+        gp, t_create = timed(lambda: lib.Paths(ctx, fg, K))
+        W = gp.num_windows
+        pb = lib.Bloom.create(ctx, W + 1_000_000, 1e-4, K, threaded=True)
+        _, t_bloom = timed(lambda: gp.count_kmers(pb))
+        ptab = lib.Table(ctx, max(W // 2, 1024), S, K)
+        mgb = lib.Bloom.create(ctx, 1000, 1e-4, K, threaded=False)
+        _, t_cls = timed(lambda: gp.classify(ptab, mgb))
+        cand, t_cand = timed(lambda: gp.candidates(ptab))
+        for g_ in gs:
+            g_.paths = None
+        fg2 = synth_graphs.flatten(gs)
+        gf, _ = timed(lambda: lib.FindPaths(ctx, fg2, K, 32, 1))
+        _, t_find = timed(lambda: gf.sample(bloom, np.arange(n_cl, dtype=np.uint32) + 7))   # the bench's path Bloom stands in for a sample filter
+        paths = {"clusters": n_cl, "kmer_windows": int(W), "rows": int(cand["kmer_off"][-1]),
+                 "enumerate_windows_per_sec": W / t_create, "bloom_insert_windows_per_sec": W / t_bloom, "classify_windows_per_sec": W / t_cls,
+                 "candidates_windows_per_sec": W / t_cand, "find_sample_paths_clusters_per_sec": n_cl / t_find,
+                 "note": "host wall-clock around each C-ABI call (includes the host-side assembly of the candidates stage)"}
+        for x in (gp, pb, ptab, mgb, gf):
+            x.close()
+
     if rank == 0:
         ms_per_step = elapsed * 1000.0 / args.steps
         total_cluster_sweeps = cluster_sweeps_per_step * world * args.steps
@@ -248,6 +288,7 @@ def main():
                                     "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": traffic_kmc, "avg_launch_ms": kmc_avg_ms, "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD,
                                     "bloom_hits": hits, "table_keys": st["num_keys"]},
             "cpu_baseline": cpu,
+            "graph_stages": paths,
             "gibbs_device_bytes": gibbs.device_bytes(),
         }
         if cpu:
