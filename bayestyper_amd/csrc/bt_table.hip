@@ -745,6 +745,68 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
     return BT_OK;
 }
 
+int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records, uint64_t first_record, uint64_t n,
+                         uint64_t chunk_records, uint64_t *h_hit_count) {
+    if (!s || !path_bloom || !table || !h_records) return fail("bt_kmc_scan_run_host: null argument");
+    if (first_record + n > s->total) return fail("bt_kmc_scan_run_host: record range exceeds the database");
+    if (n == 0) {
+        if (h_hit_count) *h_hit_count = 0;
+        return BT_OK;
+    }
+    BT_HIP(hipSetDevice(s->ctx->device));
+    const uint64_t rec = s->rec_size;
+    chunk_records = std::max<uint64_t>(16, std::min<uint64_t>(chunk_records ? chunk_records : (1ull << 24), n + 15) / 16 * 16);   // chunk starts stay 16-byte aligned
+    const size_t chunk_bytes = chunk_records * rec;
+    // two staging slots: pinned host buffer -> device buffer on a copy stream, scan on the context's stream, events both ways
+    uint8_t *h_pin[2] = {nullptr, nullptr}, *d_buf[2] = {nullptr, nullptr};
+    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    unsigned long long *d_hits = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&h_pin[b]), chunk_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_buf[b]), chunk_bytes + 16);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&scanned[b], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_hits), 8);
+    if (e == hipSuccess) e = hipMemsetAsync(d_hits, 0, 8, s->ctx->stream);
+    int rc = BT_OK;
+    uint64_t done = 0;
+    for (uint64_t i = 0; e == hipSuccess && rc == BT_OK && done < n; ++i) {
+        const int b = (int)(i & 1);
+        const uint64_t m = std::min(chunk_records, n - done);
+        if (i >= 2) e = hipEventSynchronize(copied[b]);   // the pinned buffer of this slot has been read by its previous copy
+        if (e != hipSuccess) break;
+        std::memcpy(h_pin[b], h_records + done * rec, m * rec);
+        if (i >= 2) e = hipStreamWaitEvent(copy_stream, scanned[b], 0);   // the device buffer of this slot has been scanned
+        if (e == hipSuccess) e = hipMemcpyAsync(d_buf[b], h_pin[b], m * rec, hipMemcpyHostToDevice, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(copied[b], copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s->ctx->stream, copied[b], 0);
+        if (e != hipSuccess) break;
+        rc = bt_kmc_scan_run(s, path_bloom, table, sample_idx, d_buf[b], first_record + done, m, reinterpret_cast<uint64_t *>(d_hits));
+        if (rc == BT_OK) e = hipEventRecord(scanned[b], s->ctx->stream);
+        done += m;
+    }
+    unsigned long long hits = 0;
+    if (e == hipSuccess && rc == BT_OK) e = hipMemcpyAsync(&hits, d_hits, 8, hipMemcpyDeviceToHost, s->ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(s->ctx->stream);
+    (void)hipStreamSynchronize(copy_stream);
+    for (int b = 0; b < 2; ++b) {
+        if (h_pin[b]) (void)hipHostFree(h_pin[b]);
+        if (d_buf[b]) (void)hipFree(d_buf[b]);
+        if (copied[b]) (void)hipEventDestroy(copied[b]);
+        if (scanned[b]) (void)hipEventDestroy(scanned[b]);
+    }
+    if (d_hits) (void)hipFree(d_hits);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (rc != BT_OK) return rc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return fail(std::string("bt_kmc_scan_run_host: ") + hipGetErrorString(e));
+    if (h_hit_count) *h_hit_count = hits;
+    return BT_OK;
+}
+
 int bt_kmc_scan_decode(bt_kmc_scan *s, const uint8_t *d_records, uint64_t first_record, uint64_t n, uint64_t *d_kmers, uint32_t *d_counts) {
     if (!s || !d_kmers || !d_counts) return fail("bt_kmc_scan_decode: null argument");
     if (first_record + n > s->total) return fail("bt_kmc_scan_decode: record range exceeds the database");

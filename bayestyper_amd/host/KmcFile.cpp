@@ -1,0 +1,89 @@
+#include "KmcFile.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+namespace bthost {
+
+KmcFile::KmcFile(const std::string &prefix) {
+    // ---- .kmc_pre: "KMCP" | prefix LUT | header | header_offset (4 B) | "KMCP"  (kmc_file.cpp:96-140,177-292) ----
+    std::ifstream pre(prefix + ".kmc_pre", std::ios::binary | std::ios::ate);
+    if (!pre.is_open()) throw std::runtime_error("cannot open " + prefix + ".kmc_pre");
+    const uint64_t size = (uint64_t)pre.tellg();
+    if (size < 4 + 4 + 4 + 40) throw std::runtime_error(prefix + ".kmc_pre: too short");
+    std::vector<char> buf(size);
+    pre.seekg(0);
+    pre.read(buf.data(), (std::streamsize)size);
+    if (std::memcmp(buf.data(), "KMCP", 4) != 0 || std::memcmp(buf.data() + size - 4, "KMCP", 4) != 0) throw std::runtime_error(prefix + ".kmc_pre: missing KMCP markers");
+    uint32_t kmc_version;
+    std::memcpy(&kmc_version, buf.data() + size - 12, 4);
+    if (kmc_version == 0x200) throw std::runtime_error(prefix + ": KMC2 databases (signature-binned) are not supported yet; run kmc with the KMC1 output format");
+    const uint64_t header_offset = (uint8_t)buf[size - 8];
+    const uint64_t body = size - 8;                       // without the two markers
+    if (header_offset < 40 || header_offset + 4 > body) throw std::runtime_error(prefix + ".kmc_pre: bad header offset");
+    const uint64_t header_at = 4 + (body - 4 - header_offset);   // byte offset of the header in the file
+    uint64_t h[5];
+    std::memcpy(h, buf.data() + header_at, sizeof(h));
+    kmer_length = (uint32_t)h[0];
+    mode = (uint32_t)(h[0] >> 32);
+    counter_size = (uint32_t)h[1];
+    lut_prefix_length = (uint32_t)(h[1] >> 32);
+    min_count = (uint32_t)h[2];
+    max_count = (h[2] >> 32) + (h[4] & 0xFFFFFFFF00000000ull);
+    total_kmers = h[3];
+    if (mode != 0) throw std::runtime_error(prefix + ": KMC databases with quality-weighted counters (mode 1) are not supported (KmerCounter.cpp:449)");
+    if (kmer_length == 0 || kmer_length > 64 || lut_prefix_length > kmer_length || (kmer_length - lut_prefix_length) % 4 != 0 || counter_size < 1 || counter_size > 4)
+        throw std::runtime_error(prefix + ".kmc_pre: unsupported parameters");
+    const uint64_t nlut = 1ull << (2 * lut_prefix_length);
+    if (4 + nlut * 8 > header_at) throw std::runtime_error(prefix + ".kmc_pre: prefix table shorter than 4^p entries");
+    lut.resize(nlut + 1);
+    std::memcpy(lut.data(), buf.data() + 4, nlut * 8);
+    lut[nlut] = total_kmers;
+    // ---- .kmc_suf: "KMCS" | records | "KMCS" ----
+    const std::string suf = prefix + ".kmc_suf";
+    const int fd = ::open(suf.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + suf);
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        ::close(fd);
+        throw std::runtime_error("cannot stat " + suf);
+    }
+    map_bytes = (size_t)st.st_size;
+    if (map_bytes != 8 + total_kmers * record_size()) {
+        ::close(fd);
+        throw std::runtime_error(suf + ": size does not match total_kmers x record size");
+    }
+    map = mmap(nullptr, map_bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) {
+        map = nullptr;
+        throw std::runtime_error("cannot map " + suf);
+    }
+    if (std::memcmp(map, "KMCS", 4) != 0) throw std::runtime_error(suf + ": missing KMCS marker");
+    payload = (const uint8_t *)map + 4;
+}
+
+KmcFile::~KmcFile() {
+    if (map) munmap(map, map_bytes);
+}
+
+uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, uint64_t chunk_records) {
+    bt_kmc_scan *scan = nullptr;
+    if (bt_kmc_scan_create(ctx, db.kmer_length, db.lut_prefix_length, db.counter_size, db.total_kmers, db.prefix_lut().data(), &scan) != BT_OK)
+        throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
+    uint64_t hits = 0;
+    // copies from the page cache (mmap) into pinned staging, H2D transfers and scan kernels of consecutive chunks overlap inside the library
+    const int rc = bt_kmc_scan_run_host(scan, path_bloom, table, sample_idx, db.records(), 0, db.total_kmers, chunk_records, &hits);
+    bt_kmc_scan_destroy(scan);
+    if (rc != BT_OK) throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
+    return hits;
+}
+
+}  // namespace bthost

@@ -4,6 +4,7 @@
 
 #include "CountDistribution.hpp"
 #include "Genotypes.hpp"
+#include "KmcFile.hpp"
 #include "VariantClusterGraph.hpp"
 
 using namespace bthost;
@@ -158,6 +159,32 @@ void bth_graph_fetch(void *h, uint64_t *seq_off, uint8_t *seq, uint16_t *vvar, u
     for (size_t v = 0; v < g->var_num_alleles.size(); v++) {
         var_num_alleles[v] = g->var_num_alleles[v];
         var_dep[v] = g->var_has_dependency[v];
+    }
+}
+
+
+// KmerCounter::parseSampleKmers for one sample from a KMC database on disk; returns the number of Bloom hits, or -1 (error text in *err)
+long long bth_parse_sample_kmers(void *ctx, const char *kmc_prefix, void *path_bloom, void *table, unsigned sample_idx, unsigned long long chunk_records, char *err,
+                                 unsigned err_len) {
+    try {
+        KmcFile db(kmc_prefix);
+        return (long long)parseSampleKmers((bt_ctx *)ctx, db, (bt_bloom *)path_bloom, (bt_table *)table, sample_idx, chunk_records ? chunk_records : (1ull << 24));
+    } catch (const std::exception &e) {
+        if (err && err_len) {
+            std::strncpy(err, e.what(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return -1;
+    }
+}
+// header fields of a KMC database: out[0..5] = k, mode, counter_size, lut_prefix_length, total_kmers, record_size; 0 on success
+int bth_kmc_info(const char *kmc_prefix, unsigned long long *out) {
+    try {
+        KmcFile db(kmc_prefix);
+        out[0] = db.kmer_length; out[1] = db.mode; out[2] = db.counter_size; out[3] = db.lut_prefix_length; out[4] = db.total_kmers; out[5] = db.record_size();
+        return 0;
+    } catch (...) {
+        return 1;
     }
 }
 

@@ -73,3 +73,26 @@ def test_n_runs_split_vertices():
     assert out["flags"][split] == 1 and out["nested"][split] == 0xFFFFFFFF and (out["var"][split], out["allele"][split]) == (out["var"][split - 1], out["allele"][split - 1])
     assert [tuple(e) for e in out["edges"]][-1] == (split - 1, split)
     del a
+
+
+def test_kmc_file_header_and_errors(tmp_path):
+    """bthost::KmcFile on a database written by the oracle's KMC1 writer (the reference's CKMCFile reads the same files:
+    tests/test_oracle_kmer.py), and on damaged files."""
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).parent))
+    import _oracle
+
+    orc = _oracle.load_oracle()
+    rng = np.random.default_rng(2)
+    km = np.unique(_oracle.canonical_ascii(orc, _oracle.random_kmers(rng, 5000, K), K).reshape(-1, K), axis=0)
+    pref = str(tmp_path / "db")
+    orc.kmc_write(pref, np.ascontiguousarray(km).reshape(-1), rng.integers(1, 200, len(km)).astype(np.uint32), K, 3, 1)
+    dll.bth_kmc_info.argtypes = [C.c_char_p, C.c_void_p]
+    out = np.zeros(6, np.uint64)
+    assert dll.bth_kmc_info(pref.encode(), out.ctypes.data_as(C.c_void_p)) == 0
+    assert list(out) == [K, 0, 1, 3, len(km), (K - 3) // 4 + 1]
+    assert dll.bth_kmc_info((pref + "_missing").encode(), out.ctypes.data_as(C.c_void_p)) != 0
+    raw = open(pref + ".kmc_suf", "rb").read()
+    open(pref + ".kmc_suf", "wb").write(raw[:-20])           # truncated payload
+    assert dll.bth_kmc_info(pref.encode(), out.ctypes.data_as(C.c_void_p)) != 0

@@ -537,3 +537,40 @@ def test_find_sample_paths(gpu_ctx, oracle, max_haps, fpr):
         ob.close(), gb.close()
     assert sum(b.shape[0] for b in bo) > len(gs)
     og.close(), gf.close()
+
+
+def test_parse_sample_kmers_host_driver(gpu_ctx, oracle, tmp_path):
+    """KmerCounter::parseSampleKmers as the C++ host layer drives it: KMC database on disk -> bthost::KmcFile (mmap) ->
+    bt_kmc_scan_run_host (pinned staging, copy stream, events; many small chunks here) -> count table == the oracle's."""
+    import ctypes as C
+
+    from bayestyper_amd import lib
+    from bayestyper_amd.host import dll
+
+    rng = np.random.default_rng(61)
+    S = 2
+    km = np.unique(_oracle.canonical_ascii(oracle, _oracle.random_kmers(rng, 60_000, K), K).reshape(-1, K), axis=0)
+    path = km[rng.random(len(km)) < 0.3]
+    ob = OrcBloom(oracle, len(path), 1e-3, K, threaded=True)
+    ob.insert(np.ascontiguousarray(path).reshape(-1))
+    gb = lib.Bloom.create(gpu_ctx, len(path), 1e-3, K, threaded=True)
+    gb.insert(oracle.pack(np.ascontiguousarray(path).reshape(-1), K))
+    ot, gt = OrcTable(oracle, S, K), lib.Table(gpu_ctx, 60_000, S, K)
+    dll.bth_parse_sample_kmers.restype = C.c_longlong
+    dll.bth_parse_sample_kmers.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_ulonglong, C.c_char_p, C.c_uint]
+    for s, chunk in enumerate((1000, 0)):
+        sel = km[rng.random(len(km)) < 0.8]
+        cnt = rng.integers(1, 250, len(sel)).astype(np.uint32)
+        pref = str(tmp_path / f"s{s}")
+        oracle.kmc_write(pref, np.ascontiguousarray(sel).reshape(-1), cnt, K, 7 if s else 3, 1)
+        db = OrcKmc(oracle, pref)
+        hits_o = ot.parse_sample_kmers(ob, db, s)
+        db.close()
+        err = C.create_string_buffer(256)
+        hits_g = dll.bth_parse_sample_kmers(gpu_ctx.h, pref.encode(), gb.h, gt.h, s, chunk, err, 256)
+        assert hits_g == hits_o, err.value
+    gk, gc, gm = _sorted_export(*gt.export())
+    wk, wc, wm = _sorted_export(*ot.export())
+    assert np.array_equal(gk, wk) and np.array_equal(gc, wc) and np.array_equal(gm, wm) and len(wk) > 5000
+    for x in (ob, gb, ot, gt):
+        x.close()
