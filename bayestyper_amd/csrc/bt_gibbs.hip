@@ -200,8 +200,12 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
     Tile t;
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
-    if (!tile_thread_active(t.d->split)) return;
-    t.lane = tile_lane(t.d->split);
+    if (!tile_thread_active(t.d->split, t.d->copies)) return;
+    t.lane = tile_lane(t.d->split, t.d->copies);
+    t.part = tile_part(t.d->copies);
+    t.copies = t.d->copies;
+    // the extra copies of a narrow tile's groups only take part in the sampling operations (the others tally with atomics)
+    if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN)) return;
     t.hot = nullptr;
     t.resident = 0xFFFFFFFFu;
     SPtr<uint32_t, LANES> gd = t.arr<uint32_t>(A_GDIMS);
@@ -689,6 +693,12 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         if (const char *e = getenv("BT_GIBBS_SPLIT")) {   // tuning override
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8) d.split = (uint32_t)v;
+        }
+        // narrow tiles: one wavefront, its idle lanes run identical copies of the groups and share the data-parallel phases
+        d.copies = 1;
+        if (d.lds_stride <= 32 && !getenv("BT_GIBBS_NO_COPIES")) {
+            d.split = 1;
+            d.copies = 64u / d.lds_stride;
         }
         d.base = pool;
         plans[ti].d = d;

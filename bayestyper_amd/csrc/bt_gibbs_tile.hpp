@@ -125,6 +125,7 @@ struct TileDesc {
     uint64_t off[A_COUNT];    // byte offsets of the arrays from the tile base
     uint32_t hoff[A_COUNT];   // byte offset inside the wavefront's LDS block of the arrays kept resident there (NOHOT otherwise)
     uint32_t hot_bytes, split;   // hot_bytes: LDS bytes of ONE vertex's hot arrays; split: wavefronts working on this tile (1, 2, 4 or 8), see tile_lane()
+    uint32_t copies, copies_pad;    // narrow tiles (split 1): the wavefront's idle lanes run `copies` identical instances of every group, see Tile::part
     uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (16/32/64); lds_all: every vertex has its own LDS block (no swaps)
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
@@ -145,6 +146,11 @@ struct Tile {
     uint8_t BT_GAS *base;
     const TileDesc BT_CAS *d;
     uint32_t lane;
+    // Narrow tiles leave most lanes of their wavefront idle.  Instead, 64 / width ("copies") threads run the SAME group: identical
+    // program, identical loads, identical stores to identical addresses (SIMT lockstep makes every read-modify-write of the copies
+    // read before any of them writes) — which costs nothing — and the phases that are data-parallel inside one group (the dense
+    // table fill, the compact subset copies) are divided among the copies by `part`.
+    uint32_t part, copies;
     uint8_t *hot;        // this wavefront's LDS block (generic pointer) or nullptr
     uint32_t resident;   // vertex whose hot arrays currently live in LDS (0xFFFFFFFF: none)
     // hot-capable array: LDS when the vertex is resident, HBM otherwise; one code path through generic pointers
@@ -260,8 +266,17 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
 // consecutive group lanes starting at w * 64/split and runs with only that many active threads; wavefronts of the workgroup
 // beyond `split` exit at once.  The memory layout (HBM pool and LDS hot arrays, both interleaved over 64 group lanes) does not
 // depend on the split: it only trades SIMD width for more wavefronts that each wait on fewer diverging lanes.
-__device__ inline uint32_t tile_lane(uint32_t split) { return (threadIdx.x >> 6) * (64u / split) + (threadIdx.x & 63u); }
-__device__ inline bool tile_thread_active(uint32_t split) { return (threadIdx.x >> 6) < split && (threadIdx.x & 63u) < 64u / split; }
+__device__ inline uint32_t tile_lane(uint32_t split, uint32_t copies) { return (threadIdx.x >> 6) * (64u / split) + ((threadIdx.x & 63u) % (64u / copies)); }
+__device__ inline uint32_t tile_part(uint32_t copies) { return (threadIdx.x & 63u) / (64u / copies); }
+__device__ inline bool tile_thread_active(uint32_t split, uint32_t copies) {
+    return (threadIdx.x >> 6) < split && (copies > 1u || (threadIdx.x & 63u) < 64u / split);
+}
+// make the stores of the sibling copies visible before reading what they produced (same wavefront: program order + L1 write-through)
+__device__ inline void copies_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 extern __shared__ __attribute__((aligned(16))) uint8_t bt_lds_raw[];
 __device__ inline uint8_t *lds_block() { return (uint8_t *)bt_lds_raw; }
 
@@ -273,7 +288,9 @@ __device__ inline Tile make_tile(const Env &e_in) {
     const uint32_t tile = list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x;
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
-    t.lane = tile_lane(t.d->split);
+    t.lane = tile_lane(t.d->split, t.d->copies);
+    t.part = tile_part(t.d->copies);
+    t.copies = t.d->copies;
     t.resident = e_in.resident;   // per lane: lanes of a tile may be at different vertices of their groups
     t.hot = (t.resident != 0xFFFFFFFFu && t.d->hot_bytes) ? lds_block() : nullptr;
     return t;
@@ -686,14 +703,19 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
         SPtr<uint16_t, LANES> sv = c.skv_var();
         const uint32_t HWm = c.d().HWm, HW = (c.H + 31) / 32;
         uint32_t ne = 0;
-        for (uint32_t i = 0; i < nsu; ++i) {
+        so[0] = 0;
+        for (uint32_t i = 0; i < nsu; ++i) {   // CSR offsets first (sequential, every copy of the group computes the same values)
             const uint32_t k = usub[i];
-            so[i] = ne;
+            ne += c.kv_off(k + 1) - c.kv_off(k);
+            so[i + 1] = ne;
+        }
+        for (uint32_t i = c.t.part; i < nsu; i += c.t.copies) {   // k-mer i is copied by copy i % copies (lockstep: iteration j handles j*copies + part)
+            const uint32_t k = usub[i];
+            uint32_t ne = so[i];
             for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e, ++ne) {
                 sv[ne] = c.kv_var(e);
                 for (uint32_t w = 0; w < HW; ++w) sb[ne * HWm + w] = c.a<uint32_t>(A_KVBITS, c.d().NNZm * HWm)[e * HWm + w];
             }
-            so[i + 1] = ne;
             const bool hc = c.has_counts(k) != 0;
             {
                 // row copy, eight multiplicities in flight (loads and stores may alias as far as the compiler knows)
@@ -718,7 +740,7 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
         const uint32_t Hm = c.d().Hm;
         SPtr<uint8_t, LANES> mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
         SPtr<uint32_t, LANES> msh = c.msubsh();
-        for (uint32_t i = 0; i < nsm; ++i) {
+        for (uint32_t i = c.t.part; i < nsm; i += c.t.copies) {
             const uint32_t k = msub[i];
             for (uint32_t h = 0; h < c.H; ++h) mm[i * Hm + h] = c.M(k, h);
             for (uint32_t ss = 0; ss < P.S; ++ss) mcn[i * P.S + ss] = c.count(k, ss);
@@ -727,6 +749,7 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
             msh[i] = (uint32_t)c.shared_idx(k);
         }
     }
+    if (c.t.copies > 1u) copies_sync();
     PROF(10);
     PROF_CNT(11, nsu);
     SPtrF<uint32_t, LANES> sc = c.sc();
@@ -828,9 +851,20 @@ __device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
         const uint8_t gender = P.gender[s];
         const uint32_t row = s * d.Dcm;
         // a == H is the haploid row: candidates (b, none)
-        for (uint32_t a = 0; a <= H; ++a) {
+        // blocks (a, b0..b0+3) in row order; entries are independent sums, so the copies of this group take every copies-th block:
+        // copy `part` walks ITS OWN block sequence (the copies stay in lockstep: iteration j handles blocks j*copies + part)
+        uint32_t a = 0, b0 = 0;
+        auto next_block = [&]() {
+            b0 += 4;
+            if (b0 >= H) {
+                ++a;
+                b0 = a == H ? 0u : a;
+            }
+        };
+        for (uint32_t q = 0; q < c.t.part && a <= H; ++q) next_block();
+        while (a <= H) {   // (a, b0) advance in next_block
             const bool hap = a == H;
-            for (uint32_t b0 = hap ? 0 : a; b0 < H; b0 += 4) {
+            {
                 uint32_t hb[4];
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) hb[q] = b0 + q < H ? b0 + q : H - 1;
@@ -874,8 +908,10 @@ __device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
                 for (uint32_t q = 0; q < 4; ++q)
                     if (b0 + q < H) uc[row + (hap ? H * (H + 1) / 2 + b0 + q : dip_index(c, (uint16_t)a, (uint16_t)(b0 + q)))] = acc[q];
             }
+            for (uint32_t q = 0; q < c.t.copies && a <= H; ++q) next_block();
         }
     }
+    if (c.t.copies > 1u) copies_sync();
 }
 
 // multicluster part (VariantClusterGenotyper.cpp:647-661).  For a candidate d the k-mer multiplicity is
