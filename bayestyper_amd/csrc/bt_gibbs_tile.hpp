@@ -1286,6 +1286,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         // the picked interval — about once in 10^5..10^6 draws — the reference's chain is evaluated after all.
         const uint32_t total = ploidy == 2 ? nnz * (nnz + 1) / 2 : (ploidy == 1 ? nnz : 0u);
         const bool chain_only = total <= BT_LINEAR_DRAW_MIN;
+        const bool par = !chain_only && c.t.copies > 1u && c.d().cache_mode == 0;
         double lpmax = 0;
         // lp of every candidate -> cum[0..total), in order; returns through lpmax the maximum
         // Evaluated in blocks of 8: the cache words of a whole block are requested first (independent loads, one memory round trip
@@ -1296,8 +1297,31 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             SPtr<double, LANES> uc = c.ucache(), mc = c.mcache();
             SPtr<uint32_t, LANES> uct = c.uctag(), mct = c.mctag(), mcg = c.mcgen();
             const bool multi = use_multi && nsub_m != 0;
-            uint32_t a = 0, b = 0, n = 0;   // enumeration state (diploid: b >= a)
-            for (uint32_t base = 0; base < total; base += 8) {
+            uint32_t a = 0, b = 0;   // enumeration state (diploid: b >= a)
+            // skip `steps` candidates of the enumeration (row a holds nnz - a candidates when diploid, one when haploid)
+            auto advance = [&](uint32_t steps) {
+                if (!dipl) {
+                    a += steps;
+                    return;
+                }
+                while (steps > 0 && a < nnz) {
+                    const uint32_t left = nnz - b;
+                    if (steps < left) {
+                        b += steps;
+                        steps = 0;
+                    } else {
+                        steps -= left;
+                        ++a;
+                        b = a;
+                    }
+                }
+            };
+            // with copies of the group in the wavefront (Tile::part) every copy evaluates every copies-th block (dense tables only:
+            // their slots are private to a candidate, hashed slots could collide between concurrently evaluated candidates)
+            const uint32_t stride_blocks = par ? c.t.copies : 1u;
+            if (par) advance(8u * c.t.part);
+            lpmax = -__builtin_huge_val();
+            for (uint32_t base = par ? 8u * c.t.part : 0u; base < total; base += 8u * stride_blocks) {
                 const uint32_t nb = total - base < 8 ? total - base : 8;
                 uint16_t ha[8], hb[8];
                 uint32_t uslot[8], ukey[8];
@@ -1360,10 +1384,18 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                         const bool uhit = dd.cache_mode == 0 || (dd.cache_mode == 1 && utag[q] == ukey[q]);
                         lp += uhit ? uval[q] : unique_log_prob(c, P, s, ha[q], hb[q], nsub_u);
                         if (multi) lp += mval[q];
-                        lpmax = (n == 0 || lp > lpmax) ? lp : lpmax;
-                        cum[n++] = lp;
+                        lpmax = lp > lpmax ? lp : lpmax;
+                        cum[base + q] = lp;
                     }
                 }
+                if (par) advance(8u * (stride_blocks - 1u));
+            }
+            if (par) {   // maximum over the copies (lanes lane, lane + 64/copies, ...), then make their cum[] entries visible
+                for (uint32_t m = 64u / c.t.copies; m < 64u; m <<= 1) {
+                    const double o = __shfl_xor(lpmax, (int)m);
+                    lpmax = o > lpmax ? o : lpmax;
+                }
+                copies_sync();
             }
         };
         // the reference's decision on cum[] holding the lp values: chain, then upper_bound (first index with cum > u)
@@ -1393,9 +1425,18 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             pick = chain_pick(u01);
         } else {
             double acc = 0;
-            for (uint32_t i = 0; i < total; ++i) {
-                acc += bt_exp((double)cum[i] - lpmax);
-                cum[i] = acc;
+            if (par) {   // the exponentials are independent: split among the copies; the running sum stays sequential (same order, same bits)
+                for (uint32_t i = c.t.part; i < total; i += c.t.copies) cum[i] = bt_exp((double)cum[i] - lpmax);
+                copies_sync();
+                for (uint32_t i = 0; i < total; ++i) {
+                    acc += (double)cum[i];
+                    cum[i] = acc;
+                }
+            } else {
+                for (uint32_t i = 0; i < total; ++i) {
+                    acc += bt_exp((double)cum[i] - lpmax);
+                    cum[i] = acc;
+                }
             }
             const double thr = u01 * acc;
             uint32_t lo = 0, hi = total;
