@@ -13,6 +13,10 @@
 // Integer / byte work, HBM random access; no MFMA.
 #include "bt_internal.hpp"
 
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -797,6 +801,17 @@ int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes 
     hipLaunchKernelGGL(triples_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, p->A, p->d_valid, p->d_pos_slot_a, p->d_list_flags, d_a_row, p->d_pos_path,
                        p->d_pos_nt, p->d_path_local, p->d_iv_off, p->d_iv, p->L, d_cursor, d_trip);
     HIPC(hipGetLastError());
+    // sort the triples by (row, variant, path) on the device (rocPRIM radix sort over the 64-bit keys)
+    if (ntrip > 1) {
+        uint64_t *d_sorted = nullptr;
+        TRYC(dev_alloc(&d_sorted, ntrip, tmp));
+        size_t tmp_bytes = 0;
+        HIPC(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_trip, d_sorted, (size_t)ntrip, 0, 64, st));
+        uint8_t *d_tmp = nullptr;
+        TRYC(dev_alloc(&d_tmp, tmp_bytes, tmp));
+        HIPC(rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_trip, d_sorted, (size_t)ntrip, 0, 64, st));
+        d_trip = d_sorted;
+    }
     // 6. fetch and assemble on the host
     std::vector<uint64_t> trip(ntrip);
     std::vector<uint8_t> row_flags(R);
@@ -831,8 +846,7 @@ int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes 
         p->unique_off.push_back((uint32_t)p->unique_idx.size());
         p->multi_off.push_back((uint32_t)p->multi_idx.size());
     }
-    // variant_haplotype_indices: triples sorted by (row, variant); entries of a row ordered by variant
-    std::sort(trip.begin(), trip.end());
+    // variant_haplotype_indices: the triples arrive sorted by (row, variant, path); entries of a row ordered by variant
     std::vector<uint32_t> row_cluster(R);
     for (uint32_t c = 0; c < C; ++c)
         for (uint32_t r = p->kmer_off[c]; r < p->kmer_off[c + 1]; ++r) row_cluster[r] = c;
