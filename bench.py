@@ -206,7 +206,7 @@ def main():
     # ------------------------------------------------------------------ graph stages (rank 0, outside the timed region): best-path search,
     # path k-mer enumeration, classification, haplotype candidates on synthetic SNV/indel clusters — reported beside the headline metric
     paths = None
-    if rank == 0 and not args.no_paths:
+    if rank == 0 and world == 1 and not args.no_paths:   # like the CPU baseline: single-GPU runs only (other ranks would idle at the teardown)
         from bayestyper_amd import synth_graphs
 
         prng = np.random.default_rng(11)
