@@ -1574,7 +1574,7 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
                 const double f = rng_gamma(rng, nd, (double)obs[e] + 1.0, 1.0);
                 freq[e] = f;
                 norm += f;
-                nz[e] = 1;
+                nz[e] = 2;   // selected in this call (turned into 1 below)
             }
             while (uset_size(plus) < simplex_size) {
                 const uint32_t pos = rng_uniform_int(rng, uset_size(zero));   // uniform_int(0, |zero| - 1)
@@ -1583,15 +1583,37 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
                 const double f = rng_gamma(rng, nd, 1.0, 1.0);
                 freq[e] = f;
                 norm += f;
-                nz[e] = 1;
+                nz[e] = 2;
                 // the two sets share the `next` words: leave the zero list before entering the plus list
                 uset_erase(zero, e);
                 uset_insert(plus, e);
             }
-            for (uint32_t e = uset_begin(zero); e != US_NONE; e = unext[e]) {
-                freq[e] = 0;
-                nz[e] = 0;
-                obs[e] = 0;
+            // "for z in zero: freq = 0, nz = 0, obs = 0": the zero set is exactly the haplotypes not selected above, so the reset
+            // runs over the arrays (independent accesses, eight in flight) instead of chasing the set's list links
+            {
+                uint32_t h = 0;
+                for (; h + 8 <= c.H; h += 8) {
+                    uint8_t m8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) m8[q] = nz[h + q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (m8[q] == 2) nz[h + q] = 1;
+                        else {
+                            freq[h + q] = 0;
+                            nz[h + q] = 0;
+                            obs[h + q] = 0;
+                        }
+                    }
+                }
+                for (; h < c.H; ++h) {
+                    if (nz[h] == 2) nz[h] = 1;
+                    else {
+                        freq[h] = 0;
+                        nz[h] = 0;
+                        obs[h] = 0;
+                    }
+                }
             }
             // "for p in plus: freq /= norm; zero.insert(p); obs = 0" then plus.clear(): record the plus iteration order
             // first (shared `next` words), clear plus, then insert into zero in that order — same final containers
