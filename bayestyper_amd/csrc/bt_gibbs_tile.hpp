@@ -1415,15 +1415,19 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             }
             return lo < total ? lo : total - 1;
         };
-        eval_candidates();
-        PROF(2);
-        // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome
+        // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome.  (The evaluation of
+        // the candidates consumes no random numbers, so drawing first does not change the stream.)
         const double u01 = rng_canonical(rng);
         uint32_t pick = 0;
-        if (chain_only) {
-            if (total == 0) (void)bt_log(u01);
-            pick = chain_pick(u01);
-        } else {
+        // one evaluation site (the blocked evaluation is large: instantiating it twice would not fit the instruction cache)
+        for (bool exact = chain_only;; exact = true) {
+            eval_candidates();
+            PROF(2);
+            if (exact) {
+                if (total == 0) (void)bt_log(u01);
+                pick = chain_pick(u01);
+                break;
+            }
             double acc = 0;
             if (par) {   // the exponentials are independent: split among the copies; the running sum stays sequential (same order, same bits)
                 for (uint32_t i = c.t.part; i < total; i += c.t.copies) cum[i] = bt_exp((double)cum[i] - lpmax);
@@ -1449,12 +1453,11 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             double margin = 64.0 * (double)total * amax * BT_DBL_EPS;
             margin = (margin > 1e-6 ? margin : 1e-6) * acc;
             const bool safe = lo < total && (double)cum[lo] - thr > margin && (lo == 0 || thr - (double)cum[lo - 1] > margin);
-            if (safe) pick = lo;
-            else {
-                PROF_CNT(14, 1000000);   // shows up as 1.0 per fallback in the "nested" column of scratch/prof_phases.py
-                eval_candidates();
-                pick = chain_pick(u01);
+            if (safe) {
+                pick = lo;
+                break;
             }
+            PROF_CNT(14, 1000000);   // shows up as 1.0 per fallback in the "nested" column of scratch/prof_phases.py
         }
         uint16_t h1 = NOHAP, h2 = NOHAP;
         if (ploidy == 2) {
