@@ -681,6 +681,12 @@ int bt_table_classify_batch(bt_table *t, bt_bloom *multigroup_bloom, const uint6
 
 int bt_kmc_scan_create(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_t counter_size, uint64_t total_records,
                        const uint64_t *h_prefix_lut, bt_kmc_scan **out) {
+    if (lut_prefix_len > 15) return fail("bt_kmc_scan_create: lut_prefix_len <= 15");
+    return bt_kmc_scan_create_bins(ctx, k, lut_prefix_len, counter_size, total_records, h_prefix_lut, (1ULL << (2 * lut_prefix_len)) + 1, out);
+}
+
+int bt_kmc_scan_create_bins(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_t counter_size, uint64_t total_records,
+                            const uint64_t *h_prefix_lut, uint64_t num_lut_entries, bt_kmc_scan **out) {
     if (!ctx || !out || !h_prefix_lut) return fail("bt_kmc_scan_create: null argument");
     if (k < 1 || k > 64) return fail("bt_kmc_scan_create: k must be in 1..64");
     if (lut_prefix_len > k || lut_prefix_len > 15 || ((k - lut_prefix_len) % 4) != 0)
@@ -694,7 +700,11 @@ int bt_kmc_scan_create(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_
     s->suffix_bytes = (k - lut_prefix_len) / 4;
     s->rec_size = s->suffix_bytes + counter_size;
     s->total = total_records;
-    s->lut_entries = (1ULL << (2 * lut_prefix_len)) + 1;
+    if (num_lut_entries < 2 || ((num_lut_entries - 1) % (1ULL << (2 * lut_prefix_len))) != 0) {
+        delete s;
+        return fail("bt_kmc_scan_create: the prefix LUT must hold a multiple of 4^p entries plus the terminal one");
+    }
+    s->lut_entries = num_lut_entries;
     if (h_prefix_lut[s->lut_entries - 1] != total_records || h_prefix_lut[0] != 0) {
         delete s;
         return fail("bt_kmc_scan_create: prefix LUT must start at 0 and end at total_records");

@@ -24,28 +24,50 @@ KmcFile::KmcFile(const std::string &prefix) {
     if (std::memcmp(buf.data(), "KMCP", 4) != 0 || std::memcmp(buf.data() + size - 4, "KMCP", 4) != 0) throw std::runtime_error(prefix + ".kmc_pre: missing KMCP markers");
     uint32_t kmc_version;
     std::memcpy(&kmc_version, buf.data() + size - 12, 4);
-    if (kmc_version == 0x200) throw std::runtime_error(prefix + ": KMC2 databases (signature-binned) are not supported yet; run kmc with the KMC1 output format");
     const uint64_t header_offset = (uint8_t)buf[size - 8];
     const uint64_t body = size - 8;                       // without the two markers
     if (header_offset < 40 || header_offset + 4 > body) throw std::runtime_error(prefix + ".kmc_pre: bad header offset");
-    const uint64_t header_at = 4 + (body - 4 - header_offset);   // byte offset of the header in the file
-    uint64_t h[5];
-    std::memcpy(h, buf.data() + header_at, sizeof(h));
-    kmer_length = (uint32_t)h[0];
-    mode = (uint32_t)(h[0] >> 32);
-    counter_size = (uint32_t)h[1];
-    lut_prefix_length = (uint32_t)(h[1] >> 32);
-    min_count = (uint32_t)h[2];
-    max_count = (h[2] >> 32) + (h[4] & 0xFFFFFFFF00000000ull);
-    total_kmers = h[3];
+    uint64_t lut_entries = 0;                             // prefix-table entries in the file (bins x 4^p for KMC2)
+    if (kmc_version == 0x200) {
+        // KMC2: "KMCP" | per-bin prefix tables | guard word | signature map | header | header_offset | "KMCP" (kmc_file.cpp:186-238)
+        const char *h = buf.data() + size - 8 - header_offset;
+        uint32_t f[7];
+        std::memcpy(f, h, sizeof(f));
+        kmer_length = f[0];
+        mode = f[1];
+        counter_size = f[2];
+        lut_prefix_length = f[3];
+        const uint32_t signature_len = f[4];
+        min_count = f[5];
+        max_count = f[6];
+        std::memcpy(&total_kmers, h + 28, 8);
+        if (signature_len > 11) throw std::runtime_error(prefix + ".kmc_pre: unsupported signature length");
+        const uint64_t signature_map_bytes = ((1ull << (2 * signature_len)) + 1) * 4;
+        if (body < 4 + signature_map_bytes + header_offset + 8) throw std::runtime_error(prefix + ".kmc_pre: too short for its signature map");
+        lut_entries = (body - 4 - signature_map_bytes - header_offset - 8) / 8;
+    } else if (kmc_version == 0) {
+        const uint64_t header_at = 4 + (body - 4 - header_offset);   // byte offset of the header in the file
+        uint64_t h[5];
+        std::memcpy(h, buf.data() + header_at, sizeof(h));
+        kmer_length = (uint32_t)h[0];
+        mode = (uint32_t)(h[0] >> 32);
+        counter_size = (uint32_t)h[1];
+        lut_prefix_length = (uint32_t)(h[1] >> 32);
+        min_count = (uint32_t)h[2];
+        max_count = (h[2] >> 32) + (h[4] & 0xFFFFFFFF00000000ull);
+        total_kmers = h[3];
+        lut_entries = (header_at - 4) / 8;
+    } else
+        throw std::runtime_error(prefix + ".kmc_pre: unknown KMC database version");
     if (mode != 0) throw std::runtime_error(prefix + ": KMC databases with quality-weighted counters (mode 1) are not supported (KmerCounter.cpp:449)");
-    if (kmer_length == 0 || kmer_length > 64 || lut_prefix_length > kmer_length || (kmer_length - lut_prefix_length) % 4 != 0 || counter_size < 1 || counter_size > 4)
+    if (kmer_length == 0 || kmer_length > 64 || lut_prefix_length > 15 || lut_prefix_length > kmer_length || (kmer_length - lut_prefix_length) % 4 != 0 || counter_size < 1 ||
+        counter_size > 4)
         throw std::runtime_error(prefix + ".kmc_pre: unsupported parameters");
     const uint64_t nlut = 1ull << (2 * lut_prefix_length);
-    if (4 + nlut * 8 > header_at) throw std::runtime_error(prefix + ".kmc_pre: prefix table shorter than 4^p entries");
-    lut.resize(nlut + 1);
-    std::memcpy(lut.data(), buf.data() + 4, nlut * 8);
-    lut[nlut] = total_kmers;
+    if (lut_entries == 0 || lut_entries % nlut != 0 || (kmc_version == 0 && lut_entries != nlut)) throw std::runtime_error(prefix + ".kmc_pre: prefix table is not a multiple of 4^p entries");
+    lut.resize(lut_entries + 1);
+    std::memcpy(lut.data(), buf.data() + 4, lut_entries * 8);
+    lut[lut_entries] = total_kmers;
     // ---- .kmc_suf: "KMCS" | records | "KMCS" ----
     const std::string suf = prefix + ".kmc_suf";
     const int fd = ::open(suf.c_str(), O_RDONLY);
@@ -76,7 +98,7 @@ KmcFile::~KmcFile() {
 
 uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, uint64_t chunk_records) {
     bt_kmc_scan *scan = nullptr;
-    if (bt_kmc_scan_create(ctx, db.kmer_length, db.lut_prefix_length, db.counter_size, db.total_kmers, db.prefix_lut().data(), &scan) != BT_OK)
+    if (bt_kmc_scan_create_bins(ctx, db.kmer_length, db.lut_prefix_length, db.counter_size, db.total_kmers, db.prefix_lut().data(), db.prefix_lut().size(), &scan) != BT_OK)
         throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
     uint64_t hits = 0;
     // copies from the page cache (mmap) into pinned staging, H2D transfers and scan kernels of consecutive chunks overlap inside the library

@@ -1,6 +1,6 @@
 // KMC database access for the count-table scan and the scan driver itself:
-//   CKMCFile::OpenForListing / ReadParamsFrom_prefix_file_buf (external/kmc_api/kmc_file.cpp:96-292) — header + prefix LUT of a KMC1
-//   ("version 0") database; the .kmc_suf payload is memory-mapped and streamed to the GPU as it lies on disk;
+//   CKMCFile::OpenForListing / ReadParamsFrom_prefix_file_buf (external/kmc_api/kmc_file.cpp:96-292) — header + prefix LUT(s) of a KMC1
+//   ("version 0") or KMC2 ("0x200", one prefix table per signature bin) database; the .kmc_suf payload is memory-mapped and streamed to the GPU as it lies on disk;
 //   KmerCounter::parseSampleKmers (src/bayesTyper/KmerCounter.cpp:431-524) — one sample's records through
 //   bt_kmc_scan_run in double-buffered chunks.
 #pragma once
@@ -22,7 +22,7 @@ class KmcFile {
     uint32_t kmer_length = 0, mode = 0, counter_size = 0, lut_prefix_length = 0, min_count = 0;
     uint64_t max_count = 0, total_kmers = 0;
     uint32_t record_size() const { return (kmer_length - lut_prefix_length) / 4 + counter_size; }
-    const std::vector<uint64_t> &prefix_lut() const { return lut; }   // 4^p + 1 entries, lut[4^p] = total_kmers
+    const std::vector<uint64_t> &prefix_lut() const { return lut; }   // bins * 4^p + 1 entries (bins = 1 for KMC1), last = total_kmers
     const uint8_t *records() const { return payload; }                 // total_kmers * record_size() bytes
 
   private:

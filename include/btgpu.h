@@ -206,6 +206,11 @@ typedef struct bt_kmc_scan bt_kmc_scan;
  * whose prefix is >= j, LUT[4^p] = total; host memory, copied). */
 int bt_kmc_scan_create(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_t counter_size,
                        uint64_t total_records, const uint64_t *h_prefix_lut, bt_kmc_scan **out);
+/* The same with an explicit LUT length for KMC2 ("0x200") databases, whose .kmc_pre holds one prefix table per signature bin,
+ * concatenated (num_lut_entries = bins * 4^p + 1, last entry = total; external/kmc_api/kmc_file.cpp:186-238,428-449): the record's
+ * prefix is (LUT index) mod 4^p. */
+int bt_kmc_scan_create_bins(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_t counter_size, uint64_t total_records,
+                            const uint64_t *h_prefix_lut, uint64_t num_lut_entries, bt_kmc_scan **out);
 int bt_kmc_scan_destroy(bt_kmc_scan *s);
 /* Push records [first_record, first_record + n) of the .kmc_suf payload through
  * decode -> path_bloom.lookup -> (on hit) table.addKmer(unsorted) + addSampleCount(sample, count).

@@ -226,7 +226,28 @@ bool kmc_open(const std::string &prefix, KmcDb &db) {
     if (suf.size() < 8 || memcmp(suf.data(), "KMCS", 4) || memcmp(suf.data() + suf.size() - 4, "KMCS", 4)) return false;
     uint32_t version;
     memcpy(&version, pre.data() + pre.size() - 12, 4);   // kmc_file.cpp:180-185
-    if (version != 0) return false;                        // this oracle reads KMC1 ("version 0") databases
+    if (version == 0x200) {   // KMC2: "KMCP" | per-bin LUTs | guard word | signature map | header | header_offset | "KMCP" (kmc_file.cpp:186-238)
+        const uint64_t header_offset = pre[pre.size() - 8];
+        const unsigned char *h = pre.data() + pre.size() - 8 - header_offset;
+        auto u32 = [&](unsigned i) { uint32_t w; memcpy(&w, h + 4 * i, 4); return w; };
+        db.k = u32(0);
+        if (u32(1) != 0) return false;   // mode 0 only
+        db.counter_size = u32(2);
+        db.p = u32(3);
+        const uint32_t signature_len = u32(4);
+        memcpy(&db.total, h + 28, 8);
+        const uint64_t signature_map_size = (1ULL << (2 * signature_len)) + 1;
+        const uint64_t size = pre.size() - 8 - 4;   // without markers and header_offset
+        const uint64_t lut_area = size - (signature_map_size * 4 + header_offset + 8);
+        const uint64_t m = lut_area / 8;            // number of LUT entries: bins x 4^p
+        if (m == 0 || (m % (1ULL << (2 * db.p))) != 0) return false;
+        db.lut.assign(m + 1, 0);
+        memcpy(db.lut.data(), pre.data() + 4, m * 8);
+        db.lut[m] = db.total;
+        db.suf.assign(suf.begin() + 4, suf.end() - 4);
+        return true;
+    }
+    if (version != 0) return false;
     uint64_t size = pre.size() - 8;                        // without the two markers
     uint64_t header_offset = pre[pre.size() - 8];          // kmc_file.cpp:245-246
     size -= 4;
@@ -251,6 +272,7 @@ bool kmc_open(const std::string &prefix, KmcDb &db) {
 void kmc_record(const KmcDb &db, uint64_t n, uint64_t prefix, std::string &kmer, uint32_t &count) {
     static const char nt[4] = {'A', 'C', 'G', 'T'};
     kmer.resize(db.k);
+    prefix &= (1ULL << (2 * db.p)) - 1;   // KMC2: the LUT index runs over all bins ("& prefix_mask", kmc_file.cpp:430,449)
     for (unsigned i = 0; i < db.p; i++) kmer[i] = nt[(prefix >> (2 * (db.p - 1 - i))) & 3];
     const unsigned sb = (db.k - db.p) / 4;
     const unsigned char *rec = db.suf.data() + n * (sb + db.counter_size);
@@ -510,6 +532,62 @@ int orc_kmc_write(const char *prefix, const char *kmers, const uint32_t *counts,
     return 0;
 }
 
+// KMC2 ("0x200") writer for tests: the k-mers (sorted ascending, canonical) are dealt into `nbins` bins (bin = a hash of the k-mer, as
+// KMC's signature binning does by minimiser), each bin sorted; per-bin prefix LUTs hold ABSOLUTE record offsets (kmc_file.cpp:428-447)
+int orc_kmc2_write(const char *prefix, const char *kmers, const uint32_t *counts, uint64_t n, unsigned k, unsigned p, unsigned counter_size, unsigned nbins) {
+    if ((k - p) % 4 || nbins == 0) return 1;
+    const uint64_t nlut = 1ULL << (2 * p);
+    const unsigned sb = (k - p) / 4;
+    std::vector<std::vector<uint64_t>> bin(nbins);
+    for (uint64_t i = 0; i < n; i++) bin[ntp64(kmers + i * k, k) % nbins].push_back(i);   // input order is sorted, so every bin stays sorted
+    std::vector<uint64_t> lut;
+    std::vector<unsigned char> suf;
+    uint64_t at = 0;
+    for (unsigned b = 0; b < nbins; b++) {
+        std::vector<uint64_t> per(nlut, 0);
+        for (uint64_t i : bin[b]) {
+            const char *km = kmers + i * k;
+            uint64_t pre = 0;
+            for (unsigned j = 0; j < p; j++) pre = (pre << 2) | (uint64_t)nt_code(km[j]);
+            per[pre]++;
+            for (unsigned x = 0; x < sb; x++) {
+                unsigned char byte = 0;
+                for (unsigned j = 0; j < 4; j++) byte = (unsigned char)((byte << 2) | nt_code(km[p + 4 * x + j]));
+                suf.push_back(byte);
+            }
+            for (unsigned x = 0; x < counter_size; x++) suf.push_back((unsigned char)((counts[i] >> (8 * x)) & 0xFF));
+        }
+        for (uint64_t j = 0; j < nlut; j++) {
+            lut.push_back(at);
+            at += per[j];
+        }
+    }
+    lut.push_back(at);   // guard word (the reader overwrites it with total + 1)
+    const uint32_t signature_len = 5;
+    std::vector<uint32_t> sigmap((1u << (2 * signature_len)) + 1, 0);
+    unsigned char header[48] = {0};
+    const uint32_t f[7] = {k, 0, counter_size, p, signature_len, 1, 255};
+    memcpy(header, f, 28);
+    memcpy(header + 28, &n, 8);
+    header[36] = 0;   // both-strands byte: 0 => canonical counting
+    const uint32_t version = 0x200;
+    memcpy(header + 44, &version, 4);
+    std::ofstream fp(std::string(prefix) + ".kmc_pre", std::ios::binary);
+    std::ofstream fs(std::string(prefix) + ".kmc_suf", std::ios::binary);
+    if (!fp.is_open() || !fs.is_open()) return 2;
+    fp.write("KMCP", 4);
+    fp.write((const char *)lut.data(), (std::streamsize)(lut.size() * 8));
+    fp.write((const char *)sigmap.data(), (std::streamsize)(sigmap.size() * 4));
+    fp.write((const char *)header, 48);
+    const uint32_t header_offset = 48;
+    fp.write((const char *)&header_offset, 4);
+    fp.write("KMCP", 4);
+    fs.write("KMCS", 4);
+    fs.write((const char *)suf.data(), (std::streamsize)suf.size());
+    fs.write("KMCS", 4);
+    return 0;
+}
+
 void *orc_kmc_open(const char *prefix) {
     KmcDb *db = new KmcDb();
     if (!kmc_open(prefix, *db)) {
@@ -526,6 +604,7 @@ void orc_kmc_info(void *h, unsigned *k, unsigned *p, unsigned *counter_size, uin
     *counter_size = db->counter_size;
     *total = db->total;
 }
+uint64_t orc_kmc_lut_entries(void *h) { return ((KmcDb *)h)->lut.size(); }
 void orc_kmc_lut(void *h, uint64_t *out) { memcpy(out, ((KmcDb *)h)->lut.data(), ((KmcDb *)h)->lut.size() * 8); }
 uint64_t orc_kmc_payload_size(void *h) { return ((KmcDb *)h)->suf.size(); }
 void orc_kmc_payload(void *h, uint8_t *out) { memcpy(out, ((KmcDb *)h)->suf.data(), ((KmcDb *)h)->suf.size()); }

@@ -136,6 +136,14 @@ class Oracle:
         return kmers, valid
 
     # ---- KMC ----
+    def kmc2_write(self, prefix, kmers_ascii, counts, k, p, counter_size=1, nbins=4):
+        """KMC2 ("0x200") layout: signature bins with their own prefix tables"""
+        a = ascii_kmers(kmers_ascii)
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        self.l.orc_kmc2_write.argtypes = [C.c_char_p, vp, vp, C.c_uint64, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+        rc = self.l.orc_kmc2_write(prefix.encode(), _ptr(a), _ptr(c), len(c), k, p, counter_size, nbins)
+        assert rc == 0, f"orc_kmc2_write failed ({rc})"
+
     def kmc_write(self, prefix, kmers_ascii, counts, k, p, counter_size=1):
         a = ascii_kmers(kmers_ascii)
         c = np.ascontiguousarray(counts, dtype=np.uint32)
@@ -327,7 +335,9 @@ class OrcKmc:
         self.rec_size = (self.k - self.p) // 4 + self.counter_size
 
     def lut(self):
-        out = np.zeros(4 ** self.p + 1, dtype=np.uint64)
+        self.o.l.orc_kmc_lut_entries.restype = C.c_uint64
+        self.o.l.orc_kmc_lut_entries.argtypes = [vp]
+        out = np.zeros(self.o.l.orc_kmc_lut_entries(self.h), dtype=np.uint64)   # 4^p + 1 (KMC1) or bins * 4^p + 1 (KMC2)
         self.o.l.orc_kmc_lut(self.h, _ptr(out))
         return out
 

@@ -562,7 +562,10 @@ def test_parse_sample_kmers_host_driver(gpu_ctx, oracle, tmp_path):
         sel = km[rng.random(len(km)) < 0.8]
         cnt = rng.integers(1, 250, len(sel)).astype(np.uint32)
         pref = str(tmp_path / f"s{s}")
-        oracle.kmc_write(pref, np.ascontiguousarray(sel).reshape(-1), cnt, K, 7 if s else 3, 1)
+        if s == 0:
+            oracle.kmc_write(pref, np.ascontiguousarray(sel).reshape(-1), cnt, K, 3, 1)          # KMC1 layout
+        else:
+            oracle.kmc2_write(pref, np.ascontiguousarray(sel).reshape(-1), cnt, K, 7, 1, 6)      # KMC2 layout: 6 signature bins
         db = OrcKmc(oracle, pref)
         hits_o = ot.parse_sample_kmers(ob, db, s)
         db.close()

@@ -213,3 +213,27 @@ def test_parse_sample_kmers_oracle_consistency(oracle, tmp_path):
     assert (pc[:, 0] == 0).all() and (pc[:, 2] == 0).all()
     for x in (t, bloom, db):
         x.close()
+
+
+@pytest.mark.parametrize("nbins", [1, 5])
+def test_kmc2_database_layout_vs_reference(oracle, ref, tmp_path, nbins):
+    """KMC2 ("0x200") databases — one prefix table per signature bin: the reference's CKMCFile lists what the test writer wrote
+    (pins the layout), and the oracle's reader lists the same records in the same order."""
+    rng = np.random.default_rng(17)
+    km = np.unique(_oracle.canonical_ascii(oracle, _oracle.random_kmers(rng, 3000, K), K).reshape(-1, K), axis=0)
+    cnt = rng.integers(1, 250, len(km)).astype(np.uint32)
+    prefix = str(tmp_path / "db2")
+    oracle.kmc2_write(prefix, np.ascontiguousarray(km).reshape(-1), cnt, K, 3, 1, nbins)
+    k, mode, c, pp = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint()
+    total = ref.l.ref_kmc_total(prefix.encode(), C.byref(k), C.byref(mode), C.byref(c), C.byref(pp))
+    assert total == len(km) and (k.value, mode.value, c.value, pp.value) == (K, 0, 1, 3)
+    rk = np.zeros(total * K, np.uint8)
+    rc = np.zeros(total, np.uint32)
+    assert ref.l.ref_kmc_list(prefix.encode(), _ptr(rk), _ptr(rc), total) == total
+    db = _oracle.OrcKmc(oracle, prefix)
+    ok, oc = db.list()
+    db.close()
+    assert np.array_equal(ok.reshape(-1), rk) and np.array_equal(oc, rc)
+    # same multiset as written (bins reorder the records)
+    order = np.lexsort(rk.reshape(-1, K).T[::-1])
+    assert np.array_equal(rk.reshape(-1, K)[order], km) and np.array_equal(rc[order], cnt)
