@@ -424,6 +424,37 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
     }
 }
 
+// makeBloom (src/bayesTyperTools/MakeBloom.cpp:200-295): every record's k-mer goes into the sample's KmerBloom.  Same staging as
+// kmc_scan_kernel; the insert is an atomicOr per probe (order-independent, so the filter bytes equal the reference's).
+__global__ __launch_bounds__(BLOCK) void kmc_make_bloom_kernel(KmcView v, BloomView bloom, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[KMC_RECS * KMC_MAX_REC + 32];
+    const uint64_t num_chunks = (n + KMC_RECS - 1) / KMC_RECS;
+    for (uint64_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
+        const uint64_t rec0 = chunk * KMC_RECS;
+        const unsigned nrec = (unsigned)((n - rec0) < KMC_RECS ? (n - rec0) : KMC_RECS);
+        const uint64_t byte0 = rec0 * v.rec_size;
+        const unsigned nbytes = nrec * v.rec_size;
+        const uint64_t a0 = byte0 & ~15ULL;
+        const unsigned lead = (unsigned)(byte0 - a0);
+        const unsigned nvec = (lead + nbytes + 15u) / 16u;
+        const uint64_t total_bytes = n * (uint64_t)v.rec_size;
+        for (unsigned j = threadIdx.x; j < nvec; j += BLOCK) {
+            const uint64_t off = a0 + (uint64_t)j * 16u;
+            if (off + 16u <= total_bytes) *reinterpret_cast<uint4 *>(&stage[j * 16u]) = *reinterpret_cast<const uint4 *>(records + off);
+            else
+                for (unsigned q = 0; q < 16u; ++q) stage[j * 16u + q] = (off + q < total_bytes) ? records[off + q] : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x < nrec) {
+            Kmer a;
+            uint32_t count;
+            kmc_decode(v, kmc_prefix_of(v, first_record + rec0 + threadIdx.x), &stage[lead + threadIdx.x * v.rec_size], a, count);
+            bloom_insert(nthash64(a, v.k), bloom);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -814,6 +845,19 @@ int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, 
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return fail(std::string("bt_kmc_scan_run_host: ") + hipGetErrorString(e));
     if (h_hit_count) *h_hit_count = hits;
+    return BT_OK;
+}
+
+int bt_kmc_scan_make_bloom(bt_kmc_scan *s, bt_bloom *sample_bloom, const uint8_t *d_records, uint64_t first_record, uint64_t n) {
+    if (!s || !sample_bloom) return fail("bt_kmc_scan_make_bloom: null argument");
+    if (sample_bloom->k != s->k) return fail("bt_kmc_scan_make_bloom: k mismatch");
+    if (first_record + n > s->total) return fail("bt_kmc_scan_make_bloom: record range exceeds the database");
+    if ((reinterpret_cast<uintptr_t>(d_records) & 15u) != 0) return fail("bt_kmc_scan_make_bloom: d_records must be 16-byte aligned");
+    if (n == 0) return BT_OK;
+    BT_HIP(hipSetDevice(s->ctx->device));
+    unsigned grid = grid_for((n + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8);
+    hipLaunchKernelGGL(kmc_make_bloom_kernel, dim3(grid), dim3(BLOCK), 0, s->ctx->stream, make_kmc_view(s), sample_bloom->view(), d_records, first_record, n);
+    BT_CHECK_LAUNCH();
     return BT_OK;
 }
 

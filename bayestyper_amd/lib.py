@@ -81,6 +81,7 @@ bt_table_count_intercluster = _sig("bt_table_count_intercluster", [vp, vp, vp, C
 bt_table_classify_batch = _sig("bt_table_classify_batch", [vp, vp, vp, vp, C.c_uint64, vp])
 bt_kmc_scan_create = _sig("bt_kmc_scan_create", [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.POINTER(vp)])
 bt_kmc_scan_create_bins = _sig("bt_kmc_scan_create_bins", [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint64, C.POINTER(vp)])
+bt_kmc_scan_make_bloom = _sig("bt_kmc_scan_make_bloom", [vp, vp, vp, C.c_uint64, C.c_uint64])
 bt_kmc_scan_destroy = _sig("bt_kmc_scan_destroy", [vp])
 bt_kmc_scan_run = _sig("bt_kmc_scan_run", [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.c_uint64, vp])
 bt_kmc_scan_decode = _sig("bt_kmc_scan_decode", [vp, vp, C.c_uint64, C.c_uint64, vp, vp])
@@ -441,6 +442,9 @@ class KmcScan:
         h = vp()
         check(bt_kmc_scan_create_bins(ctx.h, k, p, counter_size, total, _np_ptr(lut), len(lut), C.byref(h)))   # len: 4^p + 1, or bins * 4^p + 1 (KMC2)
         self.h = h.value
+
+    def make_bloom(self, bloom, d_records_ptr, first_record, n):
+        check(bt_kmc_scan_make_bloom(self.h, bloom.h, d_records_ptr, first_record, n))
 
     def run(self, bloom, table, sample_idx, d_records_ptr, first_record, n, d_hits_ptr=None):
         check(bt_kmc_scan_run(self.h, bloom.h, table.h, sample_idx, d_records_ptr, first_record, n, d_hits_ptr))

@@ -224,6 +224,10 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
  * chunk_records = records per transfer (0: default 2^24); *h_hit_count = number of Bloom hits. */
 int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records,
                          uint64_t first_record, uint64_t n, uint64_t chunk_records, uint64_t *h_hit_count);
+/* bayesTyperTools makeBloom (src/bayesTyperTools/MakeBloom.cpp:200-295): the k-mers of records [first_record, first_record + n)
+ * are added to a sample's KmerBloom (created with bt_bloom_create(ctx, total_kmers, fpr, k, 0, ..), written with bt_bloom_save:
+ * byte-identical .bloomMeta / .bloomData, insertion being an order-independent OR) */
+int bt_kmc_scan_make_bloom(bt_kmc_scan *s, bt_bloom *sample_bloom, const uint8_t *d_records, uint64_t first_record, uint64_t n);
 /* decode only (tests): d_kmers[2*i..] = packed k-mer of record i, d_counts[i] = its count */
 int bt_kmc_scan_decode(bt_kmc_scan *s, const uint8_t *d_records, uint64_t first_record, uint64_t n,
                        uint64_t *d_kmers, uint32_t *d_counts);

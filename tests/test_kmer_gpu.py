@@ -577,3 +577,32 @@ def test_parse_sample_kmers_host_driver(gpu_ctx, oracle, tmp_path):
     assert np.array_equal(gk, wk) and np.array_equal(gc, wc) and np.array_equal(gm, wm) and len(wk) > 5000
     for x in (ob, gb, ot, gt):
         x.close()
+
+
+def test_make_bloom_from_kmc(gpu_ctx, oracle, tmp_path):
+    """bayesTyperTools makeBloom: KMC database -> sample KmerBloom; .bloomMeta / .bloomData byte-identical to the oracle's filter
+    (which the reference's KmerBloom reads: tests/test_oracle_kmer.py)."""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(71)
+    km = np.unique(_oracle.canonical_ascii(oracle, _oracle.random_kmers(rng, 30_000, K), K).reshape(-1, K), axis=0)
+    pref = str(tmp_path / "sample")
+    oracle.kmc2_write(pref, np.ascontiguousarray(km).reshape(-1), np.ones(len(km), np.uint32), K, 7, 1, 3)
+    db = OrcKmc(oracle, pref)
+    ob = OrcBloom(oracle, db.total, 1e-3, K)                      # KmerBloom(total_kmers, fpr), MakeBloom.cpp:218
+    ob.insert(db.list()[0].reshape(-1))
+    gb = lib.Bloom.create(gpu_ctx, db.total, 1e-3, K, threaded=False)
+    sc = lib.KmcScan(gpu_ctx, db.k, db.p, db.counter_size, db.total, db.lut())
+    buf = gpu_ctx.to_device(db.payload())
+    half = (db.total // 2) // 16 * 16
+    sc.make_bloom(gb, buf.ptr, 0, half)
+    sc.make_bloom(gb, buf.ptr + half * db.rec_size, half, db.total - half)
+    gpu_ctx.sync()
+    assert np.array_equal(gb.bits(0), ob.bits(0))
+    gb.save(str(tmp_path / "g"))
+    ob.save(str(tmp_path / "o"))
+    for ext in (".bloomMeta", ".bloomData"):
+        assert open(str(tmp_path / "g") + ext, "rb").read() == open(str(tmp_path / "o") + ext, "rb").read()
+    for x in (sc, gb, ob, db):
+        x.close()
+    buf.free()
