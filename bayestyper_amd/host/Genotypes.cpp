@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <sstream>
 #include <stdexcept>
 
 namespace bthost {
@@ -123,6 +124,85 @@ std::vector<VariantGenotypes> getGenotypes(const ClusterResults &r, const Filter
             for (uint32_t a = 0; a + 1 < A; ++a) vs.alt_allele_frequency[a] = vs.alt_allele_counts[a] / (float)vs.total_count;
     }
     return out;
+}
+
+namespace {
+template <typename T>
+void writeAlleleField(std::ostream &o, const std::vector<T> &v) {   // GenotypeWriter.cpp:130-143
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i) o << ",";
+        o << v[i];
+    }
+}
+}  // namespace
+
+std::string formatVariantStatsColumns(const VariantGenotypes &g) {
+    std::ostringstream o;
+    const VariantStats &vs = g.variant_stats;
+    if (floatCompare(vs.max_alt_allele_call_probability, 1)) o << "99";
+    else if (floatCompare(vs.max_alt_allele_call_probability, 0)) o << "0";
+    else o << -10 * std::log10(1 - vs.max_alt_allele_call_probability);
+    o << (vs.total_count == 0 ? "\tAN0" : "\tPASS");
+    o << "\tAC=";
+    writeAlleleField(o, vs.alt_allele_counts);
+    o << ";AF=";
+    writeAlleleField(o, vs.alt_allele_frequency);
+    o << ";AN=" << vs.total_count << ";ACP=";
+    writeAlleleField(o, vs.allele_call_probabilities);
+    if (!g.non_covered_alleles.empty()) {
+        std::vector<uint16_t> nc = g.non_covered_alleles;
+        std::sort(nc.begin(), nc.end());
+        o << ";ANC=";
+        writeAlleleField(o, nc);
+    }
+    return o.str();
+}
+
+std::string formatSampleColumns(const ClusterResults &r, uint32_t variant, const VariantGenotypes &g) {
+    std::ostringstream o;
+    uint32_t allele_base = 0, A_total = 0;
+    for (uint32_t v = 0; v < r.V; ++v) {
+        if (v < variant) allele_base += r.var_num_alleles[v];
+        A_total += r.var_num_alleles[v];
+    }
+    const uint32_t A = r.var_num_alleles[variant];
+    for (uint32_t s = 0; s < r.S; ++s) {
+        const SampleStats &st = g.sample_stats[s];
+        o << "\t";
+        if (st.genotype_estimate.empty()) {
+            o << ":" << ".:.:.:.:.:.";   // empty_variant_sample (GenotypeWriter.cpp:58,319): the GT column itself stays empty
+            continue;
+        }
+        for (size_t i = 0; i < st.genotype_estimate.size(); ++i) {
+            if (i) o << "/";
+            if (st.genotype_estimate[i] != NONE) o << st.genotype_estimate[i];
+            else o << ".";
+        }
+        o << ":" << st.genotype_quality << ":";
+        writeAlleleField(o, st.genotype_posteriors);
+        o << ":";
+        writeAlleleField(o, st.allele_posteriors);
+        o << ":";
+        {   // writeAlleleKmerStats: the means of the count / fraction / mean statistics per allele, -1 when nothing was added
+            std::ostringstream counts, fractions, means;
+            for (uint32_t a = 0; a < A; ++a) {
+                const double *cell = r.stats + ((size_t)s * A_total + allele_base + a) * 12;
+                auto mean_of = [](const double *ks) { return ks[0] == 0 ? -1.0 : ks[2]; };   // KmerStats::getMean (KmerStats.cpp:82-92)
+                if (a) {
+                    counts << ",";
+                    fractions << ",";
+                    means << ",";
+                }
+                counts << mean_of(cell);
+                fractions << mean_of(cell + 4);
+                means << mean_of(cell + 8);
+            }
+            o << counts.str() << ":" << fractions.str() << ":" << means.str();
+        }
+        o << ":";
+        writeAlleleField(o, st.allele_filters);
+    }
+    return o.str();
 }
 
 }  // namespace bthost

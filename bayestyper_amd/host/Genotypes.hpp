@@ -4,6 +4,7 @@
 // (AC, AF, ACP, AN).  Input is exactly what bt_gibbs_result_fetch returns for a cluster.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace bthost {
@@ -54,5 +55,12 @@ struct ClusterResults {
 };
 
 std::vector<VariantGenotypes> getGenotypes(const ClusterResults &r, const Filters &filters);
+
+// The genotype-derived columns of one variant's output line as GenotypeWriter writes them (src/bayesTyper/GenotypeWriter.cpp):
+// "<QUAL>\t<FILTER>\tAC=..;AF=..;AN=..;ACP=..[;ANC=..]" (writeQualityAndFilter :174-200, writeVariantStats :202-218, writeAlleleCover
+// :220-230) and, per sample, "\tGT:GQ:GPP:APP:NAK:FAK:MAC:SAF" (writeSamples :261-322, writeAlleleKmerStats :324-345) with the
+// default ostream formatting the reference uses.  `variant` = index of the variant inside the cluster (for the k-mer statistics).
+std::string formatVariantStatsColumns(const VariantGenotypes &g);
+std::string formatSampleColumns(const ClusterResults &r, uint32_t variant, const VariantGenotypes &g);
 
 }  // namespace bthost

@@ -188,4 +188,29 @@ int bth_kmc_info(const char *kmc_prefix, unsigned long long *out) {
     }
 }
 
+
+// the genotype-derived output columns of every variant of one cluster, one line per variant ("<stats columns><sample columns>\n");
+// returns the number of bytes needed (call with out = NULL first)
+long long bth_cluster_output_columns(unsigned S, unsigned H, unsigned V, const uint16_t *hap_allele, const uint16_t *var_num_alleles, const uint8_t *var_has_dependency,
+                                     unsigned long long num_diplotypes, const uint16_t *h1, const uint16_t *h2, const uint32_t *freq, const double *stats,
+                                     const uint8_t *ploidy, float min_gpp, float min_kmers, const float *min_fraction, char *out, unsigned long long out_len) {
+    try {
+        ClusterResults r;
+        r.S = S; r.H = H; r.V = V;
+        r.hap_allele = hap_allele; r.var_num_alleles = var_num_alleles; r.var_has_dependency = var_has_dependency;
+        r.num_diplotypes = num_diplotypes; r.h1 = h1; r.h2 = h2; r.freq = freq; r.stats = stats; r.ploidy = ploidy;
+        Filters f;
+        f.min_genotype_posterior = min_gpp;
+        f.min_number_of_kmers = min_kmers;
+        f.min_fraction_observed_kmers.assign(min_fraction, min_fraction + S);
+        const auto res = getGenotypes(r, f);
+        std::string all;
+        for (unsigned v = 0; v < V; v++) all += formatVariantStatsColumns(res[v]) + formatSampleColumns(r, v, res[v]) + "\n";
+        if (out && out_len >= all.size()) std::memcpy(out, all.data(), all.size());
+        return (long long)all.size();
+    } catch (...) {
+        return -1;
+    }
+}
+
 }  // extern "C"

@@ -57,3 +57,38 @@ def cluster_genotypes(flat, res, c, ploidy, min_fraction, min_gpp=0.99, min_kmer
         raise RuntimeError("cluster_genotypes failed")
     out["num_alleles"] = vna
     return out
+
+
+def cluster_output_columns(flat, res, c, ploidy, min_fraction, min_gpp=0.99, min_kmers=1.0, fn=None):
+    """the genotype-derived columns of GenotypeWriter's line (QUAL, FILTER, AC/AF/AN/ACP[/ANC], sample columns) for every variant of
+    cluster c: list of strings, one per variant.  fn: libbthost's entry (default) or the oracle's restatement."""
+    if fn is None:
+        from . import dll
+
+        fn = dll.bth_cluster_output_columns
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_float, C.c_float, C.c_void_p, C.c_char_p, C.c_ulonglong]
+    S = flat["S"]
+    H, V = int(flat["num_haplotypes"][c]), int(flat["num_variants"][c])
+    hv0 = int(np.sum(flat["num_haplotypes"][:c].astype(np.int64) * flat["num_variants"][:c].astype(np.int64)))
+    v0 = int(np.sum(flat["num_variants"][:c]))
+    hap_allele = np.ascontiguousarray(flat["hap_allele"][hv0:hv0 + H * V], np.uint16)
+    vna = np.ascontiguousarray(flat["var_num_alleles"][v0:v0 + V], np.uint16)
+    vdep = np.ascontiguousarray(flat["var_has_dependency"][v0:v0 + V], np.uint8)
+    e0, e1 = int(res["dip_off"][c]), int(res["dip_off"][c + 1])
+    arrs = [np.ascontiguousarray(res["h1"][e0:e1], np.uint16), np.ascontiguousarray(res["h2"][e0:e1], np.uint16),
+            np.ascontiguousarray(res["freq"][e0:e1], np.uint32).reshape(-1),
+            np.ascontiguousarray(res["stats"][int(res["cell_off"][c]):int(res["cell_off"][c + 1])], np.float64).reshape(-1)]
+    for a in arrs:
+        if a.size == 0:
+            a.resize(1, refcheck=False)
+    pl = np.ascontiguousarray(ploidy, np.uint8)
+    mf = np.ascontiguousarray(min_fraction, np.float32)
+    args = [S, H, V, _p(hap_allele), _p(vna), _p(vdep), e1 - e0, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(pl), min_gpp, min_kmers, _p(mf)]
+    n = fn(*args, None, 0)
+    if n < 0:
+        raise RuntimeError("cluster_output_columns failed")
+    buf = C.create_string_buffer(int(n) + 1)
+    fn(*args, buf, n)
+    return buf.raw[:n].decode().split("\n")[:-1]

@@ -28,6 +28,8 @@
 #include <limits>
 #include <map>
 #include <random>
+#include <sstream>
+#include <string>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -1198,6 +1200,90 @@ int orc_cluster_genotypes(unsigned S, unsigned H, unsigned V, const uint16_t *ha
         for (ushort a = 0; a < num_alleles; a++) acp[(size_t)variant_idx * Amax + a] = allele_call_probabilities[a];
     }
     return 0;
+}
+
+
+// The genotype-derived columns of GenotypeWriter's output line for every variant of a cluster (GenotypeWriter.cpp:174-230,261-345),
+// from the arrays orc_cluster_genotypes fills.  One line per variant.
+long long orc_cluster_output_columns(unsigned S, unsigned H, unsigned V, const uint16_t *hap_allele, const uint16_t *var_num_alleles, const uint8_t *var_has_dependency,
+                                     unsigned long long num_diplotypes, const uint16_t *h1, const uint16_t *h2, const uint32_t *freq, const double *stats,
+                                     const uint8_t *ploidy, float min_gpp, float min_kmers, const float *min_fraction, char *out, unsigned long long out_len) {
+    unsigned Amax = 0, allele_total = 0;
+    for (unsigned v = 0; v < V; v++) {
+        Amax = std::max<unsigned>(Amax, var_num_alleles[v]);
+        allele_total += var_num_alleles[v];
+    }
+    const unsigned Gmax = Amax * (Amax + 1) / 2;
+    std::vector<float> gpp((size_t)V * S * Gmax, 0), app((size_t)V * S * Amax, 0), alt_freq((size_t)V * Amax, 0), acp((size_t)V * Amax, 0), max_alt(V, 0);
+    std::vector<uint16_t> filters((size_t)V * S * Amax, 0), estimate((size_t)V * S * 2, 0);
+    std::vector<uint32_t> gq((size_t)V * S, 0), total_count(V, 0), alt_counts((size_t)V * Amax, 0);
+    std::vector<uint8_t> non_covered((size_t)V * Amax, 0);
+    orc_cluster_genotypes(S, H, V, hap_allele, var_num_alleles, var_has_dependency, num_diplotypes, h1, h2, freq, stats, ploidy, min_gpp, min_kmers, min_fraction, Amax,
+                          gpp.data(), app.data(), filters.data(), estimate.data(), gq.data(), total_count.data(), alt_counts.data(), alt_freq.data(), acp.data(),
+                          max_alt.data(), non_covered.data());
+    std::stringstream line;
+    unsigned allele_first = 0;
+    for (unsigned v = 0; v < V; v++) {
+        const unsigned num_alleles = var_num_alleles[v];
+        // writeQualityAndFilter
+        if (floatCompareO(max_alt[v], 1)) line << "99";
+        else if (floatCompareO(max_alt[v], 0)) line << "0";
+        else line << -10 * std::log10(1 - max_alt[v]);
+        line << (total_count[v] == 0 ? "\tAN0" : "\tPASS");
+        // writeVariantStats
+        line << "\tAC=";
+        for (unsigned a = 0; a + 1 < num_alleles; a++) line << (a ? "," : "") << alt_counts[(size_t)v * Amax + a];
+        line << ";AF=";
+        for (unsigned a = 0; a + 1 < num_alleles; a++) line << (a ? "," : "") << alt_freq[(size_t)v * Amax + a];
+        line << ";AN=" << total_count[v] << ";ACP=";
+        for (unsigned a = 0; a < num_alleles; a++) line << (a ? "," : "") << acp[(size_t)v * Amax + a];
+        // writeAlleleCover
+        bool first = true;
+        for (unsigned a = 0; a < num_alleles; a++)
+            if (non_covered[(size_t)v * Amax + a]) {
+                line << (first ? ";ANC=" : ",") << a;
+                first = false;
+            }
+        // writeSamples
+        for (unsigned s = 0; s < S; s++) {
+            const size_t vs = (size_t)v * S + s;
+            line << "\t";
+            if (ploidy[s] == 0) {
+                line << ":" << ".:.:.:.:.:.";
+                continue;
+            }
+            for (unsigned i = 0; i < ploidy[s]; i++) {
+                if (i > 0) line << "/";
+                if (estimate[vs * 2 + i] != 0xFFFF) line << estimate[vs * 2 + i];
+                else line << ".";
+            }
+            line << ":" << gq[vs] << ":";
+            const unsigned ng = ploidy[s] == 2 ? (num_alleles * (num_alleles - 1)) / 2 + num_alleles : num_alleles;
+            for (unsigned g = 0; g < ng; g++) line << (g ? "," : "") << gpp[vs * Gmax + g];
+            line << ":";
+            for (unsigned a = 0; a < num_alleles; a++) line << (a ? "," : "") << app[vs * Amax + a];
+            line << ":";
+            std::stringstream allele_kmer_counts, allele_kmer_fractions, allele_kmer_means;
+            for (unsigned a = 0; a < num_alleles; a++) {
+                const double *cell = stats + ((size_t)s * allele_total + allele_first + a) * 12;
+                if (a) {
+                    allele_kmer_counts << ",";
+                    allele_kmer_fractions << ",";
+                    allele_kmer_means << ",";
+                }
+                allele_kmer_counts << (cell[0] == 0 ? -1.0 : cell[2]);        // KmerStats::getMean(): (-1, false) when empty
+                allele_kmer_fractions << (cell[4] == 0 ? -1.0 : cell[6]);
+                allele_kmer_means << (cell[8] == 0 ? -1.0 : cell[10]);
+            }
+            line << allele_kmer_counts.str() << ":" << allele_kmer_fractions.str() << ":" << allele_kmer_means.str() << ":";
+            for (unsigned a = 0; a < num_alleles; a++) line << (a ? "," : "") << filters[vs * Amax + a];
+        }
+        line << "\n";
+        allele_first += num_alleles;
+    }
+    const std::string all = line.str();
+    if (out && out_len >= all.size()) memcpy(out, all.data(), all.size());
+    return (long long)all.size();
 }
 
 }  // extern "C"

@@ -51,3 +51,31 @@ def test_host_genotypes_match_oracle_and_are_consistent(oracle):
                         assert a["gpp"][v, s, gi] >= 0.99 - 1e-6 and a["gpp"][v, s, gi] == a["gpp"][v, s].max()
                 assert a["total_count"][v] == sum(int(x != 0xFFFF) for s in range(S) for x in a["estimate"][v, s][: int(ploidy[g, s])])
     assert called > 10
+
+
+def test_output_columns_match_oracle(oracle):
+    """QUAL / FILTER / AC,AF,AN,ACP,ANC and the per-sample GT:GQ:GPP:APP:NAK:FAK:MAC:SAF columns, character for character"""
+    S = 3
+    flat, ploidy = _batch(S)
+    lut_g, lut_n = _oracle.build_luts(oracle, S)
+    og = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, seed=5, chains=2, burn=10, iters=25)
+    og.run(4)
+    res = og.results()
+    og.close()
+    mf = genotypes.min_fraction_observed_kmers([15.0] * S)
+    goff = flat["group_cluster_off"]
+    seen_pass = seen_an0 = seen_null = False
+    for g in range(flat["num_groups"]):
+        for c in range(goff[g], goff[g + 1]):
+            a = genotypes.cluster_output_columns(flat, res, c, ploidy[g], mf)
+            b = genotypes.cluster_output_columns(flat, res, c, ploidy[g], mf, fn=oracle.l.orc_cluster_output_columns)
+            assert a == b and len(a) == int(flat["num_variants"][c])
+            for line in a:
+                cols = line.split("\t")
+                assert len(cols) == 3 + S and cols[1] in ("PASS", "AN0") and cols[2].startswith("AC=")
+                seen_pass |= cols[1] == "PASS"
+                seen_an0 |= cols[1] == "AN0"
+                seen_null |= any(x == ":.:.:.:.:.:." for x in cols[3:])
+                for x in cols[3:]:
+                    assert x == ":.:.:.:.:.:." or x.count(":") == 7
+    assert seen_pass and seen_null

@@ -258,6 +258,8 @@ def test_genotype_posteriors_gpp_gq_calls(gpu_ctx, oracle):
                 assert np.array_equal(a[k], b[k]), (c, k)
             assert np.allclose(a["acp"], b["acp"], atol=TOL) and np.allclose(a["alt_freq"], b["alt_freq"], atol=TOL)
             calls += int((a["estimate"][:, :, 0] != 0xFFFF).sum())
+            # and the text GenotypeWriter would emit for these variants (QUAL, FILTER, INFO statistics, sample columns)
+            assert genotypes.cluster_output_columns(flat, rg, c, ploidy[g], mf) == genotypes.cluster_output_columns(flat, ro, c, ploidy[g], mf, fn=oracle.l.orc_cluster_output_columns)
     assert calls > 50
 
 
