@@ -1,9 +1,11 @@
 // C entry points of libbthost.so used by the Python tests and bench.py (ctypes).  The C++ classes in this directory
 // are the host layer proper; this file only exposes them.
+#include <algorithm>
 #include <cstring>
 
 #include "CountDistribution.hpp"
 #include "Genotypes.hpp"
+#include "InferenceEngine.hpp"
 #include "KmcFile.hpp"
 #include "VariantClusterGraph.hpp"
 
@@ -45,6 +47,30 @@ void bth_count_distribution_sample_noise(void *h, const unsigned long long *hist
         for (unsigned i = 0; i < 256; i++) ca.counts()[s][i] = hist[s * 256 + i];
     ((CountDistribution *)h)->sampleNoiseParameters(ca);
 }
+// NoiseGroupSelector (estimateNoise's per-chain choice of groups)
+void *bth_noise_selector_new(const uint32_t *clusters_per_group, const uint32_t *variants_per_group, uint32_t num_groups, unsigned seed, uint32_t batch_size) {
+    return new NoiseGroupSelector(clusters_per_group, variants_per_group, num_groups, seed, batch_size);
+}
+void bth_noise_selector_free(void *h) { delete (NoiseGroupSelector *)h; }
+// out must hold num_groups entries; returns the number of selected groups, *num_variants = variants they cover
+uint32_t bth_noise_selector_next_chain(void *h, uint32_t *out, uint32_t *num_variants) {
+    auto *sel = (NoiseGroupSelector *)h;
+    auto v = sel->nextChain();
+    std::memcpy(out, v.data(), v.size() * 4);
+    if (num_variants) *num_variants = sel->lastNumVariants();
+    return (uint32_t)v.size();
+}
+// row of the noise parameter file into buf (NUL-terminated, truncated to cap); returns the full length
+unsigned bth_noise_parameter_row(unsigned chain, unsigned iteration, const double *rates, unsigned S, char *buf, unsigned cap) {
+    std::string r = noiseParameterRow(chain, iteration, std::vector<double>(rates, rates + S));
+    if (cap) {
+        unsigned n = (unsigned)std::min<size_t>(r.size(), cap - 1);
+        std::memcpy(buf, r.data(), n);
+        buf[n] = 0;
+    }
+    return (unsigned)r.size();
+}
+
 void bth_count_distribution_tables(void *h, double *genomic, double *noise, unsigned S) {
     auto *cd = (CountDistribution *)h;
     if (genomic) std::memcpy(genomic, cd->genomicTable().data(), (size_t)S * 65536 * 8);

@@ -63,6 +63,11 @@ class CountDistribution:
         dll.bth_count_distribution_tables(self.h, g.ctypes.data, n.ctypes.data, self.S)
         return g, n
 
+    def noise_table(self):
+        n = np.zeros(self.S * 256)
+        dll.bth_count_distribution_tables(self.h, None, n.ctypes.data, self.S)
+        return n
+
     def close(self):
         if self.h:
             dll.bth_count_distribution_free(self.h)

@@ -192,3 +192,18 @@ def allreduce_noise_counts(hist):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     return hist
+
+
+def hist_reducer(device=None):
+    """callable(np.uint64[S*256]) -> histogram summed over all ranks, for host.inference_engine.InferenceEngine(reduce_hist=...).
+    The counters travel as int64 (all-reduce has no uint64; a count never approaches 2^63)."""
+    import torch
+
+    def reduce(hist):
+        t = torch.from_numpy(np.ascontiguousarray(hist).view(np.int64).copy())
+        if device is not None:
+            t = t.to(device)
+        allreduce_noise_counts(t)
+        return t.cpu().numpy().view(np.uint64)
+
+    return reduce

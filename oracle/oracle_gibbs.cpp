@@ -1287,3 +1287,159 @@ long long orc_cluster_output_columns(unsigned S, unsigned H, unsigned V, const u
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Noise drivers: InferenceEngine::estimateNoise (InferenceEngine.cpp:135-276) and ::estimateNoiseAndGenotypes (:384-472)
+// with the noise half of CountDistribution (CountDistribution.cpp:51-67 ctor, :163-171 resetNoiseRates, :173-186
+// sampleNoiseParameters, :188-199 calcCountSuffStats, :201-213 sampleGamma).  Single-threaded: the reference's worker
+// threads only add per-group histograms (integers) and touch disjoint groups, so thread count does not change results.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct NoiseModel {
+    std::vector<std::pair<float, float>> noise_rate_priors;
+    std::mt19937 prng;
+    std::gamma_distribution<> gamma_dist;
+    std::vector<double> noise_rates;
+    NoiseModel(uint S, float shape, float scale, uint seed) : noise_rate_priors(S, std::make_pair(shape, scale)), noise_rates(S, 0) {
+        prng = std::mt19937(seed);
+        resetNoiseRates();
+    }
+    double sampleGamma(const double shape, const double scale) {
+        gamma_dist.param(std::gamma_distribution<>::param_type(shape, scale));
+        return gamma_dist(prng);
+    }
+    void resetNoiseRates() {
+        for (uint s = 0; s < noise_rates.size(); s++) noise_rates[s] = sampleGamma(noise_rate_priors[s].first, noise_rate_priors[s].second);
+    }
+    void sampleNoiseParameters(const uint64_t *hist) {
+        for (uint s = 0; s < noise_rates.size(); s++) {
+            ulong num_observations = 0, count_sum = 0;
+            for (uint i = 0; i < 256; i++) {
+                num_observations += hist[s * 256 + i];
+                count_sum += i * hist[s * 256 + i];
+            }
+            noise_rates[s] = sampleGamma(noise_rate_priors[s].first + count_sum, noise_rate_priors[s].second / (num_observations * noise_rate_priors[s].second + 1));
+        }
+    }
+};
+void updateNoiseCache(OracleGibbs &O, const NoiseModel &nm) {
+    for (uint s = 0; s < nm.noise_rates.size(); s++)
+        for (uint c = 0; c < 256; c++) O.cd.noise[s * 256 + c] = noiseCountLogPmf(nm.noise_rates[s], (uchar)c);
+}
+void traceRow(std::vector<double> *trace, uint chain, uint iteration, const std::vector<double> &rates) {
+    if (!trace) return;
+    trace->push_back(chain);
+    trace->push_back(iteration);
+    trace->insert(trace->end(), rates.begin(), rates.end());
+}
+uint groupVariants(const OracleGibbs &O, const Group &G) {
+    uint n = 0;
+    for (auto &vx : G.vertices) n += O.B->num_variants[vx.cluster];
+    return n;
+}
+}  // namespace
+
+extern "C" {
+
+// h: an orc_gibbs_create()d unit with params.noise_seeding = 1.  rows of (chain, iteration, rate_0..rate_{S-1}) are written to
+// trace (capacity trace_cap doubles) exactly as the reference writes its noise parameter file; selected (optional, capacity
+// selected_cap) receives, per chain, the number of groups followed by their indices.  Returns the number of trace doubles.
+uint64_t orc_estimate_noise(void *h, float prior_shape, float prior_scale, uint32_t noise_variants_batch_size, double *trace, uint64_t trace_cap,
+                            uint32_t *selected, uint64_t selected_cap, double *final_rates) {
+    OracleGibbs &O = *(OracleGibbs *)h;
+    const uint S = O.P.num_samples;
+    NoiseModel cd(S, prior_shape, prior_scale, O.P.seed);
+    updateNoiseCache(O, cd);
+    std::vector<double> tr;
+    std::vector<uint32_t> sel;
+    std::vector<uint> noise_group_indices;
+    for (uint g = 0; g < O.groups.size(); g++)
+        if (O.groups[g].vertices.size() == 1) noise_group_indices.push_back(g);
+    std::vector<double> mean_noise_rates(S, 0);
+    std::mt19937 prng = std::mt19937(O.P.seed);
+    for (ushort chain = 0; chain < O.P.num_chains; chain++) {
+        std::shuffle(noise_group_indices.begin(), noise_group_indices.end(), prng);
+        uint end = 0, num_noise_variants = 0;
+        while ((num_noise_variants < noise_variants_batch_size) && (end < noise_group_indices.size())) {
+            num_noise_variants += groupVariants(O, O.groups[noise_group_indices[end]]);
+            end++;
+        }
+        std::sort(noise_group_indices.begin(), noise_group_indices.begin() + end);
+        sel.push_back(end);
+        for (uint j = 0; j < end; j++) sel.push_back(O.groups[noise_group_indices[j]].index);
+        for (uint j = 0; j < end; j++) {   // initGenotypersCallback :60-75
+            Group &G = O.groups[noise_group_indices[j]];
+            initGenotyper(O, G, O.P.seed + (G.index + 1) * (chain + 1));
+            shuffleBranchOrdering(G, O.P.seed + (G.index + 1) * (chain + 1));
+        }
+        traceRow(&tr, chain + 1, 0, cd.noise_rates);
+        for (uint iteration = 1; iteration <= (uint)O.P.burn_in + O.P.num_iterations; iteration++) {
+            std::vector<uint64_t> hist((size_t)S * 256, 0);
+            for (uint j = 0; j < end; j++) {   // sampleGenotypesCallback :77-98
+                Group &G = O.groups[noise_group_indices[j]];
+                uint32_t sweep_no = 0xFFFFFFFFu;
+                estimateGenotypes(O, G, false, nullptr, sweep_no);
+                for (auto &vx : G.vertices) {
+                    vx.genotyper->getNoiseCounts(hist.data());
+                    vx.genotyper->clearCache();
+                }
+            }
+            cd.sampleNoiseParameters(hist.data());
+            updateNoiseCache(O, cd);
+            traceRow(&tr, chain + 1, iteration, cd.noise_rates);
+            if (O.P.burn_in < iteration)
+                for (uint s = 0; s < S; s++) mean_noise_rates[s] += cd.noise_rates[s];
+        }
+        for (uint j = 0; j < end; j++)   // resetGroupsCallback :100-113
+            for (auto &vx : O.groups[noise_group_indices[j]].vertices) {
+                delete vx.genotyper;
+                vx.genotyper = nullptr;
+            }
+        cd.resetNoiseRates();
+        updateNoiseCache(O, cd);
+    }
+    for (uint s = 0; s < S; s++) mean_noise_rates[s] /= O.P.num_iterations * O.P.num_chains;
+    cd.noise_rates = mean_noise_rates;   // setNoiseRates
+    updateNoiseCache(O, cd);
+    traceRow(&tr, 0, 0, cd.noise_rates);
+    if (final_rates) std::copy(mean_noise_rates.begin(), mean_noise_rates.end(), final_rates);
+    if (trace) std::copy(tr.begin(), tr.begin() + std::min<uint64_t>(tr.size(), trace_cap), trace);
+    if (selected) std::copy(sel.begin(), sel.begin() + std::min<uint64_t>(sel.size(), selected_cap), selected);
+    return tr.size();
+}
+
+// estimateNoiseAndGenotypes over every group of the unit; afterwards orc_gibbs_result_* hold the collected samples
+uint64_t orc_estimate_noise_and_genotypes(void *h, float prior_shape, float prior_scale, double *trace, uint64_t trace_cap) {
+    OracleGibbs &O = *(OracleGibbs *)h;
+    const uint S = O.P.num_samples;
+    NoiseModel cd(S, prior_shape, prior_scale, O.P.seed);
+    updateNoiseCache(O, cd);
+    std::vector<double> tr;
+    for (ushort chain = 0; chain < O.P.num_chains; chain++) {
+        for (auto &G : O.groups) {
+            initGenotyper(O, G, O.P.seed + (G.index + 1) * (chain + 1));
+            shuffleBranchOrdering(G, O.P.seed + (G.index + 1) * (chain + 1));
+        }
+        traceRow(&tr, chain + 1, 0, cd.noise_rates);
+        for (uint iteration = 1; iteration <= (uint)O.P.burn_in + O.P.num_iterations; iteration++) {
+            std::vector<uint64_t> hist((size_t)S * 256, 0);
+            for (auto &G : O.groups) {
+                uint32_t sweep_no = 0xFFFFFFFFu;
+                estimateGenotypes(O, G, iteration > O.P.burn_in, nullptr, sweep_no);
+                for (auto &vx : G.vertices) {
+                    vx.genotyper->getNoiseCounts(hist.data());
+                    vx.genotyper->clearCache();
+                }
+            }
+            cd.sampleNoiseParameters(hist.data());
+            updateNoiseCache(O, cd);
+            traceRow(&tr, chain + 1, iteration, cd.noise_rates);
+        }
+        cd.resetNoiseRates();
+        updateNoiseCache(O, cd);
+    }
+    if (trace) std::copy(tr.begin(), tr.begin() + std::min<uint64_t>(tr.size(), trace_cap), trace);
+    return tr.size();
+}
+
+}  // extern "C"

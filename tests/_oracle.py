@@ -475,6 +475,10 @@ def _gibbs_sigs(L):
     L.orc_gibbs_sweep.argtypes = [vp, C.c_uint32, C.c_int]
     L.orc_gibbs_noise_counts.argtypes = [vp, vp, C.c_int]
     L.orc_gibbs_reset_groups.argtypes = [vp]
+    L.orc_estimate_noise.restype = u64
+    L.orc_estimate_noise.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, vp, u64, vp, u64, vp]
+    L.orc_estimate_noise_and_genotypes.restype = u64
+    L.orc_estimate_noise_and_genotypes.argtypes = [vp, C.c_float, C.c_float, vp, u64]
     L.orc_gibbs_result_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.orc_gibbs_result_fetch.argtypes = [vp] * 7
     L.orc_gibbs_trace_fetch.restype = u64
@@ -548,6 +552,30 @@ class OrcGibbs:
         self.o.l.orc_gibbs_result_fetch(self.h, _ptr(dip_off), _ptr(h1), _ptr(h2), _ptr(freq), _ptr(cell_off), _ptr(stats))
         return {"dip_off": dip_off, "h1": h1[:nd], "h2": h2[:nd], "freq": freq[: nd * self.S].reshape(nd, self.S), "cell_off": cell_off,
                 "stats": stats[: nc * 12].reshape(nc, 3, 4)}
+
+    # the noise drivers, restated whole in the oracle (InferenceEngine.cpp:135-276, 384-472); the object must have been
+    # created with noise_seeding=1 over the WHOLE unit
+    def estimate_noise(self, prior=(1.0, 0.01), variants_batch_size=100000):
+        """-> (trace rows [(chain, iteration, rates...)], per-chain selected group indices, final mean rates)"""
+        rows = self.params.num_chains * (self.params.burn_in + self.params.num_iterations + 1) + 1
+        trace = np.zeros(rows * (2 + self.S))
+        sel = np.zeros(self.params.num_chains * (1 + self.batch.num_groups) + 1, np.uint32)
+        final = np.zeros(self.S)
+        n = self.o.l.orc_estimate_noise(self.h, prior[0], prior[1], variants_batch_size, _ptr(trace), len(trace), _ptr(sel), len(sel), _ptr(final))
+        assert n == len(trace)
+        chains, p = [], 0
+        for _ in range(self.params.num_chains):
+            k = int(sel[p])
+            chains.append(sel[p + 1:p + 1 + k].copy())
+            p += 1 + k
+        return trace.reshape(rows, 2 + self.S), chains, final
+
+    def estimate_noise_and_genotypes(self, prior=(1.0, 0.01)):
+        rows = self.params.num_chains * (self.params.burn_in + self.params.num_iterations + 1)
+        trace = np.zeros(rows * (2 + self.S))
+        n = self.o.l.orc_estimate_noise_and_genotypes(self.h, prior[0], prior[1], _ptr(trace), len(trace))
+        assert n == len(trace)
+        return trace.reshape(rows, 2 + self.S)
 
     def close(self):
         if self.h:

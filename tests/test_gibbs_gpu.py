@@ -142,6 +142,52 @@ def test_stepwise_driving_and_noise_counts(gpu_ctx, oracle):
     og.close(), gg.close()
 
 
+def test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path):
+    """InferenceEngine.estimate_noise / estimate_noise_and_genotypes on the GPU (host/inference_engine.py over bt_gibbs_sweep,
+    bt_gibbs_noise_counts, bt_gibbs_set_noise_lut) against the oracle's restatement of InferenceEngine.cpp:135-276 and :384-472:
+    every sampled noise rate of every iteration of every chain (they are functions of the integer histograms and of the run's
+    generator, so equality is exact), the groups each chain selected, and the collected genotype samples."""
+    from bayestyper_amd import synth
+    from bayestyper_amd.host import count_model
+    from bayestyper_amd.host.inference_engine import InferenceEngine
+
+    S = 3
+    parts = [synth.make_batch("A", 60, S, seed=21, templates=6), synth.make_batch("C", 3, S, seed=22), synth.make_batch("B", 9, S, seed=23, templates=3)]
+    flat = synth.concat(parts)
+    flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
+    kw = dict(seed=1234, chains=3, burn=6, iters=9)
+
+    def cd():
+        d = count_model.CountDistribution(S, prior=(1.0, 0.01), seed=kw["seed"])
+        for s in range(S):
+            d.set_genomic(s, 15.0, 30.0)
+        return d
+
+    eng = InferenceEngine(gpu_ctx, kw["seed"], burn=kw["burn"], samples=kw["iters"], chains=kw["chains"])
+    # estimateNoise: a variant budget that selects a different subset of the single-cluster groups in every chain
+    cd_o, cd_g = cd(), cd()
+    og = _oracle.OrcGibbs(oracle, flat, *cd_o.tables(), noise_seeding=1, **kw)
+    want, chains, final = og.estimate_noise(variants_batch_size=25)
+    og.close()
+    assert len({tuple(c) for c in chains}) == kw["chains"] and all(0 < len(c) < 69 for c in chains)
+    got = eng.estimate_noise(cd_g, flat, output_prefix=str(tmp_path / "noise"), variants_batch_size=25)
+    assert np.array_equal(got, want)
+    assert np.array_equal(cd_g.noise_rates(), final)
+    assert len(open(tmp_path / "noise.txt").read().split("\n")) == len(want) + 2
+    # estimateNoiseAndGenotypes over all groups (nested groups included)
+    cd_o, cd_g = cd(), cd()
+    og = _oracle.OrcGibbs(oracle, flat, *cd_o.tables(), noise_seeding=1, **kw)
+    want = og.estimate_noise_and_genotypes()
+    ro = og.results()
+    og.close()
+    gg, got = eng.estimate_noise_and_genotypes(flat, cd_g)
+    rg = gg.results()
+    gg.close()
+    assert np.array_equal(got, want)
+    exact = assert_parity(flat, ro, rg, kw["chains"] * kw["iters"])
+    assert exact == flat["num_clusters"]
+
+
 def test_sharded_run_equals_unsharded_and_summary_definition(gpu_ctx, oracle):
     """Multi-GPU path by construction: the groups of a batch split over two 'ranks' (run one after the other on this GPU), each
     keeping its global group indices, give exactly the unsharded posterior summaries; bt_gibbs_posterior_summary agrees with its
