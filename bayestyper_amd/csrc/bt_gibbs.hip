@@ -841,6 +841,9 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             g->split_light = std::max(g->split_light, g->tiles[ti].split);
         }
     }
+    if (getenv("BT_GIBBS_DEBUG"))   // tuning aid: how the batch was tiled
+        fprintf(stderr, "bt_gibbs: %u tiles: light %zu (lds %u B, split %u), heavy %zu (lds %u B, split %u); tile 0: hot_bytes %u lds_stride %u copies %u\n", ntiles, g->light_tiles.size(),
+                g->lds_light, g->split_light, g->heavy_tiles.size(), g->lds_heavy, g->split_heavy, g->tiles[0].hot_bytes, g->tiles[0].lds_stride, g->tiles[0].copies);
     if (!g->heavy_tiles.empty()) {
         BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_heavy), g->heavy_tiles.size() * 4));
         g->allocs.push_back(g->d_heavy);

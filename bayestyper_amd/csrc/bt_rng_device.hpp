@@ -110,17 +110,9 @@ BT_HD void mt_seed(uint32_t *st, uint32_t seed) {
 struct Mt {
     uint32_t BT_GAS *st;
     uint32_t pos;
-#ifdef ABL_MTREG
-    uint32_t x;
-#endif
 };
-#ifdef ABL_MTREG
-BT_HD Mt mt_open(uint32_t *st) { return Mt{(uint32_t BT_GAS *)st, ((uint32_t BT_GAS *)st)[MT_N], ((uint32_t BT_GAS *)st)[0] | 1u}; }
-BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; m.st[0] = m.x; }
-#else
 BT_HD Mt mt_open(uint32_t *st) { return Mt{(uint32_t BT_GAS *)st, ((uint32_t BT_GAS *)st)[MT_N]}; }
 BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
-#endif
 
 BT_HD uint32_t mt_temper(uint32_t z) {
     z ^= (z >> 11);
@@ -136,12 +128,6 @@ BT_HD uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {   // new word from
 BT_HD uint32_t mt_wrap(uint32_t i) { return i >= MT_N ? i - MT_N : i; }
 
 BT_HD uint32_t mt_next(Mt &m) {
-#ifdef ABL_MT
-    uint32_t x = m.st[0]; x ^= x << 13; x ^= x >> 17; x ^= x << 5; m.st[0] = x; return x;
-#endif
-#ifdef ABL_MTREG
-    { uint32_t x = m.x; x ^= x << 13; x ^= x >> 17; x ^= x << 5; m.x = x; return x; }
-#endif
     const uint32_t p = m.pos, p1 = mt_wrap(p + 1), pm = mt_wrap(p + MT_M);
     const uint32_t z = mt_twist(m.st[p], m.st[p1], m.st[pm]);
     m.st[p] = z;
@@ -152,9 +138,6 @@ BT_HD uint32_t mt_next(Mt &m) {
 // generate_canonical<double, 53>(mt19937): two draws fused so that all five state loads are issued together
 // (draw 2 reads st[p+1] as it was BEFORE draw 1 replaced st[p]; draw 1 does not modify st[p+1])
 BT_HD double rng_canonical(Mt &m) {
-#if defined(ABL_MT) || defined(ABL_MTREG)
-    double s0 = (double)mt_next(m); s0 += (double)mt_next(m) * 4294967296.0; double r0 = s0 / 18446744073709551616.0; return r0 >= 1.0 ? 0.99999999999999988897769753748434595763683319091796875 : r0;
-#endif
     const uint32_t p = m.pos, p1 = mt_wrap(p + 1), p2 = mt_wrap(p + 2), pm = mt_wrap(p + MT_M), pm1 = mt_wrap(p + MT_M + 1);
     const uint32_t a = m.st[p], b = m.st[p1], c = m.st[p2], d = m.st[pm];
     // st[pm1] may be the word draw 1 has just replaced (only when p + 398 wraps onto p, impossible: 398 < 624) — always an independent word
