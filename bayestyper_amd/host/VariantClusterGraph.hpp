@@ -12,19 +12,26 @@
 
 namespace bthost {
 
-struct AlleleInfo {                    // VariantInfo.hpp: AlleleInfo
+enum class VariantType : uint8_t { SNV = 0, Insertion, Deletion, Complex, Mixture, Unsupported, VARIANT_TYPE_SIZE };   // VariantCluster.hpp:52
+
+struct AlleleInfo {                    // VariantInfo.hpp:41-63
     uint32_t ref_length = 0;
     std::string sequence;
+    std::string aco_att;               // the allele's ACO (allele call-set origin) attribute, carried to the output VCF
 };
 struct Variant {                       // VariantCluster::Variant (VariantCluster.hpp:56-71)
+    std::string id;
     bool has_dependency = false;
-    uint32_t num_redundant_nucleotides = 0;
+    VariantType type = VariantType::Unsupported;
+    uint32_t num_redundant_nucleotides = 0xFFFFFFFFu;
     std::vector<AlleleInfo> alt_alleles;
 };
 struct ContainedCluster {              // VariantCluster::ContainedCluster (:73-80)
     uint32_t cluster_idx, left_flank, right_flank;
 };
-struct VariantCluster {                // the fields of VariantCluster the constructor reads
+struct VariantCluster {                // VariantCluster.hpp:99-108
+    uint32_t cluster_idx = 0, left_flank = 0, right_flank = 0;   // flanks: 0-based positions of the first / last reference nucleotide covered
+    std::string chrom_name;
     std::map<uint32_t, Variant> variants;               // 0-based position of the first reference nucleotide -> variant
     std::list<ContainedCluster> contained_clusters;     // sorted by left flank, disjoint
 };

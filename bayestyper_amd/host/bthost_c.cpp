@@ -2,12 +2,16 @@
 // are the host layer proper; this file only exposes them.
 #include <algorithm>
 #include <cstring>
+#include <stdexcept>
+#include <sstream>
+#include <memory>
 
 #include "CountDistribution.hpp"
 #include "Genotypes.hpp"
 #include "InferenceEngine.hpp"
 #include "KmcFile.hpp"
 #include "VariantClusterGraph.hpp"
+#include "VariantFileParser.hpp"
 
 using namespace bthost;
 
@@ -185,6 +189,102 @@ void bth_graph_fetch(void *h, uint64_t *seq_off, uint8_t *seq, uint16_t *vvar, u
     for (size_t v = 0; v < g->var_num_alleles.size(); v++) {
         var_num_alleles[v] = g->var_num_alleles[v];
         var_dep[v] = g->var_has_dependency[v];
+    }
+}
+
+
+// ---- cluster stage front end: VCF + genome -> units of variant-cluster groups (VariantFileParser.hpp) ----
+namespace {
+struct ClusterStage {
+    unsigned k;
+    uint32_t max_allele_length;
+    float cnv_threshold;
+    Chromosomes chromosomes;
+    std::unique_ptr<VariantFileParser> parser;
+    std::vector<ClusterGroup> unit;   // groups of the unit parsed last
+};
+int stage_error(const std::exception &e, char *err, unsigned err_len) {
+    if (err && err_len) {
+        std::strncpy(err, e.what(), err_len - 1);
+        err[err_len - 1] = 0;
+    }
+    return -1;
+}
+uint64_t copy_out(const std::string &s, char *buf, uint64_t cap) {
+    if (buf && cap >= s.size()) std::memcpy(buf, s.data(), s.size());
+    return s.size();
+}
+}  // namespace
+
+void *bth_cluster_stage_new(unsigned k, uint32_t max_allele_length, float cnv_threshold) { return new ClusterStage{k, max_allele_length, cnv_threshold, {}, nullptr, {}}; }
+void bth_cluster_stage_free(void *h) { delete (ClusterStage *)h; }
+int bth_cluster_stage_add_sequence(void *h, const char *name, const char *seq, unsigned long long len, int is_decoy, char *err, unsigned err_len) {
+    try {
+        ((ClusterStage *)h)->chromosomes.addSequence(name, std::string(seq, seq + len), is_decoy != 0);
+        return 0;
+    } catch (const std::exception &e) {
+        return stage_error(e, err, err_len);
+    }
+}
+// the candidate variants: VCF text (vcf_len > 0) or the name of a .vcf / .vcf.gz file (vcf_len == 0)
+int bth_cluster_stage_set_variants(void *h, const char *vcf, unsigned long long vcf_len, char *err, unsigned err_len) {
+    auto *st = (ClusterStage *)h;
+    try {
+        std::string text = vcf_len ? std::string(vcf, vcf + vcf_len) : VariantFileParser::readVariantFile(vcf);
+        st->parser.reset(new VariantFileParser(std::move(text), st->k, st->max_allele_length, st->cnv_threshold));
+        return 0;
+    } catch (const std::exception &e) {
+        return stage_error(e, err, err_len);
+    }
+}
+// next unit: 1 = the file is exhausted, 0 = more units follow, -1 = error.  The unit's groups are ordered as main.cpp:247 orders them.
+int bth_cluster_stage_next_unit(void *h, uint32_t min_unit_variants, char *err, unsigned err_len) {
+    auto *st = (ClusterStage *)h;
+    try {
+        if (!st->parser) throw std::runtime_error("no variants set");
+        st->unit.clear();
+        const bool done = st->parser->constructVariantClusterGroups(&st->unit, min_unit_variants, st->chromosomes);
+        std::sort(st->unit.begin(), st->unit.end(), ClusterGroupCompare);
+        return done ? 1 : 0;
+    } catch (const std::exception &e) {
+        return stage_error(e, err, err_len);
+    }
+}
+// text views (return the size needed; nothing is written when cap is too small): 0 groups of the last unit, 1 intercluster regions in
+// their current order (file order until bth_cluster_stage_sort_regions), 3 counters
+unsigned long long bth_cluster_stage_dump(void *h, int what, char *buf, unsigned long long cap) {
+    auto *st = (ClusterStage *)h;
+    if (what == 0) return copy_out(dumpClusterGroups(st->unit), buf, cap);
+    if (!st->parser) return 0;
+    if (what == 1) return copy_out(st->parser->interclusterRegionsText(), buf, cap);
+    std::ostringstream os;
+    os << "total=" << st->parser->getNumberOfVariants() << " parsed=" << st->parser->numParsedVariants() << " clusters=" << st->parser->numVariantClusters()
+       << " groups=" << st->parser->numVariantClusterGroups() << " region_length=" << st->parser->getInterclusterRegionLength() << " alleles=";
+    for (size_t i = 0; i < st->parser->alleleTypeCounter().size(); i++) os << (i ? "," : "") << st->parser->alleleTypeCounter()[i];
+    os << " types=";
+    for (size_t i = 0; i < st->parser->variantTypeCounter().size(); i++) os << (i ? "," : "") << st->parser->variantTypeCounter()[i];
+    os << "\n";
+    return copy_out(os.str(), buf, cap);
+}
+// VariantFileParser::sortInterclusterRegions (main.cpp:306): by length, descending; call once, after the last unit
+void bth_cluster_stage_sort_regions(void *h) {
+    auto *st = (ClusterStage *)h;
+    if (st->parser) st->parser->sortInterclusterRegions();
+}
+// out[0] = groups of the last unit; out[1 + g] = clusters of group g (capacity: cap entries)
+void bth_cluster_stage_unit_sizes(void *h, uint32_t *out, unsigned cap) {
+    auto *st = (ClusterStage *)h;
+    if (cap) out[0] = (uint32_t)st->unit.size();
+    for (size_t g = 0; g < st->unit.size() && g + 1 < cap; g++) out[1 + g] = (uint32_t)st->unit[g].clusters.size();
+}
+// the graph of one cluster of the last unit (VariantClusterGraph.hpp; read it with bth_graph_sizes / bth_graph_fetch, release it with bth_graph_free)
+void *bth_cluster_stage_graph(void *h, uint32_t group, uint32_t vertex) {
+    auto *st = (ClusterStage *)h;
+    try {
+        const VariantCluster &c = st->unit.at(group).clusters.at(vertex);
+        return new VariantClusterGraph(c, st->chromosomes.sequence((size_t)st->chromosomes.find(c.chrom_name)), st->k);
+    } catch (...) {
+        return nullptr;
     }
 }
 
