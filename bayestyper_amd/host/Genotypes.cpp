@@ -136,7 +136,7 @@ void writeAlleleField(std::ostream &o, const std::vector<T> &v) {   // GenotypeW
 }
 }  // namespace
 
-std::string formatVariantStatsColumns(const VariantGenotypes &g) {
+std::string formatQualityFilterAndStats(const VariantGenotypes &g) {
     std::ostringstream o;
     const VariantStats &vs = g.variant_stats;
     if (floatCompare(vs.max_alt_allele_call_probability, 1)) o << "99";
@@ -149,14 +149,20 @@ std::string formatVariantStatsColumns(const VariantGenotypes &g) {
     writeAlleleField(o, vs.alt_allele_frequency);
     o << ";AN=" << vs.total_count << ";ACP=";
     writeAlleleField(o, vs.allele_call_probabilities);
-    if (!g.non_covered_alleles.empty()) {
-        std::vector<uint16_t> nc = g.non_covered_alleles;
-        std::sort(nc.begin(), nc.end());
-        o << ";ANC=";
-        writeAlleleField(o, nc);
-    }
     return o.str();
 }
+
+std::string formatAlleleCover(const VariantGenotypes &g) {
+    if (g.non_covered_alleles.empty()) return "";
+    std::ostringstream o;
+    std::vector<uint16_t> nc = g.non_covered_alleles;
+    std::sort(nc.begin(), nc.end());
+    o << ";ANC=";
+    writeAlleleField(o, nc);
+    return o.str();
+}
+
+std::string formatVariantStatsColumns(const VariantGenotypes &g) { return formatQualityFilterAndStats(g) + formatAlleleCover(g); }
 
 std::string formatSampleColumns(const ClusterResults &r, uint32_t variant, const VariantGenotypes &g) {
     std::ostringstream o;

@@ -61,6 +61,9 @@ std::vector<VariantGenotypes> getGenotypes(const ClusterResults &r, const Filter
 // :220-230) and, per sample, "\tGT:GQ:GPP:APP:NAK:FAK:MAC:SAF" (writeSamples :261-322, writeAlleleKmerStats :324-345) with the
 // default ostream formatting the reference uses.  `variant` = index of the variant inside the cluster (for the k-mer statistics).
 std::string formatVariantStatsColumns(const VariantGenotypes &g);
+// the two halves of the above: GenotypeWriter puts the cluster annotations (VCS .. HC) between them
+std::string formatQualityFilterAndStats(const VariantGenotypes &g);   // "<QUAL>\t<FILTER>\tAC=..;AF=..;AN=..;ACP=.."
+std::string formatAlleleCover(const VariantGenotypes &g);             // ";ANC=.." or ""
 std::string formatSampleColumns(const ClusterResults &r, uint32_t variant, const VariantGenotypes &g);
 
 }  // namespace bthost

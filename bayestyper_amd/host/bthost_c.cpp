@@ -7,6 +7,7 @@
 #include <memory>
 
 #include "CountDistribution.hpp"
+#include "GenotypeWriter.hpp"
 #include "Genotypes.hpp"
 #include "InferenceEngine.hpp"
 #include "KmcFile.hpp"
@@ -285,6 +286,71 @@ void *bth_cluster_stage_graph(void *h, uint32_t group, uint32_t vertex) {
         return new VariantClusterGraph(c, st->chromosomes.sequence((size_t)st->chromosomes.find(c.chrom_name)), st->k);
     } catch (...) {
         return nullptr;
+    }
+}
+
+
+// ---- GenotypeWriter over the clusters of a cluster stage ----
+namespace {
+struct WriterHandle {
+    ClusterStage *stage;
+    std::unique_ptr<GenotypeWriter> writer;
+};
+}  // namespace
+// sample_names: tab-separated
+void *bth_writer_new(void *stage, const char *sample_names) {
+    auto *st = (ClusterStage *)stage;
+    std::vector<std::string> names;
+    std::stringstream ss(sample_names);
+    for (std::string n; std::getline(ss, n, '\t');) names.push_back(n);
+    auto *w = new WriterHandle{st, nullptr};
+    w->writer.reset(new GenotypeWriter(names, st->chromosomes));
+    return w;
+}
+void bth_writer_free(void *h) { delete (WriterHandle *)h; }
+// every variant of cluster (group, vertex) of the stage's last unit, genotyped from the sampler's results of that cluster (the arrays of
+// bth_cluster_genotypes); H = number of haplotype candidates.  0 on success.
+int bth_writer_add_cluster(void *h, uint32_t group, uint32_t vertex, unsigned S, unsigned H, const uint16_t *hap_allele, unsigned long long num_diplotypes, const uint16_t *h1,
+                           const uint16_t *h2, const uint32_t *freq, const double *stats, const uint8_t *ploidy, float min_gpp, float min_kmers, const float *min_fraction, char *err,
+                           unsigned err_len) {
+    auto *w = (WriterHandle *)h;
+    try {
+        const ClusterGroup &g = w->stage->unit.at(group);
+        const VariantCluster &c = g.clusters.at(vertex);
+        const std::vector<VariantInfo> info = variantClusterInfo(c);
+        std::vector<uint16_t> var_num_alleles;
+        std::vector<uint8_t> var_has_dependency;
+        for (auto &vi : info) {
+            var_num_alleles.push_back(vi.numberOfAlleles());
+            var_has_dependency.push_back(vi.has_dependency ? 1 : 0);
+        }
+        ClusterResults r;
+        r.S = S; r.H = H; r.V = (uint32_t)info.size();
+        r.hap_allele = hap_allele; r.var_num_alleles = var_num_alleles.data(); r.var_has_dependency = var_has_dependency.data();
+        r.num_diplotypes = num_diplotypes; r.h1 = h1; r.h2 = h2; r.freq = freq; r.stats = stats; r.ploidy = ploidy;
+        Filters f;
+        f.min_genotype_posterior = min_gpp;
+        f.min_number_of_kmers = min_kmers;
+        f.min_fraction_observed_kmers.assign(min_fraction, min_fraction + S);
+        const auto res = getGenotypes(r, f);
+        ClusterAnnotation where{c.chrom_name, (uint32_t)info.size(), variantClusterRegion(c.chrom_name, info), (uint32_t)g.clusters.size(), g.region(), H};
+        for (size_t v = 0; v < info.size(); v++) w->writer->addGenotypes(where, info[v], res[v], formatSampleColumns(r, (uint32_t)v, res[v]));
+        return 0;
+    } catch (const std::exception &e) {
+        return stage_error(e, err, err_len);
+    }
+}
+// the VCF (header + sorted lines); returns the size needed
+unsigned long long bth_writer_text(void *h, const char *genome_filename, const char *graph_options_header, const char *genotype_options_header, char *buf, unsigned long long cap) {
+    return copy_out(((WriterHandle *)h)->writer->vcfText(genome_filename, graph_options_header, genotype_options_header), buf, cap);
+}
+// writes <output_prefix>.vcf[.gz]; returns the number of genotyped variants or -1
+long long bth_writer_finalise(void *h, const char *output_prefix, int gzip_output, const char *genome_filename, const char *graph_options_header,
+                              const char *genotype_options_header, char *err, unsigned err_len) {
+    try {
+        return ((WriterHandle *)h)->writer->finalise(output_prefix, gzip_output != 0, genome_filename, graph_options_header, genotype_options_header);
+    } catch (const std::exception &e) {
+        return stage_error(e, err, err_len);
     }
 }
 

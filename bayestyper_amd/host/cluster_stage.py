@@ -122,3 +122,56 @@ def fetch_graph(h, num_variants, free=True):
         dll.bth_graph_free(h)
     out["seq"], out["refvar"], out["edges"] = out["seq"][:nnt], out["refvar"][:nref], out["edges"][: 2 * ne].reshape(-1, 2)
     return out
+
+
+dll.bth_writer_new.restype = vp
+dll.bth_writer_new.argtypes = [vp, C.c_char_p]
+dll.bth_writer_free.argtypes = [vp]
+dll.bth_writer_add_cluster.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint, C.c_uint, vp, C.c_ulonglong, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, C.c_char_p, C.c_uint]
+dll.bth_writer_text.restype = C.c_ulonglong
+dll.bth_writer_text.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_ulonglong]
+dll.bth_writer_finalise.restype = C.c_longlong
+dll.bth_writer_finalise.argtypes = [vp, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint]
+
+
+class GenotypeWriter:
+    """bthost::GenotypeWriter over the clusters of a ClusterStage's current unit (GenotypeWriter.cpp:57-556)"""
+
+    def __init__(self, stage, sample_names):
+        self.stage = stage
+        self.h = dll.bth_writer_new(stage.h, "\t".join(sample_names).encode())
+        self._err = C.create_string_buffer(1024)
+
+    def add_cluster(self, group, vertex, S, H, hap_allele, h1, h2, freq, stats, ploidy, min_fraction, min_gpp=0.99, min_kmers=1.0):
+        """the sampler's results of one cluster (arrays as returned by lib.Gibbs.results(), restricted to the cluster)"""
+        arrs = [np.ascontiguousarray(hap_allele, np.uint16), np.ascontiguousarray(h1, np.uint16), np.ascontiguousarray(h2, np.uint16),
+                np.ascontiguousarray(freq, np.uint32).reshape(-1), np.ascontiguousarray(stats, np.float64).reshape(-1), np.ascontiguousarray(ploidy, np.uint8),
+                np.ascontiguousarray(min_fraction, np.float32)]
+        n_dip = len(arrs[1])
+        for a in arrs:
+            if a.size == 0:
+                a.resize(1, refcheck=False)
+        p = lambda a: a.ctypes.data_as(vp)   # noqa: E731
+        rc = dll.bth_writer_add_cluster(self.h, group, vertex, S, H, p(arrs[0]), n_dip, p(arrs[1]), p(arrs[2]), p(arrs[3]), p(arrs[4]), p(arrs[5]), min_gpp, min_kmers, p(arrs[6]),
+                                        self._err, len(self._err))
+        if rc != 0:
+            raise ValueError(self._err.value.decode())
+
+    def text(self, genome_filename="genome.fa", graph_options_header="", genotype_options_header=""):
+        args = [genome_filename.encode(), graph_options_header.encode(), genotype_options_header.encode()]
+        n = dll.bth_writer_text(self.h, *args, None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        dll.bth_writer_text(self.h, *args, buf, n)
+        return buf.raw[:n].decode()
+
+    def finalise(self, output_prefix, gzip_output=False, genome_filename="genome.fa", graph_options_header="", genotype_options_header=""):
+        n = dll.bth_writer_finalise(self.h, output_prefix.encode(), int(gzip_output), genome_filename.encode(), graph_options_header.encode(), genotype_options_header.encode(),
+                                    self._err, len(self._err))
+        if n < 0:
+            raise ValueError(self._err.value.decode())
+        return int(n)
+
+    def close(self):
+        if self.h:
+            dll.bth_writer_free(self.h)
+            self.h = None

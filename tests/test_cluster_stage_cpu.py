@@ -193,6 +193,7 @@ def parse_dump(text):
             alts = [(int(a.split(":")[0]), a.split(":")[1]) for a in m.group(6).split("|")]
             cur[-1]["vertices"][-1]["vars"].append((int(m.group(1)), m.group(2), int(m.group(3)), alts))
             cur[-1]["vertices"][-1].setdefault("red", []).append(int(m.group(5)))
+            cur[-1]["vertices"][-1].setdefault("aco", []).append([a.split(":", 2)[2] for a in m.group(6).split("|")])
         elif section == "REGIONS" and line:
             c, d, s, e = line.split("\t")
             regions.append((c, int(d), int(s), int(e)))
