@@ -88,20 +88,6 @@ class ClusterStage:
             self.h = None
 
 
-def run_all(stage, min_unit_variants):
-    """every unit of the file: the text the oracle's orc_cluster_stage produces (tests)"""
-    out, unit = [], 1
-    while True:
-        done = stage.next_unit(min_unit_variants)
-        out.append(f"UNIT {unit}\n" + stage.unit_text())
-        unit += 1
-        if done:
-            break
-    text = "".join(out) + "REGIONS\n" + stage.regions_text()
-    stage.sort_regions()
-    return text + "SORTED\n" + stage.regions_text() + "COUNTERS\n" + stage.counters_text()
-
-
 dll.bth_graph_free.argtypes = [vp]
 dll.bth_graph_sizes.argtypes = [vp, vp]
 dll.bth_graph_fetch.argtypes = [vp] * 12

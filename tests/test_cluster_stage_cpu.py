@@ -40,8 +40,22 @@ def oracle_text(orc, vcf, genome, k, min_unit_variants, max_allele_length=500000
     return buf.raw[:n].decode()
 
 
+def run_all(stage, min_unit_variants):
+    """every unit of the file, in the text layout of the oracle's orc_cluster_stage"""
+    out, unit = [], 1
+    while True:
+        done = stage.next_unit(min_unit_variants)
+        out.append(f"UNIT {unit}\n" + stage.unit_text())
+        unit += 1
+        if done:
+            break
+    text = "".join(out) + "REGIONS\n" + stage.regions_text()
+    stage.sort_regions()
+    return text + "SORTED\n" + stage.regions_text() + "COUNTERS\n" + stage.counters_text()
+
+
 def host_text(vcf, genome, k, min_unit_variants, max_allele_length=500000, thr=0.5):
-    from bayestyper_amd.host.cluster_stage import ClusterStage, run_all
+    from bayestyper_amd.host.cluster_stage import ClusterStage
 
     st = ClusterStage(k, max_allele_length, thr)
     for name, seq, dec in genome:
@@ -293,7 +307,7 @@ def test_properties_of_the_clustering(orc):
 def test_errors_and_file_input(tmp_path, orc):
     import gzip
 
-    from bayestyper_amd.host.cluster_stage import ClusterStage, run_all
+    from bayestyper_amd.host.cluster_stage import ClusterStage
 
     k = 15
     rng = np.random.default_rng(8)
