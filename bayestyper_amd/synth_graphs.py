@@ -262,10 +262,11 @@ def to_ctypes(f):
     return b, keep
 
 
-def gibbs_batch_from_candidates(cand, f, groups, S, gender=None, ploidy=None, cluster_ids=None):
+def gibbs_batch_from_candidates(cand, f, groups, S, gender=None, ploidy=None, cluster_ids=None, sources=None, out_edges=None):
     """The hand-over between the two halves of the path: getHaplotypeCandidates' bundle (bt_paths_candidates_fetch / the oracle's,
-    `cand`) for the graphs `f`, plus the group structure (`groups`: list of lists of cluster indices, every cluster a source of its
-    group — nested edges are not synthesised here), -> the dict layout of bt_gibbs_batch (synth.flatten's).  Multicluster k-mers of a
+    `cand`) for the graphs `f`, plus the group structure (`groups`: list of lists of cluster indices; `sources`: per group the local
+    vertex ids of its source vertices, default every cluster; `out_edges`: per cluster the local vertex ids of its nested clusters,
+    default none — VariantClusterGroup.cpp:47-107), -> the dict layout of bt_gibbs_batch (synth.flatten's).  Multicluster k-mers of a
     group share one record: kmer_shared numbers the distinct keys among the group's multicluster rows."""
     order = [c for g in groups for c in g]
     assert sorted(order) == list(range(f["num_clusters"])) and order == sorted(order), "groups must partition the clusters in order"
@@ -289,10 +290,12 @@ def gibbs_batch_from_candidates(cand, f, groups, S, gender=None, ploidy=None, cl
     out = {
         "S": S, "gender": gender, "num_groups": G, "num_clusters": f["num_clusters"],
         "group_index": np.arange(G, dtype=np.uint32), "group_cluster_off": goff, "group_ploidy": np.ascontiguousarray(ploidy.reshape(-1)),
-        "group_source_off": goff.copy(), "group_sources": np.concatenate([np.arange(len(g), dtype=np.uint32) for g in groups]),
+        "group_source_off": goff.copy() if sources is None else np.concatenate([[0], np.cumsum([len(x) for x in sources])]).astype(np.uint32),
+        "group_sources": np.concatenate([np.arange(len(g), dtype=np.uint32) for g in groups]) if sources is None else np.concatenate([np.asarray(x, np.uint32) for x in sources]),
         "group_num_shared": np.asarray(num_shared, np.uint32),
         "cluster_idx": np.arange(f["num_clusters"], dtype=np.uint32) if cluster_ids is None else np.asarray(cluster_ids, np.uint32),
-        "edge_off": np.zeros(f["num_clusters"] + 1, np.uint32), "edges": np.zeros(0, np.uint32),
+        "edge_off": np.zeros(f["num_clusters"] + 1, np.uint32) if out_edges is None else np.concatenate([[0], np.cumsum([len(x) for x in out_edges])]).astype(np.uint32),
+        "edges": np.zeros(0, np.uint32) if out_edges is None else np.concatenate([np.asarray(x, np.uint32) for x in out_edges] + [np.zeros(0, np.uint32)]),
         "num_haplotypes": H, "num_variants": V, "kmer_shared": shared,
         "var_num_alleles": f["var_num_alleles"], "var_has_dependency": f["var_has_dependency"],
     }
