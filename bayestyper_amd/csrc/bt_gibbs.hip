@@ -397,6 +397,7 @@ inline uint32_t tile_lds_bytes(const TileDesc &d) { return d.lds_all ? d.hot_byt
 #define BT_HOT_BUDGET 155648
 #endif
 constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
+constexpr uint32_t kMinTileWidth = 4;           // groups per wavefront of the narrowest tiles (the other lanes run copies)
 constexpr uint32_t kLightLds = 24576;            // tiles above this go to the "heavy" launch class
 
 // element sizes per array, in TileArr order
@@ -501,11 +502,15 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     {
         uint32_t n_tail = 0;
         while (n_tail < G && (shapes[n_tail].nv > 1 || shapes[n_tail].Hmax >= 16)) ++n_tail;   // sorted: expensive groups first
+        // Narrower is faster per group (measured, 2 304 nested groups of shape C: 271 / 259 / 245 / 237 ms at 16 / 8 / 4 / 2 groups per
+        // wavefront: fewer diverging lanes, and the idle lanes run copies that share the data-parallel phases) and needs less LDS per
+        // tile, so that tail tiles co-reside with the other launch class instead of queueing behind it — as long as all tail tiles
+        // are resident at once: aim at <= 3 tail tiles per CU, at least 4 groups per tile (2 and 1 lose: too many wavefronts).
         uint32_t width = LANES;
-        while (width > 16 && (uint64_t)n_tail * 2 <= (uint64_t)width * 256) width /= 2;         // aim at >= one tile per 2 CUs
+        while (width > kMinTileWidth && (uint64_t)n_tail * 2 <= (uint64_t)width * (3 * 256)) width /= 2;
         if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {   // tuning override
             const int v = atoi(e);
-            if (v == 8 || v == 16 || v == 32 || v == 64) width = (uint32_t)v;
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width = (uint32_t)v;
         }
         uint32_t at = 0;
         while (at < n_tail) {
@@ -670,7 +675,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                                     A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_KSCTMP, A_CUM};
             // LDS rows are interleaved over the tile's lanes only (16 / 32 / 64): a narrow tile needs a fraction of the LDS per vertex,
             // which lets every vertex of a multi-cluster group stay resident instead of being swapped around each visit
-            d.lds_stride = 16;
+            d.lds_stride = getenv("BT_GIBBS_MIN_STRIDE") ? (uint32_t)atoi(getenv("BT_GIBBS_MIN_STRIDE")) : kMinTileWidth;   // env: tuning override
             while (d.lds_stride < d.num_lanes) d.lds_stride *= 2;
             uint64_t ho = 0;
             for (int a : hot_arrs) {

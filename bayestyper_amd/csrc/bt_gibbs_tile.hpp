@@ -126,7 +126,7 @@ struct TileDesc {
     uint32_t hoff[A_COUNT];   // byte offset inside the wavefront's LDS block of the arrays kept resident there (NOHOT otherwise)
     uint32_t hot_bytes, split;   // hot_bytes: LDS bytes of ONE vertex's hot arrays; split: wavefronts working on this tile (1, 2, 4 or 8), see tile_lane()
     uint32_t copies, copies_pad;    // narrow tiles (split 1): the wavefront's idle lanes run `copies` identical instances of every group, see Tile::part
-    uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (16/32/64); lds_all: every vertex has its own LDS block (no swaps)
+    uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (4 .. 64); lds_all: every vertex has its own LDS block (no swaps)
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 constexpr uint32_t RESIDENT_ALL = 0xFFFFFFFEu;   // Env/Tile::resident: every vertex of the group has its hot arrays in LDS
