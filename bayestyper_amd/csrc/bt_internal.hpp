@@ -101,4 +101,11 @@ struct bt_kmc_scan {
     uint64_t total = 0;
     uint64_t lut_entries = 0;   // 4^p + 1
     uint64_t *d_lut = nullptr;
+    // staging of bt_kmc_scan_run_host (created on first use, kept for the life of the handle): two pinned host buffers, two device
+    // buffers, a copy stream and the events that order copy and scan
+    uint8_t *h_pin[2] = {nullptr, nullptr}, *d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
+    unsigned long long *d_host_hits = nullptr;
 };

@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <thread>
+#include <vector>
 
 #include "bt_rng_device.hpp"
 
@@ -748,11 +750,13 @@ int bt_kmc_scan_create_bins(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, ui
     return BT_OK;
 }
 
+static void free_host_staging(bt_kmc_scan *s);
 int bt_kmc_scan_destroy(bt_kmc_scan *s) {
     if (!s) return BT_OK;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->d_lut) (void)hipFree(s->d_lut);
+    free_host_staging(s);
     delete s;
     return BT_OK;
 }
@@ -786,6 +790,39 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
     return BT_OK;
 }
 
+static void free_host_staging(bt_kmc_scan *s) {
+    for (int b = 0; b < 2; ++b) {
+        if (s->h_pin[b]) (void)hipHostFree(s->h_pin[b]);
+        if (s->d_stage[b]) (void)hipFree(s->d_stage[b]);
+        if (s->copied[b]) (void)hipEventDestroy(s->copied[b]);
+        if (s->scanned[b]) (void)hipEventDestroy(s->scanned[b]);
+        s->h_pin[b] = s->d_stage[b] = nullptr;
+        s->copied[b] = s->scanned[b] = nullptr;
+    }
+    if (s->d_host_hits) (void)hipFree(s->d_host_hits);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    s->d_host_hits = nullptr;
+    s->copy_stream = nullptr;
+    s->stage_bytes = 0;
+}
+
+// host range -> pinned buffer with several threads: one core's memcpy (~12 GB/s measured on the MI355X host) is well below the link
+static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t bytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t threads = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)(hw ? hw : 1), bytes >> 22}));
+    if (threads == 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t part = (bytes / threads + 4095) / 4096 * 4096;
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < threads; ++t) {
+        const size_t lo = std::min(bytes, t * part), hi = std::min(bytes, lo + part);
+        if (hi > lo) pool.emplace_back([=]() { std::memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    for (auto &th : pool) th.join();
+}
+
 int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records, uint64_t first_record, uint64_t n,
                          uint64_t chunk_records, uint64_t *h_hit_count) {
     if (!s || !path_bloom || !table || !h_records) return fail("bt_kmc_scan_run_host: null argument");
@@ -796,51 +833,48 @@ int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, 
     }
     BT_HIP(hipSetDevice(s->ctx->device));
     const uint64_t rec = s->rec_size;
-    chunk_records = std::max<uint64_t>(16, std::min<uint64_t>(chunk_records ? chunk_records : (1ull << 24), n + 15) / 16 * 16);   // chunk starts stay 16-byte aligned
+    chunk_records = std::max<uint64_t>(16, std::min<uint64_t>(chunk_records ? chunk_records : (1ull << 23), n + 15) / 16 * 16);   // chunk starts stay 16-byte aligned
     const size_t chunk_bytes = chunk_records * rec;
     // two staging slots: pinned host buffer -> device buffer on a copy stream, scan on the context's stream, events both ways
-    uint8_t *h_pin[2] = {nullptr, nullptr}, *d_buf[2] = {nullptr, nullptr};
-    hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
-    unsigned long long *d_hits = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-        e = hipHostMalloc(reinterpret_cast<void **>(&h_pin[b]), chunk_bytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_buf[b]), chunk_bytes + 16);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&copied[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&scanned[b], hipEventDisableTiming);
+    hipError_t e = hipSuccess;
+    if (s->stage_bytes < chunk_bytes) {
+        free_host_staging(s);
+        e = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+            e = hipHostMalloc(reinterpret_cast<void **>(&s->h_pin[b]), chunk_bytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_stage[b]), chunk_bytes + 16);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->copied[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->scanned[b], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_host_hits), 8);
+        if (e != hipSuccess) {
+            free_host_staging(s);
+            return fail(std::string("bt_kmc_scan_run_host: staging buffers: ") + hipGetErrorString(e));
+        }
+        s->stage_bytes = chunk_bytes;
     }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_hits), 8);
-    if (e == hipSuccess) e = hipMemsetAsync(d_hits, 0, 8, s->ctx->stream);
+    e = hipMemsetAsync(s->d_host_hits, 0, 8, s->ctx->stream);
     int rc = BT_OK;
     uint64_t done = 0;
     for (uint64_t i = 0; e == hipSuccess && rc == BT_OK && done < n; ++i) {
         const int b = (int)(i & 1);
         const uint64_t m = std::min(chunk_records, n - done);
-        if (i >= 2) e = hipEventSynchronize(copied[b]);   // the pinned buffer of this slot has been read by its previous copy
+        if (i >= 2) e = hipEventSynchronize(s->copied[b]);   // the pinned buffer of this slot has been read by its previous copy
         if (e != hipSuccess) break;
-        std::memcpy(h_pin[b], h_records + done * rec, m * rec);
-        if (i >= 2) e = hipStreamWaitEvent(copy_stream, scanned[b], 0);   // the device buffer of this slot has been scanned
-        if (e == hipSuccess) e = hipMemcpyAsync(d_buf[b], h_pin[b], m * rec, hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(copied[b], copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s->ctx->stream, copied[b], 0);
+        parallel_copy(s->h_pin[b], h_records + done * rec, m * rec);
+        if (i >= 2) e = hipStreamWaitEvent(s->copy_stream, s->scanned[b], 0);   // the device buffer of this slot has been scanned
+        if (e == hipSuccess) e = hipMemcpyAsync(s->d_stage[b], s->h_pin[b], m * rec, hipMemcpyHostToDevice, s->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(s->copied[b], s->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s->ctx->stream, s->copied[b], 0);
         if (e != hipSuccess) break;
-        rc = bt_kmc_scan_run(s, path_bloom, table, sample_idx, d_buf[b], first_record + done, m, reinterpret_cast<uint64_t *>(d_hits));
-        if (rc == BT_OK) e = hipEventRecord(scanned[b], s->ctx->stream);
+        rc = bt_kmc_scan_run(s, path_bloom, table, sample_idx, s->d_stage[b], first_record + done, m, reinterpret_cast<uint64_t *>(s->d_host_hits));
+        if (rc == BT_OK) e = hipEventRecord(s->scanned[b], s->ctx->stream);
         done += m;
     }
     unsigned long long hits = 0;
-    if (e == hipSuccess && rc == BT_OK) e = hipMemcpyAsync(&hits, d_hits, 8, hipMemcpyDeviceToHost, s->ctx->stream);
+    if (e == hipSuccess && rc == BT_OK) e = hipMemcpyAsync(&hits, s->d_host_hits, 8, hipMemcpyDeviceToHost, s->ctx->stream);
     hipError_t e2 = hipStreamSynchronize(s->ctx->stream);
-    (void)hipStreamSynchronize(copy_stream);
-    for (int b = 0; b < 2; ++b) {
-        if (h_pin[b]) (void)hipHostFree(h_pin[b]);
-        if (d_buf[b]) (void)hipFree(d_buf[b]);
-        if (copied[b]) (void)hipEventDestroy(copied[b]);
-        if (scanned[b]) (void)hipEventDestroy(scanned[b]);
-    }
-    if (d_hits) (void)hipFree(d_hits);
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    (void)hipStreamSynchronize(s->copy_stream);
     if (rc != BT_OK) return rc;
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return fail(std::string("bt_kmc_scan_run_host: ") + hipGetErrorString(e));

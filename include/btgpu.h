@@ -221,7 +221,7 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
                     const uint8_t *d_records, uint64_t first_record, uint64_t n, uint64_t *d_hit_count);
 /* The same for records in HOST memory (e.g. the memory-mapped .kmc_suf): the range is streamed through two pinned staging
  * buffers and two device buffers — host copy, H2D transfer (own stream) and scan of consecutive chunks overlap.  Blocking;
- * chunk_records = records per transfer (0: default 2^24); *h_hit_count = number of Bloom hits. */
+ * chunk_records = records per transfer (0: default 2^23); the staging buffers are kept with the handle; *h_hit_count = number of Bloom hits. */
 int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records,
                          uint64_t first_record, uint64_t n, uint64_t chunk_records, uint64_t *h_hit_count);
 /* bayesTyperTools makeBloom (src/bayesTyperTools/MakeBloom.cpp:200-295): the k-mers of records [first_record, first_record + n)
