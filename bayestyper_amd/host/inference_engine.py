@@ -72,6 +72,31 @@ def unit_group_shape(flat):
     return (off[1:] - off[:-1]).astype(np.uint32), (csum[off[1:]] - csum[off[:-1]]).astype(np.uint32)
 
 
+class CollectedSamples:
+    """results of consecutive launches over disjoint, consecutive group ranges, presented like one sampler's"""
+
+    def __init__(self, parts):
+        self.parts = parts
+
+    def results(self):
+        out = {}
+        for key, off in (("h1", None), ("h2", None), ("freq", None), ("stats", None)):
+            out[key] = np.concatenate([r[key] for r, _ in self.parts])
+        for off_key, payload in (("dip_off", "h1"), ("cell_off", "stats")):
+            pieces, base = [], 0
+            for r, _ in self.parts:
+                pieces.append(r[off_key][:-1].astype(np.uint64) + np.uint64(base))
+                base += int(r[off_key][-1])
+            out[off_key] = np.concatenate(pieces + [np.array([base], np.uint64)])
+        return out
+
+    def posterior_summary(self):
+        return np.concatenate([s for _, s in self.parts])
+
+    def close(self):
+        self.parts = []
+
+
 class InferenceEngine:
     def __init__(self, ctx, seed, burn=100, samples=250, chains=20, rate=0.1, max_hvk=500, sampler=None, reduce_hist=None):
         """reduce_hist: callable(np.uint64[S*256]) -> the histogram summed over all ranks (None: single rank)"""
@@ -90,12 +115,27 @@ class InferenceEngine:
         return dict(seed=self.seed, chains=self.chains, burn=self.burn, iters=self.samples, rate=self.rate, max_hvk=self.max_hvk, noise_seeding=noise_seeding)
 
     # ---- default mode --------------------------------------------------------------------------------------
-    def estimate_genotypes(self, flat, count_distribution):
-        """-> the sampler holding the collected samples of this rank's groups (results(), posterior_summary())"""
+    def estimate_genotypes(self, flat, count_distribution, max_groups_per_launch=None):
+        """-> an object holding the collected samples of this rank's groups (results(), posterior_summary(), close()).
+        A unit whose state does not fit the GPU at once (one lane of state per group: ~0.14 MB for an SNV group, tens of MB for a
+        nested SV group) is run as consecutive launches of at most max_groups_per_launch groups — groups are independent and keep
+        their unit-wide index, so the split changes nothing but the peak memory (InferenceEngine.cpp:335-382 hands groups to its
+        threads in batches the same way)."""
         lut_g, lut_n = count_distribution.tables()
-        g = self.sampler(flat, lut_g, lut_n, **self._kw(0))
-        g.run()
-        return g
+        if max_groups_per_launch is None or flat["num_groups"] <= max_groups_per_launch:
+            g = self.sampler(flat, lut_g, lut_n, **self._kw(0))
+            g.run()
+            return g
+        from .. import shard
+
+        parts = []
+        for a in range(0, flat["num_groups"], max_groups_per_launch):
+            sub = shard.take_groups(flat, np.arange(a, min(a + max_groups_per_launch, flat["num_groups"])))
+            g = self.sampler(sub, lut_g, lut_n, **self._kw(0))
+            g.run()
+            parts.append((g.results(), g.posterior_summary() if hasattr(g, "posterior_summary") else None))
+            g.close()   # frees the launch's HBM before the next one is built
+        return CollectedSamples(parts)
 
     # ---- shared iteration of the two noise drivers (sampleGenotypesCallback + sampleNoiseParameters) --------
     def _iteration(self, g, S, count_distribution, collect):

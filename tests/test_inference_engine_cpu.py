@@ -173,3 +173,18 @@ def test_two_ranks_reproduce_the_unsharded_drivers(orc):
             assert np.array_equal(r[k]["final"], want_final)
             assert np.array_equal(r[k]["trace_both"], want_both)
         assert np.array_equal(r[0]["full"], want_full)
+
+
+def test_default_mode_in_several_launches(orc):
+    """estimate_genotypes over a unit cut into launches of a few groups each == one launch (groups are independent, seeds follow the
+    unit-wide group index)"""
+    flat = _unit()
+    eng = _engine(orc)
+    cd = _count_distribution(KW["seed"])
+    whole = eng.estimate_genotypes(flat, cd)
+    pieces = eng.estimate_genotypes(flat, cd, max_groups_per_launch=4)
+    a, b = whole.results(), pieces.results()
+    for k in ("dip_off", "h1", "h2", "freq", "cell_off", "stats"):
+        assert np.array_equal(a[k], b[k]), k
+    assert len(pieces.parts) == -(-flat["num_groups"] // 4)
+    whole.close(), pieces.close()
