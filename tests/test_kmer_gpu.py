@@ -606,3 +606,49 @@ def test_make_bloom_from_kmc(gpu_ctx, oracle, tmp_path):
     for x in (sc, gb, ob, db):
         x.close()
     buf.free()
+
+
+def test_error_paths_report_instead_of_computing(gpu_ctx, oracle):
+    """the C ABI returns an error code with bt_last_error() text (no exceptions across the boundary, nothing computed on bad input):
+    sample limit of main.cpp:72, count-model tables not set, k mismatches, a count table that is too small, misaligned records"""
+    from bayestyper_amd import lib, synth
+
+    flat = synth.make_batch("A", 8, 2, seed=1)
+    lut_g, lut_n = _oracle.build_luts(oracle, 2)
+    g = lib.Gibbs(gpu_ctx, flat, None, None, chains=1, burn=1, iters=1)
+    with pytest.raises(lib.BtError, match="LUT"):
+        g.run()
+    with pytest.raises(lib.BtError, match="LUT"):
+        g.sweep(1, False)
+    g.set_lut(lut_g, lut_n)
+    g.run()
+    g.close()
+    big = synth.make_batch("A", 2, 31, seed=1)
+    with pytest.raises(lib.BtError, match="1..30"):
+        lib.Gibbs(gpu_ctx, big, None, None)
+    b55 = lib.Bloom.create(gpu_ctx, 1000, 1e-3, 55, threaded=True)
+    t31 = lib.Table(gpu_ctx, 1000, 1, 31)
+    sc = lib.KmcScan(gpu_ctx, 55, 7, 1, 100, np.linspace(0, 100, 4 ** 7 + 1).astype(np.uint64))
+    buf = gpu_ctx.to_device(np.zeros(100 * 13 + 16, np.uint8))
+    with pytest.raises(lib.BtError, match="k"):
+        sc.run(b55, t31, 0, buf.ptr, 0, 100)
+    t55 = lib.Table(gpu_ctx, 1000, 1, 55)
+    with pytest.raises(lib.BtError, match="exceeds"):
+        sc.run(b55, t55, 0, buf.ptr, 50, 100)
+    with pytest.raises(lib.BtError, match="sample"):
+        sc.run(b55, t55, 3, buf.ptr, 0, 100)
+    with pytest.raises(lib.BtError, match="align"):
+        sc.make_bloom(lib.Bloom.create(gpu_ctx, 100, 1e-3, 55, threaded=False), buf.ptr + 4, 0, 10)
+    # a table sized for 16 keys cannot take 5 000: batch calls are asynchronous, so the overflow is latched on the device and reported
+    # by bt_table_status (which the host checks after every scan) instead of being dropped silently
+    rng = np.random.default_rng(3)
+    km = np.unique(oracle.pack(_oracle.canonical_ascii(oracle, _oracle.random_kmers(rng, 5000, 55), 55), 55), axis=0)
+    bb = lib.Bloom.create(gpu_ctx, len(km), 1e-3, 55, threaded=True)
+    small = lib.Table(gpu_ctx, 16, 1, 55)
+    assert not small.status()["overflowed"]
+    small.insert(km)
+    st = small.status()
+    assert st["overflowed"] and st["num_keys"] <= st["capacity"] < len(km)
+    for x in (b55, t31, t55, sc, bb, small):
+        x.close()
+    buf.free()
