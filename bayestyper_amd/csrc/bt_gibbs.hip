@@ -500,22 +500,38 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     // divergence per step and more compute units working on the tail).  Cheap groups always fill 64-lane tiles.
     std::vector<uint32_t> tile_start;
     {
-        uint32_t n_tail = 0;
-        while (n_tail < G && (shapes[n_tail].nv > 1 || shapes[n_tail].Hmax >= 16)) ++n_tail;   // sorted: expensive groups first
-        // Narrower is faster per group (measured, 2 304 nested groups of shape C: 271 / 259 / 245 / 237 ms at 16 / 8 / 4 / 2 groups per
-        // wavefront: fewer diverging lanes, and the idle lanes run copies that share the data-parallel phases) and needs less LDS per
-        // tile, so that tail tiles co-reside with the other launch class instead of queueing behind it — as long as all tail tiles
-        // are resident at once: aim at <= 3 tail tiles per CU, at least 4 groups per tile (2 and 1 lose: too many wavefronts).
-        uint32_t width = LANES;
-        while (width > kMinTileWidth && (uint64_t)n_tail * 2 <= (uint64_t)width * (3 * 256)) width /= 2;
-        if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {   // tuning override
+        // two classes of expensive groups (the batch is sorted, so they are prefixes): X = nested groups and clusters with >= 16
+        // haplotype candidates, Y = single clusters with 6..15 candidates.  Narrower is faster per group (measured: 2 304 nested
+        // groups of shape C 271 / 259 / 245 / 237 ms at 16 / 8 / 4 / 2 groups per wavefront; 16 384 ten-haplotype clusters x 10
+        // samples 730 -> 549 ms at 64 -> 16: fewer diverging lanes, and the idle lanes run copies that share the data-parallel phases)
+        // and needs less LDS per tile, so these tiles co-reside with everything else instead of queueing for a CU — as long as they
+        // are all resident at once: X gets <= 3 tiles per CU and >= 4 groups per tile, X + Y together <= 6 per CU, Y >= 16 per tile
+        // (narrower loses again: too many wavefronts for the slots).
+        const uint32_t tail_h = getenv("BT_GIBBS_TAIL_H") ? (uint32_t)atoi(getenv("BT_GIBBS_TAIL_H")) : 16u;   // env: tuning overrides
+        uint32_t n_x = 0;
+        while (n_x < G && (shapes[n_x].nv > 1 || shapes[n_x].Hmax >= tail_h)) ++n_x;
+        uint32_t n_y = n_x;
+        while (n_y < G && shapes[n_y].Hmax >= 6) ++n_y;
+        uint32_t width_x = LANES, width_y = LANES;
+        while (width_x > kMinTileWidth && (uint64_t)n_x * 2 <= (uint64_t)width_x * (3 * 256)) width_x /= 2;
+        const uint64_t tiles_x = (n_x + width_x - 1) / width_x, budget_y = 6 * 256 > tiles_x ? 6 * 256 - tiles_x : 1;
+        while (width_y > 16 && (uint64_t)(n_y - n_x) * 2 <= (uint64_t)width_y * budget_y) width_y /= 2;
+        if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {
             const int v = atoi(e);
-            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width = (uint32_t)v;
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width_x = (uint32_t)v;
+        }
+        if (const char *e = getenv("BT_GIBBS_MID_WIDTH")) {
+            const int v = atoi(e);
+            if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width_y = (uint32_t)v;
         }
         uint32_t at = 0;
-        while (at < n_tail) {
+        while (at < n_x) {
             tile_start.push_back(at);
-            at += std::min<uint32_t>(width, n_tail - at);
+            at += std::min<uint32_t>(width_x, n_x - at);
+        }
+        while (at < n_y) {
+            tile_start.push_back(at);
+            at += std::min<uint32_t>(width_y, n_y - at);
         }
         while (at < G) {
             tile_start.push_back(at);
