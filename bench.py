@@ -305,7 +305,7 @@ def main():
             "roofline": {"kernel": "gibbs_kernel", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gibbs_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
                          "note": "latency/issue-bound sequential sampler (one lane per variant-cluster group): the HBM floor (inputs + state once per chain, "
-                                 "SURVEY 8d) is tiny by construction; avg_launch_ms spans the two concurrent launches (light / heavy tiles) of one schedule; "
+                                 "SURVEY 8d) is tiny by construction; avg_launch_ms spans the sampling launch(es) of one schedule (tiles with large LDS needs form a second, concurrent launch); "
                                  "measured traffic is dominated by the per-draw mt19937 state updates of 150k groups"},
             "roofline_kmer_match": {"kernel": "kmc_scan_kernel", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": traffic_kmc, "avg_launch_ms": kmc_avg_ms, "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD,
