@@ -262,7 +262,7 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
                     }
                 }
             }
-            cache_clear(c, P);
+            cache_clear(c, P, false);   // only the first copy of a group runs this operation
         }
     } else if (op == OP_RESET) {
         // VariantClusterGroup::resetGroup: genotypers are deleted; the shared KmerCounts multiplicities are NOT reset

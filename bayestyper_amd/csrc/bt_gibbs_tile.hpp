@@ -618,13 +618,24 @@ __device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t
     sc[SC_CONSTRUCTED] = 1;
 }
 
-__device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P) {   // VariantClusterGenotyper::clearCache (:131-138)
+// Slot of a key in the tag-checked direct-mapped tables (cache_mode 1).  The copies of a narrow tile evaluate different candidates at
+// the same time, so each copy owns a private 1/copies-th of the table: no two threads ever write the same slot concurrently.  What a
+// copy finds in its part only decides whether it recomputes a value, never the value itself.
+__device__ inline uint32_t hashed_slot(const Vx &c, uint32_t key) {
+    const uint32_t sub = c.d().cache_entries / c.t.copies;   // both powers of two
+    return ((key * 2654435761u) & (sub - 1u)) + c.t.part * sub;
+}
+
+// all_copies_run: every copy of the group executes this call (sampling operations) and clears its own part; otherwise the calling
+// thread clears the whole table
+__device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool all_copies_run) {   // VariantClusterGenotyper::clearCache (:131-138)
     const TileDesc BT_CAS &d = c.d();
     if (d.cache_mode == 0) {
         c.sc()[SC_UC_DIRTY] = 1;   // dense table: rebuilt as a whole at the next visit (fill_unique_cache)
     } else if (d.cache_mode == 1) {
         SPtr<uint32_t, LANES> tg = c.uctag();
-        for (uint32_t i = 0; i < d.cache_entries; ++i) tg[i] = 0;
+        const uint32_t sub = all_copies_run ? d.cache_entries / c.t.copies : d.cache_entries;
+        for (uint32_t i = all_copies_run ? c.t.part * sub : 0u, e = i + sub; i < e; ++i) tg[i] = 0;
     }
 }
 
@@ -771,7 +782,7 @@ __device__ __noinline__ void genotyper_reset(Env env, uint32_t vtx) {
     const GParams BT_CAS &P = env_params(env);
     c.sc()[SC_USE_MULTI] = 0;
     sample_kmer_subset(c, P);
-    cache_clear(c, P);
+    cache_clear(c, P, true);
     freq_reset(c);   // HaplotypeFrequencyDistribution::reset (counts are 0 here, as the reference asserts)
 }
 
@@ -793,7 +804,7 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
         if (v == v) return v;
     } else if (d.cache_mode == 1) {
         const uint32_t key = s * d.Dcm + idx + 1u;
-        slot = (key * 2654435761u) & (d.cache_entries - 1u);
+        slot = hashed_slot(c, key);
         if (c.uctag()[slot] == key) return uc[slot];
     }
     double acc = 0;
@@ -1286,7 +1297,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         // the picked interval — about once in 10^5..10^6 draws — the reference's chain is evaluated after all.
         const uint32_t total = ploidy == 2 ? nnz * (nnz + 1) / 2 : (ploidy == 1 ? nnz : 0u);
         const bool chain_only = total <= BT_LINEAR_DRAW_MIN;
-        const bool par = !chain_only && c.t.copies > 1u && c.d().cache_mode == 0;
+        const bool par = !chain_only && c.t.copies > 1u;
         double lpmax = 0;
         // lp of every candidate -> cum[0..total), in order; returns through lpmax the maximum
         // Evaluated in blocks of 8: the cache words of a whole block are requested first (independent loads, one memory round trip
@@ -1316,8 +1327,8 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                     }
                 }
             };
-            // with copies of the group in the wavefront (Tile::part) every copy evaluates every copies-th block (dense tables only:
-            // their slots are private to a candidate, hashed slots could collide between concurrently evaluated candidates)
+            // with copies of the group in the wavefront (Tile::part) every copy evaluates every copies-th block (dense tables: a slot
+            // is private to a candidate; hashed tables: a slot is private to a copy, see hashed_slot)
             const uint32_t stride_blocks = par ? c.t.copies : 1u;
             if (par) advance(8u * c.t.part);
             lpmax = -__builtin_huge_val();
@@ -1341,7 +1352,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                             ++a;
                         const uint32_t idx = dip_index(c, ha[q], hb[q]);
                         ukey[q] = s * dd.Dcm + idx + 1u;
-                        uslot[q] = dd.cache_mode == 0 ? s * dd.Dcm + idx : ((ukey[q] * 2654435761u) & (dd.cache_entries - 1u));
+                        uslot[q] = dd.cache_mode == 0 ? s * dd.Dcm + idx : hashed_slot(c, ukey[q]);
                         uval[q] = dd.cache_mode != 2 ? (double)uc[uslot[q]] : 0.0;
                         utag[q] = dd.cache_mode == 1 ? (uint32_t)uct[uslot[q]] : 0u;
                         if (multi) {

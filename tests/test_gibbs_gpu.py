@@ -73,6 +73,23 @@ def test_single_cluster_groups(gpu_ctx, oracle, shape, n, S):
     assert exact == flat["num_clusters"]
 
 
+@pytest.mark.parametrize("S", [30, 4])
+def test_joint_shape_many_haplotypes(gpu_ctx, oracle, S):
+    """shape D of SURVEY 8(d): 256 haplotype candidates (32 per sample x 8 merged), up to the maximum of 30 samples (main.cpp:72): the
+    per-(sample, diplotype) tables exceed the dense-table budget, so the tag-checked direct-mapped cache is the one in use; sparse
+    frequency sampler over hundreds of zero-count haplotypes, hash-set emulation with rehashes up to 541 buckets"""
+    from bayestyper_amd import synth
+
+    flat = synth.make_batch("D", 2, S, seed=2000 + S)
+    assert int(flat["num_haplotypes"].max()) == 256
+    kw = dict(seed=9, chains=2, burn=3, iters=6) if S == 30 else dict(seed=9, chains=2, burn=6, iters=12)
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=9, **kw)
+    for g, (to, tg) in enumerate(tr):
+        assert np.array_equal(to, tg[: len(to)]), f"group {g}"
+    exact = assert_parity(flat, ro, rg, 2 * kw["iters"])
+    assert exact == flat["num_clusters"]
+
+
 def test_default_schedule_shape_A(gpu_ctx, oracle):
     """the reference's default schedule: 20 chains x (100 burn-in + 250 collected) (main.cpp:389-391)"""
     from bayestyper_amd import synth
