@@ -524,10 +524,28 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width_y = (uint32_t)v;
         }
+        // inside X, clusters whose per-(sample, diplotype) tables are hashed (S * D > 8192: hundreds of haplotype candidates and/or tens
+        // of samples) evaluate tens of thousands of candidates per sample in the first sweep of every chain: they get a wavefront of
+        // their own (63 copies share that work; 8 such groups x 30 samples: 10.7 / 5.7 / 3.0 s at 4 / 2 / 1 per wavefront)
+        auto hashed = [&](uint32_t i) { return (uint64_t)S * ((uint64_t)shapes[i].Hmax * (shapes[i].Hmax + 1) / 2 + shapes[i].Hmax) > 8192; };
+        uint32_t n_w = 0;
+        for (uint32_t i = 0; i < n_x; ++i) n_w += hashed(i) ? 1u : 0u;
+        uint32_t width_w = 1;
+        while (width_w < width_x && (uint64_t)n_w > (uint64_t)width_w * (4 * 256)) width_w *= 2;
+        if (const char *e = getenv("BT_GIBBS_HUGE_WIDTH")) {
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) width_w = (uint32_t)v;
+        }
         uint32_t at = 0;
-        while (at < n_x) {
-            tile_start.push_back(at);
-            at += std::min<uint32_t>(width_x, n_x - at);
+        while (at < n_x) {   // runs of equal kind
+            const bool hw = hashed(at);
+            uint32_t run_end = at;
+            while (run_end < n_x && hashed(run_end) == hw) ++run_end;
+            const uint32_t w = hw ? width_w : width_x;
+            while (at < run_end) {
+                tile_start.push_back(at);
+                at += std::min<uint32_t>(w, run_end - at);
+            }
         }
         while (at < n_y) {
             tile_start.push_back(at);
@@ -691,7 +709,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                                     A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_KSCTMP, A_CUM};
             // LDS rows are interleaved over the tile's lanes only (16 / 32 / 64): a narrow tile needs a fraction of the LDS per vertex,
             // which lets every vertex of a multi-cluster group stay resident instead of being swapped around each visit
-            d.lds_stride = getenv("BT_GIBBS_MIN_STRIDE") ? (uint32_t)atoi(getenv("BT_GIBBS_MIN_STRIDE")) : kMinTileWidth;   // env: tuning override
+            d.lds_stride = 1;
             while (d.lds_stride < d.num_lanes) d.lds_stride *= 2;
             uint64_t ho = 0;
             for (int a : hot_arrs) {
