@@ -397,6 +397,8 @@ inline uint32_t tile_lds_bytes(const TileDesc &d) { return d.lds_all ? d.hot_byt
 #define BT_HOT_BUDGET 155648
 #endif
 constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
+// a cluster's [S][D] table of unique-k-mer sums is dense up to 256 MB per tile (entries x 8 B x 64 lanes x vertices)
+inline bool dense_table_fits(uint64_t entries, uint32_t vertices) { return entries * 8 * 64 * std::max<uint32_t>(vertices, 1) <= (256ull << 20); }
 constexpr uint32_t kMinTileWidth = 4;           // groups per wavefront of the narrowest tiles (the other lanes run copies)
 constexpr uint32_t kLightLds = 24576;            // tiles above this go to the "heavy" launch class
 
@@ -524,10 +526,10 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width_y = (uint32_t)v;
         }
-        // inside X, clusters whose per-(sample, diplotype) tables are hashed (S * D > 8192: hundreds of haplotype candidates and/or tens
-        // of samples) evaluate tens of thousands of candidates per sample in the first sweep of every chain: they get a wavefront of
+        // inside X, clusters whose per-(sample, diplotype) tables are hashed (too large for a dense table: hundreds of haplotype
+        // candidates times tens of samples) evaluate tens of thousands of candidates per sample in the first sweep of every chain: they get a wavefront of
         // their own (63 copies share that work; 8 such groups x 30 samples: 10.7 / 5.7 / 3.0 s at 4 / 2 / 1 per wavefront)
-        auto hashed = [&](uint32_t i) { return (uint64_t)S * ((uint64_t)shapes[i].Hmax * (shapes[i].Hmax + 1) / 2 + shapes[i].Hmax) > 8192; };
+        auto hashed = [&](uint32_t i) { return !dense_table_fits((uint64_t)S * ((uint64_t)shapes[i].Hmax * (shapes[i].Hmax + 1) / 2 + shapes[i].Hmax), shapes[i].nv); };
         uint32_t n_w = 0;
         for (uint32_t i = 0; i < n_x; ++i) n_w += hashed(i) ? 1u : 0u;
         uint32_t width_w = 1;
@@ -599,8 +601,10 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         d.Bcap = uset_bucket_capacity(d.Hm);
         d.D2m = d.Hm * (d.Hm + 1) / 2;
         d.Dcm = d.D2m + d.Hm;
+        // dense [S][D] table when it is affordable (the pool's arrays are interleaved over 64 lanes whatever the tile's width, so a
+        // table costs 512 B per entry and vertex), otherwise the tag-checked direct-mapped table
         const uint64_t dense = (uint64_t)S * d.Dcm;
-        if (dense <= 8192) {
+        if (dense_table_fits(dense, d.nvm)) {
             d.cache_mode = 0;
             d.cache_entries = (uint32_t)dense;
         } else {
