@@ -397,8 +397,9 @@ inline uint32_t tile_lds_bytes(const TileDesc &d) { return d.lds_all ? d.hot_byt
 #define BT_HOT_BUDGET 155648
 #endif
 constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
-// a cluster's [S][D] table of unique-k-mer sums is dense up to 256 MB per tile (entries x 8 B x 64 lanes x vertices)
-inline bool dense_table_fits(uint64_t entries, uint32_t vertices) { return entries * 8 * 64 * std::max<uint32_t>(vertices, 1) <= (256ull << 20); }
+// a cluster's [S][D] table of unique-k-mer sums is dense up to `limit` bytes per tile (entries x 8 B x 64 lanes x vertices): 256 MB,
+// 64 MB when the batch would not fit the GPU otherwise.  Dense is much faster (256 candidates x 10 samples: 12x)
+inline bool dense_table_fits(uint64_t entries, uint32_t vertices, uint64_t limit) { return entries * 8 * 64 * std::max<uint32_t>(vertices, 1) <= limit; }
 constexpr uint32_t kMinTileWidth = 4;           // groups per wavefront of the narrowest tiles (the other lanes run copies)
 constexpr uint32_t kLightLds = 24576;            // tiles above this go to the "heavy" launch class
 
@@ -500,7 +501,18 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     // haplotypes) run thousands of sequential sweeps each and would otherwise occupy a handful of wavefronts while the rest of
     // the chip idles after the cheap groups finish: they are cut into narrower tiles (fewer groups per wavefront => less
     // divergence per step and more compute units working on the tail).  Cheap groups always fill 64-lane tiles.
+    // The pool's arrays are interleaved over 64 lanes whatever a tile's width, so narrow tiles trade HBM for speed (64 / width times the
+    // state of their groups).  plan_tiles(relax) lays the batch out with the one-group-per-wavefront class 2^relax times wider (up
+    // to the width of the other expensive groups), then with the smaller dense-table limit; the first layout that fits the free HBM is used.  A batch that does not fit even
+    // then is refused with the size it needs: the host splits the unit (host/inference_engine.py: max_groups_per_launch).
     std::vector<uint32_t> tile_start;
+    std::vector<TilePlan> plans;
+    uint64_t pool = 0;
+    uint32_t ntiles = 0;
+    auto plan_tiles = [&](uint32_t relax) {
+    tile_start.clear();
+    pool = 0;
+    const uint64_t dense_limit = relax >= 3 ? (64ull << 20) : (256ull << 20);
     {
         // two classes of expensive groups (the batch is sorted, so they are prefixes): X = nested groups and clusters with >= 16
         // haplotype candidates, Y = single clusters with 6..15 candidates.  Narrower is faster per group (measured: 2 304 nested
@@ -529,7 +541,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         // inside X, clusters whose per-(sample, diplotype) tables are hashed (too large for a dense table: hundreds of haplotype
         // candidates times tens of samples) evaluate tens of thousands of candidates per sample in the first sweep of every chain: they get a wavefront of
         // their own (63 copies share that work; 8 such groups x 30 samples: 10.7 / 5.7 / 3.0 s at 4 / 2 / 1 per wavefront)
-        auto hashed = [&](uint32_t i) { return !dense_table_fits((uint64_t)S * ((uint64_t)shapes[i].Hmax * (shapes[i].Hmax + 1) / 2 + shapes[i].Hmax), shapes[i].nv); };
+        auto hashed = [&](uint32_t i) { return !dense_table_fits((uint64_t)S * ((uint64_t)shapes[i].Hmax * (shapes[i].Hmax + 1) / 2 + shapes[i].Hmax), shapes[i].nv, dense_limit); };
         uint32_t n_w = 0;
         for (uint32_t i = 0; i < n_x; ++i) n_w += hashed(i) ? 1u : 0u;
         uint32_t width_w = 1;
@@ -538,6 +550,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) width_w = (uint32_t)v;
         }
+        width_w = std::min<uint32_t>(width_x, width_w << relax);   // only the one-group-per-wavefront class gives way
         uint32_t at = 0;
         while (at < n_x) {   // runs of equal kind
             const bool hw = hashed(at);
@@ -559,7 +572,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         }
         tile_start.push_back(G);
     }
-    const uint32_t ntiles = (uint32_t)tile_start.size() - 1;
+    ntiles = (uint32_t)tile_start.size() - 1;
     g->ntiles = ntiles;
     g->group_tile.assign(G, 0);
     g->group_lane.assign(G, 0);
@@ -567,8 +580,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     g->loc.assign(C, ClusterLoc{0, 0, 0, 0});
     const uint64_t collect_total = (uint64_t)std::max<uint32_t>(params->num_chains, 1) * std::max<uint32_t>(params->num_iterations, 1) * S;
 
-    std::vector<TilePlan> plans(ntiles);
-    uint64_t pool = 0;
+    plans.assign(ntiles, TilePlan{});
     for (uint32_t ti = 0; ti < ntiles; ++ti) {
         TileDesc d{};
         d.S = S;
@@ -604,7 +616,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         // dense [S][D] table when it is affordable (the pool's arrays are interleaved over 64 lanes whatever the tile's width, so a
         // table costs 512 B per entry and vertex), otherwise the tag-checked direct-mapped table
         const uint64_t dense = (uint64_t)S * d.Dcm;
-        if (dense_table_fits(dense, d.nvm)) {
+        if (dense_table_fits(dense, d.nvm, dense_limit)) {
             d.cache_mode = 0;
             d.cache_entries = (uint32_t)dense;
         } else {
@@ -748,6 +760,15 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         plans[ti].in_bytes = in_bytes;
         plans[ti].total_bytes = align_up(off, 256);
         pool += plans[ti].total_bytes;
+    }
+    };   // plan_tiles
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        for (uint32_t relax = 0;; ++relax) {
+            plan_tiles(relax);
+            if (relax >= 3 || free_b == 0 || pool + 256 <= (uint64_t)(0.92 * (double)free_b)) break;
+        }
     }
     g->pool_bytes = pool + 256;
     {
