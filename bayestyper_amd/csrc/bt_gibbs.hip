@@ -397,9 +397,8 @@ inline uint32_t tile_lds_bytes(const TileDesc &d) { return d.lds_all ? d.hot_byt
 #define BT_HOT_BUDGET 155648
 #endif
 constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
-// a cluster's [S][D] table of unique-k-mer sums is dense up to `limit` bytes per tile (entries x 8 B x 64 lanes x vertices): 256 MB,
-// 64 MB when the batch would not fit the GPU otherwise.  Dense is much faster (256 candidates x 10 samples: 12x)
-inline bool dense_table_fits(uint64_t entries, uint32_t vertices, uint64_t limit) { return entries * 8 * 64 * std::max<uint32_t>(vertices, 1) <= limit; }
+// a cluster's [S][D] tables are dense up to 256 MB per tile (64 MB when the batch would not fit the GPU otherwise): a hashed table far
+// smaller than the set of live (sample, diplotype) pairs thrashes (256 candidates x 10 samples: 12x slower than dense)
 constexpr uint32_t kMinTileWidth = 4;           // groups per wavefront of the narrowest tiles (the other lanes run copies)
 constexpr uint32_t kLightLds = 24576;            // tiles above this go to the "heavy" launch class
 
@@ -538,10 +537,9 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             const int v = atoi(e);
             if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width_y = (uint32_t)v;
         }
-        // inside X, clusters whose per-(sample, diplotype) tables are hashed (too large for a dense table: hundreds of haplotype
-        // candidates times tens of samples) evaluate tens of thousands of candidates per sample in the first sweep of every chain: they get a wavefront of
+        // inside X, clusters with more than 65 536 (sample, diplotype) pairs (hundreds of haplotype candidates times several samples) evaluate tens of thousands of candidates per sample in the first sweep of every chain: they get a wavefront of
         // their own (63 copies share that work; 8 such groups x 30 samples: 10.7 / 5.7 / 3.0 s at 4 / 2 / 1 per wavefront)
-        auto hashed = [&](uint32_t i) { return !dense_table_fits((uint64_t)S * ((uint64_t)shapes[i].Hmax * (shapes[i].Hmax + 1) / 2 + shapes[i].Hmax), shapes[i].nv, dense_limit); };
+        auto hashed = [&](uint32_t i) { return (uint64_t)S * ((uint64_t)shapes[i].Hmax * (shapes[i].Hmax + 1) / 2 + shapes[i].Hmax) > 65536; };
         uint32_t n_w = 0;
         for (uint32_t i = 0; i < n_x; ++i) n_w += hashed(i) ? 1u : 0u;
         uint32_t width_w = 1;
@@ -613,15 +611,21 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         d.Bcap = uset_bucket_capacity(d.Hm);
         d.D2m = d.Hm * (d.Hm + 1) / 2;
         d.Dcm = d.D2m + d.Hm;
-        // dense [S][D] table when it is affordable (the pool's arrays are interleaved over 64 lanes whatever the tile's width, so a
-        // table costs 512 B per entry and vertex), otherwise the tag-checked direct-mapped table
+        // dense [S][D] table of unique-k-mer sums when it is affordable, otherwise the tag-checked direct-mapped table.  Narrow tiles
+        // keep the table per-lane contiguous (TileDesc::uc_width) and pay for their own lanes only; the multicluster tables of the
+        // same size stay interleaved over 64 lanes
         const uint64_t dense = (uint64_t)S * d.Dcm;
-        if (dense_table_fits(dense, d.nvm, dense_limit)) {
+        uint32_t tile_w = 1;
+        while (tile_w < d.num_lanes) tile_w *= 2;
+        const uint64_t table_bytes = dense * 8 * (tile_w < LANES ? tile_w : LANES) * d.nvm + (d.NMm ? dense * 16 * LANES * d.nvm : 0);
+        if (table_bytes <= dense_limit && dense < (1ull << 26)) {
             d.cache_mode = 0;
             d.cache_entries = (uint32_t)dense;
+            d.uc_width = tile_w < LANES ? tile_w : 0u;
         } else {
             d.cache_mode = 1;
             d.cache_entries = 16384;
+            d.uc_width = 0;
         }
         uint64_t cap = 4;
         while (cap < 2 * std::min<uint64_t>((uint64_t)d.Dcm + 1, collect_total)) cap <<= 1;
@@ -672,7 +676,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_ZBKT] = len[A_PBKT] = nv * d.Bcap;
         len[A_UNEXT] = nv * d.Hm;
         len[A_HVCOUNT] = nv * d.Hm * d.Vm;
-        len[A_UCACHE] = nv * d.cache_entries;
+        len[A_UCACHE] = d.uc_width ? ((uint64_t)nv * d.uc_width * d.cache_entries + LANES - 1) / LANES : (uint64_t)nv * d.cache_entries;
         len[A_UCTAG] = nv * (d.cache_mode == 1 ? d.cache_entries : 1);
         len[A_CUM] = nv * std::max<uint32_t>(d.D2m, 1);
         len[A_NZLIST] = nv * d.Hm;

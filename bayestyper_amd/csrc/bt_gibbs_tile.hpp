@@ -126,6 +126,7 @@ struct TileDesc {
     uint32_t hoff[A_COUNT];   // byte offset inside the wavefront's LDS block of the arrays kept resident there (NOHOT otherwise)
     uint32_t hot_bytes, split;   // hot_bytes: LDS bytes of ONE vertex's hot arrays; split: wavefronts working on this tile (1, 2, 4 or 8), see tile_lane()
     uint32_t copies, copies_pad;    // narrow tiles (split 1): the wavefront's idle lanes run `copies` identical instances of every group, see Tile::part
+    uint32_t uc_width;              // 0: the unique-sum table is lane-interleaved like every other array; else it is per-lane contiguous over uc_width lanes
     uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (4 .. 64); lds_all: every vertex has its own LDS block (no swaps)
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
@@ -223,7 +224,20 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline HSet zero_set() const { return HSet{t.harr<uint32_t>(A_ZHDR, v, 4), t.harr<uint32_t>(A_ZBKT, v, d().Bcap), unext()}; }
     __device__ inline HSet plus_set() const { return HSet{t.harr<uint32_t>(A_PHDR, v, 4), t.harr<uint32_t>(A_PBKT, v, d().Bcap), unext()}; }
     __device__ inline SPtr<uint32_t, LANES> hvcount() const { return a<uint32_t>(A_HVCOUNT, (uint32_t)d().Hm * d().Vm); }
-    __device__ inline SPtr<double, LANES> ucache() const { return a<double>(A_UCACHE, d().cache_entries); }
+    // the [S][D] table of unique-k-mer sums.  Wide tiles: lane-interleaved.  Narrow tiles (whose lanes would leave most of every
+    // 64-lane row unused): each lane's table contiguous, so a tile pays for its own lanes only and even 256 candidates x 30 samples
+    // (10^6 entries, 8 MB) stay dense
+    struct UCPtr {
+        double BT_GAS *base;
+        uint32_t off, stride;
+        __device__ inline double BT_GAS &operator[](uint32_t i) const { return base[off + i * stride]; }
+    };
+    __device__ inline UCPtr ucache() const {
+        double BT_GAS *b = (double BT_GAS *)(t.base + d().off[A_UCACHE]);
+        const uint32_t w = d().uc_width;
+        if (w) return UCPtr{b, (v * w + t.lane) * d().cache_entries, 1u};
+        return UCPtr{b, v * d().cache_entries * LANES + t.lane, LANES};
+    }
     __device__ inline SPtr<uint32_t, LANES> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
     __device__ inline SPtrF<double, LANES> cum() const { return t.harr<double>(A_CUM, v, (d().D2m > 1 ? d().D2m : 1)); }
     __device__ inline SPtrF<uint16_t, LANES> nzlist() const { return t.harr<uint16_t>(A_NZLIST, v, d().Hm); }
@@ -798,7 +812,7 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
     const TileDesc BT_CAS &d = c.d();
     const uint32_t idx = dip_index(c, h1, h2);
     uint32_t slot = 0;
-    SPtr<double, LANES> uc = c.ucache();
+    const Vx::UCPtr uc = c.ucache();
     if (d.cache_mode == 0) {
         const double v = uc[(uint32_t)s * d.Dcm + idx];
         if (v == v) return v;
@@ -857,7 +871,7 @@ __device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
     const uint32_t nsub = c.sc()[SC_NSUB_U];
     const uint32_t Hm = d.Hm, S = P.S, H = c.H;
     SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
-    SPtr<double, LANES> uc = c.ucache();
+    const Vx::UCPtr uc = c.ucache();
     for (uint32_t s = 0; s < S; ++s) {
         const uint8_t gender = P.gender[s];
         const uint32_t row = s * d.Dcm;
@@ -1305,7 +1319,8 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         auto eval_candidates = [&]() {
             const bool dipl = ploidy == 2;
             const TileDesc BT_CAS &dd = c.d();
-            SPtr<double, LANES> uc = c.ucache(), mc = c.mcache();
+            const Vx::UCPtr uc = c.ucache();
+            SPtr<double, LANES> mc = c.mcache();
             SPtr<uint32_t, LANES> uct = c.uctag(), mct = c.mctag(), mcg = c.mcgen();
             const bool multi = use_multi && nsub_m != 0;
             uint32_t a = 0, b = 0;   // enumeration state (diploid: b >= a)
