@@ -645,7 +645,11 @@ __device__ inline uint32_t hashed_slot(const Vx &c, uint32_t key) {
 __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool all_copies_run) {   // VariantClusterGenotyper::clearCache (:131-138)
     const TileDesc BT_CAS &d = c.d();
     if (d.cache_mode == 0) {
-        c.sc()[SC_UC_DIRTY] = 1;   // dense table: rebuilt as a whole at the next visit (fill_unique_cache)
+        // dense table: rebuilt at the next visit.  As a whole (fill_unique_cache) at a chain start, where the first sweep asks for
+        // every entry anyway, and for small tables.  A large table cleared between the sweeps of a chain (clearGenotyperCache of the
+        // noise drivers) is only invalidated: the sweeps that follow ask for the pairs of the few non-zero haplotypes, which are
+        // then computed on demand like the reference does
+        c.sc()[SC_UC_DIRTY] = (!all_copies_run && d.cache_entries > 16384u) ? 2u : 1u;
     } else if (d.cache_mode == 1) {
         SPtr<uint32_t, LANES> tg = c.uctag();
         const uint32_t sub = all_copies_run ? d.cache_entries / c.t.copies : d.cache_entries;
@@ -1277,7 +1281,13 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
     const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
     uint32_t hap_count = sc[SC_HAP_COUNT];
     PROF_DECL;
-    if (sc[SC_UC_DIRTY]) {
+    if (sc[SC_UC_DIRTY] == 2u) {   // invalidate only: NaN marks "not computed" (unique_log_prob fills on demand)
+        const Vx::UCPtr ucl = c.ucache();
+        const double nan = __builtin_nan("");
+        for (uint32_t i = c.t.part, n = c.d().cache_entries; i < n; i += c.t.copies) ucl[i] = nan;
+        if (c.t.copies > 1u) copies_sync();
+        sc[SC_UC_DIRTY] = 0;
+    } else if (sc[SC_UC_DIRTY]) {
         fill_unique_cache(env, vtx);
         sc[SC_UC_DIRTY] = 0;
     }
@@ -1406,8 +1416,8 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                         if (!dipl) lp += la[q];
                         else if (ha[q] == hb[q]) lp += 2 * la[q];
                         else lp += BT_LN2 + la[q] + lb[q];
-                        // dense tables are complete (fill_unique_cache); hashed tables fill on demand
-                        const bool uhit = dd.cache_mode == 0 || (dd.cache_mode == 1 && utag[q] == ukey[q]);
+                        // dense tables are complete (fill_unique_cache) or hold NaN where not computed yet; hashed tables fill on demand
+                        const bool uhit = (dd.cache_mode == 0 && uval[q] == uval[q]) || (dd.cache_mode == 1 && utag[q] == ukey[q]);
                         lp += uhit ? uval[q] : unique_log_prob(c, P, s, ha[q], hb[q], nsub_u);
                         if (multi) lp += mval[q];
                         lpmax = lp > lpmax ? lp : lpmax;
