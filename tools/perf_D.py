@@ -1,9 +1,8 @@
 import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.')
 import numpy as np
 from bayestyper_amd import lib, synth
 from bayestyper_amd.host import count_model
-import _oracle
 ctx=lib.Ctx(0)
 n,S=int(sys.argv[1]),int(sys.argv[2])
 t=time.perf_counter(); flat=synth.make_batch("D",n,S,seed=1); print("make_batch %.1f s"%(time.perf_counter()-t), "K", int((flat["kmer_off"][1:]-flat["kmer_off"][:-1]).max()))
@@ -13,6 +12,3 @@ t=time.perf_counter(); gg=lib.Gibbs(ctx,flat,g,nz,**kw); ctx.sync(); print("crea
 t=time.perf_counter(); gg.init_chain(0); ctx.sync(); print("init_chain(0) [construct+reset] %.2f s"%(time.perf_counter()-t))
 t=time.perf_counter(); gg.sweep(5,False); ctx.sync(); print("5 burn-in sweeps %.2f s"%(time.perf_counter()-t))
 t=time.perf_counter(); gg.sweep(10,True); ctx.sync(); print("10 collected sweeps %.2f s"%(time.perf_counter()-t))
-orc=_oracle.load_oracle()
-t=time.perf_counter(); og=_oracle.OrcGibbs(orc,flat,g,nz,**kw); og.init_chain(0); print("oracle construct+reset %.2f s"%(time.perf_counter()-t))
-t=time.perf_counter(); og.sweep(15,True); print("oracle 15 sweeps %.2f s"%(time.perf_counter()-t))

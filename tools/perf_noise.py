@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0,'.')
 import numpy as np
 from bayestyper_amd import lib, synth
 from bayestyper_amd.host import count_model
