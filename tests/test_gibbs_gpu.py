@@ -205,6 +205,29 @@ def test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path):
     assert exact == flat["num_clusters"]
 
 
+def test_unit_in_several_launches(gpu_ctx):
+    """InferenceEngine.estimate_genotypes with max_groups_per_launch: a unit too large for one launch is run as consecutive launches;
+    samples and posterior summaries equal those of the single launch (groups keep their unit-wide index)"""
+    from bayestyper_amd import synth
+    from bayestyper_amd.host import count_model
+    from bayestyper_amd.host.inference_engine import InferenceEngine
+
+    S = 2
+    flat = synth.concat([synth.make_batch("A", 40, S, seed=31, templates=5), synth.make_batch("C", 3, S, seed=32), synth.make_batch("B", 10, S, seed=33, templates=2)])
+    flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
+    cd = count_model.CountDistribution(S, seed=5)
+    for s in range(S):
+        cd.set_genomic(s, 15.0, 30.0)
+    eng = InferenceEngine(gpu_ctx, 5, burn=10, samples=20, chains=2)
+    whole = eng.estimate_genotypes(flat, cd)
+    parts = eng.estimate_genotypes(flat, cd, max_groups_per_launch=17)
+    a, b = whole.results(), parts.results()
+    for k in ("dip_off", "h1", "h2", "freq", "cell_off", "stats"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(whole.posterior_summary(), parts.posterior_summary()) and len(parts.parts) == 4
+    whole.close(), parts.close()
+
+
 def test_sharded_run_equals_unsharded_and_summary_definition(gpu_ctx, oracle):
     """Multi-GPU path by construction: the groups of a batch split over two 'ranks' (run one after the other on this GPU), each
     keeping its global group indices, give exactly the unsharded posterior summaries; bt_gibbs_posterior_summary agrees with its
