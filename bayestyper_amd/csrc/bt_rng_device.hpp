@@ -155,6 +155,35 @@ BT_HD double rng_canonical(Mt &m) {
     return ret;
 }
 
+// two consecutive generate_canonical<double, 53> draws (four words) with all nine state loads issued together: the polar method of
+// normal_distribution draws its two uniforms back to back, and every memory round trip of a rejection loop is paid by the whole
+// wavefront until its last lane accepts.  None of the four regenerated words is an input of another (the recurrence reaches 1 and
+// 397 positions ahead and 227 behind), so loading everything first and storing afterwards gives the textbook stream.
+BT_HD void rng_canonical2(Mt &m, double &first, double &second) {
+    const uint32_t p = m.pos;
+    uint32_t a[5], c[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 5; ++k) a[k] = m.st[mt_wrap(p + k)];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) c[k] = m.st[mt_wrap(mt_wrap(p + k) + MT_M)];
+    uint32_t z[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        z[k] = mt_twist(a[k], a[k + 1], c[k]);
+        m.st[mt_wrap(p + k)] = z[k];
+    }
+    m.pos = mt_wrap(p + 4);
+    const double top = 0.99999999999999988897769753748434595763683319091796875;   // nextafter(1, 0)
+    double s0 = (double)mt_temper(z[0]);
+    s0 += (double)mt_temper(z[1]) * 4294967296.0;
+    first = s0 / 18446744073709551616.0;
+    if (first >= 1.0) first = top;
+    double s1 = (double)mt_temper(z[2]);
+    s1 += (double)mt_temper(z[3]) * 4294967296.0;
+    second = s1 / 18446744073709551616.0;
+    if (second >= 1.0) second = top;
+}
+
 // uniform_int_distribution<>(0, b) for b < 2^32 - 1: range = b + 1
 BT_HD uint32_t rng_uniform_int(Mt &st, uint32_t range) {
     uint64_t product = (uint64_t)mt_next(st) * (uint64_t)range;
@@ -215,8 +244,10 @@ BT_HD double rng_normal(Mt &st, NormalState nd) {
     } else {
         double x, y, r2;
         do {
-            x = 2.0 * rng_canonical(st) - 1.0;
-            y = 2.0 * rng_canonical(st) - 1.0;
+            double u1, u2;
+            rng_canonical2(st, u1, u2);
+            x = 2.0 * u1 - 1.0;
+            y = 2.0 * u2 - 1.0;
             r2 = x * x + y * y;
         } while (r2 > 1.0 || r2 == 0.0);
         const double mult = sqrt(-2 * bt_log(r2) / r2);
