@@ -617,6 +617,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         const uint64_t dense = (uint64_t)S * d.Dcm;
         uint32_t tile_w = 1;
         while (tile_w < d.num_lanes) tile_w *= 2;
+        d.mat_width = tile_w < LANES ? tile_w : 0u;   // narrow tiles: K x H matrices per-lane contiguous (TileDesc::mat_width)
         const uint64_t table_bytes = dense * 8 * (tile_w < LANES ? tile_w : LANES) * d.nvm + (d.NMm ? dense * 16 * LANES * d.nvm : 0);
         if (table_bytes <= dense_limit && dense < (1ull << 26)) {
             d.cache_mode = 0;
@@ -637,7 +638,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         // lengths (elements per lane) of every array
         const uint64_t nv = d.nvm;
         uint64_t len[A_COUNT];
-        len[A_M] = nv * d.Km * d.Hm;
+        len[A_M] = d.mat_width ? ((uint64_t)nv * d.mat_width * d.Km * d.Hm + LANES - 1) / LANES : (uint64_t)nv * d.Km * d.Hm;
         len[A_HASC] = nv * d.Km;
         len[A_COUNTS] = nv * d.Km * S;
         len[A_IC] = nv * d.Km * 2;
@@ -700,7 +701,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_MSUBC] = nv * (uint64_t)std::max<uint32_t>(d.NMm, 1) * S;
         len[A_MSUBIC] = nv * (uint64_t)std::max<uint32_t>(d.NMm, 1) * 2;
         len[A_MSUBSH] = nv * (uint64_t)std::max<uint32_t>(d.NMm, 1);
-        len[A_SUBM] = nv * (uint64_t)d.NUm * d.Hm;
+        len[A_SUBM] = d.mat_width ? ((uint64_t)nv * d.mat_width * d.NUm * d.Hm + LANES - 1) / LANES : nv * (uint64_t)d.NUm * d.Hm;
         len[A_SUBCNT] = nv * (uint64_t)d.NUm * S;
         len[A_SUBIC] = nv * (uint64_t)d.NUm * 2;
         len[A_SKVOFF] = nv * (uint64_t)(d.NUm + 1);
@@ -760,6 +761,14 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             d.copies = 64u / d.lds_stride;
         }
         d.base = pool;
+        if (ti == 0 && getenv("BT_GIBBS_DEBUG") && atoi(getenv("BT_GIBBS_DEBUG")) >= 2) {   // the arrays that make up most of tile 0
+            std::vector<std::pair<uint64_t, int>> by_size;
+            for (int a = 0; a < A_COUNT; ++a) by_size.emplace_back(len[a] * LANES * kElemSize[a], a);
+            std::sort(by_size.rbegin(), by_size.rend());
+            fprintf(stderr, "bt_gibbs: tile 0 (%u groups, %u vertices max, Hm %u, Km %u, S %u): %.1f MB;", d.num_lanes, d.nvm, d.Hm, d.Km, S, (double)align_up(off, 256) / 1048576.0);
+            for (int i = 0; i < 6; ++i) fprintf(stderr, " array %d: %.1f MB", by_size[i].second, (double)by_size[i].first / 1048576.0);
+            fprintf(stderr, "\n");
+        }
         plans[ti].d = d;
         plans[ti].in_bytes = in_bytes;
         plans[ti].total_bytes = align_up(off, 256);
@@ -820,7 +829,11 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 const uint32_t e0 = B->kv_off[r0];
                 for (uint32_t k = 0; k < K; ++k) {
                     const size_t r = (size_t)r0 + k;
-                    for (uint32_t h = 0; h < H; ++h) put<uint8_t>(img, d, A_M, (v * d.Km + k) * d.Hm + h, l, M[(size_t)k * H + h]);
+                    if (d.mat_width) {   // per-lane contiguous: ((v * width + lane) * Km + k) * Hm + h
+                        uint8_t *row = img.data() + d.off[A_M] + (((size_t)v * d.mat_width + l) * d.Km + k) * d.Hm;
+                        for (uint32_t h = 0; h < H; ++h) row[h] = M[(size_t)k * H + h];
+                    } else
+                        for (uint32_t h = 0; h < H; ++h) put<uint8_t>(img, d, A_M, (v * d.Km + k) * d.Hm + h, l, M[(size_t)k * H + h]);
                     put<uint8_t>(img, d, A_HASC, v * d.Km + k, l, B->kmer_has_counts[r]);
                     for (uint32_t s = 0; s < S; ++s) put<uint8_t>(img, d, A_COUNTS, (v * d.Km + k) * S + s, l, B->kmer_counts[r * S + s]);
                     put<uint8_t>(img, d, A_IC, (v * d.Km + k) * 2, l, B->kmer_ic_mult[2 * r]);

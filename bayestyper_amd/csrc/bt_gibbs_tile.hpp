@@ -127,6 +127,7 @@ struct TileDesc {
     uint32_t hot_bytes, split;   // hot_bytes: LDS bytes of ONE vertex's hot arrays; split: wavefronts working on this tile (1, 2, 4 or 8), see tile_lane()
     uint32_t copies, copies_pad;    // narrow tiles (split 1): the wavefront's idle lanes run `copies` identical instances of every group, see Tile::part
     uint32_t uc_width;              // 0: the unique-sum table is lane-interleaved like every other array; else it is per-lane contiguous over uc_width lanes
+    uint32_t mat_width;             // the same for the two K x H multiplicity matrices (A_M, A_SUBM): 0 interleaved, else the tile's lane count
     uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (4 .. 64); lds_all: every vertex has its own LDS block (no swaps)
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
@@ -184,8 +185,23 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline const TileDesc BT_CAS &d() const { return *t.d; }
     template <typename T>
     __device__ inline SPtr<T, LANES> a(int arr, uint32_t len) const { return t.arr<T>(arr, v * len); }
+    template <typename T>
+    struct RPtr {   // global-memory array with a run-time element stride
+        T BT_GAS *base;
+        uint32_t off, stride;
+        __device__ inline T BT_GAS &operator[](uint32_t i) const { return base[off + i * stride]; }
+        __device__ inline RPtr<T> operator+(uint32_t i) const { return RPtr<T>{base, off + i * stride, stride}; }
+    };
+    typedef RPtr<double> UCPtr;
+    // the K x H multiplicity matrices of a narrow tile are per-lane contiguous too (they are the bulk of a large cluster's state)
+    __device__ inline RPtr<uint8_t> mat(int arr, uint32_t rows) const {
+        uint8_t BT_GAS *b = (uint8_t BT_GAS *)(t.base + d().off[arr]);
+        const uint32_t w = d().mat_width, n = rows * d().Hm;
+        if (w) return RPtr<uint8_t>{b, (v * w + t.lane) * n, 1u};
+        return RPtr<uint8_t>{b, v * n * LANES + t.lane, LANES};
+    }
     // inputs
-    __device__ inline uint8_t M(uint32_t k, uint32_t h) const { return a<uint8_t>(A_M, (uint32_t)d().Km * d().Hm)[(uint32_t)k * d().Hm + h]; }
+    __device__ inline uint8_t M(uint32_t k, uint32_t h) const { return mat(A_M, d().Km)[(uint32_t)k * d().Hm + h]; }
     __device__ inline uint8_t has_counts(uint32_t k) const { return a<uint8_t>(A_HASC, d().Km)[k]; }
     __device__ inline uint8_t count(uint32_t k, uint32_t s) const { return a<uint8_t>(A_COUNTS, (uint32_t)d().Km * d().S)[(uint32_t)k * d().S + s]; }
     __device__ inline uint8_t ic(uint32_t k, uint32_t g) const { return a<uint8_t>(A_IC, (uint32_t)d().Km * 2)[2 * k + g]; }
@@ -209,7 +225,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (uint32_t)d().NMm * d().S); }
     __device__ inline SPtrF<uint16_t, LANES> dip() const { return t.harr<uint16_t>(A_DIP, v, 2 * d().S); }
     __device__ inline SPtrF<double, LANES> freq() const { return t.harr<double>(A_FREQ, v, d().Hm); }
-    __device__ inline SPtr<uint8_t, LANES> subm() const { return a<uint8_t>(A_SUBM, d().NUm * d().Hm); }
+    __device__ inline RPtr<uint8_t> subm() const { return mat(A_SUBM, d().NUm); }
     __device__ inline SPtr<uint8_t, LANES> subcnt() const { return a<uint8_t>(A_SUBCNT, d().NUm * d().S); }
     __device__ inline SPtr<uint8_t, LANES> subic() const { return a<uint8_t>(A_SUBIC, d().NUm * 2); }
     __device__ inline SPtr<uint32_t, LANES> skv_off() const { return a<uint32_t>(A_SKVOFF, d().NUm + 1); }
@@ -227,11 +243,6 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     // the [S][D] table of unique-k-mer sums.  Wide tiles: lane-interleaved.  Narrow tiles (whose lanes would leave most of every
     // 64-lane row unused): each lane's table contiguous, so a tile pays for its own lanes only and even 256 candidates x 30 samples
     // (10^6 entries, 8 MB) stay dense
-    struct UCPtr {
-        double BT_GAS *base;
-        uint32_t off, stride;
-        __device__ inline double BT_GAS &operator[](uint32_t i) const { return base[off + i * stride]; }
-    };
     __device__ inline UCPtr ucache() const {
         double BT_GAS *b = (double BT_GAS *)(t.base + d().off[A_UCACHE]);
         const uint32_t w = d().uc_width;
@@ -516,7 +527,7 @@ __device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
     SPtrF<uint32_t, LANES> obs = c.obs();
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
     const uint32_t Hm = c.d().Hm, H = c.H;
-    SPtr<uint8_t, LANES> M = c.a<uint8_t>(A_M, (uint32_t)c.d().Km * Hm);
+    const Vx::RPtr<uint8_t> M = c.mat(A_M, c.d().Km);
     // The reference recomputes the column sums of the still-uncovered rows in every round; the sums are integers, so keeping
     // them up to date (add every row once, subtract it when it gets covered) gives the same values with one pass per row.
     auto row_apply = [&](uint32_t k, bool add) {
@@ -727,7 +738,8 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
         // compact, subset-ordered copies of what calcDiplotypeLogProb reads per unique subset k-mer: the per-candidate sum then
         // walks plain arrays (index i, no k-mer indirection), so its loads are independent and coalesce across the wavefront
         const uint32_t Hm = c.d().Hm;
-        SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+        const Vx::RPtr<uint8_t> sm = c.subm();
+        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
         SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits();
         SPtr<uint16_t, LANES> sv = c.skv_var();
         const uint32_t HWm = c.d().HWm, HW = (c.H + 31) / 32;
@@ -748,7 +760,7 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
             const bool hc = c.has_counts(k) != 0;
             {
                 // row copy, eight multiplicities in flight (loads and stores may alias as far as the compiler knows)
-                SPtr<uint8_t, LANES> Mrow = c.a<uint8_t>(A_M, (uint32_t)c.d().Km * Hm) + k * Hm;
+                const Vx::RPtr<uint8_t> Mrow = c.mat(A_M, c.d().Km) + k * Hm;
                 uint32_t h = 0;
                 for (; h + 8 <= c.H; h += 8) {
                     uint8_t t8[8];
@@ -829,7 +841,8 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
     const uint8_t gender = P.gender[s];
     {
         const uint32_t Hm = d.Hm, S = P.S;
-        SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+        const Vx::RPtr<uint8_t> sm = c.subm();
+        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
         const bool two = h2 != NOHAP;
         uint32_t i = 0;
         // eight k-mers per step: all loads of a step are issued before the first table lookup; the sum itself stays in subset order
@@ -874,7 +887,8 @@ __device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
     const TileDesc BT_CAS &d = c.d();
     const uint32_t nsub = c.sc()[SC_NSUB_U];
     const uint32_t Hm = d.Hm, S = P.S, H = c.H;
-    SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+    const Vx::RPtr<uint8_t> sm = c.subm();
+        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
     const Vx::UCPtr uc = c.ucache();
     for (uint32_t s = 0; s < S; ++s) {
         const uint8_t gender = P.gender[s];
@@ -1227,7 +1241,8 @@ __device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uin
             if (h1 != NOHAP) {
                 const bool two = h2 != NOHAP;
                 const uint8_t g = P.gender[s];
-                SPtr<uint8_t, LANES> sm = c.subm(), scn = c.subcnt(), sic = c.subic();
+                const Vx::RPtr<uint8_t> sm = c.subm();
+        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
                 SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits();
                 SPtr<uint16_t, LANES> sv = c.skv_var();
                 for (uint32_t i = 0; i < nsub_u; ++i) {
