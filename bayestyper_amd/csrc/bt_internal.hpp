@@ -99,6 +99,7 @@ struct bt_kmc_scan {
     bt_ctx *ctx = nullptr;
     uint32_t k = 0, p = 0, counter_size = 0, suffix_bytes = 0, rec_size = 0;
     uint64_t total = 0;
+    uint32_t min_count = 0, max_count = 0xFFFFFFFFu;   // bt_kmc_scan_set_count_range
     uint64_t lut_entries = 0;   // 4^p + 1
     uint64_t *d_lut = nullptr;
     // staging of bt_kmc_scan_run_host (created on first use, kept for the life of the handle): two pinned host buffers, two device

@@ -38,52 +38,70 @@ __device__ inline uint64_t mix64(uint64_t x) {   // murmur3 finaliser
 
 __device__ inline uint64_t table_home(Kmer a, const TableView &t) { return mix64(a.lo ^ mix64(a.hi + 0x9e3779b97f4a7c15ULL)) & t.mask; }
 
-// findKmer: slot or -1
+// findKmer: slot or -1.  A slot's key words are read only after its state was observed READY with acquire semantics (the writer
+// publishes with a release store); a BUSY slot is polled again — the loop has a single exit, no lane leaves it from inside.
 __device__ inline int64_t table_find(const TableView &t, Kmer a) {
     uint64_t idx = table_home(a, t);
-    for (uint64_t probes = 0; probes <= t.mask; ++probes) {
-        uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (st == ST_EMPTY) return -1;
-        if (st == ST_READY) {
-            uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lo == a.lo && hi == a.hi) return (int64_t)idx;
-            idx = (idx + 1) & t.mask;
+    int64_t result = -1;
+    bool done = false;
+    uint64_t probes = 0;
+    while (!done) {
+        const uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == ST_EMPTY) {
+            done = true;
+        } else if (st == ST_READY) {
+            const uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lo == a.lo && hi == a.hi) {
+                result = (int64_t)idx;
+                done = true;
+            } else {
+                idx = (idx + 1) & t.mask;
+                done = ++probes > t.mask;
+            }
         }
         // ST_BUSY: another lane is publishing this slot; poll it again (the writer never waits)
-        else
-            --probes;
     }
-    return -1;
+    return result;
 }
 
-// addKmer: slot of the (possibly new) key, -1 if the table is full
+// addKmer: slot of the (possibly new) key, -1 if the table is full.  The lane that wins a slot publishes it INSIDE the loop body
+// (key words, then the READY state with release semantics) before the loop's exit condition is evaluated, so lanes of the same
+// wavefront that poll that slot always see it published on a later iteration.
 __device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a) {
     uint64_t idx = table_home(a, t);
-    for (uint64_t probes = 0; probes <= t.mask;) {
-        uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int64_t result = -1;
+    bool done = false;
+    uint64_t probes = 0;
+    while (!done) {
+        uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (st == ST_EMPTY) {
-            uint32_t prev = atomicCAS(&t.state[idx], ST_EMPTY, ST_BUSY);
-            if (prev == ST_EMPTY) {
+            if (atomicCAS(&t.state[idx], ST_EMPTY, ST_BUSY) == ST_EMPTY) {
                 __hip_atomic_store(&t.key_lo[idx], a.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&t.key_hi[idx], a.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&t.state[idx], ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 atomicAdd(t.num_keys, 1ULL);
-                return (int64_t)idx;
+                result = (int64_t)idx;
+                done = true;
             }
-            st = prev;
-        }
-        if (st == ST_READY) {
-            uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lo == a.lo && hi == a.hi) return (int64_t)idx;
-            idx = (idx + 1) & t.mask;
-            ++probes;
+            // lost the race: the slot is BUSY or READY now; look at it again
+        } else if (st == ST_READY) {
+            const uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lo == a.lo && hi == a.hi) {
+                result = (int64_t)idx;
+                done = true;
+            } else {
+                idx = (idx + 1) & t.mask;
+                if (++probes > t.mask) {
+                    atomicExch(t.overflow, 1u);
+                    done = true;
+                }
+            }
         }
         // ST_BUSY: poll again
     }
-    atomicExch(t.overflow, 1u);
-    return -1;
+    return result;
 }
 
 // saturating u8 add on byte `byte_idx` of a word array (ObservedKmerCounts::addSampleCount,
@@ -158,6 +176,18 @@ __global__ __launch_bounds__(BLOCK) void table_find_kernel(TableView t, const ui
     for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         Kmer a{kmers[2 * i], kmers[2 * i + 1]};
         slots[i] = table_find(t, a);
+    }
+}
+
+// bt_table_reserve: every stored record of `src` moves to its slot in the (larger, empty) table `dst`
+__global__ __launch_bounds__(BLOCK) void table_rehash_kernel(TableView src, uint64_t src_capacity, TableView dst) {
+    const uint32_t words = src.spad / 4u;
+    for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < src_capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        if (src.state[i] != ST_READY) continue;
+        const int64_t slot = table_find_or_insert(dst, Kmer{src.key_lo[i], src.key_hi[i]});
+        if (slot < 0) continue;   // cannot happen: dst is larger than src
+        dst.meta[slot] = src.meta[i];
+        for (uint32_t w = 0; w < words; ++w) dst.counts[(uint64_t)slot * words + w] = src.counts[i * words + w];
     }
 }
 
@@ -328,6 +358,7 @@ struct KmcView {
     const uint64_t *lut;     // 4^p + 1 entries
     uint64_t lut_entries;
     uint32_t k, p, counter_size, suffix_bytes, rec_size;
+    uint32_t min_count, max_count;   // records whose counter lies outside are skipped (CKMCFile::ReadNextKmer, kmc_file.cpp:496-511)
 };
 
 constexpr unsigned KMC_RECS = 256;          // records per workgroup iteration (= BLOCK)
@@ -409,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
                 out_kmers[2 * ridx] = a.lo;
                 out_kmers[2 * ridx + 1] = a.hi;
                 out_counts[ridx] = count;
-            } else if (bloom_contains(nthash64(a, v.k), bloom)) {     // KmerCounter.cpp:412
+            } else if (count >= v.min_count && count <= v.max_count && bloom_contains(nthash64(a, v.k), bloom)) {     // KmerCounter.cpp:412
                 my_hit = 1;
                 int64_t slot = table_find_or_insert(t, a);            // addKmer(kmer, false), :416
                 if (slot >= 0) sat_add_byte(t.counts, (uint64_t)slot * t.spad + sample_idx, count > 255u ? 255u : count);   // :419
@@ -451,7 +482,7 @@ __global__ __launch_bounds__(BLOCK) void kmc_make_bloom_kernel(KmcView v, BloomV
             Kmer a;
             uint32_t count;
             kmc_decode(v, kmc_prefix_of(v, first_record + rec0 + threadIdx.x), &stage[lead + threadIdx.x * v.rec_size], a, count);
-            bloom_insert(nthash64(a, v.k), bloom);
+            if (count >= v.min_count && count <= v.max_count) bloom_insert(nthash64(a, v.k), bloom);
         }
         __syncthreads();
     }
@@ -461,36 +492,97 @@ __global__ __launch_bounds__(BLOCK) void kmc_make_bloom_kernel(KmcView v, BloomV
 
 extern "C" {
 
+static void table_free_arrays(bt::TableView &v) {
+    (void)hipFree(v.key_lo);
+    (void)hipFree(v.key_hi);
+    (void)hipFree(v.state);
+    (void)hipFree(v.meta);
+    (void)hipFree(v.counts);
+    (void)hipFree(v.num_keys);
+    (void)hipFree(v.overflow);
+    v.key_lo = v.key_hi = nullptr;
+    v.state = v.meta = v.counts = v.overflow = nullptr;
+    v.num_keys = nullptr;
+}
+
+// allocate and zero the arrays of a table of `cap` slots; everything allocated so far is released on failure
+static int table_alloc_arrays(bt_ctx *ctx, uint64_t cap, uint32_t spad, uint32_t k, bt::TableView &v) {
+    v = bt::TableView{};
+    v.mask = cap - 1;
+    v.spad = spad;
+    v.k = k;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&v.key_lo), cap * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.key_hi), cap * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.state), cap * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.meta), cap * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.counts), cap * (uint64_t)spad);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.num_keys), 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.overflow), 4);
+    if (e == hipSuccess) e = hipMemsetAsync(v.state, 0, cap * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(v.meta, 0, cap * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(v.counts, 0, cap * (uint64_t)spad, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(v.num_keys, 0, 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(v.overflow, 0, 4, ctx->stream);
+    if (e != hipSuccess) {
+        table_free_arrays(v);
+        return fail(std::string("bt_table: allocating ") + std::to_string(cap) + " slots: " + hipGetErrorString(e));
+    }
+    return BT_OK;
+}
+
 int bt_table_create(bt_ctx *ctx, uint64_t expected_size, uint32_t num_samples, uint32_t k, bt_table **out) {
     if (!ctx || !out) return fail("bt_table_create: null argument");
     if (num_samples < 1 || num_samples > 30) return fail("bt_table_create: number of samples must be in 1..30");   // main.cpp:72
     if (k < 1 || k > 64) return fail("bt_table_create: k must be in 1..64");
     uint64_t cap = 1024;
     while (cap < expected_size * 2) cap <<= 1;
+    BT_HIP(hipSetDevice(ctx->device));
     bt_table *t = new bt_table();
     t->ctx = ctx;
     t->capacity = cap;
     t->num_samples = num_samples;
     t->spad = (num_samples + 3u) & ~3u;
     t->k = k;
-    BT_HIP(hipSetDevice(ctx->device));
-    TableView &v = t->v;
-    v.mask = cap - 1;
-    v.spad = t->spad;
-    v.k = k;
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.key_lo), cap * 8));
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.key_hi), cap * 8));
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.state), cap * 4));
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.meta), cap * 4));
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.counts), cap * (uint64_t)t->spad));
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.num_keys), 8));
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&v.overflow), 4));
-    BT_HIP(hipMemsetAsync(v.state, 0, cap * 4, ctx->stream));
-    BT_HIP(hipMemsetAsync(v.meta, 0, cap * 4, ctx->stream));
-    BT_HIP(hipMemsetAsync(v.counts, 0, cap * (uint64_t)t->spad, ctx->stream));
-    BT_HIP(hipMemsetAsync(v.num_keys, 0, 8, ctx->stream));
-    BT_HIP(hipMemsetAsync(v.overflow, 0, 4, ctx->stream));
+    if (table_alloc_arrays(ctx, cap, t->spad, k, t->v) != BT_OK) {
+        delete t;
+        return BT_ERR;
+    }
     *out = t;
+    return BT_OK;
+}
+
+int bt_table_clear(bt_table *t) {
+    if (!t) return fail("bt_table_clear: null table");
+    BT_HIP(hipSetDevice(t->ctx->device));
+    BT_HIP(hipMemsetAsync(t->v.state, 0, t->capacity * 4, t->ctx->stream));
+    BT_HIP(hipMemsetAsync(t->v.meta, 0, t->capacity * 4, t->ctx->stream));
+    BT_HIP(hipMemsetAsync(t->v.counts, 0, t->capacity * (uint64_t)t->spad, t->ctx->stream));
+    BT_HIP(hipMemsetAsync(t->v.num_keys, 0, 8, t->ctx->stream));
+    BT_HIP(hipMemsetAsync(t->v.overflow, 0, 4, t->ctx->stream));
+    return BT_OK;
+}
+
+int bt_table_reserve(bt_table *t, uint64_t expected_size) {
+    if (!t) return fail("bt_table_reserve: null table");
+    uint64_t cap = t->capacity;
+    while (cap < expected_size * 2) cap <<= 1;
+    if (cap == t->capacity) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    int ov = 0;
+    if (bt_table_status(t, nullptr, nullptr, &ov) != BT_OK) return BT_ERR;
+    if (ov) return fail("bt_table_reserve: the table has already overflowed (records were dropped)");
+    bt::TableView nv;
+    if (table_alloc_arrays(t->ctx, cap, t->spad, t->k, nv) != BT_OK) return BT_ERR;
+    hipLaunchKernelGGL(table_rehash_kernel, dim3(grid_for(t->capacity, BLOCK, t->ctx->num_cu * 16)), dim3(BLOCK), 0, t->ctx->stream, t->v, t->capacity, nv);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(t->ctx->stream);
+    if (e != hipSuccess) {
+        table_free_arrays(nv);
+        return fail(std::string("bt_table_reserve: ") + hipGetErrorString(e));
+    }
+    table_free_arrays(t->v);
+    t->v = nv;
+    t->capacity = cap;
     return BT_OK;
 }
 
@@ -498,13 +590,7 @@ int bt_table_destroy(bt_table *t) {
     if (!t) return BT_OK;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
-    (void)hipFree(t->v.key_lo);
-    (void)hipFree(t->v.key_hi);
-    (void)hipFree(t->v.state);
-    (void)hipFree(t->v.meta);
-    (void)hipFree(t->v.counts);
-    (void)hipFree(t->v.num_keys);
-    (void)hipFree(t->v.overflow);
+    table_free_arrays(t->v);
     delete t;
     return BT_OK;
 }
@@ -742,11 +828,23 @@ int bt_kmc_scan_create_bins(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, ui
         delete s;
         return fail("bt_kmc_scan_create: prefix LUT must start at 0 and end at total_records");
     }
-    BT_HIP(hipSetDevice(ctx->device));
-    BT_HIP(hipMalloc(reinterpret_cast<void **>(&s->d_lut), s->lut_entries * 8));
-    BT_HIP(hipMemcpyAsync(s->d_lut, h_prefix_lut, s->lut_entries * 8, hipMemcpyHostToDevice, ctx->stream));
-    BT_HIP(hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_lut), s->lut_entries * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_lut, h_prefix_lut, s->lut_entries * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        if (s->d_lut) (void)hipFree(s->d_lut);
+        delete s;
+        return fail(std::string("bt_kmc_scan_create: ") + hipGetErrorString(e));
+    }
     *out = s;
+    return BT_OK;
+}
+
+int bt_kmc_scan_set_count_range(bt_kmc_scan *s, uint32_t min_count, uint64_t max_count) {
+    if (!s) return fail("bt_kmc_scan_set_count_range: null handle");
+    s->min_count = min_count;
+    s->max_count = max_count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_count;   // counters are at most 4 bytes wide
     return BT_OK;
 }
 
@@ -770,6 +868,8 @@ static KmcView make_kmc_view(const bt_kmc_scan *s) {
     v.counter_size = s->counter_size;
     v.suffix_bytes = s->suffix_bytes;
     v.rec_size = s->rec_size;
+    v.min_count = s->min_count;
+    v.max_count = s->max_count;
     return v;
 }
 
@@ -878,6 +978,9 @@ int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, 
     if (rc != BT_OK) return rc;
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return fail(std::string("bt_kmc_scan_run_host: ") + hipGetErrorString(e));
+    int overflowed = 0;
+    if (bt_table_status(table, nullptr, nullptr, &overflowed) != BT_OK) return BT_ERR;
+    if (overflowed) return fail("bt_kmc_scan_run_host: the count table is full, matched k-mers were dropped (bt_table_reserve before the scan)");
     if (h_hit_count) *h_hit_count = hits;
     return BT_OK;
 }

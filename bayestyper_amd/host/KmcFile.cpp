@@ -100,6 +100,7 @@ uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, 
     bt_kmc_scan *scan = nullptr;
     if (bt_kmc_scan_create_bins(ctx, db.kmer_length, db.lut_prefix_length, db.counter_size, db.total_kmers, db.prefix_lut().data(), db.prefix_lut().size(), &scan) != BT_OK)
         throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
+    bt_kmc_scan_set_count_range(scan, db.min_count, db.max_count);   // ReadNextKmer's counter filter (kmc_file.cpp:496-511)
     uint64_t hits = 0;
     // copies from the page cache (mmap) into pinned staging, H2D transfers and scan kernels of consecutive chunks overlap inside the library
     const int rc = bt_kmc_scan_run_host(scan, path_bloom, table, sample_idx, db.records(), 0, db.total_kmers, chunk_records, &hits);

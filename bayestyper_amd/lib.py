@@ -59,6 +59,8 @@ bt_bloom_clear = _sig("bt_bloom_clear", [vp])
 bt_table_create = _sig("bt_table_create", [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp)])
 bt_table_destroy = _sig("bt_table_destroy", [vp])
 bt_table_status = _sig("bt_table_status", [vp, u64p, u64p, C.POINTER(C.c_int)])
+bt_table_clear = _sig("bt_table_clear", [vp])
+bt_table_reserve = _sig("bt_table_reserve", [vp, C.c_uint64])
 bt_table_insert_batch = _sig("bt_table_insert_batch", [vp, vp, C.c_uint64, C.c_int])
 bt_table_find_batch = _sig("bt_table_find_batch", [vp, vp, C.c_uint64, vp])
 bt_table_read_slots = _sig("bt_table_read_slots", [vp, vp, C.c_uint64, vp, vp])
@@ -83,6 +85,7 @@ bt_kmc_scan_create = _sig("bt_kmc_scan_create", [vp, C.c_uint32, C.c_uint32, C.c
 bt_kmc_scan_create_bins = _sig("bt_kmc_scan_create_bins", [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.c_uint64, C.POINTER(vp)])
 bt_kmc_scan_make_bloom = _sig("bt_kmc_scan_make_bloom", [vp, vp, vp, C.c_uint64, C.c_uint64])
 bt_kmc_scan_destroy = _sig("bt_kmc_scan_destroy", [vp])
+bt_kmc_scan_set_count_range = _sig("bt_kmc_scan_set_count_range", [vp, C.c_uint32, C.c_uint64])
 bt_kmc_scan_run = _sig("bt_kmc_scan_run", [vp, vp, vp, C.c_uint32, vp, C.c_uint64, C.c_uint64, vp])
 bt_kmc_scan_decode = _sig("bt_kmc_scan_decode", [vp, vp, C.c_uint64, C.c_uint64, vp, vp])
 
@@ -260,6 +263,12 @@ class Table:
         nk, cap, ov = C.c_uint64(), C.c_uint64(), C.c_int()
         check(bt_table_status(self.h, C.byref(nk), C.byref(cap), C.byref(ov)))
         return {"num_keys": nk.value, "capacity": cap.value, "overflowed": bool(ov.value)}
+
+    def clear(self):
+        check(bt_table_clear(self.h))
+
+    def reserve(self, expected):
+        check(bt_table_reserve(self.h, expected))
 
     def insert(self, packed, mark_parameter=False):
         packed = np.ascontiguousarray(packed, dtype=np.uint64)
@@ -442,6 +451,9 @@ class KmcScan:
         h = vp()
         check(bt_kmc_scan_create_bins(ctx.h, k, p, counter_size, total, _np_ptr(lut), len(lut), C.byref(h)))   # len: 4^p + 1, or bins * 4^p + 1 (KMC2)
         self.h = h.value
+
+    def set_count_range(self, min_count, max_count):
+        check(bt_kmc_scan_set_count_range(self.h, min_count, max_count))
 
     def make_bloom(self, bloom, d_records_ptr, first_record, n):
         check(bt_kmc_scan_make_bloom(self.h, bloom.h, d_records_ptr, first_record, n))

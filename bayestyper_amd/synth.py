@@ -48,8 +48,10 @@ class ClusterSpec:
 
 
 def make_cluster(rng, V, H, kmers_per_allele, flank_kmers=0, ic_kmers=0, has_dependency=False):
-    """biallelic variants; haplotype 0 is all-reference, the others are distinct random allele combinations"""
+    """biallelic variants; haplotype 0 is all-reference, the others are distinct random allele combinations.
+    kmers_per_allele: one number, or a [V][2] table (k-mers of the reference / alternative allele of every variant)"""
     c = ClusterSpec(H, V)
+    kpa = np.broadcast_to(np.asarray(kmers_per_allele, np.int64).reshape(-1, 2) if np.ndim(kmers_per_allele) else np.full((V, 2), int(kmers_per_allele)), (V, 2))
     if has_dependency:
         c.var_has_dep[:] = 1
         c.var_num_alleles[:] = 3
@@ -71,8 +73,9 @@ def make_cluster(rng, V, H, kmers_per_allele, flank_kmers=0, ic_kmers=0, has_dep
     for v in range(V):
         for a in (0, 1):
             carriers = c.hap_allele[:, v] == a
-            rows = np.tile(carriers.astype(np.uint8), (kmers_per_allele, 1))
-            c.add_kmers(rows, [[(v, carriers.copy())] for _ in range(kmers_per_allele)])
+            n_ka = int(kpa[v, a])
+            rows = np.tile(carriers.astype(np.uint8), (n_ka, 1))
+            c.add_kmers(rows, [[(v, carriers.copy())] for _ in range(n_ka)])
     if flank_kmers:   # k-mers on every haplotype, overlapping no variant allele specifically
         c.add_kmers(np.ones((flank_kmers, H), np.uint8), [[] for _ in range(flank_kmers)])
     if ic_kmers:      # allele k-mers that also occur once elsewhere in the genome (intercluster multiplicity 2 = diploid)
@@ -104,11 +107,13 @@ def group_shape_D(rng, cid=0):
     return GroupSpec([make_cluster(rng, 8, 256, 250)], [cid])
 
 
-def group_shape_C(rng, cid=0, root_H=32, root_kpa=500, child_kpa=55, shared_frac=0.05):
-    """root (V=6, variant 0 = a deletion that removes both children) + two nested children; ~5 % multicluster k-mers"""
-    root = make_cluster(rng, 6, root_H, root_kpa)
-    kids = [make_cluster(rng, 4, 10, child_kpa, has_dependency=True) for _ in range(2)]
-    cids = [cid, cid + 1, cid + 2]
+def group_shape_C(rng, cid=0, root_H=32, root_kpa=500, child_kpa=55, shared_frac=0.05, root_V=6, kids=None):
+    """root (variant 0 = a deletion that removes the children) + nested children; ~5 % multicluster k-mers.
+    kids: list of (V, H, kmers_per_allele) of the children (default: two of shape B)"""
+    root = make_cluster(rng, root_V, root_H, root_kpa)
+    kid_dims = kids if kids is not None else [(4, 10, child_kpa)] * 2
+    kids = [make_cluster(rng, v, h, kpa, has_dependency=True) for v, h, kpa in kid_dims]
+    cids = [cid + i for i in range(1 + len(kids))]
     for h in range(root.H):
         if root.hap_allele[h, 0] == 0:           # haplotypes without the deletion run through the nested regions
             root.hap_nested[h] = sorted(cids[1:])
@@ -123,7 +128,45 @@ def group_shape_C(rng, cid=0, root_H=32, root_kpa=500, child_kpa=55, shared_frac
         root.add_kmers(np.tile(carriers.astype(np.uint8), (n, 1)), [[(0, carriers.copy())] for _ in range(n)], shared=ids)
         kid.add_kmers(np.ones((n, kid.H), np.uint8), [[] for _ in range(n)], shared=ids)
         n_sh += n
-    return GroupSpec([root] + kids, cids, edges=[[1, 2], [], []], sources=[0], num_shared=n_sh)
+    return GroupSpec([root] + kids, cids, edges=[list(range(1, 1 + len(kids)))] + [[] for _ in kids], sources=[0], num_shared=n_sh)
+
+
+def _allele_kmers(rng, k=55, sv=False):
+    """(reference, alternative) k-mer counts of one candidate variant: an SNV has k per allele; an insertion / deletion of
+    L nucleotides k-1 on the short and k-1+L on the long allele (SV: hundreds to thousands of nucleotides)"""
+    u = rng.random()
+    if not sv and u < 0.7:
+        return (k, k)
+    L = int(rng.integers(200, 3000)) if sv else int(min(50, rng.geometric(0.2)))
+    return (k - 1, k - 1 + L) if rng.random() < 0.5 else (k - 1 + L, k - 1)
+
+
+def hetero_group(rng, shape, S, cid=0):
+    """One group of a shape class with its dimensions (variants, haplotype candidates, k-mers per allele, flank / intercluster k-mers,
+    nested children) drawn from the class's distribution — real clusters of a class differ, which is what pads tiles and diverges lanes."""
+    if shape == "A":     # one biallelic SNV / indel
+        return GroupSpec([make_cluster(rng, 1, 2, [_allele_kmers(rng)], flank_kmers=int(rng.integers(0, 4)) if rng.random() < 0.2 else 0,
+                                       ic_kmers=int(rng.integers(1, 4)) if rng.random() < 0.05 else 0)], [cid])
+    if shape == "B":     # a few SNVs / indels within k-1 of each other
+        V = int(rng.integers(2, 7))
+        H = int(min(2 ** V, max(V + 1, rng.integers(4, 17))))   # every allele is on some candidate (they come from paths)
+        return GroupSpec([make_cluster(rng, V, H, [_allele_kmers(rng) for _ in range(V)], flank_kmers=int(rng.integers(0, 40)),
+                                       ic_kmers=int(rng.integers(0, 3)))], [cid])
+    if shape == "C":     # an SV region: a large root cluster (a deletion over nested small clusters + neighbours)
+        V = int(rng.integers(3, 9))
+        H = int(min(2 ** V, max(V + 1, rng.integers(8, 33))))
+        kpa = [_allele_kmers(rng, sv=True)] + [_allele_kmers(rng, sv=rng.random() < 0.3) for _ in range(V - 1)]
+        kids = []
+        for _ in range(int(rng.integers(1, 4))):
+            v = int(rng.integers(2, 6))
+            kids.append((v, int(min(2 ** v, max(v + 1, rng.integers(4, 13)))), [_allele_kmers(rng) for _ in range(v)]))
+        return group_shape_C(rng, cid, root_H=H, root_kpa=kpa, root_V=V, kids=kids)
+    if shape == "D":     # the many-candidate tail: up to --max-number-of-sample-haplotypes (32) candidates per sample
+        Hmax = min(256, 32 * S)
+        H = int(rng.integers(max(16, Hmax // 2), Hmax + 1))
+        V = int(rng.integers(6, 11))
+        return GroupSpec([make_cluster(rng, V, H, [(int(rng.integers(100, 301)),) * 2 for _ in range(V)])], [cid])
+    raise ValueError(shape)
 
 
 SHAPES = {"A": group_shape_A, "B": group_shape_B, "C": group_shape_C, "D": group_shape_D}
@@ -285,8 +328,8 @@ _OFFSET_OF = {   # offset array -> the arrays it indexes (used by replicate())
 
 
 def replicate(flat, N, rng, mean=15.0, var=30.0, noise=0.05):
-    """Vectorised: N copies of a single-template flat batch (any number of groups in the template) with fresh random counts
-    for single-cluster groups (shapes A, B, D).  Group indices become 0..N*G-1."""
+    """Vectorised: N copies of a template batch (any number of groups, nested groups included), every copy with its own truth
+    diplotypes and fresh counts.  Group indices become 0..N*G-1 (copy-major)."""
     G0, C0, S = flat["num_groups"], flat["num_clusters"], flat["S"]
     out = dict(flat)
     out["num_groups"], out["num_clusters"] = G0 * N, C0 * N
@@ -301,27 +344,61 @@ def replicate(flat, N, rng, mean=15.0, var=30.0, noise=0.05):
         step = o[-1]
         body = (o[None, :-1] + (np.arange(N, dtype=np.uint64) * step)[:, None]).reshape(-1)
         out[k] = np.concatenate([body, [step * N]]).astype(np.uint32)
-    # fresh counts for single-cluster groups
-    if C0 == G0:
-        p, size = mean / var, mean * mean / (var - mean)
-        counts = out["kmer_counts"].reshape(N, -1, S).copy()
-        for c in range(C0):
+    p, size = mean / var, mean * mean / (var - mean)
+    gender = flat["gender"].astype(np.int64)
+    counts = out["kmer_counts"].reshape(N, -1, S).copy()
+    mult_off = np.concatenate([[0], np.cumsum(flat["num_haplotypes"].astype(np.int64) * (flat["kmer_off"][1:].astype(np.int64) - flat["kmer_off"][:-1].astype(np.int64)))])
+    hap_base = np.concatenate([[0], np.cumsum(flat["num_haplotypes"].astype(np.int64))])
+    for g in range(G0):
+        c0, c1 = int(flat["group_cluster_off"][g]), int(flat["group_cluster_off"][g + 1])
+        base_pl = flat["group_ploidy"][g * S:(g + 1) * S].astype(np.int64)
+        dips = {}                                  # cluster -> (haplotypes (N,S,2), valid (N,S,2))
+        parent = {}
+        for c in range(c0, c1):
+            for e in flat["edges"][int(flat["edge_off"][c]):int(flat["edge_off"][c + 1])]:
+                parent[c0 + int(e)] = c
+        for c in range(c0, c1):                    # parents precede their children in the templates
             H = int(flat["num_haplotypes"][c])
             r0, r1 = int(flat["kmer_off"][c]), int(flat["kmer_off"][c + 1])
-            m0 = int(sum(int(flat["num_haplotypes"][i]) * (int(flat["kmer_off"][i + 1]) - int(flat["kmer_off"][i])) for i in range(c)))
-            M = flat["hap_kmer_mult"][m0:m0 + (r1 - r0) * H].reshape(r1 - r0, H).astype(np.int64)
+            M = flat["hap_kmer_mult"][mult_off[c]:mult_off[c + 1]].reshape(r1 - r0, H).astype(np.int64)
             ic = flat["kmer_ic_mult"][2 * r0:2 * r1].reshape(-1, 2).astype(np.int64)
-            freq = rng.dirichlet(np.ones(H), size=N)                      # (N,H)
+            if c in parent:                        # copies = parent haplotypes that run through this cluster
+                pc = parent[c]
+                ph, pv = dips[pc]
+                through = np.zeros(int(flat["num_haplotypes"][pc]), bool)
+                cid = int(flat["cluster_idx"][c])
+                for h in range(len(through)):
+                    a, b = int(flat["hapnest_off"][hap_base[pc] + h]), int(flat["hapnest_off"][hap_base[pc] + h + 1])
+                    through[h] = cid in flat["hapnest_idx"][a:b]
+                pl = (pv & through[ph]).sum(-1)    # (N,S)
+            else:
+                pl = np.broadcast_to(base_pl, (N, S))
+            freq = rng.dirichlet(np.ones(H), size=N)
             cum = np.cumsum(freq, axis=1)
             u = rng.random((N, S, 2))
             hs = (u[..., None] > cum[:, None, None, :]).sum(-1).clip(0, H - 1)   # (N,S,2)
-            m = M[:, hs[..., 0]] + M[:, hs[..., 1]]                       # (K,N,S)
-            m = np.transpose(m, (1, 0, 2)) + ic[None, :, flat["gender"].astype(np.int64)]   # (N,K,S)
+            valid = np.arange(2)[None, None, :] < pl[..., None]
+            dips[c] = (hs, valid)
+            m = M[:, hs[..., 0]] * valid[None, ..., 0] + M[:, hs[..., 1]] * valid[None, ..., 1]     # (K,N,S)
+            m = np.transpose(m, (1, 0, 2)) + ic[None, :, gender]                                     # (N,K,S)
             cnt = rng.poisson(np.where(m > 0, 0.0, noise))
             pos = m > 0
             cnt[pos] = rng.negative_binomial(size * m[pos], p)
+            cnt[:, flat["kmer_has_counts"][r0:r1] == 0, :] = 0
             counts[:, r0:r1, :] = np.minimum(cnt, 255).astype(np.uint8)
-        out["kmer_counts"] = np.ascontiguousarray(counts.reshape(-1))
+        # multicluster k-mers are ONE k-mer: every row that shares a record carries the same (observed) counts
+        first = {}
+        for c in range(c0, c1):
+            r0, r1 = int(flat["kmer_off"][c]), int(flat["kmer_off"][c + 1])
+            sh = flat["kmer_shared"][r0:r1]
+            for k in np.nonzero(sh >= 0)[0]:
+                j = int(sh[k])
+                if j in first:
+                    counts[:, r0 + k, :] = counts[:, first[j], :]
+                else:
+                    counts[:, r0 + k, :] = np.maximum(counts[:, r0 + k, :], 1)
+                    first[j] = r0 + k
+    out["kmer_counts"] = np.ascontiguousarray(counts.reshape(-1))
     return out
 
 
@@ -339,6 +416,17 @@ def make_batch(shape, n_groups, S, seed, templates=1):
     tmpl = flatten([SHAPES[shape](rng, i) for i in range(templates)], S, rng)
     reps = (n_groups + templates - 1) // templates
     return replicate(tmpl, reps, rng)
+
+
+def make_hetero_batch(shape, n_groups, S, seed):
+    """n_groups groups of one shape class, every one with its own dimensions (hetero_group) — built group by group (tests)"""
+    rng = np.random.default_rng(seed)
+    groups, cid = [], 0
+    for _ in range(n_groups):
+        g = hetero_group(rng, shape, S, cid)
+        cid += len(g.clusters)
+        groups.append(g)
+    return flatten(groups, S, rng)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -404,32 +492,36 @@ def concat(flats):
     return out
 
 
-def make_mixture(n_groups, S, seed, fractions=None, templates=4):
-    """WGS-like mixture of group shapes, ordered by number of variants descending like the reference
-    sorts groups (main.cpp:247).  Shape D (H=256) needs >= 8 samples' worth of haplotype candidates and is left out
-    below that (--max-number-of-sample-haplotypes 32 caps H at 32*S)."""
-    if fractions is None:
-        fractions = {"A": 0.90, "B": 0.08, "C": 0.015, "D": 0.005} if S >= 8 else {"A": 0.90, "B": 0.085, "C": 0.015}
+MIXTURE = {"A": 0.90, "B": 0.08, "C": 0.015, "D": 0.005}     # BASELINE.md §3 (est. WGS-like)
+TEMPLATES = {"A": 384, "B": 384, "C": 96, "D": 32}              # distinct structures per shape class in a mixture batch
+
+
+def make_mixture(n_groups, S, seed, fractions=None, templates=None, hetero=True):
+    """WGS-like mixture of group shapes, ordered by size descending like the reference sorts groups (main.cpp:247).
+    hetero: the dimensions of every structure (variants, haplotype candidates, k-mers, nested children) are drawn per template from
+    the class's distribution (hetero_group); each of the `templates[shape]` structures is instantiated n / templates times, every
+    instance with its own truth genotypes and counts.  Shape D, the many-candidate tail, has up to 32 x S candidates (the
+    --max-number-of-sample-haplotypes cap), at most 256.  hetero=False: the fixed textbook shapes of SURVEY §8d."""
+    fractions = dict(MIXTURE) if fractions is None else fractions
+    tcount = dict(TEMPLATES)
+    if isinstance(templates, int):
+        tcount = {k: templates for k in tcount}
+    elif templates:
+        tcount.update(templates)
     rng = np.random.default_rng(seed)
     flats, counts = [], {}
     for shape in ("D", "C", "B", "A"):
-        if shape not in fractions:
-            continue
-        n = int(round(n_groups * fractions[shape]))
+        n = int(round(n_groups * fractions.get(shape, 0)))
         if n == 0:
             continue
-        counts[shape] = n
-        t = min(templates, n)
-        if shape == "C":
-            cid = 0
-            groups = []
-            for _ in range(t):
-                g = SHAPES[shape](rng, cid)
-                cid += 3
-                groups.append(g)
-            tmpl = flatten(groups, S, rng)
-        else:
-            tmpl = flatten([SHAPES[shape](rng, i) for i in range(t)], S, rng)
+        t = min(tcount[shape], n)
+        counts[shape] = (n + t - 1) // t * t   # whole instances of every structure
+        groups, cid = [], 0
+        for _ in range(t):
+            g = hetero_group(rng, shape, S, cid) if hetero else SHAPES[shape](rng, cid)
+            cid += len(g.clusters)
+            groups.append(g)
+        tmpl = flatten(groups, S, rng)
         reps = (n + t - 1) // t
         flats.append(replicate(tmpl, reps, rng))
     out = concat(flats)

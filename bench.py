@@ -2,21 +2,26 @@
 """bench.py — BayesTyper hot path on MI355X: variant-cluster Gibbs iterations/sec + k-mer matches/sec.
 
 One "step" = one pass of the hot path over one batch of synthetic input held in HBM:
-  (1) the KMC count-table scan of one sample's record stream (decode -> path-Bloom test -> count-table update,
-      KmerCounter::parseSampleKmers), then
+  (1) k-mer matching (KmerCounter::parseSampleKmers, KmerCounter.cpp:388-524): the count table is emptied and the KMC record
+      stream of EVERY sample is scanned into it (decode -> path-Bloom test -> count-table update).  Sample 0's scan inserts the
+      matched k-mers (the cold path), the others find them and add their counts — the weighting of a real S-sample run;
   (2) the default-mode Gibbs schedule (20 chains x (100 burn-in + 250 collected) sweeps,
-      InferenceEngine::estimateGenotypesCallback) for every variant-cluster group of the batch, then
+      InferenceEngine::estimateGenotypesCallback) for every variant-cluster group of the batch;
   (3) the compact posterior summary per (cluster, sample), gathered to rank 0 (RCCL when --gpus > 1).
 
-Workload at N=1 (BASELINE.json configs[1]): "GRCh38 chr20, 1 sample, ~200k candidate variants, k=55": 150 000
-variant-cluster groups in the WGS-like shape mixture of BASELINE.md §3 (S=1), and a 2x10^8-record KMC stream with a
-2 % path-k-mer hit rate against a fpr-1e-4 ThreadedKmerBloom of 2.5x10^7 path k-mers.  Weak scaling: every rank gets a
-batch of the same size (its own groups, its own byte range of the KMC stream).
+Workload at N=1 = BASELINE.json configs[2], the largest single-GPU configuration ("GRCh38 whole genome, CEU trio (3 samples),
+SNV+indel+SV merged candidates"): S=3 and one launch-sized slice of the unit — 150 000 variant-cluster groups in the WGS-like
+mixture of BASELINE.md §3 (90 % biallelic SNV/indel groups, 8 % multi-variant clusters, 1.5 % nested SV groups, 0.5 % many-candidate
+clusters with up to 32 x S haplotype candidates), every structure with its own dimensions (bayestyper_amd/synth.py: hetero_group) and
+every group with its own truth genotypes and counts; a whole genome (5-15 x 10^6 groups) is a sequence of such launches.  KMC: a
+2x10^8-record stream per sample (13-byte records, k=55, p=7), 2 % path-k-mer hit rate against a fpr-1e-4 ThreadedKmerBloom of
+2.5x10^7 path k-mers.  --samples 10 gives the north star's 10-sample mixture.  Weak scaling (default): every rank gets a batch of the
+same size (its own groups, its own KMC stream); --scaling strong shards ONE batch over the ranks (LPT on a cost proxy).
 
-Prints ONE JSON line (rank 0).  `value` = variant-cluster Gibbs iterations (cluster-sweeps) per second over the whole
-job; k-mer matches/sec is reported beside it.  `roofline` describes the dominant kernel (the Gibbs sweep kernel);
-`roofline_kmer_match` the KMC scan kernel.  `cpu_baseline` times the oracle (a scalar restatement of the reference's
-algorithm, parity-pinned in tests/) on a bounded sample of the same workload on this box's host cores.
+Prints ONE JSON line (rank 0).  `value` = variant-cluster Gibbs iterations (cluster-sweeps) per second over the whole job; k-mer
+matches/sec is reported beside it.  `roofline` describes the dominant kernel (the Gibbs sweep kernel); `roofline_kmer_match` the KMC
+scan kernel (average over the S launches of a step: one inserting, S-1 finding).  `cpu_baseline` times the oracle (a scalar
+restatement of the reference's algorithm, parity-pinned in tests/) on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
 import json
@@ -42,11 +47,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--groups", type=int, default=150_000, help="variant-cluster groups per GPU")
-    ap.add_argument("--samples", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--verify", action="store_true", help="strong scaling: rank 0 also runs the unsharded batch afterwards; the gathered summaries must equal it")
     ap.add_argument("--records", type=int, default=200_000_000, help="KMC records per GPU per step")
     ap.add_argument("--path-kmers", type=int, default=25_000_000)
     ap.add_argument("--hit-rate", type=float, default=0.02)
-    ap.add_argument("--cpu-groups-per-core", type=int, default=40)
+    ap.add_argument("--cpu-groups-per-core", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the graph-stage throughput figures")
     ap.add_argument("--path-clusters", type=int, default=50_000)
@@ -80,15 +87,36 @@ def main():
     S = args.samples
 
     # ------------------------------------------------------------------ Gibbs batch (this rank's groups)
-    flat = synth.make_mixture(args.groups, S, seed=1000 + rank)
-    flat["group_index"] = (flat["group_index"].astype(np.uint64) + rank * flat["num_groups"]).astype(np.uint32)   # global group index -> seeds
+    from bayestyper_amd import shard
+
+    strong = args.scaling == "strong" and world > 1
+    if strong:     # ONE batch, sharded: every rank builds the same unit and keeps its groups (global group indices -> seeds)
+        unit = synth.make_mixture(args.groups, S, seed=1000)
+        my_ids = shard.assign_groups(shard.group_cost(unit), world)[rank]
+        flat = shard.take_groups(unit, my_ids)
+        my_clusters = shard.cluster_ids_of(unit, my_ids)
+        flat["mixture"] = unit["mixture"]
+        C_total = unit["num_clusters"]
+        if not (args.verify and rank == 0):
+            del unit
+    else:          # weak: a batch of the same size per rank
+        flat = synth.make_mixture(args.groups, S, seed=1000 + rank)
+        flat["group_index"] = (flat["group_index"].astype(np.uint64) + rank * flat["num_groups"]).astype(np.uint32)   # global group index -> seeds
+        C_total = flat["num_clusters"] * world
     G, C = flat["num_groups"], flat["num_clusters"]
     lut_g, lut_n = count_model.build_luts(S, mean=15.0, var=30.0, noise_rate=0.05)
     gibbs = lib.Gibbs(ctx, flat, lut_g, lut_n, seed=42)
     sweeps_per_group = gibbs.params.num_chains * (gibbs.params.burn_in + gibbs.params.num_iterations)
-    cluster_sweeps_per_step = C * sweeps_per_group
+    gibbs_chains, gibbs_device_bytes = gibbs.params.num_chains, gibbs.device_bytes()
+    cluster_sweeps_per_step = C_total * sweeps_per_group          # whole job
     d_summary = torch.zeros(C * S * 2, dtype=torch.int32, device=dev)
-    gathered = [torch.zeros_like(d_summary) for _ in range(world)] if (world > 1 and rank == 0) else None
+    if world > 1:   # ranks hold different numbers of clusters under strong scaling: padded gather
+        c_all = torch.zeros(world, dtype=torch.int64, device=dev)
+        c_all[rank] = C
+        dist.all_reduce(c_all)
+        c_max = int(c_all.max().item())
+        d_pad = torch.zeros(c_max * S * 2, dtype=torch.int32, device=dev)
+        gathered = [torch.zeros_like(d_pad) for _ in range(world)] if rank == 0 else None
 
     # ------------------------------------------------------------------ KMC stream + path Bloom + count table (in HBM)
     R = args.records
@@ -113,17 +141,19 @@ def main():
     lib.check(lib.bt_bloom_insert_batch(bloom.h, absent.data_ptr(), absent.shape[0]))
     torch.cuda.synchronize()
     del kmers, cnts, absent
-    table = lib.Table(ctx, max(int(n_hit * 1.5), 1024), 30, K)
+    table = lib.Table(ctx, max(int(n_hit * 1.5), 1024), S, K)
     d_hits = torch.zeros(1, dtype=torch.int64, device=dev)
-    t_gibbs, t_kmc = lib.Timer(ctx), lib.Timer(ctx)
+    t_gibbs, t_kmc = lib.Timer(ctx), [lib.Timer(ctx) for _ in range(S)]
 
     def step(i, timed):
-        # (1) k-mer matching: sample column i % 30 of the count table
-        if timed:
-            t_kmc.start()
-        scan.run(bloom, table, i % 30, records.data_ptr(), 0, R, d_hits.data_ptr())
-        if timed:
-            t_kmc.stop()
+        # (1) k-mer matching: a fresh table per step, one scan per sample (column s of the count table)
+        table.clear()
+        for smp in range(S):
+            if timed:
+                t_kmc[smp].start()
+            scan.run(bloom, table, smp, records.data_ptr(), 0, R, d_hits.data_ptr())
+            if timed:
+                t_kmc[smp].stop()
         # (2) Gibbs: the whole default schedule for every group of the batch
         if timed:
             t_gibbs.start()
@@ -133,9 +163,10 @@ def main():
         # (3) posterior summaries -> rank 0
         lib.check(lib.bt_gibbs_posterior_summary(gibbs.h, d_summary.data_ptr()))
         if world > 1:
-            dist.gather(d_summary, gathered, dst=0)
+            d_pad[: C * S * 2] = d_summary
+            dist.gather(d_pad, gathered, dst=0)
         if timed:
-            return t_kmc.elapsed_ms(), t_gibbs.elapsed_ms()
+            return [t.elapsed_ms() for t in t_kmc], t_gibbs.elapsed_ms()
         return None
 
     def barrier():
@@ -160,6 +191,34 @@ def main():
         elapsed = float(t.item())
     hits = int(d_hits.item())
     st = table.status()
+    if st["overflowed"]:
+        raise RuntimeError("bench: the count table overflowed")
+
+    # ------------------------------------------------------------------ strong scaling self-check: gathered summaries == the unsharded run
+    verified = None
+    if strong:
+        if rank == 0:
+            whole = torch.zeros(C_total * S * 2, dtype=torch.int32, device=dev).view(C_total, S * 2)
+        ids_t = torch.from_numpy(np.ascontiguousarray(my_clusters).astype(np.int64)).to(dev)
+        id_pad = torch.full((c_max,), -1, dtype=torch.int64, device=dev)
+        id_pad[:C] = ids_t
+        id_all = [torch.zeros_like(id_pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(id_pad, id_all, dst=0)
+        if rank == 0:
+            for r in range(world):
+                n = int((id_all[r] >= 0).sum().item())
+                whole[id_all[r][:n]] = gathered[r][: n * S * 2].view(n, S * 2)
+            if args.verify:
+                gibbs.close()
+                g_all = lib.Gibbs(ctx, unit, lut_g, lut_n, seed=42)
+                g_all.run()
+                ref_summary = torch.zeros(C_total * S * 2, dtype=torch.int32, device=dev)
+                lib.check(lib.bt_gibbs_posterior_summary(g_all.h, ref_summary.data_ptr()))
+                torch.cuda.synchronize()
+                verified = bool(torch.equal(ref_summary.view(C_total, S * 2), whole))
+                g_all.close()
+                if not verified:
+                    raise RuntimeError("bench --verify: the gathered summaries of the sharded run differ from the unsharded run")
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only): the oracle on host cores
     cpu = None
@@ -169,7 +228,7 @@ def main():
 
         orc = _oracle.load_oracle()
         cores = os.cpu_count() or 1
-        n_cpu = max(64, min(args.groups, args.cpu_groups_per_core * cores))
+        n_cpu = max(2048, min(args.groups, args.cpu_groups_per_core * cores))
         cflat = synth.make_mixture(n_cpu, S, seed=999)
         og_lut_g, og_lut_n = _oracle.build_luts(orc, S)
         og = _oracle.OrcGibbs(orc, cflat, og_lut_g, og_lut_n, seed=42)
@@ -202,7 +261,7 @@ def main():
             kcpu = None
         cpu = {"value": cpu_sweeps / cpu_s, "unit": "cluster-sweeps/s", "cores": cores, "kind": "port",
                "sample": f"{cflat['num_groups']} groups of the same shape mixture ({cflat['mixture']}), S={S}, full 20x350 schedule, "
-                         f"{cpu_s:.1f} s on {cores} threads (oracle/oracle_gibbs.cpp, one group per thread at a time)",
+                         f"{cpu_s:.1f} s on {cores} threads (oracle/oracle_gibbs.cpp; threads pull groups from a shared queue, largest first, as InferenceEngine.cpp:335-382)",
                "kmer_matches_per_sec_1core": kcpu}
 
     # ------------------------------------------------------------------ graph stages (rank 0, outside the timed region): best-path search,
@@ -257,7 +316,7 @@ def main():
         best = None
         for _ in range(2):   # the first pass also faults the pinned staging buffers in
             tp = time.perf_counter()
-            lib.check(fn(scan.h, bloom.h, table.h, 1, h_rec.ctypes.data, 0, n_host, 0, ct.byref(hh)))
+            lib.check(fn(scan.h, bloom.h, table.h, 0, h_rec.ctypes.data, 0, n_host, 0, ct.byref(hh)))
             dt = time.perf_counter() - tp
             best = dt if best is None else min(best, dt)
         pcie = {"records": int(n_host), "records_per_sec": n_host / best, "host_gbytes_per_sec": n_host * REC / best / 1e9,
@@ -266,54 +325,50 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed * 1000.0 / args.steps
-        total_cluster_sweeps = cluster_sweeps_per_step * world * args.steps
+        total_cluster_sweeps = cluster_sweeps_per_step * args.steps          # whole job (all ranks)
         gibbs_avg_ms = float(np.mean(gibbs_ms))
-        kmc_avg_ms = float(np.mean(kmc_ms))
-        gibbs_bytes = synth.algorithmic_bytes_per_chain(flat) * gibbs.params.num_chains     # one launch = all chains of all clusters
+        kmc = np.asarray(kmc_ms, np.float64)                                 # [steps][S] launch times
+        kmc_avg_ms = float(kmc.mean())                                       # average launch of kmc_scan_kernel in the timed region
+        kmc_step_ms = float(kmc.sum(axis=1).mean())                          # the S scans of a step
+        gibbs_bytes = synth.algorithmic_bytes_per_chain(flat) * gibbs_chains                   # one launch = all chains of all clusters
         gibbs_gbs = gibbs_bytes / (gibbs_avg_ms * 1e-3) / 1e9
         kmc_gbs = R * KMER_MATCH_BYTES_PER_RECORD / (kmc_avg_ms * 1e-3) / 1e9
-        # HBM traffic per launch from the PMC passes of the same command (profiles/, collected with rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs; counters cannot be read from inside this process).  Only reported for the default workload.
-        traffic, traffic_kmc, traffic_src = None, None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        default_workload = (args.groups, args.samples, args.records) == (150_000, 1, 200_000_000)
-        if default_workload and os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
-            traffic = pmc["gibbs_kernel_bytes_per_step"]["total"]
-            traffic_kmc = pmc["kmc_scan_kernel_bytes_per_launch"]["fetch_raw"] + pmc["kmc_scan_kernel_bytes_per_launch"]["write"]
-            traffic_src = "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE + WRITE_SIZE, KiB -> bytes, uncorrected; Infinity-Cache hits are counted)"
+        shape_note = ("BASELINE configs[2] WGS trio" if S == 3 else "BASELINE configs[3] 10-sample mixture" if S == 10 else "mixture") + \
+            ": one launch-sized slice of the unit, %d groups/GPU (%s; heterogeneous structures), S=%d, 20 chains x (100+250) sweeps; k-mer matching: %d scans/step of a " \
+            "%d-record KMC stream (13 B, k=55, p=7) into an emptied count table, %d path k-mers, hit rate %.3f, ThreadedKmerBloom fpr 1e-4" % (
+                G, flat["mixture"], S, S, R, args.path_kmers, args.hit_rate)
         out = {
             "metric": "variant-cluster Gibbs iterations/sec + k-mer matches/sec at 1/2/4/8 MI355X",
             "value": total_cluster_sweeps / elapsed,
             "unit": "variant-cluster Gibbs iterations (cluster-sweeps)/s",
-            "kmer_matches_per_sec": R * world / (kmc_avg_ms * 1e-3),
-            "gibbs_kernel_cluster_sweeps_per_sec": cluster_sweeps_per_step * world / (gibbs_avg_ms * 1e-3),
+            "kmer_matches_per_sec": S * R * world / (kmc_step_ms * 1e-3),
+            "kmer_hits_per_sec": hits / (args.steps + args.warmup) * world / (kmc_step_ms * 1e-3),
+            "gibbs_kernel_cluster_sweeps_per_sec": cluster_sweeps_per_step / (gibbs_avg_ms * 1e-3),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64 log-probabilities over u8 k-mer counts (Gibbs); u64/u8 integer (k-mer matching)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] chr20-like: %d groups/GPU (%s), S=%d, 20 chains x (100+250) sweeps; KMC stream %d records/GPU (13 B, k=55, p=7), "
-                                   "%d path k-mers, hit rate %.3f, ThreadedKmerBloom fpr 1e-4" % (G, flat["mixture"], S, R, args.path_kmers, args.hit_rate),
-                       "groups_per_gpu": G, "clusters_per_gpu": C, "samples": S, "kmc_records_per_gpu": R, "sharding": "groups and KMC byte ranges per rank; "
-                       "gather of posterior summaries to rank 0"},
+            "config": {"workload": shape_note, "groups_per_gpu": G, "clusters_per_gpu": C, "clusters_total": C_total, "samples": S, "kmc_records_per_gpu_per_sample": R,
+                       "sharding": ("one batch sharded over the ranks (LPT on a cost proxy); " if strong else "a batch of the same size per rank; ") +
+                                   "KMC streams per rank; gather of posterior summaries to rank 0", "sharded_equals_unsharded": verified},
             "roofline": {"kernel": "gibbs_kernel", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gibbs_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
-                         "note": "latency/issue-bound sequential sampler (one lane per variant-cluster group): the HBM floor (inputs + state once per chain, "
-                                 "SURVEY 8d) is tiny by construction; avg_launch_ms spans the sampling launch(es) of one schedule (tiles with large LDS needs form a second, concurrent launch); "
-                                 "measured traffic is dominated by the per-draw mt19937 state updates of 150k groups"},
+                         "traffic": None, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
+                         "note": "latency/issue-bound sequential sampler: the HBM floor (inputs + state once per chain, SURVEY 8d) is tiny by construction; "
+                                 "avg_launch_ms spans the sampling launch(es) of one schedule (tiles with large LDS needs form a second, concurrent launch); traffic is not "
+                                 "measurable from inside this process: the PMC passes of this command are in profiles/ (r02_pmc_*.json)"},
             "roofline_kmer_match": {"kernel": "kmc_scan_kernel", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": traffic_kmc, "avg_launch_ms": kmc_avg_ms, "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD,
-                                    "bloom_hits": hits, "table_keys": st["num_keys"]},
+                                    "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kmc_avg_ms, "launches_per_step": S,
+                                    "insert_launch_ms": float(kmc[:, 0].mean()), "find_launch_ms": float(kmc[:, 1:].mean()) if S > 1 else None,
+                                    "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD, "bloom_hits_per_scan": hits // ((args.steps + args.warmup) * S), "table_keys": st["num_keys"]},
             "cpu_baseline": cpu,
             "graph_stages": paths,
             "kmer_match_from_host_memory": pcie,
-            "gibbs_device_bytes": gibbs.device_bytes(),
+            "gibbs_device_bytes": gibbs_device_bytes,
         }
         if cpu:
             out["gpu_over_cpu_allcores"] = out["gibbs_kernel_cluster_sweeps_per_sec"] / cpu["value"]

@@ -146,6 +146,12 @@ typedef struct bt_table bt_table;
  * up to a power of two; an insert into a full table is an error reported by bt_table_status. */
 int bt_table_create(bt_ctx *ctx, uint64_t expected_size, uint32_t num_samples, uint32_t k, bt_table **out);
 int bt_table_destroy(bt_table *t);
+/* forget every record (the capacity stays): a fresh table for the next unit (main.cpp:513 constructs one per unit) */
+int bt_table_clear(bt_table *t);
+/* grow to hold `expected_size` records (2 x, power of two) and move the stored records over: the reference's HybridHash
+ * grows on demand (HybridHash.tpp:162); callers that know an upper bound of a stage's inserts reserve before it.
+ * No-op when the table is large enough; an error when records were already dropped (overflow flag). */
+int bt_table_reserve(bt_table *t, uint64_t expected_size);
 /* number of stored keys, capacity, overflow flag */
 int bt_table_status(bt_table *t, uint64_t *num_keys, uint64_t *capacity, int *overflowed);
 /* addKmer(kmer, sorted) for a batch; optionally mark as parameter k-mer
@@ -211,6 +217,9 @@ int bt_kmc_scan_create(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_
  * prefix is (LUT index) mod 4^p. */
 int bt_kmc_scan_create_bins(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, uint32_t counter_size, uint64_t total_records,
                             const uint64_t *h_prefix_lut, uint64_t num_lut_entries, bt_kmc_scan **out);
+/* the database header's [min_count, max_count]: records whose counter lies outside are skipped, as CKMCFile::ReadNextKmer does
+ * (external/kmc_api/kmc_file.cpp:496-511).  Default: no record is skipped. */
+int bt_kmc_scan_set_count_range(bt_kmc_scan *s, uint32_t min_count, uint64_t max_count);
 int bt_kmc_scan_destroy(bt_kmc_scan *s);
 /* Push records [first_record, first_record + n) of the .kmc_suf payload through
  * decode -> path_bloom.lookup -> (on hit) table.addKmer(unsorted) + addSampleCount(sample, count).

@@ -30,6 +30,7 @@
 #include <random>
 #include <sstream>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <unordered_map>
 #include <unordered_set>
@@ -951,10 +952,13 @@ void orc_gibbs_run(void *h, unsigned threads) {
         for (uint g = 0; g < O->groups.size(); g++) runGroupDefault(*O, g);
         return;
     }
+    // groups are handed out in batch order from a shared counter, as the reference's worker threads pull group batches from its
+    // ProducerConsumerQueue (InferenceEngine.cpp:335-382); batches arrive sorted by size, largest first (main.cpp:247)
+    std::atomic<uint> next(0);
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < threads; t++)
-        pool.emplace_back([O, t, threads]() {
-            for (uint g = t; g < O->groups.size(); g += threads) runGroupDefault(*O, g);
+        pool.emplace_back([O, &next]() {
+            for (uint g = next.fetch_add(1); g < O->groups.size(); g = next.fetch_add(1)) runGroupDefault(*O, g);
         });
     for (auto &th : pool) th.join();
 }

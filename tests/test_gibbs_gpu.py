@@ -90,6 +90,58 @@ def test_joint_shape_many_haplotypes(gpu_ctx, oracle, S):
     assert exact == flat["num_clusters"]
 
 
+@pytest.mark.parametrize("shape,n,kw", [("B", 12, dict(chains=2, burn=10, iters=20)), ("C", 3, dict(chains=2, burn=6, iters=12)), ("D", 2, dict(chains=2, burn=3, iters=6))])
+def test_config_C4_ten_samples_shapes_BCD(gpu_ctx, oracle, shape, n, kw):
+    """BASELINE configs[3] (WGS, 10 samples): the multi-variant, nested-SV and many-candidate shapes at S=10, every group with its own
+    dimensions (synth.hetero_group: ragged tiles), per-sweep diplotype traces and sampling frequencies against the oracle"""
+    from bayestyper_amd import synth
+
+    S = 10
+    flat = synth.make_hetero_batch(shape, n, S, seed=400 + ord(shape))
+    if shape == "D":
+        assert int(flat["num_haplotypes"].min()) >= 128
+    sweeps = kw["burn"] + kw["iters"]
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=sweeps, seed=17, **kw)
+    for g, (to, tg) in enumerate(tr):
+        assert np.array_equal(to, tg[: len(to)]), f"group {g}"
+    exact = assert_parity(flat, ro, rg, kw["chains"] * kw["iters"])
+    assert exact == flat["num_clusters"]
+
+
+def test_config_C5_noise_genotyping_joint_30_samples(gpu_ctx, oracle):
+    """BASELINE configs[4]: --noise-genotyping (estimateNoiseAndGenotypes, InferenceEngine.cpp:384-472) on the joint shape — 30 samples,
+    --max-number-of-sample-haplotypes 32 => 256 merged haplotype candidates per cluster — together with small clusters in the same
+    unit: every sampled noise rate of every iteration and the collected genotype samples against the oracle's driver."""
+    from bayestyper_amd import synth
+    from bayestyper_amd.host import count_model
+    from bayestyper_amd.host.inference_engine import InferenceEngine
+
+    S = 30
+    flat = synth.concat([synth.make_batch("D", 2, S, seed=51), synth.make_hetero_batch("B", 3, S, seed=52), synth.make_hetero_batch("A", 11, S, seed=53)])
+    flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
+    assert int(flat["num_haplotypes"].max()) == 256
+    kw = dict(seed=4321, chains=2, burn=2, iters=3)
+
+    def cd():
+        d = count_model.CountDistribution(S, prior=(1.0, 0.01), seed=kw["seed"])
+        for s in range(S):
+            d.set_genomic(s, 15.0, 30.0)
+        return d
+
+    cd_o, cd_g = cd(), cd()
+    og = _oracle.OrcGibbs(oracle, flat, *cd_o.tables(), noise_seeding=1, **kw)
+    want = og.estimate_noise_and_genotypes()
+    ro = og.results()
+    og.close()
+    eng = InferenceEngine(gpu_ctx, kw["seed"], burn=kw["burn"], samples=kw["iters"], chains=kw["chains"])
+    gg, got = eng.estimate_noise_and_genotypes(flat, cd_g)
+    rg = gg.results()
+    gg.close()
+    assert got.shape == (kw["chains"] * (1 + kw["burn"] + kw["iters"]), 2 + S) and np.array_equal(got, want)
+    exact = assert_parity(flat, ro, rg, kw["chains"] * kw["iters"])
+    assert exact == flat["num_clusters"]
+
+
 def test_default_schedule_shape_A(gpu_ctx, oracle):
     """the reference's default schedule: 20 chains x (100 burn-in + 250 collected) (main.cpp:389-391)"""
     from bayestyper_amd import synth

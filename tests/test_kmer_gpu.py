@@ -190,6 +190,84 @@ def test_kmc_decode_and_scan(gpu_ctx, oracle, tmp_path):
         x.close()
 
 
+def test_table_duplicates_in_a_wavefront_clear_reserve_overflow(gpu_ctx, oracle):
+    """addKmer under contention: every key 64 times in a row (the lanes of one wavefront race for one slot), colliding home slots in a
+    small table; bt_table_reserve moves every record (keys, flags, counts) into a larger table; bt_table_clear empties it; a table
+    that is too small reports the overflow instead of silently dropping records."""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(99)
+    uniq = oracle.pack(_oracle.canonical_ascii(oracle, _oracle.random_kmers(rng, 3000, K), K), K)
+    uniq = np.unique(uniq, axis=0)
+    t = lib.Table(gpu_ctx, 2000, 2, K)                      # capacity 4096: load 0.73, long probe chains
+    t.insert(np.repeat(uniq, 64, axis=0), mark_parameter=True)
+    st = t.status()
+    assert st["num_keys"] == len(uniq) and not st["overflowed"] and st["capacity"] == 4096
+    k0, c0, m0 = _sorted_export(*t.export())
+    assert np.array_equal(k0, _sorted_export(uniq, np.zeros((len(uniq), 2), np.uint8), np.zeros((len(uniq), 4), np.uint8))[0])
+    slots = t.find(uniq)
+    assert (slots >= 0).all() and len(np.unique(slots)) == len(uniq)
+    # grow: same records, new slots
+    t.reserve(100_000)
+    st = t.status()
+    assert st["capacity"] == 262144 and st["num_keys"] == len(uniq)
+    k1, c1, m1 = _sorted_export(*t.export())
+    assert np.array_equal(k0, k1) and np.array_equal(c0, c1) and np.array_equal(m0, m1) and (m1[:, 0] & 0x20).all()
+    assert (t.find(uniq) >= 0).all()
+    t.clear()
+    assert t.status()["num_keys"] == 0 and (t.find(uniq) == -1).all()
+    t.insert(uniq[:10])
+    assert t.status()["num_keys"] == 10
+    t.close()
+    # overflow is reported, and reserve refuses a table that already lost records
+    small = lib.Table(gpu_ctx, 100, 1, K)                   # capacity 1024
+    small.insert(uniq)
+    st = small.status()
+    assert st["overflowed"] and st["num_keys"] <= 1024
+    with pytest.raises(RuntimeError):
+        small.reserve(10_000)
+    small.close()
+
+
+def test_kmc_counter_range_filter(gpu_ctx, oracle, tmp_path):
+    """CKMCFile::ReadNextKmer skips records whose counter is outside the header's [min_count, max_count] (kmc_file.cpp:496-511):
+    a scan with the range set equals a scan of a database that holds only the in-range records; same for makeBloom"""
+    from bayestyper_amd import lib
+    from test_oracle_kmer import make_kmc
+
+    rng = np.random.default_rng(5)
+    prefix, km, counts = make_kmc(oracle, tmp_path, rng, 30_000, 7, 1, name="full")
+    lo, hi = 2, 6
+    keep = (counts >= lo) & (counts <= hi)
+    assert 0 < keep.sum() < len(counts)
+    sub = str(tmp_path / "sub")
+    oracle.kmc_write(sub, np.ascontiguousarray(km.reshape(-1, K)[keep]).reshape(-1), counts[keep].astype(np.uint32), K, 7, 1)
+    gb = lib.Bloom.create(gpu_ctx, len(counts), 1e-3, K, threaded=True)
+    gb.insert(oracle.pack(km, K))
+    tables, blooms = [], []
+    for pref, rng_ in ((prefix, (lo, hi)), (sub, None)):
+        db = OrcKmc(oracle, pref)
+        scan = lib.KmcScan(gpu_ctx, db.k, db.p, db.counter_size, db.total, db.lut())
+        if rng_:
+            scan.set_count_range(*rng_)
+        t = lib.Table(gpu_ctx, 40_000, 1, K)
+        d = gpu_ctx.to_device(db.payload())
+        scan.run(gb, t, 0, d.ptr, 0, db.total)
+        sb = lib.Bloom.create(gpu_ctx, 30_000, 1e-3, K, threaded=False)
+        scan.make_bloom(sb, d.ptr, 0, db.total)
+        gpu_ctx.sync()
+        tables.append(_sorted_export(*t.export()))
+        blooms.append(sb.bits(0))
+        for x in (t, sb, scan, db):
+            x.close()
+        d.free()
+    assert len(tables[0][0]) == keep.sum()
+    for a, b in zip(tables[0], tables[1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(blooms[0], blooms[1])
+    gb.close()
+
+
 def test_intercluster_and_classify(gpu_ctx, oracle):
     """countInterclusterKmers + the table half of classifyPathKmers: flags and multiplicities bit-exact"""
     from bayestyper_amd import lib
