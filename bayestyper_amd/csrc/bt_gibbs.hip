@@ -43,7 +43,7 @@ __device__ __noinline__ void group_init_chain(Env env, uint32_t chain, uint32_t 
             ev.resident = v;
         }
         PROF_DECL;
-        if (!make_vx(make_tile(ev), v).sc()[SC_CONSTRUCTED]) genotyper_construct(ev, v, gseed + c.cid);   // VariantClusterGroup.cpp:179-182
+        if (!make_vx(make_tile(ev), v).sc()[SC_CONSTRUCTED]) genotyper_construct(ev, v, gseed + c.cid());   // VariantClusterGroup.cpp:179-182
         genotyper_reset(ev, v);
         if (swap) hot_swap(env, v, false);
     }
@@ -65,7 +65,7 @@ __device__ __noinline__ void prepare_nested(Env env, uint32_t v_parent, uint32_t
     const Tile t = make_tile(env);
     const GParams BT_CAS &P = env_params(env);
     const Vx c = make_vx(t, v_parent), cc = make_vx(t, v_child);
-    const uint32_t nd_n = vx_nd(c);
+    const uint32_t nd_n = vx_nd(c), cc_cid = cc.cid();
     const TileDesc BT_CAS &d = c.d();
     SPtr<uint32_t, LANES> ndcl = c.a<uint32_t>(A_NDCL, d.NDm > 1 ? d.NDm : 1), ndvo = c.a<uint32_t>(A_NDVOFF, d.NDm + 1);
     SPtr<uint16_t, LANES> ndv = c.a<uint16_t>(A_NDVAR, d.NDVm > 1 ? d.NDVm : 1);
@@ -83,18 +83,18 @@ __device__ __noinline__ void prepare_nested(Env env, uint32_t v_parent, uint32_t
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 const uint32_t val = c.hn_idx(mid);
-                if (val == cc.cid) {
+                if (val == cc_cid) {
                     found = true;
                     break;
                 }
-                if (val < cc.cid) lo = mid + 1;
+                if (val < cc_cid) lo = mid + 1;
                 else hi = mid;
             }
             if (found) continue;
             ploidy = ploidy == 2 ? 1 : 0;   // updateNestedPloidy
             uint32_t variant_idx = 0xFFFFFFFFu;
             for (uint32_t dd = 0; dd < nd_n; ++dd) {
-                if (ndcl[dd] != cc.cid) continue;
+                if (ndcl[dd] != cc_cid) continue;
                 for (uint32_t i = ndvo[dd], i1 = ndvo[dd + 1]; i < i1; ++i) {
                     const uint32_t nv = ndv[i];
                     const uint32_t a = c.hap_allele(h, nv);
@@ -124,6 +124,7 @@ __device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GPar
         env.resident = v;
     }
     PROF(13);
+    rng_topup(env, v);
     sample_diplotypes(env, v, collect, trace_row.off + v * P.S * LANES, tracing, (uint32_t *)trace_row.base);
     sample_haplotype_frequencies(env, v);
     PROF_DECL2;
@@ -275,6 +276,11 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
             const Vx c = make_vx(t, v);
             SPtr<uint32_t, LANES> e0 = c.a<uint32_t>(A_EDGES0, t.d->NEm > 1 ? t.d->NEm : 1), e1 = c.edges();
             for (uint32_t i = 0, n = vx_ne(c); i < n; ++i) e1[i] = e0[i];
+            SPtr<uint32_t, LANES> dm = t.arr<uint32_t>(A_VDIMS, v * 8);   // dimensions the samplers read at every call: next to the state scalars
+            SPtrF<uint32_t, LANES> sc = c.sc();
+            sc[SC_H] = dm[0];
+            sc[SC_V] = dm[1];
+            sc[SC_NM] = dm[4];
         }
     }
     if (whole)
@@ -410,7 +416,7 @@ const uint32_t kElemSize[A_COUNT] = {
     /*MT*/ 4, /*FNDSAVED*/ 8, /*SPARSITY*/ 8, /*UNIQ*/ 4, /*MULTI*/ 4, /*USUB*/ 4, /*MSUB*/ 4, /*SMM*/ 1, /*DIP*/ 2, /*FREQ*/ 8, /*OBS*/ 4, /*NZ*/ 1,
     /*ZHDR*/ 4, /*ZBKT*/ 4, /*PHDR*/ 4, /*PBKT*/ 4, /*UNEXT*/ 4, /*HVCOUNT*/ 4, /*UCACHE*/ 8, /*UCTAG*/ 4, /*CUM*/ 8, /*NZLIST*/ 2, /*SIMPLEX*/ 8,
     /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*SC*/ 4,
-    /*EDGES*/ 4, /*COVER*/ 1, /*MCACHE*/ 8, /*MCTAG*/ 4, /*MCGEN*/ 4, /*MGEN*/ 4, /*OTH*/ 1, /*SUBM*/ 1, /*SUBCNT*/ 1, /*SUBIC*/ 1, /*SKVOFF*/ 4, /*SKVVAR*/ 2, /*SKVBITS*/ 4, /*KSCTMP*/ 8, /*LOGF*/ 8, /*PEND*/ 4, /*PENDDIP*/ 2, /*PENDVALID*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1, /*MSUBM*/ 1, /*MSUBC*/ 1, /*MSUBIC*/ 1, /*MSUBSH*/ 4};
+    /*EDGES*/ 4, /*COVER*/ 1, /*MCACHE*/ 8, /*MCTAG*/ 4, /*MCGEN*/ 4, /*MGEN*/ 4, /*OTH*/ 1, /*SUBM*/ 1, /*SUBCNT*/ 1, /*SUBIC*/ 1, /*SKVOFF*/ 4, /*SKVVAR*/ 2, /*SKVBITS*/ 4, /*KSCTMP*/ 8, /*LOGF*/ 8, /*PEND*/ 4, /*PENDDIP*/ 2, /*PENDVALID*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1, /*MSUBM*/ 1, /*MSUBC*/ 1, /*MSUBIC*/ 1, /*MSUBSH*/ 4, /*RING*/ 4};
 
 }  // namespace
 
@@ -716,6 +722,15 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_STACK] = 2 * (nv + 1);
         len[A_BRNG] = MT_PAD;
         len[A_SHMULT] = (uint64_t)std::max<uint32_t>(d.NSHm, 1) * S;
+        // draw-ahead rings (MtRing): the diplotype generator consumes exactly two words per sample and visit, the frequency generator
+        // a few words per non-zero haplotype; both are topped up at the start of a visit
+        d.ring_cap[0] = 8;
+        while (d.ring_cap[0] < 2 * S && d.ring_cap[0] < 32) d.ring_cap[0] *= 2;
+        d.ring_cap[1] = 16;
+        if (const char *e = getenv("BT_GIBBS_RING0")) d.ring_cap[0] = (uint32_t)atoi(e);
+        if (const char *e = getenv("BT_GIBBS_RING1")) d.ring_cap[1] = (uint32_t)atoi(e);
+        d.ring_len = d.ring_cap[0] + d.ring_cap[1] + 2 * MT_RING_HDR;
+        len[A_RING] = nv * d.ring_len;
         uint64_t off = 0, in_bytes = 0;
         for (int a = 0; a < A_COUNT; ++a) {
             off = align_up(off, 256);
@@ -727,7 +742,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             // hot arrays (bt_gibbs_tile.hpp: Vx::harr users) -> offsets inside the wavefront's LDS block
             for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
             const int hot_arrs[] = {A_SC, A_DIP, A_NESTPL, A_NESTN, A_KSCUPD, A_MGEN, A_PEND, A_PENDDIP, A_PENDVALID, A_FREQ, A_LOGF, A_OBS, A_NZ, A_NZLIST,
-                                    A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_KSCTMP, A_CUM};
+                                    A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_KSCTMP, A_CUM, A_RING, A_FNDSAVED, A_UCACHE};
             // LDS rows are interleaved over the tile's lanes only (16 / 32 / 64): a narrow tile needs a fraction of the LDS per vertex,
             // which lets every vertex of a multi-cluster group stay resident instead of being swapped around each visit
             d.lds_stride = 1;
@@ -735,6 +750,9 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             uint64_t ho = 0;
             for (int a : hot_arrs) {
                 if (a == A_CUM && d.D2m > 16) continue;
+                // the dense table of unique-k-mer sums is read for every candidate of every sample: a few entries per lane (two-haplotype
+                // clusters x a few samples) stay in LDS for the launch
+                if (a == A_UCACHE && !(d.cache_mode == 0 && d.uc_width == 0 && d.nvm == 1 && (uint64_t)d.cache_entries * 8 <= 160)) continue;
                 const uint64_t per_vertex = len[a] / nv;   // elements per lane and vertex
                 d.hoff[a] = (uint32_t)ho;
                 ho = align_up(ho + per_vertex * d.lds_stride * kElemSize[a], 16);
@@ -1199,7 +1217,7 @@ int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *v
     if (!ops || !values || !h_order || !n) return fail("bt_diag_uset_replay: null argument");
     std::vector<uint32_t> hdr(4), bkt(uset_bucket_capacity(universe)), next(std::max<uint32_t>(universe, 1));
     std::vector<uint8_t> present(universe, 0);
-    USet s{sptr1(hdr.data()), sptr1(bkt.data()), sptr1(next.data())};
+    USet s{sptr1(hdr.data()), sptr1(bkt.data()), sptr1(next.data()), (uint32_t)bkt.size()};
     uset_init(s);
     for (uint64_t i = 0; i < num_ops; ++i) {
         if (ops[i] == 2) {
@@ -1242,7 +1260,7 @@ int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint6
     Mt st = mt_open(stv.data());
     double saved = 0;
     uint32_t avail = 0;
-    NormalState nd{(double BT_GAS *)&saved, &avail};
+    NormalState nd{&saved, &avail};
     switch (kind) {
         case 0:
             for (uint64_t i = 0; i < n; ++i) h_out[i] = (double)mt_next(st);

@@ -31,7 +31,10 @@ constexpr double BT_DBL_EPS = 2.220446049250313080847263336181640625e-16;
 constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
 
 // scalar slots per vertex (A_SC)
-enum { SC_USE_MULTI = 0, SC_NSUB_U, SC_NSUB_M, SC_HAP_COUNT, SC_CONSTRUCTED, SC_DIP_ENTRIES, SC_DIP_OVERFLOW, SC_IS_SPARSE, SC_FND_AVAIL, SC_UC_DIRTY, SC_COUNT };
+// SC_H .. SC_NM: the cluster's dimensions (copied from A_VDIMS by OP_SETUP, never cleared): with the scalars in LDS a sampler function
+// starts without a round trip to HBM
+enum { SC_USE_MULTI = 0, SC_NSUB_U, SC_NSUB_M, SC_HAP_COUNT, SC_CONSTRUCTED, SC_DIP_ENTRIES, SC_DIP_OVERFLOW, SC_IS_SPARSE, SC_FND_AVAIL, SC_UC_DIRTY, SC_H, SC_V, SC_NM, SC_COUNT };
+constexpr uint32_t SC_STATE_COUNT = SC_H;   // slots a (re)constructed genotyper resets
 
 // arrays of a tile.  [V] = per vertex (index v*LEN + i), [G] = per group
 enum TileArr {
@@ -114,6 +117,7 @@ enum TileArr {
     A_MSUBC,        // u8  [V] NMm*S          their observed counts
     A_MSUBIC,       // u8  [V] NMm*2          their intercluster multiplicities
     A_MSUBSH,       // u32 [V] NMm            their slot in the group's shared-multiplicity table
+    A_RING,         // u32 [V] ring_len       draw-ahead rings of the cluster's two generators (MtRing blocks: ring_cap[g] + MT_RING_HDR words each)
     A_COUNT
 };
 
@@ -129,6 +133,7 @@ struct TileDesc {
     uint32_t uc_width;              // 0: the unique-sum table is lane-interleaved like every other array; else it is per-lane contiguous over uc_width lanes
     uint32_t mat_width;             // the same for the two K x H multiplicity matrices (A_M, A_SUBM): 0 interleaved, else the tile's lane count
     uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (4 .. 64); lds_all: every vertex has its own LDS block (no swaps)
+    uint32_t ring_cap[2], ring_len; // draw-ahead words of the diplotype / frequency generator (powers of two); ring_len = both blocks
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 constexpr uint32_t RESIDENT_ALL = 0xFFFFFFFEu;   // Env/Tile::resident: every vertex of the group has its hot arrays in LDS
@@ -181,8 +186,12 @@ struct Env {
 
 struct Vx {   // vertex context: tile + vertex index + the lane's true dimensions of that vertex
     Tile t;
-    uint32_t v, H, V, K, nu, nm, cid;
+    uint32_t v, H, V, nm;
     __device__ inline const TileDesc BT_CAS &d() const { return *t.d; }
+    // dimensions only the chain start needs stay in HBM
+    __device__ inline uint32_t K() const { return t.arr<uint32_t>(A_VDIMS, v * 8)[2]; }
+    __device__ inline uint32_t nu() const { return t.arr<uint32_t>(A_VDIMS, v * 8)[3]; }
+    __device__ inline uint32_t cid() const { return t.arr<uint32_t>(A_VDIMS, v * 8)[7]; }
     template <typename T>
     __device__ inline SPtr<T, LANES> a(int arr, uint32_t len) const { return t.arr<T>(arr, v * len); }
     template <typename T>
@@ -192,7 +201,14 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
         __device__ inline T BT_GAS &operator[](uint32_t i) const { return base[off + i * stride]; }
         __device__ inline RPtr<T> operator+(uint32_t i) const { return RPtr<T>{base, off + i * stride, stride}; }
     };
-    typedef RPtr<double> UCPtr;
+    template <typename T>
+    struct FPtr {   // the same through a generic pointer (LDS or HBM)
+        T *base;
+        uint32_t off, stride;
+        __device__ inline T &operator[](uint32_t i) const { return base[off + i * stride]; }
+        __device__ inline FPtr<T> operator+(uint32_t i) const { return FPtr<T>{base, off + i * stride, stride}; }
+    };
+    typedef FPtr<double> UCPtr;
     // the K x H multiplicity matrices of a narrow tile are per-lane contiguous too (they are the bulk of a large cluster's state)
     __device__ inline RPtr<uint8_t> mat(int arr, uint32_t rows) const {
         uint8_t BT_GAS *b = (uint8_t BT_GAS *)(t.base + d().off[arr]);
@@ -217,6 +233,9 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint32_t allele_base(uint32_t var) const { return a<uint32_t>(A_ALBASE, d().Vm + 1)[var]; }
     // state
     __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)(v * 2 + g) * LANES + t.lane) * MT_PAD; }
+    __device__ inline SPtrF<uint32_t, LANES> ring(uint32_t g) const { return t.harr<uint32_t>(A_RING, v, d().ring_len) + (g ? d().ring_cap[0] + MT_RING_HDR : 0u); }
+    __device__ inline MtRing rng(uint32_t g) const { return mt_ring_open(mt(g), ring(g), d().ring_cap[g]); }
+    __device__ inline void rng_seed(uint32_t g, uint32_t seed) const { mt_ring_seed(mt(g), ring(g), d().ring_cap[g], seed); }
     __device__ inline SPtrF<uint32_t, LANES> sc() const { return t.harr<uint32_t>(A_SC, v, SC_COUNT); }
     __device__ inline SPtr<uint32_t, LANES> uniq() const { return a<uint32_t>(A_UNIQ, d().NUm); }
     __device__ inline SPtr<uint32_t, LANES> multi() const { return a<uint32_t>(A_MULTI, d().NMm); }
@@ -237,14 +256,17 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtrF<uint8_t, LANES> nz() const { return t.harr<uint8_t>(A_NZ, v, d().Hm); }
     __device__ inline SPtrF<uint32_t, LANES> unext() const { return t.harr<uint32_t>(A_UNEXT, v, d().Hm); }
     typedef USetP<SPtrF<uint32_t, LANES>> HSet;
-    __device__ inline HSet zero_set() const { return HSet{t.harr<uint32_t>(A_ZHDR, v, 4), t.harr<uint32_t>(A_ZBKT, v, d().Bcap), unext()}; }
-    __device__ inline HSet plus_set() const { return HSet{t.harr<uint32_t>(A_PHDR, v, 4), t.harr<uint32_t>(A_PBKT, v, d().Bcap), unext()}; }
+    __device__ inline HSet zero_set() const { return HSet{t.harr<uint32_t>(A_ZHDR, v, 4), t.harr<uint32_t>(A_ZBKT, v, d().Bcap), unext(), d().Bcap}; }
+    __device__ inline HSet plus_set() const { return HSet{t.harr<uint32_t>(A_PHDR, v, 4), t.harr<uint32_t>(A_PBKT, v, d().Bcap), unext(), d().Bcap}; }
     __device__ inline SPtr<uint32_t, LANES> hvcount() const { return a<uint32_t>(A_HVCOUNT, (uint32_t)d().Hm * d().Vm); }
     // the [S][D] table of unique-k-mer sums.  Wide tiles: lane-interleaved.  Narrow tiles (whose lanes would leave most of every
     // 64-lane row unused): each lane's table contiguous, so a tile pays for its own lanes only and even 256 candidates x 30 samples
     // (10^6 entries, 8 MB) stay dense
     __device__ inline UCPtr ucache() const {
-        double BT_GAS *b = (double BT_GAS *)(t.base + d().off[A_UCACHE]);
+        const uint32_t ho = d().hoff[A_UCACHE];
+        if (t.hot != nullptr && ho != NOHOT && (t.resident == RESIDENT_ALL || v == t.resident))   // a table of a few entries lives in LDS
+            return UCPtr{(double *)(t.hot + (t.resident == RESIDENT_ALL ? v * d().hot_bytes : 0u) + ho), t.lane, d().lds_stride};
+        double *b = (double *)(uint8_t *)(t.base + d().off[A_UCACHE]);
         const uint32_t w = d().uc_width;
         if (w) return UCPtr{b, (v * w + t.lane) * d().cache_entries, 1u};
         return UCPtr{b, v * d().cache_entries * LANES + t.lane, LANES};
@@ -281,7 +303,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtrF<uint32_t, LANES> pend() const { return t.harr<uint32_t>(A_PEND, v, d().S); }
     __device__ inline SPtrF<uint16_t, LANES> pend_dip() const { return t.harr<uint16_t>(A_PENDDIP, v, 2 * d().S); }
     __device__ inline SPtrF<uint8_t, LANES> pend_valid() const { return t.harr<uint8_t>(A_PENDVALID, v, d().S); }
-    __device__ inline double BT_GAS &fnd_saved() const { return a<double>(A_FNDSAVED, 1)[0]; }
+    __device__ inline double &fnd_saved() const { return t.harr<double>(A_FNDSAVED, v, 1)[0]; }
     __device__ inline double BT_GAS &sparsity() const { return a<double>(A_SPARSITY, 1)[0]; }
     __device__ inline NormalState fnd() const { return NormalState{&fnd_saved(), &sc()[SC_FND_AVAIL]}; }   // `available` may live in LDS
     __device__ inline SPtr<uint8_t, LANES> shared_mult() const { return t.arr<uint8_t>(A_SHMULT); }
@@ -326,13 +348,10 @@ __device__ inline Vx make_vx(const Tile &t, uint32_t v) {
     Vx x;
     x.t = t;
     x.v = v;
-    SPtr<uint32_t, LANES> dm = t.arr<uint32_t>(A_VDIMS, v * 8);
-    x.H = dm[0];
-    x.V = dm[1];
-    x.K = dm[2];
-    x.nu = dm[3];
-    x.nm = dm[4];
-    x.cid = dm[7];
+    SPtrF<uint32_t, LANES> sc = t.harr<uint32_t>(A_SC, v, SC_COUNT);
+    x.H = sc[SC_H];
+    x.V = sc[SC_V];
+    x.nm = sc[SC_NM];
     return x;
 }
 __device__ inline uint32_t vx_nd(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, c.v * 8)[5]; }
@@ -392,6 +411,9 @@ __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
     hot_copy<uint32_t>(t, A_PEND, v, d.S, to_lds, voff);
     hot_copy<uint16_t>(t, A_PENDDIP, v, 2 * d.S, to_lds, voff);
     hot_copy<uint8_t>(t, A_PENDVALID, v, d.S, to_lds, voff);
+    hot_copy<uint32_t>(t, A_RING, v, d.ring_len, to_lds, voff);
+    hot_copy<double>(t, A_FNDSAVED, v, 1, to_lds, voff);
+    hot_copy<double>(t, A_UCACHE, v, d.cache_entries, to_lds, voff);   // (hot only when the whole table is a few words per lane)
     // per-haplotype arrays: only this lane's H entries are live (rows are Hm apart; the tail is never read)
     const uint32_t H = t.arr<uint32_t>(A_VDIMS, v * 8)[0];
     hot_copy<double>(t, A_FREQ, v, d.Hm, to_lds, voff, H);
@@ -522,7 +544,8 @@ __device__ inline void freq_reset(const Vx &c) {
 
 // ---- SparsityEstimator::estimateMinimumColumnCover (SparsityEstimator.cpp:41-87), unweighted ----
 // returns the cover size; uses `rng` (freshly seeded by the caller), cover_rows, obs (column sums), nzlist
-__device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
+template <class G>
+__device__ inline uint32_t sparsity_cover(const Vx &c, G &rng) {
     SPtr<uint8_t, LANES> rows = c.cover_rows();
     SPtrF<uint32_t, LANES> obs = c.obs();
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
@@ -548,7 +571,7 @@ __device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
     };
     uint32_t remaining = 0;
     for (uint32_t h = 0; h < H; ++h) obs[h] = 0;
-    for (uint32_t k = 0; k < c.K; ++k) {
+    for (uint32_t k = 0, K = c.K(); k < K; ++k) {
         const uint8_t r = c.has_counts(k) ? 1 : 0;
         rows[k] = r;
         remaining += r;
@@ -574,7 +597,7 @@ __device__ inline uint32_t sparsity_cover(const Vx &c, Mt &rng) {
         }
         const uint32_t col = nzl[pick];
         ++cover;
-        for (uint32_t k = 0; k < c.K; ++k)
+        for (uint32_t k = 0, K = c.K(); k < K; ++k)
             if (rows[k] && M[k * Hm + col] != 0) {
                 rows[k] = 0;
                 --remaining;
@@ -589,13 +612,13 @@ __device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const TileDesc BT_CAS &d = c.d();
-    mt_seed(c.mt(0), prng_seed);
+    c.rng_seed(0, prng_seed);
     SPtrF<uint32_t, LANES> sc = c.sc();
-    for (uint32_t i = 0; i < SC_COUNT; ++i) sc[i] = 0;
+    for (uint32_t i = 0; i < SC_STATE_COUNT; ++i) sc[i] = 0;
     // a (re)built genotyper starts from the k-mer index lists in first-seen order (they are shuffled in place per chain)
     {
         SPtr<uint32_t, LANES> u0 = c.a<uint32_t>(A_UNIQ0, d.NUm), u = c.uniq(), m0 = c.a<uint32_t>(A_MULTI0, d.NMm), m = c.multi();
-        for (uint32_t i = 0; i < c.nu; ++i) u[i] = u0[i];
+        for (uint32_t i = 0, nu = c.nu(); i < nu; ++i) u[i] = u0[i];
         for (uint32_t i = 0; i < c.nm; ++i) m[i] = m0[i];
     }
     SPtrF<uint16_t, LANES> dip = c.dip();
@@ -621,14 +644,13 @@ __device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t
         for (uint32_t i = 0; i < d.scache_n; ++i) sl[i] = 0;
     }
     // SparsityEstimator(prng_seed), then (Sparse)FrequencyDistribution(.., prng_seed) with a fresh generator
-    uint32_t *fr = c.mt(1);
-    mt_seed(fr, prng_seed);
+    c.rng_seed(1, prng_seed);
     uint32_t cover;
     {
-        Mt m = mt_open(fr);
+        MtRing m = c.rng(1);
         cover = sparsity_cover(c, m);
     }
-    mt_seed(fr, prng_seed);
+    c.rng_seed(1, prng_seed);
     c.fnd_saved() = 0;
     sc[SC_FND_AVAIL] = 0;
     sc[SC_IS_SPARSE] = cover > 0 ? 1u : 0u;   // HaplotypeFrequencyDistribution.cpp:79-89
@@ -709,17 +731,18 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
     for (uint32_t h = 0; h < c.H; ++h)
         for (uint32_t v = 0; v < c.V; ++v) hv[(uint32_t)h * Vm + v] = 0;
     uint32_t nsu = 0, nsm = 0;
-    Mt rng = mt_open(c.mt(0));
+    MtRing rng = c.rng(0);
     SPtr<uint32_t, LANES> uniq = c.uniq(), usub = c.usub(), multi = c.multi(), msub = c.msub();
     PROF_DECL;
     // The generator is consumed exactly as the reference does (shuffle, one Bernoulli draw per k-mer; unique list, then the
     // multicluster list), but the isMaxHaplotypeVariantKmer filter — which draws nothing — runs afterwards over the selected
     // k-mers only, in the same order: every lane then works on ITS j-th selected k-mer instead of the wave stepping through
     // all k-mers with the ~10 % of lanes that selected that one.
-    rng_shuffle_u32(rng, uniq, c.nu);
+    const uint32_t nu = c.nu();
+    rng_shuffle_u32(rng, uniq, nu);
     PROF(8);
     uint32_t nu_sel = 0, nm_sel = 0;
-    for (uint32_t i = 0; i < c.nu; ++i)
+    for (uint32_t i = 0; i < nu; ++i)
         if (rng_bernoulli(rng, P.rate)) usub[nu_sel++] = uniq[i];
     rng_shuffle_u32(rng, multi, c.nm);
     for (uint32_t i = 0; i < c.nm; ++i)
@@ -1307,7 +1330,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         sc[SC_UC_DIRTY] = 0;
     }
     PROF(12);
-    Mt rng = mt_open(c.mt(0));
+    MtRing rng = c.rng(0);
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
     SPtrF<double, LANES> logf = c.logf(), cum = c.cum();
     SPtrF<uint16_t, LANES> dip = c.dip();
@@ -1541,6 +1564,17 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
     sc[SC_USE_MULTI] = nsub_m != 0 ? 1u : 0u;
 }
 
+// Top the draw-ahead rings of a cluster's two generators up at the start of a visit: the whole wavefront refills together (one burst
+// of independent state loads per generator), and the draws of the visit then read LDS.  Generating ahead does not change the stream.
+__device__ __noinline__ void rng_topup(Env env, uint32_t vtx) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    MtRing a = c.rng(0), b = c.rng(1);
+    a.topup();
+    b.topup();
+    mt_close(a);
+    mt_close(b);
+}
+
 // ---- SparseFrequencyDistribution::updateCachedSimplexProbVector (FrequencyDistribution.cpp:143-196) -> out[], returns length ----
 // Every lgamma argument in that formula is a positive integer (<= H + 2S + 1): the values come from a host-computed table.
 template <typename Q>
@@ -1582,7 +1616,7 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
     const uint32_t n_obs = sc[SC_HAP_COUNT];
     PROF_DECL;
     if (n_obs > 0) {
-        Mt rng = mt_open(c.mt(1));
+        MtRing rng = c.rng(1);
         const NormalState nd = c.fnd();
         SPtrF<uint32_t, LANES> obs = c.obs();
         SPtrF<double, LANES> freq = c.freq();
@@ -1609,19 +1643,30 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
             // function of (n_obs, |plus|), so caching it or not is invisible; cached when the tile reserved room for it
             uint32_t len;
             SPtr<double, LANES> vec = c.simplex();
-            if (d.scache_n && n_obs <= 2 * d.S && plus_size <= d.scache_p) {
-                const uint32_t ci = (n_obs - 1) * d.scache_p + (plus_size - 1);
-                vec = c.scache() + (uint32_t)ci * d.scache_len;
-                len = c.sclen()[ci];
-                if (len == 0) {
-                    len = simplex_prob_vector(c, P, vec, n_obs, plus_size);
-                    c.sclen()[ci] = len;
-                }
-            } else
+            const bool cached = d.scache_n && n_obs <= 2 * d.S && plus_size <= d.scache_p;
+            const uint32_t ci = cached ? (n_obs - 1) * d.scache_p + (plus_size - 1) : 0u;
+            if (cached) vec = c.scache() + (uint32_t)ci * d.scache_len;
+            // the first entries of a cached vector are requested together with its length (one memory round trip instead of a
+            // dependent chain of them: the search below usually ends within the first two entries)
+            constexpr uint32_t PRE = 4;
+            const uint32_t pre = d.scache_len < PRE ? d.scache_len : PRE;
+            double head[PRE];
+#pragma unroll
+            for (uint32_t q = 0; q < PRE; ++q) head[q] = (cached && q < pre) ? (double)vec[q] : 0.0;
+            len = cached ? (uint32_t)c.sclen()[ci] : 0u;
+            if (len == 0) {
                 len = simplex_prob_vector(c, P, vec, n_obs, plus_size);
+                if (cached) c.sclen()[ci] = len;
+#pragma unroll
+                for (uint32_t q = 0; q < PRE; ++q) head[q] = q < len ? (double)vec[q] : 0.0;
+            }
             const double u = rng_canonical(rng);
-            uint32_t ub = 0;
-            while (ub < len && !(u < vec[ub])) ++ub;   // upper_bound over a non-decreasing vector
+            uint32_t ub = 0;   // upper_bound over a non-decreasing vector
+#pragma unroll
+            for (uint32_t q = 0; q < PRE; ++q)
+                if (ub == q && q < len && !(u < head[q])) ub = q + 1;
+            if (ub == PRE)
+                while (ub < len && !(u < vec[ub])) ++ub;
             const uint32_t simplex_size = ub + plus_size;
             double norm = 0;
             for (uint32_t e = uset_begin(plus); e != US_NONE; e = unext[e]) {

@@ -104,16 +104,6 @@ BT_HD void mt_seed(uint32_t *st, uint32_t seed) {
 // position p, only words that the block form has in the same old/new state (p+1 is still old, p+397 mod 624 is old for
 // p < 227 and already new afterwards), so the output stream is identical — and no lane ever runs a 624-step refill loop
 // while its wavefront neighbours wait.
-// A generator in use: state words in memory + the position held in a register for the duration of a call sequence
-// (mt_open loads it, mt_close writes it back).  With the position in a register the three state loads of a draw have
-// independent addresses, i.e. ONE memory round trip per draw instead of a dependent chain of four.
-struct Mt {
-    uint32_t BT_GAS *st;
-    uint32_t pos;
-};
-BT_HD Mt mt_open(uint32_t *st) { return Mt{(uint32_t BT_GAS *)st, ((uint32_t BT_GAS *)st)[MT_N]}; }
-BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
-
 BT_HD uint32_t mt_temper(uint32_t z) {
     z ^= (z >> 11);
     z ^= (z << 7) & 0x9d2c5680u;
@@ -127,65 +117,153 @@ BT_HD uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {   // new word from
 }
 BT_HD uint32_t mt_wrap(uint32_t i) { return i >= MT_N ? i - MT_N : i; }
 
-BT_HD uint32_t mt_next(Mt &m) {
-    const uint32_t p = m.pos, p1 = mt_wrap(p + 1), pm = mt_wrap(p + MT_M);
-    const uint32_t z = mt_twist(m.st[p], m.st[p1], m.st[pm]);
-    m.st[p] = z;
-    m.pos = p1;
-    return mt_temper(z);
+// A generator in use, DIRECT form: state words in memory + the position held in a register for the duration of a call sequence
+// (mt_open loads it, mt_close writes it back).  With the position in a register the three state loads of a draw have
+// independent addresses, i.e. ONE memory round trip per draw instead of a dependent chain of four.
+struct Mt {
+    uint32_t BT_GAS *st;
+    uint32_t pos;
+    BT_HD uint32_t next() {
+        const uint32_t p = pos, p1 = mt_wrap(p + 1), pm = mt_wrap(p + MT_M);
+        const uint32_t z = mt_twist(st[p], st[p1], st[pm]);
+        st[p] = z;
+        pos = p1;
+        return mt_temper(z);
+    }
+    // two / four consecutive words with all state loads issued together: none of the regenerated words is an input of another (the
+    // recurrence reaches 1 and 397 positions ahead and 227 behind), so loading everything first and storing afterwards gives the
+    // textbook stream
+    template <unsigned N>
+    BT_HD void next_n(uint32_t (&out)[N]) {
+        const uint32_t p = pos;
+        uint32_t a[N + 1], c[N];
+#pragma unroll
+        for (uint32_t k = 0; k < N + 1; ++k) a[k] = st[mt_wrap(p + k)];
+#pragma unroll
+        for (uint32_t k = 0; k < N; ++k) c[k] = st[mt_wrap(mt_wrap(p + k) + MT_M)];
+#pragma unroll
+        for (uint32_t k = 0; k < N; ++k) {
+            const uint32_t z = mt_twist(a[k], a[k + 1], c[k]);
+            st[mt_wrap(p + k)] = z;
+            out[k] = mt_temper(z);
+        }
+        pos = mt_wrap(p + N);
+    }
+};
+BT_HD Mt mt_open(uint32_t *st) { return Mt{(uint32_t BT_GAS *)st, ((uint32_t BT_GAS *)st)[MT_N]}; }
+BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
+
+// DRAW-AHEAD form (the Gibbs kernels): the same stream, but the generator's output is produced in bursts of up to 16 words — all the
+// state loads of a burst are independent, so a burst is ONE memory round trip — into a small ring that lives in LDS, and the sampler's
+// draws read the ring.  A draw then costs an LDS access instead of a dependent HBM round trip per call; bursts are issued for the
+// whole wavefront at fixed points (mt_ring_topup at the start of a cluster visit), so the lanes of a wavefront refill together.
+// Ring block of one generator: [cap] tempered words, then {position of the next state word to generate, ring head, words available}.
+constexpr unsigned MT_RING_HDR = 3;
+struct MtRing {
+    uint32_t BT_GAS *st;
+    SPtrF<uint32_t, 1> ring;   // element i of the ring block at ring[i] (LDS when the cluster's hot arrays are resident, else HBM)
+    uint32_t cap;              // power of two, <= 64
+    uint32_t pos, head, avail;
+    // generate n more words (n <= cap - avail), bursts of 16
+    BT_HD void generate(uint32_t n) {
+        while (n > 0) {
+            const uint32_t c = n < 16u ? n : 16u, p = pos;
+            uint32_t a[17], b[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 17; ++k) a[k] = k <= c ? st[mt_wrap(p + k)] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) b[k] = k < c ? st[mt_wrap(mt_wrap(p + k) + MT_M)] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k)
+                if (k < c) {
+                    const uint32_t z = mt_twist(a[k], a[k + 1], b[k]);
+                    st[mt_wrap(p + k)] = z;
+                    ring[(head + avail + k) & (cap - 1u)] = mt_temper(z);
+                }
+            pos = mt_wrap(p + c);
+            avail += c;
+            n -= c;
+        }
+    }
+    BT_HD void topup() { generate(cap - avail); }
+    BT_HD void need(uint32_t n) {
+        if (avail < n) generate(cap - avail < 16u ? cap - avail : 16u);
+    }
+    BT_HD uint32_t next() {
+        need(1);
+        const uint32_t w = ring[head];
+        head = (head + 1u) & (cap - 1u);
+        avail -= 1u;
+        return w;
+    }
+    template <unsigned N>
+    BT_HD void next_n(uint32_t (&out)[N]) {
+        need(N);
+#pragma unroll
+        for (uint32_t k = 0; k < N; ++k) out[k] = ring[(head + k) & (cap - 1u)];
+        head = (head + N) & (cap - 1u);
+        avail -= N;
+    }
+};
+template <class RP>
+BT_HD MtRing mt_ring_open(uint32_t *st, RP ring, uint32_t cap) {
+    MtRing m;
+    m.st = (uint32_t BT_GAS *)st;
+    m.ring = SPtrF<uint32_t, 1>{ring.base, ring.off, ring.stride};
+    m.cap = cap;
+    m.pos = m.ring[cap];
+    m.head = m.ring[cap + 1];
+    m.avail = m.ring[cap + 2];
+    return m;
+}
+BT_HD void mt_close(const MtRing &m) {
+    m.ring[m.cap] = m.pos;
+    m.ring[m.cap + 1] = m.head;
+    m.ring[m.cap + 2] = m.avail;
+}
+template <class RP>
+BT_HD void mt_ring_seed(uint32_t *st, RP ring, uint32_t cap, uint32_t seed) {
+    mt_seed(st, seed);
+    ring[cap] = 0;
+    ring[cap + 1] = 0;
+    ring[cap + 2] = 0;
 }
 
-// generate_canonical<double, 53>(mt19937): two draws fused so that all five state loads are issued together
-// (draw 2 reads st[p+1] as it was BEFORE draw 1 replaced st[p]; draw 1 does not modify st[p+1])
-BT_HD double rng_canonical(Mt &m) {
-    const uint32_t p = m.pos, p1 = mt_wrap(p + 1), p2 = mt_wrap(p + 2), pm = mt_wrap(p + MT_M), pm1 = mt_wrap(p + MT_M + 1);
-    const uint32_t a = m.st[p], b = m.st[p1], c = m.st[p2], d = m.st[pm];
-    // st[pm1] may be the word draw 1 has just replaced (only when p + 398 wraps onto p, impossible: 398 < 624) — always an independent word
-    const uint32_t e = m.st[pm1];
-    const uint32_t z0 = mt_twist(a, b, d);
-    // draw 2 needs st[p+398]: if that index equals p (never) it would need z0
-    const uint32_t z1 = mt_twist(b, c, e);
-    m.st[p] = z0;
-    m.st[p1] = z1;
-    m.pos = p2;
-    double sum = (double)mt_temper(z0);
-    sum += (double)mt_temper(z1) * 4294967296.0;
+template <class G>
+BT_HD uint32_t mt_next(G &m) { return m.next(); }
+
+// generate_canonical<double, 53>(mt19937): two draws
+template <class G>
+BT_HD double rng_canonical(G &m) {
+    uint32_t w[2];
+    m.template next_n<2>(w);
+    double sum = (double)w[0];
+    sum += (double)w[1] * 4294967296.0;
     double ret = sum / 18446744073709551616.0;
     if (ret >= 1.0) ret = 0.99999999999999988897769753748434595763683319091796875;   // nextafter(1, 0)
     return ret;
 }
 
-// two consecutive generate_canonical<double, 53> draws (four words) with all nine state loads issued together: the polar method of
-// normal_distribution draws its two uniforms back to back, and every memory round trip of a rejection loop is paid by the whole
-// wavefront until its last lane accepts.  None of the four regenerated words is an input of another (the recurrence reaches 1 and
-// 397 positions ahead and 227 behind), so loading everything first and storing afterwards gives the textbook stream.
-BT_HD void rng_canonical2(Mt &m, double &first, double &second) {
-    const uint32_t p = m.pos;
-    uint32_t a[5], c[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 5; ++k) a[k] = m.st[mt_wrap(p + k)];
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) c[k] = m.st[mt_wrap(mt_wrap(p + k) + MT_M)];
-    uint32_t z[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        z[k] = mt_twist(a[k], a[k + 1], c[k]);
-        m.st[mt_wrap(p + k)] = z[k];
-    }
-    m.pos = mt_wrap(p + 4);
+// two consecutive generate_canonical<double, 53> draws (four words): the polar method of normal_distribution draws its two uniforms
+// back to back, and every memory round trip of a rejection loop is paid by the whole wavefront until its last lane accepts
+template <class G>
+BT_HD void rng_canonical2(G &m, double &first, double &second) {
+    uint32_t w[4];
+    m.template next_n<4>(w);
     const double top = 0.99999999999999988897769753748434595763683319091796875;   // nextafter(1, 0)
-    double s0 = (double)mt_temper(z[0]);
-    s0 += (double)mt_temper(z[1]) * 4294967296.0;
+    double s0 = (double)w[0];
+    s0 += (double)w[1] * 4294967296.0;
     first = s0 / 18446744073709551616.0;
     if (first >= 1.0) first = top;
-    double s1 = (double)mt_temper(z[2]);
-    s1 += (double)mt_temper(z[3]) * 4294967296.0;
+    double s1 = (double)w[2];
+    s1 += (double)w[3] * 4294967296.0;
     second = s1 / 18446744073709551616.0;
     if (second >= 1.0) second = top;
 }
 
 // uniform_int_distribution<>(0, b) for b < 2^32 - 1: range = b + 1
-BT_HD uint32_t rng_uniform_int(Mt &st, uint32_t range) {
+template <class G>
+BT_HD uint32_t rng_uniform_int(G &st, uint32_t range) {
     uint64_t product = (uint64_t)mt_next(st) * (uint64_t)range;
     uint32_t low = (uint32_t)product;
     if (low < range) {
@@ -198,11 +276,12 @@ BT_HD uint32_t rng_uniform_int(Mt &st, uint32_t range) {
     return (uint32_t)(product >> 32);
 }
 
-BT_HD bool rng_bernoulli(Mt &st, double p) { return rng_canonical(st) < p; }
+template <class G>
+BT_HD bool rng_bernoulli(G &st, double p) { return rng_canonical(st) < p; }
 
 // std::shuffle over a uint32 array in caller memory
-template <typename Arr>
-BT_HD void rng_shuffle_u32(Mt &st, Arr a, uint32_t n) {
+template <class G, typename Arr>
+BT_HD void rng_shuffle_u32(G &st, Arr a, uint32_t n) {
     if (n == 0) return;
     const uint64_t urngrange = 0xFFFFFFFFull;
     if (urngrange / n >= n) {
@@ -231,12 +310,13 @@ BT_HD void rng_shuffle_u32(Mt &st, Arr a, uint32_t n) {
 }
 
 // normal_distribution<double>(0,1) + gamma_distribution<double>; `nd` holds {saved value, saved_available flag}
-struct NormalState {   // references to wherever the caller keeps the two fields
-    double BT_GAS *saved;
-    uint32_t *available;   // generic: may point into LDS
+struct NormalState {   // references to wherever the caller keeps the two fields (generic pointers: LDS or HBM)
+    double *saved;
+    uint32_t *available;
 };
 
-BT_HD double rng_normal(Mt &st, NormalState nd) {
+template <class G>
+BT_HD double rng_normal(G &st, NormalState nd) {
     double ret;
     if (*nd.available) {
         *nd.available = 0;
@@ -259,7 +339,8 @@ BT_HD double rng_normal(Mt &st, NormalState nd) {
     return ret;
 }
 
-BT_HD double rng_gamma(Mt &st, NormalState nd, double alpha, double beta) {
+template <class G>
+BT_HD double rng_gamma(G &st, NormalState nd, double alpha, double beta) {
     const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
     const double a1 = malpha - 1.0 / 3.0;
     const double a2 = 1.0 / sqrt(9.0 * a1);
@@ -288,8 +369,11 @@ constexpr uint32_t US_NONE = 0xFFFFFFFFu, US_BEFORE = 0xFFFFFFFEu;
 template <class PT>   // PT: any pointer-like with operator[](uint32_t) -> uint32_t&
 struct USetP {
     PT hdr;    // 4 words
-    PT bkt;    // capacity >= uset_bucket_capacity(universe)
+    PT bkt;    // `cap` words
     PT next;   // universe words
+    // Bucket words stored.  An element e < universe lives in bucket e % B < min(B, universe), so min(uset_bucket_capacity(universe),
+    // universe) words suffice whatever the bucket count B is; the loops over "all buckets" stop at min(B, cap).
+    uint32_t cap;
 };
 typedef USetP<SPtr<uint32_t, 1>> USet;
 
@@ -303,7 +387,7 @@ BT_HD uint32_t uset_next_bucket_count(uint32_t min_needed) {   // next entry of 
 BT_HD uint32_t uset_bucket_capacity(uint32_t universe) {
     uint32_t b = 13;
     while (b < universe) b = uset_next_bucket_count(2 * b);
-    return b;
+    return b < universe ? b : (universe ? universe : 1u);   // words to store: min(largest bucket count, universe)
 }
 
 template <class PT>
@@ -323,7 +407,7 @@ BT_HD void uset_set_nxt(USetP<PT> s, uint32_t node, uint32_t v) {
 }
 template <class PT>
 BT_HD void uset_rehash(USetP<PT> s, uint32_t newB) {
-    for (uint32_t i = 0; i < newB; ++i) s.bkt[i] = US_NONE;
+    for (uint32_t i = 0, n = newB < s.cap ? newB : s.cap; i < n; ++i) s.bkt[i] = US_NONE;
     uint32_t p = s.hdr[1];
     s.hdr[1] = US_NONE;
     uint32_t bbegin_bkt = 0;
@@ -397,7 +481,7 @@ BT_HD void uset_erase(USetP<PT> s, uint32_t e) {
 template <class PT>
 BT_HD void uset_clear(USetP<PT> s) {
     const uint32_t B = s.hdr[0];
-    for (uint32_t i = 0; i < B; ++i) s.bkt[i] = US_NONE;
+    for (uint32_t i = 0, n = B < s.cap ? B : s.cap; i < n; ++i) s.bkt[i] = US_NONE;
     s.hdr[1] = US_NONE;
     s.hdr[2] = 0;
 }
