@@ -125,6 +125,7 @@ __device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GPar
     }
     PROF(13);
     rng_topup(env, v);
+    PROF(11);
     sample_diplotypes(env, v, collect, trace_row.off + v * P.S * LANES, tracing, (uint32_t *)trace_row.base);
     sample_haplotype_frequencies(env, v);
     PROF_DECL2;
@@ -357,13 +358,17 @@ struct bt_gibbs {
     std::vector<uint32_t> h_A;             // alleles per cluster
     std::vector<uint32_t> group_tile, group_lane, group_nvert;
     // trace
-    // tiles are launched in two classes so that a few LDS-hungry tiles do not cap the occupancy of all the others
-    uint32_t split_light = 1, split_heavy = 1;   // wavefronts per tile of each class (tile_lane())
-    uint32_t lds_light = 0, lds_heavy = 0;   // dynamic LDS per workgroup of each class (max hot_bytes over its tiles)
-    std::vector<uint32_t> light_tiles, heavy_tiles;
-    uint32_t *d_light = nullptr, *d_heavy = nullptr;
-    hipStream_t heavy_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Tiles are launched in classes of similar LDS need (a launch has ONE dynamic LDS size: that of its hungriest tile), concurrently on
+    // separate streams, so that a few LDS-hungry tiles do not cap the occupancy of all the others
+    struct LaunchClass {
+        uint32_t lds = 0, split = 1;      // dynamic LDS per workgroup, wavefronts per tile (tile_lane())
+        std::vector<uint32_t> tiles;
+        uint32_t *d_tiles = nullptr;
+        hipStream_t stream = nullptr;     // nullptr: the context's stream
+        hipEvent_t done = nullptr;
+    };
+    std::vector<LaunchClass> classes;      // hungriest first
+    hipEvent_t ev_fork = nullptr;
     uint32_t trace_sweeps = 0;
     uint32_t *d_trace = nullptr, *d_trace_counter = nullptr;
     uint64_t trace_words = 0;
@@ -375,24 +380,17 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     BT_HIP(hipSetDevice(g->ctx->device));
     TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
-    const bool both = !g->heavy_tiles.empty() && !g->light_tiles.empty();
-    if (!g->heavy_tiles.empty()) {
-        hipStream_t hs = both ? g->heavy_stream : g->ctx->stream;
-        if (both) {
-            BT_HIP(hipEventRecord(g->ev_fork, g->ctx->stream));
-            BT_HIP(hipStreamWaitEvent(hs, g->ev_fork, 0));
-        }
-        hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)g->heavy_tiles.size()), dim3(LANES * g->split_heavy), g->lds_heavy, hs, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
-                           (const uint32_t *)g->d_heavy);
+    const bool fork = g->classes.size() > 1;
+    if (fork) BT_HIP(hipEventRecord(g->ev_fork, g->ctx->stream));
+    for (auto &c : g->classes) {
+        hipStream_t st = c.stream ? c.stream : g->ctx->stream;
+        if (c.stream) BT_HIP(hipStreamWaitEvent(st, g->ev_fork, 0));
+        hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)c.tiles.size()), dim3(LANES * c.split), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles);
         BT_CHECK_LAUNCH();
-        if (both) BT_HIP(hipEventRecord(g->ev_join, hs));
+        if (c.stream) BT_HIP(hipEventRecord(c.done, st));
     }
-    if (!g->light_tiles.empty()) {
-        hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)g->light_tiles.size()), dim3(LANES * g->split_light), g->lds_light, g->ctx->stream, g->d_tiles, g->d_pool, g->d_params, op, a0, a1,
-                           hist, tr, (const uint32_t *)g->d_light);
-        BT_CHECK_LAUNCH();
-    }
-    if (both) BT_HIP(hipStreamWaitEvent(g->ctx->stream, g->ev_join, 0));
+    for (auto &c : g->classes)
+        if (c.stream) BT_HIP(hipStreamWaitEvent(g->ctx->stream, c.done, 0));
     return BT_OK;
 }
 
@@ -406,7 +404,8 @@ constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim f
 // a cluster's [S][D] tables are dense up to 256 MB per tile (64 MB when the batch would not fit the GPU otherwise): a hashed table far
 // smaller than the set of live (sample, diplotype) pairs thrashes (256 candidates x 10 samples: 12x slower than dense)
 constexpr uint32_t kMinTileWidth = 4;           // groups per wavefront of the narrowest tiles (the other lanes run copies)
-constexpr uint32_t kLightLds = 24576;            // tiles above this go to the "heavy" launch class
+constexpr uint32_t kLightLds = 24576;            // tiles above this are "heavy" (they get fewer wavefronts per tile)
+const uint32_t kClassLds[] = {8192, 12288, 16384, 20480, 24576, 32768, 49152, 65536, 98304, 0xFFFFFFFFu};   // upper LDS bounds of the launch classes
 
 // element sizes per array, in TileArr order
 const uint32_t kElemSize[A_COUNT] = {
@@ -748,7 +747,14 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             d.lds_stride = 1;
             while (d.lds_stride < d.num_lanes) d.lds_stride *= 2;
             uint64_t ho = 0;
+            // tuning: BT_GIBBS_HOT_SKIP = bit mask over hot_arrs[] of arrays to leave in HBM
+            const uint64_t skip_mask = getenv("BT_GIBBS_HOT_SKIP") ? strtoull(getenv("BT_GIBBS_HOT_SKIP"), nullptr, 0) : 0ull;
+            int hot_i = -1;
             for (int a : hot_arrs) {
+                ++hot_i;
+                if ((skip_mask >> hot_i) & 1ull) continue;
+                if (a == A_MGEN && d.NMm == 0) continue;          // (only clusters with multicluster k-mers read it)
+                if (a == A_KSCTMP && d.lds_stride == LANES) continue;   // scratch of the k-mer-stats rebuild: LDS only where tiles are narrow
                 if (a == A_CUM && d.D2m > 16) continue;
                 // the dense table of unique-k-mer sums is read for every candidate of every sample: a few entries per lane (two-haplotype
                 // clusters x a few samples) stay in LDS for the launch
@@ -928,34 +934,36 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         BT_TRYHIP(hipMemcpyAsync(g->d_params, &g->P, sizeof(GParams), hipMemcpyHostToDevice, ctx->stream));
         BT_TRYHIP(hipStreamSynchronize(ctx->stream));
     }
-    for (uint32_t ti = 0; ti < ntiles; ++ti) {
-        const uint32_t hb = tile_lds_bytes(g->tiles[ti]);
-        if (hb > kLightLds) {
-            g->heavy_tiles.push_back(ti);
-            g->lds_heavy = std::max(g->lds_heavy, hb);
-            g->split_heavy = std::max(g->split_heavy, g->tiles[ti].split);
-        } else {
-            g->light_tiles.push_back(ti);
-            g->lds_light = std::max(g->lds_light, hb);
-            g->split_light = std::max(g->split_light, g->tiles[ti].split);
+    {
+        const size_t nclass = sizeof(kClassLds) / sizeof(kClassLds[0]);
+        std::vector<bt_gibbs::LaunchClass> byb(nclass);
+        for (uint32_t ti = 0; ti < ntiles; ++ti) {
+            const uint32_t hb = tile_lds_bytes(g->tiles[ti]);
+            size_t b = 0;
+            while (hb > kClassLds[b]) ++b;
+            byb[b].tiles.push_back(ti);
+            byb[b].lds = std::max(byb[b].lds, hb);
+            byb[b].split = std::max(byb[b].split, g->tiles[ti].split);
         }
-    }
-    if (getenv("BT_GIBBS_DEBUG"))   // tuning aid: how the batch was tiled
-        fprintf(stderr, "bt_gibbs: %u tiles: light %zu (lds %u B, split %u), heavy %zu (lds %u B, split %u); tile 0: hot_bytes %u lds_stride %u copies %u\n", ntiles, g->light_tiles.size(),
-                g->lds_light, g->split_light, g->heavy_tiles.size(), g->lds_heavy, g->split_heavy, g->tiles[0].hot_bytes, g->tiles[0].lds_stride, g->tiles[0].copies);
-    if (!g->heavy_tiles.empty()) {
-        BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_heavy), g->heavy_tiles.size() * 4));
-        g->allocs.push_back(g->d_heavy);
-        BT_TRYHIP(hipMemcpyAsync(g->d_heavy, g->heavy_tiles.data(), g->heavy_tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        for (size_t b = nclass; b-- > 0;)   // hungriest first: those tiles run longest
+            if (!byb[b].tiles.empty()) g->classes.push_back(std::move(byb[b]));
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
-        BT_TRYHIP(hipStreamCreateWithFlags(&g->heavy_stream, hipStreamNonBlocking));
         BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-        BT_TRYHIP(hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming));
-    }
-    if (!g->light_tiles.empty()) {
-        BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_light), g->light_tiles.size() * 4));
-        g->allocs.push_back(g->d_light);
-        BT_TRYHIP(hipMemcpyAsync(g->d_light, g->light_tiles.data(), g->light_tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        for (size_t i = 0; i < g->classes.size(); ++i) {
+            auto &c = g->classes[i];
+            BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_tiles), c.tiles.size() * 4));
+            g->allocs.push_back(c.d_tiles);
+            BT_TRYHIP(hipMemcpyAsync(c.d_tiles, c.tiles.data(), c.tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (i + 1 < g->classes.size()) {   // the last class runs on the context's stream
+                BT_TRYHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+                BT_TRYHIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+            }
+        }
+        if (getenv("BT_GIBBS_DEBUG")) {   // tuning aid: how the batch was tiled
+            fprintf(stderr, "bt_gibbs: %u tiles in %zu launch classes:", ntiles, g->classes.size());
+            for (auto &c : g->classes) fprintf(stderr, " [%zu tiles, lds %u B, split %u]", c.tiles.size(), c.lds, c.split);
+            fprintf(stderr, "; tile 0: hot_bytes %u lds_stride %u copies %u\n", g->tiles[0].hot_bytes, g->tiles[0].lds_stride, g->tiles[0].copies);
+        }
     }
     BT_TRYHIP(hipStreamSynchronize(ctx->stream));
     BT_TRY(launch(g, OP_SETUP, 0, 0, nullptr));
@@ -974,12 +982,14 @@ int bt_gibbs_destroy(bt_gibbs *g) {
         if (p) (void)hipFree(p);
     if (g->d_trace) (void)hipFree(g->d_trace);
     if (g->d_trace_counter) (void)hipFree(g->d_trace_counter);
-    if (g->heavy_stream) {
-        (void)hipStreamSynchronize(g->heavy_stream);
-        (void)hipStreamDestroy(g->heavy_stream);
+    for (auto &c : g->classes) {
+        if (c.stream) {
+            (void)hipStreamSynchronize(c.stream);
+            (void)hipStreamDestroy(c.stream);
+        }
+        if (c.done) (void)hipEventDestroy(c.done);
     }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     delete g;
     return BT_OK;
 }

@@ -815,7 +815,6 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
     }
     if (c.t.copies > 1u) copies_sync();
     PROF(10);
-    PROF_CNT(11, nsu);
     SPtrF<uint32_t, LANES> sc = c.sc();
     sc[SC_NSUB_U] = nsu;
     sc[SC_NSUB_M] = nsm;
