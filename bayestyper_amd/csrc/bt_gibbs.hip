@@ -11,6 +11,7 @@
 // Groups are sorted by shape and cut into TILES of 64; a tile is one wavefront's worth of lane-interleaved HBM
 // (bt_gibbs_tile.hpp) so that the wave's memory traffic coalesces.  One workgroup = one wavefront = one tile.
 #include "bt_gibbs_tile.hpp"
+#include "bt_gibbs_simple.hpp"
 #include "bt_internal.hpp"
 
 #include <algorithm>
@@ -222,12 +223,18 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
         t.resident = RESIDENT_ALL;
         t.hot = lds_block();
     }
+    const bool simple = whole && tile_is_simple(*t.d);
     if (op == OP_RUN) {
         for (uint32_t chain = 0; chain < P.num_chains; ++chain) {
             {
                 PROF_DECL;
                 group_init_chain(env, chain, nvert, nsrc, gindex);
                 PROF(15);
+            }
+            if (simple) {
+                simple_sweeps(env, t, P, P.burn_in, false, tr.counter, tr.buf, tr.max_sweeps, tile);
+                simple_sweeps(env, t, P, P.num_iterations, true, tr.counter, tr.buf, tr.max_sweeps, tile);
+                continue;
             }
             for (uint32_t i = 0; i < P.burn_in; ++i) {
                 const TraceRow r = trace_row_for(t, P, tr, tile);
@@ -242,7 +249,8 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
     } else if (op == OP_INIT_CHAIN) {
         group_init_chain(env, arg0, nvert, nsrc, gindex);
     } else if (op == OP_SWEEP) {
-        for (uint32_t i = 0; i < arg0; ++i) {
+        if (simple) simple_sweeps(env, t, P, arg0, arg1 != 0, tr.counter, tr.buf, tr.max_sweeps, tile);
+        for (uint32_t i = 0; i < (simple ? 0u : arg0); ++i) {
             const TraceRow r = trace_row_for(t, P, tr, tile);
             group_sweep(env, t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
         }
@@ -405,7 +413,8 @@ constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim f
 // smaller than the set of live (sample, diplotype) pairs thrashes (256 candidates x 10 samples: 12x slower than dense)
 constexpr uint32_t kMinTileWidth = 4;           // groups per wavefront of the narrowest tiles (the other lanes run copies)
 constexpr uint32_t kLightLds = 24576;            // tiles above this are "heavy" (they get fewer wavefronts per tile)
-const uint32_t kClassLds[] = {8192, 12288, 16384, 20480, 24576, 32768, 49152, 65536, 98304, 0xFFFFFFFFu};   // upper LDS bounds of the launch classes
+// upper LDS bounds of the launch classes: at most four, the streams of more classes than hardware queues would run one after another
+const uint32_t kClassLds[] = {16384, 32768, 65536, 0xFFFFFFFFu};
 
 // element sizes per array, in TileArr order
 const uint32_t kElemSize[A_COUNT] = {
@@ -516,7 +525,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     auto plan_tiles = [&](uint32_t relax) {
     tile_start.clear();
     pool = 0;
-    const uint64_t dense_limit = relax >= 3 ? (64ull << 20) : (256ull << 20);
+    const uint64_t dense_limit = relax >= 4 ? (64ull << 20) : (256ull << 20);
     {
         // two classes of expensive groups (the batch is sorted, so they are prefixes): X = nested groups and clusters with >= 16
         // haplotype candidates, Y = single clusters with 6..15 candidates.  Narrower is faster per group (measured: 2 304 nested
@@ -530,10 +539,15 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         while (n_x < G && (shapes[n_x].nv > 1 || shapes[n_x].Hmax >= tail_h)) ++n_x;
         uint32_t n_y = n_x;
         while (n_y < G && shapes[n_y].Hmax >= 6) ++n_y;
-        uint32_t width_x = LANES, width_y = LANES;
-        while (width_x > kMinTileWidth && (uint64_t)n_x * 2 <= (uint64_t)width_x * (3 * 256)) width_x /= 2;
-        const uint64_t tiles_x = (n_x + width_x - 1) / width_x, budget_y = 6 * 256 > tiles_x ? 6 * 256 - tiles_x : 1;
-        while (width_y > 16 && (uint64_t)(n_y - n_x) * 2 <= (uint64_t)width_y * budget_y) width_y /= 2;
+        // Width policy (measured on MI355X, r02: 600 000-group mixture batches at S = 3): these tiles are bound by the latency of their
+        // slowest lane's sequential program, so few groups per wavefront (+ copies that share the data-parallel phases) finish a group
+        // sooner AND need little LDS per tile, which keeps many tiles resident; launches with more narrow tiles than wavefront slots
+        // simply run them in rounds next to the two-haplotype tiles (12.0 s at widths 8 / 16, 12.2 s at 4 / 16, 14.6 s at 16 / 32,
+        // 21.3 s at 64 / 64).  Four per wavefront while one round holds them all (<= 3 tiles per CU), eight beyond that (half the HBM);
+        // single clusters with 6..15 candidates sixteen.  `relax` (the batch does not fit the free HBM) doubles both.
+        uint32_t width_x = (uint64_t)n_x <= (uint64_t)kMinTileWidth * (3 * 256) ? kMinTileWidth : 2 * kMinTileWidth, width_y = 16;
+        width_x = std::min<uint32_t>(LANES, width_x << relax);
+        width_y = std::min<uint32_t>(LANES, width_y << relax);
         if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) width_x = (uint32_t)v;
@@ -553,7 +567,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) width_w = (uint32_t)v;
         }
-        width_w = std::min<uint32_t>(width_x, width_w << relax);   // only the one-group-per-wavefront class gives way
+        width_w = std::min<uint32_t>(width_x, width_w << relax);
         uint32_t at = 0;
         while (at < n_x) {   // runs of equal kind
             const bool hw = hashed(at);
@@ -764,8 +778,9 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 ho = align_up(ho + per_vertex * d.lds_stride * kElemSize[a], 16);
             }
             d.hot_bytes = (uint32_t)std::min<uint64_t>(ho, 0xFFFFFFFFu);
-            d.lds_all = d.nvm > 1 && ho * d.nvm <= kHotBudget && !getenv("BT_GIBBS_NO_LDS_ALL") ? 1u : 0u;
-            if (ho > kHotBudget || (d.nvm > 1 && getenv("BT_GIBBS_NOHOT_MULTI"))) {
+            const uint64_t hot_budget = getenv("BT_GIBBS_HOT_BUDGET") ? strtoull(getenv("BT_GIBBS_HOT_BUDGET"), nullptr, 0) : kHotBudget;   // tuning
+            d.lds_all = d.nvm > 1 && ho * d.nvm <= hot_budget && !getenv("BT_GIBBS_NO_LDS_ALL") ? 1u : 0u;
+            if (ho > hot_budget || (d.nvm > 1 && !d.lds_all && hot_budget < kHotBudget) || (d.nvm > 1 && getenv("BT_GIBBS_NOHOT_MULTI"))) {
                 for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
                 d.hot_bytes = 0;
                 d.lds_all = 0;
@@ -783,6 +798,12 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         if (d.lds_stride <= 32 && !getenv("BT_GIBBS_NO_COPIES")) {
             d.split = 1;
             d.copies = 64u / d.lds_stride;
+        }
+        {
+            bool simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.copies == 1 && d.split == 1 && d.hot_bytes != 0 && !getenv("BT_GIBBS_NO_SIMPLE");
+            for (uint32_t l = 0; l < d.num_lanes && simple; ++l) simple = B->num_haplotypes[B->group_cluster_off[shapes[tile_start[ti] + l].g]] == 2;
+            for (int a : {A_SC, A_OBS, A_PEND, A_DIP, A_PENDDIP, A_NZ, A_KSCUPD, A_PENDVALID, A_NESTPL, A_NESTN, A_FREQ, A_LOGF, A_RING}) simple = simple && d.hoff[a] != NOHOT;
+            d.simple = simple ? 1u : 0u;
         }
         d.base = pool;
         if (ti == 0 && getenv("BT_GIBBS_DEBUG") && atoi(getenv("BT_GIBBS_DEBUG")) >= 2) {   // the arrays that make up most of tile 0
@@ -804,7 +825,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         for (uint32_t relax = 0;; ++relax) {
             plan_tiles(relax);
-            if (relax >= 3 || free_b == 0 || pool + 256 <= (uint64_t)(0.92 * (double)free_b)) break;
+            if (relax >= 4 || free_b == 0 || pool + 256 <= (uint64_t)(0.92 * (double)free_b)) break;
         }
     }
     g->pool_bytes = pool + 256;

@@ -133,6 +133,7 @@ struct TileDesc {
     uint32_t uc_width;              // 0: the unique-sum table is lane-interleaved like every other array; else it is per-lane contiguous over uc_width lanes
     uint32_t mat_width;             // the same for the two K x H multiplicity matrices (A_M, A_SUBM): 0 interleaved, else the tile's lane count
     uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (4 .. 64); lds_all: every vertex has its own LDS block (no swaps)
+    uint32_t simple;                // every group of the tile is one two-haplotype cluster without multicluster k-mers: sweeps run in simple_sweeps()
     uint32_t ring_cap[2], ring_len; // draw-ahead words of the diplotype / frequency generator (powers of two); ring_len = both blocks
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
@@ -1237,67 +1238,84 @@ __device__ __noinline__ void flush_vertex(Env env, uint32_t vtx) {
 // updateAlleleKmerStats (VariantClusterHaplotypes.cpp:235-298).  A sample whose diplotype and k-mer-stats cache are the
 // same as in the previous collected sweep contributes exactly the same updates again; those are counted (pend) and
 // replayed later instead of being read-modify-written in HBM every sweep.
-__device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
-    const Vx c = make_vx(make_tile(env), vtx);
-    const GParams BT_CAS &P = env_params(env);
+// the slow path of one sample of a collected sweep: materialise what is pending, rebuild the sample's k-mer-stats cache when its
+// diplotype (or a multicluster multiplicity) changed, apply this sweep's contribution
+__device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t nsub_u, uint32_t nsub_m) {
     SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
     SPtrF<uint8_t, LANES> upd = c.ksc_upd(), pvalid = c.pend_valid();
-    for (uint32_t s = 0; s < P.S; ++s) {
-        const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
-        const uint8_t u = upd[s];
-        const uint32_t nn = c.nest_n()[s];
-#ifndef ABL_NODEFER
-        if (pvalid[s] && !u && nn == 0 && pdip[2 * s] == h1 && pdip[2 * s + 1] == h2) {
-            c.pend()[s] += 1;
-            continue;
-        }
-        flush_sample(c, P, s);
-#endif
+    const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
+    const uint8_t u = upd[s];
+    const uint32_t nn = c.nest_n()[s];
+    flush_sample(c, P, s);
+    {
         if (u) {
             upd[s] = 0;
-            // rebuild kmer_stats_cache[s] (VariantClusterHaplotypes.cpp:247-277) in scratch accumulators (LDS when the vertex is
-            // resident), walking the compact subset arrays; same k-mer order, same arithmetic, one write-back at the end
-            SPtrF<double, LANES> tmp = c.ksc_tmp();
-            const uint32_t Vm = c.d().Vm, Hm = c.d().Hm, HWm = c.d().HWm;
-            for (uint32_t i = 0; i < 2 * Vm * 4; ++i) tmp[i] = 0;
-            if (h1 != NOHAP) {
-                const bool two = h2 != NOHAP;
-                const uint8_t g = P.gender[s];
-                const Vx::RPtr<uint8_t> sm = c.subm();
-        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
-                SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits();
-                SPtr<uint16_t, LANES> sv = c.skv_var();
-                for (uint32_t i = 0; i < nsub_u; ++i) {
-                    uint8_t dm = sm[i * Hm + h1];
-                    if (two) dm = (uint8_t)(dm + sm[i * Hm + h2]);
-                    const uint32_t e0 = so[i], e1 = so[i + 1];
-                    if (dm == 0) continue;
-                    const uint8_t mult = (uint8_t)(dm + sic[2 * i + g]);
-                    const double kmer_count = scn[i * P.S + s] / (double)mult;
-                    for (uint32_t e = e0; e < e1; ++e) {
-                        const uint32_t var = sv[e];
-                        if ((sb[e * HWm + (h1 >> 5)] >> (h1 & 31u)) & 1u) ks_add(tmp + (0 * Vm + var) * 4, kmer_count);
-                        if (two && ((sb[e * HWm + (h2 >> 5)] >> (h2 & 31u)) & 1u)) ks_add(tmp + (1 * Vm + var) * 4, kmer_count);
+            // Rebuild kmer_stats_cache[s] (VariantClusterHaplotypes.cpp:247-277).  The cache is 2 x V independent KmerStats accumulators
+            // (haplotype slot x variant), each a strictly sequential Welford recurrence over the subset k-mers that lie on its haplotype
+            // and overlap its variant, in subset order.  Every accumulator is run as its own pass IN REGISTERS — the copies of the group
+            // take different accumulators — over the compact subset arrays read in blocks of eight k-mers (all operand loads of a block
+            // first): per accumulator the same values in the same order as the reference's single interleaved pass.
+            const uint32_t Hm = c.d().Hm, HWm = c.d().HWm, V = c.V;
+            const bool two = h2 != NOHAP;
+            const uint8_t g = P.gender[s];
+            const Vx::RPtr<uint8_t> sm = c.subm();
+            SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
+            SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits(), msub = c.msub();
+            SPtr<uint16_t, LANES> sv = c.skv_var();
+            for (uint32_t a = c.t.part; a < 2 * V; a += c.t.copies) {
+                const uint32_t which = a / V, var = a - which * V;
+                KS acc{0, 0, 0, 0};
+                const uint16_t h = which ? h2 : h1;
+                if (h1 != NOHAP && (which == 0 || two)) {
+                    const uint32_t hw = h >> 5, hb = h & 31u;
+                    for (uint32_t i0 = 0; i0 < nsub_u; i0 += 8) {
+                        const uint32_t nb = nsub_u - i0 < 8u ? nsub_u - i0 : 8u;
+                        uint32_t eo[9];
+                        uint8_t dm[8], icn[8], cn[8];
+#pragma unroll
+                        for (uint32_t q = 0; q < 9; ++q) eo[q] = q <= nb ? (uint32_t)so[i0 + q] : 0u;
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q) {
+                            const uint32_t i = q < nb ? i0 + q : i0;
+                            uint8_t m = sm[i * Hm + h1];
+                            if (two) m = (uint8_t)(m + sm[i * Hm + h2]);
+                            dm[q] = q < nb ? m : (uint8_t)0;
+                            icn[q] = sic[2 * i + g];
+                            cn[q] = scn[i * P.S + s];
+                        }
+                        // first entry of every k-mer of the block (most k-mers overlap one variant)
+                        uint32_t v0[8], b0[8];
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q) {
+                            const bool has = q < nb && eo[q + 1] > eo[q];
+                            v0[q] = has ? (uint32_t)sv[eo[q]] : 0xFFFFFFFFu;
+                            b0[q] = has ? (uint32_t)sb[eo[q] * HWm + hw] : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t q = 0; q < 8; ++q) {
+                            if (q >= nb || dm[q] == 0) continue;
+                            bool hit = v0[q] == var && ((b0[q] >> hb) & 1u);
+                            for (uint32_t e = eo[q] + 1; e < eo[q + 1]; ++e)    // a k-mer overlaps a variant once: at most one entry matches
+                                if (sv[e] == var && ((sb[e * HWm + hw] >> hb) & 1u)) hit = true;
+                            if (hit) ks_add_r(acc, cn[q] / (double)(uint8_t)(dm[q] + icn[q]));
+                        }
+                    }
+                    for (uint32_t i = 0; i < nsub_m; ++i) {
+                        const uint32_t k = msub[i];
+                        if (dip_mult(c, k, h1, h2) == 0) continue;
+                        bool hit = false;
+                        for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e)
+                            if (c.kv_var(e) == var && c.kv_bit(e, h)) hit = true;
+                        if (!hit) continue;
+                        const uint8_t mult = multi_mult(c, P, k, h1, h2, h1, h2, s);
+                        double kmer_count = 0;
+                        if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
+                        ks_add_r(acc, kmer_count);
                     }
                 }
-                SPtr<uint32_t, LANES> msub = c.msub();
-                for (uint32_t i = 0; i < nsub_m; ++i) {
-                    const uint32_t k = msub[i];
-                    if (dip_mult(c, k, h1, h2) == 0) continue;
-                    const uint8_t mult = multi_mult(c, P, k, h1, h2, h1, h2, s);
-                    double kmer_count = 0;
-                    if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
-                    for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
-                        const uint32_t var = c.kv_var(e);
-                        if (c.kv_bit(e, h1)) ks_add(tmp + (0 * Vm + var) * 4, kmer_count);
-                        if (two && c.kv_bit(e, h2)) ks_add(tmp + (1 * Vm + var) * 4, kmer_count);
-                    }
-                }
+                ks_store(c.ksc(s, which, var), acc);
             }
-            for (uint32_t var = 0; var < c.V; ++var) {
-                ks_store(c.ksc(s, 0, var), ks_load(tmp + (0 * Vm + var) * 4));
-                ks_store(c.ksc(s, 1, var), ks_load(tmp + (1 * Vm + var) * 4));
-            }
+            if (c.t.copies > 1u) copies_sync();
         }
         replay_collected(c, P, s, h1, h2, 1);
         for (uint32_t j = 0; j < nn; ++j)   // addNestedHaplotypeKmerStats (:360-372)
@@ -1305,6 +1323,29 @@ __device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uin
         pvalid[s] = nn == 0 ? 1 : 0;
         pdip[2 * s] = h1;
         pdip[2 * s + 1] = h2;
+    }
+}
+__device__ __noinline__ void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    SPtrF<uint32_t, LANES> sc = c.sc();
+    collect_sample_body(c, P, s, sc[SC_NSUB_U], sc[SC_NSUB_M]);
+}
+
+__device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
+    SPtrF<uint8_t, LANES> upd = c.ksc_upd(), pvalid = c.pend_valid();
+    for (uint32_t s = 0; s < P.S; ++s) {
+        const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
+#ifndef ABL_NODEFER
+        if (pvalid[s] && !upd[s] && c.nest_n()[s] == 0 && pdip[2 * s] == h1 && pdip[2 * s + 1] == h2) {
+            c.pend()[s] += 1;
+            continue;
+        }
+#endif
+        collect_sample_body(c, P, s, nsub_u, nsub_m);
     }
 }
 

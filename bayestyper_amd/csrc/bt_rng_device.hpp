@@ -159,9 +159,10 @@ BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
 // whole wavefront at fixed points (mt_ring_topup at the start of a cluster visit), so the lanes of a wavefront refill together.
 // Ring block of one generator: [cap] tempered words, then {position of the next state word to generate, ring head, words available}.
 constexpr unsigned MT_RING_HDR = 3;
-struct MtRing {
+template <class RP>   // RP: pointer-like (operator[](uint32_t) -> uint32_t&) to the ring block
+struct MtRingT {
     uint32_t BT_GAS *st;
-    SPtrF<uint32_t, 1> ring;   // element i of the ring block at ring[i] (LDS when the cluster's hot arrays are resident, else HBM)
+    RP ring;                   // element i of the ring block at ring[i] (LDS when the cluster's hot arrays are resident, else HBM)
     uint32_t cap;              // power of two, <= 64
     uint32_t pos, head, avail;
     // generate n more words (n <= cap - avail), bursts of 16
@@ -205,6 +206,18 @@ struct MtRing {
         avail -= N;
     }
 };
+typedef MtRingT<SPtrF<uint32_t, 1>> MtRing;
+template <class RP>
+BT_HD MtRingT<RP> mt_ring_open_as(uint32_t *st, RP ring, uint32_t cap) {
+    MtRingT<RP> m;
+    m.st = (uint32_t BT_GAS *)st;
+    m.ring = ring;
+    m.cap = cap;
+    m.pos = m.ring[cap];
+    m.head = m.ring[cap + 1];
+    m.avail = m.ring[cap + 2];
+    return m;
+}
 template <class RP>
 BT_HD MtRing mt_ring_open(uint32_t *st, RP ring, uint32_t cap) {
     MtRing m;
@@ -216,7 +229,8 @@ BT_HD MtRing mt_ring_open(uint32_t *st, RP ring, uint32_t cap) {
     m.avail = m.ring[cap + 2];
     return m;
 }
-BT_HD void mt_close(const MtRing &m) {
+template <class RP>
+BT_HD void mt_close(const MtRingT<RP> &m) {
     m.ring[m.cap] = m.pos;
     m.ring[m.cap + 1] = m.head;
     m.ring[m.cap + 2] = m.avail;

@@ -10,7 +10,8 @@ One "step" = one pass of the hot path over one batch of synthetic input held in 
   (3) the compact posterior summary per (cluster, sample), gathered to rank 0 (RCCL when --gpus > 1).
 
 Workload at N=1 = BASELINE.json configs[2], the largest single-GPU configuration ("GRCh38 whole genome, CEU trio (3 samples),
-SNV+indel+SV merged candidates"): S=3 and one launch-sized slice of the unit — 150 000 variant-cluster groups in the WGS-like
+SNV+indel+SV merged candidates"): S=3 and one launch-sized slice of the unit — 600 000 variant-cluster groups (80-140 GB of sampler
+state in HBM; the narrow tiles of the expensive groups run in rounds next to the two-haplotype tiles) in the WGS-like
 mixture of BASELINE.md §3 (90 % biallelic SNV/indel groups, 8 % multi-variant clusters, 1.5 % nested SV groups, 0.5 % many-candidate
 clusters with up to 32 x S haplotype candidates), every structure with its own dimensions (bayestyper_amd/synth.py: hetero_group) and
 every group with its own truth genotypes and counts; a whole genome (5-15 x 10^6 groups) is a sequence of such launches.  KMC: a
@@ -46,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--groups", type=int, default=150_000, help="variant-cluster groups per GPU")
+    ap.add_argument("--groups", type=int, default=600_000, help="variant-cluster groups per GPU")
     ap.add_argument("--samples", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--verify", action="store_true", help="strong scaling: rank 0 also runs the unsharded batch afterwards; the gathered summaries must equal it")
