@@ -109,4 +109,9 @@ struct bt_kmc_scan {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
     unsigned long long *d_host_hits = nullptr;
+    // buffers of the route-bucketed scan (bt_table.hip: kmc_route_kernel / kmc_probe_kernel), created on first use
+    void *d_route_keys[2] = {nullptr, nullptr}, *d_route_vals[2] = {nullptr, nullptr}, *d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint64_t routed_cap = 0;
+    unsigned int *d_num_hits = nullptr;
 };

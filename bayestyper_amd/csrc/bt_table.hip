@@ -20,6 +20,8 @@
 
 #include "bt_rng_device.hpp"
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 using namespace bt;
 
 namespace {
@@ -71,7 +73,7 @@ __device__ inline int64_t table_find(const TableView &t, Kmer a) {
 __device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a) {
     uint64_t idx = table_home(a, t);
     int64_t result = -1;
-    bool done = false;
+    bool done = false, inserted = false;
     uint64_t probes = 0;
     while (!done) {
         uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -80,7 +82,7 @@ __device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a) {
                 __hip_atomic_store(&t.key_lo[idx], a.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&t.key_hi[idx], a.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&t.state[idx], ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(t.num_keys, 1ULL);
+                inserted = true;
                 result = (int64_t)idx;
                 done = true;
             }
@@ -101,6 +103,8 @@ __device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a) {
         }
         // ST_BUSY: poll again
     }
+    // (no key counter is kept: millions of inserts would serialise on that one word; bt_table_status counts the READY slots)
+    (void)inserted;
     return result;
 }
 
@@ -177,6 +181,14 @@ __global__ __launch_bounds__(BLOCK) void table_find_kernel(TableView t, const ui
         Kmer a{kmers[2 * i], kmers[2 * i + 1]};
         slots[i] = table_find(t, a);
     }
+}
+
+// bt_table_status: number of stored keys = READY slots
+__global__ __launch_bounds__(BLOCK) void table_count_kernel(TableView t, uint64_t capacity, unsigned long long *__restrict__ out) {
+    unsigned long long mine = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) mine += t.state[i] == ST_READY ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(out, mine);
 }
 
 // bt_table_reserve: every stored record of `src` moves to its slot in the (larger, empty) table `dst`
@@ -376,6 +388,18 @@ __device__ inline uint64_t kmc_prefix_of(const KmcView &v, uint64_t n) {
     return lo;
 }
 
+// Prefix of record n of a block of consecutive records whose first and last prefixes are known (computed once per block): records are
+// sorted by prefix and a prefix holds thousands of records, so nearly every block lies inside one prefix and no lane searches at all
+__device__ inline uint64_t kmc_prefix_in(const KmcView &v, uint64_t n, uint64_t p_first, uint64_t p_last) {
+    uint64_t lo = p_first, hi = p_last + 1;   // invariant: lut[lo] <= n < lut[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (v.lut[mid] <= n) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
 __device__ inline void kmc_decode(const KmcView &v, uint64_t prefix, const uint8_t *rec, Kmer &out, uint32_t &count) {
     // assemble the k symbols MSB-first into a 128-bit big number, then reverse the group order
     uint64_t bhi = 0, blo = 0;   // symbols s_0 .. s_{k-1}, s_0 most significant, right-aligned at bit 0
@@ -407,6 +431,7 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
                                                          uint32_t *__restrict__ out_counts) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[KMC_RECS * KMC_MAX_REC + 32];
     __shared__ unsigned block_hits;
+    __shared__ uint64_t block_prefix[2];
     const uint64_t num_chunks = (n + KMC_RECS - 1) / KMC_RECS;
     for (uint64_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
         const uint64_t rec0 = chunk * KMC_RECS;
@@ -414,6 +439,7 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
         const uint64_t byte0 = rec0 * v.rec_size;
         const unsigned nbytes = nrec * v.rec_size;
         if (threadIdx.x == 0) block_hits = 0;
+        if (threadIdx.x < 2) block_prefix[threadIdx.x] = kmc_prefix_of(v, first_record + rec0 + (threadIdx.x ? nrec - 1 : 0));
         // 16-byte aligned window that covers [byte0, byte0 + nbytes)
         const uint64_t a0 = byte0 & ~15ULL;
         const unsigned lead = (unsigned)(byte0 - a0);
@@ -435,7 +461,7 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
             const uint8_t *rec = &stage[lead + threadIdx.x * v.rec_size];
             Kmer a;
             uint32_t count;
-            kmc_decode(v, kmc_prefix_of(v, gidx), rec, a, count);
+            kmc_decode(v, kmc_prefix_in(v, gidx, block_prefix[0], block_prefix[1]), rec, a, count);
             if (DECODE_ONLY) {
                 out_kmers[2 * ridx] = a.lo;
                 out_kmers[2 * ridx + 1] = a.hi;
@@ -457,14 +483,149 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
     }
 }
 
-// makeBloom (src/bayesTyperTools/MakeBloom.cpp:200-295): every record's k-mer goes into the sample's KmerBloom.  Same staging as
-// kmc_scan_kernel; the insert is an atomicOr per probe (order-independent, so the filter bytes equal the reference's).
-__global__ __launch_bounds__(BLOCK) void kmc_make_bloom_kernel(KmcView v, BloomView bloom, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t n) {
+// ---------------------------------------------------------------------------------------------
+// Route-bucketed scan against a ThreadedKmerBloom (65 536 sub-filters of ~1-40 KB each).  The direct kernel above pays two random
+// 64-byte sectors of the (cache-exceeding) filter per record.  Here the records of a chunk are first bucketed by the sub-filter they
+// route to — pass 1 decodes every record, computes its ntHash and route and emits (route, {hash, record index}); a radix sort on the
+// 16 route bits groups them — and pass 2 gives every sub-filter one workgroup that stages the sub-filter's bytes in LDS once
+// (coalesced) and probes them there for all of its records; the few hits re-read their record and update the count table.
+// Same decisions as the direct kernel, so the table contents are identical.
+// ---------------------------------------------------------------------------------------------
+struct RouteRec {
+    uint32_t h_lo, h_hi, idx;   // ntHash of the record's k-mer, record index inside the chunk
+};
+
+// records [rec_offset, rec_offset + n) of the call's record buffer (16-byte aligned base, n_total records)
+__global__ __launch_bounds__(BLOCK) void kmc_route_kernel(KmcView v, uint32_t bloom_k, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t rec_offset, uint64_t n,
+                                                          uint64_t n_total, uint16_t *__restrict__ keys, RouteRec *__restrict__ vals) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[KMC_RECS * KMC_MAX_REC + 32];
+    __shared__ uint64_t block_prefix[2];
     const uint64_t num_chunks = (n + KMC_RECS - 1) / KMC_RECS;
     for (uint64_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
         const uint64_t rec0 = chunk * KMC_RECS;
         const unsigned nrec = (unsigned)((n - rec0) < KMC_RECS ? (n - rec0) : KMC_RECS);
+        if (threadIdx.x < 2) block_prefix[threadIdx.x] = kmc_prefix_of(v, first_record + rec_offset + rec0 + (threadIdx.x ? nrec - 1 : 0));
+        const uint64_t byte0 = (rec_offset + rec0) * v.rec_size;
+        const unsigned nbytes = nrec * v.rec_size;
+        const uint64_t a0 = byte0 & ~15ULL;
+        const unsigned lead = (unsigned)(byte0 - a0);
+        const unsigned nvec = (lead + nbytes + 15u) / 16u;
+        const uint64_t total_bytes = n_total * (uint64_t)v.rec_size;
+        for (unsigned j = threadIdx.x; j < nvec; j += BLOCK) {
+            const uint64_t off = a0 + (uint64_t)j * 16u;
+            if (off + 16u <= total_bytes) *reinterpret_cast<uint4 *>(&stage[j * 16u]) = *reinterpret_cast<const uint4 *>(records + off);
+            else
+                for (unsigned q = 0; q < 16u; ++q) stage[j * 16u + q] = (off + q < total_bytes) ? records[off + q] : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x < nrec) {
+            Kmer a;
+            uint32_t count;
+            kmc_decode(v, kmc_prefix_in(v, first_record + rec_offset + rec0 + threadIdx.x, block_prefix[0], block_prefix[1]), &stage[lead + threadIdx.x * v.rec_size], a, count);
+            const uint64_t h = nthash64(a, v.k);
+            const uint64_t i = rec0 + threadIdx.x;
+            keys[i] = (uint16_t)(nthash64_seeded(h, bloom_k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u));
+            vals[i] = RouteRec{(uint32_t)h, (uint32_t)(h >> 32), (uint32_t)i};
+        }
+        __syncthreads();
+    }
+}
+
+// first index in the sorted keys[0..n) that is >= key
+__device__ inline uint32_t route_lower_bound(const uint16_t *__restrict__ keys, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// pass 2: one workgroup per sub-filter: the sub-filter's bytes staged in LDS, every record routed to it probed there; the records that
+// pass all probes (path k-mers present in the sample + false positives, a few per cent) are appended to the chunk's hit list
+__global__ __launch_bounds__(BLOCK) void kmc_probe_kernel(BloomView bloom, const uint16_t *__restrict__ keys, const RouteRec *__restrict__ vals, uint32_t n, uint32_t *__restrict__ hits,
+                                                          unsigned int *__restrict__ num_hits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t slice[];
+    __shared__ uint32_t range[2];
+    const uint32_t route = blockIdx.x;
+    if (threadIdx.x < 2) range[threadIdx.x] = route_lower_bound(keys, n, route + threadIdx.x);
+    __syncthreads();
+    const uint32_t lo = range[0], hi = range[1];
+    if (lo == hi) return;
+    const uint32_t words = (uint32_t)(bloom.stride / 4u);
+    const uint32_t *src = bloom.words + (uint64_t)route * words;
+    for (uint32_t j = threadIdx.x; j < words; j += BLOCK) slice[j] = src[j];
+    __syncthreads();
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(slice);
+    // hits are collected in an LDS queue and moved to the chunk's hit list with ONE global atomic per flush (a counter bumped per
+    // wavefront would serialise a million atomics per chunk on one word)
+    constexpr uint32_t QCAP = 4 * BLOCK;
+    __shared__ uint32_t queue[QCAP];
+    __shared__ uint32_t qn, qbase;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    auto flush = [&]() {
+        __syncthreads();
+        const uint32_t n_q = qn;
+        if (threadIdx.x == 0 && n_q) qbase = atomicAdd(num_hits, n_q);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n_q; j += BLOCK) hits[qbase + j] = queue[j];
+        __syncthreads();
+        if (threadIdx.x == 0) qn = 0;
+        __syncthreads();
+    };
+    for (uint32_t i0 = lo; i0 < hi; i0 += BLOCK) {
+        if (qn + BLOCK > QCAP) flush();   // (uniform: qn is read after a barrier)
+        const uint32_t i = i0 + threadIdx.x;
+        bool member = i < hi;
+        uint32_t idx = 0;
+        if (member) {
+            const RouteRec r = vals[i];
+            idx = r.idx;
+            const uint64_t h = (uint64_t)r.h_lo | ((uint64_t)r.h_hi << 32);
+            for (unsigned q = 0; q < bloom.num_hashes && member; ++q) {   // BloomFilter::containsF: stop at the first clear bit
+                const uint64_t pos = bloom_probe_pos(h, q, bloom);
+                member = (bytes[pos >> 3] & (1u << (7u - (unsigned)(pos & 7u)))) != 0;
+            }
+        }
+        if (member) queue[atomicAdd(&qn, 1u)] = idx;
+        __syncthreads();
+    }
+    flush();
+}
+
+// pass 3: the hits of a chunk, one per lane: decode the record again, add its count to the table (KmerCounter.cpp:414-419)
+__global__ __launch_bounds__(BLOCK) void kmc_apply_kernel(KmcView v, TableView t, uint32_t sample_idx, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t rec_offset,
+                                                          const uint32_t *__restrict__ hits, const unsigned int *__restrict__ num_hits, unsigned long long *__restrict__ hit_count) {
+    const uint32_t nh = *num_hits;
+    unsigned my_hits = 0;
+    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < nh; j += gridDim.x * BLOCK) {
+        const uint64_t ridx = rec_offset + hits[j];
+        Kmer a;
+        uint32_t count;
+        kmc_decode(v, kmc_prefix_of(v, first_record + ridx), records + ridx * v.rec_size, a, count);
+        if (count < v.min_count || count > v.max_count) continue;
+        my_hits += 1;
+        const int64_t slot = table_find_or_insert(t, a);
+        if (slot >= 0) sat_add_byte(t.counts, (uint64_t)slot * t.spad + sample_idx, count > 255u ? 255u : count);
+    }
+    if (hit_count) {   // one atomic per wavefront
+        for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_down(my_hits, off);
+        if ((threadIdx.x & 63u) == 0 && my_hits) atomicAdd(hit_count, (unsigned long long)my_hits);
+    }
+}
+
+// makeBloom (src/bayesTyperTools/MakeBloom.cpp:200-295): every record's k-mer goes into the sample's KmerBloom.  Same staging as
+// kmc_scan_kernel; the insert is an atomicOr per probe (order-independent, so the filter bytes equal the reference's).
+__global__ __launch_bounds__(BLOCK) void kmc_make_bloom_kernel(KmcView v, BloomView bloom, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[KMC_RECS * KMC_MAX_REC + 32];
+    __shared__ uint64_t block_prefix[2];
+    const uint64_t num_chunks = (n + KMC_RECS - 1) / KMC_RECS;
+    for (uint64_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
+        const uint64_t rec0 = chunk * KMC_RECS;
+        const unsigned nrec = (unsigned)((n - rec0) < KMC_RECS ? (n - rec0) : KMC_RECS);
+        if (threadIdx.x < 2) block_prefix[threadIdx.x] = kmc_prefix_of(v, first_record + rec0 + (threadIdx.x ? nrec - 1 : 0));
         const uint64_t byte0 = rec0 * v.rec_size;
         const unsigned nbytes = nrec * v.rec_size;
         const uint64_t a0 = byte0 & ~15ULL;
@@ -481,7 +642,7 @@ __global__ __launch_bounds__(BLOCK) void kmc_make_bloom_kernel(KmcView v, BloomV
         if (threadIdx.x < nrec) {
             Kmer a;
             uint32_t count;
-            kmc_decode(v, kmc_prefix_of(v, first_record + rec0 + threadIdx.x), &stage[lead + threadIdx.x * v.rec_size], a, count);
+            kmc_decode(v, kmc_prefix_in(v, first_record + rec0 + threadIdx.x, block_prefix[0], block_prefix[1]), &stage[lead + threadIdx.x * v.rec_size], a, count);
             if (count >= v.min_count && count <= v.max_count) bloom_insert(nthash64(a, v.k), bloom);
         }
         __syncthreads();
@@ -600,6 +761,11 @@ int bt_table_status(bt_table *t, uint64_t *num_keys, uint64_t *capacity, int *ov
     BT_HIP(hipSetDevice(t->ctx->device));
     unsigned long long nk = 0;
     uint32_t ov = 0;
+    if (num_keys) {
+        BT_HIP(hipMemsetAsync(t->v.num_keys, 0, 8, t->ctx->stream));
+        hipLaunchKernelGGL(table_count_kernel, dim3(grid_for(t->capacity, BLOCK, t->ctx->num_cu * 8)), dim3(BLOCK), 0, t->ctx->stream, t->v, t->capacity, t->v.num_keys);
+        BT_CHECK_LAUNCH();
+    }
     BT_HIP(hipMemcpyAsync(&nk, t->v.num_keys, 8, hipMemcpyDeviceToHost, t->ctx->stream));
     BT_HIP(hipMemcpyAsync(&ov, t->v.overflow, 4, hipMemcpyDeviceToHost, t->ctx->stream));
     BT_HIP(hipStreamSynchronize(t->ctx->stream));
@@ -849,12 +1015,14 @@ int bt_kmc_scan_set_count_range(bt_kmc_scan *s, uint32_t min_count, uint64_t max
 }
 
 static void free_host_staging(bt_kmc_scan *s);
+static void free_routed(bt_kmc_scan *s);
 int bt_kmc_scan_destroy(bt_kmc_scan *s) {
     if (!s) return BT_OK;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->d_lut) (void)hipFree(s->d_lut);
     free_host_staging(s);
+    free_routed(s);
     delete s;
     return BT_OK;
 }
@@ -873,6 +1041,49 @@ static KmcView make_kmc_view(const bt_kmc_scan *s) {
     return v;
 }
 
+static void free_routed(bt_kmc_scan *s) {
+    for (int b = 0; b < 2; ++b) {
+        if (s->d_route_keys[b]) (void)hipFree(s->d_route_keys[b]);
+        if (s->d_route_vals[b]) (void)hipFree(s->d_route_vals[b]);
+        s->d_route_keys[b] = nullptr;
+        s->d_route_vals[b] = nullptr;
+    }
+    if (s->d_sort_tmp) (void)hipFree(s->d_sort_tmp);
+    if (s->d_num_hits) (void)hipFree(s->d_num_hits);
+    s->d_sort_tmp = nullptr;
+    s->d_num_hits = nullptr;
+    s->sort_tmp_bytes = 0;
+    s->routed_cap = 0;
+}
+
+// buffers of the route-bucketed scan for chunks of up to `cap` records (kept with the handle)
+static int ensure_routed(bt_kmc_scan *s, uint64_t cap) {
+    if (s->routed_cap >= cap) return BT_OK;
+    free_routed(s);
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipMalloc(reinterpret_cast<void **>(&s->d_route_keys[b]), cap * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals[b]), cap * sizeof(RouteRec));
+    }
+    size_t tmp = 0;
+    if (e == hipSuccess)
+        e = rocprim::radix_sort_pairs(nullptr, tmp, (uint16_t *)s->d_route_keys[0], (uint16_t *)s->d_route_keys[1], (RouteRec *)s->d_route_vals[0], (RouteRec *)s->d_route_vals[1],
+                                      (size_t)cap, 0, 16, s->ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&s->d_sort_tmp, std::max<size_t>(tmp, 16));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_num_hits), 4);
+    if (e != hipSuccess) {
+        free_routed(s);
+        return fail(std::string("bt_kmc_scan: buffers of the route-bucketed scan: ") + hipGetErrorString(e));
+    }
+    s->sort_tmp_bytes = tmp;
+    s->routed_cap = cap;
+    return BT_OK;
+}
+
+constexpr uint64_t kRoutedChunk = 1ull << 26;      // records per bucketed chunk (14 bytes of keys + values each, double-buffered)
+constexpr uint64_t kRoutedMinRecords = 1ull << 22;  // below this a sub-filter gets too few records per chunk for its staging to pay
+constexpr uint64_t kRoutedMaxSlice = 64000;         // bytes of one sub-filter that fit the LDS of a workgroup
+
 int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *d_records,
                     uint64_t first_record, uint64_t n, uint64_t *d_hit_count) {
     if (!s || !path_bloom || !table) return fail("bt_kmc_scan_run: null argument");
@@ -882,11 +1093,41 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
     if ((reinterpret_cast<uintptr_t>(d_records) & 15u) != 0) return fail("bt_kmc_scan_run: d_records must be 16-byte aligned");
     if (n == 0) return BT_OK;
     BT_HIP(hipSetDevice(s->ctx->device));
-    unsigned grid = grid_for((n + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8);
-    hipLaunchKernelGGL(kmc_scan_kernel<false>, dim3(grid), dim3(BLOCK), 0, s->ctx->stream, make_kmc_view(s), path_bloom->view(), table->v,
-                       sample_idx, d_records, first_record, n, reinterpret_cast<unsigned long long *>(d_hit_count), (uint64_t *)nullptr,
-                       (uint32_t *)nullptr);
-    BT_CHECK_LAUNCH();
+    // a ThreadedKmerBloom and enough records: bucket by sub-filter, probe in LDS.  BT_KMC_ROUTED=0 / 1 forces the direct / bucketed kernel.
+    const char *force = getenv("BT_KMC_ROUTED");
+    bool routed = path_bloom->num_sub == BT_NUM_SUB_BLOOMS && path_bloom->stride <= kRoutedMaxSlice && n >= kRoutedMinRecords;
+    if (force) routed = path_bloom->num_sub == BT_NUM_SUB_BLOOMS && path_bloom->stride <= kRoutedMaxSlice && atoi(force) != 0;
+    if (!routed) {
+        unsigned grid = grid_for((n + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8);
+        hipLaunchKernelGGL(kmc_scan_kernel<false>, dim3(grid), dim3(BLOCK), 0, s->ctx->stream, make_kmc_view(s), path_bloom->view(), table->v,
+                           sample_idx, d_records, first_record, n, reinterpret_cast<unsigned long long *>(d_hit_count), (uint64_t *)nullptr,
+                           (uint32_t *)nullptr);
+        BT_CHECK_LAUNCH();
+        return BT_OK;
+    }
+    uint64_t chunk = std::min<uint64_t>(n, kRoutedChunk);
+    if (const char *e = getenv("BT_KMC_ROUTED_CHUNK")) chunk = std::max<uint64_t>(1024, std::min<uint64_t>(chunk, strtoull(e, nullptr, 0)));   // tests: several chunks at small sizes
+    if (ensure_routed(s, chunk) != BT_OK) return BT_ERR;
+    const KmcView kv = make_kmc_view(s);
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t m = std::min<uint64_t>(chunk, n - off);
+        uint16_t *k0 = (uint16_t *)s->d_route_keys[0], *k1 = (uint16_t *)s->d_route_keys[1];
+        RouteRec *v0 = (RouteRec *)s->d_route_vals[0], *v1 = (RouteRec *)s->d_route_vals[1];
+        hipLaunchKernelGGL(kmc_route_kernel, dim3(grid_for((m + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8)), dim3(BLOCK), 0, s->ctx->stream, kv, path_bloom->k, d_records, first_record, off, m,
+                           n, k0, v0);
+        BT_CHECK_LAUNCH();
+        size_t tmp = s->sort_tmp_bytes;
+        BT_HIP(rocprim::radix_sort_pairs(s->d_sort_tmp, tmp, k0, k1, v0, v1, (size_t)m, 0, 16, s->ctx->stream));
+        // the sorted keys are only needed to find the buckets; the unsorted values' buffer is free again: it holds the hit list
+        uint32_t *hit_list = reinterpret_cast<uint32_t *>(v0);
+        BT_HIP(hipMemsetAsync(s->d_num_hits, 0, 4, s->ctx->stream));
+        hipLaunchKernelGGL(kmc_probe_kernel, dim3(BT_NUM_SUB_BLOOMS), dim3(BLOCK), (size_t)path_bloom->stride, s->ctx->stream, path_bloom->view(), (const uint16_t *)k1, (const RouteRec *)v1,
+                           (uint32_t)m, hit_list, s->d_num_hits);
+        BT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(kmc_apply_kernel, dim3(s->ctx->num_cu * 8), dim3(BLOCK), 0, s->ctx->stream, kv, table->v, sample_idx, d_records, first_record, off, (const uint32_t *)hit_list,
+                           (const unsigned int *)s->d_num_hits, reinterpret_cast<unsigned long long *>(d_hit_count));
+        BT_CHECK_LAUNCH();
+    }
     return BT_OK;
 }
 

@@ -132,10 +132,15 @@ def test_threaded_bloom_bit_exact(gpu_ctx, oracle):
     gb.close(), ob.close()
 
 
-def test_kmc_decode_and_scan(gpu_ctx, oracle, tmp_path):
-    """parseSampleKmers: decode -> path-Bloom -> table add; table contents bit-exact incl. Bloom false positives"""
+@pytest.mark.parametrize("routed", ["0", "1"])
+def test_kmc_decode_and_scan(gpu_ctx, oracle, tmp_path, monkeypatch, routed):
+    """parseSampleKmers: decode -> path-Bloom -> table add; table contents bit-exact incl. Bloom false positives.
+    routed = 1: the route-bucketed scan (records bucketed by sub-filter, sub-filters staged in LDS) forced at this small size;
+    routed = 0: the direct kernel"""
     from bayestyper_amd import lib
     from test_oracle_kmer import make_kmc
+
+    monkeypatch.setenv("BT_KMC_ROUTED", routed)
 
     rng = np.random.default_rng(14)
     S = 3
@@ -373,6 +378,47 @@ def test_large_scan_properties(gpu_ctx, oracle):
     for x in (scan, bloom, table):
         x.close()
     d_rec.free(), d_hits.free()
+
+
+def test_routed_scan_equals_direct_at_scale(gpu_ctx, monkeypatch):
+    """6 x 10^6 records (above the size from which bt_kmc_scan_run buckets the records by sub-filter and probes the sub-filters in
+    LDS): the bucketed scan — one chunk, and several ragged chunks — leaves exactly the table the direct kernel leaves
+    (keys incl. Bloom false positives, counts, hit count)"""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(23)
+    n, p = 6_000_000, 7
+    prefixes = np.sort(rng.integers(0, 4 ** p, size=n))
+    rec = np.concatenate([rng.integers(0, 256, size=(n, 12), dtype=np.uint8), rng.integers(1, 256, size=(n, 1), dtype=np.uint8)], axis=1)
+    lut = np.searchsorted(prefixes, np.arange(4 ** p + 1)).astype(np.uint64)
+    scan = lib.KmcScan(gpu_ctx, K, p, 1, n, lut)
+    gk, _ = scan.decode(rec.reshape(-1), 0, n)
+    mk = np.unique(gk[rng.choice(n, 150_000, replace=False)], axis=0)
+    bloom = lib.Bloom.create(gpu_ctx, len(mk) + 100_000, 1e-3, K, threaded=True)      # fpr 1e-3: ~6 000 false positives in the table too
+    bloom.insert(mk)
+    d_rec = gpu_ctx.to_device(rec.reshape(-1))
+    out = []
+    for routed, chunk in (("0", None), (None, None), ("1", "1500007")):
+        if routed is None:
+            monkeypatch.delenv("BT_KMC_ROUTED", raising=False)
+        else:
+            monkeypatch.setenv("BT_KMC_ROUTED", routed)
+        if chunk:
+            monkeypatch.setenv("BT_KMC_ROUTED_CHUNK", chunk)
+        table = lib.Table(gpu_ctx, 400_000, 2, K)
+        d_hits = gpu_ctx.buffer(8).zero()
+        scan.set_count_range(2, 250)
+        scan.run(bloom, table, 1, d_rec.ptr, 0, n, d_hits.ptr)
+        gpu_ctx.sync()
+        out.append((_sorted_export(*table.export()), int(d_hits.download(np.uint64, 1)[0])))
+        table.close(), d_hits.free()
+    (ref_tab, ref_hits) = out[0]
+    assert ref_hits > len(mk) * 0.9 and len(ref_tab[0]) > len(mk)
+    for tab, hits in out[1:]:
+        assert hits == ref_hits
+        for a, b in zip(tab, ref_tab):
+            assert np.array_equal(a, b)
+    scan.close(), bloom.close(), d_rec.free()
 
 
 def test_calculate_kmer_stats(gpu_ctx, oracle, tmp_path):
