@@ -1,7 +1,12 @@
 #include "InferenceEngine.hpp"
 
 #include <algorithm>
+#include <fstream>
+#include <iostream>
 #include <sstream>
+#include <stdexcept>
+
+#include "Options.hpp"
 
 namespace bthost {
 
@@ -33,6 +38,209 @@ std::string noiseParameterRow(unsigned chain, unsigned iteration, const std::vec
     for (double r : rates) os << "\t" << r;
     os << "\n";
     return os.str();
+}
+
+// ---- the drivers ------------------------------------------------------------------------------------------------------------------
+
+namespace {
+void check(int rc, const char *what) {
+    if (rc != BT_OK) throw std::runtime_error(std::string(what) + ": " + bt_last_error());
+}
+}  // namespace
+
+// one bt_gibbs over a batch of groups
+struct InferenceEngine::Sampler {
+    bt_ctx *ctx;
+    bt_gibbs *g = nullptr;
+    uint64_t *d_hist = nullptr;
+    uint32_t S;
+    Sampler(bt_ctx *ctx_in, const bt_gibbs_params &p, const GibbsBatchData &batch) : ctx(ctx_in), S(p.num_samples) {
+        const bt_gibbs_batch b = batch.view();
+        check(bt_gibbs_create(ctx, &p, &b, &g), "bt_gibbs_create");
+    }
+    ~Sampler() {
+        if (d_hist) bt_free(ctx, d_hist);
+        bt_gibbs_destroy(g);
+    }
+    std::vector<uint64_t> noiseCounts() {   // VariantClusterGroup::getNoiseCounts of every group + clearGenotyperCache (InferenceEngine.cpp:90-92)
+        if (!d_hist) check(bt_malloc(ctx, (size_t)S * 256 * 8, (void **)&d_hist), "bt_malloc");
+        check(bt_gibbs_noise_counts(g, d_hist, 1), "bt_gibbs_noise_counts");
+        std::vector<uint64_t> h((size_t)S * 256);
+        check(bt_sync(ctx), "bt_sync");
+        check(bt_memcpy_d2h(ctx, h.data(), d_hist, h.size() * 8), "bt_memcpy_d2h");
+        return h;
+    }
+    BatchResults results(uint32_t num_clusters) {
+        BatchResults r;
+        uint64_t nd = 0, nc = 0;
+        check(bt_gibbs_result_sizes(g, &nd, &nc), "bt_gibbs_result_sizes");
+        r.dip_off.resize(num_clusters + 1);
+        r.cell_off.resize(num_clusters + 1);
+        r.h1.resize(std::max<uint64_t>(nd, 1));
+        r.h2.resize(std::max<uint64_t>(nd, 1));
+        r.freq.resize(std::max<uint64_t>(nd * S, 1));
+        r.stats.resize(std::max<uint64_t>(nc * 12, 1));
+        check(bt_gibbs_result_fetch(g, r.dip_off.data(), r.h1.data(), r.h2.data(), r.freq.data(), r.cell_off.data(), r.stats.data()), "bt_gibbs_result_fetch");
+        return r;
+    }
+};
+
+InferenceEngine::InferenceEngine(bt_ctx *ctx_in, std::vector<uint8_t> gender_in, std::vector<std::string> sample_names_in, const GibbsOptions &options, HistReducer reduce)
+    : ctx(ctx_in), gender(std::move(gender_in)), sample_names(std::move(sample_names_in)), opt(options), reduce_hist(std::move(reduce)) {}
+
+bt_gibbs_params InferenceEngine::params(uint32_t noise_seeding) const {
+    bt_gibbs_params p{};
+    p.num_samples = (uint32_t)gender.size();
+    p.seed = opt.seed;
+    p.num_chains = opt.chains;
+    p.burn_in = opt.burn_in;
+    p.num_iterations = opt.samples;
+    p.kmer_subsampling_rate = opt.kmer_subsampling_rate;
+    p.max_haplotype_variant_kmers = opt.max_haplotype_variant_kmers;
+    p.noise_seeding = noise_seeding;
+    p.gender = gender.data();
+    return p;
+}
+
+// sampleGenotypesCallback + sampleNoiseParameters of one iteration (InferenceEngine.cpp:77-98, CountDistribution.cpp:173-186)
+void InferenceEngine::iteration(Sampler *sampler, CountDistribution *cd, bool collect) {
+    const size_t S = gender.size();
+    std::vector<uint64_t> hist(S * 256, 0);
+    if (sampler) {
+        check(bt_gibbs_sweep(sampler->g, 1, collect ? 1 : 0), "bt_gibbs_sweep");
+        hist = sampler->noiseCounts();
+    }   // (a rank without groups in this chain still takes part in the reduction)
+    if (reduce_hist) reduce_hist(hist.data(), hist.size());
+    CountAllocation counts((unsigned short)S);
+    for (size_t s = 0; s < S; s++)
+        for (size_t c = 0; c < 256; c++) counts.counts()[s][c] = hist[s * 256 + c];
+    cd->sampleNoiseParameters(counts);
+    if (sampler) check(bt_gibbs_set_noise_lut(sampler->g, cd->noiseTable().data()), "bt_gibbs_set_noise_lut");
+}
+
+void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData &unit, const std::string &output_prefix, uint32_t variants_batch_size,
+                                    const std::vector<uint32_t> *unit_clusters, const std::vector<uint32_t> *unit_variants) {
+    std::cout << "[" << getLocalTime() << "] Estimating noise model parameters using " << opt.chains << " parallel gibbs sampling chains each with " << (opt.burn_in + opt.samples)
+              << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
+    const size_t S = gender.size();
+    // clusters / variants per group of the whole unit (default: `unit` is the whole unit)
+    std::vector<uint32_t> clusters, variants;
+    if (unit_clusters && unit_variants) {
+        clusters = *unit_clusters;
+        variants = *unit_variants;
+    } else {
+        for (uint32_t g = 0; g < unit.numGroups(); g++) {
+            if (unit.group_index[g] != g) throw std::runtime_error("estimateNoise: pass the unit's group shape when the batch is a shard of the unit");
+            clusters.push_back(unit.group_cluster_off[g + 1] - unit.group_cluster_off[g]);
+            uint32_t nv = 0;
+            for (uint32_t c = unit.group_cluster_off[g]; c < unit.group_cluster_off[g + 1]; c++) nv += unit.num_variants[c];
+            variants.push_back(nv);
+        }
+    }
+    NoiseGroupSelector selector(clusters.data(), variants.data(), (uint32_t)clusters.size(), opt.seed, variants_batch_size);
+    std::vector<int64_t> local(clusters.size(), -1);   // unit-wide group index -> position in this rank's batch
+    for (uint32_t g = 0; g < unit.numGroups(); g++) local[unit.group_index[g]] = g;
+    std::ofstream out(output_prefix + ".txt");
+    if (!out.is_open()) throw std::runtime_error("Unable to write file " + output_prefix + ".txt");
+    out << noiseParameterHeader(sample_names);
+    std::vector<double> mean(S, 0.0);
+    for (uint32_t chain = 0; chain < opt.chains; chain++) {
+        std::vector<uint32_t> mine;
+        for (uint32_t g : selector.nextChain())
+            if (local[g] >= 0) mine.push_back((uint32_t)local[g]);
+        std::unique_ptr<Sampler> sampler;
+        if (!mine.empty()) {
+            // a fresh sampler per chain: genotypers are constructed with seed + (i+1)(chain+1) (:70) and deleted afterwards (resetGroupsCallback, :240-251)
+            sampler.reset(new Sampler(ctx, params(1), unit.take(mine)));
+            check(bt_gibbs_set_lut(sampler->g, cd->genomicTable().data(), cd->noiseTable().data()), "bt_gibbs_set_lut");
+            check(bt_gibbs_init_chain(sampler->g, chain), "bt_gibbs_init_chain");
+        }
+        out << noiseParameterRow(chain + 1, 0, cd->getNoiseRates());
+        for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
+            iteration(sampler.get(), cd, false);
+            const std::vector<double> &rates = cd->getNoiseRates();
+            out << noiseParameterRow(chain + 1, it, rates);
+            if (opt.burn_in < it)
+                for (size_t s = 0; s < S; s++) mean[s] += rates[s];
+        }
+        sampler.reset();
+        cd->resetNoiseRates();
+    }
+    for (auto &m : mean) m /= (double)opt.samples * opt.chains;
+    cd->setNoiseRates(mean);
+    out << noiseParameterRow(0, 0, cd->getNoiseRates());
+    low_variant_warning = selector.lastNumVariants() < variants_batch_size;
+    if (low_variant_warning) {
+        std::cout << "\nWARNING: Low number of variants used for noise model parameter estimation (" << selector.lastNumVariants() << " < " << variants_batch_size << ")" << std::endl;
+        std::cout << "WARNING: The noise estimates might be biased\n" << std::endl;
+    }
+    std::cout << "[" << getLocalTime() << "] Wrote noise parameters to " << output_prefix << ".txt" << std::endl;
+}
+
+// the default schedule for a batch; a batch whose sampler state does not fit the GPU is run as two consecutive halves (groups are
+// independent and keep their unit-wide index, so the split changes nothing but the peak memory; InferenceEngine.cpp:335-382 hands
+// groups to its threads in batches the same way)
+void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistribution &cd, const Collector &collect) {
+    std::unique_ptr<Sampler> sampler;
+    try {
+        sampler.reset(new Sampler(ctx, params(0), batch));
+    } catch (const std::runtime_error &e) {
+        if (batch.numGroups() < 2 || std::string(e.what()).find("state pool") == std::string::npos) throw;
+        std::vector<uint32_t> a, b;
+        for (uint32_t g = 0; g < batch.numGroups(); g++) (g < batch.numGroups() / 2 ? a : b).push_back(g);
+        runDefault(batch.take(a), cd, collect);
+        runDefault(batch.take(b), cd, collect);
+        return;
+    }
+    num_launches += 1;
+    check(bt_gibbs_set_lut(sampler->g, cd.genomicTable().data(), cd.noiseTable().data()), "bt_gibbs_set_lut");
+    check(bt_gibbs_run(sampler->g), "bt_gibbs_run");
+    const BatchResults r = sampler->results(batch.numClusters());
+    sampler.reset();   // frees the launch's HBM before the next one is built
+    collect(batch, r);
+}
+
+void InferenceEngine::estimateGenotypes(const GibbsBatchData &unit, const CountDistribution &cd, const Collector &collect) {
+    uint64_t num_variants = 0;
+    for (uint32_t v : unit.num_variants) num_variants += v;
+    std::cout << "[" << getLocalTime() << "] Estimating genotypes on " << num_variants << " variants using " << opt.chains << " parallel gibbs sampling chains each with "
+              << (opt.burn_in + opt.samples) << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
+    num_launches = 0;
+    if (unit.numGroups()) runDefault(unit, cd, collect);
+    std::cout << "[" << getLocalTime() << "] Finished genotyping" << std::endl;
+}
+
+void InferenceEngine::estimateNoiseAndGenotypes(const GibbsBatchData &unit, CountDistribution *cd, const Collector &collect, const std::string &output_prefix) {
+    uint64_t num_variants = 0;
+    for (uint32_t v : unit.num_variants) num_variants += v;
+    std::cout << "[" << getLocalTime() << "] Estimating noise model parameters and genotypes on " << num_variants << " variants using " << opt.chains
+              << " parallel gibbs sampling chains each with " << (opt.burn_in + opt.samples) << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
+    std::ofstream out(output_prefix + ".txt");
+    if (!out.is_open()) throw std::runtime_error("Unable to write file " + output_prefix + ".txt");
+    out << noiseParameterHeader(sample_names);
+    std::unique_ptr<Sampler> sampler;
+    if (unit.numGroups()) {
+        sampler.reset(new Sampler(ctx, params(1), unit));
+        check(bt_gibbs_set_lut(sampler->g, cd->genomicTable().data(), cd->noiseTable().data()), "bt_gibbs_set_lut");
+    }
+    for (uint32_t chain = 0; chain < opt.chains; chain++) {
+        if (sampler) {
+            check(bt_gibbs_set_noise_lut(sampler->g, cd->noiseTable().data()), "bt_gibbs_set_noise_lut");
+            check(bt_gibbs_init_chain(sampler->g, chain), "bt_gibbs_init_chain");
+        }
+        out << noiseParameterRow(chain + 1, 0, cd->getNoiseRates());
+        for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
+            iteration(sampler.get(), cd, it > opt.burn_in);
+            out << noiseParameterRow(chain + 1, it, cd->getNoiseRates());
+        }
+        cd->resetNoiseRates();
+    }
+    if (sampler) {
+        const BatchResults r = sampler->results(unit.numClusters());
+        sampler.reset();
+        collect(unit, r);
+    }
+    std::cout << "[" << getLocalTime() << "] Wrote noise parameters to " << output_prefix << ".txt" << std::endl;
 }
 
 }  // namespace bthost

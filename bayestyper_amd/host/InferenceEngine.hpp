@@ -1,12 +1,23 @@
-// Deterministic host pieces of the reference's noise drivers (src/bayesTyper/InferenceEngine.cpp:135-276, 384-472):
-// which groups a chain of estimateNoise samples, and the rows of <prefix>_noise_parameters.txt.  The iteration loop itself
-// (launch a sweep on the GPU, add up the noise-count histograms — across ranks too —, draw the noise rates, upload the noise
-// table) lives in bayestyper_amd/host/inference_engine.py, above the C ABI of libbtgpu.so.
+// InferenceEngine (include/bayesTyper/InferenceEngine.hpp:60-62, src/bayesTyper/InferenceEngine.cpp): the three drivers of the
+// genotyping stage over the C ABI of libbtgpu.so —
+//   estimateNoise              (:135-276)  noise rates from single-cluster groups, chain by chain
+//   estimateGenotypes          (:278-382)  default mode: the whole schedule of every group in one launch (or a few, see below)
+//   estimateNoiseAndGenotypes  (:384-472)  --noise-genotyping
+// In the two noise drivers an iteration is: one sweep of all (selected) groups on the GPU, their noise-count histograms added up
+// (CountAllocation; across ranks: `reduce_hist`, one all-reduce of S x 256 counters), one gamma draw per sample from the run's
+// CountDistribution generator on the host, the rebuilt noise table uploaded.  Every rank draws from an identically seeded generator,
+// so all ranks hold the same rates without a broadcast.  (bayestyper_amd/host/inference_engine.py drives the same C ABI from Python
+// for the tests and the bench.)
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <random>
 #include <string>
 #include <vector>
+
+#include "../../include/btgpu.h"
+#include "CountDistribution.hpp"
+#include "KmerCounter.hpp"
 
 namespace bthost {
 
@@ -34,5 +45,51 @@ class NoiseGroupSelector {
 // digits) the reference writes with (InferenceEngine.cpp:205,236,267; Utils.hpp:209-224)
 std::string noiseParameterHeader(const std::vector<std::string> &sample_names);
 std::string noiseParameterRow(unsigned chain, unsigned iteration, const std::vector<double> &rates);
+
+// what bt_gibbs_result_fetch returns for the clusters of a batch
+struct BatchResults {
+    std::vector<uint64_t> dip_off, cell_off;   // [C+1]
+    std::vector<uint16_t> h1, h2;
+    std::vector<uint32_t> freq;                // [entries * S]
+    std::vector<double> stats;                 // [cells * 12]
+};
+
+struct GibbsOptions {   // main.cpp:389-393 + --random-seed
+    unsigned seed = 0;
+    uint32_t burn_in = 100, samples = 250, chains = 20, max_haplotype_variant_kmers = 500;
+    float kmer_subsampling_rate = 0.1f;
+};
+
+class InferenceEngine {
+  public:
+    // collected samples of a launch: `batch` holds the launched groups (group_index = index in the unit), results in its cluster order
+    typedef std::function<void(const GibbsBatchData &batch, const BatchResults &results)> Collector;
+    typedef std::function<void(uint64_t *hist, size_t n)> HistReducer;   // sums the S*256 counters over all ranks in place
+
+    InferenceEngine(bt_ctx *ctx, std::vector<uint8_t> gender, std::vector<std::string> sample_names, const GibbsOptions &options, HistReducer reduce_hist = nullptr);
+
+    // unit = this rank's groups; unit_shape (optional) = clusters / variants per group of the WHOLE unit when `unit` is a shard of it
+    void estimateNoise(CountDistribution *count_distribution, const GibbsBatchData &unit, const std::string &output_prefix, uint32_t variants_batch_size = NoiseGroupSelector::noise_variants_batch_size,
+                       const std::vector<uint32_t> *unit_clusters_per_group = nullptr, const std::vector<uint32_t> *unit_variants_per_group = nullptr);
+    void estimateGenotypes(const GibbsBatchData &unit, const CountDistribution &count_distribution, const Collector &collect);
+    void estimateNoiseAndGenotypes(const GibbsBatchData &unit, CountDistribution *count_distribution, const Collector &collect, const std::string &output_prefix);
+
+    bool lowNoiseVariantWarning() const { return low_variant_warning; }
+    uint32_t numLaunches() const { return num_launches; }   // of the last estimateGenotypes
+
+  private:
+    struct Sampler;
+    void iteration(Sampler *sampler, CountDistribution *count_distribution, bool collect);
+    void runDefault(const GibbsBatchData &batch, const CountDistribution &count_distribution, const Collector &collect);
+    bt_gibbs_params params(uint32_t noise_seeding) const;
+
+    bt_ctx *ctx;
+    std::vector<uint8_t> gender;
+    std::vector<std::string> sample_names;
+    GibbsOptions opt;
+    HistReducer reduce_hist;
+    bool low_variant_warning = false;
+    uint32_t num_launches = 0;
+};
 
 }  // namespace bthost

@@ -20,150 +20,181 @@ constexpr uint16_t NONE16 = 0xFFFF;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 }  // namespace
 
-uint32_t VariantClusterGraph::addVertex() {
-    vertices.emplace_back();
-    return (uint32_t)vertices.size() - 1;
-}
+// ---- graph assembly ------------------------------------------------------------------------------------------------------------------
+// The graph of a cluster is its stretch of the reference (k-1 flank before the first variant .. k-1 after the last allele end) cut into
+// BACKBONE pieces at every position where a variant starts or an alternative allele re-joins, plus one ALLELE piece per alternative
+// allele hanging between the backbone vertex that ends at its variant's position and the backbone piece that starts where the allele
+// ends.  Pieces are emitted left to right: a variant's allele pieces first (in allele order), then the backbone up to the next
+// variant.  A piece becomes one vertex, or several in a row when it is cut — at a contained (nested) cluster, whose own graph replaces
+// that part of the reference, and at runs of non-ACGT characters; every cut starts a "disconnected" vertex (no k-mer spans it).
+// Vertex and edge numbering follow the reference's constructor (VariantClusterGraph.cpp:62-377), which the path search and the
+// k-mer enumeration rely on (the oracle's restatement, oracle/oracle_graph.cpp, is the checker: tests/test_host_graph_cpu.py).
+namespace {
 
-// VariantClusterGraph.cpp:62-262
+struct Tail {                 // vertices whose sequence ends right before `position` and that still wait for their successor
+    uint32_t position;
+    std::vector<uint32_t> vertices;
+    std::vector<uint16_t> closing;   // variants whose longest allele ends here: they stop overlapping the backbone from here on
+};
+
+class Assembler {
+  public:
+    Assembler(std::vector<GraphVertex> *vertices_in, std::vector<std::pair<uint32_t, uint32_t>> *edges_in, const std::string &chrom_in, unsigned k_in,
+              std::list<ContainedCluster> *contained_in)
+        : vertices(*vertices_in), edges(*edges_in), chrom(chrom_in), k(k_in), contained(*contained_in) {}
+
+    // a piece over characters [begin, end) of `text`: one vertex per maximal ACGT stretch; returns the piece's LAST vertex.  `first` is
+    // the piece's first vertex (already created by the caller, so that the caller can wire its in-edges).
+    uint32_t fill(uint32_t first, const std::string &text, size_t begin, size_t end, uint16_t variant, uint16_t allele, uint32_t nested, bool redundant) {
+        uint32_t at = first;
+        stamp(at, variant, allele, nested, redundant, nested != NONE32);
+        bool in_gap = false;
+        for (size_t i = begin; i < end; i++) {
+            const int code = ntCode(text[i]);
+            if (code >= 0) {
+                vertices[at].sequence.push_back((uint8_t)code);
+                in_gap = false;
+            } else if (!in_gap) {   // first character of a run of N (or anything else): the rest continues in a disconnected vertex
+                const uint32_t next = append();
+                edges.emplace_back(at, next);
+                at = next;
+                stamp(at, variant, allele, NONE32, false, true);
+                in_gap = true;
+            }
+        }
+        return at;
+    }
+
+    uint32_t append() {
+        vertices.emplace_back();
+        return (uint32_t)vertices.size() - 1;
+    }
+
+    // the backbone piece [from, to) of the reference, entered from `sources`; contained clusters inside it split it (each one's
+    // stretch of the reference is skipped, the vertex after it carries the nested cluster's index).  Returns its last vertex.
+    uint32_t backbone(uint32_t from, uint32_t to, const std::vector<uint32_t> &sources, uint16_t variant, uint16_t allele, bool redundant) {
+        if (to > chrom.size()) throw std::invalid_argument("VariantClusterGraph: cluster runs past the chromosome end");
+        uint32_t at = append();
+        for (uint32_t s : sources) edges.emplace_back(s, at);
+        uint32_t nested = NONE32, cursor = from;
+        bool first_part = true;
+        while (!contained.empty() && contained.front().left_flank < to) {
+            const ContainedCluster inner = contained.front();
+            contained.pop_front();
+            if (inner.left_flank < cursor || inner.right_flank + k > to) throw std::invalid_argument("VariantClusterGraph: contained cluster does not fit its reference segment");
+            at = part(at, cursor, inner.left_flank, variant, allele, nested, redundant && first_part, first_part);
+            first_part = false;
+            nested = inner.cluster_idx;
+            cursor = inner.right_flank + 1;
+        }
+        return part(at, cursor, to, variant, allele, nested, redundant && first_part, first_part);
+    }
+
+    void openVariant(uint16_t v) { open.push_back(v); }
+    void closeVariants(const std::vector<uint16_t> &vs) {
+        for (uint16_t v : vs) open.erase(std::find(open.begin(), open.end(), v));
+    }
+    // a tail list kept sorted by position (a handful of entries at most)
+    Tail &tailAt(uint32_t position) {
+        auto it = std::lower_bound(tails.begin(), tails.end(), position, [](const Tail &t, uint32_t p) { return t.position < p; });
+        if (it == tails.end() || it->position != position) it = tails.insert(it, Tail{position, {}, {}});
+        return *it;
+    }
+    std::vector<Tail> tails;
+
+  private:
+    uint32_t part(uint32_t at, uint32_t from, uint32_t to, uint16_t variant, uint16_t allele, uint32_t nested, bool redundant, bool is_first) {
+        if (!is_first) {
+            const uint32_t next = append();
+            edges.emplace_back(at, next);
+            at = next;
+        }
+        return fill(at, chrom, from, to, variant, allele, nested, redundant);
+    }
+    void stamp(uint32_t v, uint16_t variant, uint16_t allele, uint32_t nested, bool redundant, bool disconnected) {
+        GraphVertex &x = vertices[v];
+        x.variant = variant;
+        x.allele = allele;
+        x.nested_variant_cluster_index = nested;
+        x.is_first_nucleotides_redundant = redundant;
+        x.is_disconnected = disconnected;
+        x.reference_variant_indices.clear();
+        for (uint16_t o : open)   // the variants still "open" over this stretch, except the one the vertex is an allele of
+            if (o != variant) x.reference_variant_indices.push_back(o);
+        std::sort(x.reference_variant_indices.begin(), x.reference_variant_indices.end());
+    }
+
+    std::vector<GraphVertex> &vertices;
+    std::vector<std::pair<uint32_t, uint32_t>> &edges;
+    const std::string &chrom;
+    const unsigned k;
+    std::list<ContainedCluster> &contained;
+    std::vector<uint16_t> open;
+};
+
+}  // namespace
+
 VariantClusterGraph::VariantClusterGraph(VariantCluster variant_cluster, const std::string &chrom_sequence, unsigned kmer_size) {
-    if (variant_cluster.variants.empty()) throw std::invalid_argument("VariantClusterGraph: cluster without variants");
-    if (variant_cluster.variants.size() >= NONE16) throw std::invalid_argument("VariantClusterGraph: too many variants");
-    std::map<uint32_t, std::pair<std::vector<uint32_t>, std::vector<uint16_t>>> added_vertices;
-    std::set<uint16_t> reference_variant_indices;   // the reference's unordered_set: only membership matters downstream
-    auto refvec = [&]() { return std::vector<uint16_t>(reference_variant_indices.begin(), reference_variant_indices.end()); };
-    auto variants_it = variant_cluster.variants.begin();
-    const auto chrom_it = chrom_sequence.begin();
-    if (variants_it->first < kmer_size - 1) throw std::invalid_argument("VariantClusterGraph: first variant closer than k-1 to the chromosome start");
-    uint32_t cur_vertex = addVertex();
-    addVertices(&cur_vertex, std::vector<StringItPair>(1, StringItPair(chrom_it + variants_it->first - (kmer_size - 1), chrom_it + variants_it->first)), {NONE16, NONE16},
-                refvec(), {}, false);
-    uint32_t prev_vertex = cur_vertex;
-    added_vertices.insert({variants_it->first, {std::vector<uint32_t>(1, cur_vertex), {}}});
-    uint32_t cur_last_position = 0, next_position = 0;
-    uint16_t variant_counter = 0;
-    while (variants_it != variant_cluster.variants.end()) {
-        const Variant &var = variants_it->second;
-        var_num_alleles.push_back((uint16_t)(1 + (var.has_dependency ? 1 : 0) + var.alt_alleles.size()));
-        var_has_dependency.push_back(var.has_dependency ? 1 : 0);
-        const bool is_first_nucleotides_redundant = var.num_redundant_nucleotides > 0;
-        uint32_t max_reference_length = 0;
-        for (uint16_t alt_allele_idx = 0; alt_allele_idx < var.alt_alleles.size(); alt_allele_idx++) {
-            const AlleleInfo &alt = var.alt_alleles[alt_allele_idx];
-            max_reference_length = std::max(max_reference_length, alt.ref_length);
-            uint32_t next_vertex = addVertex();
-            edges.emplace_back(cur_vertex, next_vertex);
-            addVertices(&next_vertex, std::vector<StringItPair>(1, StringItPair(alt.sequence.begin(), alt.sequence.end())), {variant_counter, (uint16_t)(alt_allele_idx + 1)},
-                        refvec(), {}, is_first_nucleotides_redundant);
-            added_vertices[variants_it->first + alt.ref_length].first.push_back(next_vertex);
+    const auto &variants = variant_cluster.variants;
+    if (variants.empty()) throw std::invalid_argument("VariantClusterGraph: cluster without variants");
+    if (variants.size() >= NONE16) throw std::invalid_argument("VariantClusterGraph: too many variants");
+    const uint32_t first_position = variants.begin()->first;
+    if (first_position < kmer_size - 1) throw std::invalid_argument("VariantClusterGraph: first variant closer than k-1 to the chromosome start");
+    Assembler as(&vertices, &edges, chrom_sequence, kmer_size, &variant_cluster.contained_clusters);
+
+    // left flank: the k-1 reference nucleotides before the first variant
+    uint32_t trunk = as.fill(as.append(), chrom_sequence, first_position - (kmer_size - 1), first_position, NONE16, NONE16, NONE32, false);
+    as.tailAt(first_position).vertices.push_back(trunk);
+
+    uint16_t index = 0;
+    for (auto it = variants.begin(); it != variants.end(); ++it, ++index) {
+        const uint32_t position = it->first;
+        const Variant &variant = it->second;
+        if (variant.alt_alleles.empty()) throw std::invalid_argument("VariantClusterGraph: variant without alternative alleles");
+        var_num_alleles.push_back((uint16_t)(1 + (variant.has_dependency ? 1 : 0) + variant.alt_alleles.size()));
+        var_has_dependency.push_back(variant.has_dependency ? 1 : 0);
+        const bool redundant = variant.num_redundant_nucleotides > 0;
+
+        // the alternative alleles branch off the trunk vertex that ends at the variant and re-join where their reference stretch ends
+        uint32_t longest = 0;
+        for (size_t a = 0; a < variant.alt_alleles.size(); a++) {
+            const AlleleInfo &alt = variant.alt_alleles[a];
+            const uint32_t head = as.append();
+            edges.emplace_back(trunk, head);
+            const uint32_t tail = as.fill(head, alt.sequence, 0, alt.sequence.size(), index, (uint16_t)(a + 1), NONE32, redundant);
+            as.tailAt(position + alt.ref_length).vertices.push_back(tail);
+            longest = std::max(longest, alt.ref_length);
         }
-        if (max_reference_length == 0) throw std::invalid_argument("VariantClusterGraph: variant without alternative alleles");
-        added_vertices.at(variants_it->first + max_reference_length).second.push_back(variant_counter);
-        reference_variant_indices.insert(variant_counter);
-        variants_it++;
-        bool more_edges = true, last_variant = false;
-        if (variants_it != variant_cluster.variants.end()) next_position = variants_it->first;
-        else {
-            next_position = NONE32;
-            last_variant = true;
-        }
-        while (more_edges) {
-            auto added_it = added_vertices.begin();
-            uint32_t cur_position = added_it->first;
-            const std::vector<uint32_t> next_vertices = added_it->second.first;
-            for (uint16_t variant_idx : added_it->second.second) reference_variant_indices.erase(variant_idx);
-            added_vertices.erase(added_it);
-            if (added_vertices.empty()) {
-                more_edges = false;
-                cur_last_position = last_variant ? cur_position + kmer_size - 1 : next_position;
+        if (longest == 0) throw std::invalid_argument("VariantClusterGraph: variant whose alleles cover no reference nucleotide");
+        as.tailAt(position + longest).closing.push_back(index);
+        as.openVariant(index);
+
+        // the trunk from the variant's position up to the next variant (or, after the last one, k-1 past the last allele end): one
+        // backbone piece per stretch between consecutive re-join positions.  The piece entered from the old trunk vertex is the
+        // variant's reference allele.
+        const auto next = std::next(it);
+        const bool last = next == variants.end();
+        const uint32_t limit = last ? NONE32 : next->first;
+        const uint32_t branch_vertex = trunk;
+        for (bool done = false; !done;) {
+            const Tail here = as.tails.front();
+            as.tails.erase(as.tails.begin());
+            as.closeVariants(here.closing);
+            uint32_t until;
+            if (as.tails.empty()) {
+                until = last ? here.position + kmer_size - 1 : limit;
+                done = true;
             } else {
-                cur_last_position = added_vertices.begin()->first;
-                if (!last_variant && cur_last_position > next_position) {
-                    more_edges = false;
-                    cur_last_position = next_position;
+                until = as.tails.front().position;
+                if (!last && until > limit) {
+                    until = limit;
+                    done = true;
                 }
             }
-            if (cur_last_position > chrom_sequence.size()) throw std::invalid_argument("VariantClusterGraph: cluster runs past the chromosome end");
-            std::vector<StringItPair> contained_vertices;
-            std::vector<uint32_t> nested_variant_cluster_indices;
-            uint32_t prev_contained_edge = NONE32;
-            auto contained_it = variant_cluster.contained_clusters.begin();
-            while (contained_it != variant_cluster.contained_clusters.end() && contained_it->left_flank < cur_last_position) {
-                if (!(cur_position <= contained_it->left_flank) || !(contained_it->right_flank <= cur_last_position - kmer_size))
-                    throw std::invalid_argument("VariantClusterGraph: contained cluster does not fit its reference segment");
-                if (prev_contained_edge < NONE32) nested_variant_cluster_indices.push_back(prev_contained_edge);
-                contained_vertices.emplace_back(chrom_it + cur_position, chrom_it + contained_it->left_flank);
-                prev_contained_edge = contained_it->cluster_idx;
-                cur_position = contained_it->right_flank + 1;
-                contained_it = variant_cluster.contained_clusters.erase(contained_it);
-            }
-            if (prev_contained_edge < NONE32) nested_variant_cluster_indices.push_back(prev_contained_edge);
-            contained_vertices.emplace_back(chrom_it + cur_position, chrom_it + cur_last_position);
-            cur_vertex = addVertex();
-            bool is_reference_allele = false;
-            for (uint32_t v : next_vertices) {
-                if (v == prev_vertex) is_reference_allele = true;
-                edges.emplace_back(v, cur_vertex);
-            }
-            if (is_reference_allele)
-                addVertices(&cur_vertex, contained_vertices, {variant_counter, (uint16_t)0}, refvec(), nested_variant_cluster_indices, is_first_nucleotides_redundant);
-            else
-                addVertices(&cur_vertex, contained_vertices, {NONE16, NONE16}, refvec(), nested_variant_cluster_indices, false);
-            added_vertices[cur_last_position].first.push_back(cur_vertex);
+            const bool reference_allele = std::find(here.vertices.begin(), here.vertices.end(), branch_vertex) != here.vertices.end();
+            trunk = as.backbone(here.position, until, here.vertices, reference_allele ? index : NONE16, reference_allele ? (uint16_t)0 : NONE16, reference_allele && redundant);
+            as.tailAt(until).vertices.push_back(trunk);
         }
-        variant_counter++;
-        prev_vertex = cur_vertex;
-    }
-}
-
-// VariantClusterGraph.cpp:290-316
-void VariantClusterGraph::addVertices(uint32_t *cur_vertex, const std::vector<StringItPair> &vertex_sequences, std::pair<uint16_t, uint16_t> variant_allele_idx,
-                                      const std::vector<uint16_t> &reference_variant_indices, const std::vector<uint32_t> &nested_variant_cluster_indices,
-                                      bool is_first_nucleotides_redundant) {
-    std::vector<uint16_t> vertex_reference_variant_indices;
-    for (uint16_t r : reference_variant_indices)
-        if (r != variant_allele_idx.first) vertex_reference_variant_indices.push_back(r);
-    initVertex(cur_vertex, vertex_sequences.front(), variant_allele_idx, vertex_reference_variant_indices, NONE32, is_first_nucleotides_redundant);
-    for (size_t i = 1; i < vertex_sequences.size(); i++) {
-        const uint32_t prev_vertex = *cur_vertex;
-        *cur_vertex = addVertex();
-        edges.emplace_back(prev_vertex, *cur_vertex);
-        initVertex(cur_vertex, vertex_sequences[i], variant_allele_idx, vertex_reference_variant_indices, nested_variant_cluster_indices.at(i - 1), false);
-    }
-}
-
-// VariantClusterGraph.cpp:318-377: a run of non-ACGT characters closes the vertex and opens a disconnected one
-void VariantClusterGraph::initVertex(uint32_t *cur_vertex, StringItPair vertex_sequence, std::pair<uint16_t, uint16_t> variant_allele_idx,
-                                     const std::vector<uint16_t> &vertex_reference_variant_indices, uint32_t nested_variant_cluster_index, bool is_first_nucleotides_redundant) {
-    GraphVertex *v = &vertices[*cur_vertex];
-    v->variant = variant_allele_idx.first;
-    v->allele = variant_allele_idx.second;
-    v->reference_variant_indices = vertex_reference_variant_indices;
-    v->nested_variant_cluster_index = nested_variant_cluster_index;
-    v->is_first_nucleotides_redundant = is_first_nucleotides_redundant;
-    v->is_disconnected = nested_variant_cluster_index != NONE32;
-    bool prev_is_disconnected = false;
-    while (vertex_sequence.first != vertex_sequence.second) {
-        const int code = ntCode(*vertex_sequence.first);
-        if (code < 0) {
-            if (!prev_is_disconnected) {
-                const uint32_t prev_vertex = *cur_vertex;
-                *cur_vertex = addVertex();
-                edges.emplace_back(prev_vertex, *cur_vertex);
-                v = &vertices[*cur_vertex];
-                v->variant = variant_allele_idx.first;
-                v->allele = variant_allele_idx.second;
-                v->reference_variant_indices = vertex_reference_variant_indices;
-                v->nested_variant_cluster_index = NONE32;
-                v->is_first_nucleotides_redundant = false;
-                v->is_disconnected = true;
-            }
-            prev_is_disconnected = true;
-        } else {
-            v->sequence.push_back((uint8_t)code);
-            prev_is_disconnected = false;
-        }
-        vertex_sequence.first++;
     }
 }
 

@@ -53,13 +53,6 @@ class VariantClusterGraph {
     std::vector<uint16_t> var_num_alleles;              // variant_cluster_info[v].numberOfAlleles()
     std::vector<uint8_t> var_has_dependency;
 
-  private:
-    typedef std::pair<std::string::const_iterator, std::string::const_iterator> StringItPair;
-    uint32_t addVertex();
-    void addVertices(uint32_t *cur_vertex, const std::vector<StringItPair> &vertex_sequences, std::pair<uint16_t, uint16_t> variant_allele_idx,
-                     const std::vector<uint16_t> &reference_variant_indices, const std::vector<uint32_t> &nested_variant_cluster_indices, bool is_first_nucleotides_redundant);
-    void initVertex(uint32_t *cur_vertex, StringItPair vertex_sequence, std::pair<uint16_t, uint16_t> variant_allele_idx,
-                    const std::vector<uint16_t> &vertex_reference_variant_indices, uint32_t nested_variant_cluster_index, bool is_first_nucleotides_redundant);
 };
 
 // Collects graphs (and, when known, their best paths) into the flat arrays of bt_paths_batch.

@@ -46,6 +46,11 @@ void Chromosomes::addFasta(const std::string &fasta_filename, bool is_decoy) {
     }
 }
 
+void Chromosomes::convertToUpper() {
+    for (auto &s : seqs)
+        for (char &c : s.second) c = (char)std::toupper((unsigned char)c);
+}
+
 int Chromosomes::find(const std::string &name) const {
     auto it = order.find(name);
     return it == order.end() ? -1 : (int)it->second;

@@ -28,6 +28,8 @@ class Chromosomes {
   public:
     void addFasta(const std::string &fasta_filename, bool is_decoy);                      // Chromosomes.cpp:72-113
     void addSequence(const std::string &name, const std::string &sequence, bool is_decoy);   // :52-70
+    void convertToUpper();                                                                // Chromosomes::convertToUpper (main.cpp:209,462)
+    size_t decoyCount() const { return decoys.size(); }
     int find(const std::string &name) const;                                              // index or -1 (:125-137)
     bool isDecoy(const std::string &name) const { return decoys.count(name) > 0; }
     size_t size() const { return seqs.size(); }

@@ -11,6 +11,10 @@
 #include "Genotypes.hpp"
 #include "InferenceEngine.hpp"
 #include "KmcFile.hpp"
+#include "KmerHashOrder.hpp"
+#include "InferenceUnit.hpp"
+#include "KmerCounter.hpp"
+#include "Sample.hpp"
 #include "VariantClusterGraph.hpp"
 #include "VariantFileParser.hpp"
 
@@ -402,6 +406,88 @@ long long bth_cluster_output_columns(unsigned S, unsigned H, unsigned V, const u
         return (long long)all.size();
     } catch (...) {
         return -1;
+    }
+}
+
+
+// ---- pieces of the command lines (Options / Sample / ChromosomePloidy / InferenceUnit / KmerHashOrder), for the CPU tests ----
+uint64_t bth_bitset_hash(uint64_t lo, uint64_t hi, unsigned kmer_size) { return bitsetHash(lo, hi, kmer_size); }
+void bth_hybrid_hash_order(const uint64_t *kmers, uint64_t n, unsigned kmer_size, unsigned seed, uint64_t root_hash_size, uint32_t *order_out) {
+    const std::vector<uint32_t> o = hybridHashShuffledOrder(kmers, n, kmer_size, seed, root_hash_size);
+    std::copy(o.begin(), o.end(), order_out);
+}
+// CountAllocation: counts of a (sample, count) list merged with those of a second list -> out[S*256]
+void bth_count_allocation(unsigned short S, const unsigned short *s1, const unsigned char *c1, uint64_t n1, const unsigned short *s2, const unsigned char *c2, uint64_t n2,
+                          unsigned long *out) {
+    CountAllocation a(S), b(S);
+    for (uint64_t i = 0; i < n1; i++) a.addCount(s1[i], c1[i]);
+    for (uint64_t i = 0; i < n2; i++) b.addCount(s2[i], c2[i]);
+    a.mergeInCountAllocations(b);
+    for (unsigned short s = 0; s < S; s++)
+        for (unsigned c = 0; c < 256; c++) out[(size_t)s * 256 + c] = a.getCounts()[s][c];
+}
+// unit file round trip: the cluster stage's last unit (every cluster with a few constant best paths over its graph's vertices)
+// written to `filename`, read back, and dumped as text; returns the text's size
+unsigned long long bth_unit_roundtrip(void *stage, const char *filename, uint32_t num_paths, char *buf, unsigned long long cap, char *err, unsigned err_len) {
+    auto *st = (ClusterStage *)stage;
+    try {
+        InferenceUnit u;
+        u.index = 7;
+        u.cluster_options_header = "##BayesTyperOptions=test\n";
+        u.variant_cluster_groups = st->unit;
+        u.num_variants = 123;
+        u.num_variant_clusters = 45;
+        u.num_path_kmers = 1ull << 40;
+        const UnitGraphs ug(u, st->chromosomes, st->k);
+        u.best_paths.resize(u.variant_cluster_groups.size());
+        for (size_t c = 0; c < ug.graphs.size(); c++) {
+            auto &dst = u.best_paths[ug.cluster_group[c]];
+            dst.resize(u.variant_cluster_groups[ug.cluster_group[c]].clusters.size());
+            dst[ug.cluster_vertex[c]].assign(num_paths + c % 3, std::vector<uint8_t>(ug.graphs[c].vertices.size(), (uint8_t)(c & 1)));
+        }
+        u.write(filename);
+        const InferenceUnit r = InferenceUnit::read(filename);
+        std::ostringstream os;
+        os << r.index << " " << r.cluster_options_header << r.num_variants << " " << r.num_variant_clusters << " " << r.num_path_kmers << "\n" << dumpClusterGroups(r.variant_cluster_groups);
+        bool same = dumpClusterGroups(r.variant_cluster_groups) == dumpClusterGroups(u.variant_cluster_groups) && r.best_paths == u.best_paths;
+        for (size_t g = 0; same && g < u.variant_cluster_groups.size(); g++)
+            for (size_t v = 0; same && v < u.variant_cluster_groups[g].clusters.size(); v++) {
+                const VariantCluster &a = u.variant_cluster_groups[g].clusters[v], &b = r.variant_cluster_groups[g].clusters[v];
+                same = a.variants.size() == b.variants.size();
+                for (auto ia = a.variants.begin(), ib = b.variants.begin(); same && ia != a.variants.end(); ++ia, ++ib) {
+                    same = ia->first == ib->first && ia->second.id == ib->second.id && ia->second.has_dependency == ib->second.has_dependency && ia->second.type == ib->second.type &&
+                           ia->second.num_redundant_nucleotides == ib->second.num_redundant_nucleotides && ia->second.alt_alleles.size() == ib->second.alt_alleles.size();
+                    for (size_t i = 0; same && i < ia->second.alt_alleles.size(); i++)
+                        same = ia->second.alt_alleles[i].ref_length == ib->second.alt_alleles[i].ref_length && ia->second.alt_alleles[i].sequence == ib->second.alt_alleles[i].sequence &&
+                               ia->second.alt_alleles[i].aco_att == ib->second.alt_alleles[i].aco_att;
+                }
+            }
+        os << (same ? "IDENTICAL\n" : "DIFFERENT\n");
+        return copy_out(os.str(), buf, cap);
+    } catch (const std::exception &e) {
+        stage_error(e, err, err_len);
+        return 0;
+    }
+}
+// ChromosomePloidy of the stage's genome for samples given as a gender string ("FM.."): rows "<chromosome>\t<female>\t<male>\t<per-sample ploidies>"
+unsigned long long bth_chromosome_ploidy(void *stage, const char *ploidy_filename, const char *genders, char *buf, unsigned long long cap, char *err, unsigned err_len) {
+    auto *st = (ClusterStage *)stage;
+    try {
+        std::vector<Sample> samples;
+        for (const char *g = genders; *g; g++) samples.emplace_back(std::string("s") + std::to_string(samples.size()) + "\t" + *g + "\tprefix");
+        const ChromosomePloidy cp(ploidy_filename, st->chromosomes, samples);
+        std::ostringstream os;
+        for (size_t i = 0; i < st->chromosomes.size(); i++) {
+            const std::string &name = st->chromosomes.name(i);
+            if (st->chromosomes.isDecoy(name)) continue;
+            os << name << "\t" << (int)cp.getGenderPloidy(name)[0] << "\t" << (int)cp.getGenderPloidy(name)[1] << "\t";
+            for (uint8_t p : cp.getSamplePloidy(name)) os << (int)p;
+            os << "\n";
+        }
+        return copy_out(os.str(), buf, cap);
+    } catch (const std::exception &e) {
+        stage_error(e, err, err_len);
+        return 0;
     }
 }
 

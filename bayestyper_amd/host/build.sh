@@ -1,6 +1,11 @@
 #!/bin/bash
-# Build libbthost.so: the C++ host layer that mirrors the reference's class interface over the C ABI of libbtgpu.so.
+# Build libbthost.so (the C++ host layer that mirrors the reference's class interface over the C ABI of libbtgpu.so) and the
+# `bayesTyper` executable (cluster / genotype command lines) on top of it.
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
-g++ -std=c++17 -O2 -fPIC -shared -Wall -I"$here/../../include" "$here"/*.cpp -o "$here/../libbthost.so" -L"$here/.." -l:libbtgpu.so -Wl,-rpath,'$ORIGIN' -lpthread -lz
+srcs=()
+for f in "$here"/*.cpp; do [ "$(basename "$f")" = main.cpp ] || srcs+=("$f"); done
+g++ -std=c++17 -O2 -fPIC -shared -Wall -I"$here/../../include" "${srcs[@]}" -o "$here/../libbthost.so" -L"$here/.." -l:libbtgpu.so -Wl,-rpath,'$ORIGIN' -lpthread -lz
 echo "built $here/../libbthost.so"
+g++ -std=c++17 -O2 -Wall -I"$here/../../include" "$here/main.cpp" -o "$here/../bayesTyper" -L"$here/.." -l:libbthost.so -l:libbtgpu.so -Wl,-rpath,'$ORIGIN' -lpthread -lz
+echo "built $here/../bayesTyper"

@@ -1,0 +1,444 @@
+// `bayesTyper` — the two command lines of the reference (src/bayesTyper/main.cpp:80-655) over the MI355X path:
+//
+//   bayesTyper cluster   -v <candidates.vcf[.gz]> -s <samples.tsv> -g <genome.fa> [...]   (main.cpp:110-358)
+//   bayesTyper genotype  -v <unit>/variant_clusters.bin -c <cluster_data dir> -s <samples.tsv> -g <genome.fa> [...]   (main.cpp:360-652)
+//
+// Same options, defaults, input files (VCF, FASTA, samples file, KMC databases, sample Bloom filters), stage sequence, progress lines
+// and outputs (<o>_unit_<i>/variant_clusters.bin, <o>_cluster_data/{intercluster_regions.txt.gz, parameter_kmers.fa.gz,
+// multigroup_kmers.bloom[Meta|Data]}, <o>.vcf[.gz], <o>_genomic_parameters.txt, <o>_noise_parameters.txt).  The k-mer passes and the
+// Gibbs sampler run on the GPU through libbtgpu.so (KmerCounter.hpp, InferenceEngine.hpp); there is no CPU fallback.
+// variant_clusters.bin is this build's own format (InferenceUnit.hpp), not the reference's Boost archive.
+// The k-mer size is a build constant in the reference (BT_KMER_SIZE, 55 in the released binaries); here BT_KMER_SIZE in the environment overrides 55.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "CountDistribution.hpp"
+#include "GenotypeWriter.hpp"
+#include "Genotypes.hpp"
+#include "InferenceEngine.hpp"
+#include "InferenceUnit.hpp"
+#include "KmerCounter.hpp"
+#include "KmerHashOrder.hpp"
+#include "Options.hpp"
+#include "Sample.hpp"
+
+using namespace bthost;
+
+namespace {
+
+const char *const BT_VERSION = "v1.5 (MI355X build)";
+const unsigned max_parameter_kmers = 1000000;   // main.cpp:73
+const char *const intercluster_regions_file_prefix = "intercluster_regions";
+const char *const multigroup_kmers_file_prefix = "multigroup_kmers";
+const char *const parameter_kmers_file_prefix = "parameter_kmers";
+
+std::string stamp() { return "[" + getLocalTime() + "] "; }
+
+void check(int rc, const char *what) {
+    if (rc != BT_OK) throw std::runtime_error(std::string(what) + ": " + bt_last_error());
+}
+
+struct Context {
+    bt_ctx *h = nullptr;
+    Context() {
+        const char *dev = getenv("BT_DEVICE");
+        check(bt_ctx_create(dev ? atoi(dev) : 0, &h), "bt_ctx_create");
+    }
+    ~Context() { bt_ctx_destroy(h); }
+};
+
+void makeDirectory(const std::string &dir, const char *what) {
+    if (mkdir(dir.c_str(), 0777) != 0) throw std::runtime_error(std::string(what) + " directory " + dir + "/ already exist");
+}
+
+Chromosomes readGenome(const OptionsContainer &options) {
+    std::cout << "\n" << stamp() << "Parsing reference genome ..." << std::endl;
+    Chromosomes chromosomes;
+    chromosomes.addFasta(options.getString("genome-file"), false);
+    std::cout << stamp() << "Parsed " << chromosomes.size() << " reference genome chromosomes(s) (" << chromosomes.getTotalLength() << " nucleotides)" << std::endl;
+    std::cout << "\n" << stamp() << "Parsing decoy sequence(s) ..." << std::endl;
+    const size_t before = chromosomes.size();
+    if (!options.getString("decoy-file").empty()) chromosomes.addFasta(options.getString("decoy-file"), true);
+    std::cout << stamp() << "Parsed " << chromosomes.size() - before << " decoy sequence(s) (" << chromosomes.getDecoyLength() << " nucleotides)" << std::endl;
+    chromosomes.convertToUpper();
+    return chromosomes;
+}
+
+std::string kmerToString(uint64_t lo, uint64_t hi, unsigned k) {   // Nucleotide::bitToNt (Nucleotide.hpp:101-129)
+    std::string s(k, 'A');
+    for (unsigned i = 0; i < k; i++) s[i] = "ACGT"[((i < 32 ? lo >> (2 * i) : hi >> (2 * (i - 32))) & 3u)];
+    return s;
+}
+bool stringToKmer(const std::string &s, uint64_t *lo, uint64_t *hi) {   // Nucleotide::ntToBit
+    *lo = *hi = 0;
+    for (size_t i = 0; i < s.size(); i++) {
+        uint64_t c;
+        switch (s[i]) {
+            case 'A': c = 0; break;
+            case 'C': c = 1; break;
+            case 'G': c = 2; break;
+            case 'T': c = 3; break;
+            default: return false;
+        }
+        if (i < 32) *lo |= c << (2 * i);
+        else *hi |= c << (2 * (i - 32));
+    }
+    return true;
+}
+
+// every stored k-mer of a table with its flag byte
+void exportTable(bt_table *t, std::vector<uint64_t> *kmers, std::vector<uint8_t> *flags) {
+    uint64_t n = 0;
+    check(bt_table_status(t, &n, nullptr, nullptr), "bt_table_status");
+    kmers->assign(std::max<uint64_t>(2 * n, 2), 0);
+    std::vector<uint8_t> meta(std::max<uint64_t>(4 * n, 4));
+    uint64_t written = 0;
+    check(bt_table_export(t, kmers->data(), nullptr, meta.data(), std::max<uint64_t>(n, 1), &written), "bt_table_export");
+    kmers->resize(2 * written);
+    flags->resize(written);
+    for (uint64_t i = 0; i < written; i++) (*flags)[i] = meta[4 * i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+int runCluster(int argc, char *const argv[], unsigned kmer_size) {
+    OptionsContainer options("cluster", BT_VERSION, getLocalTime(), kmer_size);
+    if (options.parse(argc, argv, clusterOptionSpecs(), "## BayesTyper cluster options ##")) return 1;
+    const uint32_t min_unit_variants = (uint32_t)options.getUInt("min-number-of-unit-variants");
+    const float cnv_threshold = options.getFloat("copy-number-variant-threshold");
+    const uint16_t max_sample_haplotypes = (uint16_t)options.getUInt("max-number-of-sample-haplotypes");
+    if (min_unit_variants == 0) throw std::runtime_error("--min-number-of-unit-variants must be positive");
+    if (cnv_threshold < 0 || cnv_threshold > 1) throw std::runtime_error("--copy-number-variant-threshold must be between zero and one");
+    if (max_sample_haplotypes == 0 || (uint32_t)max_sample_haplotypes * 30 >= 65535) throw std::runtime_error("--max-number-of-sample-haplotypes is out of range");
+    const unsigned seed = (unsigned)options.getUInt("random-seed");
+    std::cout << stamp() << "Seeding pseudo-random number generator with " << seed << " ..." << std::endl;
+    std::cout << stamp() << "Setting the kmer size to " << kmer_size << " ..." << std::endl;
+    const std::vector<Sample> samples = readSamples(options.getString("samples-file"));
+    const std::string output_prefix = options.getString("output-prefix");
+    std::cout << "\n" << stamp() << "Parsed information for " << samples.size() << " sample(s)" << std::endl;
+    const Chromosomes chromosomes = readGenome(options);
+
+    Context ctx;
+    KmerCounter kmer_counter(ctx.h, samples, kmer_size, seed);
+    VariantFileParser variant_file_parser(VariantFileParser::readVariantFile(options.getString("variant-file")), kmer_size, (uint32_t)options.getUInt("max-allele-length"), cnv_threshold);
+    const uint32_t num_variants = variant_file_parser.getNumberOfVariants();
+    const uint32_t num_units = std::max<uint32_t>(1, (uint32_t)std::floor(num_variants / (float)min_unit_variants));
+    std::cout << "\n" << stamp() << "Setting the number of inference units to " << num_units << " across " << num_variants << " variants ..." << std::endl;
+
+    const uint64_t expected_num_path_kmers = (uint64_t)std::ceil((chromosomes.getTotalLength() - chromosomes.getDecoyLength()) * (1 + (0.05 * 2 * samples.size())));
+    uint64_t num_path_kmers = 0;
+    BloomHandle path_kmer_bloom;   // ThreadedKmerBloom(expected_num_path_kmers, 0.0001)
+    check(bt_bloom_create(ctx.h, std::max<uint64_t>(expected_num_path_kmers, 1), 0.0001f, kmer_size, 1, &path_kmer_bloom.h), "bt_bloom_create");
+    TableHandle multigroup_kmer_hash;   // KmerHash<bool>(expected * 0.01)
+    check(bt_table_create(ctx.h, (uint64_t)std::ceil(expected_num_path_kmers * 0.01) + 1024, 1, kmer_size, &multigroup_kmer_hash.h), "bt_table_create");
+
+    bool variant_file_parsed = false;
+    for (uint32_t unit_idx = 1; unit_idx < num_units + 1; unit_idx++) {
+        std::cout << "\n" << std::endl;
+        if (variant_file_parsed) throw std::runtime_error("the variant file ended before the last inference unit");
+        InferenceUnit unit;
+        unit.index = unit_idx;
+        unit.cluster_options_header = options.getHeader();
+        const uint32_t parsed_before = variant_file_parser.numParsedVariants(), clusters_before = variant_file_parser.numVariantClusters();
+        variant_file_parsed = variant_file_parser.constructVariantClusterGroups(&unit.variant_cluster_groups, (uint32_t)std::ceil(num_variants / (float)num_units), chromosomes);
+        unit.num_variants = variant_file_parser.numParsedVariants() - parsed_before;
+        unit.num_variant_clusters = variant_file_parser.numVariantClusters() - clusters_before;
+        std::sort(unit.variant_cluster_groups.begin(), unit.variant_cluster_groups.end(), ClusterGroupCompare);
+        std::cout << stamp() << "Parsed unit " << unit_idx << ": " << unit.num_variants << " variants in " << unit.num_variant_clusters << " clusters and "
+                  << unit.variant_cluster_groups.size() << " groups\n" << std::endl;
+        {
+            const UnitGraphs graphs(unit, chromosomes, kmer_size);
+            kmer_counter.findVariantClusterPaths(&unit, graphs, max_sample_haplotypes);
+            kmer_counter.countPathMultigroupKmers(multigroup_kmer_hash.h, path_kmer_bloom.h, &unit, graphs);
+        }
+        num_path_kmers += unit.num_path_kmers;
+        const std::string unit_dir = output_prefix + "_unit_" + std::to_string(unit.index);
+        makeDirectory(unit_dir, "Unit");
+        unit.write(unit_dir + "/variant_clusters.bin");
+        std::cout << "\n" << stamp() << "Wrote unit " << unit.index << " variant clusters to " << unit_dir << "/variant_clusters.bin" << std::endl;
+    }
+    if (!variant_file_parsed) throw std::runtime_error("variants remain after the last inference unit");
+    if (expected_num_path_kmers < num_path_kmers)
+        std::cout << "\nWARNING: Multigroup kmer estimate might be inflated due to the number of kmers being higher than expected.\n" << std::endl;
+
+    const std::string cluster_data_dir = output_prefix + "_cluster_data";
+    makeDirectory(cluster_data_dir, "Cluster data");
+
+    std::cout << "\n\n" << stamp() << "Writing inter-cluster regions ..." << std::endl;
+    const std::string intercluster_regions_dir_prefix = cluster_data_dir + "/" + intercluster_regions_file_prefix;
+    variant_file_parser.sortInterclusterRegions();
+    writeGzFile(intercluster_regions_dir_prefix + ".txt.gz", variant_file_parser.interclusterRegionsText());
+    std::cout << stamp() << "Wrote " << variant_file_parser.getInterclusterRegions().size() << " regions to " << intercluster_regions_dir_prefix << ".txt.gz\n" << std::endl;
+
+    // parameter k-mers: non-path k-mers of the inter-cluster regions, a Bernoulli(fraction) sample of them (main.cpp:319-341)
+    const uint32_t max_intercluster_kmers = 3 * max_parameter_kmers;
+    const uint64_t num_region_kmers = variant_file_parser.getNumberOfInterclusterRegionKmers();
+    const float parameter_kmer_fraction = std::min(1.0f, (float)max_intercluster_kmers / (float)num_region_kmers);
+    uint64_t num_parameter_kmers = 0;
+    {
+        TableHandle parameter_kmer_hash;
+        check(bt_table_create(ctx.h, (uint64_t)max_intercluster_kmers + chromosomes.getDecoyLength(), 1, kmer_size, &parameter_kmer_hash.h), "bt_table_create");
+        kmer_counter.countInterclusterParameterKmers(parameter_kmer_hash.h, variant_file_parser.getInterclusterRegions(), chromosomes, path_kmer_bloom.h, parameter_kmer_fraction);
+        std::vector<uint64_t> kmers;
+        std::vector<uint8_t> flags;
+        exportTable(parameter_kmer_hash.h, &kmers, &flags);
+        // KmerHash::shuffle(seed) then writeKmersToFasta: the first <= 10^6 k-mers with value true (accepted in a non-decoy region and in no decoy)
+        const std::vector<uint32_t> order = hybridHashShuffledOrder(kmers.data(), flags.size(), kmer_size, seed);
+        std::string fasta = ">k" + std::to_string(kmer_size) + "\n";
+        for (uint32_t i : order) {
+            if (!(flags[i] & BT_KC_PARAMETER) || (flags[i] & BT_KC_DECOY_OCC)) continue;
+            fasta += kmerToString(kmers[2 * i], kmers[2 * i + 1], kmer_size);
+            fasta += "\n";
+            if (++num_parameter_kmers == max_parameter_kmers) break;
+        }
+        writeGzFile(cluster_data_dir + "/" + parameter_kmers_file_prefix + ".fa.gz", fasta);
+    }
+    std::cout << stamp() << "Wrote " << num_parameter_kmers << " kmers to " << cluster_data_dir << "/" << parameter_kmers_file_prefix << ".fa.gz" << std::endl;
+
+    std::cout << "\n" << stamp() << "Creating multigroup kmers bloom filter ..." << std::endl;
+    uint64_t num_multigroup_kmers = 0;
+    {
+        std::vector<uint64_t> kmers;
+        std::vector<uint8_t> flags;
+        exportTable(multigroup_kmer_hash.h, &kmers, &flags);
+        num_multigroup_kmers = flags.size();
+        BloomHandle multigroup_kmer_bloom;   // KmerBloom(num_multigroup_kmers, 0.0001)
+        check(bt_bloom_create(ctx.h, std::max<uint64_t>(num_multigroup_kmers, 1), 0.0001f, kmer_size, 0, &multigroup_kmer_bloom.h), "bt_bloom_create");
+        if (num_multigroup_kmers) {
+            void *d = nullptr;
+            check(bt_malloc(ctx.h, kmers.size() * 8, &d), "bt_malloc");
+            int rc = bt_memcpy_h2d(ctx.h, d, kmers.data(), kmers.size() * 8);
+            if (rc == BT_OK) rc = bt_bloom_insert_batch(multigroup_kmer_bloom.h, (const uint64_t *)d, num_multigroup_kmers);
+            if (rc == BT_OK) rc = bt_sync(ctx.h);
+            bt_free(ctx.h, d);
+            check(rc, "multigroup k-mer Bloom filter");
+        }
+        check(bt_bloom_save(multigroup_kmer_bloom.h, (cluster_data_dir + "/" + multigroup_kmers_file_prefix).c_str()), "bt_bloom_save");
+    }
+    std::cout << stamp() << "Wrote " << num_multigroup_kmers << " kmers to " << cluster_data_dir << "/" << multigroup_kmers_file_prefix << ".bloom[Meta|Data]" << std::endl;
+    std::cout << "\n\n" << stamp() << "BayesTyper cluster completed succesfully!\n" << std::endl;
+    return 0;
+}
+
+// CountDistribution::setGenomicCountDistributions (CountDistribution.cpp:66-141) from the table's parameter k-mer statistics
+void setGenomicCountDistributions(CountDistribution *cd, bt_table *table, const std::vector<Sample> &samples, const std::string &output_prefix) {
+    const unsigned max_nb_kmer_multiplicity = 32, min_nb_kmer_count = 10000;   // CountDistribution.cpp:42-43
+    const size_t S = samples.size();
+    std::vector<uint8_t> gender(S);
+    for (size_t s = 0; s < S; s++) gender[s] = samples[s].gender;
+    std::vector<uint64_t> class_counts(7), n(S * 256), nonzero(S * 256), sum(S * 256), sumsq(S * 256);
+    check(bt_table_kmer_stats(table, gender.data(), class_counts.data(), n.data(), nonzero.data(), sum.data(), sumsq.data()), "bt_table_kmer_stats");
+    // ObservedKmerCountsHash::calculateKmerStats' report (KmerHash.cpp:326-336)
+    std::cout << stamp() << "Out of " << class_counts[0] << " kmers:\n" << std::endl;
+    std::cout << "\t- " << class_counts[1] << " have a match to a single variant cluster" << std::endl;
+    std::cout << "\t- " << class_counts[2] << " have a match to single variant cluster group and multiple variant clusters" << std::endl;
+    std::cout << "\n\t- " << class_counts[3] << " have match to at least one variant cluster and has match to a decoy sequence (not used for inference)" << std::endl;
+    std::cout << "\t- " << class_counts[4] << " have match to at least one variant cluster and has a maximum haploid multiplicity higher than 127 (not used for inference)" << std::endl;
+    std::cout << "\t- " << class_counts[5] << " have matches to multiple variant cluster groups within or across inference units (not used for inference)" << std::endl;
+    std::cout << "\n\t- " << class_counts[6] << " have no match to a variant cluster (includes parameter kmers)" << std::endl;
+
+    std::cout << "\n\n" << stamp() << "Estimating genomic haploid kmer count distribution(s) from parameter kmers ...\n" << std::endl;
+    std::ofstream out(output_prefix + ".txt");
+    if (!out.is_open()) throw std::runtime_error("Unable to write file " + output_prefix + ".txt");
+    out << "Sample\tMean\tVariance" << std::endl;
+    for (size_t s = 0; s < S; s++) {
+        uint64_t max_count = 0;
+        unsigned max_multiplicity = 0;
+        for (unsigned m = 1; m <= max_nb_kmer_multiplicity; m++)
+            if (n[s * 256 + m] > max_count) {
+                max_count = n[s * 256 + m];
+                max_multiplicity = m;
+            }
+        if (max_count < min_nb_kmer_count) {
+            std::cout << "\nWARNING: Low number of kmers used for negative binomial parameters estimation for sample " << samples[s].name << " (" << max_count << " < " << min_nb_kmer_count << ")" << std::endl;
+            std::cout << "WARNING: The mean and variance estimates might be biased due to the genome used being too small, too variant dense and/or too repetitive\n" << std::endl;
+        }
+        if (max_multiplicity == 0 || max_count < 2) throw std::runtime_error("no parameter kmers to estimate the genomic kmer count distribution of sample " + samples[s].name + " from");
+        // KmerStats' running mean / M2 (KmerStats.cpp:51-63) from the exact integer moments: mean = sum / n, M2 = sumsq - sum^2 / n
+        const long double cnt = (long double)max_count, sm = (long double)sum[s * 256 + max_multiplicity], sq = (long double)sumsq[s * 256 + max_multiplicity];
+        const double mean = (double)(sm / cnt), var = (double)((sq - sm * sm / cnt) / (cnt - 1));
+        cd->setGenomicFromMoments((unsigned short)s, mean, var, max_multiplicity);
+        const NegativeBinomialDistribution &nb = cd->getGenomicCountDistributions()[s];
+        std::cout << stamp() << "Estimated negative binomial (mean = " << nb.mean() << ", var = " << nb.var() << ") for sample " << samples[s].name << " using " << max_count
+                  << " parameter kmers (multiplicity = " << max_multiplicity << ")" << std::endl;
+        out << samples[s].name << "\t" << nb.mean() << "\t" << nb.var() << std::endl;
+    }
+    std::cout << "\n" << stamp() << "Wrote genomic parameters to " << output_prefix << ".txt" << std::endl;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
+    OptionsContainer options("genotype", BT_VERSION, getLocalTime(), kmer_size);
+    if (options.parse(argc, argv, genotypeOptionSpecs(), "## BayesTyper genotype options ##")) return 1;
+    GibbsOptions gibbs;
+    gibbs.seed = (unsigned)options.getUInt("random-seed");
+    gibbs.burn_in = (uint32_t)options.getUInt("gibbs-burn-in");
+    gibbs.samples = (uint32_t)options.getUInt("gibbs-samples");
+    gibbs.chains = (uint32_t)options.getUInt("number-of-gibbs-chains");
+    gibbs.kmer_subsampling_rate = options.getFloat("kmer-subsampling-rate");
+    gibbs.max_haplotype_variant_kmers = (uint32_t)options.getUInt("max-haplotype-variant-kmers");
+    if (gibbs.burn_in == 0 || gibbs.samples == 0 || gibbs.chains == 0) throw std::runtime_error("--gibbs-burn-in, --gibbs-samples and --number-of-gibbs-chains must be positive");
+    if (!(gibbs.kmer_subsampling_rate > 0) || gibbs.kmer_subsampling_rate > 1) throw std::runtime_error("--kmer-subsampling-rate must be in (0, 1]");
+    const std::pair<float, float> noise_rate_prior = options.getFloatPair("noise-rate-prior");
+    if (!(noise_rate_prior.first > 0) || !(noise_rate_prior.second > 0)) throw std::runtime_error("--noise-rate-prior values must be positive");
+    std::cout << stamp() << "Seeding pseudo-random number generator with " << gibbs.seed << " ..." << std::endl;
+    std::cout << stamp() << "Setting the kmer size to " << kmer_size << " ..." << std::endl;
+    const std::vector<Sample> samples = readSamples(options.getString("samples-file"));
+    const size_t S = samples.size();
+    const std::string output_prefix = options.getString("output-prefix");
+    std::cout << "\n" << stamp() << "Parsed information for " << S << " sample(s)" << std::endl;
+    const Chromosomes chromosomes = readGenome(options);
+
+    std::cout << "\n\n" << stamp() << "Parsing variant clusters ..." << std::endl;
+    InferenceUnit unit = InferenceUnit::read(options.getString("variant-clusters-file"));
+    std::cout << stamp() << "Parsed " << unit.num_variant_clusters << " variant clusters (" << unit.num_variants << " variants)" << std::endl;
+    const std::string cluster_data_dir = options.getString("cluster-data-dir");
+    const std::string intercluster_regions_dir_prefix = cluster_data_dir + "/" + intercluster_regions_file_prefix;
+    const std::string parameter_kmers_dir_prefix = cluster_data_dir + "/" + parameter_kmers_file_prefix;
+    const std::string multigroup_kmers_dir_prefix = cluster_data_dir + "/" + multigroup_kmers_file_prefix;
+
+    Context ctx;
+    KmerCounter kmer_counter(ctx.h, samples, kmer_size, gibbs.seed);
+    std::unique_ptr<BloomHandle> path_kmer_bloom(new BloomHandle());   // ThreadedKmerBloom(num_path_kmers + max_parameter_kmers, 0.0001)
+    check(bt_bloom_create(ctx.h, unit.num_path_kmers + max_parameter_kmers, 0.0001f, kmer_size, 1, &path_kmer_bloom->h), "bt_bloom_create");
+    TableHandle kmer_hash;   // ObservedKmerCountsHash<N>(num_path_kmers + max_parameter_kmers)
+    check(bt_table_create(ctx.h, unit.num_path_kmers + max_parameter_kmers, (uint32_t)S, kmer_size, &kmer_hash.h), "bt_table_create");
+
+    std::cout << "\n" << stamp() << "Parsing parameter kmers ..." << std::endl;
+    uint64_t num_parameter_kmers = 0;
+    {
+        std::istringstream in(readGzFile(parameter_kmers_dir_prefix + ".fa.gz"));
+        std::string line;
+        std::getline(in, line);
+        if (line != ">k" + std::to_string(kmer_size)) throw std::runtime_error(parameter_kmers_dir_prefix + ".fa.gz was written for another kmer size (" + line + ")");
+        std::vector<uint64_t> kmers;
+        while (std::getline(in, line)) {
+            uint64_t lo, hi;
+            if (line.size() != kmer_size || !stringToKmer(line, &lo, &hi)) throw std::runtime_error("malformed kmer in " + parameter_kmers_dir_prefix + ".fa.gz: " + line);
+            kmers.push_back(lo);
+            kmers.push_back(hi);
+        }
+        num_parameter_kmers = kmers.size() / 2;
+        if (num_parameter_kmers > max_parameter_kmers) throw std::runtime_error("more than " + std::to_string(max_parameter_kmers) + " parameter kmers");
+        if (num_parameter_kmers) {   // path_kmer_bloom->addKmer + kmer_hash->addKmer + isParameter(true) (main.cpp:560-577)
+            void *d = nullptr;
+            check(bt_malloc(ctx.h, kmers.size() * 8, &d), "bt_malloc");
+            int rc = bt_memcpy_h2d(ctx.h, d, kmers.data(), kmers.size() * 8);
+            if (rc == BT_OK) rc = bt_bloom_insert_batch(path_kmer_bloom->h, (const uint64_t *)d, num_parameter_kmers);
+            if (rc == BT_OK) rc = bt_table_insert_batch(kmer_hash.h, (const uint64_t *)d, num_parameter_kmers, 1);
+            if (rc == BT_OK) rc = bt_sync(ctx.h);
+            bt_free(ctx.h, d);
+            check(rc, "parameter kmers");
+        }
+    }
+    std::cout << stamp() << "Parsed " << num_parameter_kmers << " kmers" << std::endl;
+    std::cout << "\n" << std::endl;
+
+    const ChromosomePloidy chrom_ploidy(options.getString("chromosome-ploidy-file"), chromosomes, samples);
+    const UnitGraphs graphs(unit, chromosomes, kmer_size);
+    kmer_counter.countPathKmers(path_kmer_bloom->h, unit, graphs);
+    kmer_counter.countInterclusterKmers(kmer_hash.h, path_kmer_bloom->h, intercluster_regions_dir_prefix, chromosomes, chrom_ploidy);
+    std::cout << std::endl;
+    kmer_counter.parseSampleKmers(kmer_hash.h, path_kmer_bloom->h);
+    path_kmer_bloom.reset();
+    std::cout << std::endl;
+    const GibbsBatchData batch = kmer_counter.classifyPathKmers(kmer_hash.h, unit, graphs, multigroup_kmers_dir_prefix, chrom_ploidy);
+    std::cout << "\n" << std::endl;
+
+    CountDistribution count_distribution((unsigned short)S, noise_rate_prior, gibbs.seed);
+    setGenomicCountDistributions(&count_distribution, kmer_hash.h, samples, output_prefix + "_genomic_parameters");
+    bt_table_destroy(kmer_hash.h);   // the bundles hold everything the sampler needs
+    kmer_hash.h = nullptr;
+
+    const bool noise_genotyping = options.getBool("noise-genotyping");
+    std::vector<uint8_t> gender(S);
+    std::vector<std::string> names(S);
+    for (size_t s = 0; s < S; s++) {
+        gender[s] = samples[s].gender;
+        names[s] = samples[s].name;
+    }
+    InferenceEngine inference_engine(ctx.h, gender, names, gibbs);
+    if (!noise_genotyping) {
+        std::cout << "\n" << std::endl;
+        inference_engine.estimateNoise(&count_distribution, batch, output_prefix + "_noise_parameters");
+    }
+    std::cout << "\n" << std::endl;
+
+    Filters filters;   // Filters.cpp:33-54
+    filters.min_genotype_posterior = options.getFloat("min-genotype-posterior");
+    filters.min_number_of_kmers = options.getFloat("min-number-of-kmers");
+    filters.min_fraction_observed_kmers.assign(S, 0.0f);
+    if (!options.getBool("disable-observed-kmers"))
+        for (size_t s = 0; s < S; s++) filters.min_fraction_observed_kmers[s] = Filters::minFractionObservedKmers(count_distribution.getGenomicCountDistributions()[s].mean());
+    GenotypeWriter genotype_writer(names, chromosomes);
+
+    // collectGenotypes of every cluster of a launch (VariantClusterGenotyper::getGenotypes) -> GenotypeWriter
+    const InferenceEngine::Collector collect = [&](const GibbsBatchData &b, const BatchResults &r) {
+        std::vector<uint64_t> hapvar_off(b.numClusters() + 1, 0), var_base(b.numClusters() + 1, 0);
+        for (uint32_t c = 0; c < b.numClusters(); c++) {
+            hapvar_off[c + 1] = hapvar_off[c] + (uint64_t)b.num_haplotypes[c] * b.num_variants[c];
+            var_base[c + 1] = var_base[c] + b.num_variants[c];
+        }
+        for (uint32_t g = 0; g < b.numGroups(); g++) {
+            const ClusterGroup &grp = unit.variant_cluster_groups[b.group_index[g]];
+            for (uint32_t c = b.group_cluster_off[g]; c < b.group_cluster_off[g + 1]; c++) {
+                const VariantCluster &cluster = grp.clusters[c - b.group_cluster_off[g]];
+                const std::vector<VariantInfo> info = variantClusterInfo(cluster);
+                ClusterResults cr;
+                cr.S = (uint32_t)S;
+                cr.H = b.num_haplotypes[c];
+                cr.V = b.num_variants[c];
+                cr.hap_allele = b.hap_allele.data() + hapvar_off[c];
+                cr.var_num_alleles = b.var_num_alleles.data() + var_base[c];
+                cr.var_has_dependency = b.var_has_dependency.data() + var_base[c];
+                cr.num_diplotypes = r.dip_off[c + 1] - r.dip_off[c];
+                cr.h1 = r.h1.data() + r.dip_off[c];
+                cr.h2 = r.h2.data() + r.dip_off[c];
+                cr.freq = r.freq.data() + r.dip_off[c] * S;
+                cr.stats = r.stats.data() + r.cell_off[c] * 12;
+                cr.ploidy = b.group_ploidy.data() + (uint64_t)g * S;
+                const std::vector<VariantGenotypes> res = getGenotypes(cr, filters);
+                const ClusterAnnotation where{cluster.chrom_name, (uint32_t)info.size(), variantClusterRegion(cluster.chrom_name, info), (uint32_t)grp.clusters.size(), grp.region(), cr.H};
+                for (size_t v = 0; v < info.size(); v++) genotype_writer.addGenotypes(where, info[v], res[v], formatSampleColumns(cr, (uint32_t)v, res[v]));
+            }
+        }
+    };
+    if (!noise_genotyping) inference_engine.estimateGenotypes(batch, count_distribution, collect);
+    else inference_engine.estimateNoiseAndGenotypes(batch, &count_distribution, collect, output_prefix + "_noise_parameters");
+
+    const uint32_t num_genotyped_variants = genotype_writer.finalise(output_prefix, options.getBool("gzip-output"), options.getString("genome-file"), unit.cluster_options_header, options.getHeader());
+    std::cout << "\n" << stamp() << "Out of " << unit.num_variants << " variants:\n" << std::endl;
+    std::cout << "\t- " << num_genotyped_variants << " were genotyped" << std::endl;
+    std::cout << "\t- " << unit.num_variants - num_genotyped_variants << " were skipped (unsupported)" << std::endl;
+    std::cout << "\n\n" << stamp() << "BayesTyper genotype completed succesfully!\n" << std::endl;
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char *const argv[]) {
+    const unsigned kmer_size = getenv("BT_KMER_SIZE") ? (unsigned)atoi(getenv("BT_KMER_SIZE")) : 55u;
+    std::cout << "\n[" << getLocalTime() << "] You are using BayesTyper (" << BT_VERSION << ")\n" << std::endl;
+    const std::string command_info = "Usage: bayesTyper <command> [options]\n\nCommands:\n\n\tcluster\t\tcreate variant clusters\n\tgenotype\tgenotype variant clusters\n";
+    if (argc == 1) {
+        std::cout << command_info << std::endl;
+        return 0;
+    }
+    try {
+        if (kmer_size < 1 || kmer_size > 64) throw std::runtime_error("BT_KMER_SIZE must be between 1 and 64");
+        if (std::strcmp(argv[1], "cluster") == 0) return runCluster(argc, argv, kmer_size);
+        if (std::strcmp(argv[1], "genotype") == 0) return runGenotype(argc, argv, kmer_size);
+        std::cout << command_info << std::endl;
+        return 0;
+    } catch (const std::exception &e) {   // the reference prints "\nERROR: ...\n" and exits with 1
+        std::cerr << "\nERROR: " << e.what() << "\n" << std::endl;
+        return 1;
+    }
+}

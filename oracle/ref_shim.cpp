@@ -22,6 +22,7 @@
 #include "DiscreteSampler.hpp"
 #include "SparsityEstimator.hpp"
 #include "CountAllocation.hpp"
+#include "HybridHash.hpp"
 
 static const unsigned K = BT_KMER_SIZE;
 
@@ -175,4 +176,34 @@ unsigned ref_sparsity_cover(const uint8_t *M, unsigned rows, unsigned cols, cons
     return (unsigned)cover.size();
 }
 
+
+// ---- HybridHash / PartialSortedLinearMap (header-only: include/bayesTyper/HybridHash.tpp, LinearMap.tpp) ----
+// root bucket of a k-mer: std::hash<std::bitset<2k>> % root_hash_size (HybridHash.tpp:78-82)
+uint64_t ref_hybrid_hash_root(const char *kmer, uint64_t root_hash_size) {
+    auto b = Nucleotide::ntToBit<BT_KMER_SIZE>(std::string(kmer, K));
+    return std::hash<std::bitset<BT_KMER_SIZE * 2>>()(b.first) % root_hash_size;
+}
+// the reference's own container: n k-mers inserted as KmerHash::addKmer does (add_sorted = true, KmerHash.cpp:88-95), then
+// shuffle(seed) (HybridHash.tpp:120-129) when do_shuffle, then iterated begin() .. end(): order_out[j] = index of the j-th k-mer
+uint64_t ref_hybrid_hash_order(const char *kmers, uint64_t n, uint64_t root_hash_size, unsigned seed, int do_shuffle, uint32_t *order_out) {
+    HybridHash<uint, BT_KMER_SIZE * 2> hash((uint)root_hash_size, n);
+    for (uint64_t i = 0; i < n; i++) {
+        auto b = Nucleotide::ntToBit<BT_KMER_SIZE>(std::string(kmers + i * K, K));
+        hash.insert(b.first, (uint)i, true);
+    }
+    if (do_shuffle) hash.shuffle(seed);
+    uint64_t j = 0;
+    for (auto it = hash.begin(); it != hash.end(); it++) order_out[j++] = (*it).second;
+    return j;
+}
+// CountAllocation (src/bayesTyper/CountAllocation.cpp:34-57): addCount per (sample, count) then mergeInCountAllocations of a second one
+void ref_count_allocation(unsigned short num_samples, const unsigned short *s1, const unsigned char *c1, uint64_t n1, const unsigned short *s2, const unsigned char *c2, uint64_t n2,
+                          unsigned long *out /* [S*256] */) {
+    CountAllocation a(num_samples), b(num_samples);
+    for (uint64_t i = 0; i < n1; i++) a.addCount(s1[i], c1[i]);
+    for (uint64_t i = 0; i < n2; i++) b.addCount(s2[i], c2[i]);
+    a.mergeInCountAllocations(b);
+    for (unsigned short s = 0; s < num_samples; s++)
+        for (unsigned c = 0; c < 256; c++) out[(size_t)s * 256 + c] = a.getCounts().at(s).at(c);
+}
 }  // extern "C"

@@ -1,0 +1,224 @@
+"""CPU tests of the pieces around the two command lines (bayestyper_amd/host: Options, Sample, ChromosomePloidy, InferenceUnit,
+KmerHashOrder, the `bayesTyper` executable's argument handling) — no GPU needed: the executable is only run up to the point where it
+would create a GPU context.  HybridHash's iteration order and CountAllocation are pinned against the reference's own code
+(oracle/_ref/libbtref.so)."""
+import ctypes as C
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import _oracle  # noqa: E402
+import test_cluster_stage_cpu as T  # noqa: E402
+
+K = 55
+EXE = os.path.join(ROOT, "bayestyper_amd", "bayesTyper")
+KMER = "ACGTACGTTGCAAGCTTAGCCATGGATCCGATTACAGGCTTAACGGTCATGCAAT"
+
+
+def _dll():
+    from bayestyper_amd.host import dll
+
+    dll.bth_bitset_hash.restype = C.c_uint64
+    dll.bth_bitset_hash.argtypes = [C.c_uint64, C.c_uint64, C.c_uint]
+    dll.bth_hybrid_hash_order.argtypes = [C.c_void_p, C.c_uint64, C.c_uint, C.c_uint, C.c_uint64, C.c_void_p]
+    dll.bth_count_allocation.argtypes = [C.c_ushort, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    dll.bth_unit_roundtrip.restype = C.c_ulonglong
+    dll.bth_unit_roundtrip.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_ulonglong, C.c_char_p, C.c_uint]
+    dll.bth_chromosome_ploidy.restype = C.c_ulonglong
+    dll.bth_chromosome_ploidy.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_ulonglong, C.c_char_p, C.c_uint]
+    return dll
+
+
+def _pack(oracle, ascii_u8):
+    return np.ascontiguousarray(oracle.pack(ascii_u8, K), np.uint64)
+
+
+def test_bitset_hash_known_answer_and_reference(oracle, ref):
+    """std::hash<std::bitset<110>> % 4^12 of the SURVEY A.2 k-mer is 5318332 (captured from the compiled reference); our restatement of
+    libstdc++'s _Hash_bytes agrees with the reference's HybridHash::rootHashIndex on random k-mers"""
+    dll = _dll()
+    lo, hi = (int(x) for x in _pack(oracle, np.frombuffer(KMER.encode(), np.uint8)).reshape(-1))
+    assert dll.bth_bitset_hash(lo, hi, K) % 4 ** 12 == 5318332
+    ref.l.ref_hybrid_hash_root.restype = C.c_uint64
+    ref.l.ref_hybrid_hash_root.argtypes = [C.c_char_p, C.c_uint64]
+    assert ref.l.ref_hybrid_hash_root(KMER.encode(), 4 ** 12) == 5318332
+    rng = np.random.default_rng(3)
+    km = _oracle.random_kmers(rng, 500, K)
+    packed = _pack(oracle, km).reshape(-1, 2)
+    for i in range(500):
+        want = ref.l.ref_hybrid_hash_root(km[i * K:(i + 1) * K].tobytes(), 4 ** 12)
+        assert dll.bth_bitset_hash(int(packed[i, 0]), int(packed[i, 1]), K) % 4 ** 12 == want
+
+
+@pytest.mark.parametrize("root_size,n", [(4 ** 12, 20000), (64, 3000), (1, 300)])
+def test_parameter_kmer_order_vs_reference(oracle, ref, root_size, n):
+    """KmerHash::shuffle(seed) + iteration (what picks the <= 10^6 parameter k-mers, main.cpp:326-341): the reference's own HybridHash
+    (sorted leaves, one mt19937 over all leaves) against bthost::hybridHashShuffledOrder — with the real 4^12 roots (few collisions) and
+    with tiny root tables where every leaf holds many k-mers"""
+    dll = _dll()
+    rng = np.random.default_rng(n)
+    km = np.unique(_oracle.random_kmers(rng, n, K).reshape(-1, K), axis=0)
+    km = km[rng.permutation(len(km))]
+    n = len(km)
+    flat = np.ascontiguousarray(km).reshape(-1)
+    ref.l.ref_hybrid_hash_order.restype = C.c_uint64
+    ref.l.ref_hybrid_hash_order.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint, C.c_int, C.c_void_p]
+    packed = _pack(oracle, flat)
+    for seed, shuffle in ((42, 1), (7, 1), (0, 0)):
+        want = np.zeros(n, np.uint32)
+        assert ref.l.ref_hybrid_hash_order(flat.ctypes.data, n, root_size, seed, shuffle, want.ctypes.data) == n
+        if shuffle:
+            got = np.zeros(n, np.uint32)
+            dll.bth_hybrid_hash_order(packed.ctypes.data, n, K, seed, root_size, got.ctypes.data)
+            assert np.array_equal(got, want)
+        else:   # unshuffled iteration: root order, then BitsetLess = the 110-bit value ascending
+            roots = np.array([dll.bth_bitset_hash(int(a), int(b), K) % root_size for a, b in packed.reshape(-1, 2)], np.uint64)
+            p = packed.reshape(-1, 2)
+            assert np.array_equal(want, np.lexsort((p[:, 0], p[:, 1], roots)).astype(np.uint32))
+
+
+def test_count_allocation_vs_reference(ref):
+    dll = _dll()
+    rng = np.random.default_rng(1)
+    S = 5
+    s1, c1 = rng.integers(0, S, 4000).astype(np.uint16), rng.integers(0, 256, 4000).astype(np.uint8)
+    s2, c2 = rng.integers(0, S, 900).astype(np.uint16), rng.integers(0, 256, 900).astype(np.uint8)
+    got, want = np.zeros(S * 256, np.uint64), np.zeros(S * 256, np.uint64)
+    dll.bth_count_allocation(S, s1.ctypes.data, c1.ctypes.data, len(s1), s2.ctypes.data, c2.ctypes.data, len(s2), got.ctypes.data)
+    ref.l.ref_count_allocation.argtypes = [C.c_ushort, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    ref.l.ref_count_allocation(S, s1.ctypes.data, c1.ctypes.data, len(s1), s2.ctypes.data, c2.ctypes.data, len(s2), want.ctypes.data)
+    assert np.array_equal(got, want) and got.sum() == 4900
+    expect = np.zeros((S, 256), np.uint64)
+    np.add.at(expect, (np.concatenate([s1, s2]), np.concatenate([c1, c2])), 1)
+    assert np.array_equal(got.reshape(S, 256), expect)
+
+
+def _stage(genome, vcf):
+    from bayestyper_amd.host.cluster_stage import ClusterStage
+
+    st = ClusterStage(K)
+    for g in genome:
+        st.add_sequence(*g)
+    st.set_variants(vcf_text=vcf)
+    return st
+
+
+def test_unit_file_round_trip(tmp_path):
+    """variant_clusters.bin (own gzip'd layout): groups, clusters, variants, alleles, contained clusters, edges and best-path matrices
+    survive the round trip; a file of another format is refused with a message"""
+    from bayestyper_amd.host import dll as _  # noqa: F401
+
+    dll = _dll()
+    rng = np.random.default_rng(5)
+    genome = [[f"chr{i + 1}", "".join(rng.choice(list("ACGT"), n)), False] for i, n in enumerate([30000, 20000])]
+    st = _stage(genome, T.make_vcf(rng, genome, K, 40, False, extra_contig=False, sv_blocks=2))
+    assert st.next_unit(10 ** 9)
+    err = C.create_string_buffer(512)
+    fn = str(tmp_path / "variant_clusters.bin").encode()
+    n = dll.bth_unit_roundtrip(st.h, fn, 2, None, 0, err, len(err))
+    assert n > 0, err.value
+    buf = C.create_string_buffer(int(n) + 1)
+    dll.bth_unit_roundtrip(st.h, fn, 2, buf, n, err, len(err))
+    text = buf.raw[:n].decode()
+    assert text.startswith("7 ##BayesTyperOptions=test\n123 45 1099511627776\n") and text.endswith("IDENTICAL\n")
+    assert st.unit_text() in text
+    with gzip.open(fn.decode()) as f:
+        assert f.read(10) == b"BTAMDUNIT1"
+    bad = tmp_path / "other.bin"
+    with gzip.open(bad, "wb") as f:
+        f.write(b"22 serialization::archive 15 0 0")
+    r = subprocess.run([EXE, "genotype", "-v", str(bad), "-c", str(tmp_path), "-s", _samples(tmp_path), "-g", _genome(tmp_path, genome)], capture_output=True, text=True)
+    assert r.returncode == 1 and "not a variant clusters file of this build" in r.stderr
+    st.close()
+
+
+def _samples(tmp_path, rows=("sample1\tF\t/none/a", "sample2\tMale\t/none/b")):
+    p = tmp_path / "samples.tsv"
+    p.write_text("\n".join(rows) + "\n")
+    return str(p)
+
+
+def _genome(tmp_path, genome):
+    p = tmp_path / "genome.fa"
+    with open(p, "w") as f:
+        for name, seq, _ in genome:
+            f.write(f">{name} description\n")
+            for i in range(0, len(seq), 70):
+                f.write(seq[i:i + 70].lower() + "\n")
+    return str(p)
+
+
+def test_chromosome_ploidy(tmp_path):
+    dll = _dll()
+    genome = [["chr1", "ACGT" * 30, False], ["chrX", "ACGT" * 30, False], ["Y", "ACGT" * 30, False], ["decoy1", "ACGT" * 30, True]]
+    st = _stage(genome, "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+
+    def table(ploidy_file, genders):
+        err = C.create_string_buffer(1024)
+        n = dll.bth_chromosome_ploidy(st.h, ploidy_file.encode(), genders.encode(), None, 0, err, len(err))
+        if n == 0:
+            raise ValueError(err.value.decode())
+        buf = C.create_string_buffer(int(n) + 1)
+        dll.bth_chromosome_ploidy(st.h, ploidy_file.encode(), genders.encode(), buf, n, err, len(err))
+        return buf.raw[:n].decode()
+
+    # human defaults (ChromosomePloidy.cpp:42-91): X diploid / haploid, Y absent / haploid; decoys have no ploidy
+    assert table("", "FMF") == "chr1\t2\t2\t222\nchrX\t2\t1\t212\nY\t0\t1\t010\n"
+    f = tmp_path / "ploidy.txt"
+    f.write_text("chr1\t2\t2\nchrX\t2\t2\nY\t1\t0\n")
+    assert table(str(f), "MF") == "chr1\t2\t2\t22\nchrX\t2\t2\t22\nY\t1\t0\t01\n"
+    f.write_text("chr1\t2\t2\nchrX\t3\t2\nY\t1\t0\n")
+    with pytest.raises(ValueError, match="Female ploidy"):
+        table(str(f), "F")
+    f.write_text("chr1\t2\t2\nchrX\t2\t1\n")
+    with pytest.raises(ValueError, match='Chromosome "Y" in reference genome does not appear'):
+        table(str(f), "F")
+    f.write_text("chr1\t2\t2\nchr1\t2\t1\n")
+    with pytest.raises(ValueError, match="appear multiple times"):
+        table(str(f), "F")
+    st.close()
+
+
+def test_command_lines_arguments(tmp_path):
+    """bayesTyper <command>: usage, help (exit code 1 like main.cpp:146-150), required / unknown / malformed options, the samples file's
+    error messages (Sample.cpp:38-67, main.cpp:163-192) — everything up to the first GPU call"""
+    run = lambda *a: subprocess.run([EXE, *a], capture_output=True, text=True)   # noqa: E731
+    r = run()
+    assert r.returncode == 0 and "Usage: bayesTyper <command> [options]" in r.stdout and "You are using BayesTyper" in r.stdout
+    r = run("frobnicate")
+    assert r.returncode == 0 and "genotype\tgenotype variant clusters" in r.stdout
+    for cmd, must in (("cluster", ["--variant-file", "--min-number-of-unit-variants", "--max-number-of-sample-haplotypes arg (=32)", "--copy-number-variant-threshold arg (=0.5)"]),
+                      ("genotype", ["--variant-clusters-file", "--cluster-data-dir", "--gibbs-burn-in arg (=100)", "--number-of-gibbs-chains arg (=20)", "--noise-rate-prior arg (=1,0.01)",
+                                    "--min-genotype-posterior arg (=0.99)", "--chromosome-ploidy-file", "--noise-genotyping", "-z [ --gzip-output ]"])):
+        for args in ((cmd,), (cmd, "-h"), (cmd, "--help")):
+            r = run(*args)
+            assert r.returncode == 1 and all(m in r.stdout for m in must), (args, r.stdout)
+    r = run("cluster", "-v", "x.vcf", "-s", "s.tsv")
+    assert r.returncode == 1 and "the option '--genome-file' is required but missing" in r.stderr
+    r = run("cluster", "-v", "x.vcf", "-s", "s.tsv", "-g", "g.fa", "--bogus", "1")
+    assert r.returncode == 1 and "unrecognised option '--bogus'" in r.stderr
+    r = run("genotype", "-v", "a", "-c", "b", "-s", "c", "-g", "d", "--gibbs-samples", "many")
+    assert r.returncode == 1 and "is invalid" in r.stderr
+    r = run("genotype", "-v", "a", "-c", "b", "-s", "c", "-g", "d", "--noise-rate-prior", "1")
+    assert r.returncode == 1 and "should be two values (comma-seperated)" in r.stderr
+    r = run("cluster", "-v", "x.vcf", "-s", str(tmp_path / "missing.tsv"), "-g", "g.fa")
+    assert r.returncode == 1 and "ERROR: Unable to open file" in r.stderr
+    r = run("cluster", "-v", "x.vcf", "-s", _samples(tmp_path, ["onlytwo\tF"]), "-g", "g.fa")
+    assert r.returncode == 1 and "should contain three tab-seperated columns" in r.stderr
+    r = run("cluster", "-v", "x.vcf", "-s", _samples(tmp_path, ["a\tX\tprefix"]), "-g", "g.fa")
+    assert r.returncode == 1 and 'should be either "F" (Female) or "M" (Male)' in r.stderr
+    r = run("cluster", "-v", "x.vcf", "-s", _samples(tmp_path, [f"s{i}\tF\tp" for i in range(31)]), "-g", "g.fa")
+    assert r.returncode == 1 and "maximum number of samples supported by BayesTyper is currently 30" in r.stderr
+    empty = tmp_path / "empty.tsv"
+    empty.write_text("")
+    r = run("cluster", "-v", "x.vcf", "-s", str(empty), "-g", "g.fa")
+    assert r.returncode == 1 and "Samples file empty" in r.stderr
+    r = run("cluster", "-v", "x.vcf", "-s", _samples(tmp_path), "-g", str(tmp_path / "nogenome.fa"))
+    assert r.returncode == 1 and "Unable to open file" in r.stderr and "Parsed information for 2 sample(s)" in r.stdout

@@ -11,7 +11,19 @@ K = 55
 NT = np.frombuffer(b"ACGT", np.uint8)
 
 
-def _build(chrom_ascii, variants, contained):
+def _build(chrom_ascii, variants, contained, lib=None, prefix="bth"):
+    """the graph of one cluster as flat arrays: from the product's builder (default) or, with lib = the oracle library and
+    prefix = "orc", from the oracle's restatement of the reference constructor (oracle/oracle_graph.cpp)"""
+    class _Api:
+        pass
+    api = _Api()
+    src = dll if lib is None else lib
+    for name in ("build", "free", "sizes", "fetch"):
+        setattr(api, "bth_graph_" + name, getattr(src, f"{prefix}_graph_{name}"))
+    return _build_with(api, chrom_ascii, variants, contained)
+
+
+def _build_with(dll, chrom_ascii, variants, contained):
     dll.bth_graph_build.restype = C.c_void_p
     dll.bth_graph_build.argtypes = [C.c_uint, C.c_char_p, C.c_ulonglong, C.c_uint] + [C.c_void_p] * 6 + [C.c_char_p, C.c_uint] + [C.c_void_p] * 3
     dll.bth_graph_free.argtypes = [C.c_void_p]
@@ -57,6 +69,38 @@ def test_cpp_graph_equals_python_restatement():
         assert [tuple(e) for e in out["edges"]] == g.edges
         # numberOfAlleles before the generator's has_dependency post-processing: 1 + alts (+1 when the VCF parser marked a dependency)
         assert np.array_equal(out["num_alleles"], np.array([1 + len(v["alts"]) for v in g.variants], np.uint16))
+
+
+def test_cpp_graph_equals_oracle_restatement():
+    """the product's graph builder against the oracle's own restatement of VariantClusterGraph.cpp:62-377 (oracle/oracle_graph.cpp, which
+    shares no code with bayestyper_amd): multi-allelic variants, redundant first nucleotides, dependencies, nested clusters, N runs"""
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).parent))
+    import _oracle
+
+    orc = _oracle.load_oracle()
+    rng = np.random.default_rng(17)
+    checked = n_split = 0
+    for i in range(150):
+        g = synth_graphs.random_cluster(rng, K, int(rng.integers(1, 12)), int(rng.integers(1, 4)), nested_cluster=(500 + i) if i % 2 else None)
+        variants = [dict(v) for v in g.variants]
+        for v in variants:   # vary what the parser would have set
+            v["has_dependency"] = bool(rng.random() < 0.3)
+            v["num_redundant"] = int(rng.random() < 0.3 and min(min(a[0], len(a[1])) for a in v["alts"]) > 0)
+        chrom = NT[g.chrom].copy()
+        if i % 3 == 0:   # N runs anywhere in the cluster's stretch of the reference (flanks, between and under variants)
+            lo, hi = variants[0]["pos"] - (K - 1), variants[-1]["pos"] + K
+            for _ in range(int(rng.integers(1, 4))):
+                a = int(rng.integers(lo, hi))
+                chrom[a:a + int(rng.integers(1, 6))] = ord("N")
+        a = _build(chrom.tobytes(), variants, g.contained)
+        b = _build(chrom.tobytes(), variants, g.contained, lib=orc.l, prefix="orc")
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (i, key)
+        checked += 1
+        n_split += int((a["flags"] & 1).sum() > len(g.contained))
+    assert checked == 150 and n_split > 10
 
 
 def test_n_runs_split_vertices():
