@@ -54,9 +54,10 @@ def make(out_dir, orc, genome_len=1_000_000, num_snvs=5000, num_samples=1, num_e
             gt = rng.choice(3, num_snvs, p=[0.25, 0.5, 0.25])            # number of alt copies
             truth.append(gt)
             haps = []
+            which = rng.integers(0, 2, num_snvs)                           # the haplotype that carries a heterozygous variant's alt allele
             for h in range(2):
                 c = codes.copy()
-                carries = (gt == 2) | ((gt == 1) & (rng.integers(0, 2, num_snvs) == h))
+                carries = (gt == 2) | ((gt == 1) & (which == h))
                 c[pos[carries]] = alt[carries]
                 haps.append(NT[c].tobytes())
             km, va = orc.kmers_from_sequence(haps[0] + b"N" + haps[1], K)
@@ -65,12 +66,15 @@ def make(out_dir, orc, genome_len=1_000_000, num_snvs=5000, num_samples=1, num_e
             cnt = rng.negative_binomial(size * mult, p)
             err = orc.pack(NT[rng.integers(0, 4, num_error_kmers * K)].copy(), K) if num_error_kmers else np.zeros((0, 2), np.uint64)
             if len(err):   # canonical form of the error k-mers (the database holds canonical k-mers)
-                ek, ev = [], []
                 asc = orc.unpack(err, K).reshape(-1, K)
-                comp = {65: 84, 67: 71, 71: 67, 84: 65}
-                rc = np.vectorize(comp.get)(asc[:, ::-1]).astype(np.uint8)
-                lower = np.array([bytes(a) <= bytes(b) for a, b in zip(asc, rc)])
-                err = orc.pack(np.where(lower[:, None], asc, rc).reshape(-1).astype(np.uint8), K)
+                comp = np.zeros(256, np.uint8)
+                comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+                rc = comp[asc[:, ::-1]]
+                diff = asc != rc
+                first = diff.argmax(axis=1)                                 # first position where the k-mer and its reverse complement differ
+                rows = np.arange(len(asc))
+                lower = ~diff.any(axis=1) | (asc[rows, first] < rc[rows, first])
+                err = orc.pack(np.ascontiguousarray(np.where(lower[:, None], asc, rc)).reshape(-1), K)
             keep = cnt > 0
             allk = np.concatenate([uniq[keep], err])
             allc = np.concatenate([np.minimum(cnt[keep], 255), np.ones(len(err), np.int64)])
