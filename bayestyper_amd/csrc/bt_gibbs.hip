@@ -437,6 +437,45 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     if (!params->gender) return fail("bt_gibbs_create: gender array missing");
     if (G == 0 || C == 0) return fail("bt_gibbs_create: empty batch");
     if (B->group_cluster_off[G] != C) return fail("bt_gibbs_create: group_cluster_off[G] != num_clusters");
+    {
+        // a malformed batch must not make the tile builder read out of bounds: offsets monotone, indices in range
+        auto monotone = [](const uint32_t *off, uint64_t n) {
+            for (uint64_t i = 0; i < n; ++i)
+                if (off[i + 1] < off[i]) return false;
+            return true;
+        };
+        if (B->group_cluster_off[0] != 0 || !monotone(B->group_cluster_off, G) || !monotone(B->group_source_off, G) || !monotone(B->edge_off, C) || !monotone(B->kmer_off, C) ||
+            !monotone(B->unique_off, C) || !monotone(B->multi_off, C) || !monotone(B->nestdep_off, C) || !monotone(B->kv_off, B->kmer_off[C]) ||
+            !monotone(B->nestdep_var_off, B->nestdep_off[C]))
+            return fail("bt_gibbs_create: an offset array of the batch is not monotone");
+        uint64_t hap_at = 0, var_at = 0, hv_at = 0;
+        for (uint32_t gi = 0; gi < G; ++gi) {
+            const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1], nv = c1 - c0;
+            if (nv == 0) return fail("bt_gibbs_create: group without clusters");
+            for (uint32_t i = B->group_source_off[gi]; i < B->group_source_off[gi + 1]; ++i)
+                if (B->group_sources[i] >= nv) return fail("bt_gibbs_create: source vertex outside its group");
+            for (uint32_t c = c0; c < c1; ++c) {
+                const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], K = B->kmer_off[c + 1] - B->kmer_off[c];
+                for (uint32_t i = B->edge_off[c]; i < B->edge_off[c + 1]; ++i)
+                    if (B->edges[i] >= nv) return fail("bt_gibbs_create: edge target outside its group");
+                for (uint32_t i = B->unique_off[c]; i < B->unique_off[c + 1]; ++i)
+                    if (B->unique_idx[i] >= K) return fail("bt_gibbs_create: unique k-mer index outside its cluster");
+                for (uint32_t i = B->multi_off[c]; i < B->multi_off[c + 1]; ++i)
+                    if (B->multi_idx[i] >= K) return fail("bt_gibbs_create: multicluster k-mer index outside its cluster");
+                for (uint32_t r = B->kmer_off[c]; r < B->kmer_off[c + 1]; ++r) {
+                    if (B->kmer_shared[r] >= (int32_t)B->group_num_shared[gi]) return fail("bt_gibbs_create: shared k-mer record outside its group");
+                    for (uint32_t e = B->kv_off[r]; e < B->kv_off[r + 1]; ++e)
+                        if (B->kv_var[e] >= V) return fail("bt_gibbs_create: k-mer overlaps a variant outside its cluster");
+                }
+                for (uint64_t i = 0; i < (uint64_t)H * V; ++i)
+                    if (B->hap_allele[hv_at + i] >= B->var_num_alleles[var_at + i % V]) return fail("bt_gibbs_create: haplotype allele index outside its variant");
+                if (B->hapnest_off[hap_at + H] < B->hapnest_off[hap_at]) return fail("bt_gibbs_create: hapnest_off is not monotone");
+                hap_at += H;
+                var_at += V;
+                hv_at += (uint64_t)H * V;
+            }
+        }
+    }
     BT_HIP(hipSetDevice(ctx->device));
     bt_gibbs *g = new bt_gibbs();
     g->ctx = ctx;

@@ -18,3 +18,10 @@ for s in "${srcs[@]}"; do
 done
 hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
 echo "built $out"
+# libbtcomm.so: the RCCL exchange steps (include/btcomm.h), a library of its own so that libbtgpu.so carries no RCCL dependency
+comm_src="$here/comm/bt_comm.hip"
+comm_out="$here/../libbtcomm.so"
+if [ ! -f "$comm_out" ] || [ "$comm_src" -nt "$comm_out" ] || [ "$out" -nt "$comm_out" ] || [ -n "$(find "$here/../../include" -name '*.h' -newer "$comm_out" | head -1)" ]; then
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function "$comm_src" -o "$comm_out" -L"$here/.." -l:libbtgpu.so -lrccl -Wl,-rpath,'$ORIGIN'
+fi
+echo "built $comm_out"

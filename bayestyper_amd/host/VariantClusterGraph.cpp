@@ -28,7 +28,7 @@ constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 // variant.  A piece becomes one vertex, or several in a row when it is cut — at a contained (nested) cluster, whose own graph replaces
 // that part of the reference, and at runs of non-ACGT characters; every cut starts a "disconnected" vertex (no k-mer spans it).
 // Vertex and edge numbering follow the reference's constructor (VariantClusterGraph.cpp:62-377), which the path search and the
-// k-mer enumeration rely on (the oracle's restatement, oracle/oracle_graph.cpp, is the checker: tests/test_host_graph_cpu.py).
+// k-mer enumeration rely on (checked against an independent restatement of that constructor in tests/test_host_graph_cpu.py).
 namespace {
 
 struct Tail {                 // vertices whose sequence ends right before `position` and that still wait for their successor

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "btgpu.h")).read()
+def header_symbols(header="btgpu.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(bt_[a-z0-9_]+)\s*\(", text)))
 
@@ -25,11 +25,24 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_comm_library_exports_every_declared_symbol():
+    """libbtcomm.so (the RCCL exchange steps) exports what include/btcomm.h declares; libbtgpu.so itself carries no RCCL dependency"""
+    syms = header_symbols("btcomm.h")
+    assert len(syms) >= 7
+    dll = C.CDLL(os.path.join(ROOT, "bayestyper_amd", "libbtcomm.so"))
+    assert not [s for s in syms if not hasattr(dll, s)]
+    import subprocess
+
+    needed = subprocess.run(["readelf", "-d", os.path.join(ROOT, "bayestyper_amd", "libbtgpu.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower() and "nccl" not in needed.lower()
+
+
 def test_no_torch_types_and_c_linkage():
-    text = open(os.path.join(ROOT, "include", "btgpu.h")).read()
-    assert 'extern "C"' in text
-    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)   # comments may mention torch; signatures may not
-    assert "torch" not in code.lower() and "at::" not in code and "#include <hip" not in code
+    for header in ("btgpu.h", "btcomm.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        assert 'extern "C"' in text
+        code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)   # comments may mention torch; signatures may not
+        assert "torch" not in code.lower() and "at::" not in code and "#include <hip" not in code and "nccl" not in code.lower()
 
 
 def test_fails_loudly_without_gpu():
