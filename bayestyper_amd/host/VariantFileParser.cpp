@@ -186,133 +186,165 @@ static std::pair<std::string, bool> getInfoAttributeString(const std::string &in
 
 // ---------------------------------------------------------------------------------------------------------------
 // one unit
+//
+// A unit is read record by record.  Every record passes three steps:
+//   arrive   the record's contig / position against the previous record: contig change (the previous contig's tail becomes an
+//            inter-cluster region), ordering errors, expiry of the reference stretches earlier alleles still cover, unit cut;
+//   screen   which of its alternative alleles can be genotyped at all (decoy / unknown contig, REF that does not match the genome,
+//            too close to a contig end, too long) — the reference's allele counters are kept here;
+//   place    the surviving alleles join the open group (or close it first when the record lies k or more past everything the
+//            group covers), and the gap since the previous variant becomes an inter-cluster region.
+// Behaviour, counters and error texts are the reference's (VariantFileParser.cpp:185-545).
 // ---------------------------------------------------------------------------------------------------------------
-bool VariantFileParser::constructVariantClusterGroups(std::vector<ClusterGroup> *groups, uint32_t min_unit_variants, const Chromosomes &chromosomes) {
-    const int k = (int)kmer_size;
-    bool is_first_unit_variant = true;
-    uint32_t unit_variant_counter = 0;
-    std::string cur_chrom_name;
-    int chrom = prev_chrom_name.empty() ? -1 : chromosomes.find(prev_chrom_name);
-    int cur_position = 0;
-    int cur_group_end_position = prev_var_end_position;
-    Open open;
-    std::set<uint32_t> variant_dependencies;   // last reference positions of the alleles that are still open
-
-    while (is_first_unit_variant ? line_good : (line_good = updateVariantLine())) {   // the first line of a unit is the one the previous unit stopped at
-        is_first_unit_variant = false;
-        cur_chrom_name = variant_line[0];
-        cur_position = std::stoi(variant_line[1]) - 1;
-        if (cur_chrom_name != prev_chrom_name) {
-            if (!prev_chrom_name.empty()) {
-                const int prev_chrom = chromosomes.find(prev_chrom_name);
-                if (prev_chrom >= 0) {
-                    closeGroup(&open, groups);
-                    addSequenceToInterclusterRegions(prev_chrom_name, chromosomes.isDecoy(prev_chrom_name), (uint32_t)(prev_var_end_position + 1), (uint32_t)chromosomes.sequence(prev_chrom).size() - 1);
-                    if (!intercluster_chromosomes.insert(prev_chrom_name).second)
-                        throw std::runtime_error("Variants need to be sorted by contig; variants on contig \"" + prev_chrom_name + "\" is unordered");
-                }
-            }
-            chrom = chromosomes.find(cur_chrom_name);
-            prev_var_end_position = -1;
-            cur_group_end_position = -1;
-            variant_dependencies.clear();
-        } else if (prev_position > cur_position) {
-            throw std::runtime_error("Variants need to be sorted by position; \"" + std::to_string(prev_position) + "\" is before \"" + std::to_string(cur_position) + "\" on contig \"" +
-                                     cur_chrom_name + "\"");
-        } else if (prev_position == cur_position) {
-            // the reference prints this message and then fails on the duplicate map key
-            throw std::runtime_error("Variants on the same position need to be multi-allelic; multiple variants observed on position \"" + std::to_string(prev_position) + "\" on contig \"" +
-                                     cur_chrom_name + "\"");
-        }
-        prev_chrom_name = cur_chrom_name;
-        while (!variant_dependencies.empty() && (int)*variant_dependencies.begin() < cur_position) variant_dependencies.erase(variant_dependencies.begin());
-        if (unit_variant_counter >= min_unit_variants && (cur_position - cur_group_end_position) >= k) break;   // the line stays pending for the next unit
-        prev_position = cur_position;
-
-        const std::string var_ref_seq = upper(variant_line[3]);
-        std::vector<std::string> alt_alleles = split(variant_line[4], ',');
-        std::vector<std::string> origin_allele_att;
-        const auto origin_att_str = getInfoAttributeString(variant_line[5], "ACO");
-        if (origin_att_str.second) origin_allele_att = split(origin_att_str.first, ',');
-        else origin_allele_att.assign(alt_alleles.size(), "");
-        if (origin_allele_att.size() != alt_alleles.size()) throw std::runtime_error("ACO attribute does not have one entry per alternative allele (" + variant_line[2] + ")");
-
-        Variant cur_variant;
-        cur_variant.id = variant_line[2];
-        cur_variant.has_dependency = !variant_dependencies.empty();
-        num_variants += 1;
-        unit_variant_counter += 1;
-        if (alt_alleles.back() == "*") alt_alleles.pop_back();   // the missing allele is implied by has_dependency
-        if (alt_alleles.empty()) throw std::runtime_error("Variant without alternative allele (" + variant_line[2] + ")");
-        allele_type_counter[Total] += (uint32_t)alt_alleles.size();
-
-        if (chrom >= 0 && chromosomes.isDecoy(cur_chrom_name)) {
-            allele_type_counter[Excluded_decoy] += (uint32_t)alt_alleles.size();
-            variant_type_counter[(size_t)VariantType::Unsupported]++;
-            continue;
-        }
-        if (chrom < 0) {
-            allele_type_counter[Excluded_genome] += (uint32_t)alt_alleles.size();
-            variant_type_counter[(size_t)VariantType::Unsupported]++;
-            continue;
-        }
-        const std::string &chrom_sequence = chromosomes.sequence(chrom);
-        std::vector<std::string> ref_alleles(alt_alleles.size(), var_ref_seq);
-        for (size_t i = 0; i < alt_alleles.size(); i++) {
-            alt_alleles[i] = upper(alt_alleles[i]);
-            rightTrimAllele(&ref_alleles[i], &alt_alleles[i]);
-        }
-        bool is_excluded = false;
-        const std::string gen_ref_seq = upper((size_t)cur_position <= chrom_sequence.size() ? chrom_sequence.substr(cur_position, variant_line[3].size()) : std::string());
-        if (var_ref_seq != gen_ref_seq) {
-            allele_type_counter[Excluded_match] += (uint32_t)alt_alleles.size();
-            is_excluded = true;
-        }
-        if (cur_position < k - 1) {
-            allele_type_counter[Excluded_end] += (uint32_t)alt_alleles.size();
-            is_excluded = true;
-        }
-        std::unordered_set<uint16_t> excluded_alleles;
-        if (!is_excluded) {
-            for (size_t i = 0; i < alt_alleles.size(); i++) {
-                if ((uint64_t)cur_position + ref_alleles[i].size() - 1 + kmer_size > chrom_sequence.size()) {
-                    allele_type_counter[Excluded_end]++;
-                    excluded_alleles.insert((uint16_t)i);
-                } else if (ref_alleles[i].size() > max_allele_length || alt_alleles[i].size() > max_allele_length) {
-                    allele_type_counter[Excluded_length]++;
-                    excluded_alleles.insert((uint16_t)i);
-                } else {
-                    variant_dependencies.insert((uint32_t)(cur_position + ref_alleles[i].size() - 1));
-                }
-            }
-        }
-        if (is_excluded || excluded_alleles.size() == alt_alleles.size()) {
-            variant_type_counter[(size_t)VariantType::Unsupported]++;
-            continue;
-        }
-        if ((cur_position - cur_group_end_position) >= k) closeGroup(&open, groups);
-        if (cur_position > prev_var_end_position + 1) addSequenceToInterclusterRegions(cur_chrom_name, false, (uint32_t)(prev_var_end_position + 1), (uint32_t)(cur_position - 1));
-
-        std::set<uint32_t> cur_end_positions;
-        for (size_t a = 0; a < alt_alleles.size(); a++) {
-            if (excluded_alleles.count((uint16_t)a)) continue;
-            addAlternativeAllele(&cur_variant, ref_alleles[a], alt_alleles[a], origin_allele_att[a]);
-            const uint32_t after_ref = (uint32_t)(cur_position + ref_alleles[a].size());
-            const uint32_t ref_cnv = copyNumberVariantLength(ref_alleles[a], chrom_sequence, after_ref);
-            const uint32_t alt_cnv = copyNumberVariantLength(alt_alleles[a], chrom_sequence, after_ref);
-            cur_end_positions.insert(after_ref - 1);
-            cur_group_end_position = std::max(cur_group_end_position, (int)(after_ref - 1 + std::max(ref_cnv, alt_cnv)));
-        }
-        prev_var_end_position = std::max(prev_var_end_position, (int)*cur_end_positions.rbegin());
-        clusterVariants(cur_variant, (uint32_t)cur_position, cur_end_positions, cur_chrom_name, &open);
-        variant_type_counter[(size_t)cur_variant.type]++;
+namespace {
+struct RecordAlleles {   // one VCF record's REF/ALT pairs after upper-casing and right-trimming, with their origin attributes
+    std::string ref_field;                       // REF as written (upper case)
+    std::vector<std::string> ref, alt, origin;   // per alternative allele
+};
+RecordAlleles readAlleles(const std::vector<std::string> &line) {
+    RecordAlleles r;
+    r.ref_field = upper(line[3]);
+    r.alt = split(line[4], ',');
+    const auto aco = getInfoAttributeString(line[5], "ACO");
+    if (aco.second) r.origin = split(aco.first, ',');
+    else r.origin.assign(r.alt.size(), "");
+    if (r.origin.size() != r.alt.size()) throw std::runtime_error("ACO attribute does not have one entry per alternative allele (" + line[2] + ")");
+    if (r.alt.back() == "*") {   // the missing allele is implied by has_dependency
+        r.alt.pop_back();
+        r.origin.pop_back();
     }
-    closeGroup(&open, groups);
+    if (r.alt.empty()) throw std::runtime_error("Variant without alternative allele (" + line[2] + ")");
+    r.ref.assign(r.alt.size(), r.ref_field);
+    for (size_t i = 0; i < r.alt.size(); i++) {
+        r.alt[i] = upper(r.alt[i]);
+        VariantFileParser::rightTrimAllele(&r.ref[i], &r.alt[i]);
+    }
+    return r;
+}
+}  // namespace
 
-    if (total_num_variants == num_variants) {   // the whole file has been read: close the last contig, add the untouched ones (:519-544)
-        if (chrom >= 0) {
-            addSequenceToInterclusterRegions(cur_chrom_name, chromosomes.isDecoy(cur_chrom_name), (uint32_t)(prev_var_end_position + 1), (uint32_t)chromosomes.sequence(chrom).size() - 1);
-            intercluster_chromosomes.insert(cur_chrom_name);
+struct VariantFileParser::UnitScan {   // what a unit's scan carries from record to record
+    const Chromosomes &chromosomes;
+    std::vector<ClusterGroup> *groups;
+    Open open;                          // the group under construction
+    std::set<uint32_t> covered_until;   // last reference positions of the alleles of earlier records that are still open
+    std::string contig;                 // contig of the current record
+    int contig_index = -1;              // its index in the genome (-1: not in the genome)
+    int group_reach = -1;               // last position the open group covers (alleles + their copy-number repeats)
+    uint32_t records = 0;               // records taken into this unit
+};
+
+// step 1.  Returns false when the unit ends before this record (the record stays pending for the next unit).
+bool VariantFileParser::arrive(UnitScan *u, int position, uint32_t min_unit_variants) {
+    const std::string &contig = variant_line[0];
+    if (contig != prev_chrom_name) {
+        if (!prev_chrom_name.empty()) {
+            const int left = u->chromosomes.find(prev_chrom_name);
+            if (left >= 0) {   // the contig just left: its open group is complete, its tail is inter-cluster sequence
+                closeGroup(&u->open, u->groups);
+                addSequenceToInterclusterRegions(prev_chrom_name, u->chromosomes.isDecoy(prev_chrom_name), (uint32_t)(prev_var_end_position + 1), (uint32_t)u->chromosomes.sequence(left).size() - 1);
+                if (!intercluster_chromosomes.insert(prev_chrom_name).second)
+                    throw std::runtime_error("Variants need to be sorted by contig; variants on contig \"" + prev_chrom_name + "\" is unordered");
+            }
+        }
+        u->contig_index = u->chromosomes.find(contig);
+        prev_var_end_position = -1;
+        u->group_reach = -1;
+        u->covered_until.clear();
+    } else if (prev_position > position) {
+        throw std::runtime_error("Variants need to be sorted by position; \"" + std::to_string(prev_position) + "\" is before \"" + std::to_string(position) + "\" on contig \"" + contig + "\"");
+    } else if (prev_position == position) {   // (the reference prints this message and then fails on the duplicate map key)
+        throw std::runtime_error("Variants on the same position need to be multi-allelic; multiple variants observed on position \"" + std::to_string(prev_position) + "\" on contig \"" +
+                                 contig + "\"");
+    }
+    u->contig = contig;
+    prev_chrom_name = contig;
+    while (!u->covered_until.empty() && (int)*u->covered_until.begin() < position) u->covered_until.erase(u->covered_until.begin());
+    if (u->records >= min_unit_variants && (position - u->group_reach) >= (int)kmer_size) return false;
+    prev_position = position;
+    return true;
+}
+
+// step 2.  keep[i] = alternative allele i can be genotyped; returns false when the whole record is unsupported.
+bool VariantFileParser::screen(UnitScan *u, int position, const std::vector<std::string> &ref, const std::vector<std::string> &alt, const std::string &ref_field, std::vector<bool> *keep) {
+    const uint32_t n = (uint32_t)alt.size();
+    allele_type_counter[Total] += n;
+    keep->assign(n, false);
+    if (u->contig_index >= 0 && u->chromosomes.isDecoy(u->contig)) {
+        allele_type_counter[Excluded_decoy] += n;
+        return false;
+    }
+    if (u->contig_index < 0) {
+        allele_type_counter[Excluded_genome] += n;
+        return false;
+    }
+    const std::string &sequence = u->chromosomes.sequence(u->contig_index);
+    bool whole_record_out = false;
+    if (ref_field != upper((size_t)position <= sequence.size() ? sequence.substr(position, ref_field.size()) : std::string())) {
+        allele_type_counter[Excluded_match] += n;
+        whole_record_out = true;
+    }
+    if (position < (int)kmer_size - 1) {
+        allele_type_counter[Excluded_end] += n;
+        whole_record_out = true;
+    }
+    if (whole_record_out) return false;
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if ((uint64_t)position + ref[i].size() - 1 + kmer_size > sequence.size()) allele_type_counter[Excluded_end]++;
+        else if (ref[i].size() > max_allele_length || alt[i].size() > max_allele_length) allele_type_counter[Excluded_length]++;
+        else {
+            (*keep)[i] = true;
+            kept++;
+            u->covered_until.insert((uint32_t)(position + ref[i].size() - 1));
+        }
+    }
+    return kept > 0;
+}
+
+bool VariantFileParser::constructVariantClusterGroups(std::vector<ClusterGroup> *groups, uint32_t min_unit_variants, const Chromosomes &chromosomes) {
+    UnitScan u{chromosomes, groups};
+    u.contig_index = prev_chrom_name.empty() ? -1 : chromosomes.find(prev_chrom_name);
+    u.contig = prev_chrom_name;
+    u.group_reach = prev_var_end_position;
+    // the first record of a unit is the one the previous unit stopped at (still in variant_line)
+    for (bool pending = true; pending ? line_good : (line_good = updateVariantLine()); pending = false) {
+        const int position = std::stoi(variant_line[1]) - 1;
+        if (!arrive(&u, position, min_unit_variants)) break;
+        const RecordAlleles rec = readAlleles(variant_line);
+        Variant variant;
+        variant.id = variant_line[2];
+        variant.has_dependency = !u.covered_until.empty();
+        num_variants += 1;
+        u.records += 1;
+        std::vector<bool> keep;
+        if (!screen(&u, position, rec.ref, rec.alt, rec.ref_field, &keep)) {
+            variant_type_counter[(size_t)VariantType::Unsupported]++;
+            continue;
+        }
+        // step 3: place
+        if ((position - u.group_reach) >= (int)kmer_size) closeGroup(&u.open, groups);
+        if (position > prev_var_end_position + 1) addSequenceToInterclusterRegions(u.contig, false, (uint32_t)(prev_var_end_position + 1), (uint32_t)(position - 1));
+        const std::string &sequence = chromosomes.sequence(u.contig_index);
+        std::set<uint32_t> allele_ends;
+        for (size_t i = 0; i < rec.alt.size(); i++) {
+            if (!keep[i]) continue;
+            addAlternativeAllele(&variant, rec.ref[i], rec.alt[i], rec.origin[i]);
+            const uint32_t after = (uint32_t)(position + rec.ref[i].size());
+            const uint32_t repeat = std::max(copyNumberVariantLength(rec.ref[i], sequence, after), copyNumberVariantLength(rec.alt[i], sequence, after));
+            allele_ends.insert(after - 1);
+            u.group_reach = std::max(u.group_reach, (int)(after - 1 + repeat));
+        }
+        prev_var_end_position = std::max(prev_var_end_position, (int)*allele_ends.rbegin());
+        clusterVariants(variant, (uint32_t)position, allele_ends, u.contig, &u.open);
+        variant_type_counter[(size_t)variant.type]++;
+    }
+    closeGroup(&u.open, groups);
+
+    if (total_num_variants == num_variants) {   // the whole file has been read: the last contig's tail and every contig without variants (:519-544)
+        if (u.contig_index >= 0) {
+            addSequenceToInterclusterRegions(u.contig, chromosomes.isDecoy(u.contig), (uint32_t)(prev_var_end_position + 1), (uint32_t)chromosomes.sequence(u.contig_index).size() - 1);
+            intercluster_chromosomes.insert(u.contig);
         }
         for (size_t c = 0; c < chromosomes.size(); c++)
             if (intercluster_chromosomes.insert(chromosomes.name(c)).second)

@@ -101,6 +101,9 @@ class VariantFileParser {
         std::map<uint32_t, VariantCluster *> flanks;
         std::list<std::unordered_set<uint32_t>> merge_sets;
     };
+    struct UnitScan;
+    bool arrive(UnitScan *u, int position, uint32_t min_unit_variants);
+    bool screen(UnitScan *u, int position, const std::vector<std::string> &ref, const std::vector<std::string> &alt, const std::string &ref_field, std::vector<bool> *keep);
     bool updateVariantLine();
     void addSequenceToInterclusterRegions(const std::string &chrom_name, bool is_decoy, uint32_t start_position, uint32_t end_position);
     void addAlternativeAllele(Variant *cur_variant, const std::string &ref_allele, const std::string &alt_allele, const std::string &origin_att) const;
