@@ -361,8 +361,8 @@ def main():
                          "traffic": None, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
                          "note": "latency/issue-bound sequential sampler: the HBM floor (inputs + state once per chain, SURVEY 8d) is tiny by construction; "
                                  "avg_launch_ms spans the sampling launch(es) of one schedule (tiles with large LDS needs form a second, concurrent launch); traffic is not "
-                                 "measurable from inside this process: the PMC passes of this command are in profiles/ (r02_pmc_*.json)"},
-            "roofline_kmer_match": {"kernel": "kmc_scan_kernel", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "measurable from inside this process: the PMC passes of this command are in profiles/ (r02_FETCH_SIZE_pmc.json, r02_WRITE_SIZE_pmc.json)"},
+            "roofline_kmer_match": {"kernel": "one KMC scan = kmc_route_kernel + rocPRIM radix sort (16 bits) + kmc_probe_kernel + kmc_apply_kernel per 2^26-record chunk", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kmc_avg_ms, "launches_per_step": S,
                                     "insert_launch_ms": float(kmc[:, 0].mean()), "find_launch_ms": float(kmc[:, 1:].mean()) if S > 1 else None,
                                     "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD, "bloom_hits_per_scan": hits // ((args.steps + args.warmup) * S), "table_keys": st["num_keys"]},
