@@ -211,6 +211,9 @@ __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_kernel(const Til
     if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN)) return;
     t.hot = nullptr;
     t.resident = 0xFFFFFFFFu;
+    // Narrow tiles (few groups + lockstep copies) are the launch's critical path: a handful of long sequential programs.  They take
+    // issue priority over the 64-group tiles they share a SIMD with, which have plenty of peers to fill the gaps.
+    if (t.d->prio) __builtin_amdgcn_s_setprio(3);
     SPtr<uint32_t, LANES> gd = t.arr<uint32_t>(A_GDIMS);
     if (!gd[3]) return;   // padding lane of the last tile
     const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
@@ -844,6 +847,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             for (int a : {A_SC, A_OBS, A_PEND, A_DIP, A_PENDDIP, A_NZ, A_KSCUPD, A_PENDVALID, A_NESTPL, A_NESTN, A_FREQ, A_LOGF, A_RING}) simple = simple && d.hoff[a] != NOHOT;
             d.simple = simple ? 1u : 0u;
         }
+        d.prio = (d.copies > 1 || d.num_lanes < LANES / 2) && !getenv("BT_GIBBS_NO_PRIO") ? 1u : 0u;
         d.base = pool;
         if (ti == 0 && getenv("BT_GIBBS_DEBUG") && atoi(getenv("BT_GIBBS_DEBUG")) >= 2) {   // the arrays that make up most of tile 0
             std::vector<std::pair<uint64_t, int>> by_size;
@@ -1015,7 +1019,9 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             g->allocs.push_back(c.d_tiles);
             BT_TRYHIP(hipMemcpyAsync(c.d_tiles, c.tiles.data(), c.tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             if (i + 1 < g->classes.size()) {   // the last class runs on the context's stream
-                BT_TRYHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+                int prio_lo = 0, prio_hi = 0;   // the hungrier classes (created first) get the higher dispatch priority
+                BT_TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+                BT_TRYHIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi));
                 BT_TRYHIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
             }
         }
@@ -1314,10 +1320,10 @@ int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *v
 #ifdef BT_PROF
 int bt_diag_prof(unsigned long long *h_out16, int reset) {
     BT_HIP(hipDeviceSynchronize());
-    BT_HIP(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_bt_prof), 16 * 8));
+    BT_HIP(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_bt_prof), 32 * 8));   // 32 slots
     if (reset) {
-        unsigned long long z[16] = {0};
-        BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, 16 * 8));
+        unsigned long long z[32] = {0};
+        BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, 32 * 8));
     }
     return BT_OK;
 }

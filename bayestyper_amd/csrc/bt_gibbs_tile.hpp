@@ -135,6 +135,7 @@ struct TileDesc {
     uint32_t lds_stride, lds_all;   // lanes a hot-array row is interleaved over in LDS (4 .. 64); lds_all: every vertex has its own LDS block (no swaps)
     uint32_t simple;                // every group of the tile is one two-haplotype cluster without multicluster k-mers: sweeps run in simple_sweeps()
     uint32_t ring_cap[2], ring_len; // draw-ahead words of the diplotype / frequency generator (powers of two); ring_len = both blocks
+    uint32_t prio;                  // the tile's wavefronts raise their issue priority (narrow tiles: the launch's critical path)
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 constexpr uint32_t RESIDENT_ALL = 0xFFFFFFFEu;   // Env/Tile::resident: every vertex of the group has its hot arrays in LDS
@@ -431,7 +432,7 @@ __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
 
 // ---- optional per-phase cycle accounting (build with -DBT_PROF; read with bt_diag_prof) ----
 #ifdef BT_PROF
-__device__ unsigned long long g_bt_prof[16];
+__device__ unsigned long long g_bt_prof[32];
 #define PROF_DECL unsigned long long _pt = __builtin_readcyclecounter()
 #define PROF_DECL2 _pt = __builtin_readcyclecounter()
 #define PROF(sec)                                                            \
@@ -1160,71 +1161,111 @@ __device__ inline bool hap_source(const Vx &c, uint32_t s, uint32_t which, uint1
 }
 
 // Materialise `r` identical collected sweeps of sample s that drew diplotype (h1, h2) while its k-mer-stats cache stayed
-// unchanged: diplotype_sampling_frequencies += r and, per allele cell, the reference's exact sequence of addKmerStats calls
-// replayed r times in registers (h1's contribution then h2's, interleaved when both hit the same cell).
-__device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t r) {
+// unchanged — diplotype_sampling_frequencies += r and, per allele cell, the reference's exact sequence of addKmerStats calls
+// replayed r times — followed by the `nn` addNestedHaplotypeKmerStats contributions of this sweep (:360-372; nn > 0 only with r = 1).
+//
+// An allele cell holds three independent KmerStats (count, fraction, mean), and the cells of different variants are disjoint, so the
+// work is 3 V independent Welford chains.  They are items (variant, statistic) dealt to the copies of the group (a 64-group tile: all
+// to the one lane); every chain sees its values in the reference's order: haplotype 1's source, haplotype 2's (alternating when both
+// fall into the same cell), then the nested sources.
+__device__ inline void ks_chain_rep(KS &k, double v1, bool en1, double v2, bool en2, uint32_t r) {   // r x {add v1 if en1; add v2 if en2}
+    if (en1 && en2 && v1 != v2) {
+        for (uint32_t i = 0; i < r; ++i) {
+            ks_add_r(k, v1);
+            ks_add_r(k, v2);
+        }
+        return;
+    }
+    if (en1 && en2) ks_add_rep(k, v1, 2 * r);
+    else if (en1) ks_add_rep(k, v1, r);
+    else if (en2) ks_add_rep(k, v2, r);
+}
+__device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t r, uint32_t nn) {
     dip_table_add(c, P, h1, h2, s, r);
-    if (h1 == NOHAP) return;
-    uint32_t last1 = 0xFFFFFFFFu, last2 = 0xFFFFFFFFu;
-    for (uint32_t var = 0; var < c.V; ++var) {
-        uint32_t a1 = 0, a2 = 0;
-        KS s1{0, 0, 0, 0}, s2{0, 0, 0, 0};
-        const bool ok1 = hap_source(c, s, 0, h1, var, last1, a1, s1);
-        const bool ok2 = h2 != NOHAP && hap_source(c, s, 1, h2, var, last2, a2, s2);
-        if (ok1 && ok2 && a1 == a2) {
-            SPtr<double, LANES> cell = c.astats(s, var, a1);
-            KS a = ks_load(cell), b = ks_load(cell + 4), m = ks_load(cell + 8);
-            if (r == 1 || (s1.c == s2.c && s1.f == s2.f && s1.m == s2.m)) {
-                // identical sources (or a single sweep): 2r applications of the same value per statistic
-                for (uint32_t rep = 0; rep < (r == 1 ? 1u : 0u); ++rep) {
-                    ks_add_r(a, s1.c);
-                    if (s1.c != 0.0) { ks_add_r(b, s1.f); ks_add_r(m, s1.m); }
-                    ks_add_r(a, s2.c);
-                    if (s2.c != 0.0) { ks_add_r(b, s2.f); ks_add_r(m, s2.m); }
+    const uint32_t V = c.V;
+    const bool two = h1 != NOHAP && h2 != NOHAP;
+    for (uint32_t item = c.t.part; item < 3 * V; item += c.t.copies) {
+        const uint32_t var = item / 3u, st = item - var * 3u;
+        // the source variant of each haplotype (add_haplotype_kmer_stats' missing-allele rule: a missing allele takes the stats of the
+        // last variant before it whose allele is not missing)
+        uint32_t a1 = 0, a2 = 0, src1 = 0xFFFFFFFFu, src2 = 0xFFFFFFFFu;
+        if (h1 != NOHAP) {
+            for (uint32_t w = 0; w <= var; ++w) {
+                const bool dep = c.var_dep(w);
+                const uint32_t last = (uint32_t)c.var_na(w) - 1u;
+                a1 = c.hap_allele(h1, w);
+                if (!(dep && a1 == last)) src1 = w;
+                else if (w == var && src1 == 0xFFFFFFFFu) src1 = 0xFFFFFFFEu;   // missing with nothing before it: no contribution
+                if (two) {
+                    a2 = c.hap_allele(h2, w);
+                    if (!(dep && a2 == last)) src2 = w;
+                    else if (w == var && src2 == 0xFFFFFFFFu) src2 = 0xFFFFFFFEu;
                 }
-                if (r > 1) {
-                    ks_add_rep(a, s1.c, 2 * r);
-                    if (s1.c != 0.0) { ks_add_rep(b, s1.f, 2 * r); ks_add_rep(m, s1.m, 2 * r); }
-                }
-            } else {
-                for (uint32_t rep = 0; rep < r; ++rep) {
-                    ks_add_r(a, s1.c);
-                    if (s1.c != 0.0) { ks_add_r(b, s1.f); ks_add_r(m, s1.m); }
-                    ks_add_r(a, s2.c);
-                    if (s2.c != 0.0) { ks_add_r(b, s2.f); ks_add_r(m, s2.m); }
-                }
-            }
-            ks_store(cell, a);
-            ks_store(cell + 4, b);
-            ks_store(cell + 8, m);
-        } else {
-            if (ok1) {
-                SPtr<double, LANES> cell = c.astats(s, var, a1);
-                KS a = ks_load(cell), b = ks_load(cell + 4), m = ks_load(cell + 8);
-                ks_add_rep(a, s1.c, r);
-                if (s1.c != 0.0) { ks_add_rep(b, s1.f, r); ks_add_rep(m, s1.m, r); }
-                ks_store(cell, a);
-                ks_store(cell + 4, b);
-                ks_store(cell + 8, m);
-            }
-            if (ok2) {
-                SPtr<double, LANES> cell = c.astats(s, var, a2);
-                KS a = ks_load(cell), b = ks_load(cell + 4), m = ks_load(cell + 8);
-                ks_add_rep(a, s2.c, r);
-                if (s2.c != 0.0) { ks_add_rep(b, s2.f, r); ks_add_rep(m, s2.m, r); }
-                ks_store(cell, a);
-                ks_store(cell + 4, b);
-                ks_store(cell + 8, m);
             }
         }
+        const bool ok1 = src1 < 0xFFFFFFFEu, ok2 = src2 < 0xFFFFFFFEu;
+        double v1 = 0, v2 = 0;
+        bool en1 = false, en2 = false;
+        if (ok1) {
+            SPtr<double, LANES> q = c.ksc(s, 0, src1);
+            const double cnt = q[0];
+            v1 = st == 0 ? cnt : (double)q[st];
+            en1 = st == 0 || cnt != 0.0;
+        }
+        if (ok2) {
+            SPtr<double, LANES> q = c.ksc(s, 1, src2);
+            const double cnt = q[0];
+            v2 = st == 0 ? cnt : (double)q[st];
+            en2 = st == 0 || cnt != 0.0;
+        }
+        double nv[2] = {0, 0};
+        bool nen[2] = {false, false};
+        for (uint32_t j = 0; j < nn && j < 2u; ++j) {
+            SPtr<double, LANES> q = c.nest_stats(s, j);
+            const double cnt = q[0];
+            nv[j] = st == 0 ? cnt : (double)q[st];
+            nen[j] = st == 0 || cnt != 0.0;
+        }
+        const uint32_t anest = (uint32_t)c.var_na(var) - 1u;
+        // the chain(s): at most three cells of this variant, each loaded and stored once
+        uint32_t cur = 0xFFFFFFFFu;
+        KS acc{0, 0, 0, 0};
+        auto sel = [&](uint32_t allele) {
+            if (cur == allele) return;
+            if (cur != 0xFFFFFFFFu) ks_store(c.astats(s, var, cur) + 4u * st, acc);
+            acc = ks_load(c.astats(s, var, allele) + 4u * st);
+            cur = allele;
+        };
+        if (ok1 && ok2 && a1 == a2) {
+            if (en1 || en2) {
+                sel(a1);
+                ks_chain_rep(acc, v1, en1, v2, en2, r);
+            }
+        } else {
+            if (ok1 && en1) {
+                sel(a1);
+                ks_add_rep(acc, v1, r);
+            }
+            if (ok2 && en2) {
+                sel(a2);
+                ks_add_rep(acc, v2, r);
+            }
+        }
+        for (uint32_t j = 0; j < nn && j < 2u; ++j)
+            if (nen[j]) {
+                sel(anest);
+                ks_add_r(acc, nv[j]);
+            }
+        if (cur != 0xFFFFFFFFu) ks_store(c.astats(s, var, cur) + 4u * st, acc);
     }
+    if (c.t.copies > 1u) copies_sync();
 }
 
 __device__ inline void flush_sample(const Vx &c, const GParams BT_CAS &P, uint32_t s) {
     const uint32_t r = c.pend()[s];
     if (r == 0) return;
     c.pend()[s] = 0;
-    replay_collected(c, P, s, c.pend_dip()[2 * s], c.pend_dip()[2 * s + 1], r);
+    replay_collected(c, P, s, c.pend_dip()[2 * s], c.pend_dip()[2 * s + 1], r, 0);
 }
 
 // materialise everything still pending (end of a launch: results may be read next)
@@ -1246,9 +1287,13 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
     const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
     const uint8_t u = upd[s];
     const uint32_t nn = c.nest_n()[s];
+    PROF_DECL;
+    PROF_CNT(19, 1);
     flush_sample(c, P, s);
+    PROF(16);
     {
         if (u) {
+            PROF_CNT(20, 1);
             upd[s] = 0;
             // Rebuild kmer_stats_cache[s] (VariantClusterHaplotypes.cpp:247-277).  The cache is 2 x V independent KmerStats accumulators
             // (haplotype slot x variant), each a strictly sequential Welford recurrence over the subset k-mers that lie on its haplotype
@@ -1316,13 +1361,13 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
                 ks_store(c.ksc(s, which, var), acc);
             }
             if (c.t.copies > 1u) copies_sync();
+            PROF(17);
         }
-        replay_collected(c, P, s, h1, h2, 1);
-        for (uint32_t j = 0; j < nn; ++j)   // addNestedHaplotypeKmerStats (:360-372)
-            for (uint32_t var = 0; var < c.V; ++var) aks_add(c.astats(s, var, (uint32_t)c.var_na(var) - 1u), ks_load(c.nest_stats(s, j)));
+        replay_collected(c, P, s, h1, h2, 1, nn);   // this sweep + addNestedHaplotypeKmerStats (:360-372)
         pvalid[s] = nn == 0 ? 1 : 0;
         pdip[2 * s] = h1;
         pdip[2 * s + 1] = h2;
+        PROF(18);
     }
 }
 __device__ __noinline__ void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
@@ -1532,6 +1577,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome.  (The evaluation of
         // the candidates consumes no random numbers, so drawing first does not change the stream.)
         const double u01 = rng_canonical(rng);
+        PROF(24);
         uint32_t pick = 0;
         // one evaluation site (the blocked evaluation is large: instantiating it twice would not fit the instruction cache)
         for (bool exact = chain_only;; exact = true) {
@@ -1540,33 +1586,66 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             if (exact) {
                 if (total == 0) (void)bt_log(u01);
                 pick = chain_pick(u01);
+                PROF(28);
                 break;
             }
-            double acc = 0;
-            if (par) {   // the exponentials are independent: split among the copies; the running sum stays sequential (same order, same bits)
-                for (uint32_t i = c.t.part; i < total; i += c.t.copies) cum[i] = bt_exp((double)cum[i] - lpmax);
-                copies_sync();
-                for (uint32_t i = 0; i < total; ++i) {
-                    acc += (double)cum[i];
-                    cum[i] = acc;
+            double acc = 0, thr = 0, off = 0;     // off: cumulative weight before the searched range [s0, s1)
+            uint32_t s0 = 0, s1 = total;
+            if (par) {
+                // The weights exp(lp - max) and their running sums are this kernel's own formulation of the draw (the decision is verified
+                // against the reference's chain below), so their summation order is free: every copy takes one contiguous segment of the
+                // candidates — exponentials and a local running sum in registers —, the segment totals are exchanged with lane shuffles,
+                // and every copy searches the one segment that holds U * total.
+                const uint32_t ncp = c.t.copies, cw = 64u / ncp, L = (total + ncp - 1u) / ncp;
+                const uint32_t i0 = c.t.part * L < total ? c.t.part * L : total, i1 = i0 + L < total ? i0 + L : total;
+                double run = 0;
+                for (uint32_t b0 = i0; b0 < i1; b0 += 8) {
+                    double e[8];
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q) e[q] = b0 + q < i1 ? (double)cum[b0 + q] : 0.0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q)
+                        if (b0 + q < i1) e[q] = bt_exp(e[q] - lpmax);
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q)
+                        if (b0 + q < i1) {
+                            run += e[q];
+                            cum[b0 + q] = run;
+                        }
                 }
+                const uint32_t gl = (threadIdx.x & 63u) % cw;
+                for (uint32_t m = 0; m < ncp; ++m) acc += __shfl(run, (int)(gl + m * cw));
+                thr = u01 * acc;
+                uint32_t seg = ncp;
+                for (uint32_t m = 0; m < ncp; ++m) {
+                    const double tseg = __shfl(run, (int)(gl + m * cw));
+                    if (seg == ncp) {
+                        if (thr < off + tseg) seg = m;
+                        else off += tseg;
+                    }
+                }
+                copies_sync();
+                s0 = seg * L < total ? seg * L : total;     // seg == ncp (U * total not below the grand total): empty range -> not safe
+                s1 = s0 + L < total ? s0 + L : total;
             } else {
                 for (uint32_t i = 0; i < total; ++i) {
                     acc += bt_exp((double)cum[i] - lpmax);
                     cum[i] = acc;
                 }
+                thr = u01 * acc;
             }
-            const double thr = u01 * acc;
-            uint32_t lo = 0, hi = total;
+            PROF(25);
+            uint32_t lo = s0, hi = s1;
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (thr < cum[mid]) hi = mid;
+                if (thr < off + (double)cum[mid]) hi = mid;
                 else lo = mid + 1;
             }
             const double amax = fabs(lpmax) > 1.0 ? fabs(lpmax) : 1.0;
             double margin = 64.0 * (double)total * amax * BT_DBL_EPS;
             margin = (margin > 1e-6 ? margin : 1e-6) * acc;
-            const bool safe = lo < total && (double)cum[lo] - thr > margin && (lo == 0 || thr - (double)cum[lo - 1] > margin);
+            const bool safe = lo < s1 && off + (double)cum[lo] - thr > margin && (lo == 0 || thr - (lo == s0 ? off : off + (double)cum[lo - 1]) > margin);
+            PROF(26);
             if (safe) {
                 pick = lo;
                 break;
@@ -1700,6 +1779,7 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
 #pragma unroll
                 for (uint32_t q = 0; q < PRE; ++q) head[q] = q < len ? (double)vec[q] : 0.0;
             }
+            PROF(21);
             const double u = rng_canonical(rng);
             uint32_t ub = 0;   // upper_bound over a non-decreasing vector
 #pragma unroll
@@ -1715,6 +1795,7 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
                 norm += f;
                 nz[e] = 2;   // selected in this call (turned into 1 below)
             }
+            PROF(22);
             while (uset_size(plus) < simplex_size) {
                 const uint32_t pos = rng_uniform_int(rng, uset_size(zero));   // uniform_int(0, |zero| - 1)
                 uint32_t e = uset_begin(zero);
@@ -1727,6 +1808,7 @@ __device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx)
                 uset_erase(zero, e);
                 uset_insert(plus, e);
             }
+            PROF(23);
             // "for z in zero: freq = 0, nz = 0, obs = 0": the zero set is exactly the haplotypes not selected above, so the reset
             // runs over the arrays (independent accesses, eight in flight) instead of chasing the set's list links
             {
