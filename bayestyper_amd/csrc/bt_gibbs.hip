@@ -740,7 +740,13 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_HVCOUNT] = nv * d.Hm * d.Vm;
         len[A_UCACHE] = d.uc_width ? ((uint64_t)nv * d.uc_width * d.cache_entries + LANES - 1) / LANES : (uint64_t)nv * d.cache_entries;
         len[A_UCTAG] = nv * (d.cache_mode == 1 ? d.cache_entries : 1);
-        len[A_CUM] = nv * std::max<uint32_t>(d.D2m, 1);
+        {   // teams of copies in sample_diplotypes (narrow tiles with dense tables): min(S, copies)
+            uint32_t stride = 1;
+            while (stride < d.num_lanes) stride *= 2;
+            const uint32_t copies = stride <= 32 && !getenv("BT_GIBBS_NO_COPIES") ? 64u / stride : 1u;
+            d.teams = copies > 1 && d.cache_mode == 0 && S > 1 && !getenv("BT_GIBBS_NO_TEAMS") ? std::min<uint32_t>(S, copies) : 1u;
+        }
+        len[A_CUM] = nv * std::max<uint32_t>(d.D2m, 1) * d.teams;
         len[A_NZLIST] = nv * d.Hm;
         len[A_SIMPLEX] = nv * (d.Hm + 1);
         len[A_SCACHE] = nv * (uint64_t)std::max<uint32_t>(d.scache_n, 1) * std::max<uint32_t>(d.scache_n ? d.scache_len : 1, 1);
@@ -803,6 +809,10 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             d.lds_stride = 1;
             while (d.lds_stride < d.num_lanes) d.lds_stride *= 2;
             uint64_t ho = 0;
+            // tiles of two-haplotype clusters run simple_sweeps(), which keeps the two haplotype sets and the candidate scratch in
+            // registers: those arrays stay in HBM (written once per launch) and the tile's LDS block shrinks by a fifth
+            bool want_simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.lds_stride == LANES && !getenv("BT_GIBBS_NO_SIMPLE");
+            for (uint32_t l = 0; l < d.num_lanes && want_simple; ++l) want_simple = B->num_haplotypes[B->group_cluster_off[shapes[tile_start[ti] + l].g]] == 2;
             // tuning: BT_GIBBS_HOT_SKIP = bit mask over hot_arrs[] of arrays to leave in HBM
             const uint64_t skip_mask = getenv("BT_GIBBS_HOT_SKIP") ? strtoull(getenv("BT_GIBBS_HOT_SKIP"), nullptr, 0) : 0ull;
             int hot_i = -1;
@@ -811,7 +821,8 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 if ((skip_mask >> hot_i) & 1ull) continue;
                 if (a == A_MGEN && d.NMm == 0) continue;          // (only clusters with multicluster k-mers read it)
                 if (a == A_KSCTMP && d.lds_stride == LANES) continue;   // scratch of the k-mer-stats rebuild: LDS only where tiles are narrow
-                if (a == A_CUM && d.D2m > 16) continue;
+                if (a == A_CUM && d.D2m * d.teams > 16) continue;
+                if (want_simple && (a == A_NZLIST || a == A_UNEXT || a == A_ZHDR || a == A_ZBKT || a == A_PHDR || a == A_PBKT || a == A_CUM)) continue;
                 // the dense table of unique-k-mer sums is read for every candidate of every sample: a few entries per lane (two-haplotype
                 // clusters x a few samples) stay in LDS for the launch
                 if (a == A_UCACHE && !(d.cache_mode == 0 && d.uc_width == 0 && d.nvm == 1 && (uint64_t)d.cache_entries * 8 <= 160)) continue;

@@ -136,6 +136,7 @@ struct TileDesc {
     uint32_t simple;                // every group of the tile is one two-haplotype cluster without multicluster k-mers: sweeps run in simple_sweeps()
     uint32_t ring_cap[2], ring_len; // draw-ahead words of the diplotype / frequency generator (powers of two); ring_len = both blocks
     uint32_t prio;                  // the tile's wavefronts raise their issue priority (narrow tiles: the launch's critical path)
+    uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 constexpr uint32_t RESIDENT_ALL = 0xFFFFFFFEu;   // Env/Tile::resident: every vertex of the group has its hot arrays in LDS
@@ -274,7 +275,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
         return UCPtr{b, v * d().cache_entries * LANES + t.lane, LANES};
     }
     __device__ inline SPtr<uint32_t, LANES> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
-    __device__ inline SPtrF<double, LANES> cum() const { return t.harr<double>(A_CUM, v, (d().D2m > 1 ? d().D2m : 1)); }
+    __device__ inline SPtrF<double, LANES> cum() const { return t.harr<double>(A_CUM, v, (d().D2m > 1 ? d().D2m : 1) * (d().teams > 1 ? d().teams : 1)); }
     __device__ inline SPtrF<uint16_t, LANES> nzlist() const { return t.harr<uint16_t>(A_NZLIST, v, d().Hm); }
     __device__ inline SPtr<double, LANES> simplex() const { return a<double>(A_SIMPLEX, d().Hm + 1); }
     __device__ inline SPtr<double, LANES> scache() const { return a<double>(A_SCACHE, (uint32_t)(d().scache_n ? d().scache_n : 1) * (d().scache_len ? d().scache_len : 1)); }
@@ -1417,7 +1418,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
     PROF(12);
     MtRing rng = c.rng(0);
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
-    SPtrF<double, LANES> logf = c.logf(), cum = c.cum();
+    SPtrF<double, LANES> logf = c.logf();
     SPtrF<uint16_t, LANES> dip = c.dip();
     uint32_t nnz = 0;
     {
@@ -1426,7 +1427,24 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             if (nz[h]) nzl[nnz++] = (uint16_t)h;
     }
     PROF(0);
-    for (uint32_t s = 0; s < P.S; ++s) {
+    // The S draws of a visit are independent of each other — a sample's candidates depend on the frequencies and on its own
+    // multicluster state only, and every sample consumes exactly one uniform — so the copies of a narrow tile form `T` teams that
+    // draw T samples at a time (team t takes sample s0 + t; inside a team the candidate blocks are shared as before).  The uniforms
+    // are taken from the generator in sample order by every copy, and the picks are applied in sample order by every copy.
+    const uint32_t T = c.t.copies > 1u && c.d().teams > 1u ? c.d().teams : 1u;
+    const uint32_t tsz = c.t.copies / T, team = c.t.part / tsz, tpart = c.t.part - team * tsz;   // team >= T: no sample this round
+    const uint32_t cw = 64u / c.t.copies, gl = (threadIdx.x & 63u) % cw, tlane0 = gl + team * tsz * cw;
+    SPtrF<double, LANES> cum = c.cum() + (team < T ? team : 0u) * (c.d().D2m > 1 ? c.d().D2m : 1);
+    for (uint32_t s0 = 0; s0 < P.S; s0 += T) {
+      double u01 = 0;
+      for (uint32_t j = 0; j < T && s0 + j < P.S; ++j) {   // LogDiscreteSampler::sample draws even for a single outcome (DiscreteSampler.cpp:120-125)
+          const double u = rng_canonical(rng);
+          if (j == team) u01 = u;
+      }
+      PROF(24);
+      const uint32_t s = s0 + team;
+      uint32_t mine = 0xFFFFFFFFu;
+      if (team < T && s < P.S) {
         const uint16_t p1 = dip[2 * s], p2 = dip[2 * s + 1];
         const uint8_t ploidy = c.nest_ploidy()[s];
         uint32_t gen = 0;
@@ -1444,7 +1462,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         // the picked interval — about once in 10^5..10^6 draws — the reference's chain is evaluated after all.
         const uint32_t total = ploidy == 2 ? nnz * (nnz + 1) / 2 : (ploidy == 1 ? nnz : 0u);
         const bool chain_only = total <= BT_LINEAR_DRAW_MIN;
-        const bool par = !chain_only && c.t.copies > 1u;
+        const bool par = !chain_only && tsz > 1u;
         double lpmax = 0;
         // lp of every candidate -> cum[0..total), in order; returns through lpmax the maximum
         // Evaluated in blocks of 8: the cache words of a whole block are requested first (independent loads, one memory round trip
@@ -1477,10 +1495,10 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
             };
             // with copies of the group in the wavefront (Tile::part) every copy evaluates every copies-th block (dense tables: a slot
             // is private to a candidate; hashed tables: a slot is private to a copy, see hashed_slot)
-            const uint32_t stride_blocks = par ? c.t.copies : 1u;
-            if (par) advance(8u * c.t.part);
+            const uint32_t stride_blocks = par ? tsz : 1u;
+            if (par) advance(8u * tpart);
             lpmax = -__builtin_huge_val();
-            for (uint32_t base = par ? 8u * c.t.part : 0u; base < total; base += 8u * stride_blocks) {
+            for (uint32_t base = par ? 8u * tpart : 0u; base < total; base += 8u * stride_blocks) {
                 const uint32_t nb = total - base < 8 ? total - base : 8;
                 uint16_t ha[8], hb[8];
                 uint32_t uslot[8], ukey[8];
@@ -1549,9 +1567,10 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                 }
                 if (par) advance(8u * (stride_blocks - 1u));
             }
-            if (par) {   // maximum over the copies (lanes lane, lane + 64/copies, ...), then make their cum[] entries visible
-                for (uint32_t m = 64u / c.t.copies; m < 64u; m <<= 1) {
-                    const double o = __shfl_xor(lpmax, (int)m);
+            if (par) {   // maximum over the team's copies (lanes tlane0, tlane0 + cw, ...), then make their cum[] entries visible
+                const double own = lpmax;
+                for (uint32_t m = 0; m < tsz; ++m) {
+                    const double o = __shfl(own, (int)(tlane0 + m * cw));
                     lpmax = o > lpmax ? o : lpmax;
                 }
                 copies_sync();
@@ -1576,8 +1595,6 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         };
         // LogDiscreteSampler::sample (DiscreteSampler.cpp:120-125): the draw happens even for a single outcome.  (The evaluation of
         // the candidates consumes no random numbers, so drawing first does not change the stream.)
-        const double u01 = rng_canonical(rng);
-        PROF(24);
         uint32_t pick = 0;
         // one evaluation site (the blocked evaluation is large: instantiating it twice would not fit the instruction cache)
         for (bool exact = chain_only;; exact = true) {
@@ -1596,8 +1613,8 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                 // against the reference's chain below), so their summation order is free: every copy takes one contiguous segment of the
                 // candidates — exponentials and a local running sum in registers —, the segment totals are exchanged with lane shuffles,
                 // and every copy searches the one segment that holds U * total.
-                const uint32_t ncp = c.t.copies, cw = 64u / ncp, L = (total + ncp - 1u) / ncp;
-                const uint32_t i0 = c.t.part * L < total ? c.t.part * L : total, i1 = i0 + L < total ? i0 + L : total;
+                const uint32_t ncp = tsz, L = (total + ncp - 1u) / ncp;
+                const uint32_t i0 = tpart * L < total ? tpart * L : total, i1 = i0 + L < total ? i0 + L : total;
                 double run = 0;
                 for (uint32_t b0 = i0; b0 < i1; b0 += 8) {
                     double e[8];
@@ -1613,12 +1630,11 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
                             cum[b0 + q] = run;
                         }
                 }
-                const uint32_t gl = (threadIdx.x & 63u) % cw;
-                for (uint32_t m = 0; m < ncp; ++m) acc += __shfl(run, (int)(gl + m * cw));
+                for (uint32_t m = 0; m < ncp; ++m) acc += __shfl(run, (int)(tlane0 + m * cw));
                 thr = u01 * acc;
                 uint32_t seg = ncp;
                 for (uint32_t m = 0; m < ncp; ++m) {
-                    const double tseg = __shfl(run, (int)(gl + m * cw));
+                    const double tseg = __shfl(run, (int)(tlane0 + m * cw));
                     if (seg == ncp) {
                         if (thr < off + tseg) seg = m;
                         else off += tseg;
@@ -1664,15 +1680,24 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
         } else if (ploidy == 1) {
             h1 = nzl[pick];
         }
-        PROF(3);
-        dip[2 * s] = h1;
-        dip[2 * s + 1] = h2;
+        mine = (uint32_t)h1 | ((uint32_t)h2 << 16);
+      }
+      if (T > 1u) copies_sync();
+      PROF(3);
+      for (uint32_t j = 0; j < T && s0 + j < P.S; ++j) {   // apply the round's picks in sample order (every copy)
+        const uint32_t ss = s0 + j;
+        const uint32_t hh = T > 1u ? (uint32_t)__shfl((int)mine, (int)(gl + j * tsz * cw)) : mine;
+        const uint16_t h1 = (uint16_t)(hh & 0xFFFFu), h2 = (uint16_t)(hh >> 16);
+        const uint16_t p1 = dip[2 * ss], p2 = dip[2 * ss + 1];
+        dip[2 * ss] = h1;
+        dip[2 * ss + 1] = h2;
         hfd_increment(c, h1, is_sparse, hap_count);
         hfd_increment(c, h2, is_sparse, hap_count);
         PROF(4);
-        update_multicluster_multiplicities(c, P, h1, h2, p1, p2, s, nsub_m);
+        update_multicluster_multiplicities(c, P, h1, h2, p1, p2, ss, nsub_m);
         PROF(5);
-        if (tracing) trace_row[s] = (uint32_t)h1 | ((uint32_t)h2 << 16);
+        if (tracing) trace_row[ss] = hh;
+      }
     }
     mt_close(rng);
     sc[SC_HAP_COUNT] = hap_count;
