@@ -421,7 +421,7 @@ const uint32_t kClassLds[] = {16384, 32768, 65536, 0xFFFFFFFFu};
 
 // element sizes per array, in TileArr order
 const uint32_t kElemSize[A_COUNT] = {
-    /*A_M*/ 1, /*HASC*/ 1, /*COUNTS*/ 1, /*IC*/ 1, /*SHARED*/ 4, /*KVOFF*/ 4, /*KVVAR*/ 2, /*KVBITS*/ 4, /*HAPAL*/ 2, /*HNOFF*/ 4, /*HNIDX*/ 4, /*VARNA*/ 2,
+    /*A_M*/ 1, /*HASC*/ 1, /*COUNTS*/ 1, /*IC*/ 1, /*SHARED*/ 4, /*KVOFF*/ 4, /*KVVAR*/ 2, /*KVBITS*/ 4, /*HAPAL*/ 2, /*HAPCELL*/ 4, /*HNOFF*/ 4, /*HNIDX*/ 4, /*VARNA*/ 2,
     /*VARDEP*/ 1, /*ALBASE*/ 4, /*NDCL*/ 4, /*NDVOFF*/ 4, /*NDVAR*/ 2, /*UNIQ0*/ 4, /*MULTI0*/ 4, /*EDGES0*/ 4, /*VDIMS*/ 4, /*VDIMS2*/ 4, /*GDIMS*/ 4,
     /*SOURCES0*/ 4, /*PLOIDY*/ 1,
     /*MT*/ 4, /*FNDSAVED*/ 8, /*SPARSITY*/ 8, /*UNIQ*/ 4, /*MULTI*/ 4, /*USUB*/ 4, /*MSUB*/ 4, /*SMM*/ 1, /*DIP*/ 2, /*FREQ*/ 8, /*OBS*/ 4, /*NZ*/ 1,
@@ -532,6 +532,10 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         uint32_t A = 0;
         for (uint32_t v = 0; v < V; ++v) A += B->var_num_alleles[var_base[c] + v];
         g->h_A[c] = A;
+        if (V >= 0xFFFFu || A >= 65536u) {   // A_HAPCELL packs a variant index and an allele cell into 16 bits each
+            bt_gibbs_destroy(g);
+            return fail("bt_gibbs_create: cluster with 65535 or more variants / 65536 or more alleles");
+        }
     }
 
     // ---- order groups by shape (vertices, haplotypes, k-mers: descending) and cut into tiles of 64 ----
@@ -708,6 +712,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_KVVAR] = nv * d.NNZm;
         len[A_KVBITS] = nv * (uint64_t)d.NNZm * d.HWm;
         len[A_HAPAL] = nv * d.Hm * d.Vm;
+        len[A_HAPCELL] = nv * d.Hm * d.Vm;
         len[A_HNOFF] = nv * (d.Hm + 1);
         len[A_HNIDX] = nv * d.HNm;
         len[A_VARNA] = nv * d.Vm;
@@ -949,6 +954,16 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 const uint32_t hn0 = B->hapnest_off[hap_base[c]];
                 for (uint32_t h = 0; h < H; ++h) {
                     for (uint32_t vv = 0; vv < V; ++vv) put<uint16_t>(img, d, A_HAPAL, (v * d.Hm + h) * d.Vm + vv, l, B->hap_allele[hapvar_off[c] + (size_t)h * V + vv]);
+                    {   // A_HAPCELL: addHaplotypeKmerStats' source variant (VariantClusterHaplotypes.cpp:332-358) and the allele cell, per (haplotype, variant)
+                        uint32_t last_non_missing = 0xFFFFu, albase = 0;
+                        for (uint32_t vv = 0; vv < V; ++vv) {
+                            const uint32_t al = B->hap_allele[hapvar_off[c] + (size_t)h * V + vv], na = B->var_num_alleles[var_base[c] + vv];
+                            const bool missing = B->var_has_dependency[var_base[c] + vv] && al == na - 1u;
+                            if (!missing) last_non_missing = vv;
+                            put<uint32_t>(img, d, A_HAPCELL, (v * d.Hm + h) * d.Vm + vv, l, last_non_missing | ((albase + al) << 16));
+                            albase += na;
+                        }
+                    }
                     put<uint32_t>(img, d, A_HNOFF, v * (d.Hm + 1) + h, l, B->hapnest_off[hap_base[c] + h] - hn0);
                 }
                 put<uint32_t>(img, d, A_HNOFF, v * (d.Hm + 1) + H, l, B->hapnest_off[hap_base[c] + H] - hn0);

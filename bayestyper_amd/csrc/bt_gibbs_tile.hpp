@@ -48,6 +48,9 @@ enum TileArr {
     A_KVVAR,        // u16 [V] NNZm
     A_KVBITS,       // u32 [V] NNZm*HWm
     A_HAPAL,        // u16 [V] Hm*Vm      index h*Vm + v
+    A_HAPCELL,      // u32 [V] Hm*Vm      index h*Vm + v: low 16 bits = the variant whose k-mer stats haplotype h contributes to variant v (v itself, or the last
+                    //                    variant before v without a missing allele when h's allele of v is the missing one; 0xFFFF: none), high 16 bits =
+                    //                    allele cell of (v, allele of h) within a sample's allele statistics (ALBASE[v] + allele)
     A_HNOFF,        // u32 [V] Hm+1
     A_HNIDX,        // u32 [V] HNm
     A_VARNA,        // u16 [V] Vm
@@ -228,6 +231,8 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint32_t kv_off(uint32_t k) const { return a<uint32_t>(A_KVOFF, d().Km + 1)[k]; }
     __device__ inline uint16_t kv_var(uint32_t e) const { return a<uint16_t>(A_KVVAR, d().NNZm)[e]; }
     __device__ inline bool kv_bit(uint32_t e, uint32_t h) const { return (a<uint32_t>(A_KVBITS, (uint32_t)d().NNZm * d().HWm)[(uint32_t)e * d().HWm + (h >> 5)] >> (h & 31u)) & 1u; }
+    __device__ inline uint32_t hap_cell(uint32_t h, uint32_t var) const { return a<uint32_t>(A_HAPCELL, (uint32_t)d().Hm * d().Vm)[(uint32_t)h * d().Vm + var]; }
+    __device__ inline SPtr<double, LANES> astats_cell(uint32_t s, uint32_t cell) const { return a<double>(A_ASTATS, (uint32_t)d().S * d().Am * 12) + ((uint32_t)s * d().Am + cell) * 12; }
     __device__ inline uint16_t hap_allele(uint32_t h, uint32_t var) const { return a<uint16_t>(A_HAPAL, (uint32_t)d().Hm * d().Vm)[(uint32_t)h * d().Vm + var]; }
     __device__ inline uint32_t hn_off(uint32_t h) const { return a<uint32_t>(A_HNOFF, d().Hm + 1)[h]; }
     __device__ inline uint32_t hn_idx(uint32_t i) const { return a<uint32_t>(A_HNIDX, d().HNm)[i]; }
@@ -1182,83 +1187,91 @@ __device__ inline void ks_chain_rep(KS &k, double v1, bool en1, double v2, bool 
     else if (en2) ks_add_rep(k, v2, r);
 }
 __device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t r, uint32_t nn) {
-    dip_table_add(c, P, h1, h2, s, r);
     const uint32_t V = c.V;
-    const bool two = h1 != NOHAP && h2 != NOHAP;
-    for (uint32_t item = c.t.part; item < 3 * V; item += c.t.copies) {
-        const uint32_t var = item / 3u, st = item - var * 3u;
-        // the source variant of each haplotype (add_haplotype_kmer_stats' missing-allele rule: a missing allele takes the stats of the
-        // last variant before it whose allele is not missing)
-        uint32_t a1 = 0, a2 = 0, src1 = 0xFFFFFFFFu, src2 = 0xFFFFFFFFu;
-        if (h1 != NOHAP) {
-            for (uint32_t w = 0; w <= var; ++w) {
-                const bool dep = c.var_dep(w);
-                const uint32_t last = (uint32_t)c.var_na(w) - 1u;
-                a1 = c.hap_allele(h1, w);
-                if (!(dep && a1 == last)) src1 = w;
-                else if (w == var && src1 == 0xFFFFFFFFu) src1 = 0xFFFFFFFEu;   // missing with nothing before it: no contribution
-                if (two) {
-                    a2 = c.hap_allele(h2, w);
-                    if (!(dep && a2 == last)) src2 = w;
-                    else if (w == var && src2 == 0xFFFFFFFFu) src2 = 0xFFFFFFFEu;
-                }
-            }
-        }
-        const bool ok1 = src1 < 0xFFFFFFFEu, ok2 = src2 < 0xFFFFFFFEu;
-        double v1 = 0, v2 = 0;
-        bool en1 = false, en2 = false;
-        if (ok1) {
-            SPtr<double, LANES> q = c.ksc(s, 0, src1);
-            const double cnt = q[0];
-            v1 = st == 0 ? cnt : (double)q[st];
-            en1 = st == 0 || cnt != 0.0;
-        }
-        if (ok2) {
-            SPtr<double, LANES> q = c.ksc(s, 1, src2);
-            const double cnt = q[0];
-            v2 = st == 0 ? cnt : (double)q[st];
-            en2 = st == 0 || cnt != 0.0;
-        }
-        double nv[2] = {0, 0};
-        bool nen[2] = {false, false};
-        for (uint32_t j = 0; j < nn && j < 2u; ++j) {
-            SPtr<double, LANES> q = c.nest_stats(s, j);
-            const double cnt = q[0];
-            nv[j] = st == 0 ? cnt : (double)q[st];
-            nen[j] = st == 0 || cnt != 0.0;
-        }
-        const uint32_t anest = (uint32_t)c.var_na(var) - 1u;
-        // the chain(s): at most three cells of this variant, each loaded and stored once
-        uint32_t cur = 0xFFFFFFFFu;
-        KS acc{0, 0, 0, 0};
-        auto sel = [&](uint32_t allele) {
-            if (cur == allele) return;
-            if (cur != 0xFFFFFFFFu) ks_store(c.astats(s, var, cur) + 4u * st, acc);
-            acc = ks_load(c.astats(s, var, allele) + 4u * st);
-            cur = allele;
-        };
-        if (ok1 && ok2 && a1 == a2) {
-            if (en1 || en2) {
-                sel(a1);
-                ks_chain_rep(acc, v1, en1, v2, en2, r);
-            }
-        } else {
-            if (ok1 && en1) {
-                sel(a1);
-                ks_add_rep(acc, v1, r);
-            }
-            if (ok2 && en2) {
-                sel(a2);
-                ks_add_rep(acc, v2, r);
-            }
-        }
-        for (uint32_t j = 0; j < nn && j < 2u; ++j)
-            if (nen[j]) {
-                sel(anest);
-                ks_add_r(acc, nv[j]);
-            }
-        if (cur != 0xFFFFFFFFu) ks_store(c.astats(s, var, cur) + 4u * st, acc);
+    const bool one = h1 != NOHAP, two = one && h2 != NOHAP;
+    // nested sources (the same for every variant)
+    double ncnt[2] = {0, 0}, nf[2] = {0, 0}, nm[2] = {0, 0};
+    for (uint32_t j = 0; j < nn && j < 2u; ++j) {
+        SPtr<double, LANES> q = c.nest_stats(s, j);
+        ncnt[j] = q[0];
+        nf[j] = q[1];
+        nm[j] = q[2];
     }
+    // Items in batches of three per copy: all descriptors first, then all sources and cells, then the chains, then the stores — a batch
+    // costs three dependent memory round trips instead of that many per item.
+    constexpr uint32_t NB = 3;
+    for (uint32_t base = c.t.part; base < 3 * V; base += NB * c.t.copies) {
+        uint32_t var[NB], st[NB], d1[NB], d2[NB], cn[NB];
+        bool live[NB];
+#pragma unroll
+        for (uint32_t b = 0; b < NB; ++b) {
+            const uint32_t item = base + b * c.t.copies;
+            live[b] = item < 3 * V;
+            var[b] = live[b] ? item / 3u : 0u;
+            st[b] = live[b] ? item - var[b] * 3u : 0u;
+            d1[b] = one ? c.hap_cell(h1, var[b]) : 0xFFFFu;
+            d2[b] = two ? c.hap_cell(h2, var[b]) : 0xFFFFu;
+            cn[b] = nn ? c.allele_base(var[b]) + (uint32_t)c.var_na(var[b]) - 1u : 0u;   // addNestedHaplotypeKmerStats' cell: the variant's last allele
+        }
+        double v1[NB], v2[NB];
+        bool en1[NB], en2[NB];
+        KS k1[NB], k2[NB], k3[NB];   // the (at most three) cells of the item: haplotype 1's, haplotype 2's, the nested one
+        uint32_t c1[NB], c2[NB];
+#pragma unroll
+        for (uint32_t b = 0; b < NB; ++b) {
+            const bool ok1 = live[b] && (d1[b] & 0xFFFFu) != 0xFFFFu, ok2 = live[b] && (d2[b] & 0xFFFFu) != 0xFFFFu;
+            c1[b] = d1[b] >> 16;
+            c2[b] = d2[b] >> 16;
+            v1[b] = v2[b] = 0;
+            en1[b] = en2[b] = false;
+            if (ok1) {
+                SPtr<double, LANES> q = c.ksc(s, 0, d1[b] & 0xFFFFu);
+                const double cnt = q[0], val = q[st[b]];
+                v1[b] = val;
+                en1[b] = st[b] == 0 || cnt != 0.0;
+            }
+            if (ok2) {
+                SPtr<double, LANES> q = c.ksc(s, 1, d2[b] & 0xFFFFu);
+                const double cnt = q[0], val = q[st[b]];
+                v2[b] = val;
+                en2[b] = st[b] == 0 || cnt != 0.0;
+            }
+            k1[b] = k2[b] = k3[b] = KS{0, 0, 0, 0};
+            if (en1[b]) k1[b] = ks_load(c.astats_cell(s, c1[b]) + 4u * st[b]);
+            if (en2[b] && !(en1[b] && c2[b] == c1[b])) k2[b] = ks_load(c.astats_cell(s, c2[b]) + 4u * st[b]);
+            if (live[b] && nn && !((en1[b] && cn[b] == c1[b]) || (en2[b] && cn[b] == c2[b]))) k3[b] = ks_load(c.astats_cell(s, cn[b]) + 4u * st[b]);
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < NB; ++b) {
+            if (!live[b]) continue;
+            const bool same12 = en1[b] && en2[b] && c1[b] == c2[b];
+            if (same12) ks_chain_rep(k1[b], v1[b], true, v2[b], true, r);
+            else {
+                if (en1[b]) ks_add_rep(k1[b], v1[b], r);
+                if (en2[b]) ks_add_rep(k2[b], v2[b], r);
+            }
+            // the nested contributions go to whichever register copy holds their cell
+            for (uint32_t j = 0; j < nn && j < 2u; ++j) {
+                const double val = st[b] == 0 ? ncnt[j] : (st[b] == 1 ? nf[j] : nm[j]);
+                if (!(st[b] == 0 || ncnt[j] != 0.0)) continue;
+                if (en1[b] && cn[b] == c1[b]) ks_add_r(k1[b], val);
+                else if (en2[b] && cn[b] == c2[b]) ks_add_r(k2[b], val);
+                else ks_add_r(k3[b], val);
+            }
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < NB; ++b) {
+            if (!live[b]) continue;
+            if (en1[b]) ks_store(c.astats_cell(s, c1[b]) + 4u * st[b], k1[b]);
+            if (en2[b] && !(en1[b] && c2[b] == c1[b])) ks_store(c.astats_cell(s, c2[b]) + 4u * st[b], k2[b]);
+            if (nn && !((en1[b] && cn[b] == c1[b]) || (en2[b] && cn[b] == c2[b]))) {
+                bool any = false;
+                for (uint32_t j = 0; j < nn && j < 2u; ++j) any = any || st[b] == 0 || ncnt[j] != 0.0;
+                if (any) ks_store(c.astats_cell(s, cn[b]) + 4u * st[b], k3[b]);
+            }
+        }
+    }
+    dip_table_add(c, P, h1, h2, s, r);
     if (c.t.copies > 1u) copies_sync();
 }
 

@@ -11,7 +11,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 150_000
 which = sys.argv[3] if len(sys.argv) > 3 else "+ABCD"
 ctx = lib.Ctx(0)
-flat = synth.make_mixture(G, S, seed=1000)
+flat = synth.make_mixture(G, S, seed=1000, hetero=not os.environ.get("BT_HOMO"))
 lut_g, lut_n = count_model.build_luts(S, mean=15.0, var=30.0, noise_rate=0.05)
 bounds, at = {}, 0
 for shape in ("D", "C", "B", "A"):
