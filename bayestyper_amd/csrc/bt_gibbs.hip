@@ -589,9 +589,9 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         // slowest lane's sequential program, so few groups per wavefront (+ copies that share the data-parallel phases) finish a group
         // sooner AND need little LDS per tile, which keeps many tiles resident; launches with more narrow tiles than wavefront slots
         // simply run them in rounds next to the two-haplotype tiles (12.0 s at widths 8 / 16, 12.2 s at 4 / 16, 14.6 s at 16 / 32,
-        // 21.3 s at 64 / 64).  Four per wavefront while one round holds them all (<= 3 tiles per CU), eight beyond that (half the HBM);
-        // single clusters with 6..15 candidates sixteen.  `relax` (the batch does not fit the free HBM) doubles both.
-        uint32_t width_x = (uint64_t)n_x <= (uint64_t)kMinTileWidth * (3 * 256) ? kMinTileWidth : 2 * kMinTileWidth, width_y = 16;
+        // 21.3 s at 64 / 64 before the copies worked in teams).  Four per wavefront; single clusters with 6..15 candidates sixteen.
+        // `relax` (the batch does not fit the free HBM) doubles both.
+        uint32_t width_x = kMinTileWidth, width_y = 16;   // (r02, after the copies' teams: 10.2 s at 4 / 16 against 10.6 s at 8 / 16 and 11.4 s at 8 / 32)
         width_x = std::min<uint32_t>(LANES, width_x << relax);
         width_y = std::min<uint32_t>(LANES, width_y << relax);
         if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {

@@ -1399,6 +1399,9 @@ __device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uin
     for (uint32_t s = 0; s < P.S; ++s) {
         const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
 #ifndef ABL_NODEFER
+#ifdef BT_NODEFER_NARROW
+        if (c.t.copies == 1u)
+#endif
         if (pvalid[s] && !upd[s] && c.nest_n()[s] == 0 && pdip[2 * s] == h1 && pdip[2 * s + 1] == h2) {
             c.pend()[s] += 1;
             continue;
