@@ -166,19 +166,281 @@ __global__ __launch_bounds__(BLOCK) void classify_tally_kernel(const uint32_t *_
 }
 
 // ---- countPathMultigroupKmers: D counts distinct (group, k-mer) pairs, E tracks per k-mer the first group seen and "another group too" ----
+// ---- countPathMultigroupKmers in the reference's single-thread order (KmerCounter.cpp:105-145) ----
+// The reference walks the groups in index order; a group's distinct path k-mers sit in ONE std::unordered_set<std::bitset<2k>> that
+// is clear()ed between groups (its bucket count survives) and are visited in that container's iteration order.  A k-mer the path
+// filter reports at that moment goes into the multigroup table — because an earlier group (or unit) holds it, or as a false positive
+// of what has been inserted SO FAR — and is otherwise inserted.  Reproduced exactly:
+//   1. every distinct (group, k-mer) gets its time t = (k-mers of earlier groups) + (rank in its group's iteration order): the
+//      container (libstdc++ _Hashtable, unique keys, std::hash<bitset> = _Hash_bytes, prime rehash policy) is replayed per group by
+//      one lane from the k-mers' first occurrences in path order;
+//   2. a k-mer is reported at its first time t iff every one of its filter bits was set before t.  A k-mer that is reported is not
+//      inserted, but all its bits are set already, so "first time bit b is set" = min t over ALL k-mers having b (0 for bits set by
+//      earlier units): no fixed point is needed;
+//   3. only k-mers whose bits are ALL either set by earlier units or shared with another k-mer of the unit (a second bit array filled
+//      while a scratch copy of the filter takes the unit's k-mers) can qualify — a few per 10^4 —, so the per-bit times are kept in
+//      a small hash table over just those k-mers' bits.
+constexpr uint32_t SQ_NONE = 0xFFFFFFFFu, SQ_BEFORE = 0xFFFFFFFEu;
+// std::hash<std::bitset<2k>>: _Hash_bytes (libstdc++-v3/libsupc++/hash_bytes.cc, 64-bit) over the bitset's first (2k + 7) / 8 bytes, seed 0xc70f6907
+__host__ __device__ inline uint64_t std_hash_bitset(uint64_t lo, uint64_t hi, unsigned k) {
+    const uint64_t mul = (0xc6a4a793ULL << 32) + 0x5bd1e995ULL;
+    const unsigned len = (2 * k + 7) / 8, full = len / 8;
+    uint64_t hash = 0xc70f6907ULL ^ (len * mul);
+    const uint64_t w[3] = {lo, hi, 0};
+    for (unsigned i = 0; i < full; ++i) {
+        uint64_t data = w[i] * mul;
+        data ^= data >> 47;
+        data *= mul;
+        hash ^= data;
+        hash *= mul;
+    }
+    if (len & 7u) {
+        hash ^= w[full] & ((1ULL << (8u * (len & 7u))) - 1ULL);
+        hash *= mul;
+    }
+    hash ^= hash >> 47;
+    hash *= mul;
+    hash ^= hash >> 47;
+    return hash;
+}
+// libstdc++'s bucket counts when a container grows one element at a time: 1 -> 13 -> _M_next_bkt(2 B) -> ...
+__host__ __device__ inline uint64_t std_next_bucket_count(uint64_t b) {
+    const uint64_t chain[31] = {13ull, 29ull, 59ull, 127ull, 257ull, 541ull, 1109ull, 2357ull, 5087ull, 10273ull, 20753ull, 42043ull, 85229ull, 172933ull, 351061ull, 712697ull,
+                                1447153ull, 2938679ull, 5967347ull, 12117689ull, 24607243ull, 49969847ull, 101473717ull, 206062531ull, 418451333ull, 849749479ull,
+                                1725587117ull, 3504151727ull, 8589934583ull, 25769803693ull, 68719476731ull};
+    for (int i = 0; i < 31; ++i)
+        if (chain[i] > b) return chain[i];
+    return chain[30];
+}
+
+// first pass: the (k-mer, group) index D with the first text position of every entry, the k-mer index E with "seen in two groups"
 __global__ __launch_bounds__(BLOCK) void multigroup_kernel(uint64_t *__restrict__ dlo, uint64_t *__restrict__ dhi, uint32_t *__restrict__ dtag, uint32_t *__restrict__ dstate,
-                                                            uint64_t *__restrict__ elo, uint64_t *__restrict__ ehi, uint32_t *__restrict__ etag, uint32_t *__restrict__ estate,
-                                                            uint32_t *__restrict__ egroup, uint32_t *__restrict__ emulti, uint64_t mask, const uint64_t *__restrict__ kmers,
-                                                            const uint8_t *__restrict__ valid, const uint32_t *__restrict__ pos_path, const uint32_t *__restrict__ path_cluster,
+                                                            uint32_t *__restrict__ dfirst, uint32_t *__restrict__ pos_d, uint64_t *__restrict__ elo, uint64_t *__restrict__ ehi,
+                                                            uint32_t *__restrict__ etag, uint32_t *__restrict__ estate, uint32_t *__restrict__ egroup,
+                                                            uint32_t *__restrict__ emulti, uint64_t mask, const uint64_t *__restrict__ kmers, const uint8_t *__restrict__ valid,
+                                                            const uint32_t *__restrict__ pos_path, const uint32_t *__restrict__ path_cluster,
                                                             const uint32_t *__restrict__ cluster_group, uint64_t L) {
     for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK) {
         if (!valid[pos]) continue;
         const uint64_t lo = kmers[2 * pos], hi = kmers[2 * pos + 1];
         const uint32_t g = cluster_group[path_cluster[pos_path[pos]]];
-        index_insert(dlo, dhi, dtag, dstate, mask, lo, hi, g);
+        const uint64_t d = index_insert(dlo, dhi, dtag, dstate, mask, lo, hi, g);
+        atomicMin(&dfirst[d], (uint32_t)pos);
+        pos_d[pos] = (uint32_t)d;
         const uint64_t e = index_insert(elo, ehi, etag, estate, mask, lo, hi, 0u);
         const uint32_t prev = atomicCAS(&egroup[e], 0xFFFFFFFFu, g);
         if (prev != 0xFFFFFFFFu && prev != g) emulti[e] = 1u;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void mg_flag_kernel(const uint8_t *__restrict__ valid, const uint32_t *__restrict__ pos_d, const uint32_t *__restrict__ dfirst, uint64_t L,
+                                                         uint32_t *__restrict__ flag) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK)
+        flag[pos] = (valid[pos] && dfirst[pos_d[pos]] == (uint32_t)pos) ? 1u : 0u;
+}
+__global__ __launch_bounds__(BLOCK) void mg_seq_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ rowpos, uint64_t L, uint32_t *__restrict__ seq_pos) {
+    for (uint64_t pos = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; pos < L; pos += (uint64_t)gridDim.x * BLOCK)
+        if (flag[pos]) seq_pos[rowpos[pos]] = (uint32_t)pos;
+}
+// One lane per group: replay the inserts of the group's distinct k-mers (first occurrences, path order) into an unordered_set that
+// starts with `b_init[g]` buckets (what earlier groups left behind), then number the nodes in iteration order.
+// libstdc++ _Hashtable: a node enters at the front of its bucket (behind the bucket's "before" node) or, for an empty bucket, at the
+// front of the whole list; a rehash re-threads the list front to back the same way (hashtable.h: _M_insert_bucket_begin, _M_rehash_aux).
+// The bucket array itself is not materialised (a small group may inherit millions of buckets from a large earlier one): the buckets in
+// use live in a per-group open-addressing map bucket -> "before" node with room for twice the group's k-mers.
+__global__ __launch_bounds__(BLOCK) void mg_order_kernel(const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ seq_pos, const uint32_t *__restrict__ goff,
+                                                          const uint64_t *__restrict__ moff, const uint64_t *__restrict__ b_init, uint32_t *__restrict__ next,
+                                                          uint32_t *__restrict__ map_key, uint32_t *__restrict__ map_val, uint32_t *__restrict__ time_of_seq, uint32_t G,
+                                                          unsigned k) {
+    const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t i0 = goff[g], n = goff[g + 1] - i0;
+    if (n == 0) return;
+    uint32_t *nx = next + i0, *mk = map_key + moff[g], *mv = map_val + moff[g];
+    const uint32_t mmask = (uint32_t)(moff[g + 1] - moff[g]) - 1u;
+    uint64_t B = b_init[g], next_resize = B > 1 ? B : 0;
+    uint32_t head = SQ_NONE;
+    auto bucket_of = [&](uint32_t node) {
+        const uint32_t pos = seq_pos[i0 + node];
+        return (uint32_t)(std_hash_bitset(kmers[2 * (uint64_t)pos], kmers[2 * (uint64_t)pos + 1], k) % B);
+    };
+    auto map_clear = [&]() {
+        for (uint32_t i = 0; i <= mmask; ++i) mk[i] = SQ_NONE;
+    };
+    auto map_slot = [&](uint32_t b) {   // slot of bucket b (inserted empty when absent)
+        uint32_t i = (b * 2654435761u) & mmask;
+        while (mk[i] != b) {
+            if (mk[i] == SQ_NONE) {
+                mk[i] = b;
+                mv[i] = SQ_NONE;
+                break;
+            }
+            i = (i + 1) & mmask;
+        }
+        return i;
+    };
+    map_clear();
+    for (uint32_t e = 0; e < n; ++e) {
+        if ((uint64_t)e + 1 > next_resize) {   // _Prime_rehash_policy::_M_need_rehash(B, e, 1), max_load_factor 1
+            uint64_t min_bkts = (uint64_t)e + 1;
+            if (next_resize == 0 && min_bkts < 11) min_bkts = 11;
+            if (min_bkts >= B) {
+                B = std_next_bucket_count(B);   // _M_next_bkt(max(min_bkts + 1, 2 B)) for one-at-a-time growth
+                next_resize = B;
+                map_clear();
+                uint32_t p = head, bbegin = SQ_NONE;   // bbegin: map slot of the bucket that currently begins the list
+                head = SQ_NONE;
+                while (p != SQ_NONE) {
+                    const uint32_t nxt = nx[p], sl = map_slot(bucket_of(p));
+                    if (mv[sl] == SQ_NONE) {
+                        nx[p] = head;
+                        head = p;
+                        mv[sl] = SQ_BEFORE;
+                        if (nx[p] != SQ_NONE) mv[bbegin] = p;
+                        bbegin = sl;
+                    } else {
+                        const uint32_t prev = mv[sl];
+                        if (prev == SQ_BEFORE) {
+                            nx[p] = head;
+                            head = p;
+                        } else {
+                            nx[p] = nx[prev];
+                            nx[prev] = p;
+                        }
+                    }
+                    p = nxt;
+                }
+            } else
+                next_resize = B;
+        }
+        const uint32_t sl = map_slot(bucket_of(e));
+        if (mv[sl] != SQ_NONE) {
+            const uint32_t prev = mv[sl];
+            if (prev == SQ_BEFORE) {
+                nx[e] = head;
+                head = e;
+            } else {
+                nx[e] = nx[prev];
+                nx[prev] = e;
+            }
+        } else {
+            nx[e] = head;
+            head = e;
+            if (nx[e] != SQ_NONE) mv[map_slot(bucket_of(nx[e]))] = e;
+            mv[sl] = SQ_BEFORE;
+        }
+    }
+    uint32_t rank = 0;
+#ifdef BT_MG_INSERTION_ORDER   // (test of the tests: with insertion order instead of the container's order the parity test must fail)
+    for (uint32_t p = 0; p < n; ++p) time_of_seq[i0 + p] = i0 + p + 1u;
+    return;
+#endif
+    for (uint32_t p = head; p != SQ_NONE; p = nx[p]) time_of_seq[i0 + p] = i0 + (rank++) + 1u;   // times start at 1: 0 = "set by an earlier unit"
+}
+// first time of every distinct k-mer of the unit
+__global__ __launch_bounds__(BLOCK) void mg_etime_kernel(const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ seq_pos, const uint32_t *__restrict__ time_of_seq,
+                                                          uint64_t n, uint64_t *__restrict__ elo, uint64_t *__restrict__ ehi, uint32_t *__restrict__ etag,
+                                                          uint32_t *__restrict__ estate, uint64_t mask, uint32_t *__restrict__ etime) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t pos = seq_pos[i];
+        const uint64_t e = index_insert(elo, ehi, etag, estate, mask, kmers[2 * pos], kmers[2 * pos + 1], 0u);
+        atomicMin(&etime[e], time_of_seq[i]);
+    }
+}
+__device__ inline void bloom_word_bit(uint64_t h, unsigned i, uint64_t base, const BloomView &b, uint64_t &word, uint32_t &m, uint64_t &bit_id) {
+    const uint64_t pos = bloom_probe_pos(h, i, b), byte = base + (pos >> 3);
+    word = byte >> 2;
+    m = 1u << (uint32_t)((byte & 3u) * 8u + (7u - (unsigned)(pos & 7u)));
+    bit_id = base * 8u + pos;
+}
+// scratch filter f1 takes the unit's distinct k-mers; f2 = bits that were set already when a k-mer set them (shared with another k-mer)
+__global__ __launch_bounds__(BLOCK) void mg_shared_bits_kernel(BloomView bv, const uint64_t *__restrict__ elo, const uint64_t *__restrict__ ehi, const uint32_t *__restrict__ estate,
+                                                                uint64_t mask, uint32_t *__restrict__ f1, uint32_t *__restrict__ f2) {
+    for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e <= mask; e += (uint64_t)gridDim.x * BLOCK) {
+        if (estate[e] != ST_READY) continue;
+        const uint64_t h = nthash64(Kmer{elo[e], ehi[e]}, bv.k), base = bloom_sub_base(h, bv);
+        for (unsigned i = 0; i < bv.num_hashes; ++i) {
+            uint64_t w, id;
+            uint32_t m;
+            bloom_word_bit(h, i, base, bv, w, m, id);
+            if (atomicOr(&f1[w], m) & m) atomicOr(&f2[w], m);
+        }
+    }
+}
+// candidates: not yet multigroup, every bit set by an earlier unit or shared inside the unit.  out == nullptr: count only.
+__global__ __launch_bounds__(BLOCK) void mg_candidates_kernel(BloomView bv, const uint64_t *__restrict__ elo, const uint64_t *__restrict__ ehi, const uint32_t *__restrict__ estate,
+                                                               const uint32_t *__restrict__ emulti, uint64_t mask, const uint32_t *__restrict__ f2,
+                                                               unsigned long long *__restrict__ cursor, uint64_t *__restrict__ out) {
+    for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e <= mask; e += (uint64_t)gridDim.x * BLOCK) {
+        if (estate[e] != ST_READY || emulti[e]) continue;
+        const uint64_t h = nthash64(Kmer{elo[e], ehi[e]}, bv.k), base = bloom_sub_base(h, bv);
+        bool all = true;
+        for (unsigned i = 0; i < bv.num_hashes && all; ++i) {
+            uint64_t w, id;
+            uint32_t m;
+            bloom_word_bit(h, i, base, bv, w, m, id);
+            all = ((bv.words[w] | f2[w]) & m) != 0;
+        }
+        if (all) {
+            const unsigned long long j = atomicAdd(cursor, 1ULL);
+            if (out) out[j] = e;
+        }
+    }
+}
+__device__ inline uint64_t cb_find_or_insert(unsigned long long *keys, uint64_t mask, uint64_t id, bool insert) {   // returns the slot, or ~0 if absent
+    uint64_t i = mix64(id) & mask;
+    while (true) {
+        unsigned long long cur = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == ~0ULL) {
+            if (!insert) return ~0ULL;
+            cur = atomicCAS(&keys[i], ~0ULL, (unsigned long long)id);
+            if (cur == ~0ULL) return i;
+        }
+        if (cur == id) return i;
+        i = (i + 1) & mask;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void mg_cand_bits_kernel(BloomView bv, const uint64_t *__restrict__ elo, const uint64_t *__restrict__ ehi, const uint64_t *__restrict__ cand,
+                                                              uint64_t ncand, unsigned long long *__restrict__ cb_keys, uint32_t *__restrict__ cb_time, uint64_t cb_mask) {
+    for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < ncand; j += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t e = cand[j], h = nthash64(Kmer{elo[e], ehi[e]}, bv.k), base = bloom_sub_base(h, bv);
+        for (unsigned i = 0; i < bv.num_hashes; ++i) {
+            uint64_t w, id;
+            uint32_t m;
+            bloom_word_bit(h, i, base, bv, w, m, id);
+            const uint64_t slot = cb_find_or_insert(cb_keys, cb_mask, id, true);
+            if (bv.words[w] & m) atomicMin(&cb_time[slot], 0u);   // set by an earlier unit
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void mg_bit_times_kernel(BloomView bv, const uint64_t *__restrict__ elo, const uint64_t *__restrict__ ehi, const uint32_t *__restrict__ estate,
+                                                              const uint32_t *__restrict__ etime, uint64_t mask, unsigned long long *__restrict__ cb_keys,
+                                                              uint32_t *__restrict__ cb_time, uint64_t cb_mask) {
+    for (uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; e <= mask; e += (uint64_t)gridDim.x * BLOCK) {
+        if (estate[e] != ST_READY) continue;
+        const uint64_t h = nthash64(Kmer{elo[e], ehi[e]}, bv.k), base = bloom_sub_base(h, bv);
+        for (unsigned i = 0; i < bv.num_hashes; ++i) {
+            uint64_t w, id;
+            uint32_t m;
+            bloom_word_bit(h, i, base, bv, w, m, id);
+            const uint64_t slot = cb_find_or_insert(cb_keys, cb_mask, id, false);
+            if (slot != ~0ULL) atomicMin(&cb_time[slot], etime[e]);
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void mg_reported_kernel(BloomView bv, const uint64_t *__restrict__ elo, const uint64_t *__restrict__ ehi, const uint32_t *__restrict__ etime,
+                                                             const uint64_t *__restrict__ cand, uint64_t ncand, unsigned long long *__restrict__ cb_keys,
+                                                             const uint32_t *__restrict__ cb_time, uint64_t cb_mask, uint32_t *__restrict__ emulti) {
+    for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < ncand; j += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t e = cand[j], h = nthash64(Kmer{elo[e], ehi[e]}, bv.k), base = bloom_sub_base(h, bv);
+        uint32_t latest = 0;
+        for (unsigned i = 0; i < bv.num_hashes; ++i) {
+            uint64_t w, id;
+            uint32_t m;
+            bloom_word_bit(h, i, base, bv, w, m, id);
+            const uint32_t t = cb_time[cb_find_or_insert(cb_keys, cb_mask, id, false)];
+            latest = t > latest ? t : latest;
+        }
+        if (latest < etime[e]) emulti[e] = 1u;   // every bit was set before the k-mer's first turn: the filter reports it
     }
 }
 __global__ __launch_bounds__(BLOCK) void multigroup_list_kernel(const uint64_t *__restrict__ elo, const uint64_t *__restrict__ ehi, const uint32_t *__restrict__ estate,
@@ -606,51 +868,156 @@ int bt_paths_count_kmers(bt_paths *p, bt_bloom *path_bloom) {
 int bt_paths_count_multigroup(bt_paths *p, const uint32_t *h_cluster_group, bt_bloom *path_bloom, bt_table *multigroup_table, uint64_t *h_num_path_kmers) {
     if (!p || !h_cluster_group || !path_bloom || !multigroup_table) return fail("bt_paths_count_multigroup: null argument");
     if (path_bloom->k != p->k || multigroup_table->k != p->k) return fail("bt_paths_count_multigroup: k mismatch");
+    for (uint32_t c = 1; c < p->C; ++c)
+        if (h_cluster_group[c] < h_cluster_group[c - 1]) return fail("bt_paths_count_multigroup: clusters must be listed group by group, groups in index order");
+    if (p->L >= 0xFFFFFFFEull) return fail("bt_paths_count_multigroup: more than 2^32 path positions in one unit");
     BT_HIP(hipSetDevice(p->ctx->device));
     hipStream_t st = p->ctx->stream;
     const uint64_t cap = pow2_at_least(2 * std::max<uint64_t>(p->num_valid, 8));
+    if (cap > (1ull << 32)) return fail("bt_paths_count_multigroup: more than 2^31 k-mer occurrences in one unit");
+    const uint32_t G = p->C ? h_cluster_group[p->C - 1] + 1u : 0u;
     std::vector<void *> tmp;
     auto cleanup = [&]() {
         for (void *q : tmp) (void)hipFree(q);
     };
     uint64_t *dlo, *dhi, *elo, *ehi, *d_out;
-    uint32_t *dtag, *dstate, *etag, *estate, *egroup, *emulti, *d_cg;
+    uint32_t *dtag, *dstate, *dfirst, *pos_d, *etag, *estate, *egroup, *emulti, *etime, *d_cg, *d_flag, *d_rowpos, *d_sums;
     unsigned long long *d_counters;
+    const uint64_t nblk = (p->L + BLOCK * 4 - 1) / (BLOCK * 4);
     int rc = BT_OK;
     auto A = [&](auto **q, uint64_t n) {
         if (rc == BT_OK) rc = dev_alloc(q, n, tmp);
     };
-    A(&dlo, cap); A(&dhi, cap); A(&dtag, cap); A(&dstate, cap);
-    A(&elo, cap); A(&ehi, cap); A(&etag, cap); A(&estate, cap); A(&egroup, cap); A(&emulti, cap);
-    A(&d_out, 2 * p->num_valid); A(&d_cg, p->C); A(&d_counters, 2);
+    A(&dlo, cap); A(&dhi, cap); A(&dtag, cap); A(&dstate, cap); A(&dfirst, cap); A(&pos_d, p->L);
+    A(&elo, cap); A(&ehi, cap); A(&etag, cap); A(&estate, cap); A(&egroup, cap); A(&emulti, cap); A(&etime, cap);
+    A(&d_out, 2 * p->num_valid); A(&d_cg, p->C); A(&d_counters, 4);
+    A(&d_flag, p->L); A(&d_rowpos, p->L + 1); A(&d_sums, nblk);
     if (rc != BT_OK) {
         cleanup();
         return rc;
     }
-    hipError_t e = hipMemsetAsync(dstate, 0, cap * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(estate, 0, cap * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(egroup, 0xFF, cap * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(emulti, 0, cap * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_counters, 0, 16, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_cg, h_cluster_group, (size_t)p->C * 4, hipMemcpyHostToDevice, st);
+#define MGH(call)                                                                             \
+    do {                                                                                      \
+        const hipError_t _e = (call);                                                         \
+        if (_e != hipSuccess) {                                                               \
+            cleanup();                                                                        \
+            return fail(std::string("bt_paths_count_multigroup: ") + hipGetErrorString(_e));  \
+        }                                                                                     \
+    } while (0)
+#define MGR(call)            \
+    do {                     \
+        const int _r = (call); \
+        if (_r != BT_OK) {   \
+            cleanup();       \
+            return _r;       \
+        }                    \
+    } while (0)
+    MGH(hipMemsetAsync(dstate, 0, cap * 4, st));
+    MGH(hipMemsetAsync(estate, 0, cap * 4, st));
+    MGH(hipMemsetAsync(dfirst, 0xFF, cap * 4, st));
+    MGH(hipMemsetAsync(egroup, 0xFF, cap * 4, st));
+    MGH(hipMemsetAsync(etime, 0xFF, cap * 4, st));
+    MGH(hipMemsetAsync(emulti, 0, cap * 4, st));
+    MGH(hipMemsetAsync(d_counters, 0, 32, st));
+    MGH(hipMemcpyAsync(d_cg, h_cluster_group, (size_t)p->C * 4, hipMemcpyHostToDevice, st));
     const unsigned maxb = p->ctx->num_cu * 16;
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(multigroup_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, dlo, dhi, dtag, dstate, elo, ehi, etag, estate, egroup, emulti, cap - 1,
-                           p->d_kmers, p->d_valid, p->d_pos_path, p->d_path_cluster, d_cg, p->L);
-        hipLaunchKernelGGL(multigroup_list_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, elo, ehi, estate, emulti, dstate, cap - 1, d_out, d_counters);
-        e = hipGetLastError();
+    const bt::BloomView bv = path_bloom->view();
+    // 1. indexes; first occurrences in path order
+    hipLaunchKernelGGL(multigroup_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, dlo, dhi, dtag, dstate, dfirst, pos_d, elo, ehi, etag, estate, egroup, emulti,
+                       cap - 1, p->d_kmers, p->d_valid, p->d_pos_path, p->d_path_cluster, d_cg, p->L);
+    hipLaunchKernelGGL(mg_flag_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, p->d_valid, pos_d, dfirst, p->L, d_flag);
+    uint64_t n_total = 0;
+    if (p->L) {
+        hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, d_flag, p->L, d_rowpos, d_sums);
+        std::vector<uint32_t> sums(nblk);
+        MGH(hipMemcpyAsync(sums.data(), d_sums, nblk * 4, hipMemcpyDeviceToHost, st));
+        MGH(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < nblk; ++i) {
+            const uint32_t v = sums[i];
+            sums[i] = (uint32_t)n_total;
+            n_total += v;
+        }
+        MGH(hipMemcpyAsync(d_sums, sums.data(), nblk * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, d_rowpos, p->L, d_sums);
+        MGH(hipStreamSynchronize(st));   // (sums goes out of scope)
     }
+    const uint32_t total32 = (uint32_t)n_total;
+    MGH(hipMemcpyAsync(d_rowpos + p->L, &total32, 4, hipMemcpyHostToDevice, st));
+    // 2. per group: its range of first occurrences, the bucket count it inherits, room for its bucket map
+    std::vector<uint64_t> gstart(G + 1, p->L);
+    for (uint32_t c = p->C; c-- > 0;) gstart[h_cluster_group[c]] = p->cluster_text0[c];
+    for (uint32_t g = G; g-- > 0;)
+        if (gstart[g] == p->L && g + 1 <= G) gstart[g] = gstart[g + 1];   // a group index without clusters
+    uint64_t *d_gstart = nullptr, *d_moff = nullptr, *d_binit = nullptr;
+    uint32_t *d_goff = nullptr, *d_seq = nullptr, *d_time = nullptr, *d_next = nullptr, *d_mk = nullptr, *d_mv = nullptr;
+    A(&d_gstart, G + 1); A(&d_goff, G + 1); A(&d_seq, n_total); A(&d_time, n_total); A(&d_next, n_total); A(&d_moff, G + 1); A(&d_binit, G + 1);
+    MGR(rc);
+    MGH(hipMemcpyAsync(d_gstart, gstart.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gather_u32_kernel, dim3((G + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_rowpos, d_gstart, G + 1, d_goff);
+    hipLaunchKernelGGL(mg_seq_kernel, dim3(grid_for(p->L, BLOCK, maxb)), dim3(BLOCK), 0, st, d_flag, d_rowpos, p->L, d_seq);
+    std::vector<uint32_t> goff(G + 1);
+    MGH(hipMemcpyAsync(goff.data(), d_goff, (size_t)(G + 1) * 4, hipMemcpyDeviceToHost, st));
+    MGH(hipStreamSynchronize(st));
+    std::vector<uint64_t> moff(G + 1, 0), binit(G + 1, 1);
+    {
+        uint64_t B = 1;
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint64_t n = goff[g + 1] - goff[g];
+            binit[g] = B;
+            while (B < n) B = std_next_bucket_count(B);   // the set keeps its bucket count across clear()
+            if (B >= 0xFFFFFFFEull) {
+                cleanup();
+                return fail("bt_paths_count_multigroup: a group with more than 3.5e9 distinct path k-mers");
+            }
+            moff[g + 1] = moff[g] + (n ? pow2_at_least(2 * n) : 0);
+        }
+    }
+    A(&d_mk, moff[G]); A(&d_mv, moff[G]);
+    MGR(rc);
+    MGH(hipMemcpyAsync(d_moff, moff.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, st));
+    MGH(hipMemcpyAsync(d_binit, binit.data(), (size_t)(G + 1) * 8, hipMemcpyHostToDevice, st));
+    // 3. times
+    if (G) hipLaunchKernelGGL(mg_order_kernel, dim3((G + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, p->d_kmers, d_seq, d_goff, d_moff, d_binit, d_next, d_mk, d_mv, d_time, G, p->k);
+    hipLaunchKernelGGL(mg_etime_kernel, dim3(grid_for(n_total, BLOCK, maxb)), dim3(BLOCK), 0, st, p->d_kmers, d_seq, d_time, n_total, elo, ehi, etag, estate, cap - 1, etime);
+    // 4. k-mers the filter reports at their first turn
+    uint32_t *f1 = nullptr, *f2 = nullptr;
+    const uint64_t fwords = (path_bloom->bytes + 3) / 4;
+    A(&f1, fwords); A(&f2, fwords);
+    MGR(rc);
+    MGH(hipMemsetAsync(f1, 0, fwords * 4, st));
+    MGH(hipMemsetAsync(f2, 0, fwords * 4, st));
+    hipLaunchKernelGGL(mg_shared_bits_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, bv, elo, ehi, estate, cap - 1, f1, f2);
+    hipLaunchKernelGGL(mg_candidates_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, bv, elo, ehi, estate, emulti, cap - 1, f2, d_counters + 2,
+                       (uint64_t *)nullptr);
+    unsigned long long ncand = 0;
+    MGH(hipMemcpyAsync(&ncand, d_counters + 2, 8, hipMemcpyDeviceToHost, st));
+    MGH(hipStreamSynchronize(st));
+    if (ncand) {
+        uint64_t *d_cand = nullptr;
+        unsigned long long *cb_keys = nullptr;
+        uint32_t *cb_time = nullptr;
+        const uint64_t cb_cap = pow2_at_least(2 * ncand * path_bloom->num_hashes);
+        A(&d_cand, ncand); A(&cb_keys, cb_cap); A(&cb_time, cb_cap);
+        MGR(rc);
+        MGH(hipMemsetAsync(cb_keys, 0xFF, cb_cap * 8, st));
+        MGH(hipMemsetAsync(cb_time, 0xFF, cb_cap * 4, st));
+        hipLaunchKernelGGL(mg_candidates_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, bv, elo, ehi, estate, emulti, cap - 1, f2, d_counters + 3, d_cand);
+        hipLaunchKernelGGL(mg_cand_bits_kernel, dim3(grid_for(ncand, BLOCK, maxb)), dim3(BLOCK), 0, st, bv, elo, ehi, d_cand, (uint64_t)ncand, cb_keys, cb_time, cb_cap - 1);
+        hipLaunchKernelGGL(mg_bit_times_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, bv, elo, ehi, estate, etime, cap - 1, cb_keys, cb_time, cb_cap - 1);
+        hipLaunchKernelGGL(mg_reported_kernel, dim3(grid_for(ncand, BLOCK, maxb)), dim3(BLOCK), 0, st, bv, elo, ehi, etime, d_cand, (uint64_t)ncand, cb_keys, cb_time,
+                           cb_cap - 1, emulti);
+    }
+    hipLaunchKernelGGL(multigroup_list_kernel, dim3(grid_for(cap, BLOCK, maxb)), dim3(BLOCK), 0, st, elo, ehi, estate, emulti, dstate, cap - 1, d_out, d_counters);
     unsigned long long counters[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(counters, d_counters, 16, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        cleanup();
-        return fail(std::string("bt_paths_count_multigroup: ") + hipGetErrorString(e));
-    }
+    MGH(hipGetLastError());
+    MGH(hipMemcpyAsync(counters, d_counters, 16, hipMemcpyDeviceToHost, st));
+    MGH(hipStreamSynchronize(st));
     rc = bt_table_insert_batch(multigroup_table, d_out, counters[0], 0);
     if (rc == BT_OK) rc = bt_paths_count_kmers(p, path_bloom);
     if (rc == BT_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail("bt_paths_count_multigroup: device error");
     cleanup();
+#undef MGH
+#undef MGR
     if (h_num_path_kmers) *h_num_path_kmers = counters[1];
     return rc;
 }

@@ -285,12 +285,13 @@ int bt_paths_destroy(bt_paths *p);
  * added to the path Bloom filter (the reference first collects them in an unordered_set; insertion is idempotent) */
 int bt_paths_count_kmers(bt_paths *p, bt_bloom *path_bloom);
 /* KmerCounter::countPathMultigroupKmers (src/bayesTyper/KmerCounter.cpp:105-159) — cluster stage.  h_cluster_group[c] = index of
- * the variant-cluster group of cluster c.  Every distinct path k-mer of a group is looked up in the path Bloom filter: present ->
- * it goes into the multigroup table (KmerHash<bool>), absent -> it is added to the filter; *h_num_path_kmers = sum over groups of
- * their distinct path k-mers (inference_unit->num_path_kmers).
- * DEVIATION (documented in DESIGN.md): the reference's outcome depends on the order threads reach the filter — a Bloom false
- * positive on a k-mer's first lookup also lands it in the multigroup table.  Here a k-mer is multigroup iff it occurs in at
- * least two groups (the order-independent part); afterwards every path k-mer is in the filter, as in the reference. */
+ * the variant-cluster group of cluster c; clusters are listed group by group, groups in index order, a group's clusters in its vertex
+ * order (an error otherwise).  Every distinct path k-mer of a group is looked up in the path Bloom filter: present -> it goes into
+ * the multigroup table (KmerHash<bool>), absent -> it is added to the filter; *h_num_path_kmers = sum over groups of their distinct
+ * path k-mers (inference_unit->num_path_kmers).  The outcome — including the k-mers that enter the table as false positives of what
+ * the filter holds at that moment — is the one of the reference run with ONE thread (with more threads the reference's outcome
+ * depends on thread timing): groups in index order, a group's k-mers in the iteration order of the std::unordered_set<std::bitset<2k>>
+ * (libstdc++) the reference collects them in and reuses from group to group.  Afterwards every path k-mer is in the filter. */
 int bt_paths_count_multigroup(bt_paths *p, const uint32_t *h_cluster_group, bt_bloom *path_bloom, bt_table *multigroup_table, uint64_t *h_num_path_kmers);
 /* VariantClusterGraph::classifyPathKmers for every cluster (VariantClusterGraph.cpp:848-939): per distinct path k-mer of a
  * cluster the maximum over its paths of the (saturating) per-path multiplicity -> table update as bt_table_classify_batch.

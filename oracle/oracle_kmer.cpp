@@ -10,6 +10,7 @@
 // The oracle deliberately works on ASCII k-mers and byte-addressed filters like the reference does
 // (the product works on 2-bit packed words), so the two implementations share no code.
 #include <algorithm>
+#include <bitset>
 #include <cassert>
 #include <cmath>
 #include <cstdint>
@@ -735,8 +736,12 @@ uint64_t orc_paths_count_kmers(void *gh, void *bloom) {
     return windows;
 }
 
-// KmerCounter::countPathMultigroupKmersCallback (KmerCounter.cpp:105-145), single thread: groups in index order; a path k-mer the
-// filter already reports goes into the multigroup table, otherwise it is added to the filter.  Returns num_path_kmers.
+// KmerCounter::countPathMultigroupKmersCallback (KmerCounter.cpp:105-145), single thread (the only thread count for which the
+// reference's outcome is defined): groups in index order; the group's path k-mers are collected in ONE
+// std::unordered_set<std::bitset<2k>> that lives across the groups and is clear()ed between them (its bucket count survives), and are
+// visited in that container's iteration order; a path k-mer the filter already reports goes into the multigroup table, otherwise it
+// is added to the filter.  Returns num_path_kmers.  (k = 55 as the reference is built: bitset<110>; any other k falls back to a set
+// of strings, whose order is not the reference's.)
 uint64_t orc_paths_count_multigroup(void *gh, const uint32_t *cluster_group, void *bloom, void *table) {
     const OrcGraphs &g = *(OrcGraphs *)gh;
     OrcBloom *b = (OrcBloom *)bloom;
@@ -744,17 +749,42 @@ uint64_t orc_paths_count_multigroup(void *gh, const uint32_t *cluster_group, voi
     uint32_t num_groups = 0;
     for (uint32_t c = 0; c < g.C; c++) num_groups = std::max(num_groups, cluster_group[c] + 1);
     uint64_t num_kmers = 0;
+    auto visit = [&](const std::string &km) {
+        FlatBloom &f = b->subs[b->route(km.data())];
+        if (f.containsF(km.data())) t->map[km];
+        else f.insertF(km.data());
+    };
+    if (g.k == 55) {
+        static const char nt[4] = {'A', 'C', 'G', 'T'};
+        std::unordered_set<std::bitset<110>> group_kmers;
+        for (uint32_t grp = 0; grp < num_groups; grp++) {
+            group_kmers.clear();
+            for (uint32_t c = 0; c < g.C; c++)
+                if (cluster_group[c] == grp)
+                    for (uint32_t p = 0; p < g.num_paths[c]; p++)
+                        walk_path(g, c, p, [](uint32_t) {}, [&](const std::string &km) {
+                            uint64_t w[2];
+                            pack(km.data(), 55, w);
+                            std::bitset<110> bits(w[0]);
+                            bits |= std::bitset<110>(w[1]) << 64;
+                            group_kmers.emplace(bits);
+                        }, [] {});
+            num_kmers += group_kmers.size();
+            for (auto &bits : group_kmers) {
+                std::string km(55, 'A');
+                for (unsigned i = 0; i < 55; i++) km[i] = nt[(bits[2 * i] ? 1 : 0) | (bits[2 * i + 1] ? 2 : 0)];
+                visit(km);
+            }
+        }
+        return num_kmers;
+    }
     for (uint32_t grp = 0; grp < num_groups; grp++) {
         std::unordered_set<std::string> group_kmers;
         for (uint32_t c = 0; c < g.C; c++)
             if (cluster_group[c] == grp)
                 for (uint32_t p = 0; p < g.num_paths[c]; p++) walk_path(g, c, p, [](uint32_t) {}, [&](const std::string &km) { group_kmers.insert(km); }, [] {});
         num_kmers += group_kmers.size();
-        for (auto &km : group_kmers) {
-            FlatBloom &f = b->subs[b->route(km.data())];
-            if (f.containsF(km.data())) t->map[km];
-            else f.insertF(km.data());
-        }
+        for (auto &km : group_kmers) visit(km);
     }
     return num_kmers;
 }
