@@ -500,6 +500,12 @@ __global__ __launch_bounds__(BLOCK) void kmc_route_kernel(KmcView v, uint32_t bl
                                                           uint64_t n_total, uint16_t *__restrict__ keys, RouteRec *__restrict__ vals) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[KMC_RECS * KMC_MAX_REC + 32];
     __shared__ uint64_t block_prefix[2];
+    // ntHash four nucleotides at a time: tab[b] = the Horner contribution of the nucleotides c0 c1 c2 c3 packed in byte b (c0 in the low
+    // bits, hashed first), so that h <- rol(h, 4) ^ tab[b] equals four steps of h <- rol(h, 1) ^ seed[c]
+    __shared__ uint64_t tab[256];
+    for (unsigned b = threadIdx.x; b < 256u; b += BLOCK)
+        tab[b] = rol64(nt_seed(b & 3u), 3) ^ rol64(nt_seed((b >> 2) & 3u), 2) ^ rol64(nt_seed((b >> 4) & 3u), 1) ^ nt_seed((b >> 6) & 3u);
+    __syncthreads();
     const uint64_t num_chunks = (n + KMC_RECS - 1) / KMC_RECS;
     for (uint64_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
         const uint64_t rec0 = chunk * KMC_RECS;
@@ -522,7 +528,17 @@ __global__ __launch_bounds__(BLOCK) void kmc_route_kernel(KmcView v, uint32_t bl
             Kmer a;
             uint32_t count;
             kmc_decode(v, kmc_prefix_in(v, first_record + rec_offset + rec0 + threadIdx.x, block_prefix[0], block_prefix[1]), &stage[lead + threadIdx.x * v.rec_size], a, count);
-            const uint64_t h = nthash64(a, v.k);
+            uint64_t h = 0;
+            {
+                uint64_t w = a.lo;
+                unsigned left = v.k;
+                for (unsigned word = 0; word < 2u && left; ++word, w = a.hi) {
+                    unsigned in_word = left < 32u ? left : 32u;
+                    left -= in_word;
+                    for (; in_word >= 4u; in_word -= 4u, w >>= 8) h = rol64(h, 4) ^ tab[w & 0xFFu];
+                    for (; in_word; --in_word, w >>= 2) h = rol64(h, 1) ^ nt_seed((unsigned)(w & 3u));
+                }
+            }
             const uint64_t i = rec0 + threadIdx.x;
             keys[i] = (uint16_t)(nthash64_seeded(h, bloom_k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u));
             vals[i] = RouteRec{(uint32_t)h, (uint32_t)(h >> 32), (uint32_t)i};
