@@ -1,0 +1,293 @@
+// Device code of the Gibbs kernels (the group-level schedule around bt_gibbs_tile.hpp / bt_gibbs_simple.hpp) — included by the two
+// translation units that instantiate it: bt_gibbs.hip (gibbs_kernel: every tile, every operation) and bt_gibbs_simple_kernel.hip
+// (gibbs_simple_kernel: tiles of two-haplotype clusters, the three sampling operations; compiled for half the registers).
+#pragma once
+#include "bt_gibbs_tile.hpp"
+#include "bt_gibbs_simple.hpp"
+
+namespace bt {
+
+enum GibbsOp { OP_RUN = 0, OP_INIT_CHAIN = 1, OP_SWEEP = 2, OP_NOISE = 3, OP_RESET = 4, OP_SETUP = 5 };
+
+struct TraceCfg {
+    uint32_t max_sweeps;   // 0 = off
+    uint32_t *counter;     // [ntiles*64] sweeps recorded per group
+    uint32_t *buf;         // tile blocks of [max_sweeps][nvm][S][64]
+};
+
+__device__ BT_NOINLINE void group_init_chain(Env env, uint32_t chain, uint32_t nvert, uint32_t nsrc, uint32_t gindex) {
+    const Tile t = make_tile(env);
+    const GParams BT_CAS &P = env_params(env);
+    const uint32_t gseed = P.noise_seeding ? P.seed + (gindex + 1u) * (chain + 1u) : P.seed + (gindex + 1u);
+    for (uint32_t v = 0; v < nvert; ++v) {
+        const Vx c = make_vx(t, v);
+        Env ev = env;
+        const bool swap = env.resident == 0xFFFFFFFFu && t.d->hot_bytes != 0;
+        if (swap) {
+            hot_swap(env, v, true);
+            ev.resident = v;
+        }
+        PROF_DECL;
+        if (!make_vx(make_tile(ev), v).sc()[SC_CONSTRUCTED]) genotyper_construct(ev, v, gseed + c.cid());   // VariantClusterGroup.cpp:179-182
+        genotyper_reset(ev, v);
+        if (swap) hot_swap(env, v, false);
+    }
+    // shuffleBranchOrdering (VariantClusterGroup.cpp:208-218)
+    if (nvert == 1 && nsrc == 1) return;   // nothing to shuffle (a fresh generator is seeded per call, no state carries over)
+    uint32_t *bst = (uint32_t *)(t.base + t.d->off[A_BRNG]) + (size_t)t.lane * MT_PAD;
+    mt_seed(bst, P.seed + (gindex + 1u) * (chain + 1u));
+    Mt brng = mt_open(bst);
+    rng_shuffle_u32(brng, t.arr<uint32_t>(A_SOURCES), nsrc);
+    for (uint32_t v = 0; v < nvert; ++v) {
+        const Vx c = make_vx(t, v);
+        rng_shuffle_u32(brng, c.edges(), vx_ne(c));
+    }
+}
+
+// VariantClusterGenotyper::updateNestedVariantClusterInfo (VariantClusterGenotyper.cpp:140-206): child's info := parent's info, updated
+__device__ BT_NOINLINE void prepare_nested(Env env, uint32_t v_parent, uint32_t v_child) {
+    if (env.resident != RESIDENT_ALL) env.resident = 0xFFFFFFFFu;   // swap mode: between visits every vertex's hot arrays are in HBM
+    const Tile t = make_tile(env);
+    const GParams BT_CAS &P = env_params(env);
+    const Vx c = make_vx(t, v_parent), cc = make_vx(t, v_child);
+    const uint32_t nd_n = vx_nd(c), cc_cid = cc.cid();
+    const TileDesc BT_CAS &d = c.d();
+    SPtr<uint32_t, LANES> ndcl = c.a<uint32_t>(A_NDCL, d.NDm > 1 ? d.NDm : 1), ndvo = c.a<uint32_t>(A_NDVOFF, d.NDm + 1);
+    SPtr<uint16_t, LANES> ndv = c.a<uint16_t>(A_NDVAR, d.NDVm > 1 ? d.NDVm : 1);
+    for (uint32_t s = 0; s < P.S; ++s) {
+        uint8_t ploidy = c.nest_ploidy()[s];
+        uint32_t n = c.nest_n()[s];
+        for (uint32_t j = 0; j < n; ++j)
+            for (int q = 0; q < 4; ++q) cc.nest_stats(s, j)[q] = (double)c.nest_stats(s, j)[q];
+        for (uint32_t which = 0; which < 2; ++which) {
+            const uint16_t h = c.dip()[2 * s + which];
+            if (h == NOHAP) continue;
+            // binary_search(nested_variant_cluster_indices of h, child cluster idx)
+            bool found = false;
+            uint32_t lo = c.hn_off(h), hi = c.hn_off(h + 1);
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t val = c.hn_idx(mid);
+                if (val == cc_cid) {
+                    found = true;
+                    break;
+                }
+                if (val < cc_cid) lo = mid + 1;
+                else hi = mid;
+            }
+            if (found) continue;
+            ploidy = ploidy == 2 ? 1 : 0;   // updateNestedPloidy
+            uint32_t variant_idx = 0xFFFFFFFFu;
+            for (uint32_t dd = 0; dd < nd_n; ++dd) {
+                if (ndcl[dd] != cc_cid) continue;
+                for (uint32_t i = ndvo[dd], i1 = ndvo[dd + 1]; i < i1; ++i) {
+                    const uint32_t nv = ndv[i];
+                    const uint32_t a = c.hap_allele(h, nv);
+                    if (!is_missing(c, nv, a)) {
+                        variant_idx = nv;
+                        break;
+                    }
+                }
+                break;
+            }
+            if (variant_idx != 0xFFFFFFFFu && n < 2) {
+                for (int q = 0; q < 4; ++q) cc.nest_stats(s, n)[q] = (double)c.ksc(s, which, variant_idx)[q];
+                ++n;
+            }
+        }
+        cc.nest_ploidy()[s] = ploidy;
+        cc.nest_n()[s] = (uint8_t)n;
+    }
+}
+
+__device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+    Env env = env_in;
+    const bool swap = env.resident == 0xFFFFFFFFu && t.d->hot_bytes != 0;
+    PROF_DECL;
+    if (swap) {
+        hot_swap(env, v, true);
+        env.resident = v;
+    }
+    PROF(13);
+    rng_topup(env, v);
+    PROF(11);
+    sample_diplotypes(env, v, collect, trace_row.off + v * P.S * LANES, tracing, (uint32_t *)trace_row.base);
+    sample_haplotype_frequencies(env, v);
+    PROF_DECL2;
+    if (swap) hot_swap(env, v, false);
+    PROF(13);
+}
+
+// VariantClusterGroup::estimateGenotypes + runGibbsSample (VariantClusterGroup.cpp:220-250), recursion unrolled on an explicit stack
+__device__ inline void group_sweep(const Env &env, const Tile &t, const GParams BT_CAS &P, bool collect, uint32_t nvert, uint32_t nsrc, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+    if (tracing)
+        for (uint32_t i = 0; i < t.d->nvm * P.S; ++i) trace_row[i] = 0xFFFFFFFFu;
+    SPtr<uint32_t, LANES> sources = t.arr<uint32_t>(A_SOURCES), stack = t.arr<uint32_t>(A_STACK);
+    SPtr<uint8_t, LANES> gploidy = t.arr<uint8_t>(A_PLOIDY);
+    for (uint32_t si = 0; si < nsrc; ++si) {
+        const uint32_t sv = sources[si];
+        {
+            const Vx root = make_vx(t, sv);
+            for (uint32_t s = 0; s < P.S; ++s) {
+                root.nest_ploidy()[s] = gploidy[s];
+                root.nest_n()[s] = 0;
+            }
+        }
+        visit_vertex(env, t, P, sv, collect, trace_row, tracing);
+        if (nvert == 1) continue;
+        stack[0] = sv;
+        stack[1] = 0;
+        uint32_t sp = 1;
+        while (sp > 0) {
+            const uint32_t v = stack[2 * (sp - 1)];
+            const uint32_t i = stack[2 * (sp - 1) + 1];
+            const Vx c = make_vx(t, v);
+            if (i < vx_ne(c)) {
+                stack[2 * (sp - 1) + 1] = i + 1;
+                const uint32_t tv = c.edges()[i];
+                {
+                    PROF_DECL;
+                    prepare_nested(env, v, tv);
+                    PROF(14);
+                }
+                visit_vertex(env, t, P, tv, collect, trace_row, tracing);
+                stack[2 * sp] = tv;
+                stack[2 * sp + 1] = 0;
+                ++sp;
+            } else
+                --sp;
+        }
+    }
+}
+
+struct TraceRow {
+    SPtr<uint32_t, LANES> row;
+    bool on;
+};
+__device__ inline TraceRow trace_row_for(const Tile &t, const GParams BT_CAS &P, const TraceCfg &tr, uint32_t tile) {
+    TraceRow r{SPtr<uint32_t, LANES>{(uint32_t BT_GAS *)tr.buf, 0u}, false};
+    if (!tr.max_sweeps) return r;
+    uint32_t *cnt = &tr.counter[(size_t)tile * LANES + t.lane];
+    const uint32_t n = *cnt;
+    if (n >= tr.max_sweeps) return r;
+    *cnt = n + 1;
+    r.row = SPtr<uint32_t, LANES>{(uint32_t BT_GAS *)tr.buf, (uint32_t)(t.d->trace_base + (size_t)n * t.d->nvm * P.S * LANES) + t.lane};
+    r.on = true;
+    return r;
+}
+
+#ifndef GIBBS_WAVES
+#define GIBBS_WAVES 1
+#endif
+// SIMPLE_ONLY: the instantiation for launch classes made of simple tiles only (two-haplotype clusters, the bulk of a batch) and the three
+// sampling operations (bt_gibbs_simple_kernel.hip).
+template <bool SIMPLE_ONLY>
+__device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg, int op, uint32_t arg0, uint32_t arg1,
+                                           unsigned long long *__restrict__ hist, TraceCfg tr, const uint32_t *__restrict__ tile_list) {
+    const uint32_t tile = tile_list ? tile_list[blockIdx.x] : blockIdx.x;
+    Env env{tiles, pool, Pg, tile_list, 0xFFFFFFFFu};
+    const GParams BT_CAS &P = *(const GParams BT_CAS *)Pg;
+    Tile t;
+    t.d = (const TileDesc BT_CAS *)&tiles[tile];
+    t.base = (uint8_t BT_GAS *)(pool + t.d->base);
+    if (!tile_thread_active(t.d->split, t.d->copies)) return;
+    t.lane = tile_lane(t.d->split, t.d->copies);
+    t.part = tile_part(t.d->copies);
+    t.copies = t.d->copies;
+    // the extra copies of a narrow tile's groups only take part in the sampling operations (the others tally with atomics)
+    if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN)) return;
+    t.hot = nullptr;
+    t.resident = 0xFFFFFFFFu;
+    // Narrow tiles (few groups + lockstep copies) are the launch's critical path: a handful of long sequential programs.  They take
+    // issue priority over the 64-group tiles they share a SIMD with, which have plenty of peers to fill the gaps.
+    if (t.d->prio) __builtin_amdgcn_s_setprio(3);
+    SPtr<uint32_t, LANES> gd = t.arr<uint32_t>(A_GDIMS);
+    if (!gd[3]) return;   // padding lane of the last tile
+    const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
+    // groups of ONE cluster keep that cluster's hot arrays in LDS for the whole launch; larger groups swap per vertex visit
+    // (and so do multi-cluster groups of narrow tiles, whose LDS rows are interleaved over fewer lanes: TileDesc::lds_all)
+    const bool whole = (t.d->nvm == 1 || t.d->lds_all) && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN);
+    if (whole) {
+        env.resident = RESIDENT_ALL;
+        for (uint32_t v = 0; v < nvert; ++v) hot_swap(env, v, true);
+        t.resident = RESIDENT_ALL;
+        t.hot = lds_block();
+    }
+    const bool simple = SIMPLE_ONLY || (whole && tile_is_simple(*t.d));
+    if (op == OP_RUN) {
+        for (uint32_t chain = 0; chain < P.num_chains; ++chain) {
+            {
+                PROF_DECL;
+                group_init_chain(env, chain, nvert, nsrc, gindex);
+                PROF(15);
+            }
+            if (simple) {
+                simple_sweeps(env, t, P, P.burn_in, false, tr.counter, tr.buf, tr.max_sweeps, tile);
+                simple_sweeps(env, t, P, P.num_iterations, true, tr.counter, tr.buf, tr.max_sweeps, tile);
+                continue;
+            }
+            if constexpr (!SIMPLE_ONLY) {
+                for (uint32_t i = 0; i < P.burn_in; ++i) {
+                    const TraceRow r = trace_row_for(t, P, tr, tile);
+                    group_sweep(env, t, P, false, nvert, nsrc, r.row, r.on);
+                }
+                for (uint32_t i = 0; i < P.num_iterations; ++i) {
+                    const TraceRow r = trace_row_for(t, P, tr, tile);
+                    group_sweep(env, t, P, true, nvert, nsrc, r.row, r.on);
+                }
+            }
+        }
+        for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);   // hot arrays: LDS when resident, else HBM (both valid)
+    } else if (op == OP_INIT_CHAIN) {
+        group_init_chain(env, arg0, nvert, nsrc, gindex);
+    } else if (op == OP_SWEEP) {
+        if (simple) simple_sweeps(env, t, P, arg0, arg1 != 0, tr.counter, tr.buf, tr.max_sweeps, tile);
+        if constexpr (!SIMPLE_ONLY)
+            for (uint32_t i = 0; i < (simple ? 0u : arg0); ++i) {
+                const TraceRow r = trace_row_for(t, P, tr, tile);
+                group_sweep(env, t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
+            }
+        if (arg1 != 0)
+            for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
+    } else if (SIMPLE_ONLY) {
+        // (the other operations always go through the general kernel)
+    } else if (op == OP_NOISE) {
+        // VariantClusterGenotyper::getNoiseCounts (:757-779) for every vertex, then clearCache
+        for (uint32_t v = 0; v < nvert; ++v) {
+            const Vx c = make_vx(t, v);
+            const uint32_t nsu = c.sc()[SC_NSUB_U];
+            SPtr<uint32_t, LANES> usub = c.usub();
+            for (uint32_t s = 0; s < P.S; ++s) {
+                const uint16_t h1 = c.dip()[2 * s], h2 = c.dip()[2 * s + 1];
+                for (uint32_t i = 0; i < nsu; ++i) {
+                    const uint32_t k = usub[i];
+                    if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) {
+                        const uint32_t cnt = c.has_counts(k) ? c.count(k, s) : 0;
+                        atomicAdd(&hist[s * 256u + cnt], 1ULL);
+                    }
+                }
+            }
+            cache_clear(c, P, false);   // only the first copy of a group runs this operation
+        }
+    } else if (op == OP_RESET) {
+        // VariantClusterGroup::resetGroup: genotypers are deleted; the shared KmerCounts multiplicities are NOT reset
+        for (uint32_t v = 0; v < nvert; ++v) make_vx(t, v).sc()[SC_CONSTRUCTED] = 0;
+    } else if (op == OP_SETUP) {
+        // mutable copies of the group structure (shuffled in place chain after chain, never restored)
+        SPtr<uint32_t, LANES> s0 = t.arr<uint32_t>(A_SOURCES0), s1 = t.arr<uint32_t>(A_SOURCES);
+        for (uint32_t i = 0; i < nsrc; ++i) s1[i] = s0[i];
+        for (uint32_t v = 0; v < nvert; ++v) {
+            const Vx c = make_vx(t, v);
+            SPtr<uint32_t, LANES> e0 = c.a<uint32_t>(A_EDGES0, t.d->NEm > 1 ? t.d->NEm : 1), e1 = c.edges();
+            for (uint32_t i = 0, n = vx_ne(c); i < n; ++i) e1[i] = e0[i];
+            SPtr<uint32_t, LANES> dm = t.arr<uint32_t>(A_VDIMS, v * 8);   // dimensions the samplers read at every call: next to the state scalars
+            SPtrF<uint32_t, LANES> sc = c.sc();
+            sc[SC_H] = dm[0];
+            sc[SC_V] = dm[1];
+            sc[SC_NM] = dm[4];
+        }
+    }
+    if (whole)
+        for (uint32_t v = 0; v < nvert; ++v) hot_swap(env, v, false);
+}
+}  // namespace bt

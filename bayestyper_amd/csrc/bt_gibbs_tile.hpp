@@ -404,7 +404,7 @@ __device__ inline uint32_t uniform_tile_hot_bytes(const Env &e) {
     return ((const TileDesc BT_CAS *)&tiles[tile])->hot_bytes;
 }
 // move every hot array of vertex v between HBM and the wavefront's LDS block (lane-wise, coalesced)
-__device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
+__device__ BT_NOINLINE void hot_swap(Env env, uint32_t v, bool to_lds) {
     const uint32_t voff = env.resident == RESIDENT_ALL ? v * uniform_tile_hot_bytes(env) : 0u;
     env.resident = 0xFFFFFFFFu;
     const Tile t = make_tile(env);
@@ -438,7 +438,7 @@ __device__ __noinline__ void hot_swap(Env env, uint32_t v, bool to_lds) {
 
 // ---- optional per-phase cycle accounting (build with -DBT_PROF; read with bt_diag_prof) ----
 #ifdef BT_PROF
-__device__ unsigned long long g_bt_prof[32];
+static __device__ unsigned long long g_bt_prof[32];   // (one copy per translation unit; bt_diag_prof reads the general kernel's)
 #define PROF_DECL unsigned long long _pt = __builtin_readcyclecounter()
 #define PROF_DECL2 _pt = __builtin_readcyclecounter()
 #define PROF(sec)                                                            \
@@ -616,7 +616,7 @@ __device__ inline uint32_t sparsity_cover(const Vx &c, G &rng) {
 }
 
 // ---- VariantClusterGenotyper ctor (VariantClusterGenotyper.cpp:59-106) ----
-__device__ __noinline__ void genotyper_construct(Env env, uint32_t vtx, uint32_t prng_seed) {
+__device__ BT_NOINLINE void genotyper_construct(Env env, uint32_t vtx, uint32_t prng_seed) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const TileDesc BT_CAS &d = c.d();
@@ -837,7 +837,7 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
 }
 
 // ---- VariantClusterGenotyper::reset (VariantClusterGenotyper.cpp:113-129) ----
-__device__ __noinline__ void genotyper_reset(Env env, uint32_t vtx) {
+__device__ BT_NOINLINE void genotyper_reset(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     c.sc()[SC_USE_MULTI] = 0;
@@ -911,7 +911,7 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
 // sweep anyway.  Instead the whole table is computed once per cache epoch (chain start / clearCache) with all lanes busy.
 // Every entry is the same sum in the same (subset) order as the on-demand evaluation, so values are bit-identical.
 // Four candidates sharing the first haplotype are evaluated per pass: 11 loads per k-mer for 4 sums instead of 20.
-__device__ __noinline__ void fill_unique_cache(Env env, uint32_t vtx) {
+__device__ BT_NOINLINE void fill_unique_cache(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const TileDesc BT_CAS &d = c.d();
@@ -1283,7 +1283,7 @@ __device__ inline void flush_sample(const Vx &c, const GParams BT_CAS &P, uint32
 }
 
 // materialise everything still pending (end of a launch: results may be read next)
-__device__ __noinline__ void flush_vertex(Env env, uint32_t vtx) {
+__device__ BT_NOINLINE void flush_vertex(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     for (uint32_t s = 0; s < P.S; ++s) flush_sample(c, P, s);
@@ -1384,14 +1384,14 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
         PROF(18);
     }
 }
-__device__ __noinline__ void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
+__device__ BT_NOINLINE void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     SPtrF<uint32_t, LANES> sc = c.sc();
     collect_sample_body(c, P, s, sc[SC_NSUB_U], sc[SC_NSUB_M]);
 }
 
-__device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
+__device__ BT_NOINLINE void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
@@ -1412,7 +1412,7 @@ __device__ __noinline__ void update_allele_kmer_stats(Env env, uint32_t vtx, uin
 }
 
 // ---- sampleDiplotypes / sampleDiplotype / calcDiplotypeLogProb (VariantClusterGenotyper.cpp:597-755) ----
-__device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool collect, uint32_t trace_word, bool tracing, uint32_t *trace_buf) {
+__device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collect, uint32_t trace_word, bool tracing, uint32_t *trace_buf) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const SPtr<uint32_t, LANES> trace_row{(uint32_t BT_GAS *)uniform_ptr(trace_buf), trace_word};
@@ -1726,7 +1726,7 @@ __device__ __noinline__ void sample_diplotypes(Env env, uint32_t vtx, bool colle
 
 // Top the draw-ahead rings of a cluster's two generators up at the start of a visit: the whole wavefront refills together (one burst
 // of independent state loads per generator), and the draws of the visit then read LDS.  Generating ahead does not change the stream.
-__device__ __noinline__ void rng_topup(Env env, uint32_t vtx) {
+__device__ BT_NOINLINE void rng_topup(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     MtRing a = c.rng(0), b = c.rng(1);
     a.topup();
@@ -1768,7 +1768,7 @@ __device__ inline uint32_t simplex_prob_vector(const Vx &c, const GParams BT_CAS
 
 // ---- sampleHaplotypeFrequencies (VariantClusterGenotyper.cpp:781-785 -> HaplotypeFrequencyDistribution.cpp:127-138
 //      -> FrequencyDistribution.cpp:75-93 / 209-303) ----
-__device__ __noinline__ void sample_haplotype_frequencies(Env env, uint32_t vtx) {
+__device__ BT_NOINLINE void sample_haplotype_frequencies(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const TileDesc BT_CAS &d = c.d();

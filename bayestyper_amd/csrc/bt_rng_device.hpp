@@ -24,6 +24,12 @@
 namespace bt {
 
 #define BT_HD __host__ __device__ inline
+// out-of-line device functions of the samplers; the translation unit of gibbs_simple_kernel inlines them under its own register budget
+#ifdef BT_SIMPLE_TU
+#define BT_NOINLINE
+#else
+#define BT_NOINLINE __noinline__
+#endif
 
 // fp64 transcendental functions.  On the device they are out-of-line: ocml's double-precision log/exp/log1p/pow need many
 // registers; keeping them as separate functions keeps the samplers' own allocation small enough for 2-4 waves per SIMD.
