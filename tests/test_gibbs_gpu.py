@@ -108,6 +108,24 @@ def test_config_C4_ten_samples_shapes_BCD(gpu_ctx, oracle, shape, n, kw):
     assert exact == flat["num_clusters"]
 
 
+def test_config_C3_trio_mixture_the_bench_workload(gpu_ctx, oracle):
+    """BASELINE configs[2] (WGS trio, the workload bench.py times): a 700-group batch of the bench's own mixture generator at S=3 — two-haplotype
+    clusters (the kernel's simple path, its own launch class), multi-variant clusters, nested SV groups and many-candidate clusters, every
+    structure with its own dimensions — through several launch classes at once.  Traces of the first sweeps and the sampling frequencies /
+    allele statistics of a 3 x (10 + 30) schedule against the oracle."""
+    from bayestyper_amd import synth
+
+    S = 3
+    flat = synth.make_mixture(700, S, seed=303, templates={"A": 48, "B": 24, "C": 6, "D": 3})
+    mix = flat["mixture"]
+    assert mix["A"] >= 500 and mix["B"] >= 40 and mix["C"] >= 8 and mix["D"] >= 2
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=12, seed=23, chains=3, burn=10, iters=30)
+    for g, (to, tg) in enumerate(tr):
+        assert np.array_equal(to, tg[: len(to)]), f"group {g}"
+    exact = assert_parity(flat, ro, rg, 3 * 30)
+    assert exact == flat["num_clusters"]
+
+
 def test_config_C5_noise_genotyping_joint_30_samples(gpu_ctx, oracle):
     """BASELINE configs[4]: --noise-genotyping (estimateNoiseAndGenotypes, InferenceEngine.cpp:384-472) on the joint shape — 30 samples,
     --max-number-of-sample-haplotypes 32 => 256 merged haplotype candidates per cluster — together with small clusters in the same
