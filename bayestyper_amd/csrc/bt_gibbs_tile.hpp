@@ -93,6 +93,7 @@ enum TileArr {
     A_ASTATS,       // f64 [V] S*Am*12
     A_NESTPL, A_NESTN,   // u8 [V] S
     A_NESTST,       // f64 [V] S*2*4
+    A_PENDNEST,     // f64 [V] S*2*4      the nested sources the pending (deferred) collected sweeps of a sample saw: [s][j][count, fraction, mean], [s][0][3] = how many
     A_SC,           // u32 [V] SC_COUNT
     A_EDGES,        // u32 [V] NEm
     A_COVER,        // u8  [V] Km
@@ -296,6 +297,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     }
     __device__ inline SPtrF<uint8_t, LANES> nest_ploidy() const { return t.harr<uint8_t>(A_NESTPL, v, d().S); }
     __device__ inline SPtrF<uint8_t, LANES> nest_n() const { return t.harr<uint8_t>(A_NESTN, v, d().S); }
+    __device__ inline SPtr<double, LANES> pend_nest(uint32_t s) const { return a<double>(A_PENDNEST, (uint32_t)d().S * 8) + (uint32_t)s * 8; }
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
     __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
     __device__ inline SPtr<uint8_t, LANES> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
@@ -1174,28 +1176,33 @@ __device__ inline bool hap_source(const Vx &c, uint32_t s, uint32_t which, uint1
 // work is 3 V independent Welford chains.  They are items (variant, statistic) dealt to the copies of the group (a 64-group tile: all
 // to the one lane); every chain sees its values in the reference's order: haplotype 1's source, haplotype 2's (alternating when both
 // fall into the same cell), then the nested sources.
-__device__ inline void ks_chain_rep(KS &k, double v1, bool en1, double v2, bool en2, uint32_t r) {   // r x {add v1 if en1; add v2 if en2}
-    if (en1 && en2 && v1 != v2) {
-        for (uint32_t i = 0; i < r; ++i) {
-            ks_add_r(k, v1);
-            ks_add_r(k, v2);
-        }
+// r repetitions of the value list L[0..n) on one KmerStats (n <= 4)
+__device__ inline void ks_list_rep(KS &k, const double (&L)[4], uint32_t n, uint32_t r) {
+    if (n == 0) return;
+    bool same = true;
+    for (uint32_t i = 1; i < 4; ++i) same = same && (i >= n || L[i] == L[0]);
+    if (same) {
+        ks_add_rep(k, L[0], n * r);
         return;
     }
-    if (en1 && en2) ks_add_rep(k, v1, 2 * r);
-    else if (en1) ks_add_rep(k, v1, r);
-    else if (en2) ks_add_rep(k, v2, r);
+    for (uint32_t rep = 0; rep < r; ++rep)
+        for (uint32_t i = 0; i < 4; ++i)
+            if (i < n) ks_add_r(k, L[i]);
 }
+// The nested sources come from the sample's pending copy (A_PENDNEST: what the sweeps being replayed saw), nn of them.
 __device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t r, uint32_t nn) {
     const uint32_t V = c.V;
     const bool one = h1 != NOHAP, two = one && h2 != NOHAP;
     // nested sources (the same for every variant)
     double ncnt[2] = {0, 0}, nf[2] = {0, 0}, nm[2] = {0, 0};
-    for (uint32_t j = 0; j < nn && j < 2u; ++j) {
-        SPtr<double, LANES> q = c.nest_stats(s, j);
-        ncnt[j] = q[0];
-        nf[j] = q[1];
-        nm[j] = q[2];
+    {
+        SPtr<double, LANES> q = c.pend_nest(s);
+        for (uint32_t j = 0; j < 2u; ++j)
+            if (j < nn) {
+                ncnt[j] = q[4 * j];
+                nf[j] = q[4 * j + 1];
+                nm[j] = q[4 * j + 2];
+            }
     }
     // Items in batches of three per copy: all descriptors first, then all sources and cells, then the chains, then the stores — a batch
     // costs three dependent memory round trips instead of that many per item.
@@ -1214,7 +1221,7 @@ __device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, ui
             cn[b] = nn ? c.allele_base(var[b]) + (uint32_t)c.var_na(var[b]) - 1u : 0u;   // addNestedHaplotypeKmerStats' cell: the variant's last allele
         }
         double v1[NB], v2[NB];
-        bool en1[NB], en2[NB];
+        bool en1[NB], en2[NB], use2[NB], use3[NB];
         KS k1[NB], k2[NB], k3[NB];   // the (at most three) cells of the item: haplotype 1's, haplotype 2's, the nested one
         uint32_t c1[NB], c2[NB];
 #pragma unroll
@@ -1236,39 +1243,43 @@ __device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, ui
                 v2[b] = val;
                 en2[b] = st[b] == 0 || cnt != 0.0;
             }
+            bool nested_any = false;
+            for (uint32_t j = 0; j < 2u; ++j) nested_any = nested_any || (j < nn && (st[b] == 0 || ncnt[j] != 0.0));
+            use2[b] = en2[b] && !(en1[b] && c2[b] == c1[b]);
+            use3[b] = live[b] && nested_any && !(en1[b] && cn[b] == c1[b]) && !(use2[b] && cn[b] == c2[b]);
             k1[b] = k2[b] = k3[b] = KS{0, 0, 0, 0};
             if (en1[b]) k1[b] = ks_load(c.astats_cell(s, c1[b]) + 4u * st[b]);
-            if (en2[b] && !(en1[b] && c2[b] == c1[b])) k2[b] = ks_load(c.astats_cell(s, c2[b]) + 4u * st[b]);
-            if (live[b] && nn && !((en1[b] && cn[b] == c1[b]) || (en2[b] && cn[b] == c2[b]))) k3[b] = ks_load(c.astats_cell(s, cn[b]) + 4u * st[b]);
+            if (use2[b]) k2[b] = ks_load(c.astats_cell(s, c2[b]) + 4u * st[b]);
+            if (use3[b]) k3[b] = ks_load(c.astats_cell(s, cn[b]) + 4u * st[b]);
         }
 #pragma unroll
         for (uint32_t b = 0; b < NB; ++b) {
             if (!live[b]) continue;
-            const bool same12 = en1[b] && en2[b] && c1[b] == c2[b];
-            if (same12) ks_chain_rep(k1[b], v1[b], true, v2[b], true, r);
-            else {
-                if (en1[b]) ks_add_rep(k1[b], v1[b], r);
-                if (en2[b]) ks_add_rep(k2[b], v2[b], r);
+            // per cell the values it receives in one sweep, in the reference's order: haplotype 1's source, haplotype 2's, the nested ones
+            double L1[4] = {0, 0, 0, 0}, L2[4] = {0, 0, 0, 0}, L3[4] = {0, 0, 0, 0};
+            uint32_t n1 = 0, n2 = 0, n3 = 0;
+            if (en1[b]) L1[n1++] = v1[b];
+            if (en2[b]) {
+                if (use2[b]) L2[n2++] = v2[b];
+                else L1[n1++] = v2[b];
             }
-            // the nested contributions go to whichever register copy holds their cell
-            for (uint32_t j = 0; j < nn && j < 2u; ++j) {
+            for (uint32_t j = 0; j < 2u; ++j) {
+                if (!(j < nn && (st[b] == 0 || ncnt[j] != 0.0))) continue;
                 const double val = st[b] == 0 ? ncnt[j] : (st[b] == 1 ? nf[j] : nm[j]);
-                if (!(st[b] == 0 || ncnt[j] != 0.0)) continue;
-                if (en1[b] && cn[b] == c1[b]) ks_add_r(k1[b], val);
-                else if (en2[b] && cn[b] == c2[b]) ks_add_r(k2[b], val);
-                else ks_add_r(k3[b], val);
+                if (en1[b] && cn[b] == c1[b]) L1[n1++] = val;
+                else if (use2[b] && cn[b] == c2[b]) L2[n2++] = val;
+                else L3[n3++] = val;
             }
+            ks_list_rep(k1[b], L1, n1, r);
+            ks_list_rep(k2[b], L2, n2, r);
+            ks_list_rep(k3[b], L3, n3, r);
         }
 #pragma unroll
         for (uint32_t b = 0; b < NB; ++b) {
             if (!live[b]) continue;
             if (en1[b]) ks_store(c.astats_cell(s, c1[b]) + 4u * st[b], k1[b]);
-            if (en2[b] && !(en1[b] && c2[b] == c1[b])) ks_store(c.astats_cell(s, c2[b]) + 4u * st[b], k2[b]);
-            if (nn && !((en1[b] && cn[b] == c1[b]) || (en2[b] && cn[b] == c2[b]))) {
-                bool any = false;
-                for (uint32_t j = 0; j < nn && j < 2u; ++j) any = any || st[b] == 0 || ncnt[j] != 0.0;
-                if (any) ks_store(c.astats_cell(s, cn[b]) + 4u * st[b], k3[b]);
-            }
+            if (use2[b]) ks_store(c.astats_cell(s, c2[b]) + 4u * st[b], k2[b]);
+            if (use3[b]) ks_store(c.astats_cell(s, cn[b]) + 4u * st[b], k3[b]);
         }
     }
     dip_table_add(c, P, h1, h2, s, r);
@@ -1279,7 +1290,7 @@ __device__ inline void flush_sample(const Vx &c, const GParams BT_CAS &P, uint32
     const uint32_t r = c.pend()[s];
     if (r == 0) return;
     c.pend()[s] = 0;
-    replay_collected(c, P, s, c.pend_dip()[2 * s], c.pend_dip()[2 * s + 1], r, 0);
+    replay_collected(c, P, s, c.pend_dip()[2 * s], c.pend_dip()[2 * s + 1], r, (uint32_t)(double)c.pend_nest(s)[3]);
 }
 
 // materialise everything still pending (end of a launch: results may be read next)
@@ -1377,8 +1388,25 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
             if (c.t.copies > 1u) copies_sync();
             PROF(17);
         }
+        {   // the nested sources this sweep sees become the sample's pending copy (what later identical sweeps are compared with)
+            SPtr<double, LANES> pn = c.pend_nest(s);
+            double nv[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t j = 0; j < 2u; ++j)
+                if (j < nn) {
+                    SPtr<double, LANES> q = c.nest_stats(s, j);
+                    nv[3 * j] = q[0];
+                    nv[3 * j + 1] = q[1];
+                    nv[3 * j + 2] = q[2];
+                }
+            for (uint32_t j = 0; j < 2u; ++j) {
+                pn[4 * j] = nv[3 * j];
+                pn[4 * j + 1] = nv[3 * j + 1];
+                pn[4 * j + 2] = nv[3 * j + 2];
+            }
+            pn[3] = (double)nn;
+        }
         replay_collected(c, P, s, h1, h2, 1, nn);   // this sweep + addNestedHaplotypeKmerStats (:360-372)
-        pvalid[s] = nn == 0 ? 1 : 0;
+        pvalid[s] = 1;
         pdip[2 * s] = h1;
         pdip[2 * s + 1] = h2;
         PROF(18);
@@ -1402,9 +1430,23 @@ __device__ BT_NOINLINE void update_allele_kmer_stats(Env env, uint32_t vtx, uint
 #ifdef BT_NODEFER_NARROW
         if (c.t.copies == 1u)
 #endif
-        if (pvalid[s] && !upd[s] && c.nest_n()[s] == 0 && pdip[2 * s] == h1 && pdip[2 * s + 1] == h2) {
-            c.pend()[s] += 1;
-            continue;
+        if (pvalid[s] && !upd[s] && pdip[2 * s] == h1 && pdip[2 * s + 1] == h2) {
+            const uint32_t nn = c.nest_n()[s];
+            bool same = true;
+            if (nn) {   // nested groups: the parent's contribution of this sweep equals the one the pending sweeps saw
+                SPtr<double, LANES> pn = c.pend_nest(s);
+                same = (double)pn[3] == (double)nn;
+                for (uint32_t j = 0; j < 2u; ++j)
+                    if (j < nn) {
+                        SPtr<double, LANES> q = c.nest_stats(s, j);
+                        same = same && (double)q[0] == (double)pn[4 * j] && (double)q[1] == (double)pn[4 * j + 1] && (double)q[2] == (double)pn[4 * j + 2];
+                    }
+            } else
+                same = true;
+            if (same) {
+                c.pend()[s] += 1;
+                continue;
+            }
         }
 #endif
         collect_sample_body(c, P, s, nsub_u, nsub_m);
