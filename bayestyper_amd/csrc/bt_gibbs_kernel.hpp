@@ -54,7 +54,14 @@ __device__ BT_NOINLINE void prepare_nested(Env env, uint32_t v_parent, uint32_t 
     const TileDesc BT_CAS &d = c.d();
     SPtr<uint32_t, LANES> ndcl = c.a<uint32_t>(A_NDCL, d.NDm > 1 ? d.NDm : 1), ndvo = c.a<uint32_t>(A_NDVOFF, d.NDm + 1);
     SPtr<uint16_t, LANES> ndv = c.a<uint16_t>(A_NDVAR, d.NDVm > 1 ? d.NDVm : 1);
+    SPtr<uint32_t, LANES> pver = c.nver(), cver = cc.nver();
     for (uint32_t s = 0; s < P.S; ++s) {
+        // The child's nested info of a sample is a function of the parent's diplotype, k-mer-stats cache and own nested info of that sample:
+        // nothing to do while the parent's version of them is the one this info was prepared from.
+        const uint32_t pv = pver[s];
+        if (cver[P.S + s] == pv) continue;
+        cver[P.S + s] = pv;
+        cver[s] += 1;
         uint8_t ploidy = c.nest_ploidy()[s];
         uint32_t n = c.nest_n()[s];
         for (uint32_t j = 0; j < n; ++j)

@@ -93,6 +93,8 @@ enum TileArr {
     A_ASTATS,       // f64 [V] S*Am*12
     A_NESTPL, A_NESTN,   // u8 [V] S
     A_NESTST,       // f64 [V] S*2*4
+    A_NVER,         // u32 [V] 2*S        [s]: version of what a child's nested info is derived from (the sample's diplotype, its k-mer-stats cache, the vertex's own
+                    //                    nested info); [S + s]: the parent's version this vertex's nested info was last prepared from
     A_PENDNEST,     // f64 [V] S*2*4      the nested sources the pending (deferred) collected sweeps of a sample saw: [s][j][count, fraction, mean], [s][0][3] = how many
     A_SC,           // u32 [V] SC_COUNT
     A_EDGES,        // u32 [V] NEm
@@ -297,6 +299,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     }
     __device__ inline SPtrF<uint8_t, LANES> nest_ploidy() const { return t.harr<uint8_t>(A_NESTPL, v, d().S); }
     __device__ inline SPtrF<uint8_t, LANES> nest_n() const { return t.harr<uint8_t>(A_NESTN, v, d().S); }
+    __device__ inline SPtr<uint32_t, LANES> nver() const { return a<uint32_t>(A_NVER, (uint32_t)d().S * 2); }
     __device__ inline SPtr<double, LANES> pend_nest(uint32_t s) const { return a<double>(A_PENDNEST, (uint32_t)d().S * 8) + (uint32_t)s * 8; }
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
     __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
@@ -639,6 +642,8 @@ __device__ BT_NOINLINE void genotyper_construct(Env env, uint32_t vtx, uint32_t 
         upd[s] = 1;
         c.pend()[s] = 0;
         c.pend_valid()[s] = 0;
+        c.nver()[s] = 1;
+        c.nver()[P.S + s] = 0xFFFFFFFFu;   // nested info not prepared yet
     }
     {
         const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, c.v * 2)[0];
@@ -1320,6 +1325,7 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
         if (u) {
             PROF_CNT(20, 1);
             upd[s] = 0;
+            c.nver()[s] += 1;   // the children's nested info reads this cache
             // Rebuild kmer_stats_cache[s] (VariantClusterHaplotypes.cpp:247-277).  The cache is 2 x V independent KmerStats accumulators
             // (haplotype slot x variant), each a strictly sequential Welford recurrence over the subset k-mers that lie on its haplotype
             // and overlap its variant, in subset order.  Every accumulator is run as its own pass IN REGISTERS — the copies of the group
@@ -1749,6 +1755,7 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
         const uint16_t p1 = dip[2 * ss], p2 = dip[2 * ss + 1];
         dip[2 * ss] = h1;
         dip[2 * ss + 1] = h2;
+        if (c.d().nvm > 1u && (h1 != p1 || h2 != p2)) c.nver()[ss] += 1;
         hfd_increment(c, h1, is_sparse, hap_count);
         hfd_increment(c, h2, is_sparse, hap_count);
         PROF(4);
