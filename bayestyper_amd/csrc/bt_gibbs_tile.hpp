@@ -93,6 +93,8 @@ enum TileArr {
     A_ASTATS,       // f64 [V] S*Am*12
     A_NESTPL, A_NESTN,   // u8 [V] S
     A_NESTST,       // f64 [V] S*2*4
+    A_KSCKEY,       // u32 [V] S*(KSC_WAYS+1)   per sample: the diplotypes (h1 | h2 << 16) whose k-mer-stats cache is kept in A_KSCDATA, then the next entry to replace
+    A_KSCDATA,      // f64 [V] S*KSC_WAYS*2*Vm*4  those caches ([sample][entry][haplotype slot][variant] KmerStats)
     A_NVER,         // u32 [V] 2*S        [s]: version of what a child's nested info is derived from (the sample's diplotype, its k-mer-stats cache, the vertex's own
                     //                    nested info); [S + s]: the parent's version this vertex's nested info was last prepared from
     A_PENDNEST,     // f64 [V] S*2*4      the nested sources the pending (deferred) collected sweeps of a sample saw: [s][j][count, fraction, mean], [s][0][3] = how many
@@ -144,6 +146,8 @@ struct TileDesc {
     uint32_t prio;                  // the tile's wavefronts raise their issue priority (narrow tiles: the launch's critical path)
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
+constexpr uint32_t KSC_WAYS = 4;          // recently rebuilt k-mer-stats caches kept per (cluster, sample), see collect_sample_body
+constexpr uint32_t KSC_NOKEY = 0xFFFEFFFEu;   // (haplotype indices are < 0xFFFE)
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 constexpr uint32_t RESIDENT_ALL = 0xFFFFFFFEu;   // Env/Tile::resident: every vertex of the group has its hot arrays in LDS
 
@@ -299,6 +303,10 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     }
     __device__ inline SPtrF<uint8_t, LANES> nest_ploidy() const { return t.harr<uint8_t>(A_NESTPL, v, d().S); }
     __device__ inline SPtrF<uint8_t, LANES> nest_n() const { return t.harr<uint8_t>(A_NESTN, v, d().S); }
+    __device__ inline SPtr<uint32_t, LANES> ksc_key(uint32_t s) const { return a<uint32_t>(A_KSCKEY, (uint32_t)d().S * (KSC_WAYS + 1u)) + (uint32_t)s * (KSC_WAYS + 1u); }
+    __device__ inline SPtr<double, LANES> ksc_data(uint32_t s, uint32_t e) const {
+        return a<double>(A_KSCDATA, (uint32_t)d().S * KSC_WAYS * 2 * d().Vm * 4) + ((uint32_t)s * KSC_WAYS + e) * 2 * d().Vm * 4;
+    }
     __device__ inline SPtr<uint32_t, LANES> nver() const { return a<uint32_t>(A_NVER, (uint32_t)d().S * 2); }
     __device__ inline SPtr<double, LANES> pend_nest(uint32_t s) const { return a<double>(A_PENDNEST, (uint32_t)d().S * 8) + (uint32_t)s * 8; }
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
@@ -840,7 +848,11 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
     }
     for (uint32_t s = 0; s < P.S; ++s) c.mgen()[s] += 1;   // a new k-mer subset invalidates the multicluster cache
     SPtrF<uint8_t, LANES> upd = c.ksc_upd();
-    for (uint32_t s = 0; s < P.S; ++s) upd[s] = 1;
+    for (uint32_t s = 0; s < P.S; ++s) {
+        upd[s] = 1;
+        for (uint32_t e = 0; e < KSC_WAYS; ++e) c.ksc_key(s)[e] = KSC_NOKEY;   // ... and the kept k-mer-stats caches (collect_sample_body)
+        c.ksc_key(s)[KSC_WAYS] = 0;
+    }
 }
 
 // ---- VariantClusterGenotyper::reset (VariantClusterGenotyper.cpp:113-129) ----
@@ -1334,6 +1346,28 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
             const uint32_t Hm = c.d().Hm, HWm = c.d().HWm, V = c.V;
             const bool two = h2 != NOHAP;
             const uint8_t g = P.gender[s];
+            // Without multicluster k-mers in the chain's subset the cache is a pure function of (sample, diplotype) until the next chain:
+            // the last few are kept (chains move between a handful of diplotypes), a hit is a copy instead of 2 V passes over the subset.
+            const bool keep = nsub_m == 0;
+            const uint32_t dkey = (uint32_t)h1 | ((uint32_t)h2 << 16);
+            SPtr<uint32_t, LANES> kk = c.ksc_key(s);
+            uint32_t hit = KSC_WAYS, victim = 0;
+            if (keep) {
+                uint32_t keys[KSC_WAYS];
+#pragma unroll
+                for (uint32_t e = 0; e < KSC_WAYS; ++e) keys[e] = kk[e];
+                victim = kk[KSC_WAYS];
+#pragma unroll
+                for (uint32_t e = 0; e < KSC_WAYS; ++e)
+                    if (hit == KSC_WAYS && keys[e] == dkey) hit = e;
+            }
+            if (hit < KSC_WAYS) {
+                SPtr<double, LANES> src = c.ksc_data(s, hit);
+                for (uint32_t a = c.t.part; a < 2 * V; a += c.t.copies) {
+                    const uint32_t which = a / V, var = a - which * V;
+                    ks_store(c.ksc(s, which, var), ks_load(src + (which * c.d().Vm + var) * 4u));
+                }
+            } else {
             const Vx::RPtr<uint8_t> sm = c.subm();
             SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
             SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits(), msub = c.msub();
@@ -1390,6 +1424,12 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
                     }
                 }
                 ks_store(c.ksc(s, which, var), acc);
+                if (keep) ks_store(c.ksc_data(s, victim) + (which * c.d().Vm + var) * 4u, acc);
+            }
+            if (keep) {
+                kk[victim] = dkey;
+                kk[KSC_WAYS] = victim + 1u < KSC_WAYS ? victim + 1u : 0u;
+            }
             }
             if (c.t.copies > 1u) copies_sync();
             PROF(17);
