@@ -1126,11 +1126,28 @@ __device__ inline void update_multicluster_multiplicities(const Vx &c, const GPa
     SPtr<uint8_t, LANES> smm = c.smm(), mm = c.msubm(), mcn = c.msubc();
     SPtr<uint32_t, LANES> msh = c.msubsh();
     const uint32_t Hm = c.d().Hm;
-    for (uint32_t sub = 0; sub < nsub_m; ++sub) {
-        const uint8_t shared = shm[(uint32_t)msh[sub] * P.S + s];
-        if (msub_dip_mult(mm, Hm, sub, h1, h2) > 0 && mcn[sub * P.S + s] > 0 && shared != smm[(uint32_t)sub * P.S + s]) c.ksc_upd()[s] = 1;
-        smm[(uint32_t)sub * P.S + s] = shared;
+    bool changed = false;
+    for (uint32_t s0 = 0; s0 < nsub_m; s0 += 8) {   // eight subset k-mers per step: all loads of a step first (the stores to smm would serialise them)
+        uint32_t shi[8];
+        uint8_t sh[8], dm[8], cn[8], old[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) shi[q] = s0 + q < nsub_m ? (uint32_t)msh[s0 + q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t sub = s0 + q < nsub_m ? s0 + q : s0;
+            sh[q] = shm[shi[q] * P.S + s];
+            dm[q] = msub_dip_mult(mm, Hm, sub, h1, h2);
+            cn[q] = mcn[sub * P.S + s];
+            old[q] = smm[sub * P.S + s];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q)
+            if (s0 + q < nsub_m) {
+                changed = changed || (dm[q] > 0 && cn[q] > 0 && sh[q] != old[q]);
+                if (sh[q] != old[q]) smm[(s0 + q) * P.S + s] = sh[q];
+            }
     }
+    if (changed) c.ksc_upd()[s] = 1;
 }
 
 // ---- updateKmerStatsCache / updateAlleleKmerStats (VariantClusterHaplotypes.cpp:235-372) ----
@@ -1712,7 +1729,7 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
             }
             double acc = 0, thr = 0, off = 0;     // off: cumulative weight before the searched range [s0, s1)
             uint32_t s0 = 0, s1 = total;
-            if (par) {
+            {
                 // The weights exp(lp - max) and their running sums are this kernel's own formulation of the draw (the decision is verified
                 // against the reference's chain below), so their summation order is free: every copy takes one contiguous segment of the
                 // candidates — exponentials and a local running sum in registers —, the segment totals are exchanged with lane shuffles,
@@ -1744,15 +1761,9 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
                         else off += tseg;
                     }
                 }
-                copies_sync();
+                if (tsz > 1u) copies_sync();
                 s0 = seg * L < total ? seg * L : total;     // seg == ncp (U * total not below the grand total): empty range -> not safe
                 s1 = s0 + L < total ? s0 + L : total;
-            } else {
-                for (uint32_t i = 0; i < total; ++i) {
-                    acc += bt_exp((double)cum[i] - lpmax);
-                    cum[i] = acc;
-                }
-                thr = u01 * acc;
             }
             PROF(25);
             uint32_t lo = s0, hi = s1;

@@ -410,6 +410,8 @@ BT_HD uint32_t uset_bucket_capacity(uint32_t universe) {
     return b < universe ? b : (universe ? universe : 1u);   // words to store: min(largest bucket count, universe)
 }
 
+// e % B; elements below the bucket count (every element of a set over fewer than B haplotypes) need no division
+BT_HD uint32_t uset_mod(uint32_t e, uint32_t B) { return e < B ? e : e % B; }
 template <class PT>
 BT_HD void uset_init(USetP<PT> s) {
     s.hdr[0] = 1;
@@ -433,7 +435,7 @@ BT_HD void uset_rehash(USetP<PT> s, uint32_t newB) {
     uint32_t bbegin_bkt = 0;
     while (p != US_NONE) {
         uint32_t nx = s.next[p];
-        uint32_t b = p % newB;
+        uint32_t b = uset_mod(p, newB);
         if (s.bkt[b] == US_NONE) {
             s.next[p] = s.hdr[1];
             s.hdr[1] = p;
@@ -464,7 +466,7 @@ BT_HD void uset_insert(USetP<PT> s, uint32_t e) {
         } else
             s.hdr[3] = B;
     }
-    uint32_t b = e % B;
+    uint32_t b = uset_mod(e, B);
     if (s.bkt[b] != US_NONE) {
         uint32_t prev = s.bkt[b];
         s.next[e] = uset_nxt(s, prev);
@@ -472,7 +474,7 @@ BT_HD void uset_insert(USetP<PT> s, uint32_t e) {
     } else {
         s.next[e] = s.hdr[1];
         s.hdr[1] = e;
-        if (s.next[e] != US_NONE) s.bkt[s.next[e] % B] = e;
+        if (s.next[e] != US_NONE) s.bkt[uset_mod(s.next[e], B)] = e;
         s.bkt[b] = US_BEFORE;
     }
     s.hdr[2] = size + 1;
@@ -481,18 +483,18 @@ BT_HD void uset_insert(USetP<PT> s, uint32_t e) {
 template <class PT>
 BT_HD void uset_erase(USetP<PT> s, uint32_t e) {
     const uint32_t B = s.hdr[0];
-    const uint32_t b = e % B;
+    const uint32_t b = uset_mod(e, B);
     uint32_t prev = s.bkt[b];
     while (uset_nxt(s, prev) != e) prev = uset_nxt(s, prev);
     const uint32_t nn = s.next[e];
     if (prev == s.bkt[b]) {
-        if (nn == US_NONE || (nn % B) != b) {
-            if (nn != US_NONE) s.bkt[nn % B] = s.bkt[b];
+        if (nn == US_NONE || uset_mod(nn, B) != b) {
+            if (nn != US_NONE) s.bkt[uset_mod(nn, B)] = s.bkt[b];
             if (s.bkt[b] == US_BEFORE) s.hdr[1] = nn;
             s.bkt[b] = US_NONE;
         }
     } else if (nn != US_NONE) {
-        uint32_t nb = nn % B;
+        uint32_t nb = uset_mod(nn, B);
         if (nb != b) s.bkt[nb] = prev;
     }
     uset_set_nxt(s, prev, nn);
