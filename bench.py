@@ -296,9 +296,14 @@ def main():
         fg2 = synth_graphs.flatten(gs)
         gf, _ = timed(lambda: lib.FindPaths(ctx, fg2, K, 32, 1))
         _, t_find = timed(lambda: gf.sample(bloom, np.arange(n_cl, dtype=np.uint32) + 7))   # the bench's path Bloom stands in for a sample filter
+        # the cluster stage's multigroup pass (one cluster per group) in the reference's single-thread order, into a fresh filter
+        pb2 = lib.Bloom.create(ctx, W + 1_000_000, 1e-4, K, threaded=True)
+        mgt = lib.Table(ctx, max(W // 8, 1024), 1, K)
+        _, t_mg = timed(lambda: gp.count_multigroup(np.arange(n_cl, dtype=np.uint32), pb2, mgt))
+        pb2.close(), mgt.close()
         paths = {"clusters": n_cl, "kmer_windows": int(W), "rows": int(cand["kmer_off"][-1]),
                  "enumerate_windows_per_sec": W / t_create, "bloom_insert_windows_per_sec": W / t_bloom, "classify_windows_per_sec": W / t_cls,
-                 "candidates_windows_per_sec": W / t_cand, "find_sample_paths_clusters_per_sec": n_cl / t_find,
+                 "candidates_windows_per_sec": W / t_cand, "find_sample_paths_clusters_per_sec": n_cl / t_find, "multigroup_windows_per_sec": W / t_mg,
                  "note": "host wall-clock around each C-ABI call (includes the host-side assembly of the candidates stage)"}
         for x in (gp, pb, ptab, mgb, gf):
             x.close()
