@@ -1363,28 +1363,20 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
             const uint32_t Hm = c.d().Hm, HWm = c.d().HWm, V = c.V;
             const bool two = h2 != NOHAP;
             const uint8_t g = P.gender[s];
-            // Without multicluster k-mers in the chain's subset the cache is a pure function of (sample, diplotype) until the next chain:
-            // the last few are kept (chains move between a handful of diplotypes), a hit is a copy instead of 2 V passes over the subset.
-            const bool keep = nsub_m == 0;
+            // The accumulators' state after the unique k-mers of the chain's subset is a pure function of (sample, diplotype) until the next
+            // chain: the last few are kept (chains move between a handful of diplotypes), a hit skips the 2 V passes over the unique subset.
             const uint32_t dkey = (uint32_t)h1 | ((uint32_t)h2 << 16);
             SPtr<uint32_t, LANES> kk = c.ksc_key(s);
-            uint32_t hit = KSC_WAYS, victim = 0;
-            if (keep) {
+            uint32_t hit_way = KSC_WAYS, victim = 0;
+            {
                 uint32_t keys[KSC_WAYS];
 #pragma unroll
                 for (uint32_t e = 0; e < KSC_WAYS; ++e) keys[e] = kk[e];
                 victim = kk[KSC_WAYS];
 #pragma unroll
                 for (uint32_t e = 0; e < KSC_WAYS; ++e)
-                    if (hit == KSC_WAYS && keys[e] == dkey) hit = e;
+                    if (hit_way == KSC_WAYS && keys[e] == dkey) hit_way = e;
             }
-            if (hit < KSC_WAYS) {
-                SPtr<double, LANES> src = c.ksc_data(s, hit);
-                for (uint32_t a = c.t.part; a < 2 * V; a += c.t.copies) {
-                    const uint32_t which = a / V, var = a - which * V;
-                    ks_store(c.ksc(s, which, var), ks_load(src + (which * c.d().Vm + var) * 4u));
-                }
-            } else {
             const Vx::RPtr<uint8_t> sm = c.subm();
             SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
             SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits(), msub = c.msub();
@@ -1395,6 +1387,9 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
                 const uint16_t h = which ? h2 : h1;
                 if (h1 != NOHAP && (which == 0 || two)) {
                     const uint32_t hw = h >> 5, hb = h & 31u;
+                    if (hit_way < KSC_WAYS)
+                        acc = ks_load(c.ksc_data(s, hit_way) + (which * c.d().Vm + var) * 4u);
+                    else {
                     for (uint32_t i0 = 0; i0 < nsub_u; i0 += 8) {
                         const uint32_t nb = nsub_u - i0 < 8u ? nsub_u - i0 : 8u;
                         uint32_t eo[9];
@@ -1427,6 +1422,11 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
                             if (hit) ks_add_r(acc, cn[q] / (double)(uint8_t)(dm[q] + icn[q]));
                         }
                     }
+                    }
+                }
+                // (the state after the unique k-mers is what is kept: the multicluster k-mers' multiplicities depend on the other clusters)
+                if (hit_way == KSC_WAYS) ks_store(c.ksc_data(s, victim) + (which * c.d().Vm + var) * 4u, acc);
+                if (h1 != NOHAP && (which == 0 || two)) {
                     for (uint32_t i = 0; i < nsub_m; ++i) {
                         const uint32_t k = msub[i];
                         if (dip_mult(c, k, h1, h2) == 0) continue;
@@ -1441,12 +1441,10 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
                     }
                 }
                 ks_store(c.ksc(s, which, var), acc);
-                if (keep) ks_store(c.ksc_data(s, victim) + (which * c.d().Vm + var) * 4u, acc);
             }
-            if (keep) {
+            if (hit_way == KSC_WAYS) {
                 kk[victim] = dkey;
                 kk[KSC_WAYS] = victim + 1u < KSC_WAYS ? victim + 1u : 0u;
-            }
             }
             if (c.t.copies > 1u) copies_sync();
             PROF(17);
