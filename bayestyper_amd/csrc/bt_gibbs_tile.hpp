@@ -487,8 +487,6 @@ template <typename P>
 __device__ inline KS ks_load(P p) { return KS{(double)p[0], (double)p[1], (double)p[2], (double)p[3]}; }
 template <typename P>
 __device__ inline void ks_store(P p, const KS &k) { p[0] = k.c; p[1] = k.f; p[2] = k.m; p[3] = k.m2; }
-template <typename P>
-__device__ inline void ks_reset(P ks) { ks[0] = 0; ks[1] = 0; ks[2] = 0; ks[3] = 0; }
 __device__ inline void ks_add_r(KS &k, double value) {
     const double count = k.c + 1.0;
     k.c = count;
@@ -504,20 +502,6 @@ __device__ inline void ks_add(P ks, double value) {
     ks_add_r(k, value);
     ks_store(ks, k);
 }
-// AlleleKmerStats::addKmerStats (KmerStats.cpp:114-121): cell = [3][4]
-template <typename P>
-__device__ inline void aks_add(P cell, const KS &src) {
-    KS a = ks_load(cell), b = ks_load(cell + 4), c = ks_load(cell + 8);
-    ks_add_r(a, src.c);                       // count_stats    <- (getCount(), true)
-    ks_store(cell, a);
-    if (src.c != 0.0) {
-        ks_add_r(b, src.f);                   // fraction_stats <- getFraction()  (skipped when count == 0)
-        ks_add_r(c, src.m);                   // mean_stats     <- getMean()
-        ks_store(cell + 4, b);
-        ks_store(cell + 8, c);
-    }
-}
-
 __device__ inline double count_log_prob(const GParams BT_CAS &P, uint32_t s, uint8_t mult, uint8_t count) {   // CountDistribution.cpp:255-265
     if (mult == 0) return P.lut_n[s * 256u + count];
     return P.lut_g[((uint32_t)s * 256u + mult) * 256u + count];
@@ -1150,30 +1134,7 @@ __device__ inline void update_multicluster_multiplicities(const Vx &c, const GPa
     if (changed) c.ksc_upd()[s] = 1;
 }
 
-// ---- updateKmerStatsCache / updateAlleleKmerStats (VariantClusterHaplotypes.cpp:235-372) ----
-__device__ inline void update_kmer_stats_cache(const Vx &c, const GParams BT_CAS &P, uint32_t k, uint16_t h1, uint16_t h2, uint32_t s, uint8_t mult) {
-    double kmer_count = 0;
-    if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
-    for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
-        const uint32_t var = c.kv_var(e);
-        if (c.kv_bit(e, h1)) ks_add(c.ksc(s, 0, var), kmer_count);
-        if (h2 != NOHAP && c.kv_bit(e, h2)) ks_add(c.ksc(s, 1, var), kmer_count);
-    }
-}
 __device__ inline bool is_missing(const Vx &c, uint32_t var, uint32_t a) { return c.var_dep(var) && a == (uint32_t)c.var_na(var) - 1u; }
-
-__device__ inline void add_haplotype_kmer_stats(const Vx &c, uint32_t s, uint32_t which, uint16_t h) {   // :332-358
-    uint32_t last_non_missing = 0xFFFFFFFFu;
-    for (uint32_t var = 0; var < c.V; ++var) {
-        const uint32_t a = c.hap_allele(h, var);
-        if (is_missing(c, var, a)) {
-            if (last_non_missing != 0xFFFFFFFFu) aks_add(c.astats(s, var, a), ks_load(c.ksc(s, which, last_non_missing)));
-        } else {
-            aks_add(c.astats(s, var, a), ks_load(c.ksc(s, which, var)));
-            last_non_missing = var;
-        }
-    }
-}
 
 // r repetitions of KmerStats::addValue(value) on a register copy.  Once an accumulator has converged onto the value
 // (delta == 0 and the non-zero fraction saturated) every further addValue only increments the count, so the remaining
@@ -1187,19 +1148,6 @@ __device__ inline void ks_add_rep(KS &k, double value, uint32_t r) {
         }
         ks_add_r(k, value);
     }
-}
-
-// the source KmerStats a haplotype contributes to variant `var` (add_haplotype_kmer_stats' missing-allele rule), or count < 0 for "skip"
-__device__ inline bool hap_source(const Vx &c, uint32_t s, uint32_t which, uint16_t h, uint32_t var, uint32_t &last_non_missing, uint32_t &allele, KS &src) {
-    allele = c.hap_allele(h, var);
-    if (is_missing(c, var, allele)) {
-        if (last_non_missing == 0xFFFFFFFFu) return false;
-        src = ks_load(c.ksc(s, which, last_non_missing));
-        return true;
-    }
-    src = ks_load(c.ksc(s, which, var));
-    last_non_missing = var;
-    return true;
 }
 
 // Materialise `r` identical collected sweeps of sample s that drew diplotype (h1, h2) while its k-mer-stats cache stayed

@@ -53,7 +53,7 @@ kernel_table = f"""| Kernel | Work per launch | Bound | Algorithmic bytes (SURVE
 | KMC scan = `kmc_route_kernel` → rocPRIM radix sort (16 bits) → `kmc_probe_kernel` → `kmc_apply_kernel`, per chunk of 2^26 records | R records: decode + ntHash + route key (12 B + 2 B per record written) → sorted by sub-filter → one workgroup per sub-filter copies its ≤ 64 KB slice of the filter to LDS and probes from there, hits go through an LDS queue into a dense list → hits only: table find-or-insert + saturating count | HBM stream (13 B records in, 14 B route records out and back through the sort) | 15.9 B/record pure (13 B record + E[probes]·1 B + 2 % × 34 B table update); the routed form moves 13 + 3×14 B ≈ 55 B/record | {rk['launches_per_step']} scans per step into an emptied table: 2×10^8 records in {rk['insert_launch_ms']:.1f} ms (the inserting scan) / {rk['find_launch_ms']:.1f} ms (the two finding scans) → **{e(bench['kmer_matches_per_sec'])} records/s** = {rk['achieved']:.0f} GB/s algorithmic ({100 * rk['frac']:.1f} % of 8 TB/s); round 1's direct kernel: 121 ms cold (same-address atomics on the key counter, divergent hit path), 14–30 ms warm.  PMC per step (3 scans): {kmc_rd / 1e9:.0f} GB fetched + {kmc_wr / 1e9:.0f} GB written = {(kmc_rd + kmc_wr) / 3 / 2e8:.0f} B/record.  CPU oracle {e(cpu['kmer_matches_per_sec_1core'])} records/s/core |
 | `gibbs_kernel` + `gibbs_simple_kernel` | G groups × 20 chains × 350 sweeps; one launch per LDS class, concurrent | wavefront slots × per-tile latency of a sequential sampler (below); no dense contraction → no MFMA | per (cluster, chain): `K·H + K·(S+4) + 0.1K·4 + 2(13H+4S) + 2·2·2496` B (inputs once, state in/out once): {alg / 1e9:.0f} GB for the bench batch | {bench['config']['groups_per_gpu']} groups / {bench['config']['clusters_per_gpu']} clusters, S = 3: {sched_s:.2f} s per schedule → **{e(bench['gibbs_kernel_cluster_sweeps_per_sec'])} cluster-sweeps/s**, {bench['gpu_over_cpu_allcores']:.0f}× the {cpu['cores']}-thread oracle run ({e(cpu['value'])}); launches of the last step: {classes}.  Algorithmic {rf['achieved']:.0f} GB/s = {100 * rf['frac']:.2f} % of HBM peak — the HBM fraction of this kernel is tiny by construction.  PMC traffic {(rd + wr) / 1e12:.1f} TB per schedule ({rd / 1e12:.1f} read, {wr / 1e12:.1f} written) = {(rd + wr) / alg:.0f}× the algorithmic floor (round 1: 69×) |
 | `bt_paths_*` kernels | every k-mer window of every best path of every cluster of a unit | HBM random access (atomic find-or-insert into two open-addressing indexes) | per window: 1 B text + 17 B k-mer + 2×(20–28 B index entry) + ≈21+S B table probe | {bench['graph_stages']['clusters']} clusters, {e(bench['graph_stages']['kmer_windows'])} windows: enumerate {e(bench['graph_stages']['enumerate_windows_per_sec'])} windows/s, Bloom insert {e(bench['graph_stages']['bloom_insert_windows_per_sec'])}/s, classify {e(bench['graph_stages']['classify_windows_per_sec'])}/s, candidates {e(bench['graph_stages']['candidates_windows_per_sec'])}/s (host assembly included) |
-| `mg_order_kernel` + the multigroup kernels | one lane per group replays the group's `unordered_set`; the rest one lane per k-mer | latency (sequential container replay per group) / HBM random access | ≈ 60 B per distinct (group, k-mer) | 50 000 single-cluster groups, 1.7×10^7 windows: 108 ms = 1.6×10^8 windows/s (`bench.py`: `graph_stages.multigroup_windows_per_sec`); parity-tested with undersized filters and two units |
+| `mg_order_kernel` + the multigroup kernels | one lane per group replays the group's `unordered_set`; the rest one lane per k-mer | latency (sequential container replay per group) / HBM random access | ≈ 60 B per distinct (group, k-mer) | 50 000 single-cluster groups, 1.7×10^7 windows: {e(bench['graph_stages'].get('multigroup_windows_per_sec', 0))} windows/s (`bench.py`: `graph_stages.multigroup_windows_per_sec`, host wall-clock incl. the scratch allocations; 0.7–1.6×10^8 between runs); parity-tested with undersized filters and two units |
 | `find_paths_kernel` | per sample: the best-path search of every cluster of a unit | latency of dependent accesses + random probes into the sample Bloom filter | per vertex nucleotide and live path: one Bloom probe chain | {e(bench['graph_stages']['find_sample_paths_clusters_per_sec'])} clusters/s per sample |
 | `kmer_stats_kernel`, `summary_kernel`, `bloom_*`, `table_*`, `intercluster_kernel`, `classify_kernel`, `kmers_from_sequence_kernel` | one slot / k-mer / position per lane, grid-stride | HBM stream or random access | 4 + spad + 4 B per slot; 8 B per (cluster, sample); ≈3 B/position; 21+S B per path k-mer | parity-tested; `summary_kernel` {[r['dur_ms'] for r in trace if r['kernel'] == 'summary_kernel'][-1]:.0f} ms per step |"""
 
