@@ -247,21 +247,16 @@ __global__ __launch_bounds__(BLOCK) void mg_seq_kernel(const uint32_t *__restric
 // front of the whole list; a rehash re-threads the list front to back the same way (hashtable.h: _M_insert_bucket_begin, _M_rehash_aux).
 // The bucket array itself is not materialised (a small group may inherit millions of buckets from a large earlier one): the buckets in
 // use live in a per-group open-addressing map bucket -> "before" node with room for twice the group's k-mers.
-__global__ __launch_bounds__(BLOCK) void mg_order_kernel(const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ seq_pos, const uint32_t *__restrict__ goff,
-                                                          const uint64_t *__restrict__ moff, const uint64_t *__restrict__ b_init, uint32_t *__restrict__ next,
-                                                          uint32_t *__restrict__ map_key, uint32_t *__restrict__ map_val, uint32_t *__restrict__ time_of_seq, uint32_t G,
-                                                          unsigned k) {
-    const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
-    if (g >= G) return;
-    const uint32_t i0 = goff[g], n = goff[g + 1] - i0;
-    if (n == 0) return;
-    uint32_t *nx = next + i0, *mk = map_key + moff[g], *mv = map_val + moff[g];
-    const uint32_t mmask = (uint32_t)(moff[g + 1] - moff[g]) - 1u;
-    uint64_t B = b_init[g], next_resize = B > 1 ? B : 0;
+// key(node, lo, hi) hands out the node's k-mer; rank_out(node, rank) receives its position in iteration order.  Shared by the kernel and
+// by bt_diag_kmer_set_order (the same code run on the host against the real container in the CPU tests).
+template <typename KeyFn, typename RankFn>
+__host__ __device__ inline void replay_kmer_set(uint32_t n, uint64_t b_init, unsigned k, uint32_t *nx, uint32_t *mk, uint32_t *mv, uint32_t mmask, KeyFn key, RankFn rank_out) {
+    uint64_t B = b_init, next_resize = B > 1 ? B : 0;
     uint32_t head = SQ_NONE;
     auto bucket_of = [&](uint32_t node) {
-        const uint32_t pos = seq_pos[i0 + node];
-        return (uint32_t)(std_hash_bitset(kmers[2 * (uint64_t)pos], kmers[2 * (uint64_t)pos + 1], k) % B);
+        uint64_t lo, hi;
+        key(node, lo, hi);
+        return (uint32_t)(std_hash_bitset(lo, hi, k) % B);
     };
     auto map_clear = [&]() {
         for (uint32_t i = 0; i <= mmask; ++i) mk[i] = SQ_NONE;
@@ -330,11 +325,28 @@ __global__ __launch_bounds__(BLOCK) void mg_order_kernel(const uint64_t *__restr
         }
     }
     uint32_t rank = 0;
+    for (uint32_t p = head; p != SQ_NONE; p = nx[p]) rank_out(p, rank++);
+}
+__global__ __launch_bounds__(BLOCK) void mg_order_kernel(const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ seq_pos, const uint32_t *__restrict__ goff,
+                                                          const uint64_t *__restrict__ moff, const uint64_t *__restrict__ b_init, uint32_t *__restrict__ next,
+                                                          uint32_t *__restrict__ map_key, uint32_t *__restrict__ map_val, uint32_t *__restrict__ time_of_seq, uint32_t G,
+                                                          unsigned k) {
+    const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t i0 = goff[g], n = goff[g + 1] - i0;
+    if (n == 0) return;
 #ifdef BT_MG_INSERTION_ORDER   // (test of the tests: with insertion order instead of the container's order the parity test must fail)
     for (uint32_t p = 0; p < n; ++p) time_of_seq[i0 + p] = i0 + p + 1u;
     return;
 #endif
-    for (uint32_t p = head; p != SQ_NONE; p = nx[p]) time_of_seq[i0 + p] = i0 + (rank++) + 1u;   // times start at 1: 0 = "set by an earlier unit"
+    replay_kmer_set(
+        n, b_init[g], k, next + i0, map_key + moff[g], map_val + moff[g], (uint32_t)(moff[g + 1] - moff[g]) - 1u,
+        [&](uint32_t node, uint64_t &lo, uint64_t &hi) {
+            const uint64_t pos = seq_pos[i0 + node];
+            lo = kmers[2 * pos];
+            hi = kmers[2 * pos + 1];
+        },
+        [&](uint32_t node, uint32_t rank) { time_of_seq[i0 + node] = i0 + rank + 1u; });   // times start at 1: 0 = "set by an earlier unit"
 }
 // first time of every distinct k-mer of the unit
 __global__ __launch_bounds__(BLOCK) void mg_etime_kernel(const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ seq_pos, const uint32_t *__restrict__ time_of_seq,
@@ -843,6 +855,27 @@ int bt_paths_create(bt_ctx *ctx, const bt_paths_batch *b, uint32_t k, bt_paths *
     p->num_valid = std::accumulate(hv.begin(), hv.end(), (uint64_t)0);
     if (h_num_kmer_occurrences) *h_num_kmer_occurrences = p->num_valid;
     *out = p;
+    return BT_OK;
+}
+
+int bt_diag_kmer_set_order(const uint64_t *h_kmers, uint32_t n, uint64_t initial_buckets, unsigned k, uint32_t *h_rank, uint64_t *h_final_buckets) {
+    if (!h_kmers || !h_rank) return fail("bt_diag_kmer_set_order: null argument");
+    if (initial_buckets == 0) initial_buckets = 1;
+    uint64_t cap = 4;
+    while (cap < 2ull * n) cap <<= 1;
+    std::vector<uint32_t> nx(std::max<uint32_t>(n, 1)), mk(cap), mv(cap);
+    replay_kmer_set(
+        n, initial_buckets, k, nx.data(), mk.data(), mv.data(), (uint32_t)cap - 1u,
+        [&](uint32_t node, uint64_t &lo, uint64_t &hi) {
+            lo = h_kmers[2 * (size_t)node];
+            hi = h_kmers[2 * (size_t)node + 1];
+        },
+        [&](uint32_t node, uint32_t rank) { h_rank[node] = rank; });
+    if (h_final_buckets) {
+        uint64_t B = initial_buckets;
+        while (B < n) B = std_next_bucket_count(B);
+        *h_final_buckets = B;
+    }
     return BT_OK;
 }
 

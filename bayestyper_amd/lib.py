@@ -499,6 +499,7 @@ bt_gibbs_posterior_summary = _sig("bt_gibbs_posterior_summary", [vp, vp])
 bt_gibbs_device_bytes = _sig("bt_gibbs_device_bytes", [vp, u64p])
 bt_diag_uset_replay = _sig("bt_diag_uset_replay", [C.c_uint32, vp, vp, C.c_uint64, vp, u32p])
 bt_diag_rng = _sig("bt_diag_rng", [C.c_uint32, C.c_int, vp, vp, C.c_uint64, vp])
+bt_diag_kmer_set_order = _sig("bt_diag_kmer_set_order", [vp, C.c_uint32, C.c_uint64, C.c_uint, vp, vp])
 
 
 class Gibbs:

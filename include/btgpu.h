@@ -475,6 +475,11 @@ int bt_diag_uset_replay(uint32_t universe, const uint8_t *ops, const uint32_t *v
  * 2 gamma(shape=a, scale=b) with one persistent distribution object, 3 uniform_int(0, a), 4 bernoulli(float a),
  * 5 std::shuffle of 0..a-1 (h_out gets the permutation as doubles, n ignored) */
 int bt_diag_rng(uint32_t seed, int kind, const double *a, const double *b, uint64_t n, double *h_out);
+/* Host-side run of the container replay behind bt_paths_count_multigroup: n DISTINCT k-mers (2 x u64 each) are inserted, in the given
+ * order, into an emulated libstdc++ std::unordered_set<std::bitset<2k>> that starts with `initial_buckets` buckets (1 = freshly
+ * constructed; a set that was clear()ed keeps its bucket count); h_rank[i] = position of k-mer i in the set's iteration order,
+ * *h_final_buckets = its bucket count afterwards.  (CPU tests compare it with the real container.) */
+int bt_diag_kmer_set_order(const uint64_t *h_kmers, uint32_t n, uint64_t initial_buckets, unsigned k, uint32_t *h_rank, uint64_t *h_final_buckets);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,8 @@
 // SparsityEstimator, CountAllocation, Utils.  It is used by tests/ to pin the restatement in
 // oracle_kmer.cpp / oracle_gibbs.cpp; it never ships and is never called by the product.
 #include <bitset>
+#include <unordered_map>
+#include <unordered_set>
 #include <cstring>
 #include <random>
 #include <string>
@@ -195,6 +197,25 @@ uint64_t ref_hybrid_hash_order(const char *kmers, uint64_t n, uint64_t root_hash
     uint64_t j = 0;
     for (auto it = hash.begin(); it != hash.end(); it++) order_out[j++] = (*it).second;
     return j;
+}
+// the container KmerCounter::countPathMultigroupKmersCallback collects a group's path k-mers in (KmerCounter.cpp:111-119): a
+// std::unordered_set<std::bitset<2k>> that is clear()ed between groups.  Groups are given back to back (group_off[g] .. group_off[g+1]);
+// order_out receives, group by group, the indices (within the group) of its k-mers in iteration order; buckets_out[g] = bucket_count()
+// after the group.  K-mers go through the reference's Nucleotide::ntToBit.
+void ref_group_kmer_set_orders(const char *kmers, const uint64_t *group_off, uint64_t num_groups, uint32_t *order_out, uint64_t *buckets_out) {
+    std::unordered_set<std::bitset<BT_KMER_SIZE * 2>> set;
+    for (uint64_t g = 0; g < num_groups; g++) {
+        set.clear();
+        std::unordered_map<std::bitset<BT_KMER_SIZE * 2>, uint32_t> index;
+        for (uint64_t i = group_off[g]; i < group_off[g + 1]; i++) {
+            auto b = Nucleotide::ntToBit<BT_KMER_SIZE>(std::string(kmers + i * K, K));
+            set.emplace(b.first);
+            index.emplace(b.first, (uint32_t)(i - group_off[g]));
+        }
+        uint64_t j = group_off[g];
+        for (auto &b : set) order_out[j++] = index.at(b);
+        buckets_out[g] = set.bucket_count();
+    }
 }
 // CountAllocation (src/bayesTyper/CountAllocation.cpp:34-57): addCount per (sample, count) then mergeInCountAllocations of a second one
 void ref_count_allocation(unsigned short num_samples, const unsigned short *s1, const unsigned char *c1, uint64_t n1, const unsigned short *s2, const unsigned char *c2, uint64_t n2,

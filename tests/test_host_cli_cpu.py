@@ -57,6 +57,42 @@ def test_bitset_hash_known_answer_and_reference(oracle, ref):
         assert dll.bth_bitset_hash(int(packed[i, 0]), int(packed[i, 1]), K) % 4 ** 12 == want
 
 
+def test_multigroup_kmer_set_order_vs_reference_container(oracle, ref):
+    """The order bt_paths_count_multigroup visits a group's k-mers in = the iteration order of the std::unordered_set<std::bitset<110>> the
+    reference collects them in and clear()s between groups (KmerCounter.cpp:111-119).  The library's replay of that container (the same
+    host/device code the kernel runs: bt_diag_kmer_set_order) against the real container filled through the reference's Nucleotide::ntToBit
+    (oracle/_ref): a sequence of groups of very different sizes — growth through several rehashes inside a group, small groups that
+    inherit a large bucket count, empty groups — ranks and bucket counts must agree group by group."""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(2024)
+    sizes = [5, 1, 0, 40, 13, 14, 3, 700, 2, 60, 5000, 1, 17, 30000, 12, 100]
+    groups = []
+    for n in sizes:
+        km = np.unique(_oracle.random_kmers(rng, n, K).reshape(-1, K), axis=0) if n else np.zeros((0, K), np.uint8)
+        groups.append(km[rng.permutation(len(km))])
+    off = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.uint64)
+    flat = np.ascontiguousarray(np.concatenate(groups)).reshape(-1)
+    want_order = np.zeros(int(off[-1]), np.uint32)
+    want_buckets = np.zeros(len(groups), np.uint64)
+    ref.l.ref_group_kmer_set_orders.restype = None
+    ref.l.ref_group_kmer_set_orders.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    ref.l.ref_group_kmer_set_orders(flat.ctypes.data, off.ctypes.data, len(groups), want_order.ctypes.data, want_buckets.ctypes.data)
+    buckets = 1
+    for g, km in enumerate(groups):
+        n = len(km)
+        packed = _pack(oracle, np.ascontiguousarray(km).reshape(-1)) if n else np.zeros((0, 2), np.uint64)
+        rank = np.zeros(max(n, 1), np.uint32)
+        final = C.c_uint64(0)
+        lib.check(lib.bt_diag_kmer_set_order(packed.ctypes.data if n else rank.ctypes.data, n, buckets, K, rank.ctypes.data, C.byref(final)))
+        order = np.zeros(n, np.uint32)
+        order[rank[:n]] = np.arange(n, dtype=np.uint32)          # order[j] = the k-mer visited j-th
+        assert np.array_equal(order, want_order[int(off[g]):int(off[g + 1])]), f"group {g} ({n} k-mers, {buckets} buckets inherited)"
+        assert final.value == int(want_buckets[g]), (g, final.value, int(want_buckets[g]))
+        buckets = final.value
+    assert buckets >= 30000
+
+
 @pytest.mark.parametrize("root_size,n", [(4 ** 12, 20000), (64, 3000), (1, 300)])
 def test_parameter_kmer_order_vs_reference(oracle, ref, root_size, n):
     """KmerHash::shuffle(seed) + iteration (what picks the <= 10^6 parameter k-mers, main.cpp:326-341): the reference's own HybridHash
