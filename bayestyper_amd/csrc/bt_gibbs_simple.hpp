@@ -126,8 +126,10 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
             fill_unique_cache(env, 0);
             sc[SC_UC_DIRTY] = 0;
         }
+        PROF_DECL;
         r0.topup();
         r1.topup();
+        PROF(11);
         // ---- sampleDiplotypes ----
         uint32_t nzl[2] = {0, 0}, nnz = 0;
         if (nz[0]) nzl[nnz++] = 0;
@@ -211,6 +213,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
             if (h1 != p1 || h2 != p2) upd[s] = 1;   // update_multicluster_multiplicities without multicluster k-mers
             if (tracing) trace_row[s] = (uint32_t)h1 | ((uint32_t)h2 << 16);
         }
+        PROF(2);
         // ---- collected sweep: diplotype_sampling_frequencies + updateAlleleKmerStats, deferred while nothing changes ----
         if (collect) {
             for (uint32_t s = 0; s < S; ++s) {
@@ -221,6 +224,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
                 collect_sample_slow(env, 0, s);
             }
         }
+        PROF(6);
         // ---- sampleHaplotypeFrequencies ----
         if (st.hap_count > 0) {
             double saved = st.fnd_saved;
@@ -308,6 +312,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
             st.fnd_avail = avail;
         }
         st.hap_count = 0;
+        PROF(7);
     }
     // ---- back to the general representation ----
     mt_close(r0);
