@@ -270,11 +270,12 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs):
     return out
 
 
-@pytest.mark.parametrize("genome_len,num_snvs,gibbs", [(60_000, 300, dict(chains=20, burn=100, samples=250)), (1_000_000, 5000, dict(chains=3, burn=15, samples=40))],
-                         ids=["small-default-schedule", "C1-1Mb-5000-SNVs"])
-def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genome_len, num_snvs, gibbs):
+@pytest.mark.parametrize("genome_len,num_snvs,num_samples,gibbs", [(60_000, 300, 1, dict(chains=20, burn=100, samples=250)), (1_000_000, 5000, 1, dict(chains=3, burn=15, samples=40)),
+                                                                    (80_000, 400, 3, dict(chains=4, burn=20, samples=60))],
+                         ids=["small-default-schedule", "C1-1Mb-5000-SNVs", "trio-female-male-female"])
+def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genome_len, num_snvs, num_samples, gibbs):
     ref = _oracle.load_ref()
-    ds = c1_dataset.make(str(tmp_path / "data"), oracle, genome_len, num_snvs, 1, num_error_kmers=200_000)
+    ds = c1_dataset.make(str(tmp_path / "data"), oracle, genome_len, num_snvs, num_samples, num_error_kmers=200_000, genders=["F", "M", "F"][:num_samples])
     seed = 42
     prefix = str(tmp_path / "bt")
     r = subprocess.run([EXE, "cluster", "-v", os.path.join(ds["dir"], "candidates.vcf"), "-s", os.path.join(ds["dir"], "samples.tsv"), "-g", os.path.join(ds["dir"], "genome.fa"), "-o", prefix,
@@ -296,20 +297,23 @@ def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genom
     # genotype stage files
     rows = open(prefix + "_genomic_parameters.txt").read().split("\n")
     assert rows[0] == "Sample\tMean\tVariance"
-    name, m, v = rows[1].split("\t")
-    assert name == "sample1" and abs(float(m) - want["genomic"][0][0]) < 1e-3 and abs(float(v) - want["genomic"][0][1]) < 1e-2 and abs(float(m) - 15) < 0.5
+    names = [f"sample{i + 1}" for i in range(num_samples)]
+    for i in range(num_samples):
+        name, m, v = rows[1 + i].split("\t")
+        assert name == names[i] and abs(float(m) - want["genomic"][i][0]) < 1e-3 and abs(float(v) - want["genomic"][i][1]) < 1e-2 and abs(float(m) - 15) < 0.5
     noise = open(prefix + "_noise_parameters.txt").read().split("\n")
-    assert noise[0] == "Chain\tIteration\tsample1"
+    assert noise[0] == "Chain\tIteration\t" + "\t".join(names)
     want_rows = ["%d\t%d\t%s" % (int(r_[0]), int(r_[1]), "\t".join(_fmt(x) for x in r_[2:])) for r_ in want["noise_rows"]]
     assert noise[1:-1] == want_rows
     vcf = open(prefix + ".vcf").read()
     header = [x for x in vcf.split("\n") if x.startswith("#")]
-    assert header[0] == "##fileformat=VCFv4.2" and sum(x.startswith("##BayesTyperOptions=command:") for x in header) == 2 and header[-1].endswith("FORMAT\tsample1")
+    assert header[0] == "##fileformat=VCFv4.2" and sum(x.startswith("##BayesTyperOptions=command:") for x in header) == 2 and header[-1].endswith("FORMAT\t" + "\t".join(names))
     assert any('command:"cluster"' in x and 'random-seed:"42"' in x and 'max-number-of-sample-haplotypes:"32"' in x for x in header)
     body = "".join(x + "\n" for x in vcf.split("\n") if x and not x.startswith("#"))
     assert body == want["vcf_body"]
     # and the calls are right: the sample's true genotypes are recovered
-    calls = {int(x.split("\t")[1]) - 1: x.split("\t")[9].split(":")[0] for x in body.strip().split("\n")}
-    truth = {int(p): {0: "0/0", 1: "0/1", 2: "1/1"}[int(g)] for p, g in zip(ds["pos"], ds["truth"][0])}
-    agree = sum(calls[p] == t for p, t in truth.items())
-    assert agree >= 0.97 * num_snvs, agree
+    for i in range(num_samples):
+        calls = {int(x.split("\t")[1]) - 1: x.split("\t")[9 + i].split(":")[0] for x in body.strip().split("\n")}
+        truth = {int(p): {0: "0/0", 1: "0/1", 2: "1/1"}[int(g)] for p, g in zip(ds["pos"], ds["truth"][i])}
+        agree = sum(calls[p] == t for p, t in truth.items())
+        assert agree >= 0.97 * num_snvs, (i, agree)
