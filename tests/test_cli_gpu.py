@@ -131,7 +131,7 @@ def _fmt(x):
     return "%g" % x
 
 
-def oracle_pipeline(oracle, ref, ds, seed, gibbs):
+def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False):
     import oracle_writer
     from bayestyper_amd.host import genotypes as G   # (ctypes signatures of the oracle's genotype functions only; `fn=` selects the oracle)
 
@@ -238,16 +238,22 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs):
     ploidy = np.full((len(groups), S), 2, np.uint8)
     flat = _gibbs_batch(cand, f, groups, S, ploidy, gender, cluster_ids, sources, out_edges)
     kw = dict(seed=seed, chains=gibbs["chains"], burn=gibbs["burn"], iters=gibbs["samples"])
-    ogb = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, noise_seeding=1, **kw)
-    trace, _, final = ogb.estimate_noise()
-    ogb.close()
-    out["noise_rows"] = trace
-    lut_n2 = np.zeros(S * 256)
-    oracle.l.orc_build_luts(S, _oracle._ptr(ps), _oracle._ptr(sz), _oracle._ptr(np.ascontiguousarray(final, np.float64)), _oracle._ptr(np.zeros(S * 65536)), _oracle._ptr(lut_n2))
-    ogb = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n2, **kw)
-    ogb.run(8)
-    ro = ogb.results()
-    ogb.close()
+    if noise_genotyping:   # --noise-genotyping: estimateNoiseAndGenotypes (InferenceEngine.cpp:384-472), noise rates and genotypes in one loop
+        ogb = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, noise_seeding=1, **kw)
+        out["noise_rows"] = ogb.estimate_noise_and_genotypes()
+        ro = ogb.results()
+        ogb.close()
+    else:
+        ogb = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, noise_seeding=1, **kw)
+        trace, _, final = ogb.estimate_noise()
+        ogb.close()
+        out["noise_rows"] = trace
+        lut_n2 = np.zeros(S * 256)
+        oracle.l.orc_build_luts(S, _oracle._ptr(ps), _oracle._ptr(sz), _oracle._ptr(np.ascontiguousarray(final, np.float64)), _oracle._ptr(np.zeros(S * 65536)), _oracle._ptr(lut_n2))
+        ogb = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n2, **kw)
+        ogb.run(8)
+        ro = ogb.results()
+        ogb.close()
     # ---- genotypes -> VCF lines ----
     mf = np.array([1 - np.exp(-0.275 * m) for m in means], np.float32)
     fn = oracle.l.orc_cluster_output_columns
@@ -270,10 +276,11 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs):
     return out
 
 
-@pytest.mark.parametrize("genome_len,num_snvs,num_samples,gibbs", [(60_000, 300, 1, dict(chains=20, burn=100, samples=250)), (1_000_000, 5000, 1, dict(chains=3, burn=15, samples=40)),
-                                                                    (80_000, 400, 3, dict(chains=4, burn=20, samples=60))],
-                         ids=["small-default-schedule", "C1-1Mb-5000-SNVs", "trio-female-male-female"])
-def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genome_len, num_snvs, num_samples, gibbs):
+@pytest.mark.parametrize("genome_len,num_snvs,num_samples,gibbs,noise_genotyping",
+                         [(60_000, 300, 1, dict(chains=20, burn=100, samples=250), False), (1_000_000, 5000, 1, dict(chains=3, burn=15, samples=40), False),
+                          (80_000, 400, 3, dict(chains=4, burn=20, samples=60), False), (50_000, 250, 2, dict(chains=3, burn=12, samples=30), True)],
+                         ids=["small-default-schedule", "C1-1Mb-5000-SNVs", "trio-female-male-female", "noise-genotyping-two-samples"])
+def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genome_len, num_snvs, num_samples, gibbs, noise_genotyping):
     ref = _oracle.load_ref()
     ds = c1_dataset.make(str(tmp_path / "data"), oracle, genome_len, num_snvs, num_samples, num_error_kmers=200_000, genders=["F", "M", "F"][:num_samples])
     seed = 42
@@ -284,11 +291,11 @@ def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genom
     assert "BayesTyper cluster completed succesfully!" in r.stdout
     r = subprocess.run([EXE, "genotype", "-v", prefix + "_unit_1/variant_clusters.bin", "-c", prefix + "_cluster_data", "-s", os.path.join(ds["dir"], "samples.tsv"), "-g",
                         os.path.join(ds["dir"], "genome.fa"), "-o", prefix, "-r", str(seed), "--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]),
-                        "--gibbs-samples", str(gibbs["samples"])], capture_output=True, text=True)
+                        "--gibbs-samples", str(gibbs["samples"])] + (["--noise-genotyping"] if noise_genotyping else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr
     assert "BayesTyper genotype completed succesfully!" in r.stdout and f"- {num_snvs} were genotyped" in r.stdout
 
-    want = oracle_pipeline(oracle, ref, ds, seed, gibbs)
+    want = oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping)
     # cluster stage files
     assert gzip.open(prefix + "_cluster_data/intercluster_regions.txt.gz", "rt").read() == want["regions_text"]
     got_params = gzip.open(prefix + "_cluster_data/parameter_kmers.fa.gz", "rt").read().split("\n")
