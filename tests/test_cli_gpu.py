@@ -291,7 +291,7 @@ def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genom
     assert "BayesTyper cluster completed succesfully!" in r.stdout
     r = subprocess.run([EXE, "genotype", "-v", prefix + "_unit_1/variant_clusters.bin", "-c", prefix + "_cluster_data", "-s", os.path.join(ds["dir"], "samples.tsv"), "-g",
                         os.path.join(ds["dir"], "genome.fa"), "-o", prefix, "-r", str(seed), "--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]),
-                        "--gibbs-samples", str(gibbs["samples"])] + (["--noise-genotyping"] if noise_genotyping else []), capture_output=True, text=True)
+                        "--gibbs-samples", str(gibbs["samples"])] + (["--noise-genotyping", "-z"] if noise_genotyping else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr
     assert "BayesTyper genotype completed succesfully!" in r.stdout and f"- {num_snvs} were genotyped" in r.stdout
 
@@ -312,7 +312,7 @@ def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genom
     assert noise[0] == "Chain\tIteration\t" + "\t".join(names)
     want_rows = ["%d\t%d\t%s" % (int(r_[0]), int(r_[1]), "\t".join(_fmt(x) for x in r_[2:])) for r_ in want["noise_rows"]]
     assert noise[1:-1] == want_rows
-    vcf = open(prefix + ".vcf").read()
+    vcf = gzip.open(prefix + ".vcf.gz", "rt").read() if noise_genotyping else open(prefix + ".vcf").read()   # (-z / --gzip-output in the noise-genotyping case)
     header = [x for x in vcf.split("\n") if x.startswith("#")]
     assert header[0] == "##fileformat=VCFv4.2" and sum(x.startswith("##BayesTyperOptions=command:") for x in header) == 2 and header[-1].endswith("FORMAT\t" + "\t".join(names))
     assert any('command:"cluster"' in x and 'random-seed:"42"' in x and 'max-number-of-sample-haplotypes:"32"' in x for x in header)
