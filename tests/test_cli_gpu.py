@@ -342,3 +342,59 @@ def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genom
         assert len(truth) == want["unit_variants"]
         agree = sum(calls[p] == t for p, t in truth.items())
         assert agree >= 0.97 * len(truth), (i, agree)
+
+
+def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
+    """The executable on candidates of every flavour the parser distinguishes — SNVs, indels, multi-allelic records, MNVs and blocks of structural
+    variants with variants nested inside their alleles (nested variant-cluster groups, '*' alleles, ACO attributes) — and two samples (female,
+    male) whose haplotypes carry random subsets of the candidate alleles: every output file against the oracle pipeline."""
+    from test_pipeline_gpu import sample_haplotype
+
+    ref = _oracle.load_ref()
+    rng = np.random.default_rng(77)
+    seq = "".join(rng.choice(list("ACGT"), 120_000))
+    genome = [["chr1", seq, False]]
+    vcf = T.make_vcf(rng, genome, K, 70, False, extra_contig=False, sv_blocks=3)
+    records = []
+    for line in vcf.split("\n"):
+        if line and line[0] != "#":
+            _, p, _, r_, alt = line.split("\t")[:5]
+            records.append((int(p) - 1, r_, [a for a in alt.split(",") if a != "*"]))
+    d = tmp_path / "data"
+    os.makedirs(d)
+    with open(d / "genome.fa", "w") as fh:
+        fh.write(">chr1\n" + "\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + "\n")
+    open(d / "candidates.vcf", "w").write(vcf)
+    with open(d / "samples.tsv", "w") as sf:
+        for s, gender in enumerate(["F", "M"]):
+            text = "N".join(sample_haplotype(rng, seq, records) for _ in range(2))
+            km, va = oracle.kmers_from_sequence(text.encode(), K)
+            present = np.unique(km[va == 1], axis=0)
+            cnt = (rng.poisson(14, len(present)) + 1).astype(np.uint32)
+            asc = oracle.unpack(present, K).reshape(-1, K)
+            order = np.lexsort(asc.T[::-1])                     # KMC order = ascending ASCII order
+            prefix = str(d / f"sample{s + 1}")
+            oracle.kmc_write(prefix, np.ascontiguousarray(asc[order]).reshape(-1), cnt[order], K, 7, 1)
+            bloom = OrcBloom(oracle, len(present), 1e-3, K)
+            bloom.insert(np.ascontiguousarray(asc).reshape(-1))
+            bloom.save(prefix)
+            bloom.close()
+            sf.write(f"sample{s + 1}\t{gender}\t{prefix}\n")
+    ds = {"genome": seq, "dir": str(d)}
+    seed, gibbs = 11, dict(chains=3, burn=10, samples=25)
+    prefix = str(tmp_path / "bt")
+    r = subprocess.run([EXE, "cluster", "-v", str(d / "candidates.vcf"), "-s", str(d / "samples.tsv"), "-g", str(d / "genome.fa"), "-o", prefix, "-r", str(seed)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    r = subprocess.run([EXE, "genotype", "-v", prefix + "_unit_1/variant_clusters.bin", "-c", prefix + "_cluster_data", "-s", str(d / "samples.tsv"), "-g", str(d / "genome.fa"), "-o", prefix,
+                        "-r", str(seed), "--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]), "--gibbs-samples", str(gibbs["samples"])],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    want = oracle_pipeline(oracle, ref, ds, seed, gibbs)
+    assert want["num_clusters"] > want["num_groups"] > 20          # nested variant-cluster groups are present
+    assert gzip.open(prefix + "_cluster_data/intercluster_regions.txt.gz", "rt").read() == want["regions_text"]
+    got_params = gzip.open(prefix + "_cluster_data/parameter_kmers.fa.gz", "rt").read().split("\n")
+    assert got_params[1:-1] == want["parameter_kmers"]
+    noise = open(prefix + "_noise_parameters.txt").read().split("\n")
+    assert noise[1:-1] == ["%d\t%d\t%s" % (int(r_[0]), int(r_[1]), "\t".join(_fmt(x) for x in r_[2:])) for r_ in want["noise_rows"]]
+    body = "".join(x + "\n" for x in open(prefix + ".vcf").read().split("\n") if x and not x.startswith("#"))
+    assert body == want["vcf_body"] and body.count("\n") > 100
