@@ -137,7 +137,13 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
     from bayestyper_amd.host import genotypes as G   # (ctypes signatures of the oracle's genotype functions only; `fn=` selects the oracle)
 
     out = {}
-    genome = [["chr1", ds["genome"], False]]
+    genome = ds.get("contigs") or [["chr1", ds["genome"], False]]   # [name, sequence, is_decoy]
+    seqs = {name: seq for name, seq, _ in genome}
+    chrom_rank = {name: i for i, (name, _, _) in enumerate(genome)}
+
+    def chrom_ploidy(name):   # ChromosomePloidy.cpp:40-180 without a ploidy file: (female, male)
+        return {"x": (2, 1), "chrx": (2, 1), "y": (0, 1), "chry": (0, 1)}.get(name.lower(), (2, 2))
+
     vcf = open(os.path.join(ds["dir"], "candidates.vcf")).read()
     sample_rows = [line.rstrip("\n").split("\t") for line in open(os.path.join(ds["dir"], "samples.tsv"))]
     S = len(sample_rows)
@@ -149,8 +155,7 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
     units, _, regions_sorted, _ = T.parse_dump(T.oracle_text(oracle, vcf, genome, K, min_unit_variants))
     out["num_units"] = len(units)
     out["regions_text"] = "".join(f"{c}\t{d}\t{s}\t{e}\n" for c, d, s, e in regions_sorted)
-    chrom = ds["genome"].encode()
-    genome_len = len(ds["genome"])
+    genome_len = sum(len(seq) for _, seq, decoy in genome if not decoy)
     expected_path = int(np.ceil(genome_len * (1 + 0.05 * 2 * S)))
     pb = OrcBloom(oracle, expected_path, 1e-4, K, threaded=True)
     mg_table = OrcTable(oracle, 1, K)
@@ -164,7 +169,7 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
                 where.append((gi, vi))
                 out_edges.append(v["edges"])
                 cluster_ids.append(v["cluster_idx"])
-        graphs = [_graph_arrays(oracle, chrom, groups_u[gi]["vertices"][vi]["vars"], groups_u[gi]["vertices"][vi]["red"], groups_u[gi]["vertices"][vi]["contained"]) for gi, vi in where]
+        graphs = [_graph_arrays(oracle, seqs[groups_u[gi]["vertices"][vi]["chrom"]].encode(), groups_u[gi]["vertices"][vi]["vars"], groups_u[gi]["vertices"][vi]["red"], groups_u[gi]["vertices"][vi]["contained"]) for gi, vi in where]
         # ---- best paths per sample ----
         og = OrcGraphs(oracle, _flatten(graphs), K)
         for s in range(S):
@@ -188,7 +193,7 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
     fraction = min(1.0, np.float32(3_000_000) / np.float32(num_region_kmers))
     ptab = OrcTable(oracle, 1, K)
     for i, (c, d, s, e) in enumerate(regions_sorted):
-        ptab.count_parameter_kmers(pb, ds["genome"][s:e + 1].encode(), d, seed + i, fraction)
+        ptab.count_parameter_kmers(pb, seqs[c][s:e + 1].encode(), d, seed + i, fraction)
     pk, _, pmeta = ptab.export()
     asc = oracle.unpack(pk, K)
     order = np.zeros(len(pk), np.uint32)
@@ -214,7 +219,7 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
     table.insert(flat_params, mark_parameter=True)
     og.count_kmers(pb)
     for c, d, s, e in regions_sorted:
-        table.count_intercluster(pb, ds["genome"][s:e + 1].encode(), d, 2, 2)
+        table.count_intercluster(pb, seqs[c][s:e + 1].encode(), d, *chrom_ploidy(c))
     for s in range(S):
         db = OrcKmc(oracle, sample_rows[s][2])
         table.parse_sample_kmers(pb, db, s)
@@ -242,7 +247,7 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
     lut_g, lut_n = np.zeros(S * 65536), np.zeros(S * 256)
     oracle.l.orc_build_luts(S, _oracle._ptr(ps), _oracle._ptr(sz), _oracle._ptr(np.full(S, 0.05)), _oracle._ptr(lut_g), _oracle._ptr(lut_n))   # (the noise table is replaced by the driver)
     # ---- Gibbs: estimateNoise, then estimateGenotypes ----
-    ploidy = np.full((len(groups), S), 2, np.uint8)
+    ploidy = np.array([[chrom_ploidy(g["vertices"][0]["chrom"])[gender[s_]] for s_ in range(S)] for g in groups_o], np.uint8).reshape(len(groups), S)
     flat = _gibbs_batch(cand, f, groups, S, ploidy, gender, cluster_ids, sources, out_edges)
     kw = dict(seed=seed, chains=gibbs["chains"], burn=gibbs["burn"], iters=gibbs["samples"])
     if noise_genotyping:   # --noise-genotyping: estimateNoiseAndGenotypes (InferenceEngine.cpp:384-472), noise rates and genotypes in one loop
@@ -274,7 +279,7 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
         vcr = "%s:%d-%d" % (v["chrom"], infos[0][0] + 1, max(pos + max(rl for rl, _ in alts) for pos, _, _, alts in infos))
         for (pos, vid, dep, alts), col, aco in zip(infos, cols, v["aco"]):
             full = [(rl, seq, a) for (rl, seq), a in zip(alts, aco)]
-            lines.append((pos, oracle_writer.vcf_line(v["chrom"], ds["genome"], pos, vid, bool(dep), full, col, len(infos), vcr, len(g["vertices"]), g["region"],
+            lines.append(((chrom_rank[v["chrom"]], pos), oracle_writer.vcf_line(v["chrom"], seqs[v["chrom"]], pos, vid, bool(dep), full, col, len(infos), vcr, len(g["vertices"]), g["region"],
                                                        int(flat["num_haplotypes"][c]))))
     out["vcf_body"] = "".join(line for _, line in sorted(lines))
     out["num_groups"], out["num_clusters"] = len(groups), NC
@@ -398,3 +403,70 @@ def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
     assert noise[1:-1] == ["%d\t%d\t%s" % (int(r_[0]), int(r_[1]), "\t".join(_fmt(x) for x in r_[2:])) for r_ in want["noise_rows"]]
     body = "".join(x + "\n" for x in open(prefix + ".vcf").read().split("\n") if x and not x.startswith("#"))
     assert body == want["vcf_body"] and body.count("\n") > 100
+
+
+def test_sex_chromosomes_and_decoys_through_the_executable(oracle, tmp_path):
+    """Several contigs with different ploidies and a decoy file: chr1 (diploid), chrX (female 2 / male 1), chrY (female 0 / male 1; the
+    reference's default ploidies by contig name, ChromosomePloidy.cpp:40-180) and a decoy contig (-d) that repeats a stretch of chr1 with
+    candidates on it (their path k-mers become decoy k-mers and are excluded).  A female and a male sample; every output file against the oracle
+    pipeline."""
+    from test_pipeline_gpu import sample_haplotype
+
+    ref = _oracle.load_ref()
+    rng = np.random.default_rng(99)
+    contigs = [["chr1", "".join(rng.choice(list("ACGT"), 50_000)), False], ["chrX", "".join(rng.choice(list("ACGT"), 30_000)), False],
+               ["chrY", "".join(rng.choice(list("ACGT"), 20_000)), False]]
+    decoy = "".join(rng.choice(list("ACGT"), 3_000)) + contigs[0][1][20_000:24_000] + "".join(rng.choice(list("ACGT"), 3_000))
+    vcf = T.make_vcf(rng, contigs, K, 60, False, extra_contig=False, sv_blocks=1)
+    records = {}
+    for line in vcf.split("\n"):
+        if line and line[0] != "#":
+            c, p, _, r_, alt = line.split("\t")[:5]
+            records.setdefault(c, []).append((int(p) - 1, r_, [a for a in alt.split(",") if a != "*"]))
+    assert any(20_000 <= p < 24_000 for p, _, _ in records["chr1"])
+    d = tmp_path / "data"
+    os.makedirs(d)
+    with open(d / "genome.fa", "w") as fh:
+        for name, seq, _ in contigs:
+            fh.write(f">{name}\n" + "\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + "\n")
+    with open(d / "decoy.fa", "w") as fh:
+        fh.write(">decoy1\n" + "\n".join(decoy[i:i + 60] for i in range(0, len(decoy), 60)) + "\n")
+    open(d / "candidates.vcf", "w").write(vcf)
+    copies = {"F": {"chr1": 2, "chrX": 2, "chrY": 0}, "M": {"chr1": 2, "chrX": 1, "chrY": 1}}
+    with open(d / "samples.tsv", "w") as sf:
+        for s, gender in enumerate(["F", "M"]):
+            haps = [sample_haplotype(rng, seq, records.get(name, [])) for name, seq, _ in contigs for _ in range(copies[gender][name])] + [decoy, decoy]
+            km, va = oracle.kmers_from_sequence("N".join(haps).encode(), K)
+            present = np.unique(km[va == 1], axis=0)
+            cnt = (rng.poisson(14, len(present)) + 1).astype(np.uint32)
+            asc = oracle.unpack(present, K).reshape(-1, K)
+            order = np.lexsort(asc.T[::-1])
+            prefix = str(d / f"sample{s + 1}")
+            oracle.kmc_write(prefix, np.ascontiguousarray(asc[order]).reshape(-1), cnt[order], K, 7, 1)
+            bloom = OrcBloom(oracle, len(present), 1e-3, K)
+            bloom.insert(np.ascontiguousarray(asc).reshape(-1))
+            bloom.save(prefix)
+            bloom.close()
+            sf.write(f"sample{s + 1}\t{gender}\t{prefix}\n")
+    ds = {"contigs": contigs + [["decoy1", decoy, True]], "dir": str(d)}
+    seed, gibbs = 5, dict(chains=3, burn=10, samples=25)
+    prefix = str(tmp_path / "bt")
+    common = ["-s", str(d / "samples.tsv"), "-g", str(d / "genome.fa"), "-d", str(d / "decoy.fa"), "-o", prefix, "-r", str(seed)]
+    r = subprocess.run([EXE, "cluster", "-v", str(d / "candidates.vcf")] + common, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    r = subprocess.run([EXE, "genotype", "-v", prefix + "_unit_1/variant_clusters.bin", "-c", prefix + "_cluster_data"] + common +
+                       ["--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]), "--gibbs-samples", str(gibbs["samples"])], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    want = oracle_pipeline(oracle, ref, ds, seed, gibbs)
+    assert gzip.open(prefix + "_cluster_data/intercluster_regions.txt.gz", "rt").read() == want["regions_text"] and "decoy1\t1\t" in want["regions_text"]
+    got_params = gzip.open(prefix + "_cluster_data/parameter_kmers.fa.gz", "rt").read().split("\n")
+    assert got_params[1:-1] == want["parameter_kmers"]
+    noise = open(prefix + "_noise_parameters.txt").read().split("\n")
+    assert noise[1:-1] == ["%d\t%d\t%s" % (int(r_[0]), int(r_[1]), "\t".join(_fmt(x) for x in r_[2:])) for r_ in want["noise_rows"]]
+    body = "".join(x + "\n" for x in open(prefix + ".vcf").read().split("\n") if x and not x.startswith("#"))
+    assert body == want["vcf_body"]
+    rows = [x.split("\t") for x in body.strip().split("\n")]
+    assert {x[0] for x in rows} == {"chr1", "chrX", "chrY"}
+    # ploidy shows in the calls: the female's chrY columns are the empty-sample string (GenotypeWriter.cpp:261-330), the male's chrX / chrY genotypes are haploid
+    assert all(x[9].split(":")[0] == "" for x in rows if x[0] == "chrY") and all("/" not in x[10].split(":")[0] for x in rows if x[0] in ("chrX", "chrY"))
+    assert all("/" in x[9].split(":")[0] for x in rows if x[0] in ("chr1", "chrX"))
