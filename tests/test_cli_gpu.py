@@ -141,7 +141,9 @@ def oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping=False, min_un
     seqs = {name: seq for name, seq, _ in genome}
     chrom_rank = {name: i for i, (name, _, _) in enumerate(genome)}
 
-    def chrom_ploidy(name):   # ChromosomePloidy.cpp:40-180 without a ploidy file: (female, male)
+    def chrom_ploidy(name):   # ChromosomePloidy.cpp:40-180: the ploidy file's (female, male), else the defaults by contig name
+        if ds.get("ploidy") and name in ds["ploidy"]:
+            return ds["ploidy"][name]
         return {"x": (2, 1), "chrx": (2, 1), "y": (0, 1), "chry": (0, 1)}.get(name.lower(), (2, 2))
 
     vcf = open(os.path.join(ds["dir"], "candidates.vcf")).read()
@@ -405,7 +407,8 @@ def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
     assert body == want["vcf_body"] and body.count("\n") > 100
 
 
-def test_sex_chromosomes_and_decoys_through_the_executable(oracle, tmp_path):
+@pytest.mark.parametrize("ploidy_file", [None, {"chr1": (2, 2), "chrX": (1, 2), "chrY": (1, 1)}], ids=["default-ploidies", "chromosome-ploidy-file"])
+def test_sex_chromosomes_and_decoys_through_the_executable(oracle, tmp_path, ploidy_file):
     """Several contigs with different ploidies and a decoy file: chr1 (diploid), chrX (female 2 / male 1), chrY (female 0 / male 1; the
     reference's default ploidies by contig name, ChromosomePloidy.cpp:40-180) and a decoy contig (-d) that repeats a stretch of chr1 with
     candidates on it (their path k-mers become decoy k-mers and are excluded).  A female and a male sample; every output file against the oracle
@@ -448,13 +451,17 @@ def test_sex_chromosomes_and_decoys_through_the_executable(oracle, tmp_path):
             bloom.save(prefix)
             bloom.close()
             sf.write(f"sample{s + 1}\t{gender}\t{prefix}\n")
-    ds = {"contigs": contigs + [["decoy1", decoy, True]], "dir": str(d)}
+    ds = {"contigs": contigs + [["decoy1", decoy, True]], "dir": str(d), "ploidy": ploidy_file}
     seed, gibbs = 5, dict(chains=3, burn=10, samples=25)
+    extra = []
+    if ploidy_file:   # -y: <chromosome> <female ploidy> <male ploidy> (deliberately not the defaults)
+        open(d / "ploidy.txt", "w").write("".join(f"{c}\t{f}\t{m}\n" for c, (f, m) in ploidy_file.items()))
+        extra = ["-y", str(d / "ploidy.txt")]
     prefix = str(tmp_path / "bt")
     common = ["-s", str(d / "samples.tsv"), "-g", str(d / "genome.fa"), "-d", str(d / "decoy.fa"), "-o", prefix, "-r", str(seed)]
     r = subprocess.run([EXE, "cluster", "-v", str(d / "candidates.vcf")] + common, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr
-    r = subprocess.run([EXE, "genotype", "-v", prefix + "_unit_1/variant_clusters.bin", "-c", prefix + "_cluster_data"] + common +
+    r = subprocess.run([EXE, "genotype", "-v", prefix + "_unit_1/variant_clusters.bin", "-c", prefix + "_cluster_data"] + common + extra +
                        ["--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]), "--gibbs-samples", str(gibbs["samples"])], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr
     want = oracle_pipeline(oracle, ref, ds, seed, gibbs)
@@ -467,6 +474,9 @@ def test_sex_chromosomes_and_decoys_through_the_executable(oracle, tmp_path):
     assert body == want["vcf_body"]
     rows = [x.split("\t") for x in body.strip().split("\n")]
     assert {x[0] for x in rows} == {"chr1", "chrX", "chrY"}
-    # ploidy shows in the calls: the female's chrY columns are the empty-sample string (GenotypeWriter.cpp:261-330), the male's chrX / chrY genotypes are haploid
-    assert all(x[9].split(":")[0] == "" for x in rows if x[0] == "chrY") and all("/" not in x[10].split(":")[0] for x in rows if x[0] in ("chrX", "chrY"))
-    assert all("/" in x[9].split(":")[0] for x in rows if x[0] in ("chr1", "chrX"))
+    if ploidy_file is None:
+        # ploidy shows in the calls: the female's chrY columns are the empty-sample string (GenotypeWriter.cpp:261-330), the male's chrX / chrY genotypes are haploid
+        assert all(x[9].split(":")[0] == "" for x in rows if x[0] == "chrY") and all("/" not in x[10].split(":")[0] for x in rows if x[0] in ("chrX", "chrY"))
+        assert all("/" in x[9].split(":")[0] for x in rows if x[0] in ("chr1", "chrX"))
+    else:
+        assert all("/" not in x[9].split(":")[0] and "/" in x[10].split(":")[0] for x in rows if x[0] == "chrX")
