@@ -381,7 +381,10 @@ def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
             asc = oracle.unpack(present, K).reshape(-1, K)
             order = np.lexsort(asc.T[::-1])                     # KMC order = ascending ASCII order
             prefix = str(d / f"sample{s + 1}")
-            oracle.kmc_write(prefix, np.ascontiguousarray(asc[order]).reshape(-1), cnt[order], K, 7, 1)
+            if s == 0:
+                oracle.kmc_write(prefix, np.ascontiguousarray(asc[order]).reshape(-1), cnt[order], K, 7, 1)
+            else:   # the second sample's database in the KMC2 ("0x200") layout: five signature bins
+                oracle.kmc2_write(prefix, np.ascontiguousarray(asc[order]).reshape(-1), cnt[order], K, 7, 1, 5)
             bloom = OrcBloom(oracle, len(present), 1e-3, K)
             bloom.insert(np.ascontiguousarray(asc).reshape(-1))
             bloom.save(prefix)
