@@ -166,7 +166,7 @@ const uint32_t kElemSize[A_COUNT] = {
     /*SOURCES0*/ 4, /*PLOIDY*/ 1,
     /*MT*/ 4, /*FNDSAVED*/ 8, /*SPARSITY*/ 8, /*UNIQ*/ 4, /*MULTI*/ 4, /*USUB*/ 4, /*MSUB*/ 4, /*SMM*/ 1, /*DIP*/ 2, /*FREQ*/ 8, /*OBS*/ 4, /*NZ*/ 1,
     /*ZHDR*/ 4, /*ZBKT*/ 4, /*PHDR*/ 4, /*PBKT*/ 4, /*UNEXT*/ 4, /*HVCOUNT*/ 4, /*UCACHE*/ 8, /*UCTAG*/ 4, /*CUM*/ 8, /*NZLIST*/ 2, /*SIMPLEX*/ 8,
-    /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*KSCKEY*/ 4, /*KSCDATA*/ 8, /*NVER*/ 4, /*PENDNEST*/ 8, /*SC*/ 4,
+    /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*KSCKEY*/ 4, /*KSCDATA*/ 8, /*EVLOG*/ 4, /*NVER*/ 4, /*PENDNEST*/ 8, /*SC*/ 4,
     /*EDGES*/ 4, /*COVER*/ 1, /*MCACHE*/ 8, /*MCTAG*/ 4, /*MCGEN*/ 4, /*MGEN*/ 4, /*OTH*/ 1, /*SUBM*/ 1, /*SUBCNT*/ 1, /*SUBIC*/ 1, /*SKVOFF*/ 4, /*SKVVAR*/ 2, /*SKVBITS*/ 4, /*KSCTMP*/ 8, /*LOGF*/ 8, /*PEND*/ 4, /*PENDDIP*/ 2, /*PENDVALID*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1, /*MSUBM*/ 1, /*MSUBC*/ 1, /*MSUBIC*/ 1, /*MSUBSH*/ 4, /*RING*/ 4};
 
 }  // namespace
@@ -505,6 +505,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_NESTST] = nv * S * 8;
         len[A_PENDNEST] = nv * S * 8;
         len[A_NVER] = nv * S * 2;
+        len[A_EVLOG] = nv * S * (2 * EV_CAP + 1);
         len[A_KSCKEY] = nv * S * (KSC_WAYS + 1);
         len[A_KSCDATA] = (uint64_t)nv * S * KSC_WAYS * 2 * d.Vm * 4;
         len[A_SC] = nv * SC_COUNT;

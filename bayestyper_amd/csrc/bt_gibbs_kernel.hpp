@@ -231,6 +231,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
             if (simple) {
                 simple_sweeps(env, t, P, P.burn_in, false, tr.counter, tr.buf, tr.max_sweeps, tile);
                 simple_sweeps(env, t, P, P.num_iterations, true, tr.counter, tr.buf, tr.max_sweeps, tile);
+                simple_drain(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
                 continue;
             }
             if constexpr (!SIMPLE_ONLY) {
@@ -244,7 +245,8 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                 }
             }
         }
-        for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);   // hot arrays: LDS when resident, else HBM (both valid)
+        if (!simple)
+            for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);   // hot arrays: LDS when resident, else HBM (both valid)
     } else if (op == OP_INIT_CHAIN) {
         group_init_chain(env, arg0, nvert, nsrc, gindex);
     } else if (op == OP_SWEEP) {
@@ -254,8 +256,11 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                 const TraceRow r = trace_row_for(t, P, tr, tile);
                 group_sweep(env, t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
             }
-        if (arg1 != 0)
-            for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
+        if (arg1 != 0) {
+            if (simple) simple_drain(env);
+            else
+                for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
+        }
     } else if (SIMPLE_ONLY) {
         // (the other operations always go through the general kernel)
     } else if (op == OP_NOISE) {

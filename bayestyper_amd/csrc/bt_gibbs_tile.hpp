@@ -95,6 +95,8 @@ enum TileArr {
     A_NESTST,       // f64 [V] S*2*4
     A_KSCKEY,       // u32 [V] S*(KSC_WAYS+1)   per sample: the diplotypes (h1 | h2 << 16) whose k-mer-stats cache is kept in A_KSCDATA, then the next entry to replace
     A_KSCDATA,      // f64 [V] S*KSC_WAYS*2*Vm*4  those caches ([sample][entry][haplotype slot][variant] KmerStats)
+    A_EVLOG,        // u32 [V] S*(2*EV_CAP+1)   tiles of two-haplotype clusters: per sample the runs of collected sweeps not yet applied to the statistics —
+                    //                    [s][0] = how many, then (diplotype h1 | h2 << 16, run length) pairs in order (bt_gibbs_simple.hpp: simple_drain)
     A_NVER,         // u32 [V] 2*S        [s]: version of what a child's nested info is derived from (the sample's diplotype, its k-mer-stats cache, the vertex's own
                     //                    nested info); [S + s]: the parent's version this vertex's nested info was last prepared from
     A_PENDNEST,     // f64 [V] S*2*4      the nested sources the pending (deferred) collected sweeps of a sample saw: [s][j][count, fraction, mean], [s][0][3] = how many
@@ -146,6 +148,7 @@ struct TileDesc {
     uint32_t prio;                  // the tile's wavefronts raise their issue priority (narrow tiles: the launch's critical path)
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
+constexpr uint32_t EV_CAP = 8;            // logged runs per (cluster, sample) before the log is applied early
 constexpr uint32_t KSC_WAYS = 4;          // recently rebuilt k-mer-stats caches kept per (cluster, sample), see collect_sample_body
 constexpr uint32_t KSC_NOKEY = 0xFFFEFFFEu;   // (haplotype indices are < 0xFFFE)
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
@@ -307,6 +310,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline SPtr<double, LANES> ksc_data(uint32_t s, uint32_t e) const {
         return a<double>(A_KSCDATA, (uint32_t)d().S * KSC_WAYS * 2 * d().Vm * 4) + ((uint32_t)s * KSC_WAYS + e) * 2 * d().Vm * 4;
     }
+    __device__ inline SPtr<uint32_t, LANES> evlog(uint32_t s) const { return a<uint32_t>(A_EVLOG, (uint32_t)d().S * (2u * EV_CAP + 1u)) + (uint32_t)s * (2u * EV_CAP + 1u); }
     __device__ inline SPtr<uint32_t, LANES> nver() const { return a<uint32_t>(A_NVER, (uint32_t)d().S * 2); }
     __device__ inline SPtr<double, LANES> pend_nest(uint32_t s) const { return a<double>(A_PENDNEST, (uint32_t)d().S * 8) + (uint32_t)s * 8; }
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
@@ -636,6 +640,7 @@ __device__ BT_NOINLINE void genotyper_construct(Env env, uint32_t vtx, uint32_t 
         c.pend_valid()[s] = 0;
         c.nver()[s] = 1;
         c.nver()[P.S + s] = 0xFFFFFFFFu;   // nested info not prepared yet
+        c.evlog(s)[0] = 0;
     }
     {
         const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, c.v * 2)[0];
@@ -1282,6 +1287,104 @@ __device__ BT_NOINLINE void flush_vertex(Env env, uint32_t vtx) {
     for (uint32_t s = 0; s < P.S; ++s) flush_sample(c, P, s);
 }
 
+// updateKmerStatsCache for one sample (VariantClusterHaplotypes.cpp:247-277): kmer_stats_cache[s] for the diplotype (h1, h2)
+__device__ inline void rebuild_kmer_stats_cache(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t nsub_u, uint32_t nsub_m) {
+    {
+    // Rebuild kmer_stats_cache[s] (VariantClusterHaplotypes.cpp:247-277).  The cache is 2 x V independent KmerStats accumulators
+    // (haplotype slot x variant), each a strictly sequential Welford recurrence over the subset k-mers that lie on its haplotype
+    // and overlap its variant, in subset order.  Every accumulator is run as its own pass IN REGISTERS — the copies of the group
+    // take different accumulators — over the compact subset arrays read in blocks of eight k-mers (all operand loads of a block
+    // first): per accumulator the same values in the same order as the reference's single interleaved pass.
+    const uint32_t Hm = c.d().Hm, HWm = c.d().HWm, V = c.V;
+    const bool two = h2 != NOHAP;
+    const uint8_t g = P.gender[s];
+    // The accumulators' state after the unique k-mers of the chain's subset is a pure function of (sample, diplotype) until the next
+    // chain: the last few are kept (chains move between a handful of diplotypes), a hit skips the 2 V passes over the unique subset.
+    const uint32_t dkey = (uint32_t)h1 | ((uint32_t)h2 << 16);
+    SPtr<uint32_t, LANES> kk = c.ksc_key(s);
+    uint32_t hit_way = KSC_WAYS, victim = 0;
+    {
+        uint32_t keys[KSC_WAYS];
+#pragma unroll
+        for (uint32_t e = 0; e < KSC_WAYS; ++e) keys[e] = kk[e];
+        victim = kk[KSC_WAYS];
+#pragma unroll
+        for (uint32_t e = 0; e < KSC_WAYS; ++e)
+            if (hit_way == KSC_WAYS && keys[e] == dkey) hit_way = e;
+    }
+    const Vx::RPtr<uint8_t> sm = c.subm();
+    SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
+    SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits(), msub = c.msub();
+    SPtr<uint16_t, LANES> sv = c.skv_var();
+    for (uint32_t a = c.t.part; a < 2 * V; a += c.t.copies) {
+        const uint32_t which = a / V, var = a - which * V;
+        KS acc{0, 0, 0, 0};
+        const uint16_t h = which ? h2 : h1;
+        if (h1 != NOHAP && (which == 0 || two)) {
+            const uint32_t hw = h >> 5, hb = h & 31u;
+            if (hit_way < KSC_WAYS)
+                acc = ks_load(c.ksc_data(s, hit_way) + (which * c.d().Vm + var) * 4u);
+            else {
+            for (uint32_t i0 = 0; i0 < nsub_u; i0 += 8) {
+                const uint32_t nb = nsub_u - i0 < 8u ? nsub_u - i0 : 8u;
+                uint32_t eo[9];
+                uint8_t dm[8], icn[8], cn[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 9; ++q) eo[q] = q <= nb ? (uint32_t)so[i0 + q] : 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) {
+                    const uint32_t i = q < nb ? i0 + q : i0;
+                    uint8_t m = sm[i * Hm + h1];
+                    if (two) m = (uint8_t)(m + sm[i * Hm + h2]);
+                    dm[q] = q < nb ? m : (uint8_t)0;
+                    icn[q] = sic[2 * i + g];
+                    cn[q] = scn[i * P.S + s];
+                }
+                // first entry of every k-mer of the block (most k-mers overlap one variant)
+                uint32_t v0[8], b0[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) {
+                    const bool has = q < nb && eo[q + 1] > eo[q];
+                    v0[q] = has ? (uint32_t)sv[eo[q]] : 0xFFFFFFFFu;
+                    b0[q] = has ? (uint32_t)sb[eo[q] * HWm + hw] : 0u;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) {
+                    if (q >= nb || dm[q] == 0) continue;
+                    bool hit = v0[q] == var && ((b0[q] >> hb) & 1u);
+                    for (uint32_t e = eo[q] + 1; e < eo[q + 1]; ++e)    // a k-mer overlaps a variant once: at most one entry matches
+                        if (sv[e] == var && ((sb[e * HWm + hw] >> hb) & 1u)) hit = true;
+                    if (hit) ks_add_r(acc, cn[q] / (double)(uint8_t)(dm[q] + icn[q]));
+                }
+            }
+            }
+        }
+        // (the state after the unique k-mers is what is kept: the multicluster k-mers' multiplicities depend on the other clusters)
+        if (hit_way == KSC_WAYS) ks_store(c.ksc_data(s, victim) + (which * c.d().Vm + var) * 4u, acc);
+        if (h1 != NOHAP && (which == 0 || two)) {
+            for (uint32_t i = 0; i < nsub_m; ++i) {
+                const uint32_t k = msub[i];
+                if (dip_mult(c, k, h1, h2) == 0) continue;
+                bool hit = false;
+                for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e)
+                    if (c.kv_var(e) == var && c.kv_bit(e, h)) hit = true;
+                if (!hit) continue;
+                const uint8_t mult = multi_mult(c, P, k, h1, h2, h1, h2, s);
+                double kmer_count = 0;
+                if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
+                ks_add_r(acc, kmer_count);
+            }
+        }
+        ks_store(c.ksc(s, which, var), acc);
+    }
+    if (hit_way == KSC_WAYS) {
+        kk[victim] = dkey;
+        kk[KSC_WAYS] = victim + 1u < KSC_WAYS ? victim + 1u : 0u;
+    }
+    if (c.t.copies > 1u) copies_sync();
+    }
+}
+
 // One collected sweep of a vertex: diplotype_sampling_frequencies (VariantClusterGenotyper.cpp:692-696) and
 // updateAlleleKmerStats (VariantClusterHaplotypes.cpp:235-298).  A sample whose diplotype and k-mer-stats cache are the
 // same as in the previous collected sweep contributes exactly the same updates again; those are counted (pend) and
@@ -1303,98 +1406,7 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
             PROF_CNT(20, 1);
             upd[s] = 0;
             c.nver()[s] += 1;   // the children's nested info reads this cache
-            // Rebuild kmer_stats_cache[s] (VariantClusterHaplotypes.cpp:247-277).  The cache is 2 x V independent KmerStats accumulators
-            // (haplotype slot x variant), each a strictly sequential Welford recurrence over the subset k-mers that lie on its haplotype
-            // and overlap its variant, in subset order.  Every accumulator is run as its own pass IN REGISTERS — the copies of the group
-            // take different accumulators — over the compact subset arrays read in blocks of eight k-mers (all operand loads of a block
-            // first): per accumulator the same values in the same order as the reference's single interleaved pass.
-            const uint32_t Hm = c.d().Hm, HWm = c.d().HWm, V = c.V;
-            const bool two = h2 != NOHAP;
-            const uint8_t g = P.gender[s];
-            // The accumulators' state after the unique k-mers of the chain's subset is a pure function of (sample, diplotype) until the next
-            // chain: the last few are kept (chains move between a handful of diplotypes), a hit skips the 2 V passes over the unique subset.
-            const uint32_t dkey = (uint32_t)h1 | ((uint32_t)h2 << 16);
-            SPtr<uint32_t, LANES> kk = c.ksc_key(s);
-            uint32_t hit_way = KSC_WAYS, victim = 0;
-            {
-                uint32_t keys[KSC_WAYS];
-#pragma unroll
-                for (uint32_t e = 0; e < KSC_WAYS; ++e) keys[e] = kk[e];
-                victim = kk[KSC_WAYS];
-#pragma unroll
-                for (uint32_t e = 0; e < KSC_WAYS; ++e)
-                    if (hit_way == KSC_WAYS && keys[e] == dkey) hit_way = e;
-            }
-            const Vx::RPtr<uint8_t> sm = c.subm();
-            SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
-            SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits(), msub = c.msub();
-            SPtr<uint16_t, LANES> sv = c.skv_var();
-            for (uint32_t a = c.t.part; a < 2 * V; a += c.t.copies) {
-                const uint32_t which = a / V, var = a - which * V;
-                KS acc{0, 0, 0, 0};
-                const uint16_t h = which ? h2 : h1;
-                if (h1 != NOHAP && (which == 0 || two)) {
-                    const uint32_t hw = h >> 5, hb = h & 31u;
-                    if (hit_way < KSC_WAYS)
-                        acc = ks_load(c.ksc_data(s, hit_way) + (which * c.d().Vm + var) * 4u);
-                    else {
-                    for (uint32_t i0 = 0; i0 < nsub_u; i0 += 8) {
-                        const uint32_t nb = nsub_u - i0 < 8u ? nsub_u - i0 : 8u;
-                        uint32_t eo[9];
-                        uint8_t dm[8], icn[8], cn[8];
-#pragma unroll
-                        for (uint32_t q = 0; q < 9; ++q) eo[q] = q <= nb ? (uint32_t)so[i0 + q] : 0u;
-#pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q) {
-                            const uint32_t i = q < nb ? i0 + q : i0;
-                            uint8_t m = sm[i * Hm + h1];
-                            if (two) m = (uint8_t)(m + sm[i * Hm + h2]);
-                            dm[q] = q < nb ? m : (uint8_t)0;
-                            icn[q] = sic[2 * i + g];
-                            cn[q] = scn[i * P.S + s];
-                        }
-                        // first entry of every k-mer of the block (most k-mers overlap one variant)
-                        uint32_t v0[8], b0[8];
-#pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q) {
-                            const bool has = q < nb && eo[q + 1] > eo[q];
-                            v0[q] = has ? (uint32_t)sv[eo[q]] : 0xFFFFFFFFu;
-                            b0[q] = has ? (uint32_t)sb[eo[q] * HWm + hw] : 0u;
-                        }
-#pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q) {
-                            if (q >= nb || dm[q] == 0) continue;
-                            bool hit = v0[q] == var && ((b0[q] >> hb) & 1u);
-                            for (uint32_t e = eo[q] + 1; e < eo[q + 1]; ++e)    // a k-mer overlaps a variant once: at most one entry matches
-                                if (sv[e] == var && ((sb[e * HWm + hw] >> hb) & 1u)) hit = true;
-                            if (hit) ks_add_r(acc, cn[q] / (double)(uint8_t)(dm[q] + icn[q]));
-                        }
-                    }
-                    }
-                }
-                // (the state after the unique k-mers is what is kept: the multicluster k-mers' multiplicities depend on the other clusters)
-                if (hit_way == KSC_WAYS) ks_store(c.ksc_data(s, victim) + (which * c.d().Vm + var) * 4u, acc);
-                if (h1 != NOHAP && (which == 0 || two)) {
-                    for (uint32_t i = 0; i < nsub_m; ++i) {
-                        const uint32_t k = msub[i];
-                        if (dip_mult(c, k, h1, h2) == 0) continue;
-                        bool hit = false;
-                        for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e)
-                            if (c.kv_var(e) == var && c.kv_bit(e, h)) hit = true;
-                        if (!hit) continue;
-                        const uint8_t mult = multi_mult(c, P, k, h1, h2, h1, h2, s);
-                        double kmer_count = 0;
-                        if (c.has_counts(k)) kmer_count = c.count(k, s) / (double)mult;
-                        ks_add_r(acc, kmer_count);
-                    }
-                }
-                ks_store(c.ksc(s, which, var), acc);
-            }
-            if (hit_way == KSC_WAYS) {
-                kk[victim] = dkey;
-                kk[KSC_WAYS] = victim + 1u < KSC_WAYS ? victim + 1u : 0u;
-            }
-            if (c.t.copies > 1u) copies_sync();
+            rebuild_kmer_stats_cache(c, P, s, h1, h2, nsub_u, nsub_m);
             PROF(17);
         }
         {   // the nested sources this sweep sees become the sample's pending copy (what later identical sweeps are compared with)
