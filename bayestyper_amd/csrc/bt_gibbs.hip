@@ -166,7 +166,7 @@ const uint32_t kElemSize[A_COUNT] = {
     /*SOURCES0*/ 4, /*PLOIDY*/ 1,
     /*MT*/ 4, /*FNDSAVED*/ 8, /*SPARSITY*/ 8, /*UNIQ*/ 4, /*MULTI*/ 4, /*USUB*/ 4, /*MSUB*/ 4, /*SMM*/ 1, /*DIP*/ 2, /*FREQ*/ 8, /*OBS*/ 4, /*NZ*/ 1,
     /*ZHDR*/ 4, /*ZBKT*/ 4, /*PHDR*/ 4, /*PBKT*/ 4, /*UNEXT*/ 4, /*HVCOUNT*/ 4, /*UCACHE*/ 8, /*UCTAG*/ 4, /*CUM*/ 8, /*NZLIST*/ 2, /*SIMPLEX*/ 8,
-    /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*KSCKEY*/ 4, /*KSCDATA*/ 8, /*EVLOG*/ 4, /*NVER*/ 4, /*PENDNEST*/ 8, /*SC*/ 4,
+    /*SCACHE*/ 8, /*SCLEN*/ 4, /*KSC*/ 8, /*KSCUPD*/ 1, /*DIPKEYS*/ 4, /*DIPFREQ*/ 4, /*ASTATS*/ 8, /*NESTPL*/ 1, /*NESTN*/ 1, /*NESTST*/ 8, /*KSCKEY*/ 4, /*KSCDATA*/ 8, /*EVLOG*/ 4, /*EVN*/ 1, /*NVER*/ 4, /*PENDNEST*/ 8, /*SC*/ 4,
     /*EDGES*/ 4, /*COVER*/ 1, /*MCACHE*/ 8, /*MCTAG*/ 4, /*MCGEN*/ 4, /*MGEN*/ 4, /*OTH*/ 1, /*SUBM*/ 1, /*SUBCNT*/ 1, /*SUBIC*/ 1, /*SKVOFF*/ 4, /*SKVVAR*/ 2, /*SKVBITS*/ 4, /*KSCTMP*/ 8, /*LOGF*/ 8, /*PEND*/ 4, /*PENDDIP*/ 2, /*PENDVALID*/ 1, /*SOURCES*/ 4, /*STACK*/ 4, /*BRNG*/ 4, /*SHMULT*/ 1, /*MSUBM*/ 1, /*MSUBC*/ 1, /*MSUBIC*/ 1, /*MSUBSH*/ 4, /*RING*/ 4};
 
 }  // namespace
@@ -506,6 +506,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_PENDNEST] = nv * S * 8;
         len[A_NVER] = nv * S * 2;
         len[A_EVLOG] = nv * S * (2 * EV_CAP + 1);
+        len[A_EVN] = nv * S;
         len[A_KSCKEY] = nv * S * (KSC_WAYS + 1);
         len[A_KSCDATA] = (uint64_t)nv * S * KSC_WAYS * 2 * d.Vm * 4;
         len[A_SC] = nv * SC_COUNT;
@@ -552,7 +553,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         {
             // hot arrays (bt_gibbs_tile.hpp: Vx::harr users) -> offsets inside the wavefront's LDS block
             for (int a = 0; a < A_COUNT; ++a) d.hoff[a] = NOHOT;
-            const int hot_arrs[] = {A_SC, A_DIP, A_NESTPL, A_NESTN, A_KSCUPD, A_MGEN, A_PEND, A_PENDDIP, A_PENDVALID, A_FREQ, A_LOGF, A_OBS, A_NZ, A_NZLIST,
+            const int hot_arrs[] = {A_SC, A_DIP, A_NESTPL, A_NESTN, A_KSCUPD, A_MGEN, A_PEND, A_PENDDIP, A_PENDVALID, A_EVN, A_FREQ, A_LOGF, A_OBS, A_NZ, A_NZLIST,
                                     A_UNEXT, A_ZHDR, A_ZBKT, A_PHDR, A_PBKT, A_KSCTMP, A_CUM, A_RING, A_FNDSAVED, A_UCACHE};
             // LDS rows are interleaved over the tile's lanes only (16 / 32 / 64): a narrow tile needs a fraction of the LDS per vertex,
             // which lets every vertex of a multi-cluster group stay resident instead of being swapped around each visit
@@ -605,7 +606,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         {
             bool simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.copies == 1 && d.split == 1 && d.hot_bytes != 0 && !getenv("BT_GIBBS_NO_SIMPLE");
             for (uint32_t l = 0; l < d.num_lanes && simple; ++l) simple = B->num_haplotypes[B->group_cluster_off[shapes[tile_start[ti] + l].g]] == 2;
-            for (int a : {A_SC, A_OBS, A_PEND, A_DIP, A_PENDDIP, A_NZ, A_KSCUPD, A_PENDVALID, A_NESTPL, A_NESTN, A_FREQ, A_LOGF, A_RING}) simple = simple && d.hoff[a] != NOHOT;
+            for (int a : {A_SC, A_OBS, A_PEND, A_DIP, A_PENDDIP, A_NZ, A_KSCUPD, A_PENDVALID, A_EVN, A_NESTPL, A_NESTN, A_FREQ, A_LOGF, A_RING}) simple = simple && d.hoff[a] != NOHOT;
             d.simple = simple ? 1u : 0u;
         }
         d.prio = (d.copies > 1 || d.num_lanes < LANES / 2) && !getenv("BT_GIBBS_NO_PRIO") ? 1u : 0u;

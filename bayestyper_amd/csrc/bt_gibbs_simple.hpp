@@ -83,25 +83,25 @@ __device__ inline bool tile_is_simple(const TileDesc BT_CAS &d) { return d.simpl
 // then the run's replay), so every statistic sees the same values in the same order.
 __device__ inline void simple_apply_log(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t nsub_u) {
     SPtr<uint32_t, LANES> lg = c.evlog(s);
-    const uint32_t n = lg[0];
+    const uint32_t n = c.evn()[s];
     for (uint32_t e = 0; e < n; ++e) {
         const uint32_t key = lg[1 + 2 * e], r = lg[2 + 2 * e];
         const uint16_t h1 = (uint16_t)(key & 0xFFFFu), h2 = (uint16_t)(key >> 16);
         rebuild_kmer_stats_cache(c, P, s, h1, h2, nsub_u, 0);
         replay_collected(c, P, s, h1, h2, r, 0);
     }
-    lg[0] = 0;
+    c.evn()[s] = 0;
 }
 __device__ inline void simple_log_run(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t key, uint32_t r, uint32_t nsub_u) {
     SPtr<uint32_t, LANES> lg = c.evlog(s);
-    uint32_t n = lg[0];
+    uint32_t n = c.evn()[s];
     if (n == EV_CAP) {   // (a sample that keeps changing its diplotype: apply what is logged now)
         simple_apply_log(c, P, s, nsub_u);
         n = 0;
     }
-    lg[1 + 2 * n] = key;
+    lg[1 + 2 * n] = key;   // (stores only: nothing waits for HBM while sampling)
     lg[2 + 2 * n] = r;
-    lg[0] = n + 1;
+    c.evn()[s] = (uint8_t)(n + 1);
 }
 // end of a chain / of a launch: the open runs join the log, the log is applied
 __device__ BT_NOINLINE void simple_drain(Env env) {

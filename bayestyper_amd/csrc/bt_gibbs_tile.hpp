@@ -96,7 +96,8 @@ enum TileArr {
     A_KSCKEY,       // u32 [V] S*(KSC_WAYS+1)   per sample: the diplotypes (h1 | h2 << 16) whose k-mer-stats cache is kept in A_KSCDATA, then the next entry to replace
     A_KSCDATA,      // f64 [V] S*KSC_WAYS*2*Vm*4  those caches ([sample][entry][haplotype slot][variant] KmerStats)
     A_EVLOG,        // u32 [V] S*(2*EV_CAP+1)   tiles of two-haplotype clusters: per sample the runs of collected sweeps not yet applied to the statistics —
-                    //                    [s][0] = how many, then (diplotype h1 | h2 << 16, run length) pairs in order (bt_gibbs_simple.hpp: simple_drain)
+                    //                    (diplotype h1 | h2 << 16, run length) pairs in order from [s][1] on (bt_gibbs_simple.hpp: simple_drain)
+    A_EVN,          // u8  [V] S          ... and how many of them (kept with the hot arrays)
     A_NVER,         // u32 [V] 2*S        [s]: version of what a child's nested info is derived from (the sample's diplotype, its k-mer-stats cache, the vertex's own
                     //                    nested info); [S + s]: the parent's version this vertex's nested info was last prepared from
     A_PENDNEST,     // f64 [V] S*2*4      the nested sources the pending (deferred) collected sweeps of a sample saw: [s][j][count, fraction, mean], [s][0][3] = how many
@@ -311,6 +312,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
         return a<double>(A_KSCDATA, (uint32_t)d().S * KSC_WAYS * 2 * d().Vm * 4) + ((uint32_t)s * KSC_WAYS + e) * 2 * d().Vm * 4;
     }
     __device__ inline SPtr<uint32_t, LANES> evlog(uint32_t s) const { return a<uint32_t>(A_EVLOG, (uint32_t)d().S * (2u * EV_CAP + 1u)) + (uint32_t)s * (2u * EV_CAP + 1u); }
+    __device__ inline SPtrF<uint8_t, LANES> evn() const { return t.harr<uint8_t>(A_EVN, v, d().S); }
     __device__ inline SPtr<uint32_t, LANES> nver() const { return a<uint32_t>(A_NVER, (uint32_t)d().S * 2); }
     __device__ inline SPtr<double, LANES> pend_nest(uint32_t s) const { return a<double>(A_PENDNEST, (uint32_t)d().S * 8) + (uint32_t)s * 8; }
     __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
@@ -436,6 +438,7 @@ __device__ BT_NOINLINE void hot_swap(Env env, uint32_t v, bool to_lds) {
     hot_copy<uint32_t>(t, A_PEND, v, d.S, to_lds, voff);
     hot_copy<uint16_t>(t, A_PENDDIP, v, 2 * d.S, to_lds, voff);
     hot_copy<uint8_t>(t, A_PENDVALID, v, d.S, to_lds, voff);
+    hot_copy<uint8_t>(t, A_EVN, v, d.S, to_lds, voff);
     hot_copy<uint32_t>(t, A_RING, v, d.ring_len, to_lds, voff);
     hot_copy<double>(t, A_FNDSAVED, v, 1, to_lds, voff);
     hot_copy<double>(t, A_UCACHE, v, d.cache_entries, to_lds, voff);   // (hot only when the whole table is a few words per lane)
@@ -640,7 +643,7 @@ __device__ BT_NOINLINE void genotyper_construct(Env env, uint32_t vtx, uint32_t 
         c.pend_valid()[s] = 0;
         c.nver()[s] = 1;
         c.nver()[P.S + s] = 0xFFFFFFFFu;   // nested info not prepared yet
-        c.evlog(s)[0] = 0;
+        c.evn()[s] = 0;
     }
     {
         const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, c.v * 2)[0];
