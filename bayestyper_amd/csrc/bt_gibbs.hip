@@ -609,6 +609,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             for (int a : {A_SC, A_OBS, A_PEND, A_DIP, A_PENDDIP, A_NZ, A_KSCUPD, A_PENDVALID, A_EVN, A_NESTPL, A_NESTN, A_FREQ, A_LOGF, A_RING}) simple = simple && d.hoff[a] != NOHOT;
             d.simple = simple ? 1u : 0u;
         }
+        d.logged = d.nvm == 1 && d.NMm == 0 && !getenv("BT_GIBBS_NO_LOG") ? 1u : 0u;
         d.prio = (d.copies > 1 || d.num_lanes < LANES / 2) && !getenv("BT_GIBBS_NO_PRIO") ? 1u : 0u;
         d.base = pool;
         if (ti == 0 && getenv("BT_GIBBS_DEBUG") && atoi(getenv("BT_GIBBS_DEBUG")) >= 2) {   // the arrays that make up most of tile 0

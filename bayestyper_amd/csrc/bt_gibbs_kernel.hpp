@@ -231,7 +231,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
             if (simple) {
                 simple_sweeps(env, t, P, P.burn_in, false, tr.counter, tr.buf, tr.max_sweeps, tile);
                 simple_sweeps(env, t, P, P.num_iterations, true, tr.counter, tr.buf, tr.max_sweeps, tile);
-                simple_drain(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
+                drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
                 continue;
             }
             if constexpr (!SIMPLE_ONLY) {
@@ -243,6 +243,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                     const TraceRow r = trace_row_for(t, P, tr, tile);
                     group_sweep(env, t, P, true, nvert, nsrc, r.row, r.on);
                 }
+                if (t.d->logged) drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
             }
         }
         if (!simple)
@@ -257,7 +258,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                 group_sweep(env, t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
             }
         if (arg1 != 0) {
-            if (simple) simple_drain(env);
+            if (simple) drain_collected(env);
             else
                 for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
         }

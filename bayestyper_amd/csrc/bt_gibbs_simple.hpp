@@ -74,52 +74,6 @@ struct SimpleState {   // what a run of sweeps keeps in registers between sweeps
 
 __device__ inline bool tile_is_simple(const TileDesc BT_CAS &d) { return d.simple != 0; }
 
-// ---- collected sweeps of the two-haplotype tiles: logged as runs, applied for all lanes together ----
-// A wavefront of 64 clusters used to pay the statistics update of a collected sweep — replay of the pending run, rebuild of the k-mer-stats
-// cache, this sweep's contribution — whenever ANY of its lanes changed its diplotype, with one or two lanes active.  Here a sample's
-// collected sweeps are only logged while sampling: runs (diplotype, length), appended when the diplotype changes.  The log is applied at
-// the end of the chain (the cache is a function of the chain's k-mer subset), every lane working through its own entries at the same
-// time.  Per sample the entries are applied in order, each exactly as the immediate update would have been (cache of that diplotype,
-// then the run's replay), so every statistic sees the same values in the same order.
-__device__ inline void simple_apply_log(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t nsub_u) {
-    SPtr<uint32_t, LANES> lg = c.evlog(s);
-    const uint32_t n = c.evn()[s];
-    for (uint32_t e = 0; e < n; ++e) {
-        const uint32_t key = lg[1 + 2 * e], r = lg[2 + 2 * e];
-        const uint16_t h1 = (uint16_t)(key & 0xFFFFu), h2 = (uint16_t)(key >> 16);
-        rebuild_kmer_stats_cache(c, P, s, h1, h2, nsub_u, 0);
-        replay_collected(c, P, s, h1, h2, r, 0);
-    }
-    c.evn()[s] = 0;
-}
-__device__ inline void simple_log_run(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t key, uint32_t r, uint32_t nsub_u) {
-    SPtr<uint32_t, LANES> lg = c.evlog(s);
-    uint32_t n = c.evn()[s];
-    if (n == EV_CAP) {   // (a sample that keeps changing its diplotype: apply what is logged now)
-        simple_apply_log(c, P, s, nsub_u);
-        n = 0;
-    }
-    lg[1 + 2 * n] = key;   // (stores only: nothing waits for HBM while sampling)
-    lg[2 + 2 * n] = r;
-    c.evn()[s] = (uint8_t)(n + 1);
-}
-// end of a chain / of a launch: the open runs join the log, the log is applied
-__device__ BT_NOINLINE void simple_drain(Env env) {
-    const Vx c = make_vx(make_tile(env), 0);
-    const GParams BT_CAS &P = env_params(env);
-    const uint32_t nsub_u = c.sc()[SC_NSUB_U];
-    SPtrF<uint16_t, LANES> pdip = c.pend_dip();
-    SPtrF<uint8_t, LANES> pvalid = c.pend_valid(), upd = c.ksc_upd();
-    SPtrF<uint32_t, LANES> pend = c.pend();
-    for (uint32_t s = 0; s < P.S; ++s) {
-        if (pvalid[s] && pend[s]) simple_log_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], nsub_u);
-        pend[s] = 0;
-        pvalid[s] = 0;
-        upd[s] = 1;
-        simple_apply_log(c, P, s, nsub_u);
-    }
-}
-
 // n_sweeps sweeps of the tile's clusters (one per lane).  The hot arrays of vertex 0 are resident in LDS (RESIDENT_ALL).
 __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParams BT_CAS &P, uint32_t n_sweeps, bool collect, uint32_t *trace_counter, uint32_t *trace_buf,
                                      uint32_t trace_max, uint32_t tile) {
@@ -267,7 +221,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
                     pend[s] += 1;
                     continue;
                 }
-                if (pvalid[s] && pend[s]) simple_log_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], sc[SC_NSUB_U]);
+                if (pvalid[s] && pend[s]) log_collected_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], sc[SC_NSUB_U]);
                 pdip[2 * s] = dip[2 * s];
                 pdip[2 * s + 1] = dip[2 * s + 1];
                 pend[s] = 1;

@@ -147,6 +147,7 @@ struct TileDesc {
     uint32_t simple;                // every group of the tile is one two-haplotype cluster without multicluster k-mers: sweeps run in simple_sweeps()
     uint32_t ring_cap[2], ring_len; // draw-ahead words of the diplotype / frequency generator (powers of two); ring_len = both blocks
     uint32_t prio;                  // the tile's wavefronts raise their issue priority (narrow tiles: the launch's critical path)
+    uint32_t logged;                // single clusters without multicluster k-mers: collected sweeps are logged as runs and applied at the end of the chain
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
 constexpr uint32_t EV_CAP = 8;            // logged runs per (cluster, sample) before the log is applied early
@@ -1284,11 +1285,7 @@ __device__ inline void flush_sample(const Vx &c, const GParams BT_CAS &P, uint32
 }
 
 // materialise everything still pending (end of a launch: results may be read next)
-__device__ BT_NOINLINE void flush_vertex(Env env, uint32_t vtx) {
-    const Vx c = make_vx(make_tile(env), vtx);
-    const GParams BT_CAS &P = env_params(env);
-    for (uint32_t s = 0; s < P.S; ++s) flush_sample(c, P, s);
-}
+
 
 // updateKmerStatsCache for one sample (VariantClusterHaplotypes.cpp:247-277): kmer_stats_cache[s] for the diplotype (h1, h2)
 __device__ inline void rebuild_kmer_stats_cache(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t h1, uint16_t h2, uint32_t nsub_u, uint32_t nsub_m) {
@@ -1436,6 +1433,62 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
         PROF(18);
     }
 }
+// ---- collected sweeps of single clusters without multicluster k-mers (TileDesc::logged): logged as runs, applied for all lanes together ----
+// A wavefront used to pay the statistics update of a collected sweep — replay of the pending run, rebuild of the k-mer-stats
+// cache, this sweep's contribution — whenever ANY of its lanes changed its diplotype, with one or two lanes active.  Here a sample's
+// collected sweeps are only logged while sampling: runs (diplotype, length), appended when the diplotype changes.  The log is applied at
+// the end of the chain (the cache is a function of the chain's k-mer subset), every lane working through its own entries at the same
+// time.  Per sample the entries are applied in order, each exactly as the immediate update would have been (cache of that diplotype,
+// then the run's replay), so every statistic sees the same values in the same order.
+__device__ inline void apply_collected_log(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t nsub_u) {
+    SPtr<uint32_t, LANES> lg = c.evlog(s);
+    const uint32_t n = c.evn()[s];
+    for (uint32_t e = 0; e < n; ++e) {
+        const uint32_t key = lg[1 + 2 * e], r = lg[2 + 2 * e];
+        const uint16_t h1 = (uint16_t)(key & 0xFFFFu), h2 = (uint16_t)(key >> 16);
+        rebuild_kmer_stats_cache(c, P, s, h1, h2, nsub_u, 0);
+        replay_collected(c, P, s, h1, h2, r, 0);
+    }
+    c.evn()[s] = 0;
+}
+__device__ inline void log_collected_run(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t key, uint32_t r, uint32_t nsub_u) {
+    SPtr<uint32_t, LANES> lg = c.evlog(s);
+    uint32_t n = c.evn()[s];
+    if (n == EV_CAP) {   // (a sample that keeps changing its diplotype: apply what is logged now)
+        apply_collected_log(c, P, s, nsub_u);
+        n = 0;
+    }
+    lg[1 + 2 * n] = key;   // (stores only: nothing waits for HBM while sampling)
+    lg[2 + 2 * n] = r;
+    c.evn()[s] = (uint8_t)(n + 1);
+}
+// end of a chain / of a launch: the open runs join the log, the log is applied
+__device__ BT_NOINLINE void drain_collected(Env env) {
+    const Vx c = make_vx(make_tile(env), 0);
+    const GParams BT_CAS &P = env_params(env);
+    const uint32_t nsub_u = c.sc()[SC_NSUB_U];
+    SPtrF<uint16_t, LANES> pdip = c.pend_dip();
+    SPtrF<uint8_t, LANES> pvalid = c.pend_valid(), upd = c.ksc_upd();
+    SPtrF<uint32_t, LANES> pend = c.pend();
+    for (uint32_t s = 0; s < P.S; ++s) {
+        if (pvalid[s] && pend[s]) log_collected_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], nsub_u);
+        pend[s] = 0;
+        pvalid[s] = 0;
+        upd[s] = 1;
+        apply_collected_log(c, P, s, nsub_u);
+    }
+}
+
+// materialise everything still pending (end of a launch: results may be read next)
+__device__ BT_NOINLINE void flush_vertex(Env env, uint32_t vtx) {
+    const Vx c = make_vx(make_tile(env), vtx);
+    const GParams BT_CAS &P = env_params(env);
+    if (c.d().logged) {
+        drain_collected(env);
+        return;
+    }
+    for (uint32_t s = 0; s < P.S; ++s) flush_sample(c, P, s);
+}
 __device__ BT_NOINLINE void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
@@ -1448,6 +1501,22 @@ __device__ BT_NOINLINE void update_allele_kmer_stats(Env env, uint32_t vtx, uint
     const GParams BT_CAS &P = env_params(env);
     SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
     SPtrF<uint8_t, LANES> upd = c.ksc_upd(), pvalid = c.pend_valid();
+    if (c.d().logged) {   // single cluster, no multicluster k-mers: log the run, apply it with everybody else's at the end of the chain
+        SPtrF<uint32_t, LANES> pend = c.pend();
+        for (uint32_t s = 0; s < P.S; ++s) {
+            const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
+            if (pvalid[s] && pdip[2 * s] == h1 && pdip[2 * s + 1] == h2) {
+                pend[s] += 1;
+                continue;
+            }
+            if (pvalid[s] && pend[s]) log_collected_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], nsub_u);
+            pdip[2 * s] = h1;
+            pdip[2 * s + 1] = h2;
+            pend[s] = 1;
+            pvalid[s] = 1;
+        }
+        return;
+    }
     for (uint32_t s = 0; s < P.S; ++s) {
         const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
 #ifndef ABL_NODEFER
