@@ -10,13 +10,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # posterior tolerance stated by north_star
 
 
-def run_both(gpu_ctx, oracle, flat, trace=0, **kw):
+def run_both(gpu_ctx, oracle, flat, trace=0, flat_gpu=None, **kw):
+    """the oracle on `flat`, the GPU on `flat_gpu` (default: the same batch)"""
     from bayestyper_amd import lib
 
     S = flat["S"]
     lut_g, lut_n = _oracle.build_luts(oracle, S)
     og = _oracle.OrcGibbs(oracle, flat, lut_g, lut_n, **kw)
-    gg = lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, **kw)
+    gg = lib.Gibbs(gpu_ctx, flat if flat_gpu is None else flat_gpu, lut_g, lut_n, **kw)
     if trace:
         og.trace_enable(trace)
         gg.trace_enable(trace)
@@ -380,9 +381,15 @@ def test_graphs_to_genotypes_end_to_end(gpu_ctx, oracle):
     for name in co:
         assert np.array_equal(co[name], cg[name]), name
     assert len(co["multi_idx"]) > 0 and co["kmer_has_counts"].sum() > len(co["kmer_has_counts"]) // 3 and co["kmer_counts"].sum() > 1000
-    flat = synth_graphs.gibbs_batch_from_candidates(cg, f, groups, S)
+    # each side gets the batch assembled from ITS OWN bundle, by different code: the product's harness for the GPU, the test's own for the oracle
+    from test_cli_gpu import _gibbs_batch as oracle_gibbs_batch
+
+    flat_gpu = synth_graphs.gibbs_batch_from_candidates(cg, f, groups, S)
+    flat = oracle_gibbs_batch(co, f, groups, S, np.full((len(groups), S), 2, np.uint8), [0] * S, list(range(len(gs))), [list(range(len(g))) for g in groups], [[] for _ in gs])
+    for name in flat:
+        assert np.array_equal(np.asarray(flat[name]), np.asarray(flat_gpu[name])), name
     kw = dict(seed=3, chains=2, burn=10, iters=30)
-    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=15, **kw)
+    ro, rg, tr = run_both(gpu_ctx, oracle, flat, trace=15, flat_gpu=flat_gpu, **kw)
     for g, (to, tg) in enumerate(tr):
         assert np.array_equal(to, tg[: len(to)]), f"group {g}"
     assert_parity(flat, ro, rg, 2 * 30)

@@ -6,7 +6,8 @@
   --estimateGenotypes (nested groups included)--> samples --getGenotypes + GenotypeWriter--> VCF
 
 The product side uses bayestyper_amd (libbtgpu.so kernels, libbthost.so host classes); the oracle side its own restatement of every
-stage (oracle_cluster.cpp, the Python graph builder, oracle_kmer.cpp, oracle_gibbs.cpp, oracle_writer.py).  Every hand-over is
+stage (oracle_cluster.cpp, oracle_graph.cpp, oracle_kmer.cpp, oracle_gibbs.cpp, oracle_writer.py; the flattening and the batch assembly of the
+oracle side are the test's own, tests/test_cli_gpu.py — no module of the product package runs on the oracle side).  Every hand-over is
 compared, and the two VCFs must be the same text."""
 import ctypes as C
 import os
@@ -104,21 +105,24 @@ def test_vcf_to_vcf(gpu_ctx, oracle, tmp_path):
     NC = len(where)
     assert any(len(g) > 1 for g in groups) and any(out_edges)
 
-    # ---- graphs: host C++ from the parsed clusters / Python restatement from the oracle's dump ----
+    # ---- graphs: host C++ from the parsed clusters / the oracle's own restatement of the constructor (oracle/oracle_graph.cpp) from the oracle's dump.
+    #      The oracle side is assembled by the test's own helpers (tests/test_cli_gpu.py): nothing of bayestyper_amd.synth_graphs runs on it. ----
+    from test_cli_gpu import _flatten as oracle_flatten, _gibbs_batch as oracle_gibbs_batch, _graph_arrays as oracle_graph_arrays
+
     gs_h, gs_o = [], []
     for gi, vi in where:
         v = units_o[0][gi]["vertices"][vi]
         gs_h.append(graph_from_fetch(fetch_graph(st.graph(gi, vi), len(v["vars"]))))
-        chrom = np.array([CODE[c] for c in seqs[v["chrom"]]], np.uint8)
-        variants = [{"pos": pos, "alts": [(rl, [CODE[c] for c in seq]) for rl, seq in alts], "has_dependency": bool(dep), "num_redundant": red}
-                    for (pos, _, dep, alts), red in zip(v["vars"], v["red"])]
-        go = synth_graphs.build_graph(chrom, variants, K, contained=[(lf, rf, ci) for ci, lf, rf in v["contained"]])
-        go.num_alleles = [1 + len(x["alts"]) + int(x["has_dependency"]) for x in variants]
-        go.has_dep = [int(x["has_dependency"]) for x in variants]
-        gs_o.append(go)
-    f_h, f_o = synth_graphs.flatten(gs_h), synth_graphs.flatten(gs_o)
+        gs_o.append(oracle_graph_arrays(oracle, seqs[v["chrom"]].encode(), v["vars"], v["red"], v["contained"]))
+    f_h, f_o = synth_graphs.flatten(gs_h), oracle_flatten(gs_o)
     for name in f_o:
-        assert np.array_equal(f_h[name], f_o[name]), name
+        if name not in ("num_clusters", "refvar"):
+            assert np.array_equal(np.asarray(f_h[name]).astype(np.asarray(f_o[name]).dtype), f_o[name]), name
+    # a vertex's reference_variant_indices: the reference keeps them in the iteration order of an unordered_set (as the oracle does) and only
+    # ever uses them as a set (VariantClusterGraph.cpp:1001-1011, 1124-1130); the product stores them ascending
+    for v in range(len(f_o["refvar_off"]) - 1):
+        a, b = int(f_o["refvar_off"][v]), int(f_o["refvar_off"][v + 1])
+        assert sorted(f_o["refvar"][a:b].tolist()) == f_h["refvar"][a:b].tolist(), v
 
     # ---- samples: reads of two haplotypes each -> KMC database -> sample filter (makeBloom) -> best paths ----
     og, gf = OrcGraphs(oracle, f_o, K), lib.FindPaths(gpu_ctx, f_h, K, 32, S)
@@ -152,10 +156,10 @@ def test_vcf_to_vcf(gpu_ctx, oracle, tmp_path):
     bg = gf.best_paths()
     for c in range(NC):
         assert bo[c].shape == bg[c].shape and np.array_equal(bo[c], bg[c]), c
-        gs_h[c].paths, gs_o[c].paths = bg[c], bo[c]
+        gs_h[c].paths = bg[c]
     assert sum(b.shape[0] for b in bg) > NC + NC // 3
     og.close(), gf.close()
-    f_h, f_o = synth_graphs.flatten(gs_h), synth_graphs.flatten(gs_o)
+    f_h, f_o = synth_graphs.flatten(gs_h), oracle_flatten(gs_o, bo)
 
     # ---- path k-mers -> path filter; sample counts and intercluster multiplicities -> count table ----
     og, gp = OrcGraphs(oracle, f_o, K), lib.Paths(gpu_ctx, f_h, K)
@@ -186,7 +190,7 @@ def test_vcf_to_vcf(gpu_ctx, oracle, tmp_path):
 
     # ---- Gibbs over the parsed group structure (nested clusters follow their parents) ----
     kw = dict(seed=SEED, chains=2, burn=10, iters=40)
-    flat_o = synth_graphs.gibbs_batch_from_candidates(co, f_o, groups, S, cluster_ids=cluster_ids, sources=sources, out_edges=out_edges)
+    flat_o = oracle_gibbs_batch(co, f_o, groups, S, np.full((len(groups), S), 2, np.uint8), [0] * S, cluster_ids, sources, out_edges)
     flat_h = synth_graphs.gibbs_batch_from_candidates(cg, f_h, groups, S, cluster_ids=cluster_ids, sources=sources, out_edges=out_edges)
     lut_o = _oracle.build_luts(oracle, S, mean=15.0, var=30.0)
     lut_h = count_model.build_luts(S, mean=15.0, var=30.0)
