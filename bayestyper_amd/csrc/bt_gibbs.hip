@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict
     Tile t;
     t.d = (const TileDesc BT_CAS *)&tiles[loc[c].tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
-    t.lane = loc[c].lane;
+    t.lane = t.plane = loc[c].lane;   // (ClusterLoc::lane is the pool lane; no LDS here)
     t.hot = nullptr;
     t.resident = 0xFFFFFFFFu;
     const Vx x = make_vx(t, loc[c].v);
@@ -80,7 +80,7 @@ struct TilePlan {
 
 template <typename T>
 inline void put(std::vector<uint8_t> &img, const TileDesc &d, int arr, size_t idx, uint32_t lane, T value) {
-    T *p = reinterpret_cast<T *>(img.data() + d.off[arr]) + idx * LANES + lane;
+    T *p = reinterpret_cast<T *>(img.data() + d.off[arr]) + idx * LANES + d.pool_lane0 + lane;   // lane: the group's lane in its tile
     *p = value;
 }
 
@@ -304,7 +304,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     // state of their groups).  plan_tiles(relax) lays the batch out with the one-group-per-wavefront class 2^relax times wider (up
     // to the width of the other expensive groups), then with the smaller dense-table limit; the first layout that fits the free HBM is used.  A batch that does not fit even
     // then is refused with the size it needs: the host splits the unit (host/inference_engine.py: max_groups_per_launch).
-    std::vector<uint32_t> tile_start;
+    std::vector<uint32_t> tile_start, blk_first, blk_last;   // (blk_*: first / last tile of the pool block a tile shares, see plan_tiles)
     std::vector<TilePlan> plans;
     uint64_t pool = 0;
     uint32_t ntiles = 0;
@@ -383,6 +383,31 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     g->loc.assign(C, ClusterLoc{0, 0, 0, 0});
     const uint64_t collect_total = (uint64_t)std::max<uint32_t>(params->num_chains, 1) * std::max<uint32_t>(params->num_iterations, 1) * S;
 
+    // Pool blocks.  Every array of the pool is interleaved over 64 lanes; a narrow tile uses 4 or 16 of them.  Consecutive narrow tiles of
+    // the same width therefore SHARE one pool block — 64 / width tiles side by side, tile j on pool lanes [j * width, (j + 1) * width) — laid out
+    // for the maxima of all their groups (the batch is sorted by shape, so neighbours are alike).  A tile addresses HBM with its pool lane
+    // (TileDesc::pool_lane0 + lane) and LDS with its own lane; nothing else changes.
+    blk_first.assign(ntiles, 0);
+    blk_last.assign(ntiles, 0);
+    {
+        auto width_of = [&](uint32_t ti) {
+            uint32_t w = 1;
+            while (w < tile_start[ti + 1] - tile_start[ti]) w *= 2;
+            return w;
+        };
+        const bool share = !getenv("BT_GIBBS_NO_SHARE");
+        for (uint32_t ti = 0; ti < ntiles;) {
+            const uint32_t w = width_of(ti);
+            uint32_t n = 1;
+            if (share && w < LANES)
+                while (ti + n < ntiles && n < LANES / w && width_of(ti + n) == w) ++n;
+            for (uint32_t j = 0; j < n; ++j) {
+                blk_first[ti + j] = ti;
+                blk_last[ti + j] = ti + n - 1;
+            }
+            ti += n;
+        }
+    }
     plans.assign(ntiles, TilePlan{});
     for (uint32_t ti = 0; ti < ntiles; ++ti) {
         TileDesc d{};
@@ -390,8 +415,8 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         d.first_group = tile_start[ti];
         d.num_lanes = tile_start[ti + 1] - tile_start[ti];
         uint32_t Am = 1, NSHm = 0;
-        for (uint32_t l = 0; l < d.num_lanes; ++l) {
-            const uint32_t gi = shapes[tile_start[ti] + l].g;
+        for (uint32_t bl = tile_start[blk_first[ti]]; bl < tile_start[blk_last[ti] + 1]; ++bl) {   // dimensions: maxima over the pool block
+            const uint32_t gi = shapes[bl].g;
             const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
             d.nvm = std::max(d.nvm, c1 - c0);
             NSHm = std::max(NSHm, B->group_num_shared[gi]);
@@ -422,12 +447,13 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         const uint64_t dense = (uint64_t)S * d.Dcm;
         uint32_t tile_w = 1;
         while (tile_w < d.num_lanes) tile_w *= 2;
-        d.mat_width = tile_w < LANES ? tile_w : 0u;   // narrow tiles: K x H matrices per-lane contiguous (TileDesc::mat_width)
+        d.pool_lane0 = (ti - blk_first[ti]) * tile_w;
+        d.mat_width = tile_w < LANES ? LANES : 0u;   // narrow tiles: K x H matrices contiguous per POOL lane (TileDesc::mat_width)
         const uint64_t table_bytes = dense * 8 * (tile_w < LANES ? tile_w : LANES) * d.nvm + (d.NMm ? dense * 16 * LANES * d.nvm : 0);
         if (table_bytes <= dense_limit && dense < (1ull << 26)) {
             d.cache_mode = 0;
             d.cache_entries = (uint32_t)dense;
-            d.uc_width = tile_w < LANES ? tile_w : 0u;
+            d.uc_width = tile_w < LANES ? LANES : 0u;
         } else {
             d.cache_mode = 1;
             d.cache_entries = 16384;
@@ -611,7 +637,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         }
         d.logged = d.nvm == 1 && d.NMm == 0 && !getenv("BT_GIBBS_NO_LOG") ? 1u : 0u;
         d.prio = (d.copies > 1 || d.num_lanes < LANES / 2) && !getenv("BT_GIBBS_NO_PRIO") ? 1u : 0u;
-        d.base = pool;
+        d.base = ti == blk_first[ti] ? pool : plans[blk_first[ti]].d.base;
         if (ti == 0 && getenv("BT_GIBBS_DEBUG") && atoi(getenv("BT_GIBBS_DEBUG")) >= 2) {   // the arrays that make up most of tile 0
             std::vector<std::pair<uint64_t, int>> by_size;
             for (int a = 0; a < A_COUNT; ++a) by_size.emplace_back(len[a] * LANES * kElemSize[a], a);
@@ -623,7 +649,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         plans[ti].d = d;
         plans[ti].in_bytes = in_bytes;
         plans[ti].total_bytes = align_up(off, 256);
-        pool += plans[ti].total_bytes;
+        if (ti == blk_first[ti]) pool += plans[ti].total_bytes;
     }
     };   // plan_tiles
     {
@@ -652,7 +678,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     for (uint32_t ti = 0; ti < ntiles; ++ti) {
         const TileDesc &d = plans[ti].d;
         g->tiles[ti] = d;
-        img.assign(plans[ti].in_bytes, 0);
+        if (ti == blk_first[ti]) img.assign(plans[ti].in_bytes, 0);   // one image per pool block
         for (uint32_t l = 0; l < d.num_lanes; ++l) {
             const uint32_t gi = shapes[tile_start[ti] + l].g;
             const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
@@ -668,7 +694,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             for (uint32_t s = 0; s < S; ++s) put<uint8_t>(img, d, A_PLOIDY, s, l, B->group_ploidy[(size_t)gi * S + s]);
             for (uint32_t c = c0; c < c1; ++c) {
                 const size_t v = c - c0;
-                g->loc[c] = ClusterLoc{ti, l, (uint32_t)v, 0};
+                g->loc[c] = ClusterLoc{ti, d.pool_lane0 + l, (uint32_t)v, 0};   // (the pool lane: where the cluster's arrays are)
                 const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], r0 = B->kmer_off[c], K = B->kmer_off[c + 1] - r0;
                 const uint32_t nu = B->unique_off[c + 1] - B->unique_off[c], nm = B->multi_off[c + 1] - B->multi_off[c];
                 const uint32_t nd = B->nestdep_off[c + 1] - B->nestdep_off[c], ne = B->edge_off[c + 1] - B->edge_off[c];
@@ -681,7 +707,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 for (uint32_t k = 0; k < K; ++k) {
                     const size_t r = (size_t)r0 + k;
                     if (d.mat_width) {   // per-lane contiguous: ((v * width + lane) * Km + k) * Hm + h
-                        uint8_t *row = img.data() + d.off[A_M] + (((size_t)v * d.mat_width + l) * d.Km + k) * d.Hm;
+                        uint8_t *row = img.data() + d.off[A_M] + (((size_t)v * d.mat_width + d.pool_lane0 + l) * d.Km + k) * d.Hm;
                         for (uint32_t h = 0; h < H; ++h) row[h] = M[(size_t)k * H + h];
                     } else
                         for (uint32_t h = 0; h < H; ++h) put<uint8_t>(img, d, A_M, (v * d.Km + k) * d.Hm + h, l, M[(size_t)k * H + h]);
@@ -737,8 +763,10 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 for (uint32_t i = 0; i < ne; ++i) put<uint32_t>(img, d, A_EDGES0, v * std::max<uint32_t>(d.NEm, 1) + i, l, B->edges[B->edge_off[c] + i]);
             }
         }
-        BT_TRYHIP(hipMemcpyAsync(g->d_pool + d.base, img.data(), plans[ti].in_bytes, hipMemcpyHostToDevice, ctx->stream));
-        BT_TRYHIP(hipStreamSynchronize(ctx->stream));   // img is reused
+        if (ti == blk_last[ti]) {
+            BT_TRYHIP(hipMemcpyAsync(g->d_pool + d.base, img.data(), plans[ti].in_bytes, hipMemcpyHostToDevice, ctx->stream));
+            BT_TRYHIP(hipStreamSynchronize(ctx->stream));   // img is reused
+        }
     }
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_tiles), (size_t)ntiles * sizeof(TileDesc)));
     g->allocs.push_back(g->d_tiles);
@@ -927,8 +955,8 @@ int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t
         if (rc != BT_OK) return rc;
         for (uint32_t l = 0; l < d.num_lanes; ++l)
             for (uint32_t v = 0; v < d.nvm; ++v) {
-                if (sc[((size_t)v * SC_COUNT + SC_DIP_OVERFLOW) * LANES + l]) return fail("bt_gibbs: diplotype frequency table overflowed");
-                nd += sc[((size_t)v * SC_COUNT + SC_DIP_ENTRIES) * LANES + l];
+                if (sc[((size_t)v * SC_COUNT + SC_DIP_OVERFLOW) * LANES + d.pool_lane0 + l]) return fail("bt_gibbs: diplotype frequency table overflowed");
+                nd += sc[((size_t)v * SC_COUNT + SC_DIP_ENTRIES) * LANES + d.pool_lane0 + l];
             }
     }
     for (uint32_t c = 0; c < g->C; ++c) nc += (uint64_t)g->h_A[c] * g->S;

@@ -34,7 +34,7 @@ __device__ BT_NOINLINE void group_init_chain(Env env, uint32_t chain, uint32_t n
     }
     // shuffleBranchOrdering (VariantClusterGroup.cpp:208-218)
     if (nvert == 1 && nsrc == 1) return;   // nothing to shuffle (a fresh generator is seeded per call, no state carries over)
-    uint32_t *bst = (uint32_t *)(t.base + t.d->off[A_BRNG]) + (size_t)t.lane * MT_PAD;
+    uint32_t *bst = (uint32_t *)(t.base + t.d->off[A_BRNG]) + (size_t)t.plane * MT_PAD;
     mt_seed(bst, P.seed + (gindex + 1u) * (chain + 1u));
     Mt brng = mt_open(bst);
     rng_shuffle_u32(brng, t.arr<uint32_t>(A_SOURCES), nsrc);
@@ -199,6 +199,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     if (!tile_thread_active(t.d->split, t.d->copies)) return;
     t.lane = tile_lane(t.d->split, t.d->copies);
+    t.plane = t.lane + t.d->pool_lane0;
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     // the extra copies of a narrow tile's groups only take part in the sampling operations (the others tally with atomics)

@@ -147,6 +147,7 @@ struct TileDesc {
     uint32_t simple;                // every group of the tile is one two-haplotype cluster without multicluster k-mers: sweeps run in simple_sweeps()
     uint32_t ring_cap[2], ring_len; // draw-ahead words of the diplotype / frequency generator (powers of two); ring_len = both blocks
     uint32_t prio;                  // the tile's wavefronts raise their issue priority (narrow tiles: the launch's critical path)
+    uint32_t pool_lane0;            // first lane of this tile in the pool block it shares with the neighbouring narrow tiles (0 for 64-lane tiles)
     uint32_t logged;                // single clusters without multicluster k-mers: collected sweeps are logged as runs and applied at the end of the chain
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
@@ -170,7 +171,8 @@ struct GParams {
 struct Tile {
     uint8_t BT_GAS *base;
     const TileDesc BT_CAS *d;
-    uint32_t lane;
+    uint32_t lane;      // the group's lane in its tile: LDS rows, trace rows
+    uint32_t plane;     // its lane in the pool block the tile shares with its neighbours (TileDesc::pool_lane0 + lane): everything in HBM
     // Narrow tiles leave most lanes of their wavefront idle.  Instead, 64 / width ("copies") threads run the SAME group: identical
     // program, identical loads, identical stores to identical addresses (SIMT lockstep makes every read-modify-write of the copies
     // read before any of them writes) — which costs nothing — and the phases that are data-parallel inside one group (the dense
@@ -184,11 +186,11 @@ struct Tile {
         const uint32_t ho = d->hoff[a];
         if (hot != nullptr && ho != NOHOT && (resident == RESIDENT_ALL || v == resident))
             return SPtrF<T, LANES>{(T *)(hot + (resident == RESIDENT_ALL ? v * d->hot_bytes : 0u) + ho), lane, d->lds_stride};
-        return SPtrF<T, LANES>{(T *)(uint8_t *)(base + d->off[a]), v * len * LANES + lane};
+        return SPtrF<T, LANES>{(T *)(uint8_t *)(base + d->off[a]), v * len * LANES + plane};
     }
     template <typename T>
     __device__ inline SPtr<T, LANES> arr(int a, uint32_t first = 0) const {
-        return SPtr<T, LANES>{(T BT_GAS *)(base + d->off[a]), first * LANES + lane};
+        return SPtr<T, LANES>{(T BT_GAS *)(base + d->off[a]), first * LANES + plane};
     }
 };
 
@@ -231,8 +233,8 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline RPtr<uint8_t> mat(int arr, uint32_t rows) const {
         uint8_t BT_GAS *b = (uint8_t BT_GAS *)(t.base + d().off[arr]);
         const uint32_t w = d().mat_width, n = rows * d().Hm;
-        if (w) return RPtr<uint8_t>{b, (v * w + t.lane) * n, 1u};
-        return RPtr<uint8_t>{b, v * n * LANES + t.lane, LANES};
+        if (w) return RPtr<uint8_t>{b, (v * w + t.plane) * n, 1u};
+        return RPtr<uint8_t>{b, v * n * LANES + t.plane, LANES};
     }
     // inputs
     __device__ inline uint8_t M(uint32_t k, uint32_t h) const { return mat(A_M, d().Km)[(uint32_t)k * d().Hm + h]; }
@@ -252,7 +254,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint8_t var_dep(uint32_t var) const { return a<uint8_t>(A_VARDEP, d().Vm)[var]; }
     __device__ inline uint32_t allele_base(uint32_t var) const { return a<uint32_t>(A_ALBASE, d().Vm + 1)[var]; }
     // state
-    __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)(v * 2 + g) * LANES + t.lane) * MT_PAD; }
+    __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)(v * 2 + g) * LANES + t.plane) * MT_PAD; }
     __device__ inline SPtrF<uint32_t, LANES> ring(uint32_t g) const { return t.harr<uint32_t>(A_RING, v, d().ring_len) + (g ? d().ring_cap[0] + MT_RING_HDR : 0u); }
     __device__ inline MtRing rng(uint32_t g) const { return mt_ring_open(mt(g), ring(g), d().ring_cap[g]); }
     __device__ inline void rng_seed(uint32_t g, uint32_t seed) const { mt_ring_seed(mt(g), ring(g), d().ring_cap[g], seed); }
@@ -288,8 +290,8 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
             return UCPtr{(double *)(t.hot + (t.resident == RESIDENT_ALL ? v * d().hot_bytes : 0u) + ho), t.lane, d().lds_stride};
         double *b = (double *)(uint8_t *)(t.base + d().off[A_UCACHE]);
         const uint32_t w = d().uc_width;
-        if (w) return UCPtr{b, (v * w + t.lane) * d().cache_entries, 1u};
-        return UCPtr{b, v * d().cache_entries * LANES + t.lane, LANES};
+        if (w) return UCPtr{b, (v * w + t.plane) * d().cache_entries, 1u};
+        return UCPtr{b, v * d().cache_entries * LANES + t.plane, LANES};
     }
     __device__ inline SPtr<uint32_t, LANES> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
     __device__ inline SPtrF<double, LANES> cum() const { return t.harr<double>(A_CUM, v, (d().D2m > 1 ? d().D2m : 1) * (d().teams > 1 ? d().teams : 1)); }
@@ -364,6 +366,7 @@ __device__ inline Tile make_tile(const Env &e_in) {
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = tile_lane(t.d->split, t.d->copies);
+    t.plane = t.lane + t.d->pool_lane0;
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     t.resident = e_in.resident;   // per lane: lanes of a tile may be at different vertices of their groups
@@ -392,7 +395,7 @@ __device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len
     if (ho == NOHOT) return;
     const uint32_t LS = t.d->lds_stride;
     T BT_LAS *l = (T BT_LAS *)(bt_lds_raw + lds_vertex_off + ho) + t.lane;   // explicit LDS pointer: the copies of different arrays can overlap (no aliasing with HBM)
-    T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + v * len * LANES + t.lane;
+    T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + v * len * LANES + t.plane;
     // eight elements in flight per step (the copy is latency-bound: one wavefront, one memory round trip per step)
     uint32_t i = 0;
     len = live < len ? live : len;   // (the vertex stride above used the full row count)
