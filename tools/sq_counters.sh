@@ -12,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_LDS SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"; do
   d=$out/prof_$tag/sq_$cls
   rm -rf $d
-  rocprofv3 --pmc $set --output-format csv -d $d -- python tools/perf_classes.py $S $G $cls > $d.log 2> $d.err
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $d -- python tools/perf_classes.py $S $G $cls > $d.log 2> $d.err
   python - "$d" >> $dst <<'PY'
 import csv, glob, sys
 agg = {}
