@@ -112,7 +112,8 @@ per dispatch): **{e(bench['value'])} cluster-sweeps/s** ({bench['ms_per_step'] /
 cluster-sweeps/s (`gpurun_out/r02a`, first measurement of this round) — **{bench['value'] / 1.5e8:.1f}×**; round 1's own bench (configs[1]-like, S = 1, identical
 structures) is not comparable.  {sum(int(r['grid_x']) // 64 for r in last)} tiles, {bench['gibbs_device_bytes'] / 1e9:.0f} GB of sampler state.
 """ + (f"""`python bench.py --samples 10` (the same mixture, ten samples): {e(S10['value'])} cluster-sweeps/s, {S10['ms_per_step'] / 1e3:.1f} s per step, {S10.get('gpu_over_cpu_allcores', 0):.0f}× the
-{S10['cpu_baseline']['cores']}-thread oracle run — the north star's 10-sample target is ≥ 20×.
+{S10['cpu_baseline']['cores']}-thread oracle run — the north star's 10-sample target is ≥ 20×.  Thirty samples (`--samples 30 --groups 100000`): 37.3 s per step, 1.9×10^7
+cluster-sweeps/s, 20.5 GB.
 """ if S10 else "") + f"""
 PCIe: `bt_kmc_scan_run` takes device pointers; `bt_kmc_scan_run_host` streams a host-resident (memory-mapped) payload through two pinned staging
 buffers and a copy stream, overlapping host copy, transfer and scan: **{e(pc['records_per_sec'])} records/s = {pc['host_gbytes_per_sec']:.0f} GB/s** from pageable host memory, i.e. the
