@@ -46,11 +46,12 @@ __global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict
     Tile t;
     t.d = (const TileDesc BT_CAS *)&tiles[loc[c].tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
-    t.lane = t.plane = loc[c].lane;   // (ClusterLoc::lane is the pool lane; no LDS here)
+    t.lane = t.plane = loc[c].lane;   // (no LDS here)
+    t.wsh = t.d->wsh;
     t.hot = nullptr;
     t.resident = 0xFFFFFFFFu;
     const Vx x = make_vx(t, loc[c].v);
-    SPtr<uint32_t, LANES> keys = x.dip_keys(), freq = x.dip_freq();
+    TPtr<uint32_t> keys = x.dip_keys(), freq = x.dip_freq();
     const uint32_t cap = t.d->dip_cap;
     for (uint32_t s = 0; s < S; ++s) {
         uint32_t best_key = 0xFFFFFFFFu, best = 0;
@@ -80,7 +81,7 @@ struct TilePlan {
 
 template <typename T>
 inline void put(std::vector<uint8_t> &img, const TileDesc &d, int arr, size_t idx, uint32_t lane, T value) {
-    T *p = reinterpret_cast<T *>(img.data() + d.off[arr]) + idx * LANES + d.pool_lane0 + lane;   // lane: the group's lane in its tile
+    T *p = reinterpret_cast<T *>(img.data() + d.off[arr]) + (idx << d.wsh) + lane;   // rows interleaved over the tile's own width
     *p = value;
 }
 
@@ -395,7 +396,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             while (w < tile_start[ti + 1] - tile_start[ti]) w *= 2;
             return w;
         };
-        const bool share = !getenv("BT_GIBBS_NO_SHARE");
+        const bool share = false;   // (round 3: every tile has a pool block of its own width, see TileDesc::wsh)
         for (uint32_t ti = 0; ti < ntiles;) {
             const uint32_t w = width_of(ti);
             uint32_t n = 1;
@@ -447,13 +448,15 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         const uint64_t dense = (uint64_t)S * d.Dcm;
         uint32_t tile_w = 1;
         while (tile_w < d.num_lanes) tile_w *= 2;
-        d.pool_lane0 = (ti - blk_first[ti]) * tile_w;
-        d.mat_width = tile_w < LANES ? LANES : 0u;   // narrow tiles: K x H matrices contiguous per POOL lane (TileDesc::mat_width)
-        const uint64_t table_bytes = dense * 8 * (tile_w < LANES ? tile_w : LANES) * d.nvm + (d.NMm ? dense * 16 * LANES * d.nvm : 0);
+        d.pool_lane0 = 0;
+        d.wsh = 0;
+        while ((1u << d.wsh) < tile_w) ++d.wsh;
+        d.mat_width = tile_w < LANES ? tile_w : 0u;   // narrow tiles: K x H matrices contiguous per lane (TileDesc::mat_width)
+        const uint64_t table_bytes = dense * 8 * tile_w * d.nvm + (d.NMm ? dense * 16 * tile_w * d.nvm : 0);
         if (table_bytes <= dense_limit && dense < (1ull << 26)) {
             d.cache_mode = 0;
             d.cache_entries = (uint32_t)dense;
-            d.uc_width = tile_w < LANES ? LANES : 0u;
+            d.uc_width = tile_w < LANES ? tile_w : 0u;
         } else {
             d.cache_mode = 1;
             d.cache_entries = 16384;
@@ -469,7 +472,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         // lengths (elements per lane) of every array
         const uint64_t nv = d.nvm;
         uint64_t len[A_COUNT];
-        len[A_M] = d.mat_width ? ((uint64_t)nv * d.mat_width * d.Km * d.Hm + LANES - 1) / LANES : (uint64_t)nv * d.Km * d.Hm;
+        len[A_M] = (uint64_t)nv * d.Km * d.Hm;
         len[A_HASC] = nv * d.Km;
         len[A_COUNTS] = nv * d.Km * S;
         len[A_IC] = nv * d.Km * 2;
@@ -509,7 +512,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_ZBKT] = len[A_PBKT] = nv * d.Bcap;
         len[A_UNEXT] = nv * d.Hm;
         len[A_HVCOUNT] = nv * d.Hm * d.Vm;
-        len[A_UCACHE] = d.uc_width ? ((uint64_t)nv * d.uc_width * d.cache_entries + LANES - 1) / LANES : (uint64_t)nv * d.cache_entries;
+        len[A_UCACHE] = (uint64_t)nv * d.cache_entries;
         len[A_UCTAG] = nv * (d.cache_mode == 1 ? d.cache_entries : 1);
         {   // teams of copies in sample_diplotypes (narrow tiles with dense tables): min(S, copies)
             uint32_t stride = 1;
@@ -545,7 +548,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         len[A_MSUBC] = nv * (uint64_t)std::max<uint32_t>(d.NMm, 1) * S;
         len[A_MSUBIC] = nv * (uint64_t)std::max<uint32_t>(d.NMm, 1) * 2;
         len[A_MSUBSH] = nv * (uint64_t)std::max<uint32_t>(d.NMm, 1);
-        len[A_SUBM] = d.mat_width ? ((uint64_t)nv * d.mat_width * d.NUm * d.Hm + LANES - 1) / LANES : nv * (uint64_t)d.NUm * d.Hm;
+        len[A_SUBM] = nv * (uint64_t)d.NUm * d.Hm;
         len[A_SUBCNT] = nv * (uint64_t)d.NUm * S;
         len[A_SUBIC] = nv * (uint64_t)d.NUm * 2;
         len[A_SKVOFF] = nv * (uint64_t)(d.NUm + 1);
@@ -573,7 +576,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         for (int a = 0; a < A_COUNT; ++a) {
             off = align_up(off, 256);
             d.off[a] = off;
-            off += len[a] * LANES * kElemSize[a];
+            off += len[a] * tile_w * kElemSize[a];
             if (a == A_PLOIDY) in_bytes = align_up(off, 256);
         }
         {
@@ -640,7 +643,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         d.base = ti == blk_first[ti] ? pool : plans[blk_first[ti]].d.base;
         if (ti == 0 && getenv("BT_GIBBS_DEBUG") && atoi(getenv("BT_GIBBS_DEBUG")) >= 2) {   // the arrays that make up most of tile 0
             std::vector<std::pair<uint64_t, int>> by_size;
-            for (int a = 0; a < A_COUNT; ++a) by_size.emplace_back(len[a] * LANES * kElemSize[a], a);
+            for (int a = 0; a < A_COUNT; ++a) by_size.emplace_back(len[a] * tile_w * kElemSize[a], a);
             std::sort(by_size.rbegin(), by_size.rend());
             fprintf(stderr, "bt_gibbs: tile 0 (%u groups, %u vertices max, Hm %u, Km %u, S %u): %.1f MB;", d.num_lanes, d.nvm, d.Hm, d.Km, S, (double)align_up(off, 256) / 1048576.0);
             for (int i = 0; i < 6; ++i) fprintf(stderr, " array %d: %.1f MB", by_size[i].second, (double)by_size[i].first / 1048576.0);
@@ -694,7 +697,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
             for (uint32_t s = 0; s < S; ++s) put<uint8_t>(img, d, A_PLOIDY, s, l, B->group_ploidy[(size_t)gi * S + s]);
             for (uint32_t c = c0; c < c1; ++c) {
                 const size_t v = c - c0;
-                g->loc[c] = ClusterLoc{ti, d.pool_lane0 + l, (uint32_t)v, 0};   // (the pool lane: where the cluster's arrays are)
+                g->loc[c] = ClusterLoc{ti, l, (uint32_t)v, 0};
                 const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], r0 = B->kmer_off[c], K = B->kmer_off[c + 1] - r0;
                 const uint32_t nu = B->unique_off[c + 1] - B->unique_off[c], nm = B->multi_off[c + 1] - B->multi_off[c];
                 const uint32_t nd = B->nestdep_off[c + 1] - B->nestdep_off[c], ne = B->edge_off[c + 1] - B->edge_off[c];
@@ -707,7 +710,7 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
                 for (uint32_t k = 0; k < K; ++k) {
                     const size_t r = (size_t)r0 + k;
                     if (d.mat_width) {   // per-lane contiguous: ((v * width + lane) * Km + k) * Hm + h
-                        uint8_t *row = img.data() + d.off[A_M] + (((size_t)v * d.mat_width + d.pool_lane0 + l) * d.Km + k) * d.Hm;
+                        uint8_t *row = img.data() + d.off[A_M] + (((size_t)v * d.mat_width + l) * d.Km + k) * d.Hm;
                         for (uint32_t h = 0; h < H; ++h) row[h] = M[(size_t)k * H + h];
                     } else
                         for (uint32_t h = 0; h < H; ++h) put<uint8_t>(img, d, A_M, (v * d.Km + k) * d.Hm + h, l, M[(size_t)k * H + h]);
@@ -936,7 +939,7 @@ int bt_gibbs_device_bytes(bt_gibbs *g, uint64_t *bytes) {
 // copy one array of one tile to the host (all vertices, all lanes)
 template <typename T>
 static int fetch_array(bt_gibbs *g, uint32_t ti, int arr, uint64_t elems_per_lane, std::vector<T> &out) {
-    out.resize(elems_per_lane * LANES);
+    out.resize(elems_per_lane << g->tiles[ti].wsh);
     BT_HIP(hipMemcpy(out.data(), g->d_pool + g->tiles[ti].base + g->tiles[ti].off[arr], out.size() * sizeof(T), hipMemcpyDeviceToHost));
     return BT_OK;
 }
@@ -955,8 +958,8 @@ int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t
         if (rc != BT_OK) return rc;
         for (uint32_t l = 0; l < d.num_lanes; ++l)
             for (uint32_t v = 0; v < d.nvm; ++v) {
-                if (sc[((size_t)v * SC_COUNT + SC_DIP_OVERFLOW) * LANES + d.pool_lane0 + l]) return fail("bt_gibbs: diplotype frequency table overflowed");
-                nd += sc[((size_t)v * SC_COUNT + SC_DIP_ENTRIES) * LANES + d.pool_lane0 + l];
+                if (sc[(((size_t)v * SC_COUNT + SC_DIP_OVERFLOW) << d.wsh) + l]) return fail("bt_gibbs: diplotype frequency table overflowed");
+                nd += sc[(((size_t)v * SC_COUNT + SC_DIP_ENTRIES) << d.wsh) + l];
             }
     }
     for (uint32_t c = 0; c < g->C; ++c) nc += (uint64_t)g->h_A[c] * g->S;
@@ -990,7 +993,7 @@ int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, 
         }
         auto &e = ents[c];
         for (uint32_t slot = 0; slot < d.dip_cap; ++slot) {
-            const uint32_t tag = keys[((size_t)L.v * d.dip_cap + slot) * LANES + L.lane];
+            const uint32_t tag = keys[(((size_t)L.v * d.dip_cap + slot) << d.wsh) + L.lane];
             if (!tag) continue;
             e.emplace_back(tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u, slot);
         }
@@ -1027,7 +1030,7 @@ int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, 
             if (h_dip_h1) h_dip_h1[e] = (uint16_t)(kv.first & 0xFFFF);
             if (h_dip_h2) h_dip_h2[e] = (uint16_t)(kv.first >> 16);
             if (h_dip_freq)
-                for (uint32_t s = 0; s < S; ++s) h_dip_freq[e * S + s] = freq[(((size_t)L.v * d.dip_cap + kv.second) * S + s) * LANES + L.lane];
+                for (uint32_t s = 0; s < S; ++s) h_dip_freq[e * S + s] = freq[((((size_t)L.v * d.dip_cap + kv.second) * S + s) << d.wsh) + L.lane];
             ++e;
         }
         if (h_stats) {
@@ -1035,7 +1038,7 @@ int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, 
             for (uint32_t s = 0; s < S; ++s)
                 for (uint32_t a = 0; a < A; ++a)
                     for (uint32_t q = 0; q < 12; ++q)
-                        h_stats[(h_cell_off[c] + (uint64_t)s * A + a) * 12 + q] = ast[((((size_t)L.v * S + s) * d.Am + a) * 12 + q) * LANES + L.lane];
+                        h_stats[(h_cell_off[c] + (uint64_t)s * A + a) * 12 + q] = ast[(((((size_t)L.v * S + s) * d.Am + a) * 12 + q) << d.wsh) + L.lane];
         }
     }
     return BT_OK;

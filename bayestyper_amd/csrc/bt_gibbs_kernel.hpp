@@ -52,9 +52,9 @@ __device__ BT_NOINLINE void prepare_nested(Env env, uint32_t v_parent, uint32_t 
     const Vx c = make_vx(t, v_parent), cc = make_vx(t, v_child);
     const uint32_t nd_n = vx_nd(c), cc_cid = cc.cid();
     const TileDesc BT_CAS &d = c.d();
-    SPtr<uint32_t, LANES> ndcl = c.a<uint32_t>(A_NDCL, d.NDm > 1 ? d.NDm : 1), ndvo = c.a<uint32_t>(A_NDVOFF, d.NDm + 1);
-    SPtr<uint16_t, LANES> ndv = c.a<uint16_t>(A_NDVAR, d.NDVm > 1 ? d.NDVm : 1);
-    SPtr<uint32_t, LANES> pver = c.nver(), cver = cc.nver();
+    TPtr<uint32_t> ndcl = c.a<uint32_t>(A_NDCL, d.NDm > 1 ? d.NDm : 1), ndvo = c.a<uint32_t>(A_NDVOFF, d.NDm + 1);
+    TPtr<uint16_t> ndv = c.a<uint16_t>(A_NDVAR, d.NDVm > 1 ? d.NDVm : 1);
+    TPtr<uint32_t> pver = c.nver(), cver = cc.nver();
     for (uint32_t s = 0; s < P.S; ++s) {
         // The child's nested info of a sample is a function of the parent's diplotype, k-mer-stats cache and own nested info of that sample:
         // nothing to do while the parent's version of them is the one this info was prepared from.
@@ -107,7 +107,7 @@ __device__ BT_NOINLINE void prepare_nested(Env env, uint32_t v_parent, uint32_t 
     }
 }
 
-__device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+__device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, TPtr<uint32_t> trace_row, bool tracing) {
     Env env = env_in;
     const bool swap = env.resident == 0xFFFFFFFFu && t.d->hot_bytes != 0;
     PROF_DECL;
@@ -126,11 +126,11 @@ __device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GPar
 }
 
 // VariantClusterGroup::estimateGenotypes + runGibbsSample (VariantClusterGroup.cpp:220-250), recursion unrolled on an explicit stack
-__device__ inline void group_sweep(const Env &env, const Tile &t, const GParams BT_CAS &P, bool collect, uint32_t nvert, uint32_t nsrc, SPtr<uint32_t, LANES> trace_row, bool tracing) {
+__device__ inline void group_sweep(const Env &env, const Tile &t, const GParams BT_CAS &P, bool collect, uint32_t nvert, uint32_t nsrc, TPtr<uint32_t> trace_row, bool tracing) {
     if (tracing)
         for (uint32_t i = 0; i < t.d->nvm * P.S; ++i) trace_row[i] = 0xFFFFFFFFu;
-    SPtr<uint32_t, LANES> sources = t.arr<uint32_t>(A_SOURCES), stack = t.arr<uint32_t>(A_STACK);
-    SPtr<uint8_t, LANES> gploidy = t.arr<uint8_t>(A_PLOIDY);
+    TPtr<uint32_t> sources = t.arr<uint32_t>(A_SOURCES), stack = t.arr<uint32_t>(A_STACK);
+    TPtr<uint8_t> gploidy = t.arr<uint8_t>(A_PLOIDY);
     for (uint32_t si = 0; si < nsrc; ++si) {
         const uint32_t sv = sources[si];
         {
@@ -168,17 +168,17 @@ __device__ inline void group_sweep(const Env &env, const Tile &t, const GParams 
 }
 
 struct TraceRow {
-    SPtr<uint32_t, LANES> row;
+    TPtr<uint32_t> row;
     bool on;
 };
 __device__ inline TraceRow trace_row_for(const Tile &t, const GParams BT_CAS &P, const TraceCfg &tr, uint32_t tile) {
-    TraceRow r{SPtr<uint32_t, LANES>{(uint32_t BT_GAS *)tr.buf, 0u}, false};
+    TraceRow r{TPtr<uint32_t>{(uint32_t BT_GAS *)tr.buf, 0u, 6u}, false};
     if (!tr.max_sweeps) return r;
     uint32_t *cnt = &tr.counter[(size_t)tile * LANES + t.lane];
     const uint32_t n = *cnt;
     if (n >= tr.max_sweeps) return r;
     *cnt = n + 1;
-    r.row = SPtr<uint32_t, LANES>{(uint32_t BT_GAS *)tr.buf, (uint32_t)(t.d->trace_base + (size_t)n * t.d->nvm * P.S * LANES) + t.lane};
+    r.row = TPtr<uint32_t>{(uint32_t BT_GAS *)tr.buf, (uint32_t)(t.d->trace_base + (size_t)n * t.d->nvm * P.S * LANES) + t.lane, 6u};
     r.on = true;
     return r;
 }
@@ -200,6 +200,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     if (!tile_thread_active(t.d->split, t.d->copies)) return;
     t.lane = tile_lane(t.d->split, t.d->copies);
     t.plane = t.lane + t.d->pool_lane0;
+    t.wsh = t.d->wsh;
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     // the extra copies of a narrow tile's groups only take part in the sampling operations (the others tally with atomics)
@@ -209,7 +210,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     // Narrow tiles (few groups + lockstep copies) are the launch's critical path: a handful of long sequential programs.  They take
     // issue priority over the 64-group tiles they share a SIMD with, which have plenty of peers to fill the gaps.
     if (t.d->prio) __builtin_amdgcn_s_setprio(3);
-    SPtr<uint32_t, LANES> gd = t.arr<uint32_t>(A_GDIMS);
+    TPtr<uint32_t> gd = t.arr<uint32_t>(A_GDIMS);
     if (!gd[3]) return;   // padding lane of the last tile
     const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
     // groups of ONE cluster keep that cluster's hot arrays in LDS for the whole launch; larger groups swap per vertex visit
@@ -270,7 +271,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
         for (uint32_t v = 0; v < nvert; ++v) {
             const Vx c = make_vx(t, v);
             const uint32_t nsu = c.sc()[SC_NSUB_U];
-            SPtr<uint32_t, LANES> usub = c.usub();
+            TPtr<uint32_t> usub = c.usub();
             for (uint32_t s = 0; s < P.S; ++s) {
                 const uint16_t h1 = c.dip()[2 * s], h2 = c.dip()[2 * s + 1];
                 for (uint32_t i = 0; i < nsu; ++i) {
@@ -288,13 +289,13 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
         for (uint32_t v = 0; v < nvert; ++v) make_vx(t, v).sc()[SC_CONSTRUCTED] = 0;
     } else if (op == OP_SETUP) {
         // mutable copies of the group structure (shuffled in place chain after chain, never restored)
-        SPtr<uint32_t, LANES> s0 = t.arr<uint32_t>(A_SOURCES0), s1 = t.arr<uint32_t>(A_SOURCES);
+        TPtr<uint32_t> s0 = t.arr<uint32_t>(A_SOURCES0), s1 = t.arr<uint32_t>(A_SOURCES);
         for (uint32_t i = 0; i < nsrc; ++i) s1[i] = s0[i];
         for (uint32_t v = 0; v < nvert; ++v) {
             const Vx c = make_vx(t, v);
-            SPtr<uint32_t, LANES> e0 = c.a<uint32_t>(A_EDGES0, t.d->NEm > 1 ? t.d->NEm : 1), e1 = c.edges();
+            TPtr<uint32_t> e0 = c.a<uint32_t>(A_EDGES0, t.d->NEm > 1 ? t.d->NEm : 1), e1 = c.edges();
             for (uint32_t i = 0, n = vx_ne(c); i < n; ++i) e1[i] = e0[i];
-            SPtr<uint32_t, LANES> dm = t.arr<uint32_t>(A_VDIMS, v * 8);   // dimensions the samplers read at every call: next to the state scalars
+            TPtr<uint32_t> dm = t.arr<uint32_t>(A_VDIMS, v * 8);   // dimensions the samplers read at every call: next to the state scalars
             SPtrF<uint32_t, LANES> sc = c.sc();
             sc[SC_H] = dm[0];
             sc[SC_V] = dm[1];

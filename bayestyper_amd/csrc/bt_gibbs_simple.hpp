@@ -16,16 +16,17 @@
 namespace bt {
 
 // lane-interleaved array in this wavefront's LDS block
+// (tiles of two-haplotype clusters are always 64 groups wide — TileDesc::simple requires it — so the row stride is a constant and
+// element offsets fold into the ds_* instructions)
 template <typename T>
 struct LdsArr {
     T BT_LAS *p;
-    uint32_t stride;
-    __device__ inline T BT_LAS &operator[](uint32_t i) const { return p[i * stride]; }
-    __device__ inline LdsArr<T> operator+(uint32_t i) const { return LdsArr<T>{p + i * stride, stride}; }
+    __device__ inline T BT_LAS &operator[](uint32_t i) const { return p[i * LANES]; }
+    __device__ inline LdsArr<T> operator+(uint32_t i) const { return LdsArr<T>{p + i * LANES}; }
 };
 template <typename T>
 __device__ inline LdsArr<T> lds_arr(const Tile &t, int arr) {
-    return LdsArr<T>{(T BT_LAS *)(bt_lds_raw + t.d->hoff[arr]) + t.lane, t.d->lds_stride};
+    return LdsArr<T>{(T BT_LAS *)(bt_lds_raw + t.d->hoff[arr]) + t.lane};
 }
 
 // std::unordered_set<uint> over the universe {0, 1}: both elements always sit in buckets of their own (13 buckets from the first
@@ -88,7 +89,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
     const Vx::UCPtr uc = c.ucache();   // LDS when the table is small, else HBM
     // the group's ploidy per sample is the cluster's (a root cluster without nesting: VariantClusterGroup.cpp:225-231)
     {
-        SPtr<uint8_t, LANES> gp = t.arr<uint8_t>(A_PLOIDY);
+        TPtr<uint8_t> gp = t.arr<uint8_t>(A_PLOIDY);
         for (uint32_t s = 0; s < S; ++s) {
             ploidy[s] = gp[s];
             nest_n[s] = 0;
@@ -112,7 +113,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
     for (uint32_t sweep = 0; sweep < n_sweeps; ++sweep) {
         // ---- trace row of this sweep ----
         bool tracing = false;
-        SPtr<uint32_t, LANES> trace_row{(uint32_t BT_GAS *)trace_buf, 0u};
+        TPtr<uint32_t> trace_row{(uint32_t BT_GAS *)trace_buf, 0u, 6u};
         if (trace_max) {
             uint32_t *cnt = &trace_counter[(size_t)tile * LANES + t.lane];
             const uint32_t n = *cnt;
@@ -251,7 +252,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
             } else {
                 const uint32_t n_obs = st.hap_count, plus_size = st.plus.n;
                 // cached simplex-size distribution (FrequencyDistribution.cpp:143-196,211-229): at most 3 - plus_size entries
-                SPtr<double, LANES> vec = c.simplex();
+                TPtr<double> vec = c.simplex();
                 const bool cached = d.scache_n && n_obs <= 2 * d.S && plus_size <= d.scache_p;
                 const uint32_t ci = cached ? (n_obs - 1) * d.scache_p + (plus_size - 1) : 0u;
                 if (cached) vec = c.scache() + ci * d.scache_len;

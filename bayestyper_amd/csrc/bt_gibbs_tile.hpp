@@ -149,6 +149,7 @@ struct TileDesc {
     uint32_t prio;                  // the tile's wavefronts raise their issue priority (narrow tiles: the launch's critical path)
     uint32_t pool_lane0;            // first lane of this tile in the pool block it shares with the neighbouring narrow tiles (0 for 64-lane tiles)
     uint32_t logged;                // single clusters without multicluster k-mers: collected sweeps are logged as runs and applied at the end of the chain
+    uint32_t wsh;                   // log2 of the tile's width W (power of two >= num_lanes): every array of the tile is interleaved over W lanes, in HBM and in LDS
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
 constexpr uint32_t EV_CAP = 8;            // logged runs per (cluster, sample) before the log is applied early
@@ -178,6 +179,7 @@ struct Tile {
     // read before any of them writes) — which costs nothing — and the phases that are data-parallel inside one group (the dense
     // table fill, the compact subset copies) are divided among the copies by `part`.
     uint32_t part, copies;
+    uint32_t wsh;        // TileDesc::wsh
     uint8_t *hot;        // this wavefront's LDS block (generic pointer) or nullptr
     uint32_t resident;   // vertex whose hot arrays currently live in LDS (0xFFFFFFFF: none)
     // hot-capable array: LDS when the vertex is resident, HBM otherwise; one code path through generic pointers
@@ -185,12 +187,12 @@ struct Tile {
     __device__ inline SPtrF<T, LANES> harr(int a, uint32_t v, uint32_t len) const {
         const uint32_t ho = d->hoff[a];
         if (hot != nullptr && ho != NOHOT && (resident == RESIDENT_ALL || v == resident))
-            return SPtrF<T, LANES>{(T *)(hot + (resident == RESIDENT_ALL ? v * d->hot_bytes : 0u) + ho), lane, d->lds_stride};
-        return SPtrF<T, LANES>{(T *)(uint8_t *)(base + d->off[a]), v * len * LANES + plane};
+            return SPtrF<T, LANES>{(T *)(hot + (resident == RESIDENT_ALL ? v * d->hot_bytes : 0u) + ho), lane, wsh};
+        return SPtrF<T, LANES>{(T *)(uint8_t *)(base + d->off[a]), ((v * len) << wsh) + plane, wsh};
     }
     template <typename T>
-    __device__ inline SPtr<T, LANES> arr(int a, uint32_t first = 0) const {
-        return SPtr<T, LANES>{(T BT_GAS *)(base + d->off[a]), first * LANES + plane};
+    __device__ inline TPtr<T> arr(int a, uint32_t first = 0) const {
+        return TPtr<T>{(T BT_GAS *)(base + d->off[a]), (first << wsh) + plane, wsh};
     }
 };
 
@@ -213,28 +215,28 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint32_t nu() const { return t.arr<uint32_t>(A_VDIMS, v * 8)[3]; }
     __device__ inline uint32_t cid() const { return t.arr<uint32_t>(A_VDIMS, v * 8)[7]; }
     template <typename T>
-    __device__ inline SPtr<T, LANES> a(int arr, uint32_t len) const { return t.arr<T>(arr, v * len); }
+    __device__ inline TPtr<T> a(int arr, uint32_t len) const { return t.arr<T>(arr, v * len); }
     template <typename T>
     struct RPtr {   // global-memory array with a run-time element stride
         T BT_GAS *base;
-        uint32_t off, stride;
-        __device__ inline T BT_GAS &operator[](uint32_t i) const { return base[off + i * stride]; }
-        __device__ inline RPtr<T> operator+(uint32_t i) const { return RPtr<T>{base, off + i * stride, stride}; }
+        uint32_t off, sh;
+        __device__ inline T BT_GAS &operator[](uint32_t i) const { return base[off + (i << sh)]; }
+        __device__ inline RPtr<T> operator+(uint32_t i) const { return RPtr<T>{base, off + (i << sh), sh}; }
     };
     template <typename T>
     struct FPtr {   // the same through a generic pointer (LDS or HBM)
         T *base;
-        uint32_t off, stride;
-        __device__ inline T &operator[](uint32_t i) const { return base[off + i * stride]; }
-        __device__ inline FPtr<T> operator+(uint32_t i) const { return FPtr<T>{base, off + i * stride, stride}; }
+        uint32_t off, sh;
+        __device__ inline T &operator[](uint32_t i) const { return base[off + (i << sh)]; }
+        __device__ inline FPtr<T> operator+(uint32_t i) const { return FPtr<T>{base, off + (i << sh), sh}; }
     };
     typedef FPtr<double> UCPtr;
     // the K x H multiplicity matrices of a narrow tile are per-lane contiguous too (they are the bulk of a large cluster's state)
     __device__ inline RPtr<uint8_t> mat(int arr, uint32_t rows) const {
         uint8_t BT_GAS *b = (uint8_t BT_GAS *)(t.base + d().off[arr]);
         const uint32_t w = d().mat_width, n = rows * d().Hm;
-        if (w) return RPtr<uint8_t>{b, (v * w + t.plane) * n, 1u};
-        return RPtr<uint8_t>{b, v * n * LANES + t.plane, LANES};
+        if (w) return RPtr<uint8_t>{b, (v * w + t.plane) * n, 0u};
+        return RPtr<uint8_t>{b, ((v * n) << t.wsh) + t.plane, t.wsh};
     }
     // inputs
     __device__ inline uint8_t M(uint32_t k, uint32_t h) const { return mat(A_M, d().Km)[(uint32_t)k * d().Hm + h]; }
@@ -246,7 +248,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint16_t kv_var(uint32_t e) const { return a<uint16_t>(A_KVVAR, d().NNZm)[e]; }
     __device__ inline bool kv_bit(uint32_t e, uint32_t h) const { return (a<uint32_t>(A_KVBITS, (uint32_t)d().NNZm * d().HWm)[(uint32_t)e * d().HWm + (h >> 5)] >> (h & 31u)) & 1u; }
     __device__ inline uint32_t hap_cell(uint32_t h, uint32_t var) const { return a<uint32_t>(A_HAPCELL, (uint32_t)d().Hm * d().Vm)[(uint32_t)h * d().Vm + var]; }
-    __device__ inline SPtr<double, LANES> astats_cell(uint32_t s, uint32_t cell) const { return a<double>(A_ASTATS, (uint32_t)d().S * d().Am * 12) + ((uint32_t)s * d().Am + cell) * 12; }
+    __device__ inline TPtr<double> astats_cell(uint32_t s, uint32_t cell) const { return a<double>(A_ASTATS, (uint32_t)d().S * d().Am * 12) + ((uint32_t)s * d().Am + cell) * 12; }
     __device__ inline uint16_t hap_allele(uint32_t h, uint32_t var) const { return a<uint16_t>(A_HAPAL, (uint32_t)d().Hm * d().Vm)[(uint32_t)h * d().Vm + var]; }
     __device__ inline uint32_t hn_off(uint32_t h) const { return a<uint32_t>(A_HNOFF, d().Hm + 1)[h]; }
     __device__ inline uint32_t hn_idx(uint32_t i) const { return a<uint32_t>(A_HNIDX, d().HNm)[i]; }
@@ -254,24 +256,24 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint8_t var_dep(uint32_t var) const { return a<uint8_t>(A_VARDEP, d().Vm)[var]; }
     __device__ inline uint32_t allele_base(uint32_t var) const { return a<uint32_t>(A_ALBASE, d().Vm + 1)[var]; }
     // state
-    __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)(v * 2 + g) * LANES + t.plane) * MT_PAD; }
+    __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)((v * 2 + g) << t.wsh) + t.plane) * MT_PAD; }
     __device__ inline SPtrF<uint32_t, LANES> ring(uint32_t g) const { return t.harr<uint32_t>(A_RING, v, d().ring_len) + (g ? d().ring_cap[0] + MT_RING_HDR : 0u); }
     __device__ inline MtRing rng(uint32_t g) const { return mt_ring_open(mt(g), ring(g), d().ring_cap[g]); }
     __device__ inline void rng_seed(uint32_t g, uint32_t seed) const { mt_ring_seed(mt(g), ring(g), d().ring_cap[g], seed); }
     __device__ inline SPtrF<uint32_t, LANES> sc() const { return t.harr<uint32_t>(A_SC, v, SC_COUNT); }
-    __device__ inline SPtr<uint32_t, LANES> uniq() const { return a<uint32_t>(A_UNIQ, d().NUm); }
-    __device__ inline SPtr<uint32_t, LANES> multi() const { return a<uint32_t>(A_MULTI, d().NMm); }
-    __device__ inline SPtr<uint32_t, LANES> usub() const { return a<uint32_t>(A_USUB, d().NUm); }
-    __device__ inline SPtr<uint32_t, LANES> msub() const { return a<uint32_t>(A_MSUB, d().NMm); }
-    __device__ inline SPtr<uint8_t, LANES> smm() const { return a<uint8_t>(A_SMM, (uint32_t)d().NMm * d().S); }
+    __device__ inline TPtr<uint32_t> uniq() const { return a<uint32_t>(A_UNIQ, d().NUm); }
+    __device__ inline TPtr<uint32_t> multi() const { return a<uint32_t>(A_MULTI, d().NMm); }
+    __device__ inline TPtr<uint32_t> usub() const { return a<uint32_t>(A_USUB, d().NUm); }
+    __device__ inline TPtr<uint32_t> msub() const { return a<uint32_t>(A_MSUB, d().NMm); }
+    __device__ inline TPtr<uint8_t> smm() const { return a<uint8_t>(A_SMM, (uint32_t)d().NMm * d().S); }
     __device__ inline SPtrF<uint16_t, LANES> dip() const { return t.harr<uint16_t>(A_DIP, v, 2 * d().S); }
     __device__ inline SPtrF<double, LANES> freq() const { return t.harr<double>(A_FREQ, v, d().Hm); }
     __device__ inline RPtr<uint8_t> subm() const { return mat(A_SUBM, d().NUm); }
-    __device__ inline SPtr<uint8_t, LANES> subcnt() const { return a<uint8_t>(A_SUBCNT, d().NUm * d().S); }
-    __device__ inline SPtr<uint8_t, LANES> subic() const { return a<uint8_t>(A_SUBIC, d().NUm * 2); }
-    __device__ inline SPtr<uint32_t, LANES> skv_off() const { return a<uint32_t>(A_SKVOFF, d().NUm + 1); }
-    __device__ inline SPtr<uint16_t, LANES> skv_var() const { return a<uint16_t>(A_SKVVAR, d().NNZm > 1 ? d().NNZm : 1); }
-    __device__ inline SPtr<uint32_t, LANES> skv_bits() const { return a<uint32_t>(A_SKVBITS, (d().NNZm > 1 ? d().NNZm : 1) * d().HWm); }
+    __device__ inline TPtr<uint8_t> subcnt() const { return a<uint8_t>(A_SUBCNT, d().NUm * d().S); }
+    __device__ inline TPtr<uint8_t> subic() const { return a<uint8_t>(A_SUBIC, d().NUm * 2); }
+    __device__ inline TPtr<uint32_t> skv_off() const { return a<uint32_t>(A_SKVOFF, d().NUm + 1); }
+    __device__ inline TPtr<uint16_t> skv_var() const { return a<uint16_t>(A_SKVVAR, d().NNZm > 1 ? d().NNZm : 1); }
+    __device__ inline TPtr<uint32_t> skv_bits() const { return a<uint32_t>(A_SKVBITS, (d().NNZm > 1 ? d().NNZm : 1) * d().HWm); }
     __device__ inline SPtrF<double, LANES> ksc_tmp() const { return t.harr<double>(A_KSCTMP, v, 2 * d().Vm * 4); }
     __device__ inline SPtrF<double, LANES> logf() const { return t.harr<double>(A_LOGF, v, d().Hm); }
     __device__ inline SPtrF<uint32_t, LANES> obs() const { return t.harr<uint32_t>(A_OBS, v, d().Hm); }
@@ -280,63 +282,63 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     typedef USetP<SPtrF<uint32_t, LANES>> HSet;
     __device__ inline HSet zero_set() const { return HSet{t.harr<uint32_t>(A_ZHDR, v, 4), t.harr<uint32_t>(A_ZBKT, v, d().Bcap), unext(), d().Bcap}; }
     __device__ inline HSet plus_set() const { return HSet{t.harr<uint32_t>(A_PHDR, v, 4), t.harr<uint32_t>(A_PBKT, v, d().Bcap), unext(), d().Bcap}; }
-    __device__ inline SPtr<uint32_t, LANES> hvcount() const { return a<uint32_t>(A_HVCOUNT, (uint32_t)d().Hm * d().Vm); }
+    __device__ inline TPtr<uint32_t> hvcount() const { return a<uint32_t>(A_HVCOUNT, (uint32_t)d().Hm * d().Vm); }
     // the [S][D] table of unique-k-mer sums.  Wide tiles: lane-interleaved.  Narrow tiles (whose lanes would leave most of every
     // 64-lane row unused): each lane's table contiguous, so a tile pays for its own lanes only and even 256 candidates x 30 samples
     // (10^6 entries, 8 MB) stay dense
     __device__ inline UCPtr ucache() const {
         const uint32_t ho = d().hoff[A_UCACHE];
         if (t.hot != nullptr && ho != NOHOT && (t.resident == RESIDENT_ALL || v == t.resident))   // a table of a few entries lives in LDS
-            return UCPtr{(double *)(t.hot + (t.resident == RESIDENT_ALL ? v * d().hot_bytes : 0u) + ho), t.lane, d().lds_stride};
+            return UCPtr{(double *)(t.hot + (t.resident == RESIDENT_ALL ? v * d().hot_bytes : 0u) + ho), t.lane, t.wsh};
         double *b = (double *)(uint8_t *)(t.base + d().off[A_UCACHE]);
         const uint32_t w = d().uc_width;
-        if (w) return UCPtr{b, (v * w + t.plane) * d().cache_entries, 1u};
-        return UCPtr{b, v * d().cache_entries * LANES + t.plane, LANES};
+        if (w) return UCPtr{b, (v * w + t.plane) * d().cache_entries, 0u};
+        return UCPtr{b, ((v * d().cache_entries) << t.wsh) + t.plane, t.wsh};
     }
-    __device__ inline SPtr<uint32_t, LANES> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
+    __device__ inline TPtr<uint32_t> uctag() const { return a<uint32_t>(A_UCTAG, d().cache_mode == 1 ? d().cache_entries : 1); }
     __device__ inline SPtrF<double, LANES> cum() const { return t.harr<double>(A_CUM, v, (d().D2m > 1 ? d().D2m : 1) * (d().teams > 1 ? d().teams : 1)); }
     __device__ inline SPtrF<uint16_t, LANES> nzlist() const { return t.harr<uint16_t>(A_NZLIST, v, d().Hm); }
-    __device__ inline SPtr<double, LANES> simplex() const { return a<double>(A_SIMPLEX, d().Hm + 1); }
-    __device__ inline SPtr<double, LANES> scache() const { return a<double>(A_SCACHE, (uint32_t)(d().scache_n ? d().scache_n : 1) * (d().scache_len ? d().scache_len : 1)); }
-    __device__ inline SPtr<uint32_t, LANES> sclen() const { return a<uint32_t>(A_SCLEN, d().scache_n > 1 ? d().scache_n : 1); }
-    __device__ inline SPtr<double, LANES> ksc(uint32_t s, uint32_t which, uint32_t var) const {
+    __device__ inline TPtr<double> simplex() const { return a<double>(A_SIMPLEX, d().Hm + 1); }
+    __device__ inline TPtr<double> scache() const { return a<double>(A_SCACHE, (uint32_t)(d().scache_n ? d().scache_n : 1) * (d().scache_len ? d().scache_len : 1)); }
+    __device__ inline TPtr<uint32_t> sclen() const { return a<uint32_t>(A_SCLEN, d().scache_n > 1 ? d().scache_n : 1); }
+    __device__ inline TPtr<double> ksc(uint32_t s, uint32_t which, uint32_t var) const {
         return a<double>(A_KSC, (uint32_t)d().S * 2 * d().Vm * 4) + (((uint32_t)s * 2 + which) * d().Vm + var) * 4;
     }
     __device__ inline SPtrF<uint8_t, LANES> ksc_upd() const { return t.harr<uint8_t>(A_KSCUPD, v, d().S); }
-    __device__ inline SPtr<uint32_t, LANES> dip_keys() const { return a<uint32_t>(A_DIPKEYS, d().dip_cap); }
-    __device__ inline SPtr<uint32_t, LANES> dip_freq() const { return a<uint32_t>(A_DIPFREQ, (uint32_t)d().dip_cap * d().S); }
-    __device__ inline SPtr<double, LANES> astats(uint32_t s, uint32_t var, uint32_t al) const {
+    __device__ inline TPtr<uint32_t> dip_keys() const { return a<uint32_t>(A_DIPKEYS, d().dip_cap); }
+    __device__ inline TPtr<uint32_t> dip_freq() const { return a<uint32_t>(A_DIPFREQ, (uint32_t)d().dip_cap * d().S); }
+    __device__ inline TPtr<double> astats(uint32_t s, uint32_t var, uint32_t al) const {
         return a<double>(A_ASTATS, (uint32_t)d().S * d().Am * 12) + ((uint32_t)s * d().Am + allele_base(var) + al) * 12;
     }
     __device__ inline SPtrF<uint8_t, LANES> nest_ploidy() const { return t.harr<uint8_t>(A_NESTPL, v, d().S); }
     __device__ inline SPtrF<uint8_t, LANES> nest_n() const { return t.harr<uint8_t>(A_NESTN, v, d().S); }
-    __device__ inline SPtr<uint32_t, LANES> ksc_key(uint32_t s) const { return a<uint32_t>(A_KSCKEY, (uint32_t)d().S * (KSC_WAYS + 1u)) + (uint32_t)s * (KSC_WAYS + 1u); }
-    __device__ inline SPtr<double, LANES> ksc_data(uint32_t s, uint32_t e) const {
+    __device__ inline TPtr<uint32_t> ksc_key(uint32_t s) const { return a<uint32_t>(A_KSCKEY, (uint32_t)d().S * (KSC_WAYS + 1u)) + (uint32_t)s * (KSC_WAYS + 1u); }
+    __device__ inline TPtr<double> ksc_data(uint32_t s, uint32_t e) const {
         return a<double>(A_KSCDATA, (uint32_t)d().S * KSC_WAYS * 2 * d().Vm * 4) + ((uint32_t)s * KSC_WAYS + e) * 2 * d().Vm * 4;
     }
-    __device__ inline SPtr<uint32_t, LANES> evlog(uint32_t s) const { return a<uint32_t>(A_EVLOG, (uint32_t)d().S * (2u * EV_CAP + 1u)) + (uint32_t)s * (2u * EV_CAP + 1u); }
+    __device__ inline TPtr<uint32_t> evlog(uint32_t s) const { return a<uint32_t>(A_EVLOG, (uint32_t)d().S * (2u * EV_CAP + 1u)) + (uint32_t)s * (2u * EV_CAP + 1u); }
     __device__ inline SPtrF<uint8_t, LANES> evn() const { return t.harr<uint8_t>(A_EVN, v, d().S); }
-    __device__ inline SPtr<uint32_t, LANES> nver() const { return a<uint32_t>(A_NVER, (uint32_t)d().S * 2); }
-    __device__ inline SPtr<double, LANES> pend_nest(uint32_t s) const { return a<double>(A_PENDNEST, (uint32_t)d().S * 8) + (uint32_t)s * 8; }
-    __device__ inline SPtr<double, LANES> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
-    __device__ inline SPtr<uint32_t, LANES> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
-    __device__ inline SPtr<uint8_t, LANES> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
-    __device__ inline SPtr<double, LANES> mcache() const { return a<double>(A_MCACHE, d().cache_entries); }
-    __device__ inline SPtr<uint32_t, LANES> mctag() const { return a<uint32_t>(A_MCTAG, d().cache_entries); }
-    __device__ inline SPtr<uint32_t, LANES> mcgen() const { return a<uint32_t>(A_MCGEN, d().cache_entries); }
+    __device__ inline TPtr<uint32_t> nver() const { return a<uint32_t>(A_NVER, (uint32_t)d().S * 2); }
+    __device__ inline TPtr<double> pend_nest(uint32_t s) const { return a<double>(A_PENDNEST, (uint32_t)d().S * 8) + (uint32_t)s * 8; }
+    __device__ inline TPtr<double> nest_stats(uint32_t s, uint32_t j) const { return a<double>(A_NESTST, (uint32_t)d().S * 8) + ((uint32_t)s * 2 + j) * 4; }
+    __device__ inline TPtr<uint32_t> edges() const { return a<uint32_t>(A_EDGES, d().NEm > 1 ? d().NEm : 1); }
+    __device__ inline TPtr<uint8_t> cover_rows() const { return a<uint8_t>(A_COVER, d().Km); }
+    __device__ inline TPtr<double> mcache() const { return a<double>(A_MCACHE, d().cache_entries); }
+    __device__ inline TPtr<uint32_t> mctag() const { return a<uint32_t>(A_MCTAG, d().cache_entries); }
+    __device__ inline TPtr<uint32_t> mcgen() const { return a<uint32_t>(A_MCGEN, d().cache_entries); }
     __device__ inline SPtrF<uint32_t, LANES> mgen() const { return t.harr<uint32_t>(A_MGEN, v, d().S); }
-    __device__ inline SPtr<uint8_t, LANES> oth() const { return a<uint8_t>(A_OTH, d().NMm * d().S); }
-    __device__ inline SPtr<uint8_t, LANES> msubm() const { return a<uint8_t>(A_MSUBM, (d().NMm > 1 ? d().NMm : 1) * d().Hm); }
-    __device__ inline SPtr<uint8_t, LANES> msubc() const { return a<uint8_t>(A_MSUBC, (d().NMm > 1 ? d().NMm : 1) * d().S); }
-    __device__ inline SPtr<uint8_t, LANES> msubic() const { return a<uint8_t>(A_MSUBIC, (d().NMm > 1 ? d().NMm : 1) * 2); }
-    __device__ inline SPtr<uint32_t, LANES> msubsh() const { return a<uint32_t>(A_MSUBSH, d().NMm > 1 ? d().NMm : 1); }
+    __device__ inline TPtr<uint8_t> oth() const { return a<uint8_t>(A_OTH, d().NMm * d().S); }
+    __device__ inline TPtr<uint8_t> msubm() const { return a<uint8_t>(A_MSUBM, (d().NMm > 1 ? d().NMm : 1) * d().Hm); }
+    __device__ inline TPtr<uint8_t> msubc() const { return a<uint8_t>(A_MSUBC, (d().NMm > 1 ? d().NMm : 1) * d().S); }
+    __device__ inline TPtr<uint8_t> msubic() const { return a<uint8_t>(A_MSUBIC, (d().NMm > 1 ? d().NMm : 1) * 2); }
+    __device__ inline TPtr<uint32_t> msubsh() const { return a<uint32_t>(A_MSUBSH, d().NMm > 1 ? d().NMm : 1); }
     __device__ inline SPtrF<uint32_t, LANES> pend() const { return t.harr<uint32_t>(A_PEND, v, d().S); }
     __device__ inline SPtrF<uint16_t, LANES> pend_dip() const { return t.harr<uint16_t>(A_PENDDIP, v, 2 * d().S); }
     __device__ inline SPtrF<uint8_t, LANES> pend_valid() const { return t.harr<uint8_t>(A_PENDVALID, v, d().S); }
     __device__ inline double &fnd_saved() const { return t.harr<double>(A_FNDSAVED, v, 1)[0]; }
     __device__ inline double BT_GAS &sparsity() const { return a<double>(A_SPARSITY, 1)[0]; }
     __device__ inline NormalState fnd() const { return NormalState{&fnd_saved(), &sc()[SC_FND_AVAIL]}; }   // `available` may live in LDS
-    __device__ inline SPtr<uint8_t, LANES> shared_mult() const { return t.arr<uint8_t>(A_SHMULT); }
+    __device__ inline TPtr<uint8_t> shared_mult() const { return t.arr<uint8_t>(A_SHMULT); }
 };
 
 // A tile is worked on by `split` wavefronts (TileDesc::split, chosen per tile by the host): wavefront w owns the 64/split
@@ -367,6 +369,7 @@ __device__ inline Tile make_tile(const Env &e_in) {
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = tile_lane(t.d->split, t.d->copies);
     t.plane = t.lane + t.d->pool_lane0;
+    t.wsh = t.d->wsh;
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     t.resident = e_in.resident;   // per lane: lanes of a tile may be at different vertices of their groups
@@ -393,9 +396,9 @@ template <typename T>
 __device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len, bool to_lds, uint32_t lds_vertex_off, uint32_t live = 0xFFFFFFFFu) {
     const uint32_t ho = t.d->hoff[arr];
     if (ho == NOHOT) return;
-    const uint32_t LS = t.d->lds_stride;
+    const uint32_t sh = t.wsh;   // the rows have the tile's width in LDS and in HBM
     T BT_LAS *l = (T BT_LAS *)(bt_lds_raw + lds_vertex_off + ho) + t.lane;   // explicit LDS pointer: the copies of different arrays can overlap (no aliasing with HBM)
-    T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + v * len * LANES + t.plane;
+    T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + ((v * len) << sh) + t.plane;
     // eight elements in flight per step (the copy is latency-bound: one wavefront, one memory round trip per step)
     uint32_t i = 0;
     len = live < len ? live : len;   // (the vertex stride above used the full row count)
@@ -404,20 +407,20 @@ __device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len
         for (; i + U <= len; i += U) {
             T tmp[U];
 #pragma unroll
-            for (int q = 0; q < U; ++q) tmp[q] = g[(i + q) * LANES];
+            for (int q = 0; q < U; ++q) tmp[q] = g[(i + q) << sh];
 #pragma unroll
-            for (int q = 0; q < U; ++q) l[(i + q) * LS] = tmp[q];
+            for (int q = 0; q < U; ++q) l[(i + q) << sh] = tmp[q];
         }
-        for (; i < len; ++i) l[i * LS] = g[i * LANES];
+        for (; i < len; ++i) l[i << sh] = g[i << sh];
     } else {
         for (; i + U <= len; i += U) {
             T tmp[U];
 #pragma unroll
-            for (int q = 0; q < U; ++q) tmp[q] = l[(i + q) * LS];
+            for (int q = 0; q < U; ++q) tmp[q] = l[(i + q) << sh];
 #pragma unroll
-            for (int q = 0; q < U; ++q) g[(i + q) * LANES] = tmp[q];
+            for (int q = 0; q < U; ++q) g[(i + q) << sh] = tmp[q];
         }
-        for (; i < len; ++i) g[i * LANES] = l[i * LS];
+        for (; i < len; ++i) g[i << sh] = l[i << sh];
     }
 }
 __device__ inline uint32_t uniform_tile_hot_bytes(const Env &e) {
@@ -562,7 +565,7 @@ __device__ inline void freq_reset(const Vx &c) {
 // returns the cover size; uses `rng` (freshly seeded by the caller), cover_rows, obs (column sums), nzlist
 template <class G>
 __device__ inline uint32_t sparsity_cover(const Vx &c, G &rng) {
-    SPtr<uint8_t, LANES> rows = c.cover_rows();
+    TPtr<uint8_t> rows = c.cover_rows();
     SPtrF<uint32_t, LANES> obs = c.obs();
     SPtrF<uint16_t, LANES> nzl = c.nzlist();
     const uint32_t Hm = c.d().Hm, H = c.H;
@@ -633,7 +636,7 @@ __device__ BT_NOINLINE void genotyper_construct(Env env, uint32_t vtx, uint32_t 
     for (uint32_t i = 0; i < SC_STATE_COUNT; ++i) sc[i] = 0;
     // a (re)built genotyper starts from the k-mer index lists in first-seen order (they are shuffled in place per chain)
     {
-        SPtr<uint32_t, LANES> u0 = c.a<uint32_t>(A_UNIQ0, d.NUm), u = c.uniq(), m0 = c.a<uint32_t>(A_MULTI0, d.NMm), m = c.multi();
+        TPtr<uint32_t> u0 = c.a<uint32_t>(A_UNIQ0, d.NUm), u = c.uniq(), m0 = c.a<uint32_t>(A_MULTI0, d.NMm), m = c.multi();
         for (uint32_t i = 0, nu = c.nu(); i < nu; ++i) u[i] = u0[i];
         for (uint32_t i = 0; i < c.nm; ++i) m[i] = m0[i];
     }
@@ -651,15 +654,15 @@ __device__ BT_NOINLINE void genotyper_construct(Env env, uint32_t vtx, uint32_t 
     }
     {
         const uint32_t A = c.t.arr<uint32_t>(A_VDIMS2, c.v * 2)[0];
-        SPtr<double, LANES> as = c.a<double>(A_ASTATS, (uint32_t)d.S * d.Am * 12);
+        TPtr<double> as = c.a<double>(A_ASTATS, (uint32_t)d.S * d.Am * 12);
         for (size_t s = 0; s < P.S; ++s)
             for (size_t i = 0; i < (uint32_t)A * 12; ++i) as[s * d.Am * 12 + i] = 0;
-        SPtr<double, LANES> k = c.a<double>(A_KSC, (uint32_t)d.S * 2 * d.Vm * 4);
+        TPtr<double> k = c.a<double>(A_KSC, (uint32_t)d.S * 2 * d.Vm * 4);
         for (size_t i = 0; i < (uint32_t)P.S * 2 * d.Vm * 4; ++i) k[i] = 0;
-        SPtr<uint32_t, LANES> dk = c.dip_keys(), df = c.dip_freq();
+        TPtr<uint32_t> dk = c.dip_keys(), df = c.dip_freq();
         for (uint32_t i = 0; i < d.dip_cap; ++i) dk[i] = 0;
         for (size_t i = 0; i < (uint32_t)d.dip_cap * P.S; ++i) df[i] = 0;
-        SPtr<uint32_t, LANES> sl = c.sclen();
+        TPtr<uint32_t> sl = c.sclen();
         for (uint32_t i = 0; i < d.scache_n; ++i) sl[i] = 0;
     }
     // SparsityEstimator(prng_seed), then (Sparse)FrequencyDistribution(.., prng_seed) with a fresh generator
@@ -703,7 +706,7 @@ __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool al
         // then computed on demand like the reference does
         c.sc()[SC_UC_DIRTY] = (!all_copies_run && d.cache_entries > 16384u) ? 2u : 1u;
     } else if (d.cache_mode == 1) {
-        SPtr<uint32_t, LANES> tg = c.uctag();
+        TPtr<uint32_t> tg = c.uctag();
         const uint32_t sub = all_copies_run ? d.cache_entries / c.t.copies : d.cache_entries;
         for (uint32_t i = all_copies_run ? c.t.part * sub : 0u, e = i + sub; i < e; ++i) tg[i] = 0;
     }
@@ -712,9 +715,9 @@ __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool al
 // ---- VariantClusterHaplotypes::sampleKmerSubset (+ isMaxHaplotypeVariantKmer) (VariantClusterHaplotypes.cpp:110-177) ----
 __device__ inline bool is_max_hv_kmer(const Vx &c, uint32_t k, uint32_t maxk) {
     bool is_max = true;
-    SPtr<uint32_t, LANES> hv = c.hvcount();
+    TPtr<uint32_t> hv = c.hvcount();
     const uint32_t Vm = c.d().Vm, HWm = c.d().HWm, HW = (c.H + 31) / 32;
-    SPtr<uint32_t, LANES> bits = c.a<uint32_t>(A_KVBITS, (uint32_t)c.d().NNZm * HWm);
+    TPtr<uint32_t> bits = c.a<uint32_t>(A_KVBITS, (uint32_t)c.d().NNZm * HWm);
     for (uint32_t e = c.kv_off(k), e1 = c.kv_off(k + 1); e < e1; ++e) {
         const uint32_t var = c.kv_var(e);
         for (uint32_t w = 0; w < HW; ++w) {
@@ -746,12 +749,12 @@ __device__ inline bool is_max_hv_kmer(const Vx &c, uint32_t k, uint32_t maxk) {
 }
 __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) {
     const uint32_t Vm = c.d().Vm;
-    SPtr<uint32_t, LANES> hv = c.hvcount();
+    TPtr<uint32_t> hv = c.hvcount();
     for (uint32_t h = 0; h < c.H; ++h)
         for (uint32_t v = 0; v < c.V; ++v) hv[(uint32_t)h * Vm + v] = 0;
     uint32_t nsu = 0, nsm = 0;
     MtRing rng = c.rng(0);
-    SPtr<uint32_t, LANES> uniq = c.uniq(), usub = c.usub(), multi = c.multi(), msub = c.msub();
+    TPtr<uint32_t> uniq = c.uniq(), usub = c.usub(), multi = c.multi(), msub = c.msub();
     PROF_DECL;
     // The generator is consumed exactly as the reference does (shuffle, one Bernoulli draw per k-mer; unique list, then the
     // multicluster list), but the isMaxHaplotypeVariantKmer filter — which draws nothing — runs afterwards over the selected
@@ -781,9 +784,9 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
         // walks plain arrays (index i, no k-mer indirection), so its loads are independent and coalesce across the wavefront
         const uint32_t Hm = c.d().Hm;
         const Vx::RPtr<uint8_t> sm = c.subm();
-        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
-        SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits();
-        SPtr<uint16_t, LANES> sv = c.skv_var();
+        TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
+        TPtr<uint32_t> so = c.skv_off(), sb = c.skv_bits();
+        TPtr<uint16_t> sv = c.skv_var();
         const uint32_t HWm = c.d().HWm, HW = (c.H + 31) / 32;
         uint32_t ne = 0;
         so[0] = 0;
@@ -821,8 +824,8 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
     {
         // the same for the multicluster subset k-mers (multi_refresh / multi_log_prob / updateMulticlusterDiplotypeLogProb inputs)
         const uint32_t Hm = c.d().Hm;
-        SPtr<uint8_t, LANES> mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
-        SPtr<uint32_t, LANES> msh = c.msubsh();
+        TPtr<uint8_t> mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
+        TPtr<uint32_t> msh = c.msubsh();
         for (uint32_t i = c.t.part; i < nsm; i += c.t.copies) {
             const uint32_t k = msub[i];
             for (uint32_t h = 0; h < c.H; ++h) mm[i * Hm + h] = c.M(k, h);
@@ -837,7 +840,7 @@ __device__ inline void sample_kmer_subset(const Vx &c, const GParams BT_CAS &P) 
     SPtrF<uint32_t, LANES> sc = c.sc();
     sc[SC_NSUB_U] = nsu;
     sc[SC_NSUB_M] = nsm;
-    SPtr<uint8_t, LANES> smm = c.smm(), oth = c.oth();
+    TPtr<uint8_t> smm = c.smm(), oth = c.oth();
     for (uint32_t i = 0; i < nsm * P.S; ++i) {
         smm[i] = 0;
         oth[i] = 0;
@@ -887,7 +890,7 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
     {
         const uint32_t Hm = d.Hm, S = P.S;
         const Vx::RPtr<uint8_t> sm = c.subm();
-        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
+        TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
         const bool two = h2 != NOHAP;
         uint32_t i = 0;
         // eight k-mers per step: all loads of a step are issued before the first table lookup; the sum itself stays in subset order
@@ -933,7 +936,7 @@ __device__ BT_NOINLINE void fill_unique_cache(Env env, uint32_t vtx) {
     const uint32_t nsub = c.sc()[SC_NSUB_U];
     const uint32_t Hm = d.Hm, S = P.S, H = c.H;
     const Vx::RPtr<uint8_t> sm = c.subm();
-        SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
+        TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
     const Vx::UCPtr uc = c.ucache();
     for (uint32_t s = 0; s < S; ++s) {
         const uint8_t gender = P.gender[s];
@@ -1008,15 +1011,15 @@ __device__ BT_NOINLINE void fill_unique_cache(Env env, uint32_t vtx) {
 // is generation-stamped per sample: multi_refresh() compares the other clusters' contribution of every subset k-mer with a
 // snapshot and bumps the sample's generation when anything moved, which invalidates that sample's entries in O(1).  A hit
 // returns exactly the direct sum a miss would compute.
-__device__ inline uint8_t msub_dip_mult(SPtr<uint8_t, LANES> mm, uint32_t Hm, uint32_t i, uint16_t h1, uint16_t h2) {
+__device__ inline uint8_t msub_dip_mult(TPtr<uint8_t> mm, uint32_t Hm, uint32_t i, uint16_t h1, uint16_t h2) {
     uint8_t m = 0;
     if (h1 != NOHAP) m = (uint8_t)(m + mm[i * Hm + h1]);
     if (h2 != NOHAP) m = (uint8_t)(m + mm[i * Hm + h2]);
     return m;
 }
 __device__ inline void multi_refresh(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint16_t p1, uint16_t p2, uint32_t nsub_m) {
-    SPtr<uint8_t, LANES> oth = c.oth(), shm = c.shared_mult(), mm = c.msubm(), mcn = c.msubc();
-    SPtr<uint32_t, LANES> msh = c.msubsh();
+    TPtr<uint8_t> oth = c.oth(), shm = c.shared_mult(), mm = c.msubm(), mcn = c.msubc();
+    TPtr<uint32_t> msh = c.msubsh();
     const uint32_t Hm = c.d().Hm;
     bool moved = false;
     for (uint32_t sub = 0; sub < nsub_m; ++sub) {
@@ -1035,7 +1038,7 @@ __device__ inline void multi_refresh(const Vx &c, const GParams BT_CAS &P, uint3
 // read once and the candidates' multiplicity rows and table lookups are independent loads.  Sums stay in subset order.
 __device__ inline void multi_log_prob_block(const Vx &c, const GParams BT_CAS &P, uint32_t s, const uint16_t (&ha)[8], const uint16_t (&hb)[8], const bool (&need)[8],
                                             uint32_t nsub_m, double (&out)[8]) {
-    SPtr<uint8_t, LANES> oth = c.oth(), mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
+    TPtr<uint8_t> oth = c.oth(), mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
     const uint32_t Hm = c.d().Hm;
     const uint8_t gender = P.gender[s];
     double acc[8];
@@ -1081,7 +1084,7 @@ __device__ inline void dip_table_add(const Vx &c, const GParams BT_CAS &P, uint1
     // which no other key + 1 can equal because haplotype indices are < 0xFFFE
     const uint32_t want = key == 0xFFFFFFFFu ? 0xFFFFFFFFu : key + 1u;
     const uint32_t cap = c.d().dip_cap, mask = cap - 1u;
-    SPtr<uint32_t, LANES> keys = c.dip_keys(), freq = c.dip_freq();
+    TPtr<uint32_t> keys = c.dip_keys(), freq = c.dip_freq();
     uint32_t slot = (key * 2654435761u) & mask;
     for (uint32_t probes = 0; probes < cap; ++probes) {
         const uint32_t tag = keys[slot];
@@ -1104,9 +1107,9 @@ __device__ inline void dip_table_add(const Vx &c, const GParams BT_CAS &P, uint1
 __device__ inline void update_multicluster_multiplicities(const Vx &c, const GParams BT_CAS &P, uint16_t h1, uint16_t h2, uint16_t p1, uint16_t p2, uint32_t s, uint32_t nsub_m) {
     if (h1 != p1 || h2 != p2) c.ksc_upd()[s] = 1;
     if (c.nm == 0) return;
-    SPtr<uint8_t, LANES> shm = c.shared_mult();
+    TPtr<uint8_t> shm = c.shared_mult();
     if (h1 != p1 || h2 != p2) {
-        SPtr<uint32_t, LANES> multi = c.multi();
+        TPtr<uint32_t> multi = c.multi();
         for (uint32_t i = 0; i < c.nm; ++i) {
             const uint32_t k = multi[i];
             const uint8_t cur = dip_mult(c, k, h1, h2), pre = dip_mult(c, k, p1, p2);
@@ -1119,8 +1122,8 @@ __device__ inline void update_multicluster_multiplicities(const Vx &c, const GPa
             }
         }
     }
-    SPtr<uint8_t, LANES> smm = c.smm(), mm = c.msubm(), mcn = c.msubc();
-    SPtr<uint32_t, LANES> msh = c.msubsh();
+    TPtr<uint8_t> smm = c.smm(), mm = c.msubm(), mcn = c.msubc();
+    TPtr<uint32_t> msh = c.msubsh();
     const uint32_t Hm = c.d().Hm;
     bool changed = false;
     for (uint32_t s0 = 0; s0 < nsub_m; s0 += 8) {   // eight subset k-mers per step: all loads of a step first (the stores to smm would serialise them)
@@ -1190,7 +1193,7 @@ __device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, ui
     // nested sources (the same for every variant)
     double ncnt[2] = {0, 0}, nf[2] = {0, 0}, nm[2] = {0, 0};
     {
-        SPtr<double, LANES> q = c.pend_nest(s);
+        TPtr<double> q = c.pend_nest(s);
         for (uint32_t j = 0; j < 2u; ++j)
             if (j < nn) {
                 ncnt[j] = q[4 * j];
@@ -1226,13 +1229,13 @@ __device__ inline void replay_collected(const Vx &c, const GParams BT_CAS &P, ui
             v1[b] = v2[b] = 0;
             en1[b] = en2[b] = false;
             if (ok1) {
-                SPtr<double, LANES> q = c.ksc(s, 0, d1[b] & 0xFFFFu);
+                TPtr<double> q = c.ksc(s, 0, d1[b] & 0xFFFFu);
                 const double cnt = q[0], val = q[st[b]];
                 v1[b] = val;
                 en1[b] = st[b] == 0 || cnt != 0.0;
             }
             if (ok2) {
-                SPtr<double, LANES> q = c.ksc(s, 1, d2[b] & 0xFFFFu);
+                TPtr<double> q = c.ksc(s, 1, d2[b] & 0xFFFFu);
                 const double cnt = q[0], val = q[st[b]];
                 v2[b] = val;
                 en2[b] = st[b] == 0 || cnt != 0.0;
@@ -1304,7 +1307,7 @@ __device__ inline void rebuild_kmer_stats_cache(const Vx &c, const GParams BT_CA
     // The accumulators' state after the unique k-mers of the chain's subset is a pure function of (sample, diplotype) until the next
     // chain: the last few are kept (chains move between a handful of diplotypes), a hit skips the 2 V passes over the unique subset.
     const uint32_t dkey = (uint32_t)h1 | ((uint32_t)h2 << 16);
-    SPtr<uint32_t, LANES> kk = c.ksc_key(s);
+    TPtr<uint32_t> kk = c.ksc_key(s);
     uint32_t hit_way = KSC_WAYS, victim = 0;
     {
         uint32_t keys[KSC_WAYS];
@@ -1316,9 +1319,9 @@ __device__ inline void rebuild_kmer_stats_cache(const Vx &c, const GParams BT_CA
             if (hit_way == KSC_WAYS && keys[e] == dkey) hit_way = e;
     }
     const Vx::RPtr<uint8_t> sm = c.subm();
-    SPtr<uint8_t, LANES> scn = c.subcnt(), sic = c.subic();
-    SPtr<uint32_t, LANES> so = c.skv_off(), sb = c.skv_bits(), msub = c.msub();
-    SPtr<uint16_t, LANES> sv = c.skv_var();
+    TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
+    TPtr<uint32_t> so = c.skv_off(), sb = c.skv_bits(), msub = c.msub();
+    TPtr<uint16_t> sv = c.skv_var();
     for (uint32_t a = c.t.part; a < 2 * V; a += c.t.copies) {
         const uint32_t which = a / V, var = a - which * V;
         KS acc{0, 0, 0, 0};
@@ -1413,11 +1416,11 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
             PROF(17);
         }
         {   // the nested sources this sweep sees become the sample's pending copy (what later identical sweeps are compared with)
-            SPtr<double, LANES> pn = c.pend_nest(s);
+            TPtr<double> pn = c.pend_nest(s);
             double nv[6] = {0, 0, 0, 0, 0, 0};
             for (uint32_t j = 0; j < 2u; ++j)
                 if (j < nn) {
-                    SPtr<double, LANES> q = c.nest_stats(s, j);
+                    TPtr<double> q = c.nest_stats(s, j);
                     nv[3 * j] = q[0];
                     nv[3 * j + 1] = q[1];
                     nv[3 * j + 2] = q[2];
@@ -1444,7 +1447,7 @@ __device__ inline void collect_sample_body(const Vx &c, const GParams BT_CAS &P,
 // time.  Per sample the entries are applied in order, each exactly as the immediate update would have been (cache of that diplotype,
 // then the run's replay), so every statistic sees the same values in the same order.
 __device__ inline void apply_collected_log(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t nsub_u) {
-    SPtr<uint32_t, LANES> lg = c.evlog(s);
+    TPtr<uint32_t> lg = c.evlog(s);
     const uint32_t n = c.evn()[s];
     for (uint32_t e = 0; e < n; ++e) {
         const uint32_t key = lg[1 + 2 * e], r = lg[2 + 2 * e];
@@ -1455,7 +1458,7 @@ __device__ inline void apply_collected_log(const Vx &c, const GParams BT_CAS &P,
     c.evn()[s] = 0;
 }
 __device__ inline void log_collected_run(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t key, uint32_t r, uint32_t nsub_u) {
-    SPtr<uint32_t, LANES> lg = c.evlog(s);
+    TPtr<uint32_t> lg = c.evlog(s);
     uint32_t n = c.evn()[s];
     if (n == EV_CAP) {   // (a sample that keeps changing its diplotype: apply what is logged now)
         apply_collected_log(c, P, s, nsub_u);
@@ -1530,11 +1533,11 @@ __device__ BT_NOINLINE void update_allele_kmer_stats(Env env, uint32_t vtx, uint
             const uint32_t nn = c.nest_n()[s];
             bool same = true;
             if (nn) {   // nested groups: the parent's contribution of this sweep equals the one the pending sweeps saw
-                SPtr<double, LANES> pn = c.pend_nest(s);
+                TPtr<double> pn = c.pend_nest(s);
                 same = (double)pn[3] == (double)nn;
                 for (uint32_t j = 0; j < 2u; ++j)
                     if (j < nn) {
-                        SPtr<double, LANES> q = c.nest_stats(s, j);
+                        TPtr<double> q = c.nest_stats(s, j);
                         same = same && (double)q[0] == (double)pn[4 * j] && (double)q[1] == (double)pn[4 * j + 1] && (double)q[2] == (double)pn[4 * j + 2];
                     }
             } else
@@ -1553,7 +1556,7 @@ __device__ BT_NOINLINE void update_allele_kmer_stats(Env env, uint32_t vtx, uint
 __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collect, uint32_t trace_word, bool tracing, uint32_t *trace_buf) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
-    const SPtr<uint32_t, LANES> trace_row{(uint32_t BT_GAS *)uniform_ptr(trace_buf), trace_word};
+    const TPtr<uint32_t> trace_row{(uint32_t BT_GAS *)uniform_ptr(trace_buf), trace_word, 6u};   // (trace blocks are interleaved over 64 lanes whatever the tile)
     SPtrF<uint32_t, LANES> sc = c.sc();
     const uint32_t nsub_u = sc[SC_NSUB_U], nsub_m = sc[SC_NSUB_M];
     const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
@@ -1625,8 +1628,8 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
             const bool dipl = ploidy == 2;
             const TileDesc BT_CAS &dd = c.d();
             const Vx::UCPtr uc = c.ucache();
-            SPtr<double, LANES> mc = c.mcache();
-            SPtr<uint32_t, LANES> uct = c.uctag(), mct = c.mctag(), mcg = c.mcgen();
+            TPtr<double> mc = c.mcache();
+            TPtr<uint32_t> uct = c.uctag(), mct = c.mctag(), mcg = c.mcgen();
             const bool multi = use_multi && nsub_m != 0;
             uint32_t a = 0, b = 0;   // enumeration state (diploid: b >= a)
             // skip `steps` candidates of the enumeration (row a holds nnz - a candidates when diploid, one when haploid)
@@ -1935,7 +1938,7 @@ __device__ BT_NOINLINE void sample_haplotype_frequencies(Env env, uint32_t vtx) 
             // cached_simplex_prob_vectors[sum_observation_counts][|plus| - 1] (FrequencyDistribution.cpp:211-229): the vector is a pure
             // function of (n_obs, |plus|), so caching it or not is invisible; cached when the tile reserved room for it
             uint32_t len;
-            SPtr<double, LANES> vec = c.simplex();
+            TPtr<double> vec = c.simplex();
             const bool cached = d.scache_n && n_obs <= 2 * d.S && plus_size <= d.scache_p;
             const uint32_t ci = cached ? (n_obs - 1) * d.scache_p + (plus_size - 1) : 0u;
             if (cached) vec = c.scache() + (uint32_t)ci * d.scache_len;

@@ -67,14 +67,25 @@ struct SPtr {
 };
 template <typename T>
 BT_HD SPtr<T, 1> sptr1(T *p) { return SPtr<T, 1>{(T BT_GAS *)p, 0u}; }
+// Array of a Gibbs tile in HBM: element i of lane l at base[off + (i << sh)], the rows interleaved over the tile's OWN width 2^sh
+// (4 .. 64 lanes; a run-time, wave-uniform shift).  A narrow tile's rows are as wide as the tile, so a cache line holds consecutive
+// elements of the tile's own groups instead of one element of 64 lanes of which the tile uses a few.
+template <typename T>
+struct TPtr {
+    T BT_GAS *base;
+    uint32_t off;
+    uint32_t sh;
+    BT_HD T BT_GAS &operator[](uint32_t i) const { return base[off + (i << sh)]; }
+    BT_HD TPtr<T> operator+(uint32_t i) const { return TPtr<T>{base, off + (i << sh), sh}; }
+};
 // same, with a generic ("flat") base pointer: may point into LDS as well as into HBM
 template <typename T, unsigned STRIDE>
 struct SPtrF {
     T *base;
     uint32_t off;
-    uint32_t stride = STRIDE;   // run-time: LDS-resident arrays of narrow tiles are interleaved over fewer lanes than the HBM layout
-    BT_HD T &operator[](uint32_t i) const { return base[off + i * stride]; }
-    BT_HD SPtrF<T, STRIDE> operator+(uint32_t i) const { return SPtrF<T, STRIDE>{base, off + i * stride, stride}; }
+    uint32_t sh = STRIDE == 64 ? 6u : 0u;   // run-time: log2 of the lanes the rows are interleaved over (the tile's width)
+    BT_HD T &operator[](uint32_t i) const { return base[off + (i << sh)]; }
+    BT_HD SPtrF<T, STRIDE> operator+(uint32_t i) const { return SPtrF<T, STRIDE>{base, off + (i << sh), sh}; }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 // tell the compiler that a pointer handed through a non-inlined call is wave-uniform (it then lives in scalar registers and
@@ -228,7 +239,7 @@ template <class RP>
 BT_HD MtRing mt_ring_open(uint32_t *st, RP ring, uint32_t cap) {
     MtRing m;
     m.st = (uint32_t BT_GAS *)st;
-    m.ring = SPtrF<uint32_t, 1>{ring.base, ring.off, ring.stride};
+    m.ring = SPtrF<uint32_t, 1>{ring.base, ring.off, ring.sh};
     m.cap = cap;
     m.pos = m.ring[cap];
     m.head = m.ring[cap + 1];

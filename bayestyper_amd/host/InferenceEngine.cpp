@@ -48,21 +48,28 @@ void check(int rc, const char *what) {
 }
 }  // namespace
 
-// one bt_gibbs over a batch of groups
-struct InferenceEngine::Sampler {
+// one bt_gibbs over a batch of groups: the product's sampler
+namespace {
+struct GpuSampler : GibbsSampler {
     bt_ctx *ctx;
     bt_gibbs *g = nullptr;
     uint64_t *d_hist = nullptr;
     uint32_t S;
-    Sampler(bt_ctx *ctx_in, const bt_gibbs_params &p, const GibbsBatchData &batch) : ctx(ctx_in), S(p.num_samples) {
+    GpuSampler(bt_ctx *ctx_in, const bt_gibbs_params &p, const GibbsBatchData &batch) : ctx(ctx_in), S(p.num_samples) {
+        if (!ctx) throw std::runtime_error("InferenceEngine: no GPU context (there is no CPU path)");
         const bt_gibbs_batch b = batch.view();
         check(bt_gibbs_create(ctx, &p, &b, &g), "bt_gibbs_create");
     }
-    ~Sampler() {
+    ~GpuSampler() override {
         if (d_hist) bt_free(ctx, d_hist);
         bt_gibbs_destroy(g);
     }
-    std::vector<uint64_t> noiseCounts() {   // VariantClusterGroup::getNoiseCounts of every group + clearGenotyperCache (InferenceEngine.cpp:90-92)
+    void setLut(const double *genomic, const double *noise) override { check(bt_gibbs_set_lut(g, genomic, noise), "bt_gibbs_set_lut"); }
+    void setNoiseLut(const double *noise) override { check(bt_gibbs_set_noise_lut(g, noise), "bt_gibbs_set_noise_lut"); }
+    void initChain(uint32_t chain) override { check(bt_gibbs_init_chain(g, chain), "bt_gibbs_init_chain"); }
+    void sweep(uint32_t n, bool collect) override { check(bt_gibbs_sweep(g, n, collect ? 1 : 0), "bt_gibbs_sweep"); }
+    void run() override { check(bt_gibbs_run(g), "bt_gibbs_run"); }
+    std::vector<uint64_t> noiseCounts() override {   // VariantClusterGroup::getNoiseCounts of every group + clearGenotyperCache (InferenceEngine.cpp:90-92)
         if (!d_hist) check(bt_malloc(ctx, (size_t)S * 256 * 8, (void **)&d_hist), "bt_malloc");
         check(bt_gibbs_noise_counts(g, d_hist, 1), "bt_gibbs_noise_counts");
         std::vector<uint64_t> h((size_t)S * 256);
@@ -70,7 +77,7 @@ struct InferenceEngine::Sampler {
         check(bt_memcpy_d2h(ctx, h.data(), d_hist, h.size() * 8), "bt_memcpy_d2h");
         return h;
     }
-    BatchResults results(uint32_t num_clusters) {
+    BatchResults results(uint32_t num_clusters) override {
         BatchResults r;
         uint64_t nd = 0, nc = 0;
         check(bt_gibbs_result_sizes(g, &nd, &nc), "bt_gibbs_result_sizes");
@@ -84,6 +91,22 @@ struct InferenceEngine::Sampler {
         return r;
     }
 };
+}  // namespace
+
+std::unique_ptr<GibbsSampler> InferenceEngine::newSampler(uint32_t noise_seeding, const GibbsBatchData &batch) {
+    const bt_gibbs_params p = params(noise_seeding);
+    if (make_sampler) return make_sampler(p, batch);
+    return std::unique_ptr<GibbsSampler>(new GpuSampler(ctx, p, batch));
+}
+
+void InferenceEngine::logRow(std::ostream &out, unsigned chain, unsigned iteration, const std::vector<double> &rates) {
+    out << noiseParameterRow(chain, iteration, rates);
+    if (record_rows) {
+        noise_rows.push_back((double)chain);
+        noise_rows.push_back((double)iteration);
+        noise_rows.insert(noise_rows.end(), rates.begin(), rates.end());
+    }
+}
 
 InferenceEngine::InferenceEngine(bt_ctx *ctx_in, std::vector<uint8_t> gender_in, std::vector<std::string> sample_names_in, const GibbsOptions &options, HistReducer reduce)
     : ctx(ctx_in), gender(std::move(gender_in)), sample_names(std::move(sample_names_in)), opt(options), reduce_hist(std::move(reduce)) {}
@@ -107,7 +130,7 @@ void InferenceEngine::iteration(Sampler *sampler, CountDistribution *cd, bool co
     const size_t S = gender.size();
     std::vector<uint64_t> hist(S * 256, 0);
     if (sampler) {
-        check(bt_gibbs_sweep(sampler->g, 1, collect ? 1 : 0), "bt_gibbs_sweep");
+        sampler->sweep(1, collect);
         hist = sampler->noiseCounts();
     }   // (a rank without groups in this chain still takes part in the reduction)
     if (reduce_hist) reduce_hist(hist.data(), hist.size());
@@ -115,14 +138,16 @@ void InferenceEngine::iteration(Sampler *sampler, CountDistribution *cd, bool co
     for (size_t s = 0; s < S; s++)
         for (size_t c = 0; c < 256; c++) counts.counts()[s][c] = hist[s * 256 + c];
     cd->sampleNoiseParameters(counts);
-    if (sampler) check(bt_gibbs_set_noise_lut(sampler->g, cd->noiseTable().data()), "bt_gibbs_set_noise_lut");
+    if (sampler) sampler->setNoiseLut(cd->noiseTable().data());
 }
 
 void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData &unit, const std::string &output_prefix, uint32_t variants_batch_size,
                                     const std::vector<uint32_t> *unit_clusters, const std::vector<uint32_t> *unit_variants) {
-    std::cout << "[" << getLocalTime() << "] Estimating noise model parameters using " << opt.chains << " parallel gibbs sampling chains each with " << (opt.burn_in + opt.samples)
-              << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
+    if (!quiet)
+        std::cout << "[" << getLocalTime() << "] Estimating noise model parameters using " << opt.chains << " parallel gibbs sampling chains each with " << (opt.burn_in + opt.samples)
+                  << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
     const size_t S = gender.size();
+    noise_rows.clear();
     // clusters / variants per group of the whole unit (default: `unit` is the whole unit)
     std::vector<uint32_t> clusters, variants;
     if (unit_clusters && unit_variants) {
@@ -151,15 +176,15 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         std::unique_ptr<Sampler> sampler;
         if (!mine.empty()) {
             // a fresh sampler per chain: genotypers are constructed with seed + (i+1)(chain+1) (:70) and deleted afterwards (resetGroupsCallback, :240-251)
-            sampler.reset(new Sampler(ctx, params(1), unit.take(mine)));
-            check(bt_gibbs_set_lut(sampler->g, cd->genomicTable().data(), cd->noiseTable().data()), "bt_gibbs_set_lut");
-            check(bt_gibbs_init_chain(sampler->g, chain), "bt_gibbs_init_chain");
+            sampler = newSampler(1, unit.take(mine));
+            sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
+            sampler->initChain(chain);
         }
-        out << noiseParameterRow(chain + 1, 0, cd->getNoiseRates());
+        logRow(out, chain + 1, 0, cd->getNoiseRates());
         for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
             iteration(sampler.get(), cd, false);
             const std::vector<double> &rates = cd->getNoiseRates();
-            out << noiseParameterRow(chain + 1, it, rates);
+            logRow(out, chain + 1, it, rates);
             if (opt.burn_in < it)
                 for (size_t s = 0; s < S; s++) mean[s] += rates[s];
         }
@@ -168,22 +193,30 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
     }
     for (auto &m : mean) m /= (double)opt.samples * opt.chains;
     cd->setNoiseRates(mean);
-    out << noiseParameterRow(0, 0, cd->getNoiseRates());
+    logRow(out, 0, 0, cd->getNoiseRates());
     low_variant_warning = selector.lastNumVariants() < variants_batch_size;
-    if (low_variant_warning) {
+    if (low_variant_warning && !quiet) {
         std::cout << "\nWARNING: Low number of variants used for noise model parameter estimation (" << selector.lastNumVariants() << " < " << variants_batch_size << ")" << std::endl;
         std::cout << "WARNING: The noise estimates might be biased\n" << std::endl;
     }
-    std::cout << "[" << getLocalTime() << "] Wrote noise parameters to " << output_prefix << ".txt" << std::endl;
+    if (!quiet) std::cout << "[" << getLocalTime() << "] Wrote noise parameters to " << output_prefix << ".txt" << std::endl;
 }
 
 // the default schedule for a batch; a batch whose sampler state does not fit the GPU is run as two consecutive halves (groups are
 // independent and keep their unit-wide index, so the split changes nothing but the peak memory; InferenceEngine.cpp:335-382 hands
 // groups to its threads in batches the same way)
 void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistribution &cd, const Collector &collect) {
+    if (opt.max_groups_per_launch && batch.numGroups() > opt.max_groups_per_launch) {   // consecutive group ranges of the unit, in order
+        for (uint32_t a = 0; a < batch.numGroups(); a += opt.max_groups_per_launch) {
+            std::vector<uint32_t> ids;
+            for (uint32_t g = a; g < std::min<uint32_t>(a + opt.max_groups_per_launch, batch.numGroups()); g++) ids.push_back(g);
+            runDefault(batch.take(ids), cd, collect);
+        }
+        return;
+    }
     std::unique_ptr<Sampler> sampler;
     try {
-        sampler.reset(new Sampler(ctx, params(0), batch));
+        sampler = newSampler(0, batch);
     } catch (const std::runtime_error &e) {
         if (batch.numGroups() < 2 || std::string(e.what()).find("state pool") == std::string::npos) throw;
         std::vector<uint32_t> a, b;
@@ -193,8 +226,8 @@ void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistrib
         return;
     }
     num_launches += 1;
-    check(bt_gibbs_set_lut(sampler->g, cd.genomicTable().data(), cd.noiseTable().data()), "bt_gibbs_set_lut");
-    check(bt_gibbs_run(sampler->g), "bt_gibbs_run");
+    sampler->setLut(cd.genomicTable().data(), cd.noiseTable().data());
+    sampler->run();
     const BatchResults r = sampler->results(batch.numClusters());
     sampler.reset();   // frees the launch's HBM before the next one is built
     collect(batch, r);
@@ -203,35 +236,38 @@ void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistrib
 void InferenceEngine::estimateGenotypes(const GibbsBatchData &unit, const CountDistribution &cd, const Collector &collect) {
     uint64_t num_variants = 0;
     for (uint32_t v : unit.num_variants) num_variants += v;
-    std::cout << "[" << getLocalTime() << "] Estimating genotypes on " << num_variants << " variants using " << opt.chains << " parallel gibbs sampling chains each with "
-              << (opt.burn_in + opt.samples) << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
+    if (!quiet)
+        std::cout << "[" << getLocalTime() << "] Estimating genotypes on " << num_variants << " variants using " << opt.chains << " parallel gibbs sampling chains each with "
+                  << (opt.burn_in + opt.samples) << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
     num_launches = 0;
     if (unit.numGroups()) runDefault(unit, cd, collect);
-    std::cout << "[" << getLocalTime() << "] Finished genotyping" << std::endl;
+    if (!quiet) std::cout << "[" << getLocalTime() << "] Finished genotyping" << std::endl;
 }
 
 void InferenceEngine::estimateNoiseAndGenotypes(const GibbsBatchData &unit, CountDistribution *cd, const Collector &collect, const std::string &output_prefix) {
     uint64_t num_variants = 0;
     for (uint32_t v : unit.num_variants) num_variants += v;
-    std::cout << "[" << getLocalTime() << "] Estimating noise model parameters and genotypes on " << num_variants << " variants using " << opt.chains
-              << " parallel gibbs sampling chains each with " << (opt.burn_in + opt.samples) << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
+    if (!quiet)
+        std::cout << "[" << getLocalTime() << "] Estimating noise model parameters and genotypes on " << num_variants << " variants using " << opt.chains
+                  << " parallel gibbs sampling chains each with " << (opt.burn_in + opt.samples) << " iterations (" << opt.burn_in << " burn-in) ..." << std::endl;
+    noise_rows.clear();
     std::ofstream out(output_prefix + ".txt");
     if (!out.is_open()) throw std::runtime_error("Unable to write file " + output_prefix + ".txt");
     out << noiseParameterHeader(sample_names);
     std::unique_ptr<Sampler> sampler;
     if (unit.numGroups()) {
-        sampler.reset(new Sampler(ctx, params(1), unit));
-        check(bt_gibbs_set_lut(sampler->g, cd->genomicTable().data(), cd->noiseTable().data()), "bt_gibbs_set_lut");
+        sampler = newSampler(1, unit);
+        sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
     }
     for (uint32_t chain = 0; chain < opt.chains; chain++) {
         if (sampler) {
-            check(bt_gibbs_set_noise_lut(sampler->g, cd->noiseTable().data()), "bt_gibbs_set_noise_lut");
-            check(bt_gibbs_init_chain(sampler->g, chain), "bt_gibbs_init_chain");
+            sampler->setNoiseLut(cd->noiseTable().data());
+            sampler->initChain(chain);
         }
-        out << noiseParameterRow(chain + 1, 0, cd->getNoiseRates());
+        logRow(out, chain + 1, 0, cd->getNoiseRates());
         for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
             iteration(sampler.get(), cd, it > opt.burn_in);
-            out << noiseParameterRow(chain + 1, it, cd->getNoiseRates());
+            logRow(out, chain + 1, it, cd->getNoiseRates());
         }
         cd->resetNoiseRates();
     }
@@ -240,7 +276,7 @@ void InferenceEngine::estimateNoiseAndGenotypes(const GibbsBatchData &unit, Coun
         sampler.reset();
         collect(unit, r);
     }
-    std::cout << "[" << getLocalTime() << "] Wrote noise parameters to " << output_prefix << ".txt" << std::endl;
+    if (!quiet) std::cout << "[" << getLocalTime() << "] Wrote noise parameters to " << output_prefix << ".txt" << std::endl;
 }
 
 }  // namespace bthost

@@ -6,11 +6,12 @@
 // In the two noise drivers an iteration is: one sweep of all (selected) groups on the GPU, their noise-count histograms added up
 // (CountAllocation; across ranks: `reduce_hist`, one all-reduce of S x 256 counters), one gamma draw per sample from the run's
 // CountDistribution generator on the host, the rebuilt noise table uploaded.  Every rank draws from an identically seeded generator,
-// so all ranks hold the same rates without a broadcast.  (bayestyper_amd/host/inference_engine.py drives the same C ABI from Python
-// for the tests and the bench.)
+// so all ranks hold the same rates without a broadcast.  (bayestyper_amd/host/inference_engine.py is the ctypes binding of THIS class
+// for the tests and the bench: there is one implementation of the drivers.)
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <random>
 #include <string>
 #include <vector>
@@ -58,7 +59,24 @@ struct GibbsOptions {   // main.cpp:389-393 + --random-seed
     unsigned seed = 0;
     uint32_t burn_in = 100, samples = 250, chains = 20, max_haplotype_variant_kmers = 500;
     float kmer_subsampling_rate = 0.1f;
+    uint32_t max_groups_per_launch = 0;   // default mode: a unit is genotyped in consecutive launches of at most this many groups (0: as many as fit the free HBM)
 };
+
+// What the drivers need from the object that samples a batch of groups.  The product's sampler is bt_gibbs on the engine's GPU
+// (InferenceEngine.cpp: GpuSampler, the default); the interface exists so that the drivers' own logic — group selection, sharding,
+// the histogram reduction, launch splitting — can be exercised on a machine without a GPU by handing the engine another sampler
+// (tests/: the oracle's, through bth_engine_set_sampler; nothing in the product provides one).
+struct GibbsSampler {
+    virtual ~GibbsSampler() {}
+    virtual void setLut(const double *genomic, const double *noise) = 0;
+    virtual void setNoiseLut(const double *noise) = 0;
+    virtual void initChain(uint32_t chain) = 0;
+    virtual void sweep(uint32_t n, bool collect) = 0;
+    virtual void run() = 0;                                   // the whole default schedule
+    virtual std::vector<uint64_t> noiseCounts() = 0;          // [S*256], VariantClusterGroup::getNoiseCounts of every group + clearGenotyperCache
+    virtual BatchResults results(uint32_t num_clusters) = 0;
+};
+typedef std::function<std::unique_ptr<GibbsSampler>(const bt_gibbs_params &, const GibbsBatchData &)> SamplerFactory;
 
 class InferenceEngine {
   public:
@@ -76,10 +94,18 @@ class InferenceEngine {
 
     bool lowNoiseVariantWarning() const { return low_variant_warning; }
     uint32_t numLaunches() const { return num_launches; }   // of the last estimateGenotypes
+    void setSamplerFactory(SamplerFactory f) { make_sampler = std::move(f); }
+    void setHistReducer(HistReducer r) { reduce_hist = std::move(r); }
+    // every row of the noise parameter file in full precision: (chain, iteration, rate_0 .. rate_{S-1}) per row (tests compare these, the file has 6 digits)
+    void recordNoiseRows(bool on) { record_rows = on; }
+    const std::vector<double> &noiseRows() const { return noise_rows; }
+    void setQuiet(bool q) { quiet = q; }
 
   private:
-    struct Sampler;
+    typedef GibbsSampler Sampler;
     void iteration(Sampler *sampler, CountDistribution *count_distribution, bool collect);
+    void logRow(std::ostream &out, unsigned chain, unsigned iteration, const std::vector<double> &rates);
+    std::unique_ptr<Sampler> newSampler(uint32_t noise_seeding, const GibbsBatchData &batch);
     void runDefault(const GibbsBatchData &batch, const CountDistribution &count_distribution, const Collector &collect);
     bt_gibbs_params params(uint32_t noise_seeding) const;
 
@@ -90,6 +116,9 @@ class InferenceEngine {
     HistReducer reduce_hist;
     bool low_variant_warning = false;
     uint32_t num_launches = 0;
+    SamplerFactory make_sampler;
+    bool record_rows = false, quiet = false;
+    std::vector<double> noise_rows;
 };
 
 }  // namespace bthost

@@ -98,6 +98,58 @@ void appendSlice(std::vector<T> &dst, const std::vector<T> &src, uint64_t a, uin
 }
 }  // namespace
 
+GibbsBatchData GibbsBatchData::fromView(const bt_gibbs_batch &b, uint32_t S) {
+    GibbsBatchData o;
+    o.S = S;
+    const uint64_t G = b.num_groups, C = b.num_clusters;
+    auto cp = [](auto &dst, const auto *src, uint64_t n) { dst.assign(src, src + n); };
+    cp(o.group_index, b.group_index, G);
+    cp(o.group_cluster_off, b.group_cluster_off, G + 1);
+    cp(o.group_ploidy, b.group_ploidy, G * S);
+    cp(o.group_source_off, b.group_source_off, G + 1);
+    cp(o.group_sources, b.group_sources, b.group_source_off[G]);
+    cp(o.group_num_shared, b.group_num_shared, G);
+    cp(o.cluster_idx, b.cluster_idx, C);
+    cp(o.edge_off, b.edge_off, C + 1);
+    cp(o.edges, b.edges, b.edge_off[C]);
+    cp(o.num_haplotypes, b.num_haplotypes, C);
+    cp(o.num_variants, b.num_variants, C);
+    cp(o.kmer_off, b.kmer_off, C + 1);
+    const uint64_t R = b.kmer_off[C];
+    uint64_t mult = 0, hv = 0, hsum = 0, vsum = 0, kvb = 0;
+    for (uint64_t c = 0; c < C; c++) {
+        const uint64_t H = b.num_haplotypes[c], V = b.num_variants[c], K = b.kmer_off[c + 1] - b.kmer_off[c];
+        mult += K * H;
+        hv += H * V;
+        hsum += H;
+        vsum += V;
+        kvb += (uint64_t)(b.kv_off[b.kmer_off[c + 1]] - b.kv_off[b.kmer_off[c]]) * ((H + 31) / 32);
+    }
+    cp(o.hap_kmer_mult, b.hap_kmer_mult, mult);
+    cp(o.kmer_has_counts, b.kmer_has_counts, R);
+    cp(o.kmer_counts, b.kmer_counts, R * S);
+    cp(o.kmer_ic_mult, b.kmer_ic_mult, R * 2);
+    cp(o.kmer_shared, b.kmer_shared, R);
+    cp(o.kv_off, b.kv_off, R + 1);
+    cp(o.kv_var, b.kv_var, b.kv_off[R]);
+    cp(o.kv_bits, b.kv_bits, kvb);
+    cp(o.unique_off, b.unique_off, C + 1);
+    cp(o.unique_idx, b.unique_idx, b.unique_off[C]);
+    cp(o.multi_off, b.multi_off, C + 1);
+    cp(o.multi_idx, b.multi_idx, b.multi_off[C]);
+    cp(o.hap_allele, b.hap_allele, hv);
+    cp(o.hapnest_off, b.hapnest_off, hsum + 1);
+    cp(o.hapnest_idx, b.hapnest_idx, b.hapnest_off[hsum]);
+    cp(o.var_num_alleles, b.var_num_alleles, vsum);
+    cp(o.var_has_dependency, b.var_has_dependency, vsum);
+    cp(o.nestdep_off, b.nestdep_off, C + 1);
+    const uint64_t ND = b.nestdep_off[C];
+    cp(o.nestdep_cluster, b.nestdep_cluster, ND);
+    cp(o.nestdep_var_off, b.nestdep_var_off, ND + 1);
+    cp(o.nestdep_var, b.nestdep_var, b.nestdep_var_off[ND]);
+    return o;
+}
+
 GibbsBatchData GibbsBatchData::take(const std::vector<uint32_t> &ids) const {
     GibbsBatchData o;
     o.S = S;

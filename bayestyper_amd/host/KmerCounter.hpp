@@ -46,6 +46,7 @@ struct GibbsBatchData {
     std::vector<int32_t> kmer_shared;
     std::vector<uint16_t> kv_var, hap_allele, var_num_alleles, nestdep_var;
     bt_gibbs_batch view() const;
+    static GibbsBatchData fromView(const bt_gibbs_batch &b, uint32_t S);   // a deep copy of a batch handed in as plain arrays (include/btgpu.h: bt_gibbs_batch)
     // the groups `ids` (ascending) as a batch of their own; group_index keeps the unit-wide index
     GibbsBatchData take(const std::vector<uint32_t> &ids) const;
     uint32_t numGroups() const { return (uint32_t)group_index.size(); }

@@ -56,6 +56,194 @@ void bth_count_distribution_sample_noise(void *h, const unsigned long long *hist
         for (unsigned i = 0; i < 256; i++) ca.counts()[s][i] = hist[s * 256 + i];
     ((CountDistribution *)h)->sampleNoiseParameters(ca);
 }
+// ---- InferenceEngine (the three drivers) behind a handle: what bayestyper_amd/host/inference_engine.py binds ----------------------
+// A sampler supplied by the caller (tests: the oracle's; see InferenceEngine.hpp: GibbsSampler).  All callbacks get `user` first.
+struct bth_sampler_vtable {
+    void *(*create)(void *user, const bt_gibbs_params *params, const bt_gibbs_batch *batch);
+    void (*destroy)(void *user, void *h);
+    void (*set_lut)(void *user, void *h, const double *genomic, const double *noise);
+    void (*set_noise_lut)(void *user, void *h, const double *noise);
+    void (*init_chain)(void *user, void *h, uint32_t chain);
+    void (*sweep)(void *user, void *h, uint32_t n, int collect);
+    void (*run)(void *user, void *h);
+    void (*noise_counts)(void *user, void *h, uint64_t *hist /* [S*256] */);
+    void (*result_sizes)(void *user, void *h, uint64_t *num_entries, uint64_t *num_cells);
+    void (*result_fetch)(void *user, void *h, uint64_t *dip_off, uint16_t *h1, uint16_t *h2, uint32_t *freq, uint64_t *cell_off, double *stats);
+};
+namespace {
+struct CallbackSampler : GibbsSampler {
+    bth_sampler_vtable vt;
+    void *user, *h;
+    uint32_t S;
+    CallbackSampler(const bth_sampler_vtable &v, void *u, const bt_gibbs_params &p, const GibbsBatchData &batch) : vt(v), user(u), S(p.num_samples) {
+        const bt_gibbs_batch b = batch.view();
+        h = vt.create(user, &p, &b);
+        if (!h) throw std::runtime_error("sampler callback: create failed");
+    }
+    ~CallbackSampler() override { vt.destroy(user, h); }
+    void setLut(const double *g, const double *n) override { vt.set_lut(user, h, g, n); }
+    void setNoiseLut(const double *n) override { vt.set_noise_lut(user, h, n); }
+    void initChain(uint32_t c) override { vt.init_chain(user, h, c); }
+    void sweep(uint32_t n, bool collect) override { vt.sweep(user, h, n, collect ? 1 : 0); }
+    void run() override { vt.run(user, h); }
+    std::vector<uint64_t> noiseCounts() override {
+        std::vector<uint64_t> hist((size_t)S * 256, 0);
+        vt.noise_counts(user, h, hist.data());
+        return hist;
+    }
+    BatchResults results(uint32_t num_clusters) override {
+        BatchResults r;
+        uint64_t nd = 0, nc = 0;
+        vt.result_sizes(user, h, &nd, &nc);
+        r.dip_off.resize(num_clusters + 1);
+        r.cell_off.resize(num_clusters + 1);
+        r.h1.resize(std::max<uint64_t>(nd, 1));
+        r.h2.resize(std::max<uint64_t>(nd, 1));
+        r.freq.resize(std::max<uint64_t>(nd * S, 1));
+        r.stats.resize(std::max<uint64_t>(nc * 12, 1));
+        vt.result_fetch(user, h, r.dip_off.data(), r.h1.data(), r.h2.data(), r.freq.data(), r.cell_off.data(), r.stats.data());
+        return r;
+    }
+};
+struct EngineHandle {
+    std::unique_ptr<InferenceEngine> engine;
+    uint32_t S = 0;
+    // collected samples of the last estimateGenotypes / estimateNoiseAndGenotypes: the launches' results appended in call order
+    BatchResults collected;
+    uint64_t num_clusters = 0, num_entries = 0, num_cells = 0;
+    std::vector<uint32_t> launch_groups;   // groups per launch
+    void reset() {
+        collected = BatchResults();
+        collected.dip_off.push_back(0);
+        collected.cell_off.push_back(0);
+        num_clusters = num_entries = num_cells = 0;
+        launch_groups.clear();
+    }
+    InferenceEngine::Collector collector() {
+        return [this](const GibbsBatchData &batch, const BatchResults &r) {
+            const uint32_t C = batch.numClusters();
+            const uint64_t nd = r.dip_off[C], nc = r.cell_off[C];
+            for (uint32_t c = 0; c < C; c++) {
+                collected.dip_off.push_back(num_entries + r.dip_off[c + 1]);
+                collected.cell_off.push_back(num_cells + r.cell_off[c + 1]);
+            }
+            collected.h1.insert(collected.h1.end(), r.h1.begin(), r.h1.begin() + nd);
+            collected.h2.insert(collected.h2.end(), r.h2.begin(), r.h2.begin() + nd);
+            collected.freq.insert(collected.freq.end(), r.freq.begin(), r.freq.begin() + nd * S);
+            collected.stats.insert(collected.stats.end(), r.stats.begin(), r.stats.begin() + nc * 12);
+            num_clusters += C;
+            num_entries += nd;
+            num_cells += nc;
+            launch_groups.push_back(batch.numGroups());
+        };
+    }
+};
+int engine_error(const std::exception &e, char *err, unsigned err_len) {
+    if (err && err_len) {
+        std::strncpy(err, e.what(), err_len - 1);
+        err[err_len - 1] = 0;
+    }
+    return 1;
+}
+}  // namespace
+
+void *bth_engine_new(bt_ctx *ctx, unsigned S, const uint8_t *gender, const char *sample_names /* tab-separated */, unsigned seed, uint32_t burn_in, uint32_t samples, uint32_t chains, float kmer_subsampling_rate,
+                     uint32_t max_haplotype_variant_kmers, uint32_t max_groups_per_launch) {
+    GibbsOptions o;
+    o.seed = seed;
+    o.burn_in = burn_in;
+    o.samples = samples;
+    o.chains = chains;
+    o.kmer_subsampling_rate = kmer_subsampling_rate;
+    o.max_haplotype_variant_kmers = max_haplotype_variant_kmers;
+    o.max_groups_per_launch = max_groups_per_launch;
+    std::vector<std::string> names;
+    {
+        std::stringstream ss(sample_names ? sample_names : "");
+        std::string n;
+        while (std::getline(ss, n, '\t')) names.push_back(n);
+        for (unsigned s = (unsigned)names.size(); s < S; s++) names.push_back("sample_" + std::to_string(s));
+    }
+    auto *h = new EngineHandle();
+    h->S = S;
+    h->engine.reset(new InferenceEngine(ctx, std::vector<uint8_t>(gender, gender + S), names, o));
+    h->engine->recordNoiseRows(true);
+    h->engine->setQuiet(true);
+    h->reset();
+    return h;
+}
+void bth_engine_free(void *h) { delete (EngineHandle *)h; }
+void bth_engine_set_sampler(void *h, const bth_sampler_vtable *vt, void *user) {
+    const bth_sampler_vtable v = *vt;
+    ((EngineHandle *)h)->engine->setSamplerFactory([v, user](const bt_gibbs_params &p, const GibbsBatchData &b) { return std::unique_ptr<GibbsSampler>(new CallbackSampler(v, user, p, b)); });
+}
+void bth_engine_set_hist_reducer(void *h, void (*fn)(uint64_t *hist, uint64_t n, void *user), void *user) {
+    ((EngineHandle *)h)->engine->setHistReducer([fn, user](uint64_t *hist, size_t n) { fn(hist, (uint64_t)n, user); });
+}
+int bth_engine_estimate_noise(void *h, void *count_distribution, const bt_gibbs_batch *batch, const char *output_prefix, uint32_t variants_batch_size,
+                              const uint32_t *unit_clusters_per_group, const uint32_t *unit_variants_per_group, uint32_t unit_groups, int *low_variant_warning, char *err,
+                              unsigned err_len) {
+    auto *e = (EngineHandle *)h;
+    try {
+        const GibbsBatchData unit = GibbsBatchData::fromView(*batch, e->S);
+        std::vector<uint32_t> cl, va;
+        if (unit_clusters_per_group && unit_variants_per_group) {
+            cl.assign(unit_clusters_per_group, unit_clusters_per_group + unit_groups);
+            va.assign(unit_variants_per_group, unit_variants_per_group + unit_groups);
+        }
+        e->engine->estimateNoise((CountDistribution *)count_distribution, unit, output_prefix, variants_batch_size, cl.empty() ? nullptr : &cl, va.empty() ? nullptr : &va);
+        if (low_variant_warning) *low_variant_warning = e->engine->lowNoiseVariantWarning() ? 1 : 0;
+    } catch (const std::exception &ex) {
+        return engine_error(ex, err, err_len);
+    }
+    return 0;
+}
+int bth_engine_estimate_genotypes(void *h, const bt_gibbs_batch *batch, void *count_distribution, char *err, unsigned err_len) {
+    auto *e = (EngineHandle *)h;
+    try {
+        e->reset();
+        e->engine->estimateGenotypes(GibbsBatchData::fromView(*batch, e->S), *(CountDistribution *)count_distribution, e->collector());
+    } catch (const std::exception &ex) {
+        return engine_error(ex, err, err_len);
+    }
+    return 0;
+}
+int bth_engine_estimate_noise_and_genotypes(void *h, const bt_gibbs_batch *batch, void *count_distribution, const char *output_prefix, char *err, unsigned err_len) {
+    auto *e = (EngineHandle *)h;
+    try {
+        e->reset();
+        e->engine->estimateNoiseAndGenotypes(GibbsBatchData::fromView(*batch, e->S), (CountDistribution *)count_distribution, e->collector(), output_prefix);
+    } catch (const std::exception &ex) {
+        return engine_error(ex, err, err_len);
+    }
+    return 0;
+}
+// sizes[4] = clusters, diplotype entries, allele cells, launches
+void bth_engine_result_sizes(void *h, uint64_t *sizes) {
+    auto *e = (EngineHandle *)h;
+    sizes[0] = e->num_clusters;
+    sizes[1] = e->num_entries;
+    sizes[2] = e->num_cells;
+    sizes[3] = e->launch_groups.size();
+}
+void bth_engine_result_fetch(void *h, uint64_t *dip_off, uint16_t *h1, uint16_t *h2, uint32_t *freq, uint64_t *cell_off, double *stats, uint32_t *launch_groups) {
+    auto *e = (EngineHandle *)h;
+    const BatchResults &r = e->collected;
+    std::memcpy(dip_off, r.dip_off.data(), r.dip_off.size() * 8);
+    std::memcpy(cell_off, r.cell_off.data(), r.cell_off.size() * 8);
+    if (!r.h1.empty()) std::memcpy(h1, r.h1.data(), r.h1.size() * 2);
+    if (!r.h2.empty()) std::memcpy(h2, r.h2.data(), r.h2.size() * 2);
+    if (!r.freq.empty()) std::memcpy(freq, r.freq.data(), r.freq.size() * 4);
+    if (!r.stats.empty()) std::memcpy(stats, r.stats.data(), r.stats.size() * 8);
+    if (launch_groups && !e->launch_groups.empty()) std::memcpy(launch_groups, e->launch_groups.data(), e->launch_groups.size() * 4);
+}
+// rows of the noise parameter file in full precision: (chain, iteration, rate_0 ..) per row; returns the number of doubles
+uint64_t bth_engine_noise_rows(void *h, double *out, uint64_t cap) {
+    const std::vector<double> &r = ((EngineHandle *)h)->engine->noiseRows();
+    if (out && cap >= r.size() && !r.empty()) std::memcpy(out, r.data(), r.size() * 8);
+    return r.size();
+}
+
 // NoiseGroupSelector (estimateNoise's per-chain choice of groups)
 void *bth_noise_selector_new(const uint32_t *clusters_per_group, const uint32_t *variants_per_group, uint32_t num_groups, unsigned seed, uint32_t batch_size) {
     return new NoiseGroupSelector(clusters_per_group, variants_per_group, num_groups, seed, batch_size);

@@ -469,6 +469,53 @@ def to_ctypes(flat, seed=42, chains=20, burn=100, iters=250, rate=0.1, max_hvk=5
     return p, b, keep
 
 
+_PTR_DTYPES = {"group_index": np.uint32, "group_cluster_off": np.uint32, "group_ploidy": np.uint8, "group_source_off": np.uint32, "group_sources": np.uint32,
+               "group_num_shared": np.uint32, "cluster_idx": np.uint32, "edge_off": np.uint32, "edges": np.uint32, "num_haplotypes": np.uint32, "num_variants": np.uint32,
+               "kmer_off": np.uint32, "hap_kmer_mult": np.uint8, "kmer_has_counts": np.uint8, "kmer_counts": np.uint8, "kmer_ic_mult": np.uint8, "kmer_shared": np.int32,
+               "kv_off": np.uint32, "kv_var": np.uint16, "kv_bits": np.uint32, "unique_off": np.uint32, "unique_idx": np.uint32, "multi_off": np.uint32, "multi_idx": np.uint32,
+               "hap_allele": np.uint16, "hapnest_off": np.uint32, "hapnest_idx": np.uint32, "var_num_alleles": np.uint16, "var_has_dependency": np.uint8,
+               "nestdep_off": np.uint32, "nestdep_cluster": np.uint32, "nestdep_var_off": np.uint32, "nestdep_var": np.uint16}
+
+
+def from_ctypes(batch, S, gender):
+    """the inverse of to_ctypes: a GibbsBatch (include/btgpu.h: bt_gibbs_batch, plain pointers) -> a flat dict holding COPIES of its arrays"""
+    def view(name, n):
+        dt = np.dtype(_PTR_DTYPES[name])
+        if n == 0:
+            return np.zeros(0, dt)
+        buf = (C.c_char * (int(n) * dt.itemsize)).from_address(getattr(batch, name))
+        return np.frombuffer(buf, dt, int(n)).copy()
+
+    G, Cn = int(batch.num_groups), int(batch.num_clusters)
+    f = {"S": int(S), "gender": np.asarray(gender, np.uint8).copy(), "num_groups": G, "num_clusters": Cn}
+    for name, n in (("group_index", G), ("group_cluster_off", G + 1), ("group_ploidy", G * S), ("group_source_off", G + 1), ("group_num_shared", G), ("cluster_idx", Cn),
+                    ("edge_off", Cn + 1), ("num_haplotypes", Cn), ("num_variants", Cn), ("kmer_off", Cn + 1), ("unique_off", Cn + 1), ("multi_off", Cn + 1), ("nestdep_off", Cn + 1)):
+        f[name] = view(name, n)
+    H, V = f["num_haplotypes"].astype(np.int64), f["num_variants"].astype(np.int64)
+    K = f["kmer_off"].astype(np.int64)
+    R = int(K[-1]) if Cn else 0
+    f["group_sources"] = view("group_sources", int(f["group_source_off"][-1]))
+    f["edges"] = view("edges", int(f["edge_off"][-1]))
+    f["hap_kmer_mult"] = view("hap_kmer_mult", int(((K[1:] - K[:-1]) * H).sum()))
+    for name, n in (("kmer_has_counts", R), ("kmer_counts", R * S), ("kmer_ic_mult", R * 2), ("kmer_shared", R), ("kv_off", R + 1)):
+        f[name] = view(name, n)
+    kvo = f["kv_off"].astype(np.int64)
+    f["kv_var"] = view("kv_var", int(kvo[-1]))
+    f["kv_bits"] = view("kv_bits", int(((kvo[K[1:]] - kvo[K[:-1]]) * ((H + 31) // 32)).sum()))
+    f["unique_idx"] = view("unique_idx", int(f["unique_off"][-1]))
+    f["multi_idx"] = view("multi_idx", int(f["multi_off"][-1]))
+    f["hap_allele"] = view("hap_allele", int((H * V).sum()))
+    f["hapnest_off"] = view("hapnest_off", int(H.sum()) + 1)
+    f["hapnest_idx"] = view("hapnest_idx", int(f["hapnest_off"][-1]))
+    f["var_num_alleles"] = view("var_num_alleles", int(V.sum()))
+    f["var_has_dependency"] = view("var_has_dependency", int(V.sum()))
+    ND = int(f["nestdep_off"][-1])
+    f["nestdep_cluster"] = view("nestdep_cluster", ND)
+    f["nestdep_var_off"] = view("nestdep_var_off", ND + 1)
+    f["nestdep_var"] = view("nestdep_var", int(f["nestdep_var_off"][-1]))
+    return f
+
+
 _PER_ITEM = ("group_ploidy", "group_sources", "group_num_shared", "cluster_idx", "edges", "num_haplotypes", "num_variants", "hap_kmer_mult",
              "kmer_has_counts", "kmer_counts", "kmer_ic_mult", "kmer_shared", "kv_var", "kv_bits", "unique_idx", "multi_idx", "hap_allele",
              "hapnest_idx", "var_num_alleles", "var_has_dependency", "nestdep_cluster", "nestdep_var")
