@@ -10,6 +10,9 @@
 // draws (samples within a sweep, sweeps within a chain, chains within a genotyper), so the parallel axis is the group.
 // Groups are sorted by shape and cut into TILES of 64; a tile is one wavefront's worth of lane-interleaved HBM
 // (bt_gibbs_tile.hpp) so that the wave's memory traffic coalesces.  One workgroup = one wavefront = one tile.
+#ifndef BT_SWEEP_OUTLINE
+#define BT_SWEEP_INLINE   // the per-visit sweep functions are part of the kernel body (bt_rng_device.hpp: BT_SWEEPFN)
+#endif
 #include "bt_gibbs_kernel.hpp"
 #include "bt_internal.hpp"
 

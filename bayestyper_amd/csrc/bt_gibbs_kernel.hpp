@@ -107,7 +107,7 @@ __device__ BT_NOINLINE void prepare_nested(Env env, uint32_t v_parent, uint32_t 
     }
 }
 
-__device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, TPtr<uint32_t> trace_row, bool tracing) {
+__device__ __forceinline__ void visit_vertex(const Env &env_in, const Tile &t, const GParams BT_CAS &P, uint32_t v, bool collect, TPtr<uint32_t> trace_row, bool tracing) {
     Env env = env_in;
     const bool swap = env.resident == 0xFFFFFFFFu && t.d->hot_bytes != 0;
     PROF_DECL;
@@ -125,8 +125,10 @@ __device__ inline void visit_vertex(const Env &env_in, const Tile &t, const GPar
     PROF(13);
 }
 
-// VariantClusterGroup::estimateGenotypes + runGibbsSample (VariantClusterGroup.cpp:220-250), recursion unrolled on an explicit stack
-__device__ inline void group_sweep(const Env &env, const Tile &t, const GParams BT_CAS &P, bool collect, uint32_t nvert, uint32_t nsrc, TPtr<uint32_t> trace_row, bool tracing) {
+// VariantClusterGroup::estimateGenotypes + runGibbsSample (VariantClusterGroup.cpp:220-250), recursion unrolled on an explicit stack.
+// ONE call site of visit_vertex (and one of group_sweep in the kernel): the sweep functions are part of the kernel body (BT_SWEEP_INLINE),
+// tens of thousands of instructions that must exist once.
+__device__ __forceinline__ void group_sweep(const Env &env, const Tile &t, const GParams BT_CAS &P, bool collect, uint32_t nvert, uint32_t nsrc, TPtr<uint32_t> trace_row, bool tracing) {
     if (tracing)
         for (uint32_t i = 0; i < t.d->nvm * P.S; ++i) trace_row[i] = 0xFFFFFFFFu;
     TPtr<uint32_t> sources = t.arr<uint32_t>(A_SOURCES), stack = t.arr<uint32_t>(A_STACK);
@@ -140,29 +142,33 @@ __device__ inline void group_sweep(const Env &env, const Tile &t, const GParams 
                 root.nest_n()[s] = 0;
             }
         }
-        visit_vertex(env, t, P, sv, collect, trace_row, tracing);
-        if (nvert == 1) continue;
-        stack[0] = sv;
-        stack[1] = 0;
-        uint32_t sp = 1;
-        while (sp > 0) {
-            const uint32_t v = stack[2 * (sp - 1)];
-            const uint32_t i = stack[2 * (sp - 1) + 1];
-            const Vx c = make_vx(t, v);
-            if (i < vx_ne(c)) {
-                stack[2 * (sp - 1) + 1] = i + 1;
-                const uint32_t tv = c.edges()[i];
-                {
-                    PROF_DECL;
-                    prepare_nested(env, v, tv);
-                    PROF(14);
-                }
-                visit_vertex(env, t, P, tv, collect, trace_row, tracing);
-                stack[2 * sp] = tv;
-                stack[2 * sp + 1] = 0;
-                ++sp;
-            } else
-                --sp;
+        // depth-first from the source: visit a vertex, push it, then descend into the next unvisited child of the top of the stack
+        uint32_t next = sv, sp = 0;
+        bool have = true;
+        while (have) {
+            visit_vertex(env, t, P, next, collect, trace_row, tracing);
+            if (nvert == 1) break;
+            stack[2 * sp] = next;
+            stack[2 * sp + 1] = 0;
+            ++sp;
+            have = false;
+            while (sp > 0 && !have) {
+                const uint32_t v = stack[2 * (sp - 1)];
+                const uint32_t i = stack[2 * (sp - 1) + 1];
+                const Vx c = make_vx(t, v);
+                if (i < vx_ne(c)) {
+                    stack[2 * (sp - 1) + 1] = i + 1;
+                    const uint32_t tv = c.edges()[i];
+                    {
+                        PROF_DECL;
+                        prepare_nested(env, v, tv);
+                        PROF(14);
+                    }
+                    next = tv;
+                    have = true;
+                } else
+                    --sp;
+            }
         }
     }
 }
@@ -222,48 +228,36 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
         t.resident = RESIDENT_ALL;
         t.hot = lds_block();
     }
-    const bool simple = SIMPLE_ONLY || (whole && tile_is_simple(*t.d));
-    if (op == OP_RUN) {
-        for (uint32_t chain = 0; chain < P.num_chains; ++chain) {
-            {
+    // tiles of two-haplotype clusters run their straight-line sweep in gibbs_simple_kernel only; launched through the general kernel
+    // (BT_GIBBS_NO_SIMPLE_KERNEL) they take the general path
+    const bool simple = SIMPLE_ONLY;
+    if (op == OP_RUN || op == OP_SWEEP) {
+        // OP_RUN: every chain = init + burn-in + collected sweeps; OP_SWEEP: arg0 sweeps of the chain in progress.  One loop for both,
+        // so that the sweep code (inlined) exists once
+        const bool is_run = op == OP_RUN;
+        const uint32_t nchains = is_run ? P.num_chains : 1u;
+        const uint32_t n_burn = is_run ? P.burn_in : (arg1 != 0 ? 0u : arg0), n_collect = is_run ? P.num_iterations : (arg1 != 0 ? arg0 : 0u);
+        for (uint32_t chain = 0; chain < nchains; ++chain) {
+            if (is_run) {
                 PROF_DECL;
                 group_init_chain(env, chain, nvert, nsrc, gindex);
                 PROF(15);
             }
-            if (simple) {
-                simple_sweeps(env, t, P, P.burn_in, false, tr.counter, tr.buf, tr.max_sweeps, tile);
-                simple_sweeps(env, t, P, P.num_iterations, true, tr.counter, tr.buf, tr.max_sweeps, tile);
-                drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
-                continue;
-            }
-            if constexpr (!SIMPLE_ONLY) {
-                for (uint32_t i = 0; i < P.burn_in; ++i) {
+            if constexpr (SIMPLE_ONLY) {
+                simple_sweeps(env, t, P, n_burn, n_collect, tr.counter, tr.buf, tr.max_sweeps, tile);
+                if (is_run || n_collect) drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
+            } else {
+                for (uint32_t i = 0; i < n_burn + n_collect; ++i) {
                     const TraceRow r = trace_row_for(t, P, tr, tile);
-                    group_sweep(env, t, P, false, nvert, nsrc, r.row, r.on);
+                    group_sweep(env, t, P, i >= n_burn, nvert, nsrc, r.row, r.on);
                 }
-                for (uint32_t i = 0; i < P.num_iterations; ++i) {
-                    const TraceRow r = trace_row_for(t, P, tr, tile);
-                    group_sweep(env, t, P, true, nvert, nsrc, r.row, r.on);
-                }
-                if (t.d->logged) drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
+                if (is_run && t.d->logged) drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
             }
         }
-        if (!simple)
+        if (!simple && (is_run || n_collect))
             for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);   // hot arrays: LDS when resident, else HBM (both valid)
     } else if (op == OP_INIT_CHAIN) {
         group_init_chain(env, arg0, nvert, nsrc, gindex);
-    } else if (op == OP_SWEEP) {
-        if (simple) simple_sweeps(env, t, P, arg0, arg1 != 0, tr.counter, tr.buf, tr.max_sweeps, tile);
-        if constexpr (!SIMPLE_ONLY)
-            for (uint32_t i = 0; i < (simple ? 0u : arg0); ++i) {
-                const TraceRow r = trace_row_for(t, P, tr, tile);
-                group_sweep(env, t, P, arg1 != 0, nvert, nsrc, r.row, r.on);
-            }
-        if (arg1 != 0) {
-            if (simple) drain_collected(env);
-            else
-                for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);
-        }
     } else if (SIMPLE_ONLY) {
         // (the other operations always go through the general kernel)
     } else if (op == OP_NOISE) {

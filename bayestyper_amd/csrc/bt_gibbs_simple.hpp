@@ -75,9 +75,11 @@ struct SimpleState {   // what a run of sweeps keeps in registers between sweeps
 
 __device__ inline bool tile_is_simple(const TileDesc BT_CAS &d) { return d.simple != 0; }
 
-// n_sweeps sweeps of the tile's clusters (one per lane).  The hot arrays of vertex 0 are resident in LDS (RESIDENT_ALL).
-__device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParams BT_CAS &P, uint32_t n_sweeps, bool collect, uint32_t *trace_counter, uint32_t *trace_buf,
+// n_burn sweeps without and then n_collect sweeps with collection of the tile's clusters (one per lane).  The hot arrays of vertex 0 are
+// resident in LDS (RESIDENT_ALL).  (One call site per kernel: the routine is inlined, and every further site would be another 24 000 instructions.)
+__device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParams BT_CAS &P, uint32_t n_burn, uint32_t n_collect, uint32_t *trace_counter, uint32_t *trace_buf,
                                      uint32_t trace_max, uint32_t tile) {
+    const uint32_t n_sweeps = n_burn + n_collect;
     const TileDesc BT_CAS &d = *t.d;
     const Vx c = make_vx(t, 0);   // (general accessors for the arrays that stay in HBM and for the slow paths)
     const uint32_t S = P.S, Dcm = d.Dcm;
@@ -111,6 +113,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
     Ring r0 = mt_ring_open_as(c.mt(0), ring0, d.ring_cap[0]), r1 = mt_ring_open_as(c.mt(1), ring1, d.ring_cap[1]);
 
     for (uint32_t sweep = 0; sweep < n_sweeps; ++sweep) {
+        const bool collect = sweep >= n_burn;
         // ---- trace row of this sweep ----
         bool tracing = false;
         TPtr<uint32_t> trace_row{(uint32_t BT_GAS *)trace_buf, 0u, 6u};

@@ -28,6 +28,10 @@ constexpr double BT_DBL_EPS = 2.220446049250313080847263336181640625e-16;
 #ifndef BT_LINEAR_DRAW_MIN
 #define BT_LINEAR_DRAW_MIN 4u   // candidate sets up to this size always use the reference's chain of logAddition calls
 #endif
+#ifndef BT_EVAL_BLOCK
+#define BT_EVAL_BLOCK 4u        // candidates evaluated per step of sample_diplotypes' blocked evaluation (their cache words are requested together)
+#endif
+constexpr uint32_t EVB = BT_EVAL_BLOCK;
 constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
 
 // scalar slots per vertex (A_SC)
@@ -709,6 +713,11 @@ __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool al
         TPtr<uint32_t> tg = c.uctag();
         const uint32_t sub = all_copies_run ? d.cache_entries / c.t.copies : d.cache_entries;
         for (uint32_t i = all_copies_run ? c.t.part * sub : 0u, e = i + sub; i < e; ++i) tg[i] = 0;
+    }    // ... and the multicluster sums (the reference clears both maps): their entries are stamped with the sample's generation, so a bump
+    // invalidates them.  (Without it a sum cached under the previous noise table survived clearGenotyperCache in the noise drivers.)
+    if (d.NMm) {
+        SPtrF<uint32_t, LANES> mg = c.mgen();
+        for (uint32_t s = 0; s < P.S; ++s) mg[s] += 1;
     }
 }
 
@@ -1036,30 +1045,30 @@ __device__ inline void multi_refresh(const Vx &c, const GParams BT_CAS &P, uint3
 // oth + M[h1] + M[h2] + intercluster in uchar arithmetic, with oth as refreshed by multi_refresh for the current generation.
 // The misses of a block of 8 candidates, evaluated together: per subset k-mer the shared operands (oth, intercluster, count) are
 // read once and the candidates' multiplicity rows and table lookups are independent loads.  Sums stay in subset order.
-__device__ inline void multi_log_prob_block(const Vx &c, const GParams BT_CAS &P, uint32_t s, const uint16_t (&ha)[8], const uint16_t (&hb)[8], const bool (&need)[8],
-                                            uint32_t nsub_m, double (&out)[8]) {
+__device__ inline void multi_log_prob_block(const Vx &c, const GParams BT_CAS &P, uint32_t s, const uint16_t (&ha)[EVB], const uint16_t (&hb)[EVB], const bool (&need)[EVB],
+                                            uint32_t nsub_m, double (&out)[EVB]) {
     TPtr<uint8_t> oth = c.oth(), mm = c.msubm(), mcn = c.msubc(), mic = c.msubic();
     const uint32_t Hm = c.d().Hm;
     const uint8_t gender = P.gender[s];
-    double acc[8];
+    double acc[EVB];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0;
+    for (int q = 0; q < (int)EVB; ++q) acc[q] = 0;
     for (uint32_t i = 0; i < nsub_m; ++i) {
         const uint8_t o = (uint8_t)(oth[i * P.S + s]), icn = mic[2 * i + gender], cn = mcn[i * P.S + s];
-        uint8_t m[8];
+        uint8_t m[EVB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < (int)EVB; ++q) {
             const uint16_t a = need[q] ? ha[q] : (uint16_t)0, b = need[q] ? hb[q] : NOHAP;   // safe addresses for unused slots
             m[q] = (uint8_t)((uint8_t)(o + msub_dip_mult(mm, Hm, i, a, b)) + icn);
         }
-        double lp[8];
+        double lp[EVB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) lp[q] = count_log_prob(P, s, m[q], cn);
+        for (int q = 0; q < (int)EVB; ++q) lp[q] = count_log_prob(P, s, m[q], cn);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += lp[q];
+        for (int q = 0; q < (int)EVB; ++q) acc[q] += lp[q];
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) out[q] = acc[q];
+    for (int q = 0; q < (int)EVB; ++q) out[q] = acc[q];
 }
 
 // ---- HaplotypeFrequencyDistribution::incrementCount (HaplotypeFrequencyDistribution.cpp:113-125) ----
@@ -1495,14 +1504,14 @@ __device__ BT_NOINLINE void flush_vertex(Env env, uint32_t vtx) {
     }
     for (uint32_t s = 0; s < P.S; ++s) flush_sample(c, P, s);
 }
-__device__ BT_NOINLINE void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
+__device__ BT_SWEEPFN void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     SPtrF<uint32_t, LANES> sc = c.sc();
     collect_sample_body(c, P, s, sc[SC_NSUB_U], sc[SC_NSUB_M]);
 }
 
-__device__ BT_NOINLINE void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
+__device__ BT_SWEEPFN void update_allele_kmer_stats(Env env, uint32_t vtx, uint32_t nsub_u, uint32_t nsub_m) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
@@ -1553,7 +1562,7 @@ __device__ BT_NOINLINE void update_allele_kmer_stats(Env env, uint32_t vtx, uint
 }
 
 // ---- sampleDiplotypes / sampleDiplotype / calcDiplotypeLogProb (VariantClusterGenotyper.cpp:597-755) ----
-__device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collect, uint32_t trace_word, bool tracing, uint32_t *trace_buf) {
+__device__ BT_SWEEPFN void sample_diplotypes(Env env, uint32_t vtx, bool collect, uint32_t trace_word, bool tracing, uint32_t *trace_buf) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const TPtr<uint32_t> trace_row{(uint32_t BT_GAS *)uniform_ptr(trace_buf), trace_word, 6u};   // (trace blocks are interleaved over 64 lanes whatever the tile)
@@ -1653,16 +1662,16 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
             // with copies of the group in the wavefront (Tile::part) every copy evaluates every copies-th block (dense tables: a slot
             // is private to a candidate; hashed tables: a slot is private to a copy, see hashed_slot)
             const uint32_t stride_blocks = par ? tsz : 1u;
-            if (par) advance(8u * tpart);
+            if (par) advance(EVB * tpart);
             lpmax = -__builtin_huge_val();
-            for (uint32_t base = par ? 8u * tpart : 0u; base < total; base += 8u * stride_blocks) {
-                const uint32_t nb = total - base < 8 ? total - base : 8;
-                uint16_t ha[8], hb[8];
-                uint32_t uslot[8], ukey[8];
-                double uval[8], mval[8], la[8], lb[8];
-                uint32_t utag[8], mtag[8], mgn[8];
+            for (uint32_t base = par ? EVB * tpart : 0u; base < total; base += EVB * stride_blocks) {
+                const uint32_t nb = total - base < EVB ? total - base : EVB;
+                uint16_t ha[EVB], hb[EVB];
+                uint32_t uslot[EVB], ukey[EVB];
+                double uval[EVB], mval[EVB], la[EVB], lb[EVB];
+                uint32_t utag[EVB], mtag[EVB], mgn[EVB];
 #pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) {
+                for (uint32_t q = 0; q < EVB; ++q) {
                     if (q < nb) {
                         ha[q] = nzl[a];
                         hb[q] = dipl ? (uint16_t)nzl[b] : NOHAP;
@@ -1688,17 +1697,17 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
                     }
                 }
                 if (multi) {
-                    bool need[8], any = false;
+                    bool need[EVB], any = false;
 #pragma unroll
-                    for (uint32_t q = 0; q < 8; ++q) {
+                    for (uint32_t q = 0; q < EVB; ++q) {
                         need[q] = q < nb && !(mtag[q] == ukey[q] && mgn[q] == gen);
                         any = any || need[q];
                     }
                     if (any) {
-                        double fresh[8];
+                        double fresh[EVB];
                         multi_log_prob_block(c, P, s, ha, hb, need, nsub_m, fresh);
 #pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q)
+                        for (uint32_t q = 0; q < EVB; ++q)
                             if (need[q]) {
                                 mval[q] = fresh[q];
                                 mct[uslot[q]] = ukey[q];
@@ -1708,7 +1717,7 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
                     }
                 }
 #pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) {
+                for (uint32_t q = 0; q < EVB; ++q) {
                     if (q < nb) {
                         double lp = 0;
                         if (!dipl) lp += la[q];
@@ -1722,7 +1731,7 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
                         cum[base + q] = lp;
                     }
                 }
-                if (par) advance(8u * (stride_blocks - 1u));
+                if (par) advance(EVB * (stride_blocks - 1u));
             }
             if (par) {   // maximum over the team's copies (lanes tlane0, tlane0 + cw, ...), then make their cum[] entries visible
                 const double own = lpmax;
@@ -1862,7 +1871,7 @@ __device__ BT_NOINLINE void sample_diplotypes(Env env, uint32_t vtx, bool collec
 
 // Top the draw-ahead rings of a cluster's two generators up at the start of a visit: the whole wavefront refills together (one burst
 // of independent state loads per generator), and the draws of the visit then read LDS.  Generating ahead does not change the stream.
-__device__ BT_NOINLINE void rng_topup(Env env, uint32_t vtx) {
+__device__ BT_SWEEPFN void rng_topup(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     MtRing a = c.rng(0), b = c.rng(1);
     a.topup();
@@ -1904,7 +1913,7 @@ __device__ inline uint32_t simplex_prob_vector(const Vx &c, const GParams BT_CAS
 
 // ---- sampleHaplotypeFrequencies (VariantClusterGenotyper.cpp:781-785 -> HaplotypeFrequencyDistribution.cpp:127-138
 //      -> FrequencyDistribution.cpp:75-93 / 209-303) ----
-__device__ BT_NOINLINE void sample_haplotype_frequencies(Env env, uint32_t vtx) {
+__device__ BT_SWEEPFN void sample_haplotype_frequencies(Env env, uint32_t vtx) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     const TileDesc BT_CAS &d = c.d();

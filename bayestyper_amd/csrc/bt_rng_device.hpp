@@ -25,21 +25,34 @@ namespace bt {
 
 #define BT_HD __host__ __device__ inline
 // out-of-line device functions of the samplers; the translation unit of gibbs_simple_kernel inlines them under its own register budget
+// BT_SWEEPFN: the functions a sweep calls per vertex visit.  Out of line they each save and restore ~120 callee-saved registers per call
+// (30 KB of scratch traffic per wavefront and call); BT_SWEEP_INLINE makes them part of the kernel body instead.
+#if defined(BT_SIMPLE_TU) || defined(BT_SWEEP_INLINE)
+#define BT_SWEEPFN inline
+#else
+#define BT_SWEEPFN static __noinline__
+#endif
 #ifdef BT_SIMPLE_TU
 #define BT_NOINLINE
 #else
-#define BT_NOINLINE __noinline__
+#define BT_NOINLINE static __noinline__   // (internal linkage: the code generator then drops the callee-saved register convention for them)
 #endif
 
 // fp64 transcendental functions.  On the device they are out-of-line: ocml's double-precision log/exp/log1p/pow need many
 // registers; keeping them as separate functions keeps the samplers' own allocation small enough for 2-4 waves per SIMD.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BT_MATH __host__ __device__ __noinline__
+#ifdef BT_INLINE_MATH
+#define BT_MATHI __host__ __device__ inline
+#else
+#define BT_MATHI BT_MATH
+#endif
 #else
 #define BT_MATH __host__ __device__ inline
+#define BT_MATHI BT_MATH
 #endif
-BT_MATH double bt_log(double x) { return log(x); }
-BT_MATH double bt_exp(double x) { return exp(x); }
+BT_MATHI double bt_log(double x) { return log(x); }
+BT_MATHI double bt_exp(double x) { return exp(x); }
 BT_MATH double bt_log1p(double x) { return log1p(x); }
 BT_MATH double bt_pow(double x, double y) { return pow(x, y); }
 

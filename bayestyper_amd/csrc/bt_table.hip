@@ -591,8 +591,16 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_kernel(BloomView bloom, const
         if (threadIdx.x == 0) qn = 0;
         __syncthreads();
     };
+    // The flush decision must be the same in every thread (flush() holds barriers): it is taken on a register that bounds the queue
+    // length from above — at most BLOCK entries per iteration — not on the shared counter, which faster wavefronts may already have
+    // advanced when a slower one reads it.
+    uint32_t q_bound = 0;
     for (uint32_t i0 = lo; i0 < hi; i0 += BLOCK) {
-        if (qn + BLOCK > QCAP) flush();   // (uniform: qn is read after a barrier)
+        if (q_bound + BLOCK > QCAP) {
+            flush();
+            q_bound = 0;
+        }
+        q_bound += BLOCK;
         const uint32_t i = i0 + threadIdx.x;
         bool member = i < hi;
         uint32_t idx = 0;
@@ -629,6 +637,44 @@ __global__ __launch_bounds__(BLOCK) void kmc_apply_kernel(KmcView v, TableView t
     if (hit_count) {   // one atomic per wavefront
         for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_down(my_hits, off);
         if ((threadIdx.x & 63u) == 0 && my_hits) atomicAdd(hit_count, (unsigned long long)my_hits);
+    }
+}
+
+// count rows (bt_table_export_count_rows / bt_table_merge_count_rows): 16 key bytes + spad count bytes per record with a non-zero count
+__global__ __launch_bounds__(BLOCK) void export_count_rows_kernel(TableView t, uint64_t cap, uint8_t *__restrict__ rows, uint64_t capacity_rows, unsigned long long *__restrict__ num_rows) {
+    const uint32_t words = t.spad / 4u, row_words = 4u + words;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK) {
+        if (t.state[i] != ST_READY) continue;
+        uint32_t any = 0;
+        for (uint32_t w = 0; w < words; ++w) any |= t.counts[i * words + w];
+        if (!any) continue;
+        const unsigned long long at = atomicAdd(num_rows, 1ULL);
+        if (at >= capacity_rows) continue;   // (sizing pass, or an undersized buffer: the host compares the counter with the capacity)
+        uint32_t *out = reinterpret_cast<uint32_t *>(rows) + at * row_words;
+        const uint64_t lo = t.key_lo[i], hi = t.key_hi[i];
+        out[0] = (uint32_t)lo;
+        out[1] = (uint32_t)(lo >> 32);
+        out[2] = (uint32_t)hi;
+        out[3] = (uint32_t)(hi >> 32);
+        for (uint32_t w = 0; w < words; ++w) out[4 + w] = t.counts[i * words + w];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void merge_count_rows_kernel(TableView t, const uint8_t *__restrict__ rows, uint64_t n) {
+    const uint32_t words = t.spad / 4u, row_words = 4u + words;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(rows) + r * row_words;
+        Kmer a;
+        a.lo = (uint64_t)in[0] | ((uint64_t)in[1] << 32);
+        a.hi = (uint64_t)in[2] | ((uint64_t)in[3] << 32);
+        const int64_t slot = table_find_or_insert(t, a);
+        if (slot < 0) continue;
+        for (uint32_t w = 0; w < words; ++w) {
+            const uint32_t c = in[4 + w];
+            for (uint32_t b = 0; b < 4u; ++b) {
+                const uint32_t add = (c >> (8u * b)) & 0xFFu;
+                if (add) sat_add_byte(t.counts, (uint64_t)slot * t.spad + 4u * w + b, add);
+            }
+        }
     }
 }
 
@@ -858,6 +904,43 @@ int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *
         ++w;
     }
     *num_written = w;
+    return BT_OK;
+}
+
+int bt_table_count_row_bytes(bt_table *t, uint32_t *row_bytes) {
+    if (!t || !row_bytes) return fail("bt_table_count_row_bytes: null argument");
+    *row_bytes = 16u + t->spad;
+    return BT_OK;
+}
+
+int bt_table_export_count_rows(bt_table *t, uint8_t *d_rows, uint64_t capacity_rows, uint64_t *h_num_rows) {
+    if (!t || !h_num_rows || (capacity_rows && !d_rows)) return fail("bt_table_export_count_rows: null argument");
+    BT_HIP(hipSetDevice(t->ctx->device));
+    unsigned long long *d_n = nullptr;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_n), 8));
+    hipError_t e = hipMemsetAsync(d_n, 0, 8, t->ctx->stream);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((t->capacity + BLOCK - 1) / BLOCK, 1u << 16);
+        hipLaunchKernelGGL(export_count_rows_kernel, dim3(grid), dim3(BLOCK), 0, t->ctx->stream, t->v, t->capacity, d_rows, capacity_rows, d_n);
+        e = hipGetLastError();
+    }
+    unsigned long long n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, t->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(t->ctx->stream);
+    (void)hipFree(d_n);
+    if (e != hipSuccess) return fail(std::string("bt_table_export_count_rows: ") + hipGetErrorString(e));
+    *h_num_rows = n;
+    if (capacity_rows && n > capacity_rows) return fail("bt_table_export_count_rows: output buffer too small");
+    return BT_OK;
+}
+
+int bt_table_merge_count_rows(bt_table *t, const uint8_t *d_rows, uint64_t num_rows) {
+    if (!t || (num_rows && !d_rows)) return fail("bt_table_merge_count_rows: null argument");
+    if (num_rows == 0) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    const unsigned grid = (unsigned)std::min<uint64_t>((num_rows + BLOCK - 1) / BLOCK, 1u << 16);
+    hipLaunchKernelGGL(merge_count_rows_kernel, dim3(grid), dim3(BLOCK), 0, t->ctx->stream, t->v, d_rows, num_rows);
+    BT_CHECK_LAUNCH();
     return BT_OK;
 }
 

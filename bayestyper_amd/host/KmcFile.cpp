@@ -96,14 +96,19 @@ KmcFile::~KmcFile() {
     if (map) munmap(map, map_bytes);
 }
 
-uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, uint64_t chunk_records) {
+uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, uint64_t chunk_records, uint64_t first_record,
+                          uint64_t num_records) {
+    if (first_record > db.total_kmers) first_record = db.total_kmers;
+    if (num_records > db.total_kmers - first_record) num_records = db.total_kmers - first_record;
+    if (num_records == 0) return 0;
     bt_kmc_scan *scan = nullptr;
     if (bt_kmc_scan_create_bins(ctx, db.kmer_length, db.lut_prefix_length, db.counter_size, db.total_kmers, db.prefix_lut().data(), db.prefix_lut().size(), &scan) != BT_OK)
         throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
     bt_kmc_scan_set_count_range(scan, db.min_count, db.max_count);   // ReadNextKmer's counter filter (kmc_file.cpp:496-511)
     uint64_t hits = 0;
     // copies from the page cache (mmap) into pinned staging, H2D transfers and scan kernels of consecutive chunks overlap inside the library
-    const int rc = bt_kmc_scan_run_host(scan, path_bloom, table, sample_idx, db.records(), 0, db.total_kmers, chunk_records, &hits);
+    const uint64_t rec_bytes = (db.kmer_length - db.lut_prefix_length) / 4 + db.counter_size;
+    const int rc = bt_kmc_scan_run_host(scan, path_bloom, table, sample_idx, db.records() + first_record * rec_bytes, first_record, num_records, chunk_records, &hits);
     bt_kmc_scan_destroy(scan);
     if (rc != BT_OK) throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
     return hits;

@@ -34,6 +34,8 @@ class KmcFile {
 
 // KmerCounter::parseSampleKmers for ONE sample: every record of the database through decode -> path-Bloom lookup -> (hit)
 // addKmer + addSampleCount(sample_idx).  Returns the number of Bloom hits.  chunk_records: records per host-to-device copy.
-uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, uint64_t chunk_records = 1ull << 24);
+// [first_record, first_record + num_records): the part of the database this rank scans (default: all of it)
+uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, uint64_t chunk_records = 1ull << 24, uint64_t first_record = 0,
+                          uint64_t num_records = ~0ull);
 
 }  // namespace bthost

@@ -6,6 +6,7 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "Comm.hpp"
 #include "KmcFile.hpp"
 #include "Options.hpp"
 
@@ -366,14 +367,52 @@ void KmerCounter::countInterclusterKmers(bt_table *table, bt_bloom *path_bloom, 
     checkTable(table, "countInterclusterKmers");
 }
 
-void KmerCounter::parseSampleKmers(bt_table *table, bt_bloom *path_bloom) {
+void KmerCounter::parseSampleKmers(bt_table *table, bt_bloom *path_bloom, Comm *comm) {
+    const uint64_t world = comm ? (uint64_t)comm->world() : 1, rank = comm ? (uint64_t)comm->rank() : 0;
     for (size_t s = 0; s < samples.size(); s++) {
         std::cout << "[" << getLocalTime() << "] Parsing kmers from sample " << samples[s].name << " ..." << std::endl;
         KmcFile db(samples[s].file);
         if (db.kmer_length != kmer_size) throw std::runtime_error("KMC database " + samples[s].file + " holds " + std::to_string(db.kmer_length) + "-mers, not " + std::to_string(kmer_size) + "-mers");
-        const uint64_t hits = bthost::parseSampleKmers(ctx, db, path_bloom, table, (uint32_t)s);
+        // rank r of w scans records [r * total / w, (r + 1) * total / w): a byte range of the .kmc_suf payload
+        const uint64_t first = db.total_kmers / world * rank + std::min<uint64_t>(rank, db.total_kmers % world);
+        const uint64_t count = db.total_kmers / world + (rank < db.total_kmers % world ? 1 : 0);
+        uint64_t hits = bthost::parseSampleKmers(ctx, db, path_bloom, table, (uint32_t)s, 1ull << 24, first, count);
+        if (comm) comm->allreduceHist(&hits, 1);
         std::cout << "[" << getLocalTime() << "] Parsed " << db.total_kmers << " kmers (" << hits << " passed the path kmer filter)" << std::endl;
     }
+    if (!comm) return;
+    // merge: a (k-mer, sample) count comes from ONE KMC record, i.e. from one rank; before the scans the replicas are identical and hold no
+    // counts, so the records with a non-zero count are exactly what a rank's scans added
+    checkTable(table, "parseSampleKmers");
+    uint32_t row_bytes = 0;
+    check(bt_table_count_row_bytes(table, &row_bytes), "bt_table_count_row_bytes");
+    uint64_t mine = 0;
+    check(bt_table_export_count_rows(table, nullptr, 0, &mine), "bt_table_export_count_rows");
+    std::vector<uint64_t> sizes((size_t)world, 0);
+    sizes[rank] = mine;
+    comm->allreduceHist(sizes.data(), sizes.size());
+    uint64_t total = 0;
+    for (uint64_t n : sizes) total += n;
+    void *d_mine = nullptr, *d_all = nullptr;
+    check(bt_malloc(ctx, std::max<uint64_t>(mine, 1) * row_bytes, &d_mine), "bt_malloc");
+    check(bt_malloc(ctx, std::max<uint64_t>(total, 1) * row_bytes, &d_all), "bt_malloc");
+    try {
+        uint64_t written = 0;
+        check(bt_table_export_count_rows(table, (uint8_t *)d_mine, std::max<uint64_t>(mine, 1), &written), "bt_table_export_count_rows");
+        if (written != mine) throw std::runtime_error("parseSampleKmers: the table changed between sizing and export");
+        const std::vector<uint64_t> off = comm->allgatherDevice((const uint8_t *)d_mine, mine * row_bytes, (uint8_t *)d_all, std::max<uint64_t>(total, 1) * row_bytes);
+        for (uint64_t r = 0; r < world; r++)
+            if (r != rank && off[r + 1] > off[r]) check(bt_table_merge_count_rows(table, (const uint8_t *)d_all + off[r], (off[r + 1] - off[r]) / row_bytes), "bt_table_merge_count_rows");
+        check(bt_sync(ctx), "bt_sync");
+    } catch (...) {
+        bt_free(ctx, d_mine);
+        bt_free(ctx, d_all);
+        throw;
+    }
+    bt_free(ctx, d_mine);
+    bt_free(ctx, d_all);
+    checkTable(table, "parseSampleKmers (merge)");
+    std::cout << "[" << getLocalTime() << "] Merged the sample counts of " << world << " ranks (" << total << " kmers with counts)" << std::endl;
 }
 
 GibbsBatchData KmerCounter::classifyPathKmers(bt_table *table, const InferenceUnit &unit, const UnitGraphs &ug, const std::string &multigroup_kmers_bloom_prefix,

@@ -53,6 +53,8 @@ struct GibbsBatchData {
     uint32_t numClusters() const { return (uint32_t)cluster_idx.size(); }
 };
 
+class Comm;
+
 class KmerCounter {
   public:
     KmerCounter(bt_ctx *ctx, const std::vector<Sample> &samples, unsigned kmer_size, unsigned prng_seed);
@@ -65,7 +67,9 @@ class KmerCounter {
     // ---- genotype stage (KmerCounter.cpp:252-555) ----
     void countPathKmers(bt_bloom *path_bloom, const InferenceUnit &unit, const UnitGraphs &graphs);   // keeps the enumerated paths for classifyPathKmers
     void countInterclusterKmers(bt_table *table, bt_bloom *path_bloom, const std::string &intercluster_regions_prefix, const Chromosomes &chromosomes, const ChromosomePloidy &chrom_ploidy);
-    void parseSampleKmers(bt_table *table, bt_bloom *path_bloom);
+    // comm (several ranks): every rank scans its byte range of every sample's database into its replica of the table; the records with
+    // counts are then all-gathered and merged, so that every rank holds the table a one-rank scan fills
+    void parseSampleKmers(bt_table *table, bt_bloom *path_bloom, Comm *comm = nullptr);
     // classifyPathKmers, then getHaplotypeCandidates of every cluster against the classified table -> the unit's Gibbs batch
     GibbsBatchData classifyPathKmers(bt_table *table, const InferenceUnit &unit, const UnitGraphs &graphs, const std::string &multigroup_kmers_bloom_prefix,
                                      const ChromosomePloidy &chrom_ploidy);

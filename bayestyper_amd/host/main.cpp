@@ -9,7 +9,18 @@
 // Gibbs sampler run on the GPU through libbtgpu.so (KmerCounter.hpp, InferenceEngine.hpp); there is no CPU fallback.
 // variant_clusters.bin is this build's own format (InferenceUnit.hpp), not the reference's Boost archive.
 // The k-mer size is a build constant in the reference (BT_KMER_SIZE, 55 in the released binaries); here BT_KMER_SIZE in the environment overrides 55.
+//
+// Several GPUs of one node (`genotype` only; the reference's -p/--threads has no meaning here): one process per GPU (Comm.hpp).
+//   BT_GPUS=N bayesTyper genotype ...      this process becomes rank 0 and starts ranks 1..N-1 itself (GPU r for rank r)
+//   BT_WORLD=N BT_RANK=r BT_COMM_ID_FILE=<path> bayesTyper genotype ...   ranks started by a launcher of one's own
+// Every rank reads the inputs; the KMC scan of every sample is split by record range and the matched counts are merged (all-gather); the
+// unit's variant-cluster groups are dealt to the ranks (every group keeps its unit-wide index, from which its seeds derive); the noise
+// drivers add up their histograms with one all-reduce per iteration; rank 0 gathers the collected samples and writes the outputs —
+// byte for byte the files of a one-GPU run.
 #include <sys/stat.h>
+#include <signal.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -20,6 +31,7 @@
 #include <iostream>
 #include <sstream>
 
+#include "Comm.hpp"
 #include "CountDistribution.hpp"
 #include "GenotypeWriter.hpp"
 #include "Genotypes.hpp"
@@ -48,9 +60,9 @@ void check(int rc, const char *what) {
 
 struct Context {
     bt_ctx *h = nullptr;
-    Context() {
+    Context() {   // BT_DEVICE, else the rank (one GPU per rank of a multi-GPU run), else GPU 0
         const char *dev = getenv("BT_DEVICE");
-        check(bt_ctx_create(dev ? atoi(dev) : 0, &h), "bt_ctx_create");
+        check(bt_ctx_create(dev ? atoi(dev) : Comm::envRank(), &h), "bt_ctx_create");
     }
     ~Context() { bt_ctx_destroy(h); }
 };
@@ -305,6 +317,9 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     const std::string multigroup_kmers_dir_prefix = cluster_data_dir + "/" + multigroup_kmers_file_prefix;
 
     Context ctx;
+    std::unique_ptr<Comm> comm = Comm::fromEnvironment(ctx.h);   // nullptr: one rank
+    const int rank = comm ? comm->rank() : 0, world = comm ? comm->world() : 1;
+    if (comm) std::cout << stamp() << "Rank " << rank << " of " << world << " (one GPU per rank)" << std::endl;
     KmerCounter kmer_counter(ctx.h, samples, kmer_size, gibbs.seed);
     std::unique_ptr<BloomHandle> path_kmer_bloom(new BloomHandle());   // ThreadedKmerBloom(num_path_kmers + max_parameter_kmers, 0.0001)
     check(bt_bloom_create(ctx.h, unit.num_path_kmers + max_parameter_kmers, 0.0001f, kmer_size, 1, &path_kmer_bloom->h), "bt_bloom_create");
@@ -346,14 +361,16 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     kmer_counter.countPathKmers(path_kmer_bloom->h, unit, graphs);
     kmer_counter.countInterclusterKmers(kmer_hash.h, path_kmer_bloom->h, intercluster_regions_dir_prefix, chromosomes, chrom_ploidy);
     std::cout << std::endl;
-    kmer_counter.parseSampleKmers(kmer_hash.h, path_kmer_bloom->h);
+    kmer_counter.parseSampleKmers(kmer_hash.h, path_kmer_bloom->h, comm.get());
     path_kmer_bloom.reset();
     std::cout << std::endl;
     const GibbsBatchData batch = kmer_counter.classifyPathKmers(kmer_hash.h, unit, graphs, multigroup_kmers_dir_prefix, chrom_ploidy);
     std::cout << "\n" << std::endl;
 
+    // (every rank holds the whole table: the same moments, the same count model; only rank 0's files are kept)
+    const std::string rank_suffix = rank == 0 ? "" : ".rank" + std::to_string(rank);
     CountDistribution count_distribution((unsigned short)S, noise_rate_prior, gibbs.seed);
-    setGenomicCountDistributions(&count_distribution, kmer_hash.h, samples, output_prefix + "_genomic_parameters");
+    setGenomicCountDistributions(&count_distribution, kmer_hash.h, samples, output_prefix + "_genomic_parameters" + rank_suffix);
     bt_table_destroy(kmer_hash.h);   // the bundles hold everything the sampler needs
     kmer_hash.h = nullptr;
 
@@ -365,9 +382,27 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
         names[s] = samples[s].name;
     }
     InferenceEngine inference_engine(ctx.h, gender, names, gibbs);
+    // this rank's groups: the whole unit, or its share (ascending unit-wide group indices; LPT on a cost proxy, the same on every rank)
+    std::vector<std::vector<uint32_t>> rank_groups;
+    std::vector<uint32_t> unit_clusters, unit_variants;   // per group of the WHOLE unit (estimateNoise selects its groups from them on every rank alike)
+    GibbsBatchData shard;
+    if (comm) {
+        inference_engine.setHistReducer([&](uint64_t *hist, size_t n) { comm->allreduceHist(hist, n); });
+        rank_groups = assignGroups(batch, world);
+        shard = batch.take(rank_groups[rank]);
+        for (uint32_t g = 0; g < batch.numGroups(); g++) {
+            unit_clusters.push_back(batch.group_cluster_off[g + 1] - batch.group_cluster_off[g]);
+            uint32_t nv = 0;
+            for (uint32_t c = batch.group_cluster_off[g]; c < batch.group_cluster_off[g + 1]; c++) nv += batch.num_variants[c];
+            unit_variants.push_back(nv);
+        }
+    }
+    const GibbsBatchData &my_batch = comm ? shard : batch;
+    const std::string noise_prefix = output_prefix + "_noise_parameters" + rank_suffix;
     if (!noise_genotyping) {
         std::cout << "\n" << std::endl;
-        inference_engine.estimateNoise(&count_distribution, batch, output_prefix + "_noise_parameters");
+        inference_engine.estimateNoise(&count_distribution, my_batch, noise_prefix, NoiseGroupSelector::noise_variants_batch_size, comm ? &unit_clusters : nullptr,
+                                       comm ? &unit_variants : nullptr);
     }
     std::cout << "\n" << std::endl;
 
@@ -410,15 +445,77 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
             }
         }
     };
-    if (!noise_genotyping) inference_engine.estimateGenotypes(batch, count_distribution, collect);
-    else inference_engine.estimateNoiseAndGenotypes(batch, &count_distribution, collect, output_prefix + "_noise_parameters");
+    if (!comm) {
+        if (!noise_genotyping) inference_engine.estimateGenotypes(batch, count_distribution, collect);
+        else inference_engine.estimateNoiseAndGenotypes(batch, &count_distribution, collect, noise_prefix);
+    } else {
+        // every rank samples its groups; the collected samples are gathered to rank 0, which turns them into genotypes in the unit's order
+        BatchResults mine;
+        mine.dip_off.push_back(0);
+        mine.cell_off.push_back(0);
+        const InferenceEngine::Collector keep = [&](const GibbsBatchData &b, const BatchResults &r) {   // launches arrive in group order
+            const uint32_t C = b.numClusters();
+            const uint64_t e0 = mine.dip_off.back(), k0 = mine.cell_off.back(), nd = r.dip_off[C], nc = r.cell_off[C];
+            for (uint32_t c = 0; c < C; c++) {
+                mine.dip_off.push_back(e0 + r.dip_off[c + 1]);
+                mine.cell_off.push_back(k0 + r.cell_off[c + 1]);
+            }
+            mine.h1.insert(mine.h1.end(), r.h1.begin(), r.h1.begin() + nd);
+            mine.h2.insert(mine.h2.end(), r.h2.begin(), r.h2.begin() + nd);
+            mine.freq.insert(mine.freq.end(), r.freq.begin(), r.freq.begin() + nd * S);
+            mine.stats.insert(mine.stats.end(), r.stats.begin(), r.stats.begin() + nc * 12);
+        };
+        if (!noise_genotyping) inference_engine.estimateGenotypes(my_batch, count_distribution, keep);
+        else inference_engine.estimateNoiseAndGenotypes(my_batch, &count_distribution, keep, noise_prefix);
+        if (mine.dip_off.size() != (size_t)my_batch.numClusters() + 1) throw std::runtime_error("rank " + std::to_string(rank) + ": collected samples do not cover the rank's clusters");
+        const BatchResults all = gatherResults(*comm, batch, rank_groups, mine, (uint32_t)S);
+        if (rank == 0) collect(batch, all);
+    }
+    if (rank != 0) {   // rank 0 writes the outputs; the other ranks' parameter files are copies of its own
+        std::remove((output_prefix + "_genomic_parameters" + rank_suffix + ".txt").c_str());
+        std::remove((noise_prefix + ".txt").c_str());
+        comm->barrier();
+        return 0;
+    }
 
     const uint32_t num_genotyped_variants = genotype_writer.finalise(output_prefix, options.getBool("gzip-output"), options.getString("genome-file"), unit.cluster_options_header, options.getHeader());
     std::cout << "\n" << stamp() << "Out of " << unit.num_variants << " variants:\n" << std::endl;
     std::cout << "\t- " << num_genotyped_variants << " were genotyped" << std::endl;
     std::cout << "\t- " << unit.num_variants - num_genotyped_variants << " were skipped (unsupported)" << std::endl;
     std::cout << "\n\n" << stamp() << "BayesTyper genotype completed succesfully!\n" << std::endl;
+    if (comm) comm->barrier();
     return 0;
+}
+
+// BT_GPUS=N: this process becomes rank 0 of N and starts the other ranks as copies of itself (before anything touches the GPU); their
+// output goes to <output-prefix>.rank<r>.log.  Returns the children's pids (empty when the ranks were started by someone else).
+std::vector<pid_t> startRanks(int argc, char *const argv[]) {
+    std::vector<pid_t> children;
+    const char *gpus = getenv("BT_GPUS");
+    const int n = gpus ? atoi(gpus) : 1;
+    if (n <= 1 || getenv("BT_WORLD")) return children;
+    if (argc < 2 || std::strcmp(argv[1], "genotype") != 0) return children;
+    std::string prefix = "bayestyper";   // -o / --output-prefix (main.cpp:379)
+    for (int i = 2; i + 1 < argc; i++)
+        if (std::strcmp(argv[i], "-o") == 0 || std::strcmp(argv[i], "--output-prefix") == 0) prefix = argv[i + 1];
+    const std::string id_file = prefix + ".comm_id." + std::to_string((long)getpid());
+    std::remove(id_file.c_str());
+    setenv("BT_WORLD", std::to_string(n).c_str(), 1);
+    setenv("BT_COMM_ID_FILE", id_file.c_str(), 1);
+    for (int r = 1; r < n; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) throw std::runtime_error("cannot start rank " + std::to_string(r));
+        if (pid == 0) {
+            setenv("BT_RANK", std::to_string(r).c_str(), 1);
+            const std::string log = prefix + ".rank" + std::to_string(r) + ".log";
+            if (!freopen(log.c_str(), "w", stdout) || !freopen(log.c_str(), "a", stderr)) _exit(1);
+            execv("/proc/self/exe", argv);
+            _exit(127);
+        }
+        children.push_back(pid);
+    }
+    setenv("BT_RANK", "0", 1);
+    return children;
 }
 
 }  // namespace
@@ -431,14 +528,30 @@ int main(int argc, char *const argv[]) {
         std::cout << command_info << std::endl;
         return 0;
     }
+    std::vector<pid_t> children;
+    int rc = 0;
     try {
         if (kmer_size < 1 || kmer_size > 64) throw std::runtime_error("BT_KMER_SIZE must be between 1 and 64");
         if (std::strcmp(argv[1], "cluster") == 0) return runCluster(argc, argv, kmer_size);
-        if (std::strcmp(argv[1], "genotype") == 0) return runGenotype(argc, argv, kmer_size);
-        std::cout << command_info << std::endl;
-        return 0;
+        if (std::strcmp(argv[1], "genotype") == 0) {
+            children = startRanks(argc, argv);
+            rc = runGenotype(argc, argv, kmer_size);
+        } else {
+            std::cout << command_info << std::endl;
+            return 0;
+        }
     } catch (const std::exception &e) {   // the reference prints "\nERROR: ...\n" and exits with 1
         std::cerr << "\nERROR: " << e.what() << "\n" << std::endl;
-        return 1;
+        rc = 1;
     }
+    for (pid_t pid : children) {   // the ranks this process started
+        int status = 0;
+        if (rc != 0) kill(pid, SIGTERM);   // rank 0 failed: the others would wait for it forever
+        if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+            if (rc == 0) std::cerr << "\nERROR: a rank of this run failed (see <output-prefix>.rank<r>.log)\n" << std::endl;
+            rc = 1;
+        }
+    }
+    if (!children.empty() && getenv("BT_COMM_ID_FILE")) std::remove(getenv("BT_COMM_ID_FILE"));
+    return rc;
 }

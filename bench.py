@@ -16,8 +16,11 @@ mixture of BASELINE.md §3 (90 % biallelic SNV/indel groups, 8 % multi-variant c
 clusters with up to 32 x S haplotype candidates), every structure with its own dimensions (bayestyper_amd/synth.py: hetero_group) and
 every group with its own truth genotypes and counts; a whole genome (5-15 x 10^6 groups) is a sequence of such launches.  KMC: a
 2x10^8-record stream per sample (13-byte records, k=55, p=7), 2 % path-k-mer hit rate against a fpr-1e-4 ThreadedKmerBloom of
-2.5x10^7 path k-mers.  --samples 10 gives the north star's 10-sample mixture.  Weak scaling (default): every rank gets a batch of the
-same size (its own groups, its own KMC stream); --scaling strong shards ONE batch over the ranks (LPT on a cost proxy).
+5x10^7 path k-mers (SURVEY 8d's stream: 10^9 records per sample).  --samples 10 gives the north star's 10-sample mixture.
+Several GPUs (--gpus N, one rank per GPU): ONE batch is sharded over the ranks (LPT on a cost proxy, every group keeps its unit-wide index) and
+every rank scans its own share of the KMC stream; the posterior summaries are gathered to rank 0 through the product's own exchange library
+(libbtcomm.so: RCCL over xGMI; torch.distributed/gloo only passes the communicator id), and rank 0 then runs the unsharded batch and checks
+that the gathered summaries equal it (config.sharded_equals_unsharded).  --scaling weak gives every rank its own batch of the full size instead.
 
 Prints ONE JSON line (rank 0).  `value` = variant-cluster Gibbs iterations (cluster-sweeps) per second over the whole job; k-mer
 matches/sec is reported beside it.  `roofline` describes the dominant kernel (the Gibbs sweep kernel); `roofline_kmer_match` the KMC
@@ -49,10 +52,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--groups", type=int, default=600_000, help="variant-cluster groups per GPU")
     ap.add_argument("--samples", type=int, default=3)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--verify", action="store_true", help="strong scaling: rank 0 also runs the unsharded batch afterwards; the gathered summaries must equal it")
-    ap.add_argument("--records", type=int, default=200_000_000, help="KMC records per GPU per step")
-    ap.add_argument("--path-kmers", type=int, default=25_000_000)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: strong (one batch sharded over the ranks) when --gpus > 1")
+    ap.add_argument("--no-verify", action="store_true", help="strong scaling: skip the check of the gathered summaries against the unsharded batch (run by rank 0 after the timed region)")
+    ap.add_argument("--records", type=int, default=1_000_000_000, help="KMC records per sample per step (whole job under strong scaling: every rank scans its share)")
+    ap.add_argument("--path-kmers", type=int, default=50_000_000)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target duration of the all-cores CPU leg (the sample is sized from a short probe)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sub-records (ten-sample mixture, joint noise genotyping, C4-sized sub-filters)")
+    ap.add_argument("--unique-structures", action="store_true", help="every multi-variant / nested / many-candidate group gets a structure of its own (slow to generate)")
     ap.add_argument("--hit-rate", type=float, default=0.02)
     ap.add_argument("--cpu-groups-per-core", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,8 +83,6 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
 
     from bayestyper_amd import lib, synth
     from bayestyper_amd.host import count_model
@@ -86,22 +90,35 @@ def main():
     ctx = lib.Ctx(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     S = args.samples
+    comm = None
+    if world > 1:
+        # the exchange steps are the product's (libbtcomm.so: RCCL on the context's stream); the gloo group only carries the communicator id
+        from bayestyper_amd import comm as btcomm
+
+        dist.init_process_group(backend="gloo")
+        ident = [btcomm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        comm = btcomm.Comm(ctx, ident[0], rank, world)
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
 
     # ------------------------------------------------------------------ Gibbs batch (this rank's groups)
     from bayestyper_amd import shard
 
     strong = args.scaling == "strong" and world > 1
+    verify = strong_verify = args.scaling == "strong" and world > 1 and not args.no_verify
+    mix_templates = {"B": 10 ** 9, "C": 10 ** 9, "D": 10 ** 9} if args.unique_structures else None   # (capped at the class's group count)
     if strong:     # ONE batch, sharded: every rank builds the same unit and keeps its groups (global group indices -> seeds)
-        unit = synth.make_mixture(args.groups, S, seed=1000)
+        unit = synth.make_mixture(args.groups, S, seed=1000, templates=mix_templates)
         my_ids = shard.assign_groups(shard.group_cost(unit), world)[rank]
         flat = shard.take_groups(unit, my_ids)
         my_clusters = shard.cluster_ids_of(unit, my_ids)
         flat["mixture"] = unit["mixture"]
         C_total = unit["num_clusters"]
-        if not (args.verify and rank == 0):
+        if not (verify and rank == 0):
             del unit
     else:          # weak: a batch of the same size per rank
-        flat = synth.make_mixture(args.groups, S, seed=1000 + rank)
+        flat = synth.make_mixture(args.groups, S, seed=1000 + rank, templates=mix_templates)
         flat["group_index"] = (flat["group_index"].astype(np.uint64) + rank * flat["num_groups"]).astype(np.uint32)   # global group index -> seeds
         C_total = flat["num_clusters"] * world
     G, C = flat["num_groups"], flat["num_clusters"]
@@ -111,16 +128,18 @@ def main():
     gibbs_chains, gibbs_device_bytes = gibbs.params.num_chains, gibbs.device_bytes()
     cluster_sweeps_per_step = C_total * sweeps_per_group          # whole job
     d_summary = torch.zeros(C * S * 2, dtype=torch.int32, device=dev)
-    if world > 1:   # ranks hold different numbers of clusters under strong scaling: padded gather
+    if world > 1:   # variable-length gather (bt_comm_gather_summaries): rank 0 receives the ranks' parts in rank order
         c_all = torch.zeros(world, dtype=torch.int64, device=dev)
         c_all[rank] = C
-        dist.all_reduce(c_all)
-        c_max = int(c_all.max().item())
-        d_pad = torch.zeros(c_max * S * 2, dtype=torch.int32, device=dev)
-        gathered = [torch.zeros_like(d_pad) for _ in range(world)] if rank == 0 else None
+        comm.allreduce(c_all.data_ptr(), world)
+        torch.cuda.synchronize()
+        c_all = [int(x) for x in c_all.tolist()]
+        d_gathered = torch.zeros(sum(c_all) * S * 2 if rank == 0 else 2, dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------ KMC stream + path Bloom + count table (in HBM)
-    R = args.records
+    # under strong scaling the job's stream of args.records records per sample is split over the ranks (every rank scans its share against the
+    # replicated path filter, as the executable's ranks do with their record ranges); weak scaling gives every rank a stream of its own
+    R = args.records // world if strong else args.records
     gen = torch.Generator(device=dev)
     gen.manual_seed(4 + rank)
     records = torch.randint(0, 256, (R * REC + 16,), dtype=torch.uint8, device=dev, generator=gen)
@@ -130,18 +149,25 @@ def main():
     scan = lib.KmcScan(ctx, K, KMC_P, 1, R, lut)
     bloom = lib.Bloom.create(ctx, args.path_kmers + 1_000_000, 1e-4, K, threaded=True)       # main.cpp:517
     n_hit = int(R * args.hit_rate)
-    # members that are in the database: decode a strided subset of the records on the device, insert into the path Bloom
-    kmers = torch.zeros((R, 2), dtype=torch.int64, device=dev)
-    cnts = torch.zeros(R, dtype=torch.int32, device=dev)
-    lib.check(lib.bt_kmc_scan_decode(scan.h, records.data_ptr(), 0, R, kmers.data_ptr(), cnts.data_ptr()))
+    # members that are in the database: decode the records on the device (a chunk at a time), insert a strided subset into the path Bloom
     stride = max(1, R // max(n_hit, 1))
-    members = kmers[::stride][:n_hit].contiguous()
-    lib.check(lib.bt_bloom_insert_batch(bloom.h, members.data_ptr(), members.shape[0]))
+    CH = 50_000_000 // stride * stride or stride
+    kmers = torch.zeros((min(CH, R), 2), dtype=torch.int64, device=dev)
+    cnts = torch.zeros(min(CH, R), dtype=torch.int32, device=dev)
+    inserted = 0
+    for a in range(0, R, CH):
+        m = min(CH, R - a)
+        lib.check(lib.bt_kmc_scan_decode(scan.h, records.data_ptr() + a * REC, a, m, kmers.data_ptr(), cnts.data_ptr()))
+        members = kmers[:m:stride][: max(0, n_hit - inserted)].contiguous()
+        if members.shape[0]:
+            lib.check(lib.bt_bloom_insert_batch(bloom.h, members.data_ptr(), members.shape[0]))
+        inserted += members.shape[0]
+        torch.cuda.synchronize()
     absent = torch.randint(-(2 ** 62), 2 ** 62, (max(args.path_kmers - n_hit, 1), 2), dtype=torch.int64, device=dev, generator=gen)
     absent[:, 1] &= (1 << 46) - 1            # 55-mers: 110 bits
     lib.check(lib.bt_bloom_insert_batch(bloom.h, absent.data_ptr(), absent.shape[0]))
     torch.cuda.synchronize()
-    del kmers, cnts, absent
+    del kmers, cnts, absent, members
     table = lib.Table(ctx, max(int(n_hit * 1.5), 1024), S, K)
     d_hits = torch.zeros(1, dtype=torch.int64, device=dev)
     t_gibbs, t_kmc = lib.Timer(ctx), [lib.Timer(ctx) for _ in range(S)]
@@ -164,15 +190,14 @@ def main():
         # (3) posterior summaries -> rank 0
         lib.check(lib.bt_gibbs_posterior_summary(gibbs.h, d_summary.data_ptr()))
         if world > 1:
-            d_pad[: C * S * 2] = d_summary
-            dist.gather(d_pad, gathered, dst=0)
+            comm.gather_words(d_summary.data_ptr(), C * S * 2, d_gathered.data_ptr(), d_gathered.numel())
         if timed:
             return [t.elapsed_ms() for t in t_kmc], t_gibbs.elapsed_ms()
         return None
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            comm.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -187,7 +212,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     hits = int(d_hits.item())
@@ -198,18 +223,17 @@ def main():
     # ------------------------------------------------------------------ strong scaling self-check: gathered summaries == the unsharded run
     verified = None
     if strong:
-        if rank == 0:
+        if rank == 0:   # the assignment is deterministic: rank 0 knows every rank's clusters
             whole = torch.zeros(C_total * S * 2, dtype=torch.int32, device=dev).view(C_total, S * 2)
-        ids_t = torch.from_numpy(np.ascontiguousarray(my_clusters).astype(np.int64)).to(dev)
-        id_pad = torch.full((c_max,), -1, dtype=torch.int64, device=dev)
-        id_pad[:C] = ids_t
-        id_all = [torch.zeros_like(id_pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(id_pad, id_all, dst=0)
-        if rank == 0:
+            parts = shard.assign_groups(shard.group_cost(unit), world) if verify else None
+            at = 0
             for r in range(world):
-                n = int((id_all[r] >= 0).sum().item())
-                whole[id_all[r][:n]] = gathered[r][: n * S * 2].view(n, S * 2)
-            if args.verify:
+                n = c_all[r]
+                if verify:
+                    ids_r = torch.from_numpy(np.ascontiguousarray(shard.cluster_ids_of(unit, parts[r])).astype(np.int64)).to(dev)
+                    whole[ids_r] = d_gathered[at * S * 2: (at + n) * S * 2].view(n, S * 2)
+                at += n
+            if verify:
                 gibbs.close()
                 g_all = lib.Gibbs(ctx, unit, lut_g, lut_n, seed=42)
                 g_all.run()
@@ -219,7 +243,7 @@ def main():
                 verified = bool(torch.equal(ref_summary.view(C_total, S * 2), whole))
                 g_all.close()
                 if not verified:
-                    raise RuntimeError("bench --verify: the gathered summaries of the sharded run differ from the unsharded run")
+                    raise RuntimeError("bench: the gathered summaries of the sharded run differ from the unsharded run")
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only): the oracle on host cores
     cpu = None
@@ -229,17 +253,29 @@ def main():
 
         orc = _oracle.load_oracle()
         cores = os.cpu_count() or 1
-        n_cpu = max(2048, min(args.groups, args.cpu_groups_per_core * cores))
-        cflat = synth.make_mixture(n_cpu, S, seed=999)
         og_lut_g, og_lut_n = _oracle.build_luts(orc, S)
-        og = _oracle.OrcGibbs(orc, cflat, og_lut_g, og_lut_n, seed=42)
-        tc = time.perf_counter()
-        og.run(cores)
-        cpu_s = time.perf_counter() - tc
-        og.close()
+
+        def cpu_leg(n_groups, threads, seed):
+            cf = synth.make_mixture(n_groups, S, seed=seed)
+            og = _oracle.OrcGibbs(orc, cf, og_lut_g, og_lut_n, seed=42)
+            tc = time.perf_counter()
+            og.run(threads)
+            dt = time.perf_counter() - tc
+            og.close()
+            return cf, dt
+
+        # all cores: a short probe sizes the sample for ~args.cpu_seconds of work (the tail of a small sample — a few long nested groups per
+        # thread — would otherwise dominate); one core: a sample of its own, a few seconds
+        probe, probe_s = cpu_leg(max(2048, 16 * cores), cores, 998)
+        rate = probe["num_clusters"] * sweeps_per_group / probe_s
+        n_cpu = int(max(4096, min(args.groups, args.cpu_seconds * rate / sweeps_per_group * probe["num_groups"] / probe["num_clusters"])))
+        cflat, cpu_s = cpu_leg(n_cpu, cores, 999)
         cpu_sweeps = cflat["num_clusters"] * sweeps_per_group
-        # k-mer matching on one core: decode -> Bloom lookup for a bounded slice of an equivalent database
-        kcpu = None
+        one_flat, one_s = cpu_leg(max(256, int(n_cpu / cores * 0.4)), 1, 997)
+        cpu_one = one_flat["num_clusters"] * sweeps_per_group / one_s
+        # k-mer matching: decode -> Bloom lookup for a bounded slice of an equivalent database — the reference's shape (ONE producer thread
+        # decoding the KMC records, KmerCounter.cpp:469-505) and the best-effort shape (every core decodes its own record range)
+        kcpu = kcpu_par = None
         try:
             import tempfile
 
@@ -256,14 +292,28 @@ def main():
                 tk = time.perf_counter()
                 orc.l.orc_match_only(ob.h, db.h, 0, db.total)
                 kcpu = db.total / (time.perf_counter() - tk)
+                import threading
+
+                nthr = min(cores, 64)
+                per = db.total // nthr
+                thr = [threading.Thread(target=orc.l.orc_match_only, args=(ob.h, db.h, i * per, per)) for i in range(nthr)]   # (ctypes releases the GIL)
+                tk = time.perf_counter()
+                for t_ in thr:
+                    t_.start()
+                for t_ in thr:
+                    t_.join()
+                kcpu_par = per * nthr / (time.perf_counter() - tk)
                 ob.close()
                 db.close()
         except Exception:   # the k-mer CPU leg is informative only
-            kcpu = None
+            pass
         cpu = {"value": cpu_sweeps / cpu_s, "unit": "cluster-sweeps/s", "cores": cores, "kind": "port",
                "sample": f"{cflat['num_groups']} groups of the same shape mixture ({cflat['mixture']}), S={S}, full 20x350 schedule, "
                          f"{cpu_s:.1f} s on {cores} threads (oracle/oracle_gibbs.cpp; threads pull groups from a shared queue, largest first, as InferenceEngine.cpp:335-382)",
-               "kmer_matches_per_sec_1core": kcpu}
+               "one_core": {"value": cpu_one, "sample": f"{one_flat['num_groups']} groups of the same mixture, {one_s:.1f} s on 1 thread"},
+               "kmer_matches_per_sec_single_producer": kcpu, "kmer_matches_per_sec_parallel_decode": kcpu_par,
+               "kmer_match_note": "400 000-record database: one thread decoding and probing (the reference's single producer is the serial stage) / "
+                                  "every core its own record range (up to 64 threads)"}
 
     # ------------------------------------------------------------------ graph stages (rank 0, outside the timed region): best-path search,
     # path k-mer enumeration, classification, haplotype candidates on synthetic SNV/indel clusters — reported beside the headline metric
@@ -380,6 +430,8 @@ def main():
             out["gpu_over_cpu_allcores"] = out["gibbs_kernel_cluster_sweeps_per_sec"] / cpu["value"]
         print(json.dumps(out))
     if world > 1:
+        comm.barrier()
+        comm.close()
         dist.destroy_process_group()
 
 

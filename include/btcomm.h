@@ -42,9 +42,15 @@ int bt_comm_allreduce_hist(bt_comm *c, uint64_t *d_hist, uint64_t n);
  * h_offsets[world_size + 1] (every rank) receives the word offsets of the ranks' parts; on rank 0 d_out (capacity out_capacity words)
  * receives the parts in rank order */
 int bt_comm_gather_summaries(bt_comm *c, const uint32_t *d_local, uint64_t local_words, uint32_t *d_out, uint64_t out_capacity, uint64_t *h_offsets);
+/* all-gather of variable-length byte arrays: every rank's d_local (local_bytes bytes) lands in every rank's d_out in rank order,
+ * h_offsets[world_size + 1] = byte offsets of the parts (the count rows of bt_table_export_count_rows after a KMC scan sharded by byte range:
+ * every rank merges the other ranks' rows into its replica of the count table) */
+int bt_comm_allgatherv(bt_comm *c, const uint8_t *d_local, uint64_t local_bytes, uint8_t *d_out, uint64_t out_capacity, uint64_t *h_offsets);
 /* variable all-to-all of byte records: h_send_bytes[r] bytes of d_send (parts in rank order, contiguous) go to rank r; d_recv receives the
  * parts of all ranks in rank order, h_recv_bytes[r] = bytes received from rank r.  Record framing (e.g. 18-byte (k-mer, sample, count)
- * tuples) is the caller's. */
+ * tuples) is the caller's.
+ * In all three variable-size calls the ranks agree on failure: capacities and null-buffer flags travel with the sizes, every rank evaluates
+ * the same conditions, so either all ranks post their transfers or all return the error (no rank is left waiting in a send). */
 int bt_comm_alltoallv_matches(bt_comm *c, const uint8_t *d_send, const uint64_t *h_send_bytes, uint8_t *d_recv, uint64_t recv_capacity, uint64_t *h_recv_bytes);
 
 #ifdef __cplusplus

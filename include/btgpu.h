@@ -164,6 +164,15 @@ int bt_table_find_batch(bt_table *t, const uint64_t *d_kmers, uint64_t n, int64_
 int bt_table_read_slots(bt_table *t, const int64_t *h_slots, uint64_t n, uint8_t *h_counts, uint8_t *h_meta);
 /* export every stored record (iteration order unspecified); arrays sized by bt_table_status */
 int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *h_meta, uint64_t max_records, uint64_t *num_written);
+/* Merging the sample counts of tables filled by ranks that each scanned their own byte range of the samples' KMC databases
+ * (KmerCounter::parseSampleKmers, KmerCounter.cpp:431-524, sharded over GPUs; a (k-mer, sample) count comes from exactly one KMC record,
+ * i.e. from one rank).  A count row = 16 key bytes (lo, hi) + *row_bytes - 16 count bytes (the samples' counts, padded to 4).
+ * bt_table_export_count_rows: every record with a non-zero sample count -> d_rows (device, capacity_rows rows; *h_num_rows = number of
+ * such records, an error if it exceeds the capacity — call with capacity 0 and d_rows NULL to size the buffer).
+ * bt_table_merge_count_rows: addKmer + saturating addSampleCount of every sample for each row (rows of OTHER ranks). */
+int bt_table_count_row_bytes(bt_table *t, uint32_t *row_bytes);
+int bt_table_export_count_rows(bt_table *t, uint8_t *d_rows, uint64_t capacity_rows, uint64_t *h_num_rows);
+int bt_table_merge_count_rows(bt_table *t, const uint8_t *d_rows, uint64_t num_rows);
 
 /* ObservedKmerCountsHash<N>::calculateKmerStats (src/bayesTyper/KmerHash.cpp:256-340): one pass over the table.
  * h_class_counts[7] = {total, unique, multicluster, decoy, max_multiplicity, multigroup, non_cluster} exactly as the reference

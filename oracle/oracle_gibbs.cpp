@@ -973,9 +973,11 @@ void orc_gibbs_init_chain(void *h, uint32_t chain) {
 }
 void orc_gibbs_sweep(void *h, uint32_t n, int collect) {
     OracleGibbs *O = (OracleGibbs *)h;
-    for (auto &G : O->groups) {
-        uint32_t sweep_no = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < n; i++) estimateGenotypes(*O, G, collect != 0, nullptr, sweep_no);
+    for (size_t gi = 0; gi < O->groups.size(); gi++) {   // (traces, when enabled, continue where the previous call stopped)
+        Group &G = O->groups[gi];
+        std::vector<uint32_t> *trace = O->trace_sweeps ? &O->traces[gi] : nullptr;
+        uint32_t sweep_no = trace ? (uint32_t)(trace->size() / (G.vertices.size() * O->P.num_samples)) : 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < n; i++) estimateGenotypes(*O, G, collect != 0, trace, sweep_no);
     }
 }
 void orc_gibbs_noise_counts(void *h, uint64_t *hist, int zero_first) {   // getNoiseCounts + clearGenotyperCache

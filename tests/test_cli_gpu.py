@@ -351,10 +351,14 @@ def test_cluster_then_genotype_equal_the_oracle_pipeline(oracle, tmp_path, genom
         assert agree >= 0.97 * len(truth), (i, agree)
 
 
-def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
+@pytest.mark.parametrize("num_samples,gibbs,noise_genotyping", [(2, dict(chains=3, burn=10, samples=25), False), (10, dict(chains=3, burn=20, samples=50), True)],
+                         ids=["two-samples-default-mode", "ten-samples-noise-genotyping"])
+def test_sv_rich_candidates_through_the_executable(oracle, tmp_path, num_samples, gibbs, noise_genotyping):
     """The executable on candidates of every flavour the parser distinguishes — SNVs, indels, multi-allelic records, MNVs and blocks of structural
-    variants with variants nested inside their alleles (nested variant-cluster groups, '*' alleles, ACO attributes) — and two samples (female,
-    male) whose haplotypes carry random subsets of the candidate alleles: every output file against the oracle pipeline."""
+    variants with variants nested inside their alleles (nested variant-cluster groups, '*' alleles, ACO attributes) — and samples (female,
+    male alternating) whose haplotypes carry random subsets of the candidate alleles: every output file against the oracle pipeline.  The second case
+    is BASELINE configs[3]'s sample count through the shipped C++ estimateNoiseAndGenotypes (--noise-genotyping, InferenceEngine.cpp:384-472): ten
+    samples, nested SV groups, 3 x (20 + 50) iterations, every noise rate of every iteration and the VCF body."""
     from test_pipeline_gpu import sample_haplotype
 
     ref = _oracle.load_ref()
@@ -373,7 +377,7 @@ def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
         fh.write(">chr1\n" + "\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + "\n")
     open(d / "candidates.vcf", "w").write(vcf)
     with open(d / "samples.tsv", "w") as sf:
-        for s, gender in enumerate(["F", "M"]):
+        for s, gender in enumerate((["F", "M"] * 5)[:num_samples]):
             text = "N".join(sample_haplotype(rng, seq, records) for _ in range(2))
             km, va = oracle.kmers_from_sequence(text.encode(), K)
             present = np.unique(km[va == 1], axis=0)
@@ -381,9 +385,9 @@ def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
             asc = oracle.unpack(present, K).reshape(-1, K)
             order = np.lexsort(asc.T[::-1])                     # KMC order = ascending ASCII order
             prefix = str(d / f"sample{s + 1}")
-            if s == 0:
+            if s % 2 == 0:
                 oracle.kmc_write(prefix, np.ascontiguousarray(asc[order]).reshape(-1), cnt[order], K, 7, 1)
-            else:   # the second sample's database in the KMC2 ("0x200") layout: five signature bins
+            else:   # every second sample's database in the KMC2 ("0x200") layout: five signature bins
                 oracle.kmc2_write(prefix, np.ascontiguousarray(asc[order]).reshape(-1), cnt[order], K, 7, 1, 5)
             bloom = OrcBloom(oracle, len(present), 1e-3, K)
             bloom.insert(np.ascontiguousarray(asc).reshape(-1))
@@ -391,15 +395,15 @@ def test_sv_rich_candidates_through_the_executable(oracle, tmp_path):
             bloom.close()
             sf.write(f"sample{s + 1}\t{gender}\t{prefix}\n")
     ds = {"genome": seq, "dir": str(d)}
-    seed, gibbs = 11, dict(chains=3, burn=10, samples=25)
+    seed = 11
     prefix = str(tmp_path / "bt")
     r = subprocess.run([EXE, "cluster", "-v", str(d / "candidates.vcf"), "-s", str(d / "samples.tsv"), "-g", str(d / "genome.fa"), "-o", prefix, "-r", str(seed)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr
     r = subprocess.run([EXE, "genotype", "-v", prefix + "_unit_1/variant_clusters.bin", "-c", prefix + "_cluster_data", "-s", str(d / "samples.tsv"), "-g", str(d / "genome.fa"), "-o", prefix,
-                        "-r", str(seed), "--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]), "--gibbs-samples", str(gibbs["samples"])],
-                       capture_output=True, text=True)
+                        "-r", str(seed), "--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]), "--gibbs-samples", str(gibbs["samples"])]
+                       + (["--noise-genotyping"] if noise_genotyping else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr
-    want = oracle_pipeline(oracle, ref, ds, seed, gibbs)
+    want = oracle_pipeline(oracle, ref, ds, seed, gibbs, noise_genotyping)
     assert want["num_clusters"] > want["num_groups"] > 20          # nested variant-cluster groups are present
     assert gzip.open(prefix + "_cluster_data/intercluster_regions.txt.gz", "rt").read() == want["regions_text"]
     got_params = gzip.open(prefix + "_cluster_data/parameter_kmers.fa.gz", "rt").read().split("\n")
@@ -483,3 +487,59 @@ def test_sex_chromosomes_and_decoys_through_the_executable(oracle, tmp_path, plo
         assert all("/" in x[9].split(":")[0] for x in rows if x[0] in ("chr1", "chrX"))
     else:
         assert all("/" not in x[9].split(":")[0] and "/" in x[10].split(":")[0] for x in rows if x[0] == "chrX")
+
+
+def _genotype(prefix, unit_prefix, ds_dir, seed, gibbs, extra_args=(), env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([EXE, "genotype", "-v", unit_prefix + "_unit_1/variant_clusters.bin", "-c", unit_prefix + "_cluster_data", "-s", os.path.join(ds_dir, "samples.tsv"), "-g",
+                        os.path.join(ds_dir, "genome.fa"), "-o", prefix, "-r", str(seed), "--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]),
+                        "--gibbs-samples", str(gibbs["samples"])] + list(extra_args), capture_output=True, text=True, env=e)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "BayesTyper genotype completed succesfully!" in r.stdout
+    return r.stdout
+
+
+def _outputs(prefix):
+    vcf = [x for x in open(prefix + ".vcf").read().split("\n") if not x.startswith("##BayesTyperOptions=")]   # (the options line names the output prefix)
+    return vcf, open(prefix + "_noise_parameters.txt").read(), open(prefix + "_genomic_parameters.txt").read()
+
+
+def _sharded_equals_single(oracle, tmp_path, ranks_env, noise_genotyping):
+    """`bayesTyper genotype` on several ranks (BT_GPUS: the process forks its ranks; host/Comm.hpp) against the same command on one rank: the KMC
+    scan split by record range + count merge, the groups dealt to the ranks, the per-iteration histogram reduction of the noise drivers and the
+    gather of the collected samples must leave every output file as the one-rank run writes it (which the tests above compare with the oracle)."""
+    ds = c1_dataset.make(str(tmp_path / "data"), oracle, 70_000, 350, 3, num_error_kmers=150_000, genders=["F", "M", "F"])
+    seed, gibbs = 7, dict(chains=3, burn=12, samples=30)
+    unit_prefix = str(tmp_path / "bt")
+    r = subprocess.run([EXE, "cluster", "-v", os.path.join(ds["dir"], "candidates.vcf"), "-s", os.path.join(ds["dir"], "samples.tsv"), "-g", os.path.join(ds["dir"], "genome.fa"), "-o", unit_prefix,
+                        "-r", str(seed)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr
+    extra = ["--noise-genotyping"] if noise_genotyping else []
+    one = str(tmp_path / "one")
+    _genotype(one, unit_prefix, ds["dir"], seed, gibbs, extra)
+    many = str(tmp_path / "many")
+    out = _genotype(many, unit_prefix, ds["dir"], seed, gibbs, extra, env=ranks_env)
+    assert "Rank 0 of " in out and "Merged the sample counts of" in out
+    a, b = _outputs(one), _outputs(many)
+    assert a[0] == b[0] and len(a[0]) > 300
+    assert a[1] == b[1] and a[2] == b[2]
+    n = int(ranks_env["BT_GPUS"])
+    for r_ in range(1, n):   # the other ranks leave a log, no parameter files
+        assert os.path.exists(many + f".rank{r_}.log") and not os.path.exists(many + f"_noise_parameters.rank{r_}.txt")
+    assert not [f for f in os.listdir(tmp_path) if ".comm_id" in f]
+
+
+@pytest.mark.parametrize("noise_genotyping", [False, True], ids=["default-mode", "noise-genotyping"])
+def test_three_ranks_sharing_one_gpu(oracle, tmp_path, noise_genotyping):
+    """three ranks on GPU 0 exchanging through files (BT_COMM_TRANSPORT=files: RCCL forms no communicator over ranks that share a GPU) — the
+    sharded run's logic on a one-GPU box"""
+    _sharded_equals_single(oracle, tmp_path, {"BT_GPUS": "3", "BT_COMM_TRANSPORT": "files", "BT_DEVICE": "0"}, noise_genotyping)
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_visible(oracle, tmp_path):
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _sharded_equals_single(oracle, tmp_path, {"BT_GPUS": "2", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, True)

@@ -24,6 +24,7 @@ def _comm_lib():
     dll.bt_comm_allreduce_hist.argtypes = [vp, vp, C.c_uint64]
     dll.bt_comm_gather_summaries.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp]
     dll.bt_comm_alltoallv_matches.argtypes = [vp, vp, vp, vp, C.c_uint64, vp]
+    dll.bt_comm_allgatherv.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp]
     return lib, dll
 
 
@@ -66,8 +67,23 @@ def _rank_body(rank, world, id_bytes, queue):
     ctx.sync()
     assert list(recv_sizes) == [(q + rank + 1) * 18 for q in range(world)]
     assert np.array_equal(dr.download(np.uint8, recv_total), np.concatenate([np.full((q + rank + 1) * 18, 16 * q + rank, np.uint8) for q in range(world)]))
-    # too small a receive buffer is an error, not a truncation
-    assert dll.bt_comm_alltoallv_matches(h, ds.ptr, send_sizes.ctypes.data, dr.ptr, recv_total - 1, recv_sizes.ctypes.data) != 0
+    # too small a receive buffer is an error, not a truncation — and an error on EVERY rank, also when only ONE rank's buffer is short
+    # (the capacities travel with the sizes: nobody is left waiting in a send)
+    assert dll.bt_comm_alltoallv_matches(h, ds.ptr, send_sizes.ctypes.data, dr.ptr, recv_total - (1 if rank == world - 1 else 0), recv_sizes.ctypes.data) != 0
+    assert dll.bt_comm_gather_summaries(h, dl.ptr, len(local), out.ptr, total - (1 if rank == 0 else 0), offs.ctypes.data) != 0
+    assert dll.bt_comm_alltoallv_matches(h, None, send_sizes.ctypes.data, dr.ptr, recv_total, recv_sizes.ctypes.data) != 0     # null send buffer with sizes
+    # all-gather of variable-length byte strings: rank r contributes 7 + 5r bytes of value 100 + r
+    mine = np.full(7 + 5 * rank, 100 + rank, np.uint8)
+    dm = ctx.to_device(mine)
+    ag_total = sum(7 + 5 * q for q in range(world))
+    dg = ctx.buffer(ag_total)
+    ag_offs = np.zeros(world + 1, np.uint64)
+    lib.check(dll.bt_comm_allgatherv(h, dm.ptr, len(mine), dg.ptr, ag_total, ag_offs.ctypes.data))
+    ctx.sync()
+    assert list(ag_offs) == [sum(7 + 5 * q for q in range(i)) for i in range(world + 1)]
+    assert np.array_equal(dg.download(np.uint8, ag_total), np.concatenate([np.full(7 + 5 * q, 100 + q, np.uint8) for q in range(world)]))
+    assert dll.bt_comm_allgatherv(h, dm.ptr, len(mine), dg.ptr, ag_total - (1 if rank == 0 else 0), ag_offs.ctypes.data) != 0
+    dm.free(), dg.free()
     lib.check(dll.bt_comm_destroy(h))
     for b in (d, dl, out, ds, dr):
         b.free()

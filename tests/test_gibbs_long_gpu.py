@@ -139,3 +139,56 @@ def test_mixed_tile_classes_full_schedule_S3(gpu_ctx, oracle):
         parts.append(f)
     flat = synth.concat(parts)
     run_full(gpu_ctx, oracle, flat, seed=101, trace_all=True, **FULL)
+
+
+def _noise_genotyping_case(gpu_ctx, oracle, flat, kw):
+    """estimateNoiseAndGenotypes through the C++ InferenceEngine (the class the executable ships, bound by host/inference_engine.py) against the
+    oracle's restatement of InferenceEngine.cpp:384-472: every sampled noise rate of every iteration of every chain, then the collected samples"""
+    from bayestyper_amd.host import count_model
+    from bayestyper_amd.host.inference_engine import InferenceEngine
+
+    S = flat["S"]
+    flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
+
+    def cd():
+        d = count_model.CountDistribution(S, prior=(1.0, 0.01), seed=kw["seed"])
+        for s in range(S):
+            d.set_genomic(s, 15.0, 30.0)
+        return d
+
+    cd_o, cd_g = cd(), cd()
+    og = _oracle.OrcGibbs(oracle, flat, *cd_o.tables(), noise_seeding=1, **kw)
+    want = og.estimate_noise_and_genotypes()
+    ro = og.results()
+    og.close()
+    eng = InferenceEngine(gpu_ctx, kw["seed"], burn=kw["burn"], samples=kw["iters"], chains=kw["chains"])
+    gg, got = eng.estimate_noise_and_genotypes(flat, cd_g)
+    rg = gg.results()
+    gg.close()
+    assert got.shape == want.shape == (kw["chains"] * (1 + kw["burn"] + kw["iters"]), 2 + S)
+    assert np.array_equal(got, want), f"noise rates diverge at row {int(np.argwhere((got != want).any(axis=1))[0, 0])}"
+    exact = assert_parity(flat, ro, rg, kw["chains"] * kw["iters"])
+    assert exact == flat["num_clusters"]
+
+
+def test_noise_genotyping_ten_samples_sv_rich_cpp_engine(gpu_ctx, oracle):
+    """BASELINE configs[3]'s sample count in --noise-genotyping mode: nested SV groups with multicluster k-mers, multi-variant clusters, a
+    many-candidate cluster and two-haplotype clusters in one unit, 3 x (20 + 50) iterations (caches cleared every iteration)"""
+    from bayestyper_amd import synth
+
+    S = 10
+    flat = synth.concat([synth.make_hetero_batch("D", 1, S, seed=61), synth.make_hetero_batch("C", 5, S, seed=62), synth.make_hetero_batch("B", 10, S, seed=63),
+                         synth.make_hetero_batch("A", 40, S, seed=64)])
+    assert int(flat["multi_off"][-1]) > 0
+    _noise_genotyping_case(gpu_ctx, oracle, flat, dict(seed=2468, chains=3, burn=20, iters=50))
+
+
+def test_config_C5_thirty_samples_joint_cpp_engine(gpu_ctx, oracle):
+    """BASELINE configs[4]: --noise-genotyping, 30 samples, --max-number-of-sample-haplotypes 32 (256 merged candidates per cluster) next to
+    small clusters, 2 x (10 + 20) iterations through the C++ estimateNoiseAndGenotypes"""
+    from bayestyper_amd import synth
+
+    S = 30
+    flat = synth.concat([synth.make_batch("D", 2, S, seed=51), synth.make_hetero_batch("B", 3, S, seed=52), synth.make_hetero_batch("A", 11, S, seed=53)])
+    assert int(flat["num_haplotypes"].max()) == 256
+    _noise_genotyping_case(gpu_ctx, oracle, flat, dict(seed=4321, chains=2, burn=10, iters=20))
