@@ -123,6 +123,9 @@ struct bt_gibbs {
     uint32_t trace_sweeps = 0;
     uint32_t *d_trace = nullptr, *d_trace_counter = nullptr;
     uint64_t trace_words = 0;
+    // bt_gibbs_noise_iteration: pinned staging of the histogram (device -> host) and of the noise table (host -> device), device histogram
+    uint64_t *h_pin_hist = nullptr, *d_iter_hist = nullptr;
+    double *h_pin_noise = nullptr;
 };
 
 namespace {
@@ -865,6 +868,9 @@ int bt_gibbs_destroy(bt_gibbs *g) {
         if (p) (void)hipFree(p);
     if (g->d_trace) (void)hipFree(g->d_trace);
     if (g->d_trace_counter) (void)hipFree(g->d_trace_counter);
+    if (g->h_pin_hist) (void)hipHostFree(g->h_pin_hist);
+    if (g->h_pin_noise) (void)hipHostFree(g->h_pin_noise);
+    if (g->d_iter_hist) (void)hipFree(g->d_iter_hist);
     for (auto &c : g->classes) {
         if (c.stream) {
             (void)hipStreamSynchronize(c.stream);
@@ -916,6 +922,31 @@ int bt_gibbs_noise_counts(bt_gibbs *g, uint64_t *d_hist, int zero_first) {
     BT_HIP(hipSetDevice(g->ctx->device));
     if (zero_first) BT_HIP(hipMemsetAsync(d_hist, 0, (size_t)g->S * 256 * 8, g->ctx->stream));
     return launch(g, OP_NOISE, 0, 0, reinterpret_cast<unsigned long long *>(d_hist));
+}
+
+int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_samples, uint64_t *h_hist) {
+    if (!g || !h_hist) return fail("bt_gibbs_noise_iteration: null argument");
+    BT_HIP(hipSetDevice(g->ctx->device));
+    const size_t nh = (size_t)g->S * 256;
+    if (!g->h_pin_hist) {
+        BT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_pin_hist), nh * 8, hipHostMallocDefault));
+        BT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_pin_noise), nh * 8, hipHostMallocDefault));
+        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_iter_hist), nh * 8));
+    }
+    hipStream_t st = g->ctx->stream;
+    if (h_noise) {   // (the staging buffer is free: the previous call ended with a synchronisation after its upload)
+        std::memcpy(g->h_pin_noise, h_noise, nh * 8);
+        BT_HIP(hipMemcpyAsync(g->d_lut_n, g->h_pin_noise, nh * 8, hipMemcpyHostToDevice, st));
+    }
+    int rc = launch(g, OP_SWEEP, 1, collect_samples ? 1u : 0u, nullptr);
+    if (rc != BT_OK) return rc;
+    BT_HIP(hipMemsetAsync(g->d_iter_hist, 0, nh * 8, st));
+    rc = launch(g, OP_NOISE, 0, 0, reinterpret_cast<unsigned long long *>(g->d_iter_hist));
+    if (rc != BT_OK) return rc;
+    BT_HIP(hipMemcpyAsync(g->h_pin_hist, g->d_iter_hist, nh * 8, hipMemcpyDeviceToHost, st));
+    BT_HIP(hipStreamSynchronize(st));
+    std::memcpy(h_hist, g->h_pin_hist, nh * 8);
+    return BT_OK;
 }
 
 int bt_gibbs_reset_groups(bt_gibbs *g) {

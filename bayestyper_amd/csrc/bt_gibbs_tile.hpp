@@ -156,7 +156,10 @@ struct TileDesc {
     uint32_t wsh;                   // log2 of the tile's width W (power of two >= num_lanes): every array of the tile is interleaved over W lanes, in HBM and in LDS
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
-constexpr uint32_t EV_CAP = 8;            // logged runs per (cluster, sample) before the log is applied early
+#ifndef BT_EV_CAP
+#define BT_EV_CAP 8
+#endif
+constexpr uint32_t EV_CAP = BT_EV_CAP;    // logged runs per (cluster, sample) before the log is applied early
 constexpr uint32_t KSC_WAYS = 4;          // recently rebuilt k-mer-stats caches kept per (cluster, sample), see collect_sample_body
 constexpr uint32_t KSC_NOKEY = 0xFFFEFFFEu;   // (haplotype indices are < 0xFFFE)
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;

@@ -195,8 +195,13 @@ struct MtRingT {
     RP ring;                   // element i of the ring block at ring[i] (LDS when the cluster's hot arrays are resident, else HBM)
     uint32_t cap;              // power of two, <= 64
     uint32_t pos, head, avail;
-    // generate n more words (n <= cap - avail), bursts of 16
-    BT_HD void generate(uint32_t n) {
+    // generate n more words (n <= cap - avail), bursts of 16.  UNIFORM: the caller has checked that n is the same in every lane of the
+    // wavefront; it is then held in a scalar register, and the slots a burst does not need are skipped by scalar branches
+    template <bool UNIFORM>
+    BT_HD void generate_t(uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (UNIFORM) n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+#endif
         while (n > 0) {
             const uint32_t c = n < 16u ? n : 16u, p = pos;
             uint32_t a[17], b[16];
@@ -216,10 +221,28 @@ struct MtRingT {
             n -= c;
         }
     }
+    BT_HD void generate(uint32_t n) { generate_t<false>(n); }
+#if defined(BT_RING_REFILL_OUTLINE) && defined(__HIP_DEVICE_COMPILE__)
+    // Refills are calls: ONE copy of the 16-word burst (600 instructions) instead of one per draw site.  When every lane of the wavefront
+    // asks for the same number of words (the diplotype generator of a 64-cluster tile: exactly two words per sample and sweep in every
+    // lane) the count is a scalar and the unused slots of a burst are skipped by scalar branches instead of being issued under an empty mask.
+    __device__ __noinline__ void generate_uniform(uint32_t n) { generate_t<true>(n); }
+    __device__ __noinline__ void generate_vector(uint32_t n) { generate_t<false>(n); }
+    __device__ inline void generate_out(uint32_t n) {
+        const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+        if (__builtin_amdgcn_ballot_w64(n != nu) == 0) generate_uniform(n);
+        else generate_vector(n);
+    }
+    __device__ inline void topup() { generate_out(cap - avail); }
+    __device__ inline void need(uint32_t n) {
+        if (avail < n) generate_out(cap - avail < 16u ? cap - avail : 16u);
+    }
+#else
     BT_HD void topup() { generate(cap - avail); }
     BT_HD void need(uint32_t n) {
         if (avail < n) generate(cap - avail < 16u ? cap - avail : 16u);
     }
+#endif
     BT_HD uint32_t next() {
         need(1);
         const uint32_t w = ring[head];

@@ -56,6 +56,12 @@ struct DeviceBuffer {
 }  // namespace
 
 int Comm::envRank() { return envInt("BT_RANK", 0); }
+void Comm::markFailed() {
+    const char *id_file = getenv("BT_COMM_ID_FILE");
+    if (envWorld() <= 1 || !id_file || !*id_file) return;
+    std::ofstream f(std::string(id_file) + ".failed");
+    f << "rank " << envRank() << "\n";
+}
 int Comm::envWorld() { return std::max(1, envInt("BT_WORLD", 1)); }
 
 std::unique_ptr<Comm> Comm::fromEnvironment(bt_ctx *ctx) {
@@ -129,9 +135,23 @@ Comm::Comm() {}
 Comm::~Comm() {
     if (comm && api) api->destroy(comm);
     if (dl) dlclose(dl);
-    if (!dir.empty()) {   // the last exchange's files; rank 0 removes the directory when it is empty
-        for (uint64_t s = seq > 2 ? seq - 2 : 0; s <= seq; s++) std::remove((dir + "/" + std::to_string(s) + "." + std::to_string(rank_)).c_str());
-        if (rank_ == 0) rmdir(dir.c_str());
+    if (!dir.empty()) {
+        // A rank's file of the LAST exchange may still be unread by a slower rank, so nobody removes its own: every rank leaves a "done"
+        // marker when it is through, and rank 0 clears the directory once all markers are there (or after a while, if a rank died).
+        { std::ofstream f(dir + "/done." + std::to_string(rank_)); }
+        if (rank_ == 0) {
+            for (int tries = 0; tries < 3000; ++tries) {
+                int done = 0;
+                for (int r = 0; r < world_; r++) done += access((dir + "/done." + std::to_string(r)).c_str(), F_OK) == 0 ? 1 : 0;
+                if (done == world_) break;
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+            for (int r = 0; r < world_; r++) {
+                std::remove((dir + "/done." + std::to_string(r)).c_str());
+                for (uint64_t s = seq > 2 ? seq - 2 : 0; s <= seq; s++) std::remove((dir + "/" + std::to_string(s) + "." + std::to_string(r)).c_str());
+            }
+            rmdir(dir.c_str());
+        }
     }
 }
 
@@ -159,7 +179,10 @@ std::vector<std::vector<uint8_t>> Comm::exchangeFiles(const void *mine, size_t b
                 f.seekg(0);
                 if (len == 0 || f.read((char *)all[r].data(), len)) got = true;
             }
-            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(tries < 100 ? 1 : 10));
+            if (!got) {
+                if (tries % 20 == 19 && access((dir.substr(0, dir.size() - 2) + ".failed").c_str(), F_OK) == 0) throw std::runtime_error("files transport: another rank of this run failed");
+                std::this_thread::sleep_for(std::chrono::milliseconds(tries < 100 ? 1 : 10));
+            }
         }
         if (!got) throw std::runtime_error("files transport: rank " + std::to_string(r) + " did not reach exchange " + std::to_string(n));
     }

@@ -31,6 +31,9 @@ class Comm {
     // nullptr when the run has one rank (BT_WORLD unset or 1)
     static std::unique_ptr<Comm> fromEnvironment(bt_ctx *ctx);
     static int envRank();    // BT_RANK (0 when unset)
+    // a rank that fails says so (a marker next to BT_COMM_ID_FILE): ranks waiting in a files-transport exchange give up instead of waiting
+    // for it; with RCCL the process that started the ranks ends the run (host/main.cpp)
+    static void markFailed();
     static int envWorld();   // BT_WORLD (1 when unset)
     ~Comm();
     int rank() const { return rank_; }

@@ -77,6 +77,11 @@ struct GpuSampler : GibbsSampler {
         check(bt_memcpy_d2h(ctx, h.data(), d_hist, h.size() * 8), "bt_memcpy_d2h");
         return h;
     }
+    std::vector<uint64_t> noiseIteration(const double *noise, bool collect) override {
+        std::vector<uint64_t> h((size_t)S * 256);
+        check(bt_gibbs_noise_iteration(g, noise, collect ? 1 : 0, h.data()), "bt_gibbs_noise_iteration");
+        return h;
+    }
     BatchResults results(uint32_t num_clusters) override {
         BatchResults r;
         uint64_t nd = 0, nc = 0;
@@ -129,16 +134,15 @@ bt_gibbs_params InferenceEngine::params(uint32_t noise_seeding) const {
 void InferenceEngine::iteration(Sampler *sampler, CountDistribution *cd, bool collect) {
     const size_t S = gender.size();
     std::vector<uint64_t> hist(S * 256, 0);
-    if (sampler) {
-        sampler->sweep(1, collect);
-        hist = sampler->noiseCounts();
-    }   // (a rank without groups in this chain still takes part in the reduction)
+    // the table drawn at the end of the previous iteration travels with this iteration's sweep (pending_noise); the first iteration of a
+    // chain finds the table set by the driver
+    if (sampler) hist = sampler->noiseIteration(pending_noise ? cd->noiseTable().data() : nullptr, collect);   // (a rank without groups in this chain still takes part in the reduction)
     if (reduce_hist) reduce_hist(hist.data(), hist.size());
     CountAllocation counts((unsigned short)S);
     for (size_t s = 0; s < S; s++)
         for (size_t c = 0; c < 256; c++) counts.counts()[s][c] = hist[s * 256 + c];
     cd->sampleNoiseParameters(counts);
-    if (sampler) sampler->setNoiseLut(cd->noiseTable().data());
+    pending_noise = true;
 }
 
 void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData &unit, const std::string &output_prefix, uint32_t variants_batch_size,
@@ -180,6 +184,7 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
             sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
             sampler->initChain(chain);
         }
+        pending_noise = false;   // (the chain's sampler starts with the current table)
         logRow(out, chain + 1, 0, cd->getNoiseRates());
         for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
             iteration(sampler.get(), cd, false);
@@ -264,6 +269,7 @@ void InferenceEngine::estimateNoiseAndGenotypes(const GibbsBatchData &unit, Coun
             sampler->setNoiseLut(cd->noiseTable().data());
             sampler->initChain(chain);
         }
+        pending_noise = false;
         logRow(out, chain + 1, 0, cd->getNoiseRates());
         for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
             iteration(sampler.get(), cd, it > opt.burn_in);

@@ -74,6 +74,13 @@ struct GibbsSampler {
     virtual void sweep(uint32_t n, bool collect) = 0;
     virtual void run() = 0;                                   // the whole default schedule
     virtual std::vector<uint64_t> noiseCounts() = 0;          // [S*256], VariantClusterGroup::getNoiseCounts of every group + clearGenotyperCache
+    // one iteration of the noise drivers: (the noise table drawn in the previous iteration, or nullptr;) one sweep; the noise counts.
+    // The GPU sampler does it with one synchronisation (bt_gibbs_noise_iteration).
+    virtual std::vector<uint64_t> noiseIteration(const double *noise, bool collect) {
+        if (noise) setNoiseLut(noise);
+        sweep(1, collect);
+        return noiseCounts();
+    }
     virtual BatchResults results(uint32_t num_clusters) = 0;
 };
 typedef std::function<std::unique_ptr<GibbsSampler>(const bt_gibbs_params &, const GibbsBatchData &)> SamplerFactory;
@@ -118,6 +125,7 @@ class InferenceEngine {
     uint32_t num_launches = 0;
     SamplerFactory make_sampler;
     bool record_rows = false, quiet = false;
+    bool pending_noise = false;   // the count distribution holds a noise table the sampler has not been given yet
     std::vector<double> noise_rows;
 };
 

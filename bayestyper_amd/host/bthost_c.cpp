@@ -6,6 +6,7 @@
 #include <sstream>
 #include <memory>
 
+#include "Comm.hpp"
 #include "CountDistribution.hpp"
 #include "GenotypeWriter.hpp"
 #include "Genotypes.hpp"
@@ -242,6 +243,45 @@ uint64_t bth_engine_noise_rows(void *h, double *out, uint64_t cap) {
     const std::vector<double> &r = ((EngineHandle *)h)->engine->noiseRows();
     if (out && cap >= r.size() && !r.empty()) std::memcpy(out, r.data(), r.size() * 8);
     return r.size();
+}
+
+// bthost::Comm over the files transport (no GPU needed): `rounds` rounds of all-reduce, byte all-gather and word gather with checked contents.
+// Called by every rank of a test run (BT_WORLD / BT_RANK / BT_COMM_ID_FILE / BT_COMM_TRANSPORT=files in the environment); 0 = all exchanges correct.
+int bth_comm_selftest(unsigned rounds, char *err, unsigned err_len) {
+    try {
+        std::unique_ptr<Comm> c = Comm::fromEnvironment(nullptr);
+        if (!c) throw std::runtime_error("bth_comm_selftest: BT_WORLD is 1");
+        const int W = c->world(), R = c->rank();
+        for (unsigned i = 0; i < rounds; i++) {
+            std::vector<uint64_t> h(5);
+            for (size_t j = 0; j < h.size(); j++) h[j] = (uint64_t)(R + 1) * (j + 1) + i;
+            c->allreduceHist(h.data(), h.size());
+            for (size_t j = 0; j < h.size(); j++)
+                if (h[j] != (uint64_t)W * (W + 1) / 2 * (j + 1) + (uint64_t)W * i) throw std::runtime_error("all-reduce: wrong sum");
+            std::vector<uint8_t> mine((size_t)(3 + R + i % 2), (uint8_t)(10 * R + i));
+            std::vector<uint64_t> off;
+            const std::vector<uint8_t> all = c->allgatherBytes(mine, &off);
+            for (int r = 0; r < W; r++) {
+                if (off[r + 1] - off[r] != (uint64_t)(3 + r + i % 2)) throw std::runtime_error("all-gather: wrong part size");
+                for (uint64_t b = off[r]; b < off[r + 1]; b++)
+                    if (all[b] != (uint8_t)(10 * r + i)) throw std::runtime_error("all-gather: wrong byte");
+            }
+            std::vector<uint32_t> words((size_t)(R == 1 ? 0 : 2 + R), (uint32_t)(1000 * R + i));   // (one rank contributes nothing)
+            const std::vector<uint32_t> g = c->gatherWords(words, &off);
+            if (R == 0) {
+                for (int r = 0; r < W; r++)
+                    for (uint64_t b = off[r]; b < off[r + 1]; b++)
+                        if (g[b] != (uint32_t)(1000 * r + i)) throw std::runtime_error("gather: wrong word");
+                if (off[W] != g.size()) throw std::runtime_error("gather: wrong total");
+            } else if (!g.empty())
+                throw std::runtime_error("gather: a rank other than 0 received data");
+        }
+        c->barrier();
+    } catch (const std::exception &e) {
+        Comm::markFailed();
+        return engine_error(e, err, err_len);
+    }
+    return 0;
 }
 
 // NoiseGroupSelector (estimateNoise's per-chain choice of groups)

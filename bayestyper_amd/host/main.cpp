@@ -19,10 +19,14 @@
 // byte for byte the files of a one-GPU run.
 #include <sys/stat.h>
 #include <signal.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -506,6 +510,7 @@ std::vector<pid_t> startRanks(int argc, char *const argv[]) {
         const pid_t pid = fork();
         if (pid < 0) throw std::runtime_error("cannot start rank " + std::to_string(r));
         if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGTERM);   // (a rank does not outlive the process that started it)
             setenv("BT_RANK", std::to_string(r).c_str(), 1);
             const std::string log = prefix + ".rank" + std::to_string(r) + ".log";
             if (!freopen(log.c_str(), "w", stdout) || !freopen(log.c_str(), "a", stderr)) _exit(1);
@@ -529,12 +534,29 @@ int main(int argc, char *const argv[]) {
         return 0;
     }
     std::vector<pid_t> children;
+    std::atomic<bool> finished(false);
+    std::thread watchdog;
     int rc = 0;
     try {
         if (kmer_size < 1 || kmer_size > 64) throw std::runtime_error("BT_KMER_SIZE must be between 1 and 64");
         if (std::strcmp(argv[1], "cluster") == 0) return runCluster(argc, argv, kmer_size);
         if (std::strcmp(argv[1], "genotype") == 0) {
             children = startRanks(argc, argv);
+            if (!children.empty())   // a rank that dies would leave the others waiting in a collective: end the run instead
+                watchdog = std::thread([&]() {
+                    while (!finished.load()) {
+                        for (pid_t pid : children) {
+                            int status = 0;
+                            if (waitpid(pid, &status, WNOHANG) == pid && !(WIFEXITED(status) && WEXITSTATUS(status) == 0)) {
+                                std::cerr << "\nERROR: a rank of this run failed (see <output-prefix>.rank<r>.log)\n" << std::endl;
+                                for (pid_t other : children) kill(other, SIGTERM);
+                                if (getenv("BT_COMM_ID_FILE")) std::remove(getenv("BT_COMM_ID_FILE"));
+                                _exit(1);
+                            }
+                        }
+                        std::this_thread::sleep_for(std::chrono::milliseconds(200));
+                    }
+                });
             rc = runGenotype(argc, argv, kmer_size);
         } else {
             std::cout << command_info << std::endl;
@@ -542,16 +564,22 @@ int main(int argc, char *const argv[]) {
         }
     } catch (const std::exception &e) {   // the reference prints "\nERROR: ...\n" and exits with 1
         std::cerr << "\nERROR: " << e.what() << "\n" << std::endl;
+        Comm::markFailed();
         rc = 1;
     }
-    for (pid_t pid : children) {   // the ranks this process started
+    finished.store(true);
+    if (watchdog.joinable()) watchdog.join();
+    for (pid_t pid : children) {   // the ranks this process started (those the watchdog has reaped already return -1 here: they ended well)
         int status = 0;
         if (rc != 0) kill(pid, SIGTERM);   // rank 0 failed: the others would wait for it forever
-        if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) {
+        if (waitpid(pid, &status, 0) == pid && !(WIFEXITED(status) && WEXITSTATUS(status) == 0)) {
             if (rc == 0) std::cerr << "\nERROR: a rank of this run failed (see <output-prefix>.rank<r>.log)\n" << std::endl;
             rc = 1;
         }
     }
-    if (!children.empty() && getenv("BT_COMM_ID_FILE")) std::remove(getenv("BT_COMM_ID_FILE"));
+    if (!children.empty() && getenv("BT_COMM_ID_FILE")) {
+        std::remove(getenv("BT_COMM_ID_FILE"));
+        std::remove((std::string(getenv("BT_COMM_ID_FILE")) + ".failed").c_str());
+    }
     return rc;
 }

@@ -45,6 +45,34 @@ REC = 13                # (55-7)/4 suffix bytes + 1 counter byte
 KMER_MATCH_BYTES_PER_RECORD = 15.9   # 13 B record + E[probes] + hit * table update, pure-algorithmic floor
 
 
+def source_hash():
+    """hash of the device sources the library was built from: profiles/ summaries made from the same sources carry the same hash"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bayestyper_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "bayestyper_amd", "csrc", "comm", "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kind):
+    """HBM bytes per launch of the Gibbs / KMC-scan kernels from the committed PMC passes of this command (profiles/*_traffic.json,
+    written by tools/pmc_traffic.py on the GPU box), but only when they were measured on the sources this library was built from"""
+    import glob
+
+    mine = source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("source_hash") == mine and kind in d:
+            return d[kind], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,6 +407,58 @@ def main():
                 "note": "bt_kmc_scan_run_host from pageable host memory (host copy -> pinned staging -> H2D -> scan, overlapped); never part of `value`"}
         del h_rec
 
+    # ------------------------------------------------------------------ sub-records (rank 0, N=1, outside the timed region)
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra:
+        # (1) the north star's ten-sample mixture (BASELINE configs[3] per GPU): 100 000 groups, full default schedule, beside the oracle on all cores
+        gibbs.close()
+        S10 = 10
+        f10 = synth.make_mixture(100_000, S10, seed=1010)
+        lg10, ln10 = count_model.build_luts(S10, mean=15.0, var=30.0, noise_rate=0.05)
+        g10 = lib.Gibbs(ctx, f10, lg10, ln10, seed=42)
+        t10 = lib.Timer(ctx)
+        ms10 = []
+        for _ in range(2):
+            t10.start()
+            g10.run()
+            t10.stop()
+            ms10.append(t10.elapsed_ms())
+        g10.close()
+        rec10 = {"workload": "BASELINE configs[3] shape on one GPU: 100 000 groups of the mixture (%s), S=10, 20 chains x (100+250) sweeps" % f10["mixture"],
+                 "ms_per_schedule": min(ms10), "cluster_sweeps_per_sec": f10["num_clusters"] * sweeps_per_group / (min(ms10) * 1e-3)}
+        if not args.no_cpu_baseline:
+            c10 = synth.make_mixture(max(2048, 12 * (os.cpu_count() or 1)), S10, seed=1011)
+            og = _oracle.OrcGibbs(orc, c10, *_oracle.build_luts(orc, S10), seed=42)
+            tc = time.perf_counter()
+            og.run(os.cpu_count() or 1)
+            dt = time.perf_counter() - tc
+            og.close()
+            rec10["cpu_allcores_cluster_sweeps_per_sec"] = c10["num_clusters"] * sweeps_per_group / dt
+            rec10["cpu_sample"] = f"{c10['num_groups']} groups, {dt:.1f} s on {os.cpu_count()} threads"
+            rec10["gpu_over_cpu_allcores"] = rec10["cluster_sweeps_per_sec"] / rec10["cpu_allcores_cluster_sweeps_per_sec"]
+        extra["samples10"] = rec10
+        # (2) k-mer matching against sub-filters of BASELINE configs[3] size: a ThreadedKmerBloom of 10^9 path k-mers (~37 KB per sub-filter,
+        # 2.4 GB) — the LDS-staged probe at the other end of its range
+        big = lib.Bloom.create(ctx, 1_000_000_000, 1e-4, K, threaded=True)
+        for a in range(0, 400_000_000, 100_000_000):   # fill a part of it (bit density decides the probe depth of non-members)
+            fill = torch.randint(-(2 ** 62), 2 ** 62, (100_000_000, 2), dtype=torch.int64, device=dev, generator=gen)
+            fill[:, 1] &= (1 << 46) - 1
+            lib.check(lib.bt_bloom_insert_batch(big.h, fill.data_ptr(), fill.shape[0]))
+            torch.cuda.synchronize()
+            del fill
+        n_big = min(R, 200_000_000)
+        table.clear()
+        tb = lib.Timer(ctx)
+        msb = []
+        for _ in range(3):
+            tb.start()
+            scan.run(big, table, 0, records.data_ptr(), 0, n_big, d_hits.data_ptr())
+            tb.stop()
+            msb.append(tb.elapsed_ms())
+        extra["kmer_match_c4_subfilters"] = {"records": n_big, "path_filter": "ThreadedKmerBloom(10^9 k-mers, fpr 1e-4): %d bytes per sub-filter, 40 %% filled" % (big.info()["num_bits"] // 8),
+                                             "ms": min(msb), "records_per_sec": n_big / (min(msb) * 1e-3)}
+        big.close()
+
     if rank == 0:
         ms_per_step = elapsed * 1000.0 / args.steps
         total_cluster_sweeps = cluster_sweeps_per_step * args.steps          # whole job (all ranks)
@@ -389,6 +469,10 @@ def main():
         gibbs_bytes = synth.algorithmic_bytes_per_chain(flat) * gibbs_chains                   # one launch = all chains of all clusters
         gibbs_gbs = gibbs_bytes / (gibbs_avg_ms * 1e-3) / 1e9
         kmc_gbs = R * KMER_MATCH_BYTES_PER_RECORD / (kmc_avg_ms * 1e-3) / 1e9
+        gibbs_traffic, gibbs_traffic_src = committed_traffic("gibbs_bytes_per_schedule")
+        kmc_traffic, kmc_traffic_src = committed_traffic("kmc_bytes_per_scan")
+        if (args.groups, S, args.records) != (600_000, 3, 1_000_000_000) or world != 1:   # the committed passes are of the default command
+            gibbs_traffic = kmc_traffic = gibbs_traffic_src = kmc_traffic_src = None
         shape_note = ("BASELINE configs[2] WGS trio" if S == 3 else "BASELINE configs[3] 10-sample mixture" if S == 10 else "mixture") + \
             ": one launch-sized slice of the unit, %d groups/GPU (%s; heterogeneous structures), S=%d, 20 chains x (100+250) sweeps; k-mer matching: %d scans/step of a " \
             "%d-record KMC stream (13 B, k=55, p=7) into an emptied count table, %d path k-mers, hit rate %.3f, ThreadedKmerBloom fpr 1e-4" % (
@@ -412,20 +496,23 @@ def main():
             "config": {"workload": shape_note, "groups_per_gpu": G, "clusters_per_gpu": C, "clusters_total": C_total, "samples": S, "kmc_records_per_gpu_per_sample": R,
                        "sharding": ("one batch sharded over the ranks (LPT on a cost proxy); " if strong else "a batch of the same size per rank; ") +
                                    "KMC streams per rank; gather of posterior summaries to rank 0", "sharded_equals_unsharded": verified},
-            "roofline": {"kernel": "gibbs_kernel", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gibbs_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
+            "roofline": {"kernel": "gibbs_kernel + gibbs_simple_kernel (the concurrent launches of one schedule)", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gibbs_gbs / HBM_PEAK_GBS, "traffic": gibbs_traffic, "traffic_source": gibbs_traffic_src, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
                          "note": "latency/issue-bound sequential sampler: the HBM floor (inputs + state once per chain, SURVEY 8d) is tiny by construction; "
-                                 "avg_launch_ms spans the sampling launch(es) of one schedule (tiles with large LDS needs form a second, concurrent launch); traffic is not "
-                                 "measurable from inside this process: the PMC passes of this command are in profiles/ (r02_FETCH_SIZE_pmc.json, r02_WRITE_SIZE_pmc.json)"},
+                                 "avg_launch_ms spans the sampling launches of one schedule; traffic = FETCH_SIZE + WRITE_SIZE of those launches from the committed PMC "
+                                 "passes of this command (separate rocprofv3 --pmc runs, KiB -> bytes), filled in only when they were made from the same device sources "
+                                 "(source_hash), else null"},
             "roofline_kmer_match": {"kernel": "one KMC scan = kmc_route_kernel + rocPRIM radix sort (16 bits) + kmc_probe_kernel + kmc_apply_kernel per 2^26-record chunk", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": kmc_avg_ms, "launches_per_step": S,
+                                    "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": kmc_traffic, "traffic_source": kmc_traffic_src, "avg_launch_ms": kmc_avg_ms, "launches_per_step": S,
                                     "insert_launch_ms": float(kmc[:, 0].mean()), "find_launch_ms": float(kmc[:, 1:].mean()) if S > 1 else None,
                                     "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD, "bloom_hits_per_scan": hits // ((args.steps + args.warmup) * S), "table_keys": st["num_keys"]},
             "cpu_baseline": cpu,
             "graph_stages": paths,
             "kmer_match_from_host_memory": pcie,
             "gibbs_device_bytes": gibbs_device_bytes,
+            "source_hash": source_hash(),
         }
+        out.update(extra)
         if cpu:
             out["gpu_over_cpu_allcores"] = out["gibbs_kernel_cluster_sweeps_per_sec"] / cpu["value"]
         print(json.dumps(out))

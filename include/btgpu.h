@@ -451,6 +451,11 @@ int bt_gibbs_run(bt_gibbs *g);
 /* getNoiseCounts of every group accumulated into a [S*256] histogram on the device, then clearGenotyperCache
  * (InferenceEngine.cpp:90-92); d_hist is zeroed first when zero_first != 0 */
 int bt_gibbs_noise_counts(bt_gibbs *g, uint64_t *d_hist, int zero_first);
+/* One iteration of the noise drivers with ONE host synchronisation (InferenceEngine.cpp:77-98): (the noise table of the previous
+ * iteration, h_noise [S*256] or NULL, is uploaded without waiting;) one sweep of every group; the noise-count histogram of all groups
+ * (+ clearGenotyperCache) lands in h_hist [S*256].  The caller draws the new rates from h_hist (after its all-reduce over the ranks) and
+ * hands the rebuilt table to the next call. */
+int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_samples, uint64_t *h_hist);
 /* resetGroup for every group (InferenceEngine.cpp:100-113): genotypers are rebuilt by the next init_chain */
 int bt_gibbs_reset_groups(bt_gibbs *g);
 

@@ -494,8 +494,9 @@ def _genotype(prefix, unit_prefix, ds_dir, seed, gibbs, extra_args=(), env=None)
     e.update(env or {})
     r = subprocess.run([EXE, "genotype", "-v", unit_prefix + "_unit_1/variant_clusters.bin", "-c", unit_prefix + "_cluster_data", "-s", os.path.join(ds_dir, "samples.tsv"), "-g",
                         os.path.join(ds_dir, "genome.fa"), "-o", prefix, "-r", str(seed), "--number-of-gibbs-chains", str(gibbs["chains"]), "--gibbs-burn-in", str(gibbs["burn"]),
-                        "--gibbs-samples", str(gibbs["samples"])] + list(extra_args), capture_output=True, text=True, env=e)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+                        "--gibbs-samples", str(gibbs["samples"])] + list(extra_args), capture_output=True, text=True, env=e, timeout=600)
+    logs = "".join(f"\n--- {f}\n" + open(os.path.join(os.path.dirname(prefix), f)).read()[-1500:] for f in sorted(os.listdir(os.path.dirname(prefix))) if f.endswith(".log"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:] + logs
     assert "BayesTyper genotype completed succesfully!" in r.stdout
     return r.stdout
 
@@ -543,3 +544,37 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible(oracle, tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _sharded_equals_single(oracle, tmp_path, {"BT_GPUS": "2", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, True)
+
+
+def test_make_bloom_command_line_feeds_cluster(oracle, tmp_path):
+    """`bayesTyperTools makeBloom -k <kmc prefix>` (src/bayesTyperTools/main.cpp:101-146, MakeBloom.cpp:39-51,200-295): the .bloomMeta / .bloomData it
+    writes are byte-identical to the reference KmerBloom's (the dataset's filters come from the oracle), for a KMC1 and a KMC2 database, and
+    `bayesTyper cluster` on samples that point to them writes what it writes on the dataset's own filters"""
+    import shutil
+
+    tools = os.path.join(os.path.dirname(EXE), "bayesTyperTools")
+    ds = c1_dataset.make(str(tmp_path / "data"), oracle, 40_000, 200, 2, num_error_kmers=80_000, genders=["F", "M"])
+    r = subprocess.run([tools, "makeBloom"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--false-positive-rate arg (=0.001)" in r.stdout          # help screen, returns 1 (main.cpp:137-141)
+    with open(os.path.join(ds["dir"], "samples_mb.tsv"), "w") as sf:
+        for s, gender in ((1, "F"), (2, "M")):
+            src, dst = os.path.join(ds["dir"], f"sample{s}"), os.path.join(ds["dir"], f"mb{s}")
+            for ext in (".kmc_pre", ".kmc_suf"):
+                shutil.copy(src + ext, dst + ext)
+            r = subprocess.run([tools, "makeBloom", "-k", dst] + (["--false-positive-rate", "0.001", "-p", "4"] if s == 2 else []), capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout[-1500:] + r.stderr
+            assert "Making bloom filter of" in r.stdout and "Completed saving bloom filter" in r.stdout
+            for ext in (".bloomMeta", ".bloomData"):
+                assert open(dst + ext, "rb").read() == open(src + ext, "rb").read(), ext
+            sf.write(f"sample{s}\t{gender}\t{dst}\n")
+    outs = []
+    for tag, samples in (("a", "samples.tsv"), ("b", "samples_mb.tsv")):
+        prefix = str(tmp_path / tag)
+        r = subprocess.run([EXE, "cluster", "-v", os.path.join(ds["dir"], "candidates.vcf"), "-s", os.path.join(ds["dir"], samples), "-g", os.path.join(ds["dir"], "genome.fa"), "-o", prefix, "-r", "5"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr
+        outs.append((gzip.open(prefix + "_cluster_data/parameter_kmers.fa.gz", "rt").read(), gzip.open(prefix + "_cluster_data/intercluster_regions.txt.gz", "rt").read(),
+                     open(prefix + "_cluster_data/multigroup_kmers.bloomData", "rb").read()))
+    assert outs[0] == outs[1] and len(outs[0][0]) > 1000
+    r = subprocess.run([tools, "makeBloom", "-k", os.path.join(ds["dir"], "nothing_here")], capture_output=True, text=True)
+    assert r.returncode == 1 and "ERROR" in r.stderr

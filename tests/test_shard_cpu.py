@@ -105,3 +105,34 @@ def test_two_rank_gloo_gather_matches_unsharded():
     assert got.shape == ref.shape
     assert np.array_equal(got, ref)
     assert (ref[:, :, 1] > 0).any()
+
+
+# ---- the host layer's rank exchange (bthost::Comm) over its files transport: three processes, no GPU --------------------------------
+def _comm_rank(rank, world, id_file, q):
+    os.environ.update({"BT_WORLD": str(world), "BT_RANK": str(rank), "BT_COMM_ID_FILE": id_file, "BT_COMM_TRANSPORT": "files"})
+    import ctypes as C
+
+    from bayestyper_amd.host import dll
+
+    err = C.create_string_buffer(512)
+    dll.bth_comm_selftest.argtypes = [C.c_uint, C.c_char_p, C.c_uint]
+    rc = dll.bth_comm_selftest(25, err, len(err))
+    q.put((rank, rc, err.value.decode()))
+
+
+def test_host_comm_files_transport_three_ranks(tmp_path):
+    """bthost::Comm (the exchange steps `bayesTyper genotype` uses between its ranks) over the files transport: all-reduce, all-gather of byte
+    strings of different lengths, gather of words to rank 0 with an empty contribution, 25 rounds, three processes"""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    id_file = str(tmp_path / "run.comm_id")
+    procs = [ctx.Process(target=_comm_rank, args=(r, 3, id_file, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(30)
+    assert got == [(0, 0, ""), (1, 0, ""), (2, 0, "")], got
+    assert not os.path.exists(id_file + ".d") or not os.listdir(id_file + ".d")   # the exchange files are gone
