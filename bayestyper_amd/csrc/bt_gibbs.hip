@@ -75,6 +75,98 @@ __global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict
     }
 }
 
+// ---- the noise model's update of one iteration (bt_gibbs_noise_chain) ----------------------------------------------------------------
+// std::mt19937 as libstdc++ runs it: the whole block of 624 words is regenerated when it is used up (bits/random.tcc _M_gen_rand)
+struct MtBlock {
+    uint32_t *x;
+    uint32_t p;
+    __device__ void gen_rand() {
+        for (uint32_t k = 0; k < MT_N - MT_M; ++k) x[k] = mt_twist(x[k], x[k + 1], x[k + MT_M]);
+        for (uint32_t k = MT_N - MT_M; k < MT_N - 1; ++k) x[k] = mt_twist(x[k], x[k + 1], x[k + MT_M - MT_N]);
+        x[MT_N - 1] = mt_twist(x[MT_N - 1], x[0], x[MT_M - 1]);
+        p = 0;
+    }
+    __device__ uint32_t next() {
+        if (p >= MT_N) gen_rand();
+        return mt_temper(x[p++]);
+    }
+    template <unsigned N>
+    __device__ void next_n(uint32_t (&out)[N]) {
+        for (uint32_t k = 0; k < N; ++k) out[k] = next();
+    }
+};
+struct NoiseDev {   // device copy of bt_noise_rng + the per-sample priors / rates
+    uint32_t mt[MT_N];
+    uint32_t mt_pos, saved_available;
+    double saved;
+};
+// one workgroup of 256 threads: sufficient statistics of the histogram (calcCountSuffStats), S gamma draws by thread 0 (the stream is
+// sequential), then the S x 256 Poisson log-pmf table with the tail of counts >= 255 folded into entry 255 (CountDistribution.cpp:314-347)
+__global__ __launch_bounds__(256) void noise_update_kernel(NoiseDev *__restrict__ st, const float *__restrict__ prior, uint32_t S, const unsigned long long *__restrict__ hist,
+                                                           const double *__restrict__ lgamma_c /* lgamma(c + 1), c = 0..255 */, double *__restrict__ rates_row, double *__restrict__ rates_cur,
+                                                           double *__restrict__ lut_n) {
+    __shared__ unsigned long long s_obs[32], s_sum[32];
+    __shared__ double s_rate[32];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t s = 0; s < S; ++s) {   // num_observations = sum_i n_i, count_sum = sum_i i * n_i
+        unsigned long long o = hist[s * 256u + t], w = o * t;
+        for (int off = 32; off > 0; off >>= 1) {
+            o += __shfl_down(o, off);
+            w += __shfl_down(w, off);
+        }
+        __shared__ unsigned long long part_o[4], part_w[4];
+        if ((t & 63u) == 0) {
+            part_o[t >> 6] = o;
+            part_w[t >> 6] = w;
+        }
+        __syncthreads();
+        if (t == 0) {
+            s_obs[s] = part_o[0] + part_o[1] + part_o[2] + part_o[3];
+            s_sum[s] = part_w[0] + part_w[1] + part_w[2] + part_w[3];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        MtBlock g{st->mt, st->mt_pos};
+        NormalState nd{&st->saved, &st->saved_available};
+        for (uint32_t s = 0; s < S; ++s) {
+            // CountDistribution.cpp:173-186: the priors are floats and the counts unsigned longs there, so both arguments are computed in FLOAT
+            // arithmetic (usual arithmetic conversions) before sampleGamma widens them
+            const float shape = prior[2 * s], scale = prior[2 * s + 1];
+            const float shape_f = shape + (float)s_sum[s];
+            const float scale_f = scale / ((float)s_obs[s] * scale + 1.0f);
+            const double r = rng_gamma(g, nd, (double)shape_f, (double)scale_f);
+            s_rate[s] = r;
+            rates_row[s] = r;
+            rates_cur[s] = r;
+        }
+        st->mt_pos = g.p;
+    }
+    __syncthreads();
+    for (uint32_t s = 0; s < S; ++s) {
+        const double rate = s_rate[s], lr = log(rate);
+        double v = (double)t * lr - rate - lgamma_c[t];   // poissonLogProb (:349-352)
+        if (t == 255) {
+            unsigned limit = 255;
+            double prev = 0;
+            bool more = true;
+            while (more) {
+                limit++;
+                prev = v;
+                const double q = (double)limit * lr - rate - lgamma((double)limit + 1.0);
+                v = v < q ? q + log1p(exp(v - q)) : v + log1p(exp(q - v));   // Utils::logAddition
+                if (v > 0) {
+                    v = 0;
+                    break;
+                }
+                const double mn = prev < v ? prev : v;
+                more = !((prev == v) || (fabs(prev - v) < fabs(mn) * BT_DBL_EPS * 100));   // Utils::doubleCompare
+            }
+        }
+        lut_n[s * 256u + t] = v;
+    }
+}
+
 // ---- host-side tile builder -------------------------------------------------------------------------------------
 struct TilePlan {
     TileDesc d;
@@ -946,6 +1038,104 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
     BT_HIP(hipMemcpyAsync(g->h_pin_hist, g->d_iter_hist, nh * 8, hipMemcpyDeviceToHost, st));
     BT_HIP(hipStreamSynchronize(st));
     std::memcpy(h_hist, g->h_pin_hist, nh * 8);
+    return BT_OK;
+}
+
+struct bt_noise_model {
+    bt_ctx *ctx = nullptr;
+    uint32_t S = 0;
+    NoiseDev *d_state = nullptr;
+    float *d_prior = nullptr;
+    double *d_lgamma = nullptr, *d_rates_cur = nullptr, *d_lut_spare = nullptr;
+    unsigned long long *d_hist = nullptr;
+};
+
+int bt_noise_model_create(bt_ctx *ctx, uint32_t S, const float *h_prior, bt_noise_model **out) {
+    if (!ctx || !h_prior || !out) return fail("bt_noise_model_create: null argument");
+    if (S < 1 || S > 30) return fail("bt_noise_model_create: number of samples must be in 1..30");
+    BT_HIP(hipSetDevice(ctx->device));
+    bt_noise_model *m = new bt_noise_model();
+    m->ctx = ctx;
+    m->S = S;
+    std::vector<double> lg(256);
+    for (uint32_t c = 0; c < 256; ++c) lg[c] = std::lgamma((double)c + 1.0);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_state), sizeof(NoiseDev));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_prior), 2 * S * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_lgamma), 256 * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_rates_cur), S * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_lut_spare), (size_t)S * 256 * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_hist), (size_t)S * 256 * 8);
+    if (e == hipSuccess) e = hipMemcpy(m->d_prior, h_prior, 2 * S * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_lgamma, lg.data(), 256 * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(m->d_state, 0, sizeof(NoiseDev));
+    if (e != hipSuccess) {
+        bt_noise_model_destroy(m);
+        return fail(std::string("bt_noise_model_create: ") + hipGetErrorString(e));
+    }
+    *out = m;
+    return BT_OK;
+}
+
+int bt_noise_model_destroy(bt_noise_model *m) {
+    if (!m) return BT_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (void *p : {(void *)m->d_state, (void *)m->d_prior, (void *)m->d_lgamma, (void *)m->d_rates_cur, (void *)m->d_lut_spare, (void *)m->d_hist})
+        if (p) (void)hipFree(p);
+    delete m;
+    return BT_OK;
+}
+
+int bt_noise_model_set_rng(bt_noise_model *m, const bt_noise_rng *h) {
+    if (!m || !h) return fail("bt_noise_model_set_rng: null argument");
+    if (h->mt_pos > MT_N) return fail("bt_noise_model_set_rng: generator position outside 0..624");
+    static_assert(sizeof(bt_noise_rng) == sizeof(NoiseDev), "bt_noise_rng and its device copy differ");
+    BT_HIP(hipSetDevice(m->ctx->device));
+    BT_HIP(hipMemcpyAsync(m->d_state, h, sizeof(NoiseDev), hipMemcpyHostToDevice, m->ctx->stream));
+    BT_HIP(hipStreamSynchronize(m->ctx->stream));
+    return BT_OK;
+}
+
+int bt_noise_model_get_rng(bt_noise_model *m, bt_noise_rng *h) {
+    if (!m || !h) return fail("bt_noise_model_get_rng: null argument");
+    BT_HIP(hipSetDevice(m->ctx->device));
+    BT_HIP(hipMemcpyAsync(h, m->d_state, sizeof(NoiseDev), hipMemcpyDeviceToHost, m->ctx->stream));
+    BT_HIP(hipStreamSynchronize(m->ctx->stream));
+    return BT_OK;
+}
+
+int bt_gibbs_noise_chain(bt_gibbs *g, bt_noise_model *m, uint32_t num_iterations, uint32_t first_collect, int (*reduce)(void *user, uint64_t *d_hist, uint64_t n), void *user,
+                         double *h_rates) {
+    if (!m || !h_rates) return fail("bt_gibbs_noise_chain: null argument");
+    if (g && (g->S != m->S || g->ctx != m->ctx)) return fail("bt_gibbs_noise_chain: sampler and noise model differ in samples or context");
+    if (num_iterations == 0) return BT_OK;
+    BT_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t st = m->ctx->stream;
+    const size_t nh = (size_t)m->S * 256;
+    double *d_rates = nullptr;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_rates), (size_t)num_iterations * m->S * 8));
+    int rc = BT_OK;
+    hipError_t e = hipSuccess;
+    for (uint32_t it = 0; it < num_iterations && rc == BT_OK && e == hipSuccess; ++it) {
+        if (g) rc = launch(g, OP_SWEEP, 1, it >= first_collect ? 1u : 0u, nullptr);
+        if (rc != BT_OK) break;
+        e = hipMemsetAsync(m->d_hist, 0, nh * 8, st);
+        if (e != hipSuccess) break;
+        if (g) rc = launch(g, OP_NOISE, 0, 0, m->d_hist);
+        if (rc != BT_OK) break;
+        if (reduce && reduce(user, reinterpret_cast<uint64_t *>(m->d_hist), nh) != 0) {
+            rc = fail("bt_gibbs_noise_chain: the reduction of the noise counts failed");
+            break;
+        }
+        hipLaunchKernelGGL(noise_update_kernel, dim3(1), dim3(256), 0, st, m->d_state, m->d_prior, m->S, m->d_hist, m->d_lgamma, d_rates + (size_t)it * m->S, m->d_rates_cur,
+                           g ? g->d_lut_n : m->d_lut_spare);
+        e = hipGetLastError();
+    }
+    if (rc == BT_OK && e == hipSuccess) e = hipMemcpyAsync(h_rates, d_rates, (size_t)num_iterations * m->S * 8, hipMemcpyDeviceToHost, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_rates);
+    if (rc != BT_OK) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return fail(std::string("bt_gibbs_noise_chain: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return BT_OK;
 }
 

@@ -157,7 +157,7 @@ struct TileDesc {
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
 };
 #ifndef BT_EV_CAP
-#define BT_EV_CAP 8
+#define BT_EV_CAP 32
 #endif
 constexpr uint32_t EV_CAP = BT_EV_CAP;    // logged runs per (cluster, sample) before the log is applied early
 constexpr uint32_t KSC_WAYS = 4;          // recently rebuilt k-mer-stats caches kept per (cluster, sample), see collect_sample_body

@@ -222,27 +222,10 @@ struct MtRingT {
         }
     }
     BT_HD void generate(uint32_t n) { generate_t<false>(n); }
-#if defined(BT_RING_REFILL_OUTLINE) && defined(__HIP_DEVICE_COMPILE__)
-    // Refills are calls: ONE copy of the 16-word burst (600 instructions) instead of one per draw site.  When every lane of the wavefront
-    // asks for the same number of words (the diplotype generator of a 64-cluster tile: exactly two words per sample and sweep in every
-    // lane) the count is a scalar and the unused slots of a burst are skipped by scalar branches instead of being issued under an empty mask.
-    __device__ __noinline__ void generate_uniform(uint32_t n) { generate_t<true>(n); }
-    __device__ __noinline__ void generate_vector(uint32_t n) { generate_t<false>(n); }
-    __device__ inline void generate_out(uint32_t n) {
-        const uint32_t nu = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
-        if (__builtin_amdgcn_ballot_w64(n != nu) == 0) generate_uniform(n);
-        else generate_vector(n);
-    }
-    __device__ inline void topup() { generate_out(cap - avail); }
-    __device__ inline void need(uint32_t n) {
-        if (avail < n) generate_out(cap - avail < 16u ? cap - avail : 16u);
-    }
-#else
     BT_HD void topup() { generate(cap - avail); }
     BT_HD void need(uint32_t n) {
         if (avail < n) generate(cap - avail < 16u ? cap - avail : 16u);
     }
-#endif
     BT_HD uint32_t next() {
         need(1);
         const uint32_t w = ring[head];

@@ -212,6 +212,11 @@ void Comm::allreduceHist(uint64_t *hist, size_t n) {
     check(bt_memcpy_d2h(ctx, hist, d.p, n * 8), "bt_memcpy_d2h");
 }
 
+void Comm::allreduceDeviceAsync(uint64_t *d_hist, size_t n) {
+    if (!dir.empty()) throw std::runtime_error("Comm: the files transport has no device-side reduction");
+    check(api->allreduce_hist(comm, d_hist, n), "bt_comm_allreduce_hist");
+}
+
 void Comm::barrier() {
     uint64_t one = 1;
     allreduceHist(&one, 1);

@@ -40,6 +40,9 @@ class Comm {
     int world() const { return world_; }
     // in-place sum over all ranks of n counters held on the host (the S x 256 noise-count histogram of an iteration)
     void allreduceHist(uint64_t *hist, size_t n);
+    // the same for counters on the device, only ENQUEUED on the context's stream (RCCL transport only: deviceReduction() says whether)
+    bool deviceReduction() const { return dir.empty(); }
+    void allreduceDeviceAsync(uint64_t *d_hist, size_t n);
     // every rank's byte string, concatenated in rank order, on every rank (device round trip inside); offsets[world + 1]
     std::vector<uint8_t> allgatherBytes(const std::vector<uint8_t> &mine, std::vector<uint64_t> *offsets);
     // the same for device buffers: d_out (capacity bytes) receives all parts; returns the offsets

@@ -4,6 +4,7 @@
 #include <cassert>
 #include <cmath>
 #include <limits>
+#include <sstream>
 #include <stdexcept>
 
 namespace bthost {
@@ -91,6 +92,40 @@ void CountDistribution::sampleNoiseParameters(const CountAllocation &noise_count
         noise_rates[s] = sampleGamma(noise_rate_priors[s].first + count_sum, noise_rate_priors[s].second / (num_observations * noise_rate_priors[s].second + 1));
     }
     updateNoiseCache();
+}
+// (the stream operators are the standard's way to reach the state; doubles are written with max_digits10, so the round trip is exact)
+void CountDistribution::exportGenerator(uint32_t *mt624, uint32_t *mt_pos, uint32_t *saved_available, double *saved) const {
+    std::stringstream ss;
+    ss << prng;
+    for (int i = 0; i < 624; i++) {
+        unsigned long w;
+        ss >> w;
+        mt624[i] = (uint32_t)w;
+    }
+    unsigned long p;
+    ss >> p;
+    *mt_pos = (uint32_t)p;
+    std::stringstream gs;
+    gs << gamma_dist;   // alpha beta | mean stddev saved_available [saved]
+    double alpha, beta, mean, stddev;
+    int avail = 0;
+    gs >> alpha >> beta >> mean >> stddev >> avail;
+    *saved_available = avail ? 1u : 0u;
+    *saved = 0;
+    if (avail) gs >> *saved;
+    if (!ss || !gs) throw std::runtime_error("CountDistribution: cannot read the generator state");
+}
+void CountDistribution::importGenerator(const uint32_t *mt624, uint32_t mt_pos, uint32_t saved_available, double saved) {
+    std::stringstream ss;
+    for (int i = 0; i < 624; i++) ss << mt624[i] << ' ';
+    ss << mt_pos;
+    ss >> prng;
+    std::stringstream gs;
+    gs.precision(std::numeric_limits<double>::max_digits10);
+    gs << std::scientific << 1.0 << ' ' << 1.0 << ' ' << 0.0 << ' ' << 1.0 << ' ' << (saved_available ? 1 : 0);
+    if (saved_available) gs << ' ' << saved;
+    gs >> gamma_dist;
+    if (!ss || !gs) throw std::runtime_error("CountDistribution: cannot set the generator state");
 }
 double CountDistribution::sampleGamma(double shape, double scale) {
     gamma_dist.param(std::gamma_distribution<>::param_type(shape, scale));

@@ -60,6 +60,12 @@ class CountDistribution {
     const std::vector<double> &genomicTable() const { return genomic_cache; }
     const std::vector<double> &noiseTable() const { return noise_cache; }
 
+    // The generator the noise rates are drawn from, in libstdc++'s own terms (std::mt19937: 624 words + next index; the gamma distribution's
+    // normal distribution: saved variate) — handed to the device for a whole chain of draws (bt_gibbs_noise_chain) and taken back afterwards.
+    void exportGenerator(uint32_t *mt624, uint32_t *mt_pos, uint32_t *saved_available, double *saved) const;
+    void importGenerator(const uint32_t *mt624, uint32_t mt_pos, uint32_t saved_available, double saved);
+    const std::vector<std::pair<float, float>> &noiseRatePriors() const { return noise_rate_priors; }
+
   private:
     double sampleGamma(double shape, double scale);
     void updateGenomicCache();

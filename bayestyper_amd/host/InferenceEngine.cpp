@@ -61,6 +61,7 @@ struct GpuSampler : GibbsSampler {
         check(bt_gibbs_create(ctx, &p, &b, &g), "bt_gibbs_create");
     }
     ~GpuSampler() override {
+        if (noise_model) bt_noise_model_destroy(noise_model);
         if (d_hist) bt_free(ctx, d_hist);
         bt_gibbs_destroy(g);
     }
@@ -76,6 +77,38 @@ struct GpuSampler : GibbsSampler {
         check(bt_sync(ctx), "bt_sync");
         check(bt_memcpy_d2h(ctx, h.data(), d_hist, h.size() * 8), "bt_memcpy_d2h");
         return h;
+    }
+    bt_noise_model *noise_model = nullptr;
+    bool noiseChain(CountDistribution *cd, uint32_t n_iterations, uint32_t first_collect, const DeviceReducer &reduce, std::vector<double> *rows) override {
+        if (getenv("BT_NOISE_ON_HOST")) return false;   // (the per-iteration host loop: draws by libstdc++ itself)
+        if (!noise_model) {
+            std::vector<float> prior;
+            for (auto &p : cd->noiseRatePriors()) {
+                prior.push_back(p.first);
+                prior.push_back(p.second);
+            }
+            check(bt_noise_model_create(ctx, S, prior.data(), &noise_model), "bt_noise_model_create");
+        }
+        bt_noise_rng rng;
+        cd->exportGenerator(rng.mt, &rng.mt_pos, &rng.saved_available, &rng.saved);
+        check(bt_noise_model_set_rng(noise_model, &rng), "bt_noise_model_set_rng");
+        rows->assign((size_t)n_iterations * S, 0.0);
+        struct Hook {
+            const DeviceReducer *r;
+            static int call(void *user, uint64_t *d_hist, uint64_t n) {
+                try {
+                    (*((Hook *)user)->r)(d_hist, (size_t)n);
+                } catch (...) {
+                    return 1;
+                }
+                return 0;
+            }
+        } hook{&reduce};
+        check(bt_gibbs_noise_chain(g, noise_model, n_iterations, first_collect, reduce ? &Hook::call : nullptr, &hook, rows->data()), "bt_gibbs_noise_chain");
+        check(bt_noise_model_get_rng(noise_model, &rng), "bt_noise_model_get_rng");
+        cd->importGenerator(rng.mt, rng.mt_pos, rng.saved_available, rng.saved);
+        cd->setNoiseRates(std::vector<double>(rows->end() - S, rows->end()));
+        return true;
     }
     std::vector<uint64_t> noiseIteration(const double *noise, bool collect) override {
         std::vector<uint64_t> h((size_t)S * 256);
@@ -145,6 +178,36 @@ void InferenceEngine::iteration(Sampler *sampler, CountDistribution *cd, bool co
     pending_noise = true;
 }
 
+void InferenceEngine::runNoiseChain(Sampler *sampler, CountDistribution *cd, uint32_t chain, uint32_t first_collect_iteration, std::ostream &out,
+                                    const std::function<void(uint32_t, const std::vector<double> &)> &each) {
+    const uint32_t n = opt.burn_in + opt.samples;
+    const size_t S = gender.size();
+    // On the device: a single rank, or ranks whose histograms are reduced on the device and that ALL hold a sampler in this chain (a rank
+    // without one would have to draw on the host, and host and device arithmetic may differ in the last bit — the ranks' generators must not)
+    bool on_device = sampler != nullptr && (!reduce_hist || device_reduce);
+    if (reduce_hist && device_reduce) {
+        uint64_t have = sampler ? 1 : 0;
+        uint64_t all[2] = {have, 1};
+        reduce_hist(all, 2);
+        on_device = all[0] == all[1];
+    }
+    std::vector<double> rows;
+    if (on_device && sampler->noiseChain(cd, n, first_collect_iteration - 1, reduce_hist ? device_reduce : GibbsSampler::DeviceReducer(), &rows)) {
+        for (uint32_t it = 1; it <= n; it++) {
+            const std::vector<double> rates(rows.begin() + (size_t)(it - 1) * S, rows.begin() + (size_t)it * S);
+            logRow(out, chain + 1, it, rates);
+            if (each) each(it, rates);
+        }
+        pending_noise = false;   // (the sampler holds the table of the last rates)
+        return;
+    }
+    for (uint32_t it = 1; it <= n; it++) {
+        iteration(sampler, cd, it >= first_collect_iteration);
+        logRow(out, chain + 1, it, cd->getNoiseRates());
+        if (each) each(it, cd->getNoiseRates());
+    }
+}
+
 void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData &unit, const std::string &output_prefix, uint32_t variants_batch_size,
                                     const std::vector<uint32_t> *unit_clusters, const std::vector<uint32_t> *unit_variants) {
     if (!quiet)
@@ -186,13 +249,10 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         }
         pending_noise = false;   // (the chain's sampler starts with the current table)
         logRow(out, chain + 1, 0, cd->getNoiseRates());
-        for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
-            iteration(sampler.get(), cd, false);
-            const std::vector<double> &rates = cd->getNoiseRates();
-            logRow(out, chain + 1, it, rates);
+        runNoiseChain(sampler.get(), cd, chain, opt.burn_in + opt.samples + 1 /* never collects */, out, [&](uint32_t it, const std::vector<double> &rates) {
             if (opt.burn_in < it)
                 for (size_t s = 0; s < S; s++) mean[s] += rates[s];
-        }
+        });
         sampler.reset();
         cd->resetNoiseRates();
     }
@@ -271,10 +331,7 @@ void InferenceEngine::estimateNoiseAndGenotypes(const GibbsBatchData &unit, Coun
         }
         pending_noise = false;
         logRow(out, chain + 1, 0, cd->getNoiseRates());
-        for (uint32_t it = 1; it <= opt.burn_in + opt.samples; it++) {
-            iteration(sampler.get(), cd, it > opt.burn_in);
-            logRow(out, chain + 1, it, cd->getNoiseRates());
-        }
+        runNoiseChain(sampler.get(), cd, chain, opt.burn_in + 1, out, nullptr);
         cd->resetNoiseRates();
     }
     if (sampler) {

@@ -81,6 +81,12 @@ struct GibbsSampler {
         sweep(1, collect);
         return noiseCounts();
     }
+    // A whole chain of a noise driver on the sampler's side, without a host round trip per iteration: num_iterations x { sweep
+    // (collecting from iteration first_collect on); noise counts; reduction over the ranks (device_reduce, may be empty); the rates drawn
+    // from count_distribution's generator; the rebuilt table }.  rows receives the rates of every iteration ([it * S + s]); afterwards
+    // count_distribution holds the last rates and the advanced generator.  false: not supported (the driver then iterates itself).
+    typedef std::function<void(uint64_t *d_hist, size_t n)> DeviceReducer;   // enqueues the all-reduce of a DEVICE histogram on the context's stream
+    virtual bool noiseChain(CountDistribution *, uint32_t, uint32_t, const DeviceReducer &, std::vector<double> *) { return false; }
     virtual BatchResults results(uint32_t num_clusters) = 0;
 };
 typedef std::function<std::unique_ptr<GibbsSampler>(const bt_gibbs_params &, const GibbsBatchData &)> SamplerFactory;
@@ -103,6 +109,8 @@ class InferenceEngine {
     uint32_t numLaunches() const { return num_launches; }   // of the last estimateGenotypes
     void setSamplerFactory(SamplerFactory f) { make_sampler = std::move(f); }
     void setHistReducer(HistReducer r) { reduce_hist = std::move(r); }
+    // with several ranks the noise chains stay on the device only if the histogram can be reduced there (Comm over RCCL: bt_comm_allreduce_hist)
+    void setDeviceHistReducer(GibbsSampler::DeviceReducer r) { device_reduce = std::move(r); }
     // every row of the noise parameter file in full precision: (chain, iteration, rate_0 .. rate_{S-1}) per row (tests compare these, the file has 6 digits)
     void recordNoiseRows(bool on) { record_rows = on; }
     const std::vector<double> &noiseRows() const { return noise_rows; }
@@ -124,6 +132,11 @@ class InferenceEngine {
     bool low_variant_warning = false;
     uint32_t num_launches = 0;
     SamplerFactory make_sampler;
+    GibbsSampler::DeviceReducer device_reduce;
+    // one chain of a noise driver (iterations 1..n of the reference's loop): on the device when the sampler can, else iteration by iteration;
+    // every iteration's rates are logged (row) and handed to `each`
+    void runNoiseChain(Sampler *sampler, CountDistribution *cd, uint32_t chain, uint32_t first_collect_iteration, std::ostream &out,
+                       const std::function<void(uint32_t iteration, const std::vector<double> &rates)> &each);
     bool record_rows = false, quiet = false;
     bool pending_noise = false;   // the count distribution holds a noise table the sampler has not been given yet
     std::vector<double> noise_rows;

@@ -50,6 +50,13 @@ void bth_count_distribution_noise_rates(void *h, double *out) {
 }
 void bth_count_distribution_set_noise_rates(void *h, const double *rates, unsigned S) { ((CountDistribution *)h)->setNoiseRates(std::vector<double>(rates, rates + S)); }
 void bth_count_distribution_reset_noise_rates(void *h) { ((CountDistribution *)h)->resetNoiseRates(); }
+// the generator state as bt_noise_rng lays it out: 624 words, position, saved_available, then the saved variate
+void bth_count_distribution_export_generator(void *h, uint32_t *words626, double *saved) {
+    ((CountDistribution *)h)->exportGenerator(words626, words626 + 624, words626 + 625, saved);
+}
+void bth_count_distribution_import_generator(void *h, const uint32_t *words626, double saved) {
+    ((CountDistribution *)h)->importGenerator(words626, words626[624], words626[625], saved);
+}
 // sampleNoiseParameters from a [S*256] u64 histogram
 void bth_count_distribution_sample_noise(void *h, const unsigned long long *hist, unsigned S) {
     CountAllocation ca((unsigned short)S);

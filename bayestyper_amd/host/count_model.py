@@ -16,6 +16,8 @@ dll.bth_count_distribution_set_noise_rates.argtypes = [vp, vp, C.c_uint]
 dll.bth_count_distribution_reset_noise_rates.argtypes = [vp]
 dll.bth_count_distribution_sample_noise.argtypes = [vp, vp, C.c_uint]
 dll.bth_count_distribution_tables.argtypes = [vp, vp, vp, C.c_uint]
+dll.bth_count_distribution_export_generator.argtypes = [vp, vp, vp]
+dll.bth_count_distribution_import_generator.argtypes = [vp, vp, C.c_double]
 
 
 def build_luts(S, mean=15.0, var=30.0, noise_rate=0.05, multiplicity=1):
@@ -56,6 +58,16 @@ class CountDistribution:
     def sample_noise_parameters(self, hist):
         h = np.ascontiguousarray(hist, np.uint64)
         dll.bth_count_distribution_sample_noise(self.h, h.ctypes.data, self.S)
+
+    def export_generator(self):
+        """-> (uint32[626]: the 624 mt19937 words, the next index, the normal distribution's saved flag; the saved variate)"""
+        w, s = np.zeros(626, np.uint32), C.c_double()
+        dll.bth_count_distribution_export_generator(self.h, w.ctypes.data, C.byref(s))
+        return w, s.value
+
+    def import_generator(self, words, saved):
+        w = np.ascontiguousarray(words, np.uint32)
+        dll.bth_count_distribution_import_generator(self.h, w.ctypes.data, saved)
 
     def tables(self):
         g = np.zeros(self.S * 65536)

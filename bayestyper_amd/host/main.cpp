@@ -392,6 +392,7 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     GibbsBatchData shard;
     if (comm) {
         inference_engine.setHistReducer([&](uint64_t *hist, size_t n) { comm->allreduceHist(hist, n); });
+        if (comm->deviceReduction()) inference_engine.setDeviceHistReducer([&](uint64_t *d_hist, size_t n) { comm->allreduceDeviceAsync(d_hist, n); });
         rank_groups = assignGroups(batch, world);
         shard = batch.take(rank_groups[rank]);
         for (uint32_t g = 0; g < batch.numGroups(); g++) {

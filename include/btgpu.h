@@ -479,6 +479,35 @@ int bt_gibbs_trace_fetch(bt_gibbs *g, uint32_t *h_trace, uint64_t max_words, uin
 int bt_gibbs_device_bytes(bt_gibbs *g, uint64_t *bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * The noise half of CountDistribution on the device (src/bayesTyper/CountDistribution.cpp:163-200 sampleNoiseParameters /
+ * calcCountSuffStats, :314-352 the Poisson noise table with its tail fold) and a whole chain of a noise driver
+ * (InferenceEngine.cpp:77-98 per iteration) without a host round trip per iteration.
+ * bt_noise_rng = the run's generator as libstdc++ holds it: std::mt19937 (block form: 624 words + the index of the next word) and
+ * the gamma distribution's normal distribution (its saved second variate).  The host exchanges it with its CountDistribution
+ * before and after a chain, so host-side and device-side draws continue one stream.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bt_noise_rng {
+    uint32_t mt[624];
+    uint32_t mt_pos;             /* 0..624 (624: the next draw regenerates the block) */
+    uint32_t saved_available;    /* std::normal_distribution::_M_saved_available */
+    double saved;                /* std::normal_distribution::_M_saved */
+} bt_noise_rng;
+typedef struct bt_noise_model bt_noise_model;
+/* h_prior[2*s], h_prior[2*s+1] = shape, scale of sample s's noise-rate prior (--noise-rate-prior, floats as the reference holds them) */
+int bt_noise_model_create(bt_ctx *ctx, uint32_t num_samples, const float *h_prior, bt_noise_model **out);
+int bt_noise_model_destroy(bt_noise_model *m);
+int bt_noise_model_set_rng(bt_noise_model *m, const bt_noise_rng *h_rng);
+int bt_noise_model_get_rng(bt_noise_model *m, bt_noise_rng *h_rng);
+/* num_iterations iterations of a chain: { one sweep of every group of g (collecting from iteration first_collect on, 0-based);
+ * noise counts of all groups + clearGenotyperCache; reduce(user, d_hist, S*256) if given — it must only ENQUEUE work on the context's
+ * stream (bt_comm_allreduce_hist does); one gamma draw per sample from the model's generator (shape + sum of counts,
+ * scale / (observations * scale + 1)); the rebuilt noise table becomes g's }.  Everything is enqueued at once; the call returns after
+ * the last iteration with h_rates[it*S + s] = the rate drawn in iteration it.  g may be NULL (a rank without groups in this chain
+ * still reduces and draws, so that all ranks' generators stay in step). */
+int bt_gibbs_noise_chain(bt_gibbs *g, bt_noise_model *m, uint32_t num_iterations, uint32_t first_collect,
+                         int (*reduce)(void *user, uint64_t *d_hist, uint64_t n), void *user, double *h_rates);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostics: host-side entry points of the libstdc++-compatible primitives the sampler relies on
  * (SURVEY Appendix B.2).  They run the same __host__ __device__ code the kernels use.
  * ---------------------------------------------------------------------------------------- */

@@ -35,6 +35,21 @@ def run_both(gpu_ctx, oracle, flat, trace=0, flat_gpu=None, **kw):
     return ro, rg, tr
 
 
+RATE_RTOL = 1e-12   # noise rates drawn on the device (bt_gibbs_noise_chain: ocml log / pow / sqrt) against libstdc++'s draws through glibc: the last bits may differ
+
+
+def assert_noise_rows(got, want):
+    """rows of the noise parameter file: (chain, iteration) exact, the rates within RATE_RTOL; with BT_NOISE_ON_HOST the draws are libstdc++'s own and exact"""
+    import os
+
+    assert got.shape == want.shape
+    assert np.array_equal(got[:, :2], want[:, :2])
+    if os.environ.get("BT_NOISE_ON_HOST"):
+        assert np.array_equal(got, want)
+    else:
+        assert np.allclose(got[:, 2:], want[:, 2:], rtol=RATE_RTOL, atol=0), f"noise rates differ by {np.abs(got[:, 2:] / want[:, 2:] - 1).max()} (relative)"
+
+
 def posteriors(r, c, S):
     """{(h1,h2): freq/total} per sample for cluster c"""
     e0, e1 = int(r["dip_off"][c]), int(r["dip_off"][c + 1])
@@ -156,7 +171,8 @@ def test_config_C5_noise_genotyping_joint_30_samples(gpu_ctx, oracle):
     gg, got = eng.estimate_noise_and_genotypes(flat, cd_g)
     rg = gg.results()
     gg.close()
-    assert got.shape == (kw["chains"] * (1 + kw["burn"] + kw["iters"]), 2 + S) and np.array_equal(got, want)
+    assert got.shape == (kw["chains"] * (1 + kw["burn"] + kw["iters"]), 2 + S)
+    assert_noise_rows(got, want)
     exact = assert_parity(flat, ro, rg, kw["chains"] * kw["iters"])
     assert exact == flat["num_clusters"]
 
@@ -259,8 +275,8 @@ def test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path):
     og.close()
     assert len({tuple(c) for c in chains}) == kw["chains"] and all(0 < len(c) < 69 for c in chains)
     got = eng.estimate_noise(cd_g, flat, output_prefix=str(tmp_path / "noise"), variants_batch_size=25)
-    assert np.array_equal(got, want)
-    assert np.array_equal(cd_g.noise_rates(), final)
+    assert_noise_rows(got, want)
+    assert np.allclose(cd_g.noise_rates(), final, rtol=RATE_RTOL, atol=0)
     assert len(open(tmp_path / "noise.txt").read().split("\n")) == len(want) + 2
     # estimateNoiseAndGenotypes over all groups (nested groups included)
     cd_o, cd_g = cd(), cd()
@@ -271,9 +287,16 @@ def test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path):
     gg, got = eng.estimate_noise_and_genotypes(flat, cd_g)
     rg = gg.results()
     gg.close()
-    assert np.array_equal(got, want)
+    assert_noise_rows(got, want)
     exact = assert_parity(flat, ro, rg, kw["chains"] * kw["iters"])
     assert exact == flat["num_clusters"]
+
+
+def test_noise_drivers_host_draws_are_exact(gpu_ctx, oracle, tmp_path, monkeypatch):
+    """BT_NOISE_ON_HOST=1: the drivers iterate on the host (one synchronisation per iteration, the rates drawn by libstdc++'s own gamma distribution):
+    every rate equals the oracle's bit for bit"""
+    monkeypatch.setenv("BT_NOISE_ON_HOST", "1")
+    test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path)
 
 
 def test_unit_in_several_launches(gpu_ctx):

@@ -188,3 +188,23 @@ def test_default_mode_in_several_launches(orc):
         assert np.array_equal(a[k], b[k]), k
     assert len(pieces.parts) == -(-flat["num_groups"] // 4)
     whole.close(), pieces.close()
+
+
+def test_count_distribution_generator_travels():
+    """the run's generator (std::mt19937 + the gamma distribution's saved normal variate) exported after some draws and imported into another
+    CountDistribution continues the same stream of noise rates — what bt_gibbs_noise_chain relies on when a chain's draws move to the device"""
+    rng = np.random.default_rng(3)
+    a, b = _count_distribution(11), _count_distribution(99)
+    for i in range(7):   # an odd number of normal variates leaves one saved in some of these draws
+        a.sample_noise_parameters(rng.integers(0, 50, S * 256).astype(np.uint64))
+    words, saved = a.export_generator()
+    assert words[624] <= 624 and words[625] in (0, 1)
+    b.import_generator(words, saved)
+    for i in range(40):
+        h = rng.integers(0, 50, S * 256).astype(np.uint64)
+        a.sample_noise_parameters(h)
+        b.sample_noise_parameters(h)
+        assert np.array_equal(a.noise_rates(), b.noise_rates())
+    w2, s2 = b.export_generator()
+    w1, s1 = a.export_generator()
+    assert np.array_equal(w1, w2) and s1 == s2

@@ -20,11 +20,13 @@ for shape in ("D", "C", "B", "A"):
     at += n
 for w in which:
     f = flat if w == "+" else shard.take_groups(flat, np.arange(*bounds[w]))
+    t_create = time.perf_counter()
     g = lib.Gibbs(ctx, f, lut_g, lut_n, seed=42)
+    t_create = time.perf_counter() - t_create
     t = lib.Timer(ctx)
     ms = []
     for _ in range(2):
         t.start(); g.run(); t.stop(); ms.append(t.elapsed_ms())
-    print(json.dumps({"class": w, "S": S, "groups": int(f["num_groups"]), "clusters": int(f["num_clusters"]), "ms": ms, "device_GB": g.device_bytes() / 1e9,
+    print(json.dumps({"class": w, "S": S, "groups": int(f["num_groups"]), "clusters": int(f["num_clusters"]), "ms": ms, "create_s": round(t_create, 2), "device_GB": g.device_bytes() / 1e9,
                       "cluster_sweeps_per_s": f["num_clusters"] * 7000 / (min(ms) * 1e-3)}), flush=True)
     g.close()
