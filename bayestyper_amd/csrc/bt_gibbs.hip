@@ -167,6 +167,126 @@ __global__ __launch_bounds__(256) void noise_update_kernel(NoiseDev *__restrict_
     }
 }
 
+// ---- tile builder on the device (bt_gibbs_create) --------------------------------------------------------------------------------
+// The batch arrives as flat arrays (include/btgpu.h: bt_gibbs_batch).  One workgroup per cluster scatters the cluster's slices into its
+// tile's arrays (rows interleaved over the tile's width, TileDesc::wsh); the host computes only the descriptors below.
+struct BuildCluster {
+    uint32_t tile, lane, v, H, V, K, r0, u0, nu, m0, nm, nd0, nd, e0, ne, cid, A, hap_base, var_base, pad;
+    uint64_t mult_off, kvb_off, hapvar_off;
+};
+struct BuildGroup {
+    uint32_t tile, lane, nvert, src0, nsrc, group_index, g, pad;
+};
+struct BuildBatch {
+    const BuildCluster *clusters;
+    const BuildGroup *groups;
+    const uint8_t *group_ploidy;
+    const uint32_t *group_sources, *edges;
+    const uint8_t *hap_kmer_mult, *kmer_has_counts, *kmer_counts, *kmer_ic_mult;
+    const int32_t *kmer_shared;
+    const uint32_t *kv_off;
+    const uint16_t *kv_var;
+    const uint32_t *kv_bits, *unique_idx, *multi_idx;
+    const uint16_t *hap_allele;
+    const uint32_t *hapnest_off, *hapnest_idx;
+    const uint16_t *var_num_alleles;
+    const uint8_t *var_has_dependency;
+    const uint32_t *nestdep_cluster, *nestdep_var_off;
+    const uint16_t *nestdep_var;
+};
+template <typename T>
+__device__ inline void tput(uint8_t *tile_base, const TileDesc &d, int arr, uint64_t idx, uint32_t lane, T value) {
+    reinterpret_cast<T *>(tile_base + d.off[arr])[(idx << d.wsh) + lane] = value;
+}
+__global__ __launch_bounds__(256) void build_tiles_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, BuildBatch b, uint32_t S) {
+    const BuildCluster x = b.clusters[blockIdx.x];
+    const TileDesc &d = tiles[x.tile];
+    uint8_t *tb = pool + d.base;
+    const uint32_t l = x.lane, t = threadIdx.x, NT = blockDim.x;
+    const uint64_t v = x.v;
+    const uint32_t H = x.H, V = x.V, K = x.K, HW = (H + 31) / 32;
+    if (t < 8) {
+        const uint32_t dims[8] = {H, V, K, x.nu, x.nm, x.nd, x.ne, x.cid};
+        tput<uint32_t>(tb, d, A_VDIMS, v * 8 + t, l, dims[t]);
+    }
+    if (t == 8) tput<uint32_t>(tb, d, A_VDIMS2, v * 2, l, x.A);
+    // K x H multiplicities: per-lane contiguous in narrow tiles, interleaved rows otherwise
+    const uint8_t *M = b.hap_kmer_mult + x.mult_off;
+    for (uint64_t i = t; i < (uint64_t)K * H; i += NT) {
+        const uint32_t k = (uint32_t)(i / H), h = (uint32_t)(i - (uint64_t)k * H);
+        if (d.mat_width) (tb + d.off[A_M])[((v * d.mat_width + l) * d.Km + k) * d.Hm + h] = M[i];
+        else tput<uint8_t>(tb, d, A_M, (v * d.Km + k) * d.Hm + h, l, M[i]);
+    }
+    const uint32_t e0 = b.kv_off[x.r0];
+    for (uint32_t k = t; k < K; k += NT) {
+        const uint64_t r = (uint64_t)x.r0 + k;
+        tput<uint8_t>(tb, d, A_HASC, v * d.Km + k, l, b.kmer_has_counts[r]);
+        for (uint32_t s = 0; s < S; ++s) tput<uint8_t>(tb, d, A_COUNTS, (v * d.Km + k) * S + s, l, b.kmer_counts[r * S + s]);
+        tput<uint8_t>(tb, d, A_IC, (v * d.Km + k) * 2, l, b.kmer_ic_mult[2 * r]);
+        tput<uint8_t>(tb, d, A_IC, (v * d.Km + k) * 2 + 1, l, b.kmer_ic_mult[2 * r + 1]);
+        tput<int32_t>(tb, d, A_SHARED, v * d.Km + k, l, b.kmer_shared[r]);
+        tput<uint32_t>(tb, d, A_KVOFF, v * (d.Km + 1) + k, l, b.kv_off[r] - e0);
+    }
+    const uint32_t nnz = b.kv_off[(uint64_t)x.r0 + K] - e0;
+    if (t == 0) tput<uint32_t>(tb, d, A_KVOFF, v * (d.Km + 1) + K, l, nnz);
+    for (uint32_t e = t; e < nnz; e += NT) {
+        tput<uint16_t>(tb, d, A_KVVAR, v * d.NNZm + e, l, b.kv_var[e0 + e]);
+        for (uint32_t w = 0; w < HW; ++w) tput<uint32_t>(tb, d, A_KVBITS, (v * d.NNZm + e) * d.HWm + w, l, b.kv_bits[x.kvb_off + (uint64_t)e * HW + w]);
+    }
+    const uint32_t hn0 = b.hapnest_off[x.hap_base];
+    for (uint32_t h = t; h < H; h += NT) {
+        // A_HAPCELL: addHaplotypeKmerStats' source variant (VariantClusterHaplotypes.cpp:332-358) and the allele cell, per (haplotype, variant)
+        uint32_t last_non_missing = 0xFFFFu, albase = 0;
+        for (uint32_t vv = 0; vv < V; ++vv) {
+            const uint32_t al = b.hap_allele[x.hapvar_off + (uint64_t)h * V + vv], na = b.var_num_alleles[x.var_base + vv];
+            tput<uint16_t>(tb, d, A_HAPAL, (v * d.Hm + h) * d.Vm + vv, l, (uint16_t)al);
+            const bool missing = b.var_has_dependency[x.var_base + vv] && al == na - 1u;
+            if (!missing) last_non_missing = vv;
+            tput<uint32_t>(tb, d, A_HAPCELL, (v * d.Hm + h) * d.Vm + vv, l, last_non_missing | ((albase + al) << 16));
+            albase += na;
+        }
+        tput<uint32_t>(tb, d, A_HNOFF, v * (d.Hm + 1) + h, l, b.hapnest_off[x.hap_base + h] - hn0);
+    }
+    const uint32_t hn_n = b.hapnest_off[x.hap_base + H] - hn0;
+    if (t == 0) tput<uint32_t>(tb, d, A_HNOFF, v * (d.Hm + 1) + H, l, hn_n);
+    for (uint32_t i = t; i < hn_n; i += NT) tput<uint32_t>(tb, d, A_HNIDX, v * d.HNm + i, l, b.hapnest_idx[hn0 + i]);
+    if (t == 0) {   // per-variant arrays with a running allele base (a few entries)
+        uint32_t acc = 0;
+        for (uint32_t vv = 0; vv < V; ++vv) {
+            tput<uint16_t>(tb, d, A_VARNA, v * d.Vm + vv, l, b.var_num_alleles[x.var_base + vv]);
+            tput<uint8_t>(tb, d, A_VARDEP, v * d.Vm + vv, l, b.var_has_dependency[x.var_base + vv]);
+            tput<uint32_t>(tb, d, A_ALBASE, v * (d.Vm + 1) + vv, l, acc);
+            acc += b.var_num_alleles[x.var_base + vv];
+        }
+        tput<uint32_t>(tb, d, A_ALBASE, v * (d.Vm + 1) + V, l, acc);
+        const uint32_t ndv0 = b.nestdep_var_off[x.nd0];
+        const uint32_t NDm1 = d.NDm > 1 ? d.NDm : 1, NDVm1 = d.NDVm > 1 ? d.NDVm : 1;
+        for (uint32_t i = 0; i < x.nd; ++i) {
+            tput<uint32_t>(tb, d, A_NDCL, v * NDm1 + i, l, b.nestdep_cluster[x.nd0 + i]);
+            tput<uint32_t>(tb, d, A_NDVOFF, v * (d.NDm + 1) + i, l, b.nestdep_var_off[x.nd0 + i] - ndv0);
+        }
+        tput<uint32_t>(tb, d, A_NDVOFF, v * (d.NDm + 1) + x.nd, l, b.nestdep_var_off[x.nd0 + x.nd] - ndv0);
+        for (uint32_t i = 0, n = b.nestdep_var_off[x.nd0 + x.nd] - ndv0; i < n; ++i) tput<uint16_t>(tb, d, A_NDVAR, v * NDVm1 + i, l, b.nestdep_var[ndv0 + i]);
+        const uint32_t NEm1 = d.NEm > 1 ? d.NEm : 1;
+        for (uint32_t i = 0; i < x.ne; ++i) tput<uint32_t>(tb, d, A_EDGES0, v * NEm1 + i, l, b.edges[x.e0 + i]);
+    }
+    for (uint32_t i = t; i < x.nu; i += NT) tput<uint32_t>(tb, d, A_UNIQ0, v * d.NUm + i, l, b.unique_idx[x.u0 + i]);
+    for (uint32_t i = t; i < x.nm; i += NT) tput<uint32_t>(tb, d, A_MULTI0, v * d.NMm + i, l, b.multi_idx[x.m0 + i]);
+}
+__global__ __launch_bounds__(256) void build_groups_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, BuildBatch b, uint32_t G, uint32_t S) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= G) return;
+    const BuildGroup x = b.groups[i];
+    const TileDesc &d = tiles[x.tile];
+    uint8_t *tb = pool + d.base;
+    tput<uint32_t>(tb, d, A_GDIMS, 0, x.lane, x.nvert);
+    tput<uint32_t>(tb, d, A_GDIMS, 1, x.lane, x.nsrc);
+    tput<uint32_t>(tb, d, A_GDIMS, 2, x.lane, x.group_index);
+    tput<uint32_t>(tb, d, A_GDIMS, 3, x.lane, 1u);
+    for (uint32_t q = 0; q < x.nsrc; ++q) tput<uint32_t>(tb, d, A_SOURCES0, q, x.lane, b.group_sources[x.src0 + q]);
+    for (uint32_t s = 0; s < S; ++s) tput<uint8_t>(tb, d, A_PLOIDY, s, x.lane, b.group_ploidy[(uint64_t)x.g * S + s]);
+}
+
 // ---- host-side tile builder -------------------------------------------------------------------------------------
 struct TilePlan {
     TileDesc d;
@@ -272,8 +392,21 @@ const uint32_t kElemSize[A_COUNT] = {
 
 extern "C" {
 
+static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, bt_gibbs **out, uint64_t *plan_bytes);
+
 int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, bt_gibbs **out) {
-    if (!ctx || !params || !B || !out) return fail("bt_gibbs_create: null argument");
+    if (!out) return fail("bt_gibbs_create: null argument");
+    return gibbs_create_impl(ctx, params, B, out, nullptr);
+}
+
+int bt_gibbs_state_bytes(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, uint64_t *bytes) {
+    if (!bytes) return fail("bt_gibbs_state_bytes: null argument");
+    return gibbs_create_impl(ctx, params, B, nullptr, bytes);
+}
+
+// plan_bytes != nullptr: validate and lay the batch out only; *plan_bytes = device bytes bt_gibbs_create would allocate for it
+static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, bt_gibbs **out, uint64_t *plan_bytes) {
+    if (!ctx || !params || !B) return fail("bt_gibbs_create: null argument");
     const uint32_t S = params->num_samples, G = B->num_groups, C = B->num_clusters;
     if (S < 1 || S > 30) return fail("bt_gibbs_create: number of samples must be in 1..30");   // main.cpp:72
     if (!params->gender) return fail("bt_gibbs_create: gender array missing");
@@ -762,6 +895,13 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
         }
     }
     g->pool_bytes = pool + 256;
+    if (plan_bytes) {   // + the count-model tables, descriptors and the transient device copy of the flat batch the tile builder reads
+        uint64_t flat = (uint64_t)C * 160 + (uint64_t)G * (32 + S) + mult_off[C] + (uint64_t)B->kmer_off[C] * (S + 11) + (uint64_t)B->kv_off[B->kmer_off[C]] * 2 + kvb_off[C] * 4 +
+                        ((uint64_t)B->unique_off[C] + B->multi_off[C]) * 4 + hapvar_off[C] * 2 + (uint64_t)hap_base[C] * 4 + (uint64_t)B->hapnest_off[hap_base[C]] * 4;
+        *plan_bytes = g->pool_bytes + (uint64_t)S * (65536 + 256) * 8 + (uint64_t)ntiles * sizeof(TileDesc) + (uint64_t)C * sizeof(ClusterLoc) + flat;
+        bt_gibbs_destroy(g);
+        return BT_OK;
+    }
     {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->d_pool), g->pool_bytes);
         if (e != hipSuccess) {
@@ -773,105 +913,107 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
     g->device_bytes += g->pool_bytes;
     BT_TRYHIP(hipMemsetAsync(g->d_pool, 0, g->pool_bytes, ctx->stream));
 
-    // ---- build and upload the input image of every tile ----
-    std::vector<uint8_t> img;
+    // ---- the input arrays of every tile: the flat batch is uploaded as it is and scattered into the tiles' layout ON THE DEVICE
+    // (build_tiles_kernel, one workgroup per cluster).  The host only computes where things go: a descriptor per cluster.
     g->tiles.resize(ntiles);
-    for (uint32_t ti = 0; ti < ntiles; ++ti) {
-        const TileDesc &d = plans[ti].d;
-        g->tiles[ti] = d;
-        if (ti == blk_first[ti]) img.assign(plans[ti].in_bytes, 0);   // one image per pool block
-        for (uint32_t l = 0; l < d.num_lanes; ++l) {
-            const uint32_t gi = shapes[tile_start[ti] + l].g;
-            const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
-            g->group_tile[gi] = ti;
-            g->group_lane[gi] = l;
-            g->group_nvert[gi] = c1 - c0;
-            const uint32_t nsrc = B->group_source_off[gi + 1] - B->group_source_off[gi];
-            put<uint32_t>(img, d, A_GDIMS, 0, l, c1 - c0);
-            put<uint32_t>(img, d, A_GDIMS, 1, l, nsrc);
-            put<uint32_t>(img, d, A_GDIMS, 2, l, B->group_index[gi]);
-            put<uint32_t>(img, d, A_GDIMS, 3, l, 1u);
-            for (uint32_t i = 0; i < nsrc; ++i) put<uint32_t>(img, d, A_SOURCES0, i, l, B->group_sources[B->group_source_off[gi] + i]);
-            for (uint32_t s = 0; s < S; ++s) put<uint8_t>(img, d, A_PLOIDY, s, l, B->group_ploidy[(size_t)gi * S + s]);
-            for (uint32_t c = c0; c < c1; ++c) {
-                const size_t v = c - c0;
-                g->loc[c] = ClusterLoc{ti, l, (uint32_t)v, 0};
-                const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], r0 = B->kmer_off[c], K = B->kmer_off[c + 1] - r0;
-                const uint32_t nu = B->unique_off[c + 1] - B->unique_off[c], nm = B->multi_off[c + 1] - B->multi_off[c];
-                const uint32_t nd = B->nestdep_off[c + 1] - B->nestdep_off[c], ne = B->edge_off[c + 1] - B->edge_off[c];
-                const uint32_t dims[8] = {H, V, K, nu, nm, nd, ne, B->cluster_idx[c]};
-                for (int q = 0; q < 8; ++q) put<uint32_t>(img, d, A_VDIMS, v * 8 + q, l, dims[q]);
-                put<uint32_t>(img, d, A_VDIMS2, v * 2, l, g->h_A[c]);
-                const uint8_t *M = B->hap_kmer_mult + mult_off[c];
-                const uint32_t HW = (H + 31) / 32;
-                const uint32_t e0 = B->kv_off[r0];
-                for (uint32_t k = 0; k < K; ++k) {
-                    const size_t r = (size_t)r0 + k;
-                    if (d.mat_width) {   // per-lane contiguous: ((v * width + lane) * Km + k) * Hm + h
-                        uint8_t *row = img.data() + d.off[A_M] + (((size_t)v * d.mat_width + l) * d.Km + k) * d.Hm;
-                        for (uint32_t h = 0; h < H; ++h) row[h] = M[(size_t)k * H + h];
-                    } else
-                        for (uint32_t h = 0; h < H; ++h) put<uint8_t>(img, d, A_M, (v * d.Km + k) * d.Hm + h, l, M[(size_t)k * H + h]);
-                    put<uint8_t>(img, d, A_HASC, v * d.Km + k, l, B->kmer_has_counts[r]);
-                    for (uint32_t s = 0; s < S; ++s) put<uint8_t>(img, d, A_COUNTS, (v * d.Km + k) * S + s, l, B->kmer_counts[r * S + s]);
-                    put<uint8_t>(img, d, A_IC, (v * d.Km + k) * 2, l, B->kmer_ic_mult[2 * r]);
-                    put<uint8_t>(img, d, A_IC, (v * d.Km + k) * 2 + 1, l, B->kmer_ic_mult[2 * r + 1]);
-                    put<int32_t>(img, d, A_SHARED, v * d.Km + k, l, B->kmer_shared[r]);
-                    put<uint32_t>(img, d, A_KVOFF, v * (d.Km + 1) + k, l, B->kv_off[r] - e0);
-                }
-                put<uint32_t>(img, d, A_KVOFF, v * (d.Km + 1) + K, l, B->kv_off[(size_t)r0 + K] - e0);
-                const uint32_t nnz = B->kv_off[(size_t)r0 + K] - e0;
-                for (uint32_t e = 0; e < nnz; ++e) {
-                    put<uint16_t>(img, d, A_KVVAR, v * d.NNZm + e, l, B->kv_var[e0 + e]);
-                    for (uint32_t w = 0; w < HW; ++w) put<uint32_t>(img, d, A_KVBITS, (v * d.NNZm + e) * d.HWm + w, l, B->kv_bits[kvb_off[c] + (uint64_t)e * HW + w]);
-                }
-                const uint32_t hn0 = B->hapnest_off[hap_base[c]];
-                for (uint32_t h = 0; h < H; ++h) {
-                    for (uint32_t vv = 0; vv < V; ++vv) put<uint16_t>(img, d, A_HAPAL, (v * d.Hm + h) * d.Vm + vv, l, B->hap_allele[hapvar_off[c] + (size_t)h * V + vv]);
-                    {   // A_HAPCELL: addHaplotypeKmerStats' source variant (VariantClusterHaplotypes.cpp:332-358) and the allele cell, per (haplotype, variant)
-                        uint32_t last_non_missing = 0xFFFFu, albase = 0;
-                        for (uint32_t vv = 0; vv < V; ++vv) {
-                            const uint32_t al = B->hap_allele[hapvar_off[c] + (size_t)h * V + vv], na = B->var_num_alleles[var_base[c] + vv];
-                            const bool missing = B->var_has_dependency[var_base[c] + vv] && al == na - 1u;
-                            if (!missing) last_non_missing = vv;
-                            put<uint32_t>(img, d, A_HAPCELL, (v * d.Hm + h) * d.Vm + vv, l, last_non_missing | ((albase + al) << 16));
-                            albase += na;
-                        }
-                    }
-                    put<uint32_t>(img, d, A_HNOFF, v * (d.Hm + 1) + h, l, B->hapnest_off[hap_base[c] + h] - hn0);
-                }
-                put<uint32_t>(img, d, A_HNOFF, v * (d.Hm + 1) + H, l, B->hapnest_off[hap_base[c] + H] - hn0);
-                for (uint32_t i = 0, n = B->hapnest_off[hap_base[c] + H] - hn0; i < n; ++i) put<uint32_t>(img, d, A_HNIDX, v * d.HNm + i, l, B->hapnest_idx[hn0 + i]);
-                uint32_t acc = 0;
-                for (uint32_t vv = 0; vv < V; ++vv) {
-                    put<uint16_t>(img, d, A_VARNA, v * d.Vm + vv, l, B->var_num_alleles[var_base[c] + vv]);
-                    put<uint8_t>(img, d, A_VARDEP, v * d.Vm + vv, l, B->var_has_dependency[var_base[c] + vv]);
-                    put<uint32_t>(img, d, A_ALBASE, v * (d.Vm + 1) + vv, l, acc);
-                    acc += B->var_num_alleles[var_base[c] + vv];
-                }
-                put<uint32_t>(img, d, A_ALBASE, v * (d.Vm + 1) + V, l, acc);
-                const uint32_t nd0 = B->nestdep_off[c];
-                const uint32_t ndv0 = B->nestdep_var_off[nd0];
-                for (uint32_t i = 0; i < nd; ++i) {
-                    put<uint32_t>(img, d, A_NDCL, v * std::max<uint32_t>(d.NDm, 1) + i, l, B->nestdep_cluster[nd0 + i]);
-                    put<uint32_t>(img, d, A_NDVOFF, v * (d.NDm + 1) + i, l, B->nestdep_var_off[nd0 + i] - ndv0);
-                }
-                put<uint32_t>(img, d, A_NDVOFF, v * (d.NDm + 1) + nd, l, B->nestdep_var_off[nd0 + nd] - ndv0);
-                for (uint32_t i = 0, n = B->nestdep_var_off[nd0 + nd] - ndv0; i < n; ++i)
-                    put<uint16_t>(img, d, A_NDVAR, v * std::max<uint32_t>(d.NDVm, 1) + i, l, B->nestdep_var[ndv0 + i]);
-                for (uint32_t i = 0; i < nu; ++i) put<uint32_t>(img, d, A_UNIQ0, v * d.NUm + i, l, B->unique_idx[B->unique_off[c] + i]);
-                for (uint32_t i = 0; i < nm; ++i) put<uint32_t>(img, d, A_MULTI0, v * d.NMm + i, l, B->multi_idx[B->multi_off[c] + i]);
-                for (uint32_t i = 0; i < ne; ++i) put<uint32_t>(img, d, A_EDGES0, v * std::max<uint32_t>(d.NEm, 1) + i, l, B->edges[B->edge_off[c] + i]);
-            }
-        }
-        if (ti == blk_last[ti]) {
-            BT_TRYHIP(hipMemcpyAsync(g->d_pool + d.base, img.data(), plans[ti].in_bytes, hipMemcpyHostToDevice, ctx->stream));
-            BT_TRYHIP(hipStreamSynchronize(ctx->stream));   // img is reused
-        }
-    }
+    for (uint32_t ti = 0; ti < ntiles; ++ti) g->tiles[ti] = plans[ti].d;
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_tiles), (size_t)ntiles * sizeof(TileDesc)));
     g->allocs.push_back(g->d_tiles);
     BT_TRYHIP(hipMemcpyAsync(g->d_tiles, g->tiles.data(), (size_t)ntiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+    {
+        std::vector<BuildCluster> bc(C);
+        std::vector<BuildGroup> bg(G);
+        for (uint32_t ti = 0; ti < ntiles; ++ti) {
+            const TileDesc &d = plans[ti].d;
+            for (uint32_t l = 0; l < d.num_lanes; ++l) {
+                const uint32_t gi = shapes[tile_start[ti] + l].g;
+                const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
+                g->group_tile[gi] = ti;
+                g->group_lane[gi] = l;
+                g->group_nvert[gi] = c1 - c0;
+                bg[gi] = BuildGroup{ti, l, c1 - c0, B->group_source_off[gi], B->group_source_off[gi + 1] - B->group_source_off[gi], B->group_index[gi], gi, 0};
+                for (uint32_t c = c0; c < c1; ++c) {
+                    g->loc[c] = ClusterLoc{ti, l, c - c0, 0};
+                    BuildCluster &x = bc[c];
+                    x.tile = ti;
+                    x.lane = l;
+                    x.v = c - c0;
+                    x.H = B->num_haplotypes[c];
+                    x.V = B->num_variants[c];
+                    x.r0 = B->kmer_off[c];
+                    x.K = B->kmer_off[c + 1] - x.r0;
+                    x.u0 = B->unique_off[c];
+                    x.nu = B->unique_off[c + 1] - x.u0;
+                    x.m0 = B->multi_off[c];
+                    x.nm = B->multi_off[c + 1] - x.m0;
+                    x.nd0 = B->nestdep_off[c];
+                    x.nd = B->nestdep_off[c + 1] - x.nd0;
+                    x.e0 = B->edge_off[c];
+                    x.ne = B->edge_off[c + 1] - x.e0;
+                    x.cid = B->cluster_idx[c];
+                    x.A = g->h_A[c];
+                    x.mult_off = mult_off[c];
+                    x.kvb_off = kvb_off[c];
+                    x.hapvar_off = hapvar_off[c];
+                    x.hap_base = hap_base[c];
+                    x.var_base = var_base[c];
+                }
+            }
+        }
+        // device copies of the flat batch (freed after the build)
+        std::vector<void *> tmp;
+        auto up = [&](const void *h, size_t bytes, const void **d_out) -> hipError_t {
+            void *d = nullptr;
+            hipError_t e = hipMalloc(&d, std::max<size_t>(bytes, 16));
+            if (e != hipSuccess) return e;
+            tmp.push_back(d);
+            *d_out = d;
+            return bytes ? hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        };
+        const uint64_t R = B->kmer_off[C], NNZ = B->kv_off[R], Hs = hap_base[C], Vs = var_base[C], ND = B->nestdep_off[C];
+        BuildBatch bb{};
+        hipError_t e = hipSuccess;
+#define BT_UP(field, ptr, bytes) \
+    if (e == hipSuccess) e = up(ptr, bytes, reinterpret_cast<const void **>(&bb.field))
+        BT_UP(clusters, bc.data(), (size_t)C * sizeof(BuildCluster));
+        BT_UP(groups, bg.data(), (size_t)G * sizeof(BuildGroup));
+        BT_UP(group_ploidy, B->group_ploidy, (size_t)G * S);
+        BT_UP(group_sources, B->group_sources, (size_t)B->group_source_off[G] * 4);
+        BT_UP(edges, B->edges, (size_t)B->edge_off[C] * 4);
+        BT_UP(hap_kmer_mult, B->hap_kmer_mult, (size_t)mult_off[C]);
+        BT_UP(kmer_has_counts, B->kmer_has_counts, (size_t)R);
+        BT_UP(kmer_counts, B->kmer_counts, (size_t)R * S);
+        BT_UP(kmer_ic_mult, B->kmer_ic_mult, (size_t)R * 2);
+        BT_UP(kmer_shared, B->kmer_shared, (size_t)R * 4);
+        BT_UP(kv_off, B->kv_off, (size_t)(R + 1) * 4);
+        BT_UP(kv_var, B->kv_var, (size_t)NNZ * 2);
+        BT_UP(kv_bits, B->kv_bits, (size_t)kvb_off[C] * 4);
+        BT_UP(unique_idx, B->unique_idx, (size_t)B->unique_off[C] * 4);
+        BT_UP(multi_idx, B->multi_idx, (size_t)B->multi_off[C] * 4);
+        BT_UP(hap_allele, B->hap_allele, (size_t)hapvar_off[C] * 2);
+        BT_UP(hapnest_off, B->hapnest_off, (size_t)(Hs + 1) * 4);
+        BT_UP(hapnest_idx, B->hapnest_idx, (size_t)B->hapnest_off[Hs] * 4);
+        BT_UP(var_num_alleles, B->var_num_alleles, (size_t)Vs * 2);
+        BT_UP(var_has_dependency, B->var_has_dependency, (size_t)Vs);
+        BT_UP(nestdep_cluster, B->nestdep_cluster, (size_t)ND * 4);
+        BT_UP(nestdep_var_off, B->nestdep_var_off, (size_t)(ND + 1) * 4);
+        BT_UP(nestdep_var, B->nestdep_var, (size_t)B->nestdep_var_off[ND] * 2);
+#undef BT_UP
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(build_tiles_kernel, dim3(C), dim3(256), 0, ctx->stream, g->d_tiles, g->d_pool, bb, S);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(build_groups_kernel, dim3((G + 255) / 256), dim3(256), 0, ctx->stream, g->d_tiles, g->d_pool, bb, G, S);
+            e = hipGetLastError();
+        }
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);   // bc / bg and the temporaries are released below
+        for (void *d : tmp) (void)hipFree(d);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            bt_gibbs_destroy(g);
+            return fail(std::string("bt_gibbs_create: building the tiles: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+    }
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_loc), (size_t)C * sizeof(ClusterLoc)));
     g->allocs.push_back(g->d_loc);
     BT_TRYHIP(hipMemcpyAsync(g->d_loc, g->loc.data(), (size_t)C * sizeof(ClusterLoc), hipMemcpyHostToDevice, ctx->stream));

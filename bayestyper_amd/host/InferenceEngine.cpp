@@ -279,6 +279,27 @@ void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistrib
         }
         return;
     }
+    // The product's sampler: a unit larger than the GPU is genotyped as consecutive group ranges sized from the free HBM
+    // (bt_gibbs_state_bytes lays a range out without allocating); groups are independent and keep their unit-wide index.
+    if (!make_sampler && ctx && batch.numGroups() > 1) {
+        const bt_gibbs_params p = params(0);
+        const bt_gibbs_batch view = batch.view();
+        uint64_t need = 0, total = 0, free_bytes = 0;
+        int num_cu = 0;
+        int have = bt_gibbs_state_bytes(ctx, &p, &view, &need) == BT_OK && bt_ctx_info(ctx, &num_cu, &total, &free_bytes, nullptr, 0) == BT_OK;
+        if (const char *e = getenv("BT_GIBBS_FREE_BYTES")) free_bytes = strtoull(e, nullptr, 0);   // (tests: pretend a smaller GPU)
+        if (have && free_bytes && (double)need > 0.9 * (double)free_bytes) {
+            const uint32_t parts = (uint32_t)std::min<uint64_t>(batch.numGroups(), (uint64_t)((double)need / (0.75 * (double)free_bytes)) + 1);
+            if (!quiet) std::cout << "[" << getLocalTime() << "] " << batch.numGroups() << " groups need " << need / 1000000000.0 << " GB of sampler state (" << free_bytes / 1000000000.0
+                                  << " GB free): " << parts << " launches" << std::endl;
+            for (uint32_t q = 0; q < parts; q++) {   // (a range that still does not fit is cut again by the recursion)
+                std::vector<uint32_t> ids;
+                for (uint32_t g = (uint32_t)((uint64_t)batch.numGroups() * q / parts); g < (uint32_t)((uint64_t)batch.numGroups() * (q + 1) / parts); g++) ids.push_back(g);
+                if (!ids.empty()) runDefault(batch.take(ids), cd, collect);
+            }
+            return;
+        }
+    }
     std::unique_ptr<Sampler> sampler;
     try {
         sampler = newSampler(0, batch);

@@ -436,6 +436,9 @@ typedef struct bt_gibbs_batch {
 typedef struct bt_gibbs bt_gibbs;
 
 int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *batch, bt_gibbs **out);
+/* the device memory bt_gibbs_create would need for this batch (nothing is allocated): the host sizes its launches from it and
+ * bt_ctx_info's free HBM (InferenceEngine.cpp:335-382 hands groups to its workers in batches; here a batch is what fits the GPU) */
+int bt_gibbs_state_bytes(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *batch, uint64_t *bytes);
 int bt_gibbs_destroy(bt_gibbs *g);
 /* upload the count-model LUTs (see above); must be called before the first sweep and after every noise update */
 int bt_gibbs_set_lut(bt_gibbs *g, const double *h_genomic /* [S*256*256] */, const double *h_noise /* [S*256] */);

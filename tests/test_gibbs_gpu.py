@@ -319,7 +319,19 @@ def test_unit_in_several_launches(gpu_ctx):
     for k in ("dip_off", "h1", "h2", "freq", "cell_off", "stats"):
         assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(whole.posterior_summary(), parts.posterior_summary()) and len(parts.parts) == 4
-    whole.close(), parts.close()
+    # ... and sized by the engine itself from the free HBM (bt_gibbs_state_bytes against bt_ctx_info; here the GPU is pretended small)
+    import os
+
+    os.environ["BT_GIBBS_FREE_BYTES"] = str(6 << 20)
+    try:
+        auto = eng.estimate_genotypes(flat, cd)
+    finally:
+        del os.environ["BT_GIBBS_FREE_BYTES"]
+    c = auto.results()
+    for k in ("dip_off", "h1", "h2", "freq", "cell_off", "stats"):
+        assert np.array_equal(a[k], c[k]), k
+    assert len(auto.parts) > 1 and sum(auto.parts) == flat["num_groups"]
+    whole.close(), parts.close(), auto.close()
 
 
 def test_sharded_run_equals_unsharded_and_summary_definition(gpu_ctx, oracle):

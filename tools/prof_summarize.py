@@ -30,6 +30,15 @@ for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
     if out:
         t0 = min(x["start_ns"] for x in out)
         for x in out: x["start_ms"] = (x.pop("start_ns") - t0) / 1e6
+        # dispatches shorter than 0.1 ms (the thousands of per-iteration launches of a noise-driver chain, setup dispatches) are kept as one
+        # aggregate row per kernel
+        small = {}
+        for x in out:
+            if x["dur_ms"] < 0.1:
+                a = small.setdefault(x["kernel"], {"kernel": x["kernel"], "aggregate_of_dispatches_shorter_than_0.1_ms": 0, "dur_ms": 0.0})
+                a["aggregate_of_dispatches_shorter_than_0.1_ms"] += 1
+                a["dur_ms"] += x["dur_ms"]
+        out = [x for x in out if x["dur_ms"] >= 0.1] + list(small.values())
         json.dump(out, open(os.path.join(dest, f"{tag}_kernel_trace.json"), "w"), indent=0)
 agg = {}
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
