@@ -14,4 +14,31 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_traffic.py $out/summ_$tag $tag 3
 rm -rf $out/prof_$tag/trace $out/prof_$tag/pmc_*   # raw traces are large; summaries stay
+: > $out/summ_$tag/${tag}_sq_graph_stages.txt
+ls -la $out/summ_$tag
+# SQ counters of the two kernels that run one lane per cluster / group (find_paths_kernel, mg_order_kernel): tools/graph_stages.py
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM FETCH_SIZE WRITE_SIZE"; do
+  d=$out/prof_$tag/graph
+  rm -rf $d
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python tools/graph_stages.py > $d.log 2> $d.err
+  python - "$d" >> $out/summ_$tag/${tag}_sq_graph_stages.txt <<'PY'
+import csv, glob, sys
+agg, dur = {}, {}
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        for k in ("find_paths_kernel", "mg_order_kernel"):
+            if k in r["Kernel_Name"]:
+                agg[(k, r["Counter_Name"])] = agg.get((k, r["Counter_Name"]), 0.0) + float(r["Counter_Value"])
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        for k in ("find_paths_kernel", "mg_order_kernel"):
+            if k in r["Kernel_Name"]:
+                dur[k] = dur.get(k, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+for (k, c), v in sorted(agg.items()): print(k, c, "%.4g" % v)
+for k, v in sorted(dur.items()): print(k, "duration_ms", "%.3f" % v)
+PY
+  grep -h clusters $d.log | cut -c1-300 >> $out/summ_$tag/${tag}_sq_graph_stages.txt
+  rm -rf $d
+done
+for c in A B C D; do bash tools/sq_counters.sh $tag $c > /dev/null 2>&1; done
 ls -la $out/summ_$tag
