@@ -502,6 +502,64 @@ bt_diag_rng = _sig("bt_diag_rng", [C.c_uint32, C.c_int, vp, vp, C.c_uint64, vp])
 bt_diag_kmer_set_order = _sig("bt_diag_kmer_set_order", [vp, C.c_uint32, C.c_uint64, C.c_uint, vp, vp])
 
 
+bt_noise_model_create = _sig("bt_noise_model_create", [vp, C.c_uint32, vp, C.POINTER(vp)])
+bt_noise_model_destroy = _sig("bt_noise_model_destroy", [vp])
+bt_noise_model_set_rng = _sig("bt_noise_model_set_rng", [vp, vp])
+bt_noise_model_get_rng = _sig("bt_noise_model_get_rng", [vp, vp])
+NOISE_REDUCE = C.CFUNCTYPE(C.c_int, vp, vp, C.c_uint64)
+bt_gibbs_noise_chain = _sig("bt_gibbs_noise_chain", [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp])
+
+
+class NoiseRng(C.Structure):   # include/btgpu.h: bt_noise_rng
+    _fields_ = [("mt", C.c_uint32 * 624), ("mt_pos", C.c_uint32), ("saved_available", C.c_uint32), ("saved", C.c_double)]
+
+
+class NoiseModel:
+    """the noise half of the count model on the device (bt_noise_model_*): priors [(shape, scale)] per sample + the run's generator"""
+
+    def __init__(self, ctx, priors):
+        self.ctx, self.S = ctx, len(priors)
+        pr = np.ascontiguousarray(np.asarray(priors, np.float32).reshape(-1))
+        h = vp()
+        check(bt_noise_model_create(ctx.h, self.S, _np_ptr(pr), C.byref(h)))
+        self.h = h.value
+
+    def set_generator(self, words626, saved):
+        """words626 / saved as count_model.CountDistribution.export_generator() returns them"""
+        r = NoiseRng()
+        C.memmove(r.mt, np.ascontiguousarray(words626[:624], np.uint32).ctypes.data, 624 * 4)
+        r.mt_pos, r.saved_available, r.saved = int(words626[624]), int(words626[625]), float(saved)
+        check(bt_noise_model_set_rng(self.h, C.addressof(r)))
+
+    def get_generator(self):
+        r = NoiseRng()
+        check(bt_noise_model_get_rng(self.h, C.addressof(r)))
+        w = np.zeros(626, np.uint32)
+        w[:624] = np.frombuffer(r.mt, np.uint32)
+        w[624], w[625] = r.mt_pos, r.saved_available
+        return w, r.saved
+
+    def chain(self, gibbs, num_iterations, first_collect, reduce=None):
+        """bt_gibbs_noise_chain -> rates [num_iterations, S]; reduce(d_hist_ptr, n) must only enqueue work on the context's stream"""
+        rates = np.zeros(num_iterations * self.S)
+        cb = None
+        if reduce is not None:
+            def hook(_user, d_hist, n):
+                try:
+                    reduce(d_hist, n)
+                    return 0
+                except Exception:   # an exception must not unwind through the library's frames
+                    return 1
+            cb = NOISE_REDUCE(hook)
+        check(bt_gibbs_noise_chain(gibbs.h if gibbs is not None else None, self.h, num_iterations, first_collect, C.cast(cb, vp) if cb is not None else None, None, _np_ptr(rates)))
+        return rates.reshape(num_iterations, self.S)
+
+    def close(self):
+        if self.h:
+            bt_noise_model_destroy(self.h)
+            self.h = None
+
+
 class Gibbs:
     """A batch of variant-cluster groups on one GPU (bt_gibbs_*).  `flat` is a dict as produced by bayestyper_amd.synth."""
 

@@ -117,3 +117,70 @@ def test_two_ranks_when_two_gpus_are_visible():
     for p in procs:
         p.join(120)
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1] and all(p.exitcode == 0 for p in procs)
+
+
+def test_noise_chain_on_the_device_with_the_enqueued_all_reduce(gpu_ctx, oracle):
+    """bt_gibbs_noise_chain, the noise drivers' chain without a host round trip: (1) against the host loop (sweep, noise counts, libstdc++'s gamma draws of
+    CountDistribution) — the same rates within 1e-12, and the generator handed back continues the host's stream; (2) with the reduction hook the ranks of a
+    multi-GPU run install — bt_comm_allreduce_hist enqueued on the context's stream between the histogram and the draw (a one-rank communicator here: identity)
+    — the chain gives the same rates again; (3) without a sampler (a rank that holds no group in this chain) the draws still advance the generator."""
+    import _oracle
+    from bayestyper_amd import comm as btcomm, lib, synth
+    from bayestyper_amd.host import count_model
+
+    S, n_it = 3, 40
+    flat = synth.concat([synth.make_batch("A", 50, S, seed=3, templates=5), synth.make_batch("C", 2, S, seed=4), synth.make_batch("B", 6, S, seed=5, templates=2)])
+    kw = dict(seed=9, chains=1, burn=10, iters=30, noise_seeding=1)
+
+    def cd():
+        d = count_model.CountDistribution(S, prior=(1.0, 0.01), seed=kw["seed"])
+        for s in range(S):
+            d.set_genomic(s, 15.0, 30.0)
+        return d
+
+    # host loop
+    c0 = cd()
+    g = lib.Gibbs(gpu_ctx, flat, *c0.tables(), **kw)
+    g.init_chain(0)
+    want = []
+    for it in range(n_it):
+        g.sweep(1, it >= 10)
+        c0.sample_noise_parameters(g.noise_counts())
+        g.set_noise_lut(c0.noise_table())
+        want.append(c0.noise_rates().copy())
+    res_host = g.results()
+    g.close()
+    want = np.array(want)
+
+    def device_chain(reduce):
+        c1 = cd()
+        g1 = lib.Gibbs(gpu_ctx, flat, *c1.tables(), **kw)
+        g1.init_chain(0)
+        m = lib.NoiseModel(gpu_ctx, [(1.0, 0.01)] * S)
+        m.set_generator(*c1.export_generator())
+        got = m.chain(g1, n_it, 10, reduce)
+        gen = m.get_generator()
+        res = g1.results()
+        m.close(), g1.close()
+        return got, gen, res
+
+    got, gen, res_dev = device_chain(None)
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+    w_host, s_host = c0.export_generator()
+    assert np.array_equal(gen[0], w_host) and gen[0][625] == w_host[625] and abs(gen[1] - s_host) <= 1e-12 * max(1.0, abs(s_host))
+    for k in ("dip_off", "h1", "h2", "freq", "cell_off"):
+        assert np.array_equal(res_host[k], res_dev[k]), k
+    one = btcomm.Comm(gpu_ctx, btcomm.unique_id(), 0, 1)
+    got2, gen2, _ = device_chain(lambda d_hist, n: one.allreduce(d_hist, n))
+    assert np.array_equal(got2, got) and np.array_equal(gen2[0], gen[0])
+    # a rank without groups: zero histograms, the prior's posterior, the generator advances
+    m = lib.NoiseModel(gpu_ctx, [(1.0, 0.01)] * S)
+    c2 = cd()
+    before = c2.export_generator()
+    m.set_generator(*before)
+    r = m.chain(None, 5, 5, lambda d_hist, n: one.allreduce(d_hist, n))
+    for it in range(5):
+        c2.sample_noise_parameters(np.zeros(S * 256, np.uint64))
+        assert np.allclose(r[it], c2.noise_rates(), rtol=1e-12, atol=0)
+    assert np.array_equal(m.get_generator()[0], c2.export_generator()[0])
+    m.close(), one.close()
