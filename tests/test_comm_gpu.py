@@ -167,7 +167,7 @@ def test_noise_chain_on_the_device_with_the_enqueued_all_reduce(gpu_ctx, oracle)
     got, gen, res_dev = device_chain(None)
     assert np.allclose(got, want, rtol=1e-12, atol=0)
     w_host, s_host = c0.export_generator()
-    assert np.array_equal(gen[0], w_host) and gen[0][625] == w_host[625] and abs(gen[1] - s_host) <= 1e-12 * max(1.0, abs(s_host))
+    assert np.array_equal(gen[0], w_host) and (not w_host[625] or abs(gen[1] - s_host) <= 1e-12 * max(1.0, abs(s_host)))   # (the saved variate counts only while it is available)
     for k in ("dip_off", "h1", "h2", "freq", "cell_off"):
         assert np.array_equal(res_host[k], res_dev[k]), k
     one = btcomm.Comm(gpu_ctx, btcomm.unique_id(), 0, 1)
