@@ -28,6 +28,9 @@ namespace bt {
 hipError_t launch_gibbs_simple_kernel(unsigned grid, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
                                       unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
 hipError_t prepare_gibbs_simple_kernel(int max_lds);
+#ifdef BT_PROF
+hipError_t simple_prof_read(unsigned long long *h_out32, int reset);
+#endif
 }  // namespace bt
 
 namespace {
@@ -1505,6 +1508,9 @@ int bt_diag_prof(unsigned long long *h_out16, int reset) {
         unsigned long long z[32] = {0};
         BT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, 32 * 8));
     }
+    unsigned long long more[32];   // + the simple kernel's translation unit
+    BT_HIP(bt::simple_prof_read(more, reset));
+    for (int i = 0; i < 32; ++i) h_out16[i] += more[i];
     return BT_OK;
 }
 #endif

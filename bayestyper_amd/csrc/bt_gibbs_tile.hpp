@@ -28,6 +28,9 @@ constexpr double BT_DBL_EPS = 2.220446049250313080847263336181640625e-16;
 #ifndef BT_LINEAR_DRAW_MIN
 #define BT_LINEAR_DRAW_MIN 4u   // candidate sets up to this size always use the reference's chain of logAddition calls
 #endif
+#ifndef BT_UC_INVALIDATE_MIN
+#define BT_UC_INVALIDATE_MIN 64u   // clearGenotyperCache between the sweeps of a chain: tables above this many entries are invalidated and refilled on demand (block-wise), smaller ones rebuilt whole
+#endif
 #ifndef BT_EVAL_BLOCK
 #define BT_EVAL_BLOCK 4u        // candidates evaluated per step of sample_diplotypes' blocked evaluation (their cache words are requested together)
 #endif
@@ -711,7 +714,7 @@ __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool al
         // every entry anyway, and for small tables.  A large table cleared between the sweeps of a chain (clearGenotyperCache of the
         // noise drivers) is only invalidated: the sweeps that follow ask for the pairs of the few non-zero haplotypes, which are
         // then computed on demand like the reference does
-        c.sc()[SC_UC_DIRTY] = (!all_copies_run && d.cache_entries > 16384u) ? 2u : 1u;
+        c.sc()[SC_UC_DIRTY] = (!all_copies_run && d.cache_entries > BT_UC_INVALIDATE_MIN) ? 2u : 1u;
     } else if (d.cache_mode == 1) {
         TPtr<uint32_t> tg = c.uctag();
         const uint32_t sub = all_copies_run ? d.cache_entries / c.t.copies : d.cache_entries;
@@ -934,6 +937,74 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
         uc[slot] = acc;
     }
     return acc;
+}
+
+// The misses of a block of candidates evaluated TOGETHER (the noise drivers clear the caches every iteration, so every sweep asks for the sums
+// of its candidates again): one pass over the k-mer subset, four k-mers per step — the shared operands (intercluster multiplicity, count) are
+// read once per k-mer, the candidates' multiplicity rows and table lookups are independent loads — instead of one pass per candidate.
+// Every sum still runs in subset order, so the values are those of unique_log_prob; they are stored in the table the same way.
+__device__ inline void unique_log_prob_block(const Vx &c, const GParams BT_CAS &P, uint32_t s, const uint16_t (&ha)[EVB], const uint16_t (&hb)[EVB], const bool (&need)[EVB],
+                                             uint32_t nsub_u, double (&out)[EVB]) {
+    const TileDesc BT_CAS &d = c.d();
+    const uint32_t Hm = d.Hm, S = P.S;
+    const uint8_t gender = P.gender[s];
+    const Vx::RPtr<uint8_t> sm = c.subm();
+    TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
+    uint16_t a[EVB], b[EVB];
+#pragma unroll
+    for (uint32_t q = 0; q < EVB; ++q) {   // safe addresses for the slots that need nothing
+        a[q] = need[q] ? ha[q] : (uint16_t)0;
+        b[q] = need[q] ? hb[q] : NOHAP;
+    }
+    double acc[EVB];
+#pragma unroll
+    for (uint32_t q = 0; q < EVB; ++q) acc[q] = 0;
+    uint32_t i = 0;
+    for (; i + 4 <= nsub_u; i += 4) {
+        uint8_t m[4][EVB], cn[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint8_t icn = sic[2 * (i + r) + gender];
+            cn[r] = scn[(i + r) * S + s];
+#pragma unroll
+            for (uint32_t q = 0; q < EVB; ++q) {
+                uint8_t mm = sm[(i + r) * Hm + a[q]];
+                if (b[q] != NOHAP) mm = (uint8_t)(mm + sm[(i + r) * Hm + b[q]]);
+                m[r][q] = (uint8_t)(mm + icn);
+            }
+        }
+        double lp[4][EVB];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+            for (uint32_t q = 0; q < EVB; ++q) lp[r][q] = count_log_prob(P, s, m[r][q], cn[r]);
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+            for (uint32_t q = 0; q < EVB; ++q) acc[q] += lp[r][q];
+    }
+    for (; i < nsub_u; ++i) {
+        const uint8_t icn = sic[2 * i + gender], cn = scn[i * S + s];
+#pragma unroll
+        for (uint32_t q = 0; q < EVB; ++q) {
+            uint8_t mm = sm[i * Hm + a[q]];
+            if (b[q] != NOHAP) mm = (uint8_t)(mm + sm[i * Hm + b[q]]);
+            acc[q] += count_log_prob(P, s, (uint8_t)(mm + icn), cn);
+        }
+    }
+    const Vx::UCPtr uc = c.ucache();
+#pragma unroll
+    for (uint32_t q = 0; q < EVB; ++q) {
+        out[q] = acc[q];
+        if (!need[q]) continue;
+        const uint32_t idx = dip_index(c, ha[q], hb[q]);
+        if (d.cache_mode == 0) uc[(uint32_t)s * d.Dcm + idx] = acc[q];
+        else if (d.cache_mode == 1) {
+            const uint32_t key = s * d.Dcm + idx + 1u, slot = hashed_slot(c, key);
+            c.uctag()[slot] = key;
+            uc[slot] = acc[q];
+        }
+    }
 }
 
 // Dense-table tiles (cache_mode 0) do not fill the unique-part cache on demand: a miss would stall the 63 other lanes of the
@@ -1719,6 +1790,21 @@ __device__ BT_SWEEPFN void sample_diplotypes(Env env, uint32_t vtx, bool collect
                             }
                     }
                 }
+                {   // dense tables are complete (fill_unique_cache) or hold NaN where not computed yet; hashed tables fill on demand: the block's misses together
+                    bool umiss[EVB], any = false;
+#pragma unroll
+                    for (uint32_t q = 0; q < EVB; ++q) {
+                        umiss[q] = q < nb && !((dd.cache_mode == 0 && uval[q] == uval[q]) || (dd.cache_mode == 1 && utag[q] == ukey[q]));
+                        any = any || umiss[q];
+                    }
+                    if (any) {
+                        double fresh[EVB];
+                        unique_log_prob_block(c, P, s, ha, hb, umiss, nsub_u, fresh);
+#pragma unroll
+                        for (uint32_t q = 0; q < EVB; ++q)
+                            if (umiss[q]) uval[q] = fresh[q];
+                    }
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < EVB; ++q) {
                     if (q < nb) {
@@ -1726,9 +1812,7 @@ __device__ BT_SWEEPFN void sample_diplotypes(Env env, uint32_t vtx, bool collect
                         if (!dipl) lp += la[q];
                         else if (ha[q] == hb[q]) lp += 2 * la[q];
                         else lp += BT_LN2 + la[q] + lb[q];
-                        // dense tables are complete (fill_unique_cache) or hold NaN where not computed yet; hashed tables fill on demand
-                        const bool uhit = (dd.cache_mode == 0 && uval[q] == uval[q]) || (dd.cache_mode == 1 && utag[q] == ukey[q]);
-                        lp += uhit ? uval[q] : unique_log_prob(c, P, s, ha[q], hb[q], nsub_u);
+                        lp += uval[q];
                         if (multi) lp += mval[q];
                         lpmax = lp > lpmax ? lp : lpmax;
                         cum[base + q] = lp;
