@@ -1045,7 +1045,13 @@ int bt_paths_count_multigroup(bt_paths *p, const uint32_t *h_cluster_group, bt_b
     MGH(hipGetLastError());
     MGH(hipMemcpyAsync(counters, d_counters, 16, hipMemcpyDeviceToHost, st));
     MGH(hipStreamSynchronize(st));
-    rc = bt_table_insert_batch(multigroup_table, d_out, counters[0], 0);
+    {   // the reference's KmerHash grows on demand; this table is grown before the unit's multigroup k-mers go in (their number is known here)
+        uint64_t keys = 0, capacity = 0;
+        int overflowed = 0;
+        rc = bt_table_status(multigroup_table, &keys, &capacity, &overflowed);
+        if (rc == BT_OK && 2 * (keys + counters[0]) > capacity) rc = bt_table_reserve(multigroup_table, keys + counters[0]);
+    }
+    if (rc == BT_OK) rc = bt_table_insert_batch(multigroup_table, d_out, counters[0], 0);
     if (rc == BT_OK) rc = bt_paths_count_kmers(p, path_bloom);
     if (rc == BT_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail("bt_paths_count_multigroup: device error");
     cleanup();

@@ -46,12 +46,14 @@ KMER_MATCH_BYTES_PER_RECORD = 15.9   # 13 B record + E[probes] + 
 
 
 def source_hash():
-    """hash of the device sources the library was built from: profiles/ summaries made from the same sources carry the same hash"""
+    """hash of the device sources of the kernels a step runs (Gibbs sampler, count table + KMC scan, Bloom filter, their shared headers — not the
+    graph-stage kernels of bt_paths.hip / bt_find_paths.hip, which a step does not launch): profiles/ summaries made from the same sources carry the same hash"""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "bayestyper_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "bayestyper_amd", "csrc", "comm", "*.hip"))):
+    names = ("bt_gibbs", "bt_rng_device", "bt_table", "bt_bloom", "bt_kmer_device", "bt_internal", "bt_ctx")
+    for f in sorted(f for f in glob.glob(os.path.join(ROOT, "bayestyper_amd", "csrc", "*.h*")) if os.path.basename(f).startswith(names)):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
