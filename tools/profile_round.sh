@@ -14,6 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_traffic.py $out/summ_$tag $tag 3
 rm -rf $out/prof_$tag/trace $out/prof_$tag/pmc_*   # raw traces are large; summaries stay
+if [ -n "$BT_PROFILE_QUICK" ]; then ls -la $out/summ_$tag; exit 0; fi   # the passes below do not depend on the Gibbs sources
 : > $out/summ_$tag/${tag}_sq_graph_stages.txt
 ls -la $out/summ_$tag
 # SQ counters of the two kernels that run one lane per cluster / group (find_paths_kernel, mg_order_kernel): tools/graph_stages.py
