@@ -305,6 +305,14 @@ inline void put(std::vector<uint8_t> &img, const TileDesc &d, int arr, size_t id
 
 }  // namespace
 
+struct FillChunk {
+    uint64_t off;      // bytes from the pool
+    uint32_t words, pad;
+};
+struct PrefillItem {
+    uint32_t tile, lane, v, pad;
+};
+
 struct bt_gibbs {
     bt_ctx *ctx = nullptr;
     GParams P{};
@@ -332,7 +340,15 @@ struct bt_gibbs {
         uint32_t *d_tiles = nullptr;
         hipStream_t stream = nullptr;     // nullptr: the context's stream
         hipEvent_t done = nullptr;
+        // the tiles' large dense tables of unique-k-mer sums in pieces of <= 256 KB: clearGenotyperCache between two iterations of the noise
+        // drivers invalidates them with the whole GPU (nan_fill_kernel) instead of the tile's own lanes
+        FillChunk *d_fill = nullptr;
+        uint32_t num_fill = 0;
+        // (tile, lane, vertex) of every vertex with such a table: ucache_prefill_kernel
+        struct PrefillItem *d_prefill = nullptr;
+        uint32_t num_prefill = 0;
     };
+    bool prefill_armed = false, wide_fill = true;   // wide_fill: BT_GIBBS_NO_WIDE_FILL unset
     std::vector<LaunchClass> classes;      // hungriest first
     hipEvent_t ev_fork = nullptr;
     uint32_t trace_sweeps = 0;
@@ -345,25 +361,130 @@ struct bt_gibbs {
 
 namespace {
 
+__global__ __launch_bounds__(256) void nan_fill_kernel(uint8_t *__restrict__ pool, const FillChunk *__restrict__ chunks) {
+    const FillChunk c = chunks[blockIdx.x];
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(pool + c.off);
+    for (uint32_t i = threadIdx.x; i < c.words; i += 256) p[i] = 0x7FF8000000000000ULL;   // "not computed" (unique_log_prob tests v == v)
+}
+
+// The sums a sweep of the noise drivers will ask for, computed by the whole GPU before the sweep starts.  clearGenotyperCache empties the
+// tables after every iteration, so each sweep evaluates its candidates' sums over the k-mer subset again; inside the sweep that work is bound to the
+// lanes of the group's own tile (an iteration then lasts as long as the largest group).  The candidates of a vertex visit are the pairs (and, for a
+// nested vertex with one parental copy, the singles) of the haplotypes with a non-zero frequency, and the frequencies of a vertex only change at the
+// end of its own visit: the set is known when the sweep starts.  One workgroup per (vertex of a group, sample); every entry is the sum
+// unique_log_prob_block computes, stored where the sweep looks it up; whatever is missing is still computed on demand.
+constexpr uint32_t kPrefillMaxH = 2048;
+__global__ __launch_bounds__(256) void ucache_prefill_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg,
+                                                              const PrefillItem *__restrict__ items) {
+    __shared__ uint16_t nzl[kPrefillMaxH];
+    __shared__ uint32_t nnz_sh;
+    const PrefillItem it = items[blockIdx.x];
+    const uint32_t s = blockIdx.y;
+    const GParams BT_CAS &P = *(const GParams BT_CAS *)Pg;
+    Tile t;
+    t.d = (const TileDesc BT_CAS *)&tiles[it.tile];
+    t.base = (uint8_t BT_GAS *)(pool + t.d->base);
+    t.lane = it.lane;
+    t.plane = it.lane + t.d->pool_lane0;
+    t.wsh = t.d->wsh;
+    t.part = 0;
+    t.copies = t.d->copies;
+    t.hot = nullptr;
+    t.resident = 0xFFFFFFFFu;
+    const Vx c = make_vx(t, it.v);
+    SPtrF<uint32_t, LANES> sc = c.sc();
+    if (!sc[SC_CONSTRUCTED] || sc[SC_UC_DIRTY] || c.H > kPrefillMaxH) return;   // (a table to be rebuilt whole is rebuilt by the sweep)
+    if (threadIdx.x == 0) nnz_sh = 0;
+    __syncthreads();
+    {
+        SPtrF<uint8_t, LANES> nz = c.nz();
+        for (uint32_t h = threadIdx.x; h < c.H; h += 256)
+            if (nz[h]) nzl[atomicAdd(&nnz_sh, 1u)] = (uint16_t)h;   // (any order: the entries are independent)
+    }
+    __syncthreads();
+    const uint32_t nnz = nnz_sh, pairs = nnz * (nnz + 1) / 2, total = pairs + (t.d->nvm > 1 ? nnz : 0u);
+    const uint32_t nsub_u = sc[SC_NSUB_U];
+    const TileDesc BT_CAS &d = c.d();
+    const Vx::UCPtr uc = c.ucache();
+    for (uint32_t base = EVB * threadIdx.x; base < total; base += EVB * 256) {
+        uint16_t ha[EVB], hb[EVB];
+        bool need[EVB], any = false;
+        uint32_t a = 0, b = 0;
+        if (base < pairs) {   // row a of the triangle holds nnz - a pairs
+            uint32_t q = base, left = nnz;
+            while (q >= left) {
+                q -= left;
+                ++a;
+                --left;
+            }
+            b = a + q;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < EVB; ++q) {
+            const uint32_t i = base + q;
+            need[q] = false;
+            ha[q] = 0;
+            hb[q] = NOHAP;
+            if (i >= total) continue;
+            if (i < pairs) {
+                uint16_t x = nzl[a], y = nzl[b];
+                if (x > y) {   // (the list is unordered here; dip_index wants h1 <= h2)
+                    const uint16_t z = x;
+                    x = y;
+                    y = z;
+                }
+                ha[q] = x;
+                hb[q] = y;
+                if (++b == nnz) {
+                    ++a;
+                    b = a;
+                }
+            } else {
+                ha[q] = nzl[i - pairs];
+            }
+            const double v = uc[(uint32_t)s * d.Dcm + dip_index(c, ha[q], hb[q])];
+            need[q] = !(v == v);
+            any = any || need[q];
+        }
+        if (any) {
+            double out[EVB];
+            unique_log_prob_block(c, P, s, ha, hb, need, nsub_u, out);
+        }
+    }
+}
+
 int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hist) {
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     BT_HIP(hipSetDevice(g->ctx->device));
+    if (op == OP_NOISE && !g->wide_fill) a0 = 0;
+    if (op == OP_INIT_CHAIN) a1 = g->wide_fill ? 1u : 0u;
+    const bool wide = (op == OP_NOISE && a0 != 0) || (op == OP_INIT_CHAIN && a1 != 0);
     TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
     const bool fork = g->classes.size() > 1;
     if (fork) BT_HIP(hipEventRecord(g->ev_fork, g->ctx->stream));
     for (auto &c : g->classes) {
         hipStream_t st = c.stream ? c.stream : g->ctx->stream;
         if (c.stream) BT_HIP(hipStreamWaitEvent(st, g->ev_fork, 0));
+        if (op == OP_SWEEP && g->prefill_armed && c.num_prefill) {
+            hipLaunchKernelGGL(ucache_prefill_kernel, dim3(c.num_prefill, g->S), dim3(256), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const GParams *)g->d_params,
+                               (const PrefillItem *)c.d_prefill);
+            BT_CHECK_LAUNCH();
+        }
         if (c.simple && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
             BT_HIP(launch_gibbs_simple_kernel((unsigned)c.tiles.size(), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
         else
             hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)c.tiles.size()), dim3(LANES * c.split), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
                                (const uint32_t *)c.d_tiles);
         BT_CHECK_LAUNCH();
+        if (wide && c.num_fill) {
+            hipLaunchKernelGGL(nan_fill_kernel, dim3(c.num_fill), dim3(256), 0, st, g->d_pool, (const FillChunk *)c.d_fill);
+            BT_CHECK_LAUNCH();
+        }
         if (c.stream) BT_HIP(hipEventRecord(c.done, st));
     }
     for (auto &c : g->classes)
         if (c.stream) BT_HIP(hipStreamWaitEvent(g->ctx->stream, c.done, 0));
+    g->prefill_armed = wide;   // the sweep that follows a chain start or a cache-clearing noise count starts with the prefill
     return BT_OK;
 }
 
@@ -1070,11 +1191,42 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_simple_kernel((int)kHotBudget));
         BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        g->wide_fill = !getenv("BT_GIBBS_NO_WIDE_FILL");
         for (size_t i = 0; i < g->classes.size(); ++i) {
             auto &c = g->classes[i];
             BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_tiles), c.tiles.size() * 4));
             g->allocs.push_back(c.d_tiles);
             BT_TRYHIP(hipMemcpyAsync(c.d_tiles, c.tiles.data(), c.tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            std::vector<FillChunk> fill;
+            for (uint32_t ti : c.tiles) {
+                const TileDesc &d = g->tiles[ti];
+                if (!(d.cache_mode == 0 && !d.simple && d.cache_entries > BT_UC_INVALIDATE_MIN && d.hoff[A_UCACHE] == NOHOT)) continue;   // (cache_clear's condition)
+                const uint64_t words = ((uint64_t)d.nvm * d.cache_entries) << d.wsh;
+                for (uint64_t w = 0; w < words; w += 32768) fill.push_back(FillChunk{d.base + d.off[A_UCACHE] + w * 8, (uint32_t)std::min<uint64_t>(32768, words - w), 0u});
+            }
+            std::vector<PrefillItem> pre;
+            if (!fill.empty() && !getenv("BT_GIBBS_NO_PREFILL")) {
+                std::vector<uint8_t> in_class(ntiles, 0);
+                for (uint32_t ti : c.tiles) {
+                    const TileDesc &d = g->tiles[ti];
+                    in_class[ti] = d.cache_mode == 0 && !d.simple && d.cache_entries > BT_UC_INVALIDATE_MIN && d.hoff[A_UCACHE] == NOHOT;
+                }
+                for (uint32_t gi = 0; gi < g->G; ++gi)
+                    if (in_class[g->group_tile[gi]])
+                        for (uint32_t v = 0; v < g->group_nvert[gi]; ++v) pre.push_back(PrefillItem{g->group_tile[gi], g->group_lane[gi], v, 0u});
+            }
+            if (!pre.empty()) {
+                BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_prefill), pre.size() * sizeof(PrefillItem)));
+                g->allocs.push_back(c.d_prefill);
+                BT_TRYHIP(hipMemcpy(c.d_prefill, pre.data(), pre.size() * sizeof(PrefillItem), hipMemcpyHostToDevice));
+                c.num_prefill = (uint32_t)pre.size();
+            }
+            if (!fill.empty() && !getenv("BT_GIBBS_NO_WIDE_FILL")) {
+                BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_fill), fill.size() * sizeof(FillChunk)));
+                g->allocs.push_back(c.d_fill);
+                BT_TRYHIP(hipMemcpy(c.d_fill, fill.data(), fill.size() * sizeof(FillChunk), hipMemcpyHostToDevice));
+                c.num_fill = (uint32_t)fill.size();
+            }
             if (i + 1 < g->classes.size()) {   // the last class runs on the context's stream
                 int prio_lo = 0, prio_hi = 0;   // the hungrier classes (created first) get the higher dispatch priority
                 BT_TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -1158,7 +1310,7 @@ int bt_gibbs_noise_counts(bt_gibbs *g, uint64_t *d_hist, int zero_first) {
     if (!g || !d_hist) return fail("bt_gibbs_noise_counts: null argument");
     BT_HIP(hipSetDevice(g->ctx->device));
     if (zero_first) BT_HIP(hipMemsetAsync(d_hist, 0, (size_t)g->S * 256 * 8, g->ctx->stream));
-    return launch(g, OP_NOISE, 0, 0, reinterpret_cast<unsigned long long *>(d_hist));
+    return launch(g, OP_NOISE, 1, 0, reinterpret_cast<unsigned long long *>(d_hist));
 }
 
 int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_samples, uint64_t *h_hist) {
@@ -1178,7 +1330,7 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
     int rc = launch(g, OP_SWEEP, 1, collect_samples ? 1u : 0u, nullptr);
     if (rc != BT_OK) return rc;
     BT_HIP(hipMemsetAsync(g->d_iter_hist, 0, nh * 8, st));
-    rc = launch(g, OP_NOISE, 0, 0, reinterpret_cast<unsigned long long *>(g->d_iter_hist));
+    rc = launch(g, OP_NOISE, 1, 0, reinterpret_cast<unsigned long long *>(g->d_iter_hist));
     if (rc != BT_OK) return rc;
     BT_HIP(hipMemcpyAsync(g->h_pin_hist, g->d_iter_hist, nh * 8, hipMemcpyDeviceToHost, st));
     BT_HIP(hipStreamSynchronize(st));
@@ -1266,7 +1418,7 @@ int bt_gibbs_noise_chain(bt_gibbs *g, bt_noise_model *m, uint32_t num_iterations
         if (rc != BT_OK) break;
         e = hipMemsetAsync(m->d_hist, 0, nh * 8, st);
         if (e != hipSuccess) break;
-        if (g) rc = launch(g, OP_NOISE, 0, 0, m->d_hist);
+        if (g) rc = launch(g, OP_NOISE, 1, 0, m->d_hist);
         if (rc != BT_OK) break;
         if (reduce && reduce(user, reinterpret_cast<uint64_t *>(m->d_hist), nh) != 0) {
             rc = fail("bt_gibbs_noise_chain: the reduction of the noise counts failed");

@@ -210,7 +210,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     // the extra copies of a narrow tile's groups only take part in the sampling operations (the others tally with atomics)
-    if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN)) return;
+    if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || op == OP_NOISE)) return;
     t.hot = nullptr;
     t.resident = 0xFFFFFFFFu;
     // Narrow tiles (few groups + lockstep copies) are the launch's critical path: a handful of long sequential programs.  They take
@@ -258,6 +258,11 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
             for (uint32_t v = 0; v < nvert; ++v) flush_vertex(env, v);   // hot arrays: LDS when resident, else HBM (both valid)
     } else if (op == OP_INIT_CHAIN) {
         group_init_chain(env, arg0, nvert, nsrc, gindex);
+        // stepwise driving (the noise drivers, tests): the launch is followed by nan_fill_kernel, and the first sweep by ucache_prefill_kernel — at a
+        // chain start every haplotype has a non-zero frequency, so the first sweep asks for the whole table: the whole GPU computes it instead of the
+        // tile's own lanes
+        if (!SIMPLE_ONLY && arg1 != 0 && wide_table(*t.d))
+            for (uint32_t v = 0; v < nvert; ++v) make_vx(t, v).sc()[SC_UC_DIRTY] = 0;
     } else if (SIMPLE_ONLY) {
         // (the other operations always go through the general kernel)
     } else if (op == OP_NOISE) {
@@ -268,7 +273,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
             TPtr<uint32_t> usub = c.usub();
             for (uint32_t s = 0; s < P.S; ++s) {
                 const uint16_t h1 = c.dip()[2 * s], h2 = c.dip()[2 * s + 1];
-                for (uint32_t i = 0; i < nsu; ++i) {
+                for (uint32_t i = t.part; i < nsu; i += t.copies) {   // the copies of a narrow tile's group share the k-mers of the subset (a tally: any order)
                     const uint32_t k = usub[i];
                     if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) {
                         const uint32_t cnt = c.has_counts(k) ? c.count(k, s) : 0;
@@ -276,7 +281,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                     }
                 }
             }
-            cache_clear(c, P, false);   // only the first copy of a group runs this operation
+            if (t.part == 0) cache_clear(c, P, false, arg0 != 0);   // (the other copies read nothing this touches)
         }
     } else if (op == OP_RESET) {
         // VariantClusterGroup::resetGroup: genotypers are deleted; the shared KmerCounts multiplicities are NOT reset

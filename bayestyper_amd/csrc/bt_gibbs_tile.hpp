@@ -707,9 +707,16 @@ __device__ inline uint32_t hashed_slot(const Vx &c, uint32_t key) {
 
 // all_copies_run: every copy of the group executes this call (sampling operations) and clears its own part; otherwise the calling
 // thread clears the whole table
-__device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool all_copies_run) {   // VariantClusterGenotyper::clearCache (:131-138)
+// tiles whose dense tables the host invalidates and refills with the whole GPU between launches (nan_fill_kernel, ucache_prefill_kernel in bt_gibbs.hip)
+__device__ inline bool wide_table(const TileDesc BT_CAS &d) { return d.cache_mode == 0 && !d.simple && d.cache_entries > BT_UC_INVALIDATE_MIN && d.hoff[A_UCACHE] == NOHOT; }
+
+// wide_fill: the caller's launch is followed by nan_fill_kernel over this tile's table block (the noise drivers, between two iterations): a
+// large table is then already invalidated when the next sweep starts
+__device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool all_copies_run, bool wide_fill = false) {   // VariantClusterGenotyper::clearCache (:131-138)
     const TileDesc BT_CAS &d = c.d();
-    if (d.cache_mode == 0) {
+    if (wide_fill && !all_copies_run && wide_table(d)) {   // (simple tiles rebuild their few entries whole)
+        c.sc()[SC_UC_DIRTY] = 0;
+    } else if (d.cache_mode == 0) {
         // dense table: rebuilt at the next visit.  As a whole (fill_unique_cache) at a chain start, where the first sweep asks for
         // every entry anyway, and for small tables.  A large table cleared between the sweeps of a chain (clearGenotyperCache of the
         // noise drivers) is only invalidated: the sweeps that follow ask for the pairs of the few non-zero haplotypes, which are

@@ -444,32 +444,50 @@ def main():
         # rates drawn from the run's generator, the rebuilt table — no host round trip per iteration).
         from bayestyper_amd.host.inference_engine import InferenceEngine
 
+        def noise_pair(flat, S_, chains, label):
+            """default mode and --noise-genotyping on the same batch through the engine: wall-clock of the whole driver call"""
+            flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
+            cd = count_model.CountDistribution(S_, prior=(1.0, 0.01), seed=42)
+            for s_ in range(S_):
+                cd.set_genomic(s_, 15.0, 30.0)
+            eng = InferenceEngine(ctx, 42, chains=chains)
+            tn = time.perf_counter()
+            r = eng.estimate_genotypes(flat, cd)
+            t_default = time.perf_counter() - tn
+            r.close()
+            tn = time.perf_counter()
+            r, _rows = eng.estimate_noise_and_genotypes(flat, cd)
+            t_noise = time.perf_counter() - tn
+            r.close()
+            sw = flat["num_clusters"] * chains * 350
+            return cd, {"workload": label, "default_mode_cluster_sweeps_per_sec": sw / t_default, "default_mode_s": t_default,
+                        "noise_genotyping_cluster_sweeps_per_sec": sw / t_noise, "noise_genotyping_s": t_noise, "noise_over_default_time": t_noise / t_default,
+                        "iterations_per_sec": chains * 350 / t_noise}
+
         S30 = 30
         f30 = synth.make_mixture(2_000, S30, seed=3030)
-        f30["group_index"] = np.arange(f30["num_groups"], dtype=np.uint32)
-        cd30 = count_model.CountDistribution(S30, prior=(1.0, 0.01), seed=42)
-        for s_ in range(S30):
-            cd30.set_genomic(s_, 15.0, 30.0)
-        chains30 = 2   # (two of the twenty chains: the rate per sweep is what is reported; a full schedule of this leg takes minutes)
-        eng = InferenceEngine(ctx, 42, chains=chains30)
-        tn = time.perf_counter()
-        r30 = eng.estimate_genotypes(f30, cd30)
-        t_default = time.perf_counter() - tn
-        r30.close()
-        tn = time.perf_counter()
-        r30, _rows = eng.estimate_noise_and_genotypes(f30, cd30)
-        t_noise = time.perf_counter() - tn
-        r30.close()
+        chains30 = 1   # (one of the twenty chains: the rate per sweep is what is reported; a full schedule of this leg takes minutes)
+        cd30, rec30 = noise_pair(f30, S30, chains30, "BASELINE configs[4] shape on one GPU: 2 000 groups of the mixture (%s), S=30 (up to 256 haplotype candidates), %d chain x "
+                                 "(100+250) iterations, wall-clock of the whole driver call (sampler construction and result fetch included)" % (f30["mixture"], chains30))
+        rec30["note"] = ("in this mode every genotyper's caches are cleared every iteration (InferenceEngine.cpp:92), so every sweep recomputes its per-(sample, diplotype) "
+                         "sums over the k-mer subset, and an iteration lasts as long as its slowest group (a 256-candidate cluster at 30 samples) — on the CPU as well: "
+                         "cpu_allcores_* is the oracle's estimateNoiseAndGenotypes on the same batch.  The chain runs on the device without host round trips")
+        if not args.no_cpu_baseline:
+            it_cpu = (2, 3)
+            og = _oracle.OrcGibbs(orc, f30, *cd30.tables(), noise_seeding=1, seed=42, chains=1, burn=it_cpu[0], iters=it_cpu[1])
+            tc = time.perf_counter()
+            og.estimate_noise_and_genotypes(threads=os.cpu_count() or 1)
+            dt = time.perf_counter() - tc
+            og.close()
+            rec30["cpu_allcores_cluster_sweeps_per_sec"] = f30["num_clusters"] * sum(it_cpu) / dt
+            rec30["cpu_sample"] = f"the same batch, {sum(it_cpu)} iterations, {dt:.1f} s on {os.cpu_count()} threads (groups of an iteration dealt to the threads)"
+            rec30["gpu_over_cpu_allcores"] = rec30["noise_genotyping_cluster_sweeps_per_sec"] / rec30["cpu_allcores_cluster_sweeps_per_sec"]
         cd30.close()
-        sw30 = f30["num_clusters"] * chains30 * 350
-        extra["noise_genotyping"] = {"workload": "BASELINE configs[4] shape on one GPU: 2 000 groups of the mixture (%s), S=30 (up to 256 haplotype candidates), 2 chains x (100+250) "
-                                                 "iterations, wall-clock of the whole driver call (sampler construction and result fetch included)" % f30["mixture"],
-                                     "default_mode_cluster_sweeps_per_sec": sw30 / t_default, "default_mode_s": t_default,
-                                     "noise_genotyping_cluster_sweeps_per_sec": sw30 / t_noise, "noise_genotyping_s": t_noise, "noise_over_default_time": t_noise / t_default,
-                                     "iterations_per_sec": chains30 * 350 / t_noise,
-                                     "note": "in this mode every genotyper's caches are cleared every iteration (InferenceEngine.cpp:92), so every sweep recomputes its "
-                                             "per-(sample, diplotype) sums over the k-mer subset, and an iteration lasts as long as its slowest group (a 256-candidate cluster "
-                                             "at 30 samples): the time over the default mode is that work — the chain runs on the device without host round trips"}
+        extra["noise_genotyping"] = rec30
+        # ... and in the throughput regime: the ten-sample batch above (100 000 groups fill the GPU, so an iteration is no longer one group's latency)
+        cd10, rec10n = noise_pair(f10, S10, 1, "the samples10 batch (100 000 groups, S=10) in --noise-genotyping mode beside the default mode, 1 chain x (100+250) iterations")
+        cd10.close()
+        extra["noise_genotyping_samples10"] = rec10n
         # (2) k-mer matching against sub-filters of BASELINE configs[3] size: a ThreadedKmerBloom of 10^9 path k-mers (~37 KB per sub-filter,
         # 2.4 GB) — the LDS-staged probe at the other end of its range
         big = lib.Bloom.create(ctx, 1_000_000_000, 1e-4, K, threaded=True)

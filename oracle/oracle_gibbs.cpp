@@ -1415,7 +1415,13 @@ uint64_t orc_estimate_noise(void *h, float prior_shape, float prior_scale, uint3
 }
 
 // estimateNoiseAndGenotypes over every group of the unit; afterwards orc_gibbs_result_* hold the collected samples
+// threads > 1: the groups of an iteration are dealt to worker threads as the reference's estimateNoiseAndGenotypes hands group batches
+// to its threads (InferenceEngine.cpp:424-447); every thread tallies its own noise counts, summed after the join (integer sums: any order)
+uint64_t orc_estimate_noise_and_genotypes_mt(void *h, float prior_shape, float prior_scale, double *trace, uint64_t trace_cap, unsigned threads);
 uint64_t orc_estimate_noise_and_genotypes(void *h, float prior_shape, float prior_scale, double *trace, uint64_t trace_cap) {
+    return orc_estimate_noise_and_genotypes_mt(h, prior_shape, prior_scale, trace, trace_cap, 1);
+}
+uint64_t orc_estimate_noise_and_genotypes_mt(void *h, float prior_shape, float prior_scale, double *trace, uint64_t trace_cap, unsigned threads) {
     OracleGibbs &O = *(OracleGibbs *)h;
     const uint S = O.P.num_samples;
     NoiseModel cd(S, prior_shape, prior_scale, O.P.seed);
@@ -1429,13 +1435,27 @@ uint64_t orc_estimate_noise_and_genotypes(void *h, float prior_shape, float prio
         traceRow(&tr, chain + 1, 0, cd.noise_rates);
         for (uint iteration = 1; iteration <= (uint)O.P.burn_in + O.P.num_iterations; iteration++) {
             std::vector<uint64_t> hist((size_t)S * 256, 0);
-            for (auto &G : O.groups) {
+            auto one_group = [&](Group &G, uint64_t *into) {
                 uint32_t sweep_no = 0xFFFFFFFFu;
                 estimateGenotypes(O, G, iteration > O.P.burn_in, nullptr, sweep_no);
                 for (auto &vx : G.vertices) {
-                    vx.genotyper->getNoiseCounts(hist.data());
+                    vx.genotyper->getNoiseCounts(into);
                     vx.genotyper->clearCache();
                 }
+            };
+            if (threads <= 1) {
+                for (auto &G : O.groups) one_group(G, hist.data());
+            } else {
+                std::atomic<size_t> next(0);
+                std::vector<std::vector<uint64_t>> part(threads, std::vector<uint64_t>((size_t)S * 256, 0));
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < threads; t++)
+                    pool.emplace_back([&, t]() {
+                        for (size_t g = next.fetch_add(1); g < O.groups.size(); g = next.fetch_add(1)) one_group(O.groups[g], part[t].data());
+                    });
+                for (auto &th : pool) th.join();
+                for (auto &p : part)
+                    for (size_t i = 0; i < hist.size(); i++) hist[i] += p[i];
             }
             cd.sampleNoiseParameters(hist.data());
             updateNoiseCache(O, cd);

@@ -479,6 +479,8 @@ def _gibbs_sigs(L):
     L.orc_estimate_noise.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, vp, u64, vp, u64, vp]
     L.orc_estimate_noise_and_genotypes.restype = u64
     L.orc_estimate_noise_and_genotypes.argtypes = [vp, C.c_float, C.c_float, vp, u64]
+    L.orc_estimate_noise_and_genotypes_mt.restype = u64
+    L.orc_estimate_noise_and_genotypes_mt.argtypes = [vp, C.c_float, C.c_float, vp, u64, C.c_uint]
     L.orc_gibbs_result_sizes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.orc_gibbs_result_fetch.argtypes = [vp] * 7
     L.orc_gibbs_trace_fetch.restype = u64
@@ -570,10 +572,10 @@ class OrcGibbs:
             p += 1 + k
         return trace.reshape(rows, 2 + self.S), chains, final
 
-    def estimate_noise_and_genotypes(self, prior=(1.0, 0.01)):
+    def estimate_noise_and_genotypes(self, prior=(1.0, 0.01), threads=1):
         rows = self.params.num_chains * (self.params.burn_in + self.params.num_iterations + 1)
         trace = np.zeros(rows * (2 + self.S))
-        n = self.o.l.orc_estimate_noise_and_genotypes(self.h, prior[0], prior[1], _ptr(trace), len(trace))
+        n = self.o.l.orc_estimate_noise_and_genotypes_mt(self.h, prior[0], prior[1], _ptr(trace), len(trace), int(threads))
         assert n == len(trace)
         return trace.reshape(rows, 2 + self.S)
 

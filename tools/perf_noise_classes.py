@@ -1,4 +1,4 @@
-"""Time per iteration of the noise drivers' loop (one sweep + noise counts with cache clearing) per shape class.  usage: perf_noise_classes.py [S] [groups]"""
+"""Time per iteration of the noise drivers' loop (one sweep + noise counts with cache clearing) per shape class.  usage: perf_noise_classes.py [S] [groups] [classes]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,13 +6,16 @@ from bayestyper_amd import lib, shard, synth
 from bayestyper_amd.host import count_model
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+which = sys.argv[3] if len(sys.argv) > 3 else "DCBA"
 ctx = lib.Ctx(0)
 flat = synth.make_mixture(G, S, seed=3030)
 lg, ln = count_model.build_luts(S)
 at = 0
 for shape in ("D", "C", "B", "A"):
     n = flat["mixture"].get(shape, 0)
-    f = shard.take_groups(flat, np.arange(at, at + n)); at += n
+    ids = np.arange(at, at + n); at += n
+    if shape not in which or n == 0: continue
+    f = shard.take_groups(flat, ids)
     g = lib.Gibbs(ctx, f, lg, ln, seed=42, noise_seeding=1)
     g.init_chain(0)
     for phase, collect in (("burn", False), ("collect", True)):
