@@ -348,6 +348,7 @@ struct bt_gibbs {
         struct PrefillItem *d_prefill = nullptr;
         uint32_t num_prefill = 0;
     };
+    bool stepwise_run = false;   // bt_gibbs_run chain by chain (BT_GIBBS_STEPWISE)
     bool prefill_armed = false, wide_fill = true;   // wide_fill: BT_GIBBS_NO_WIDE_FILL unset
     std::vector<LaunchClass> classes;      // hungriest first
     hipEvent_t ev_fork = nullptr;
@@ -1192,6 +1193,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         BT_TRYHIP(prepare_gibbs_simple_kernel((int)kHotBudget));
         BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         g->wide_fill = !getenv("BT_GIBBS_NO_WIDE_FILL");
+        if (const char *e = getenv("BT_GIBBS_STEPWISE")) g->stepwise_run = atoi(e) != 0 && g->wide_fill;
         for (size_t i = 0; i < g->classes.size(); ++i) {
             auto &c = g->classes[i];
             BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_tiles), c.tiles.size() * 4));
@@ -1303,6 +1305,17 @@ int bt_gibbs_sweep(bt_gibbs *g, uint32_t num_sweeps, int collect_samples) {
 
 int bt_gibbs_run(bt_gibbs *g) {
     if (!g) return fail("bt_gibbs_run: null handle");
+    if (g->stepwise_run) {
+        // chain by chain: the launches of a chain start are followed by the wide table refill (nan_fill_kernel, ucache_prefill_kernel) instead of
+        // every tile filling its own tables with its own lanes; the same operations in the same order as OP_RUN
+        for (uint32_t chain = 0; chain < g->P.num_chains; ++chain) {
+            int rc = launch(g, OP_INIT_CHAIN, chain, 0, nullptr);
+            if (rc == BT_OK && g->P.burn_in) rc = launch(g, OP_SWEEP, g->P.burn_in, 0, nullptr);
+            if (rc == BT_OK && g->P.num_iterations) rc = launch(g, OP_SWEEP, g->P.num_iterations, 1, nullptr);
+            if (rc != BT_OK) return rc;
+        }
+        return BT_OK;
+    }
     return launch(g, OP_RUN, 0, 0, nullptr);
 }
 

@@ -487,3 +487,55 @@ def test_scale_properties_of_a_mixture_batch(gpu_ctx):
     assert (total == 20 * 250).all()                                   # Null-ploidy samples would still record (none, none)
     assert np.array_equal(s0, shard.summary_from_results(r0, flat["num_clusters"], S))
     assert (s0[:, :, 1] > 0).all() and (s0[:, :, 1] <= 20 * 250).all()
+
+
+def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatch):
+    """The whole-GPU table refill (nan_fill_kernel + ucache_prefill_kernel after a stepwise chain start and after every cache-clearing noise count)
+    and bt_gibbs_run chain by chain (BT_GIBBS_STEPWISE) only move work: every collected statistic is bit-identical to the single-launch schedule,
+    and a noise drivers' loop gives the same noise counts and samples with the refill switched off."""
+    from bayestyper_amd import lib, synth
+
+    S = 10
+    flat = synth.concat([synth.make_hetero_batch("D", 1, S, seed=71), synth.make_hetero_batch("C", 3, S, seed=72), synth.make_hetero_batch("B", 6, S, seed=73),
+                         synth.make_hetero_batch("A", 20, S, seed=74)])
+    lut_g, lut_n = _oracle.build_luts(oracle, S)
+    kw = dict(seed=97, chains=3, burn=15, iters=30)
+
+    def default_run(env):
+        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, **kw)
+        g.run()
+        r = g.results()
+        g.close()
+        return r
+
+    def noise_loop(env):
+        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, noise_seeding=1, **kw)
+        hists = []
+        for chain in range(2):
+            g.init_chain(chain)
+            for it in range(12):
+                g.sweep(1, it >= 4)
+                hists.append(g.noise_counts().copy())
+        r = g.results()
+        g.close()
+        return hists, r
+
+    base = default_run({})
+    for env in ({"BT_GIBBS_STEPWISE": "1"}, {"BT_GIBBS_STEPWISE": "1", "BT_GIBBS_NO_PREFILL": "1"}):
+        got = default_run(env)
+        for k in base:
+            assert np.array_equal(base[k], got[k]), (env, k)
+    h0, r0 = noise_loop({})
+    for env in ({"BT_GIBBS_NO_PREFILL": "1"}, {"BT_GIBBS_NO_PREFILL": "1", "BT_GIBBS_NO_WIDE_FILL": "1"}):
+        h1, r1 = noise_loop(env)
+        assert all(np.array_equal(a, b) for a, b in zip(h0, h1)), env
+        for k in r0:
+            assert np.array_equal(r0[k], r1[k]), (env, k)

@@ -49,6 +49,7 @@ for r in traffic["detail"]:
     detail[r["kernel"]] += r["bytes"]
 gs = bench["graph_stages"]
 s10, ng, c4 = bench.get("samples10"), bench.get("noise_genotyping"), bench.get("kmer_match_c4_subfilters")
+ng10 = bench.get("noise_genotyping_samples10")
 pc = bench["kmer_match_from_host_memory"]
 C = bench["config"]["clusters_per_gpu"]
 
@@ -57,7 +58,7 @@ kernel_table = f"""| Kernel | Work per launch | Bound | Algorithmic bytes (SURVE
 | KMC scan = `kmc_route_kernel` → rocPRIM radix sort (16 bits) → `kmc_probe_kernel` → `kmc_apply_kernel`, per chunk of 2^26 records | R records: decode + ntHash + route key (12 B + 2 B per record written) → sorted by sub-filter → one workgroup per sub-filter copies its ≤ 64 KB slice of the filter to LDS and probes from there, hits go through an LDS queue into a dense list → hits only: table find-or-insert + saturating count | HBM stream (13 B records in, 14 B route records out and back through the sort) | 15.9 B/record pure (13 B record + E[probes]·1 B + 2 % × 34 B table update); the routed form moves 13 + 3×14 B ≈ 55 B/record | SURVEY §8d's stream, {rk['launches_per_step']} scans per step into an emptied table: {e(R)} records in {rk['insert_launch_ms']:.0f} ms (the inserting scan, {e(rk['bloom_hits_per_scan'])} hits) / {rk['find_launch_ms']:.0f} ms (the finding scans) → **{e(bench['kmer_matches_per_sec'])} records/s** = {rk['achieved']:.0f} GB/s algorithmic ({100 * rk['frac']:.1f} % of 8 TB/s).  Counter traffic {kb / 1e9:.0f} GB per scan = {kb / R:.0f} B/record ({kb / R / 15.9:.1f}× the pure floor, {kb / R / 55:.1f}× the routed design's own bytes).  Sub-filters of C4 size ({c4['path_filter'] if c4 else 'n/a'}): {e(c4['records_per_sec']) if c4 else 'n/a'} records/s (a finding scan).  CPU oracle: {e(cpu['kmer_matches_per_sec_single_producer'])} records/s with the reference's single producer, {e(cpu['kmer_matches_per_sec_parallel_decode'])} with every core decoding its own range |
 | `gibbs_kernel` + `gibbs_simple_kernel` | G groups × 20 chains × 350 sweeps; one launch per LDS class, concurrent | wavefront slots × per-tile latency of a sequential sampler (below); no dense contraction → no MFMA | per (cluster, chain): `K·H + K·(S+4) + 0.1K·4 + 2(13H+4S) + 2·2·2496` B (inputs once, state in/out once): {alg / 1e9:.0f} GB for the bench batch | {bench['config']['groups_per_gpu']} groups / {C} clusters, S = 3: {sched_s:.2f} s per schedule → **{e(bench['gibbs_kernel_cluster_sweeps_per_sec'])} cluster-sweeps/s**, {bench['gpu_over_cpu_allcores']:.0f}× the {cpu['cores']}-thread oracle run ({e(cpu['value'])}; one core {e(cpu['one_core']['value'])}); launches of one step: {classes}.  Algorithmic {rf['achieved']:.0f} GB/s = {100 * rf['frac']:.2f} % of HBM peak — tiny by construction.  Counter traffic **{gb / 1e12:.2f} TB per schedule** ({gr / 1e12:.2f} read, {gw / 1e12:.2f} written) = {gb / alg:.0f}× the algorithmic floor (round 2: 12.1 TB, 68×), {gb / (C * 7000):.0f} B per cluster-sweep |
 | `build_tiles_kernel` (`bt_gibbs_create`) | one workgroup per cluster scatters the cluster's slices of the flat batch into its tile's rows | HBM stream | the batch once in, once out | 600 320 groups: 0.5 s for the whole `bt_gibbs_create` (planning on the host, upload, build) |
-| `noise_update_kernel` (`bt_gibbs_noise_chain`) | per iteration of a noise driver: S × 256 histogram → S gamma draws (one thread: the stream is sequential) → S × 256 Poisson log-pmf entries | latency (a few µs per iteration; it replaces a host round trip) | 2 KB · S in, 2 KB · S out | thirty samples, 2 000 groups: {f"{ng['iterations_per_sec']:.0f} iterations/s, {ng['noise_over_default_time']:.1f}× the default mode's time on the same batch (the caches are cleared every iteration)" if ng else 'n/a'} |
+| `noise_update_kernel` (`bt_gibbs_noise_chain`) | per iteration of a noise driver: S × 256 histogram → S gamma draws (one thread: the stream is sequential) → S × 256 Poisson log-pmf entries | latency (a few µs per iteration; it replaces a host round trip) | 2 KB · S in, 2 KB · S out | thirty samples, 2 000 groups: {f"{ng['iterations_per_sec']:.0f} iterations/s, {ng['noise_over_default_time']:.1f}× the default mode's time on the same batch (the caches are cleared every iteration)" + (f", {ng['gpu_over_cpu_allcores']:.0f}× the oracle's estimateNoiseAndGenotypes on all cores" if 'gpu_over_cpu_allcores' in ng else '') if ng else 'n/a'}; ten samples, 100 000 groups: {f"{ng10['iterations_per_sec']:.0f} iterations/s, {ng10['noise_over_default_time']:.1f}× the default mode's time" if ng10 else 'n/a'} |
 | `bt_paths_*` kernels | every k-mer window of every best path of every cluster of a unit | HBM random access (atomic find-or-insert into two open-addressing indexes) | per window: 1 B text + 17 B k-mer + 2×(20–28 B index entry) + ≈21+S B table probe | {gs['clusters']} clusters, {e(gs['kmer_windows'])} windows: enumerate {e(gs['enumerate_windows_per_sec'])} windows/s, Bloom insert {e(gs['bloom_insert_windows_per_sec'])}/s, classify {e(gs['classify_windows_per_sec'])}/s, candidates {e(gs['candidates_windows_per_sec'])}/s (host wall-clock, fetch to host arrays included) |
 | `mg_order_kernel` + the multigroup kernels | one lane per group replays the group's `unordered_set`; the rest one lane per k-mer | latency (sequential container replay per group) / HBM random access | ≈ 60 B per distinct (group, k-mer) | {e(gs.get('multigroup_windows_per_sec', 0))} windows/s for 50 000 single-cluster groups; counters: @@MG_ORDER@@ |
 | `find_paths_kernel` | per sample: the best-path search of every cluster of a unit, one lane per cluster | latency of dependent accesses + random probes into the sample Bloom filter | per vertex nucleotide and live path: one Bloom probe chain | {e(gs['find_sample_paths_clusters_per_sec'])} clusters/s per sample; counters: @@FIND_PATHS@@ |
@@ -112,7 +113,7 @@ of at least 0.1 ms): **{e(bench['value'])} cluster-sweeps/s** ({bench['ms_per_st
 {rk['launches_per_step'] * rk['avg_launch_ms'] / 1e3:.2f} s), {bench['gpu_over_cpu_allcores']:.0f}× the {cpu['cores']}-thread oracle run and {bench['gibbs_kernel_cluster_sweeps_per_sec'] / cpu['one_core']['value']:.0f}× one core; {e(bench['kmer_matches_per_sec'])} KMC records/s
 ({bench['kmer_matches_per_sec'] / cpu['kmer_matches_per_sec_single_producer']:.0f}× the single-producer scan, {bench['kmer_matches_per_sec'] / cpu['kmer_matches_per_sec_parallel_decode']:.0f}× the parallel one).  Round 2 on this batch: 8.21 s per step.  {bench['gibbs_device_bytes'] / 1e9:.0f} GB of sampler state.
 Sub-records of the same line: **ten samples** (`samples10`: {s10['workload'].split(':')[1].split(',')[0].strip() if s10 else ''}, the north star's sample count): {e(s10['cluster_sweeps_per_sec']) if s10 else 'n/a'} cluster-sweeps/s, {f"{s10['gpu_over_cpu_allcores']:.0f}" if s10 else 'n/a'}× the
-{cpu['cores']}-thread oracle run (target ≥ 20×); **thirty samples, `--noise-genotyping`** through the C++ engine (`noise_genotyping`): {f"{e(ng['noise_genotyping_cluster_sweeps_per_sec'])} cluster-sweeps/s against {e(ng['default_mode_cluster_sweeps_per_sec'])} in the default mode on the same batch" if ng else 'n/a'};
+{cpu['cores']}-thread oracle run (target ≥ 20×); **thirty samples, `--noise-genotyping`** through the C++ engine (`noise_genotyping`): {f"{e(ng['noise_genotyping_cluster_sweeps_per_sec'])} cluster-sweeps/s against {e(ng['default_mode_cluster_sweeps_per_sec'])} in the default mode on the same batch" + (f" and {e(ng['cpu_allcores_cluster_sweeps_per_sec'])} for the oracle's estimateNoiseAndGenotypes on {cpu['cores']} threads" if 'cpu_allcores_cluster_sweeps_per_sec' in ng else '') if ng else 'n/a'}; the ten-sample batch in that mode (`noise_genotyping_samples10`): {f"{e(ng10['noise_genotyping_cluster_sweeps_per_sec'])} cluster-sweeps/s, {ng10['noise_over_default_time']:.1f}× the default mode's time" if ng10 else 'n/a'};
 **C4-sized sub-filters** (`kmer_match_c4_subfilters`): {e(c4['records_per_sec']) if c4 else 'n/a'} records/s.
 
 PCIe: `bt_kmc_scan_run` takes device pointers; `bt_kmc_scan_run_host` streams a host-resident (memory-mapped) payload through two pinned staging
