@@ -305,6 +305,10 @@ inline void put(std::vector<uint8_t> &img, const TileDesc &d, int arr, size_t id
 
 }  // namespace
 
+#ifndef BT_HOT_BUDGET
+#define BT_HOT_BUDGET 155648
+#endif
+constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
 struct FillChunk {
     uint64_t off;      // bytes from the pool
     uint32_t words, pad;
@@ -349,6 +353,7 @@ struct bt_gibbs {
         uint32_t num_prefill = 0;
     };
     bool stepwise_run = false;   // bt_gibbs_run chain by chain (BT_GIBBS_STEPWISE)
+    bool noise_in_gibbs_kernel = false;   // BT_GIBBS_NOISE_GLOBAL_ATOMICS: the OP_NOISE branch of gibbs_kernel instead of gibbs_noise_kernel
     bool prefill_armed = false, wide_fill = true;   // wide_fill: BT_GIBBS_NO_WIDE_FILL unset
     std::vector<LaunchClass> classes;      // hungriest first
     hipEvent_t ev_fork = nullptr;
@@ -361,6 +366,57 @@ struct bt_gibbs {
 };
 
 namespace {
+
+// VariantClusterGenotyper::getNoiseCounts (:757-779) + clearCache for every vertex of every group of a launch class.  Every group adds
+// |subset| x S counts to S x 256 bins of which a few dozen are ever hit: tallied with global atomics (the OP_NOISE branch of gibbs_kernel) the
+// 90 240 two-haplotype groups of the ten-sample batch spent 10.5 ms per iteration queueing on those words.  Here a workgroup tallies the tiles it
+// walks in LDS and adds its non-empty bins once.
+__global__ __launch_bounds__(LANES * 8) void gibbs_noise_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg, uint32_t wide,
+                                                              unsigned long long *__restrict__ hist, const uint32_t *__restrict__ tile_list, uint32_t ntiles) {
+    const GParams BT_CAS &P = *(const GParams BT_CAS *)Pg;
+    uint32_t *lh = reinterpret_cast<uint32_t *>(lds_block());
+    const uint32_t nb = P.S * 256u;
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (uint32_t b = blockIdx.x; b < ntiles; b += gridDim.x) {
+        const uint32_t tile = tile_list ? tile_list[b] : b;
+        Tile t;
+        t.d = (const TileDesc BT_CAS *)&tiles[tile];
+        if (!tile_thread_active(t.d->split, t.d->copies)) continue;
+        t.base = (uint8_t BT_GAS *)(pool + t.d->base);
+        t.lane = tile_lane(t.d->split, t.d->copies);
+        t.plane = t.lane + t.d->pool_lane0;
+        t.wsh = t.d->wsh;
+        t.part = tile_part(t.d->copies);
+        t.copies = t.d->copies;
+        t.hot = nullptr;
+        t.resident = 0xFFFFFFFFu;
+        TPtr<uint32_t> gd = t.arr<uint32_t>(A_GDIMS);
+        if (!gd[3]) continue;   // padding lane of the last tile
+        const uint32_t nvert = gd[0];
+        for (uint32_t v = 0; v < nvert; ++v) {
+            const Vx c = make_vx(t, v);
+            const uint32_t nsu = c.sc()[SC_NSUB_U];
+            TPtr<uint32_t> usub = c.usub();
+            for (uint32_t s = 0; s < P.S; ++s) {
+                const uint16_t h1 = c.dip()[2 * s], h2 = c.dip()[2 * s + 1];
+                for (uint32_t i = t.part; i < nsu; i += t.copies) {   // the copies of a narrow tile's group share the k-mers of the subset (a tally: any order)
+                    const uint32_t k = usub[i];
+                    if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) {
+                        const uint32_t cnt = c.has_counts(k) ? c.count(k, s) : 0;
+                        atomicAdd(&lh[s * 256u + cnt], 1u);
+                    }
+                }
+            }
+            if (t.part == 0) cache_clear(c, P, false, wide != 0);   // (the other copies read nothing this touches)
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
+        const uint32_t n = lh[i];
+        if (n) atomicAdd(&hist[i], (unsigned long long)n);
+    }
+}
 
 __global__ __launch_bounds__(256) void nan_fill_kernel(uint8_t *__restrict__ pool, const FillChunk *__restrict__ chunks) {
     const FillChunk c = chunks[blockIdx.x];
@@ -471,7 +527,11 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
                                (const PrefillItem *)c.d_prefill);
             BT_CHECK_LAUNCH();
         }
-        if (c.simple && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
+        if (op == OP_NOISE && (size_t)g->S * 1024 <= kHotBudget && !g->noise_in_gibbs_kernel) {
+            const unsigned grid = (unsigned)std::min<size_t>(c.tiles.size(), (size_t)g->ctx->num_cu * 4);
+            hipLaunchKernelGGL(gibbs_noise_kernel, dim3(grid), dim3(LANES * c.split), (size_t)g->S * 1024, st, (const TileDesc *)g->d_tiles, g->d_pool, (const GParams *)g->d_params, a0, hist,
+                               (const uint32_t *)c.d_tiles, (uint32_t)c.tiles.size());
+        } else if (c.simple && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
             BT_HIP(launch_gibbs_simple_kernel((unsigned)c.tiles.size(), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
         else
             hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)c.tiles.size()), dim3(LANES * c.split), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
@@ -492,10 +552,6 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 // dynamic LDS a workgroup of this tile needs: one block per vertex when all vertices are resident
 inline uint32_t tile_lds_bytes(const TileDesc &d) { return d.lds_all ? d.hot_bytes * d.nvm : d.hot_bytes; }
-#ifndef BT_HOT_BUDGET
-#define BT_HOT_BUDGET 155648
-#endif
-constexpr uint32_t kHotBudget = BT_HOT_BUDGET;   // LDS bytes a tile may claim for its hot arrays (larger tiles stay in HBM)
 // a cluster's [S][D] tables are dense up to 256 MB per tile (64 MB when the batch would not fit the GPU otherwise): a hashed table far
 // smaller than the set of live (sample, diplotype) pairs thrashes (256 candidates x 10 samples: 12x slower than dense)
 constexpr uint32_t kMinTileWidth = 4;           // groups per wavefront of the narrowest tiles (the other lanes run copies)
@@ -1193,6 +1249,8 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         BT_TRYHIP(prepare_gibbs_simple_kernel((int)kHotBudget));
         BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         g->wide_fill = !getenv("BT_GIBBS_NO_WIDE_FILL");
+        g->noise_in_gibbs_kernel = getenv("BT_GIBBS_NOISE_GLOBAL_ATOMICS") != nullptr;
+        BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_noise_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         if (const char *e = getenv("BT_GIBBS_STEPWISE")) g->stepwise_run = atoi(e) != 0 && g->wide_fill;
         for (size_t i = 0; i < g->classes.size(); ++i) {
             auto &c = g->classes[i];
