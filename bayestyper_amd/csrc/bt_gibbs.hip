@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void ucache_prefill_kernel(const TileDesc *__r
     __syncthreads();
     {
         SPtrF<uint8_t, LANES> nz = c.nz();
-        for (uint32_t h = threadIdx.x; h < c.H; h += 256)
+        for (uint32_t h = threadIdx.x; h < c.H; h += blockDim.x)
             if (nz[h]) nzl[atomicAdd(&nnz_sh, 1u)] = (uint16_t)h;   // (any order: the entries are independent)
     }
     __syncthreads();
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void ucache_prefill_kernel(const TileDesc *__r
     const uint32_t nsub_u = sc[SC_NSUB_U];
     const TileDesc BT_CAS &d = c.d();
     const Vx::UCPtr uc = c.ucache();
-    for (uint32_t base = EVB * threadIdx.x; base < total; base += EVB * 256) {
+    for (uint32_t base = EVB * threadIdx.x; base < total; base += EVB * blockDim.x) {
         uint16_t ha[EVB], hb[EVB];
         bool need[EVB], any = false;
         uint32_t a = 0, b = 0;
@@ -523,7 +523,10 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
         hipStream_t st = c.stream ? c.stream : g->ctx->stream;
         if (c.stream) BT_HIP(hipStreamWaitEvent(st, g->ev_fork, 0));
         if (op == OP_SWEEP && g->prefill_armed && c.num_prefill) {
-            hipLaunchKernelGGL(ucache_prefill_kernel, dim3(c.num_prefill, g->S), dim3(256), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const GParams *)g->d_params,
+            // one wavefront per (vertex, sample) when there are many of them: between two iterations a vertex has a handful of candidates, and a
+            // 256-thread workgroup with one busy wavefront holds four wavefront slots for the length of a subset walk
+            const unsigned threads = (uint64_t)c.num_prefill * g->S >= 4096 ? 64u : 256u;
+            hipLaunchKernelGGL(ucache_prefill_kernel, dim3(c.num_prefill, g->S), dim3(threads), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const GParams *)g->d_params,
                                (const PrefillItem *)c.d_prefill);
             BT_CHECK_LAUNCH();
         }
