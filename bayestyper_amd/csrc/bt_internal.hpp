@@ -113,5 +113,7 @@ struct bt_kmc_scan {
     void *d_route_keys[2] = {nullptr, nullptr}, *d_route_vals[2] = {nullptr, nullptr}, *d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     uint64_t routed_cap = 0;
+    unsigned int *d_part_cursor = nullptr;   // partitioned scan: fill of the 256 bucket regions
+    uint32_t part_cap = 0;                   // records per bucket region
     unsigned int *d_num_hits = nullptr;
 };

@@ -619,6 +619,173 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_kernel(BloomView bloom, const
     flush();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Partitioned scan (sub-filters of a few KB: 256 consecutive sub-filters fit an XCD's L2).  The sort of the route-bucketed scan moves every
+// 14-byte route record four more times; here ONE kernel decodes, hashes and writes every route record once, grouped by the upper 8 route
+// bits, and the probe reads it once:
+//   kmc_partition_kernel  — a workgroup takes slabs of 4096 records: the slab's bytes into LDS in one coalesced burst, decode + ntHash
+//                           (hashes stay in registers), an LDS histogram over the 256 buckets, one reservation per bucket and slab in the
+//                           bucket's region (atomicAdd on its cursor), a counting sort of the slab in the same LDS, then the runs (about 16
+//                           records = 192 bytes per bucket and slab) are written out coalesced.  Two workgroups per CU: one loads while the
+//                           other sorts.  A bucket's region holds its expected share + 3 % + 1024 records; a record beyond it (hash routes are
+//                           uniform: it does not happen outside the test that forces it) is probed against the filter in HBM on the spot.
+//   kmc_probe_bucket_kernel — workgroups are mapped so that the ones resident on an XCD work on the same few buckets: the 256 sub-filters
+//                           of a bucket (0.5 MB at the WGS shape) stay in that XCD's L2 while its records stream through.
+// 13 B record + 12 B written + 12 B read per record (+ the filter once per chunk).  Same decisions as the direct kernel.
+// ---------------------------------------------------------------------------------------------
+#ifndef BT_KMC_PSLAB
+#define BT_KMC_PSLAB 4096
+#endif
+constexpr unsigned PBLOCK = 512, PSLAB = BT_KMC_PSLAB, PRPT = PSLAB / PBLOCK;
+
+__device__ inline uint32_t route_bucket(uint64_t h, uint32_t bloom_k) { return (uint32_t)((nthash64_seeded(h, bloom_k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) >> 8); }
+
+// dynamic LDS: the slab's raw record bytes (read once, coalesced), later overwritten by the slab's route records in bucket order
+static size_t partition_lds_bytes(uint32_t rec_size) { return std::max<size_t>((size_t)PSLAB * rec_size + 48, (size_t)PSLAB * sizeof(RouteRec)); }
+
+__global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomView bloom, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t rec_offset, uint64_t n,
+                                                               uint64_t n_total, RouteRec *__restrict__ part, uint32_t cap, unsigned int *__restrict__ cursor, uint32_t *__restrict__ hits,
+                                                               unsigned int *__restrict__ num_hits) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t part_lds[];
+    uint8_t *raw = part_lds;
+    RouteRec *sorted = reinterpret_cast<RouteRec *>(part_lds);   // [PSLAB], after the slab has been decoded
+    __shared__ uint64_t block_prefix[2];
+    __shared__ uint64_t tab[256];
+    __shared__ uint32_t hist[256], lofs[256], gbase[256], lcur[256], wave_tot[4];
+    for (unsigned b = threadIdx.x; b < 256u; b += PBLOCK)
+        tab[b] = rol64(nt_seed(b & 3u), 3) ^ rol64(nt_seed((b >> 2) & 3u), 2) ^ rol64(nt_seed((b >> 4) & 3u), 1) ^ nt_seed((b >> 6) & 3u);
+    const uint64_t num_slabs = (n + PSLAB - 1) / PSLAB;
+    const uint64_t total_bytes = n_total * (uint64_t)v.rec_size;
+    for (uint64_t slab = blockIdx.x; slab < num_slabs; slab += gridDim.x) {
+        const uint64_t slab0 = slab * PSLAB;
+        const uint32_t slab_n = (uint32_t)((n - slab0) < PSLAB ? (n - slab0) : PSLAB);
+        if (threadIdx.x < 256u) hist[threadIdx.x] = 0;
+        if (threadIdx.x < 2) block_prefix[threadIdx.x] = kmc_prefix_of(v, first_record + rec_offset + slab0 + (threadIdx.x ? slab_n - 1 : 0));
+        const uint64_t byte0 = (rec_offset + slab0) * v.rec_size;
+        const unsigned nbytes = slab_n * v.rec_size;
+        const uint64_t a0 = byte0 & ~15ULL;
+        const unsigned lead = (unsigned)(byte0 - a0);
+        const unsigned nvec = (lead + nbytes + 15u) / 16u;
+        for (unsigned q = threadIdx.x; q < nvec; q += PBLOCK) {
+            const uint64_t off = a0 + (uint64_t)q * 16u;
+            if (off + 16u <= total_bytes) *reinterpret_cast<uint4 *>(&raw[q * 16u]) = *reinterpret_cast<const uint4 *>(records + off);
+            else
+                for (unsigned z = 0; z < 16u; ++z) raw[q * 16u + z] = (off + z < total_bytes) ? records[off + z] : 0;
+        }
+        __syncthreads();
+        uint64_t hh[PRPT];
+        uint32_t valid = 0;
+#pragma unroll
+        for (unsigned j = 0; j < PRPT; ++j) {
+            hh[j] = 0;
+            const uint32_t r = j * PBLOCK + threadIdx.x;
+            if (r >= slab_n) continue;
+            Kmer a;
+            uint32_t count;
+            kmc_decode(v, kmc_prefix_in(v, first_record + rec_offset + slab0 + r, block_prefix[0], block_prefix[1]), &raw[lead + r * v.rec_size], a, count);
+            uint64_t h = 0;
+            uint64_t w = a.lo;
+            unsigned left = v.k;
+            for (unsigned word = 0; word < 2u && left; ++word, w = a.hi) {
+                unsigned in_word = left < 32u ? left : 32u;
+                left -= in_word;
+                for (; in_word >= 4u; in_word -= 4u, w >>= 8) h = rol64(h, 4) ^ tab[w & 0xFFu];
+                for (; in_word; --in_word, w >>= 2) h = rol64(h, 1) ^ nt_seed((unsigned)(w & 3u));
+            }
+            hh[j] = h;
+            valid |= 1u << j;
+            atomicAdd(&hist[route_bucket(h, bloom.k)], 1u);
+        }
+        __syncthreads();   // (every raw byte has been read: the region becomes `sorted`)
+        // exclusive scan of the 256 counts (four wavefronts of 64 bins), one reservation per bucket in its region
+        if (threadIdx.x < 256u) {
+            const uint32_t c = hist[threadIdx.x];
+            uint32_t incl = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if ((int)(threadIdx.x & 63u) >= d) incl += o;
+            }
+            lofs[threadIdx.x] = incl - c;
+            if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
+            gbase[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256u) {
+            uint32_t add = 0;
+            for (unsigned wv = 0; wv < (threadIdx.x >> 6); ++wv) add += wave_tot[wv];
+            lofs[threadIdx.x] += add;
+            lcur[threadIdx.x] = lofs[threadIdx.x];
+        }
+        __syncthreads();
+#pragma unroll
+        for (unsigned j = 0; j < PRPT; ++j)
+            if (valid & (1u << j)) {
+                const uint64_t h = hh[j];
+                const uint32_t pos = atomicAdd(&lcur[route_bucket(h, bloom.k)], 1u);
+                sorted[pos] = RouteRec{(uint32_t)h, (uint32_t)(h >> 32), (uint32_t)(slab0 + j * PBLOCK + threadIdx.x)};
+            }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < slab_n; i += PBLOCK) {
+            const RouteRec r = sorted[i];
+            const uint64_t h = (uint64_t)r.h_lo | ((uint64_t)r.h_hi << 32);
+            const uint32_t b = route_bucket(h, bloom.k);
+            const uint32_t dest = gbase[b] + (i - lofs[b]);
+            if (dest < cap) part[(uint64_t)b * cap + dest] = r;
+            else if (bloom_contains(h, bloom)) hits[atomicAdd(num_hits, 1u)] = r.idx;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom, const RouteRec *__restrict__ part, uint32_t cap, const unsigned int *__restrict__ cursor, uint32_t blocks_per_bucket,
+                                                                 uint32_t *__restrict__ hits, unsigned int *__restrict__ num_hits) {
+    // workgroups go to the XCDs round-robin: x % 8 picks the XCD, and all blocks_per_bucket workgroups of bucket 8 g + (x % 8) are neighbours in
+    // dispatch order, so an XCD works its way through one bucket (or a few) at a time
+    const uint32_t x = blockIdx.x, xcd = x & 7u, y = x >> 3, sub = y % blocks_per_bucket, bucket = (y / blocks_per_bucket) * 8u + xcd;
+    const uint32_t filled = cursor[bucket], n = filled < cap ? filled : cap;
+    const RouteRec *src = part + (uint64_t)bucket * cap;
+    constexpr uint32_t QCAP = 4 * BLOCK;
+    __shared__ uint32_t queue[QCAP];
+    __shared__ uint32_t qn, qbase;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    auto flush = [&]() {
+        __syncthreads();
+        const uint32_t n_q = qn;
+        if (threadIdx.x == 0 && n_q) qbase = atomicAdd(num_hits, n_q);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n_q; j += BLOCK) hits[qbase + j] = queue[j];
+        __syncthreads();
+        if (threadIdx.x == 0) qn = 0;
+        __syncthreads();
+    };
+    uint32_t q_bound = 0;   // (the flush decision must be uniform: see kmc_probe_kernel)
+    const uint8_t *filter = reinterpret_cast<const uint8_t *>(bloom.words);
+    for (uint32_t i0 = sub * BLOCK; i0 < n; i0 += blocks_per_bucket * BLOCK) {
+        if (q_bound + BLOCK > QCAP) {
+            flush();
+            q_bound = 0;
+        }
+        q_bound += BLOCK;
+        const uint32_t i = i0 + threadIdx.x;
+        bool member = i < n;
+        uint32_t idx = 0;
+        if (member) {
+            const RouteRec r = src[i];
+            idx = r.idx;
+            const uint64_t h = (uint64_t)r.h_lo | ((uint64_t)r.h_hi << 32);
+            const uint8_t *bytes = filter + (nthash64_seeded(h, bloom.k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) * bloom.stride;
+            for (unsigned q = 0; q < bloom.num_hashes && member; ++q) {   // BloomFilter::containsF: stop at the first clear bit
+                const uint64_t pos = bloom_probe_pos(h, q, bloom);
+                member = (bytes[pos >> 3] & (1u << (7u - (unsigned)(pos & 7u)))) != 0;
+            }
+        }
+        if (member) queue[atomicAdd(&qn, 1u)] = idx;
+        __syncthreads();
+    }
+    flush();
+}
+
 // pass 3: the hits of a chunk, one per lane: decode the record again, add its count to the table (KmerCounter.cpp:414-419)
 __global__ __launch_bounds__(BLOCK) void kmc_apply_kernel(KmcView v, TableView t, uint32_t sample_idx, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t rec_offset,
                                                           const uint32_t *__restrict__ hits, const unsigned int *__restrict__ num_hits, unsigned long long *__restrict__ hit_count) {
@@ -1149,6 +1316,9 @@ static void free_routed(bt_kmc_scan *s) {
     }
     if (s->d_sort_tmp) (void)hipFree(s->d_sort_tmp);
     if (s->d_num_hits) (void)hipFree(s->d_num_hits);
+    if (s->d_part_cursor) (void)hipFree(s->d_part_cursor);
+    s->d_part_cursor = nullptr;
+    s->part_cap = 0;
     s->d_sort_tmp = nullptr;
     s->d_num_hits = nullptr;
     s->sort_tmp_bytes = 0;
@@ -1160,10 +1330,14 @@ static int ensure_routed(bt_kmc_scan *s, uint64_t cap) {
     if (s->routed_cap >= cap) return BT_OK;
     free_routed(s);
     hipError_t e = hipSuccess;
+    // (the first value buffer doubles as the 256 bucket regions of the partitioned scan: a bucket's expected share + 3 % + 1024 records)
+    const uint64_t part_cap = cap / 256 + cap / 256 * 3 / 100 + 1024;
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
         e = hipMalloc(reinterpret_cast<void **>(&s->d_route_keys[b]), cap * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals[b]), cap * sizeof(RouteRec));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals[b]), std::max<uint64_t>(cap, b == 0 ? 256 * part_cap : 0) * sizeof(RouteRec));
     }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_part_cursor), 256 * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmc_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_lds_bytes(KMC_MAX_REC));
     size_t tmp = 0;
     if (e == hipSuccess)
         e = rocprim::radix_sort_pairs(nullptr, tmp, (uint16_t *)s->d_route_keys[0], (uint16_t *)s->d_route_keys[1], (RouteRec *)s->d_route_vals[0], (RouteRec *)s->d_route_vals[1],
@@ -1176,12 +1350,14 @@ static int ensure_routed(bt_kmc_scan *s, uint64_t cap) {
     }
     s->sort_tmp_bytes = tmp;
     s->routed_cap = cap;
+    s->part_cap = (uint32_t)part_cap;
     return BT_OK;
 }
 
 constexpr uint64_t kRoutedChunk = 1ull << 26;      // records per bucketed chunk (14 bytes of keys + values each, double-buffered)
 constexpr uint64_t kRoutedMinRecords = 1ull << 22;  // below this a sub-filter gets too few records per chunk for its staging to pay
 constexpr uint64_t kRoutedMaxSlice = 64000;         // bytes of one sub-filter that fit the LDS of a workgroup
+constexpr uint64_t kPartMaxSlice = 4096;            // partitioned scan: 256 sub-filters of a bucket (<= 1 MB) stay in an XCD's 4 MB L2 next to the streams
 
 int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *d_records,
                     uint64_t first_record, uint64_t n, uint64_t *d_hit_count) {
@@ -1208,6 +1384,29 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
     if (const char *e = getenv("BT_KMC_ROUTED_CHUNK")) chunk = std::max<uint64_t>(1024, std::min<uint64_t>(chunk, strtoull(e, nullptr, 0)));   // tests: several chunks at small sizes
     if (ensure_routed(s, chunk) != BT_OK) return BT_ERR;
     const KmcView kv = make_kmc_view(s);
+    bool partitioned = path_bloom->stride <= kPartMaxSlice && chunk < (1ull << 32);
+    if (const char *e = getenv("BT_KMC_PARTITIONED")) partitioned = partitioned && atoi(e) != 0;
+    uint32_t part_cap = s->part_cap;
+    if (const char *e = getenv("BT_KMC_PART_CAP")) part_cap = std::max<uint32_t>(1, std::min<uint32_t>(part_cap, (uint32_t)strtoul(e, nullptr, 0)));   // tests: records beyond a bucket's region
+    for (uint64_t off = 0; partitioned && off < n; off += chunk) {
+        const uint64_t m = std::min<uint64_t>(chunk, n - off);
+        RouteRec *part = (RouteRec *)s->d_route_vals[0];
+        uint32_t *hit_list = reinterpret_cast<uint32_t *>(s->d_route_vals[1]);
+        BT_HIP(hipMemsetAsync(s->d_num_hits, 0, 4, s->ctx->stream));
+        BT_HIP(hipMemsetAsync(s->d_part_cursor, 0, 256 * sizeof(unsigned int), s->ctx->stream));
+        const unsigned pgrid = grid_for((m + PSLAB - 1) / PSLAB, 1, s->ctx->num_cu * 4);
+        hipLaunchKernelGGL(kmc_partition_kernel, dim3(pgrid), dim3(PBLOCK), partition_lds_bytes(s->rec_size), s->ctx->stream, kv, path_bloom->view(), d_records, first_record, off, m, n, part, part_cap,
+                           s->d_part_cursor, hit_list, s->d_num_hits);
+        BT_CHECK_LAUNCH();
+        const uint32_t bpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (m / 256 + BLOCK * 8 - 1) / (BLOCK * 8)));
+        hipLaunchKernelGGL(kmc_probe_bucket_kernel, dim3(256 * bpb), dim3(BLOCK), 0, s->ctx->stream, path_bloom->view(), (const RouteRec *)part, part_cap, (const unsigned int *)s->d_part_cursor, bpb,
+                           hit_list, s->d_num_hits);
+        BT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(kmc_apply_kernel, dim3(s->ctx->num_cu * 8), dim3(BLOCK), 0, s->ctx->stream, kv, table->v, sample_idx, d_records, first_record, off, (const uint32_t *)hit_list,
+                           (const unsigned int *)s->d_num_hits, reinterpret_cast<unsigned long long *>(d_hit_count));
+        BT_CHECK_LAUNCH();
+    }
+    if (partitioned) return BT_OK;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = std::min<uint64_t>(chunk, n - off);
         uint16_t *k0 = (uint16_t *)s->d_route_keys[0], *k1 = (uint16_t *)s->d_route_keys[1];

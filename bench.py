@@ -553,7 +553,7 @@ def main():
                                  "avg_launch_ms spans the sampling launches of one schedule; traffic = FETCH_SIZE + WRITE_SIZE of those launches from the committed PMC "
                                  "passes of this command (separate rocprofv3 --pmc runs, KiB -> bytes), filled in only when they were made from the same device sources "
                                  "(source_hash), else null"},
-            "roofline_kmer_match": {"kernel": "one KMC scan = kmc_route_kernel + rocPRIM radix sort (16 bits) + kmc_probe_kernel + kmc_apply_kernel per 2^26-record chunk", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline_kmer_match": {"kernel": "one KMC scan = kmc_partition_kernel + kmc_probe_bucket_kernel + kmc_apply_kernel per 2^26-record chunk", "bound": "hbm", "achieved": kmc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": kmc_gbs / HBM_PEAK_GBS, "traffic": kmc_traffic, "traffic_source": kmc_traffic_src, "avg_launch_ms": kmc_avg_ms, "launches_per_step": S,
                                     "insert_launch_ms": float(kmc[:, 0].mean()), "find_launch_ms": float(kmc[:, 1:].mean()) if S > 1 else None,
                                     "bytes_per_record": KMER_MATCH_BYTES_PER_RECORD, "bloom_hits_per_scan": hits // ((args.steps + args.warmup) * S), "table_keys": st["num_keys"]},

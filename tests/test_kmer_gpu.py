@@ -132,15 +132,16 @@ def test_threaded_bloom_bit_exact(gpu_ctx, oracle):
     gb.close(), ob.close()
 
 
-@pytest.mark.parametrize("routed", ["0", "1"])
+@pytest.mark.parametrize("routed", ["0", "1", "partitioned"])
 def test_kmc_decode_and_scan(gpu_ctx, oracle, tmp_path, monkeypatch, routed):
     """parseSampleKmers: decode -> path-Bloom -> table add; table contents bit-exact incl. Bloom false positives.
-    routed = 1: the route-bucketed scan (records bucketed by sub-filter, sub-filters staged in LDS) forced at this small size;
-    routed = 0: the direct kernel"""
+    routed = 1: the route-bucketed scan (records sorted by sub-filter, sub-filters staged in LDS) forced at this small size;
+    partitioned: the one-pass partition by the upper route bits + probe through L2 (what small sub-filters get); routed = 0: the direct kernel"""
     from bayestyper_amd import lib
     from test_oracle_kmer import make_kmc
 
-    monkeypatch.setenv("BT_KMC_ROUTED", routed)
+    monkeypatch.setenv("BT_KMC_ROUTED", "0" if routed == "0" else "1")
+    monkeypatch.setenv("BT_KMC_PARTITIONED", "1" if routed == "partitioned" else "0")
 
     rng = np.random.default_rng(14)
     S = 3
@@ -381,9 +382,9 @@ def test_large_scan_properties(gpu_ctx, oracle):
 
 
 def test_routed_scan_equals_direct_at_scale(gpu_ctx, monkeypatch):
-    """6 x 10^6 records (above the size from which bt_kmc_scan_run buckets the records by sub-filter and probes the sub-filters in
-    LDS): the bucketed scan — one chunk, and several ragged chunks — leaves exactly the table the direct kernel leaves
-    (keys incl. Bloom false positives, counts, hit count)"""
+    """6 x 10^6 records (above the size from which bt_kmc_scan_run buckets the records by sub-filter): the sorted scan (sub-filters staged in
+    LDS) and the partitioned scan (one partition pass, probe through L2) — one chunk, several ragged chunks, and chunks so small that the bucket
+    regions' slack matters — leave exactly the table the direct kernel leaves (keys incl. Bloom false positives, counts, hit count)"""
     from bayestyper_amd import lib
 
     rng = np.random.default_rng(23)
@@ -398,13 +399,17 @@ def test_routed_scan_equals_direct_at_scale(gpu_ctx, monkeypatch):
     bloom.insert(mk)
     d_rec = gpu_ctx.to_device(rec.reshape(-1))
     out = []
-    for routed, chunk in (("0", None), (None, None), ("1", "1500007")):
+    for routed, chunk, partitioned in (("0", None, None), (None, None, "0"), ("1", "1500007", "0"), (None, None, "1"), ("1", "1500007", "1"), ("1", "70001", "1"), ("1", "2000003", "overflow")):
         if routed is None:
             monkeypatch.delenv("BT_KMC_ROUTED", raising=False)
         else:
             monkeypatch.setenv("BT_KMC_ROUTED", routed)
         if chunk:
             monkeypatch.setenv("BT_KMC_ROUTED_CHUNK", chunk)
+        if partitioned:     # "0": the sorted form (LDS-staged sub-filters); "1": the partitioned form; "overflow": bucket regions of 3 000 records for ~7 800
+            monkeypatch.setenv("BT_KMC_PARTITIONED", "0" if partitioned == "0" else "1")
+            if partitioned == "overflow":
+                monkeypatch.setenv("BT_KMC_PART_CAP", "3000")
         table = lib.Table(gpu_ctx, 400_000, 2, K)
         d_hits = gpu_ctx.buffer(8).zero()
         scan.set_count_range(2, 250)
