@@ -744,46 +744,46 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom
     const uint32_t x = blockIdx.x, xcd = x & 7u, y = x >> 3, sub = y % blocks_per_bucket, bucket = (y / blocks_per_bucket) * 8u + xcd;
     const uint32_t filled = cursor[bucket], n = filled < cap ? filled : cap;
     const RouteRec *src = part + (uint64_t)bucket * cap;
-    constexpr uint32_t QCAP = 4 * BLOCK;
+    // hits (a few per cent of the records) are collected in an LDS queue and moved to the chunk's hit list with one global atomic per workgroup; a
+    // hit that finds the queue full goes to the list directly — so the record loop holds no barrier and every wavefront keeps several records in flight
+    constexpr uint32_t QCAP = 8 * BLOCK;
     __shared__ uint32_t queue[QCAP];
     __shared__ uint32_t qn, qbase;
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
-    auto flush = [&]() {
-        __syncthreads();
-        const uint32_t n_q = qn;
-        if (threadIdx.x == 0 && n_q) qbase = atomicAdd(num_hits, n_q);
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < n_q; j += BLOCK) hits[qbase + j] = queue[j];
-        __syncthreads();
-        if (threadIdx.x == 0) qn = 0;
-        __syncthreads();
-    };
-    uint32_t q_bound = 0;   // (the flush decision must be uniform: see kmc_probe_kernel)
     const uint8_t *filter = reinterpret_cast<const uint8_t *>(bloom.words);
-    for (uint32_t i0 = sub * BLOCK; i0 < n; i0 += blocks_per_bucket * BLOCK) {
-        if (q_bound + BLOCK > QCAP) {
-            flush();
-            q_bound = 0;
+    const uint32_t step = blocks_per_bucket * BLOCK;
+    for (uint32_t i0 = sub * BLOCK + threadIdx.x; i0 < n; i0 += 2u * step) {
+        RouteRec r[2];
+        bool member[2];
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; ++u) {
+            const uint32_t i = i0 + u * step;
+            member[u] = i < n;
+            r[u] = member[u] ? src[i] : RouteRec{0u, 0u, 0u};
         }
-        q_bound += BLOCK;
-        const uint32_t i = i0 + threadIdx.x;
-        bool member = i < n;
-        uint32_t idx = 0;
-        if (member) {
-            const RouteRec r = src[i];
-            idx = r.idx;
-            const uint64_t h = (uint64_t)r.h_lo | ((uint64_t)r.h_hi << 32);
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; ++u) {
+            if (!member[u]) continue;
+            const uint64_t h = (uint64_t)r[u].h_lo | ((uint64_t)r[u].h_hi << 32);
             const uint8_t *bytes = filter + (nthash64_seeded(h, bloom.k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) * bloom.stride;
-            for (unsigned q = 0; q < bloom.num_hashes && member; ++q) {   // BloomFilter::containsF: stop at the first clear bit
+            bool in = true;
+            for (unsigned q = 0; q < bloom.num_hashes && in; ++q) {   // BloomFilter::containsF: stop at the first clear bit
                 const uint64_t pos = bloom_probe_pos(h, q, bloom);
-                member = (bytes[pos >> 3] & (1u << (7u - (unsigned)(pos & 7u)))) != 0;
+                in = (bytes[pos >> 3] & (1u << (7u - (unsigned)(pos & 7u)))) != 0;
+            }
+            if (in) {
+                const uint32_t p = atomicAdd(&qn, 1u);
+                if (p < QCAP) queue[p] = r[u].idx;
+                else hits[atomicAdd(num_hits, 1u)] = r[u].idx;
             }
         }
-        if (member) queue[atomicAdd(&qn, 1u)] = idx;
-        __syncthreads();
     }
-    flush();
+    __syncthreads();
+    const uint32_t n_q = qn < QCAP ? qn : QCAP;
+    if (threadIdx.x == 0 && n_q) qbase = atomicAdd(num_hits, n_q);
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < n_q; j += BLOCK) hits[qbase + j] = queue[j];
 }
 
 // pass 3: the hits of a chunk, one per lane: decode the record again, add its count to the table (KmerCounter.cpp:414-419)
