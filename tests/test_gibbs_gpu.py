@@ -513,7 +513,7 @@ def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatc
         return r
 
     def noise_loop(env):
-        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL"):
+        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL", "BT_GIBBS_NOISE_GLOBAL_ATOMICS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -534,7 +534,8 @@ def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatc
         for k in base:
             assert np.array_equal(base[k], got[k]), (env, k)
     h0, r0 = noise_loop({})
-    for env in ({"BT_GIBBS_NO_PREFILL": "1"}, {"BT_GIBBS_NO_PREFILL": "1", "BT_GIBBS_NO_WIDE_FILL": "1"}):
+    # ... and with the noise counts tallied by the OP_NOISE branch of gibbs_kernel (what more than 152 samples get) instead of gibbs_noise_kernel
+    for env in ({"BT_GIBBS_NO_PREFILL": "1"}, {"BT_GIBBS_NO_PREFILL": "1", "BT_GIBBS_NO_WIDE_FILL": "1"}, {"BT_GIBBS_NOISE_GLOBAL_ATOMICS": "1"}):
         h1, r1 = noise_loop(env)
         assert all(np.array_equal(a, b) for a, b in zip(h0, h1)), env
         for k in r0:
