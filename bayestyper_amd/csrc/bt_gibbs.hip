@@ -28,6 +28,10 @@ namespace bt {
 hipError_t launch_gibbs_simple_kernel(unsigned grid, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
                                       unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
 hipError_t prepare_gibbs_simple_kernel(int max_lds);
+// defined in bt_gibbs_hot_kernel.hip
+hipError_t launch_gibbs_hot_kernel(unsigned grid, unsigned block, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
+                                   unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
+hipError_t prepare_gibbs_hot_kernel(int max_lds);
 #ifdef BT_PROF
 hipError_t simple_prof_read(unsigned long long *h_out32, int reset);
 #endif
@@ -340,6 +344,7 @@ struct bt_gibbs {
     struct LaunchClass {
         uint32_t lds = 0, split = 1;      // dynamic LDS per workgroup, wavefronts per tile (tile_lane())
         bool simple = false;              // every tile runs simple_sweeps(): launched as gibbs_simple_kernel
+        bool hot = false;                 // every tile keeps all vertices' hot arrays in LDS for the launch: sampling operations launched as gibbs_hot_kernel
         std::vector<uint32_t> tiles;
         uint32_t *d_tiles = nullptr;
         hipStream_t stream = nullptr;     // nullptr: the context's stream
@@ -536,6 +541,8 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
                                (const uint32_t *)c.d_tiles, (uint32_t)c.tiles.size());
         } else if (c.simple && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
             BT_HIP(launch_gibbs_simple_kernel((unsigned)c.tiles.size(), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
+        else if (c.hot && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
+            BT_HIP(launch_gibbs_hot_kernel((unsigned)c.tiles.size(), LANES * c.split, c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
         else
             hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)c.tiles.size()), dim3(LANES * c.split), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
                                (const uint32_t *)c.d_tiles);
@@ -1228,7 +1235,14 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
     }
     {
         const size_t nclass = sizeof(kClassLds) / sizeof(kClassLds[0]);
-        std::vector<bt_gibbs::LaunchClass> byb(nclass);
+        std::vector<bt_gibbs::LaunchClass> byb(2 * nclass);   // [LDS class] and [nclass + LDS class]: the same for the tiles gibbs_hot_kernel takes
+        const bool hot_kernel = !getenv("BT_GIBBS_NO_HOT_KERNEL");
+        auto hot_tile = [&](const TileDesc &d) {
+            bool ok = hot_kernel && !d.simple && d.hot_bytes != 0 && (d.nvm == 1 || d.lds_all);
+            for (int a = 0; a < A_COUNT && ok; ++a)
+                if (hot_core(a)) ok = d.hoff[a] != NOHOT;
+            return ok;
+        };
         bt_gibbs::LaunchClass simple_class;
         simple_class.simple = true;
         const bool own_kernel = !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
@@ -1241,15 +1255,21 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             }
             size_t b = 0;
             while (hb > kClassLds[b]) ++b;
+            if (hot_tile(g->tiles[ti])) {
+                b += nclass;
+                byb[b].hot = true;
+            }
             byb[b].tiles.push_back(ti);
             byb[b].lds = std::max(byb[b].lds, hb);
             byb[b].split = std::max(byb[b].split, g->tiles[ti].split);
         }
         for (size_t b = nclass; b-- > 0;)   // hungriest first: those tiles run longest
-            if (!byb[b].tiles.empty()) g->classes.push_back(std::move(byb[b]));
+            for (size_t h : {b + nclass, b})
+                if (!byb[h].tiles.empty()) g->classes.push_back(std::move(byb[h]));
         if (!simple_class.tiles.empty()) g->classes.push_back(std::move(simple_class));
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_simple_kernel((int)kHotBudget));
+        BT_TRYHIP(prepare_gibbs_hot_kernel((int)kHotBudget));
         BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         g->wide_fill = !getenv("BT_GIBBS_NO_WIDE_FILL");
         g->noise_in_gibbs_kernel = getenv("BT_GIBBS_NOISE_GLOBAL_ATOMICS") != nullptr;
@@ -1299,7 +1319,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         }
         if (getenv("BT_GIBBS_DEBUG")) {   // tuning aid: how the batch was tiled
             fprintf(stderr, "bt_gibbs: %u tiles in %zu launch classes:", ntiles, g->classes.size());
-            for (auto &c : g->classes) fprintf(stderr, " [%zu tiles, lds %u B, split %u]", c.tiles.size(), c.lds, c.split);
+            for (auto &c : g->classes) fprintf(stderr, " [%zu tiles, lds %u B, split %u%s%s]", c.tiles.size(), c.lds, c.split, c.simple ? ", simple" : "", c.hot ? ", hot" : "");
             fprintf(stderr, "; tile 0: hot_bytes %u lds_stride %u copies %u\n", g->tiles[0].hot_bytes, g->tiles[0].lds_stride, g->tiles[0].copies);
         }
     }

@@ -178,6 +178,18 @@ struct GParams {
     uint32_t lgamma_n, pad;
 };
 
+extern __shared__ __attribute__((aligned(16))) uint8_t bt_lds_raw[];
+__device__ inline uint8_t *lds_block() { return (uint8_t *)bt_lds_raw; }
+
+// The arrays every tile with an LDS block keeps there (bt_gibbs.hip: hot_arrs, minus the ones that depend on the tile's shape).  In the translation
+// unit of gibbs_hot_kernel (BT_HOT_ALL: launch classes whose tiles all keep every vertex resident for the whole launch) an access to one of them is an
+// LDS access at compile time — a ds instruction counted by lgkmcnt alone — instead of a flat access through a pointer that may be either, which
+// the hardware counts on both counters and the compiler has to wait out with both at zero.
+__host__ __device__ constexpr bool hot_core(int a) {
+    return a == A_SC || a == A_DIP || a == A_NESTPL || a == A_NESTN || a == A_KSCUPD || a == A_PEND || a == A_PENDDIP || a == A_PENDVALID || a == A_EVN || a == A_FREQ || a == A_LOGF ||
+           a == A_OBS || a == A_NZ || a == A_NZLIST || a == A_UNEXT || a == A_ZHDR || a == A_ZBKT || a == A_PHDR || a == A_PBKT || a == A_RING || a == A_FNDSAVED;
+}
+
 // ---- lane view of a tile / of one vertex of the lane's group ------------------------------------------------------
 struct Tile {
     uint8_t BT_GAS *base;
@@ -195,6 +207,9 @@ struct Tile {
     // hot-capable array: LDS when the vertex is resident, HBM otherwise; one code path through generic pointers
     template <typename T>
     __device__ inline SPtrF<T, LANES> harr(int a, uint32_t v, uint32_t len) const {
+#ifdef BT_HOT_ALL
+        if (hot_core(a)) return SPtrF<T, LANES>{(T *)(lds_block() + v * d->hot_bytes + d->hoff[a]), lane, wsh};
+#endif
         const uint32_t ho = d->hoff[a];
         if (hot != nullptr && ho != NOHOT && (resident == RESIDENT_ALL || v == resident))
             return SPtrF<T, LANES>{(T *)(hot + (resident == RESIDENT_ALL ? v * d->hot_bytes : 0u) + ho), lane, wsh};
@@ -366,8 +381,6 @@ __device__ inline void copies_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-extern __shared__ __attribute__((aligned(16))) uint8_t bt_lds_raw[];
-__device__ inline uint8_t *lds_block() { return (uint8_t *)bt_lds_raw; }
 
 __device__ inline Tile make_tile(const Env &e_in) {
     Tile t;
