@@ -547,7 +547,7 @@ def main():
             "config": {"workload": shape_note, "groups_per_gpu": G, "clusters_per_gpu": C, "clusters_total": C_total, "samples": S, "kmc_records_per_gpu_per_sample": R,
                        "sharding": ("one batch sharded over the ranks (LPT on a cost proxy); " if strong else "a batch of the same size per rank; ") +
                                    "KMC streams per rank; gather of posterior summaries to rank 0", "sharded_equals_unsharded": verified},
-            "roofline": {"kernel": "gibbs_kernel + gibbs_simple_kernel (the concurrent launches of one schedule)", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "gibbs_hot_kernel + gibbs_simple_kernel (the concurrent launches of one schedule; gibbs_kernel for tiles that do not keep every vertex in LDS)", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gibbs_gbs / HBM_PEAK_GBS, "traffic": gibbs_traffic, "traffic_source": gibbs_traffic_src, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
                          "note": "latency/issue-bound sequential sampler: the HBM floor (inputs + state once per chain, SURVEY 8d) is tiny by construction; "
                                  "avg_launch_ms spans the sampling launches of one schedule; traffic = FETCH_SIZE + WRITE_SIZE of those launches from the committed PMC "

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/sq_counters.sh <tag> <class A|B|C|D|+> [S] [groups]   (on the GPU box, from the repo root)
-# SQ counters of gibbs_kernel + gibbs_simple_kernel on one shape class of the bench mixture, two --pmc passes (8 SQ slots each), summed over the
+# SQ counters of gibbs_kernel / gibbs_hot_kernel + gibbs_simple_kernel on one shape class of the bench mixture, two --pmc passes (8 SQ slots each), summed over the
 # dispatches of the sampling launches -> gpurun_out/summ_<tag>/<tag>_sq_<class>.txt
 tag=$1; cls=$2; S=${3:-3}; G=${4:-600000}
 export TMPDIR=/tmp
@@ -18,7 +18,7 @@ import csv, glob, sys
 agg = {}
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gibbs_kernel" in r["Kernel_Name"] or "gibbs_simple_kernel" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("gibbs_kernel", "gibbs_simple_kernel", "gibbs_hot_kernel")):
             agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 for k, v in agg.items(): print(k, "%.4g" % v)
 PY
