@@ -490,8 +490,8 @@ def test_scale_properties_of_a_mixture_batch(gpu_ctx):
 
 
 def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatch):
-    """The whole-GPU table refill (nan_fill_kernel + ucache_prefill_kernel after a stepwise chain start and after every cache-clearing noise count)
-    and bt_gibbs_run chain by chain (BT_GIBBS_STEPWISE) only move work: every collected statistic is bit-identical to the single-launch schedule,
+    """The whole-GPU table refill (nan_fill_kernel + ucache_prefill_kernel after a stepwise chain start and after every cache-clearing noise count),
+    bt_gibbs_run chain by chain (BT_GIBBS_STEPWISE) and the choice between gibbs_hot_kernel and gibbs_kernel only move work: every collected statistic is bit-identical to the single-launch schedule,
     and a noise drivers' loop gives the same noise counts and samples with the refill switched off."""
     from bayestyper_amd import lib, synth
 
@@ -502,7 +502,7 @@ def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatc
     kw = dict(seed=97, chains=3, burn=15, iters=30)
 
     def default_run(env):
-        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL"):
+        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL", "BT_GIBBS_NO_HOT_KERNEL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -529,7 +529,8 @@ def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatc
         return hists, r
 
     base = default_run({})
-    for env in ({"BT_GIBBS_STEPWISE": "1"}, {"BT_GIBBS_STEPWISE": "1", "BT_GIBBS_NO_PREFILL": "1"}):
+    # (BT_GIBBS_NO_HOT_KERNEL: the sampling launches through gibbs_kernel's generic pointers instead of gibbs_hot_kernel's LDS accesses)
+    for env in ({"BT_GIBBS_STEPWISE": "1"}, {"BT_GIBBS_STEPWISE": "1", "BT_GIBBS_NO_PREFILL": "1"}, {"BT_GIBBS_NO_HOT_KERNEL": "1"}):
         got = default_run(env)
         for k in base:
             assert np.array_equal(base[k], got[k]), (env, k)
