@@ -1,5 +1,6 @@
 """Time the default Gibbs schedule of the bench's mixture batch as a whole and per shape class (one MI355X).
-usage: python tools/perf_classes.py [S] [groups] [classes e.g. ABCD+]   ('+' = the whole mixture)"""
+usage: python tools/perf_classes.py [S] [groups] [classes e.g. ABCD+]   ('+' = the whole mixture)
+BT_PERF_RUNS = schedules per class (default 2: the second is the warm one; tools/sq_counters.sh sets 1 so that the counters of a pass cover ONE schedule)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +26,7 @@ for w in which:
     t_create = time.perf_counter() - t_create
     t = lib.Timer(ctx)
     ms = []
-    for _ in range(2):
+    for _ in range(int(os.environ.get("BT_PERF_RUNS", "2"))):
         t.start(); g.run(); t.stop(); ms.append(t.elapsed_ms())
     print(json.dumps({"class": w, "S": S, "groups": int(f["num_groups"]), "clusters": int(f["num_clusters"]), "ms": ms, "create_s": round(t_create, 2), "device_GB": g.device_bytes() / 1e9,
                       "cluster_sweeps_per_s": f["num_clusters"] * 7000 / (min(ms) * 1e-3)}), flush=True)
