@@ -383,10 +383,27 @@ __global__ __launch_bounds__(LANES * 8) void gibbs_noise_kernel(const TileDesc *
     const uint32_t nb = P.S * 256u;
     for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) lh[i] = 0;
     __syncthreads();
+    // the LDS bins are 32 bits wide: they are added to the 64-bit histogram before the tiles walked since the last flush could have put 2^31 counts
+    // into one of them (a tile adds at most lanes x vertices x subset k-mers to a bin; the bound is the same in every thread of the workgroup)
+    uint64_t bound = 0;
     for (uint32_t b = blockIdx.x; b < ntiles; b += gridDim.x) {
         const uint32_t tile = tile_list ? tile_list[b] : b;
         Tile t;
         t.d = (const TileDesc BT_CAS *)&tiles[tile];
+        {
+            const uint64_t add = (uint64_t)t.d->num_lanes * t.d->nvm * (t.d->NUm > 1 ? t.d->NUm : 1);
+            if (bound + add > (1ull << 31)) {
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) {
+                    const uint32_t n = lh[i];
+                    if (n) atomicAdd(&hist[i], (unsigned long long)n);
+                    lh[i] = 0;
+                }
+                __syncthreads();
+                bound = 0;
+            }
+            bound += add;
+        }
         if (!tile_thread_active(t.d->split, t.d->copies)) continue;
         t.base = (uint8_t BT_GAS *)(pool + t.d->base);
         t.lane = tile_lane(t.d->split, t.d->copies);
@@ -1013,7 +1030,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             uint64_t ho = 0;
             // tiles of two-haplotype clusters run simple_sweeps(), which keeps the two haplotype sets and the candidate scratch in
             // registers: those arrays stay in HBM (written once per launch) and the tile's LDS block shrinks by a fifth
-            bool want_simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.lds_stride == LANES && !getenv("BT_GIBBS_NO_SIMPLE");
+            bool want_simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.lds_stride == LANES && !getenv("BT_GIBBS_NO_SIMPLE") && !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
             for (uint32_t l = 0; l < d.num_lanes && want_simple; ++l) want_simple = B->num_haplotypes[B->group_cluster_off[shapes[tile_start[ti] + l].g]] == 2;
             // tuning: BT_GIBBS_HOT_SKIP = bit mask over hot_arrs[] of arrays to leave in HBM
             const uint64_t skip_mask = getenv("BT_GIBBS_HOT_SKIP") ? strtoull(getenv("BT_GIBBS_HOT_SKIP"), nullptr, 0) : 0ull;
@@ -1024,13 +1041,18 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
                 if (a == A_MGEN && d.NMm == 0) continue;          // (only clusters with multicluster k-mers read it)
                 if (a == A_KSCTMP && d.lds_stride == LANES) continue;   // scratch of the k-mer-stats rebuild: LDS only where tiles are narrow
                 if (a == A_CUM && d.D2m * d.teams > 16) continue;
-                if (want_simple && (a == A_NZLIST || a == A_UNEXT || a == A_ZHDR || a == A_ZBKT || a == A_PHDR || a == A_PBKT || a == A_CUM)) continue;
+                if (want_simple && a != A_RING) continue;   // (simple_sweeps keeps the cluster's state in registers and its own per-sample words: TileDesc::sblk)
                 // the dense table of unique-k-mer sums is read for every candidate of every sample: a few entries per lane (two-haplotype
                 // clusters x a few samples) stay in LDS for the launch
                 if (a == A_UCACHE && !(d.cache_mode == 0 && d.uc_width == 0 && d.nvm == 1 && (uint64_t)d.cache_entries * 8 <= 160)) continue;
                 const uint64_t per_vertex = len[a] / nv;   // elements per lane and vertex
                 d.hoff[a] = (uint32_t)ho;
                 ho = align_up(ho + per_vertex * d.lds_stride * kElemSize[a], 16);
+            }
+            d.sblk = 0;
+            if (want_simple) {   // per sample: two weights + the packed state word (bt_gibbs_simple.hpp: SB_WORDS), lane-interleaved
+                d.sblk = (uint32_t)ho;
+                ho = align_up(ho + (uint64_t)3 * S * LANES * 4, 16);
             }
             d.hot_bytes = (uint32_t)std::min<uint64_t>(ho, 0xFFFFFFFFu);
             const uint64_t hot_budget = getenv("BT_GIBBS_HOT_BUDGET") ? strtoull(getenv("BT_GIBBS_HOT_BUDGET"), nullptr, 0) : kHotBudget;   // tuning
@@ -1057,7 +1079,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         {
             bool simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.copies == 1 && d.split == 1 && d.hot_bytes != 0 && !getenv("BT_GIBBS_NO_SIMPLE");
             for (uint32_t l = 0; l < d.num_lanes && simple; ++l) simple = B->num_haplotypes[B->group_cluster_off[shapes[tile_start[ti] + l].g]] == 2;
-            for (int a : {A_SC, A_OBS, A_PEND, A_DIP, A_PENDDIP, A_NZ, A_KSCUPD, A_PENDVALID, A_EVN, A_NESTPL, A_NESTN, A_FREQ, A_LOGF, A_RING}) simple = simple && d.hoff[a] != NOHOT;
+            simple = simple && d.hoff[A_RING] != NOHOT && d.hoff[A_SC] == NOHOT;   // (the LDS block was laid out for simple_sweeps above)
             d.simple = simple ? 1u : 0u;
         }
         d.logged = d.nvm == 1 && d.NMm == 0 && !getenv("BT_GIBBS_NO_LOG") ? 1u : 0u;
@@ -1228,6 +1250,23 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         BT_TRYHIP(hipStreamSynchronize(ctx->stream));
         g->P.lgamma_int = (const double BT_GAS *)g->d_lgamma;
         g->P.lgamma_n = n;
+        // Marsaglia-Tsang's a2 = 1 / sqrt(9 (alpha - 1/3)) for alpha = an observation count + 1 <= 2S + 1 (gamma_distribution::param_type::_M_initialize,
+        // bits/random.tcc: the same two correctly rounded IEEE operations the device would execute per draw)
+        {
+            const uint32_t na = 2 * S + 8;
+            std::vector<double> a2(na, 0.0);
+            for (uint32_t i = 1; i < na; ++i) {
+                const double a1 = (double)i - 1.0 / 3.0;
+                a2[i] = 1.0 / std::sqrt(9.0 * a1);
+            }
+            double *d_a2 = nullptr;
+            BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&d_a2), (size_t)na * 8));
+            g->allocs.push_back(d_a2);
+            BT_TRYHIP(hipMemcpyAsync(d_a2, a2.data(), (size_t)na * 8, hipMemcpyHostToDevice, ctx->stream));
+            BT_TRYHIP(hipStreamSynchronize(ctx->stream));
+            g->P.gamma_a2 = (const double BT_GAS *)d_a2;
+            g->P.gamma_n = na;
+        }
         BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_params), sizeof(GParams)));
         g->allocs.push_back(g->d_params);
         BT_TRYHIP(hipMemcpyAsync(g->d_params, &g->P, sizeof(GParams), hipMemcpyHostToDevice, ctx->stream));

@@ -1,15 +1,29 @@
 // Sweeps of TWO-HAPLOTYPE single-cluster groups (a biallelic SNV / indel: reference and alternative haplotype) — nine out of ten
-// variant-cluster groups of a genome.  Same state, same arrays, same draw stream and arithmetic as the general sampler in
-// bt_gibbs_tile.hpp (which still constructs, resets and flushes these clusters and runs the rare slow paths); what differs is HOW a
-// sweep is executed: one straight-line routine with the cluster's dimensions as constants (H = 2: at most three diplotype
-// candidates, so always the reference's chain of logAddition calls), the hot arrays addressed as LDS (ds_* instructions instead of
-// generic pointers), the two emulated unordered_set<uint> kept as two-entry lists in registers, and no calls on the common path.
+// variant-cluster groups of a genome.  Same state, same draw stream and the same decisions as the general sampler in bt_gibbs_tile.hpp
+// (which still constructs, resets and drains these clusters); what differs is HOW a sweep is executed (round 4):
+//
+//  * the cluster's sampler state lives in REGISTERS for a whole chain — the two frequencies, the observation counts, the two emulated
+//    unordered_set<uint> as two-entry lists, the polar method's saved variate — and a sample's state in ONE packed LDS word (diplotype, the
+//    pending run of collected sweeps, its length, the log fill, ploidy, flags), read and written once per sample and sweep;
+//  * the diplotype draw of a sample (at most three candidates) is taken in the LINEAR domain from weights that are fixed for a chain: the
+//    unique-k-mer sums of the candidates enter as exp(sum - max), computed once per chain start in double precision and kept as two floats per
+//    sample; a sweep multiplies them with the current frequencies (f0 f0, 2 f0 f1, f1 f1) and compares U * total with the running sums.  The
+//    decision is VERIFIED: whenever U * total lies within 1e-5 * total of a boundary (the weights' own error is below 2e-7 * total) — about
+//    once in 10^4 draws — the reference's chain of logAddition calls over the double-precision log-probabilities decides (simple_exact_code),
+//    so every sampled diplotype is the reference's.  log(frequency) is therefore only needed on that path and is no longer kept up to date;
+//  * the simplex-size draw of the sparse frequency distribution needs one number per chain (the cached probability vector's first entry: the
+//    observation total of a cluster is the same in every sweep);
+//  * gamma draws read 1 / sqrt(9 (alpha - 1/3)) from a table (alpha = an observation count + 1) and screen Marsaglia-Tsang's second test in
+//    single precision (bt_rng_device.hpp);
+//  * generator refills in bursts of four (MtRingT::generate4).
+// LDS per cluster: the two draw-ahead rings + 12 bytes per sample (round 3: 430 bytes at three samples), so that a CU holds twelve and more
+// of these wavefronts instead of six.
 //
 // Reference behaviour (as in bt_gibbs_tile.hpp):
 //   VariantClusterGenotyper::sampleDiplotypes / sampleDiplotype / calcDiplotypeLogProb   VariantClusterGenotyper.cpp:597-755
 //   HaplotypeFrequencyDistribution::incrementCount / SparseFrequencyDistribution          HaplotypeFrequencyDistribution.cpp:113-138,
 //                                                                                         FrequencyDistribution.cpp:75-93,198-303
-//   VariantClusterHaplotypes::updateAlleleKmerStats (deferred as in update_allele_kmer_stats)
+//   VariantClusterHaplotypes::updateAlleleKmerStats (logged as runs, applied by drain_collected)
 #pragma once
 #include "bt_gibbs_tile.hpp"
 
@@ -67,50 +81,221 @@ __device__ inline void set2_store(HS s, const Set2 &v) {   // rebuild the genera
     if (v.n >= 1) uset_insert(s, v.e0);
 }
 
-struct SimpleState {   // what a run of sweeps keeps in registers between sweeps
-    Set2 zero, plus;
-    double fnd_saved;
-    uint32_t fnd_avail, is_sparse, hap_count;
-};
-
 __device__ inline bool tile_is_simple(const TileDesc BT_CAS &d) { return d.simple != 0; }
 
-// n_burn sweeps without and then n_collect sweeps with collection of the tile's clusters (one per lane).  The hot arrays of vertex 0 are
-// resident in LDS (RESIDENT_ALL).  (One call site per kernel: the routine is inlined, and every further site would be another 24 000 instructions.)
+// ---- a sample's packed state word -------------------------------------------------------------------------------------------------
+// diplotype codes of a two-haplotype cluster: 0 (0,0)  1 (0,1)  2 (1,1)  3 (0,-)  4 (1,-)  5 (-,-)
+constexpr uint32_t SD_NONE = 5;
+__device__ inline uint32_t sd_code(uint16_t h1, uint16_t h2) { return h1 == NOHAP ? SD_NONE : (h2 == NOHAP ? 3u + h1 : (uint32_t)h1 + h2); }
+__device__ inline uint32_t sd_h1(uint32_t code) { return code < 3u ? code >> 1 : (code < 5u ? code - 3u : (uint32_t)NOHAP); }
+__device__ inline uint32_t sd_h2(uint32_t code) { return code < 3u ? (code + 1u) >> 1 : (uint32_t)NOHAP; }
+__device__ inline uint32_t sd_key(uint32_t code) { return sd_h1(code) | (sd_h2(code) << 16); }
+// bits 0-2 diplotype, 3-5 the pending run's diplotype, 6-7 which candidate's weight is the maximum (= 1), 8-15 length of the pending run,
+// 16-23 runs in the sample's log, 24-25 ploidy, 26 k-mer-stats cache out of date (A_KSCUPD), 27 a run is pending (A_PENDVALID)
+constexpr uint32_t SP_PDIP = 3, SP_WMAX = 6, SP_PEND = 8, SP_EVN = 16, SP_PLOIDY = 24, SP_UPD = 26, SP_PVALID = 27;
+constexpr uint32_t SB_WORDS = 3;   // per sample: two weights (float bits), the packed word
+
+// The reference's decision for one sample, as round 3's sweep took it for every draw: the chain of logAddition calls over the candidates' log-probabilities
+// (log frequencies + the table of unique-k-mer sums), upper_bound of log(U) + total.  Returns the diplotype code.
+__device__ static __noinline__ uint32_t simple_exact_code(Env env, uint32_t s, uint32_t pl, uint32_t nzmask, double f0, double f1, double u01) {
+    const Vx c = make_vx(make_tile(env), 0);
+    const uint32_t Dcm = c.d().Dcm;
+    const Vx::UCPtr uc = c.ucache();
+    uint32_t nzl[2] = {0, 0}, nnz = 0;
+    if (nzmask & 1u) nzl[nnz++] = 0;
+    if (nzmask & 2u) nzl[nnz++] = 1;
+    const double lf0 = bt_log(nzl[0] ? f1 : f0), lf1 = nnz > 1 ? bt_log(f1) : 0.0;
+    const uint32_t total = pl == 2 ? nnz * (nnz + 1) / 2 : (pl == 1 ? nnz : 0u);
+    double lp[3];
+    uint16_t ca[3], cb[3];
+    if (pl == 2) {
+        ca[0] = (uint16_t)nzl[0], cb[0] = (uint16_t)nzl[0];
+        ca[1] = (uint16_t)nzl[0], cb[1] = (uint16_t)nzl[1];
+        ca[2] = (uint16_t)nzl[1], cb[2] = (uint16_t)nzl[1];
+        if (nnz == 1) ca[1] = ca[2] = ca[0], cb[1] = cb[2] = cb[0];
+    } else {
+        ca[0] = (uint16_t)nzl[0], cb[0] = NOHAP;
+        ca[1] = (uint16_t)nzl[nnz > 1 ? 1 : 0], cb[1] = NOHAP;
+        ca[2] = ca[1], cb[2] = NOHAP;
+    }
+    double uv[3];
+#pragma unroll
+    for (uint32_t q = 0; q < 3; ++q) {   // H = 2: dip_index(a, b) = 2a - a(a-1)/2 + (b - a), haploid 3 + a
+        const uint32_t a = ca[q], b = cb[q];
+        const uint32_t idx = cb[q] == NOHAP ? 3u + a : 2u * a - (a * (a - 1u)) / 2u + (b - a);
+        uv[q] = q < total ? (double)uc[s * Dcm + idx] : 0.0;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 3; ++q) {
+        const double la = ca[q] == nzl[0] ? lf0 : lf1, lb = cb[q] == nzl[0] ? lf0 : lf1;
+        double v = 0;
+        if (pl != 2) v += la;
+        else if (ca[q] == cb[q]) v += 2 * la;
+        else v += BT_LN2 + la + lb;
+        lp[q] = v + uv[q];
+    }
+    if (total == 0) return SD_NONE;
+    uint32_t pick = 0;
+    double cum1 = 0, cum2 = 0;
+    double run = lp[0];
+    if (total > 1) {
+        run = log_addition(lp[1], run);
+        cum1 = run;
+    }
+    if (total > 2) {
+        run = log_addition(lp[2], run);
+        cum2 = run;
+    }
+    const double u = bt_log(u01) + run;
+    // upper_bound(cum, u): first index with u < cum[i]; past the end -> last
+    if (u < lp[0]) pick = 0;
+    else if (total > 1 && u < cum1) pick = 1;
+    else if (total > 2 && u < cum2) pick = 2;
+    else pick = total - 1;
+    return sd_code(ca[pick], cb[pick]);
+}
+
+// the log of a sample is full: apply it (rare: a sample that changed its diplotype EV_CAP times within a chain)
+__device__ static __noinline__ void simple_apply_full_log(Env env, uint32_t s) {
+    const Vx c = make_vx(make_tile(env), 0);
+    const GParams BT_CAS &P = env_params(env);
+    c.evn()[s] = (uint8_t)EV_CAP;
+    apply_collected_log(c, P, s, c.sc()[SC_NSUB_U]);
+}
+
+// Chain entry: the per-sample LDS words from the general arrays, the candidates' weights from the table of unique-k-mer sums (rebuilt when
+// the chain start / clearCache marked it), the sparse distribution's simplex-size probability.  Returns P(simplex size = |plus|) for |plus| = 1.
+__device__ static __noinline__ double simple_enter(Env env, uint32_t blk_off) {
+    const Tile t = make_tile(env);
+    const Vx c = make_vx(t, 0);
+    const GParams BT_CAS &P = env_params(env);
+    const TileDesc BT_CAS &d = *t.d;
+    const uint32_t S = P.S, Dcm = d.Dcm;
+    SPtrF<uint32_t, LANES> sc = c.sc();
+    if (sc[SC_UC_DIRTY]) {   // chain start / clearCache: the dense table of unique-k-mer sums is rebuilt as a whole
+        fill_unique_cache(env, 0);
+        sc[SC_UC_DIRTY] = 0;
+    }
+    LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
+    const Vx::UCPtr uc = c.ucache();
+    TPtr<uint8_t> gp = t.arr<uint8_t>(A_PLOIDY);
+    SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
+    SPtrF<uint32_t, LANES> pend = c.pend();
+    SPtrF<uint8_t, LANES> pvalid = c.pend_valid(), upd = c.ksc_upd(), evn = c.evn(), npl = c.nest_ploidy(), nn = c.nest_n();
+    uint32_t n_obs = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint32_t pl = gp[s];
+        // the group's ploidy per sample is the cluster's (a root cluster without nesting: VariantClusterGroup.cpp:225-231)
+        npl[s] = (uint8_t)pl;
+        nn[s] = 0;
+        n_obs += pl == 2 ? 2u : (pl == 1 ? 1u : 0u);
+        const uint32_t i0 = pl == 2 ? 0u : 3u;
+        const double v0 = pl ? (double)uc[s * Dcm + i0] : 0.0, v1 = pl ? (double)uc[s * Dcm + i0 + 1u] : 0.0;
+        const double ninf = -__builtin_huge_val();
+        const double v2 = pl == 2 ? (double)uc[s * Dcm + 2u] : ninf;
+        uint32_t wmax = 0;
+        double m = v0;
+        if (v1 > m) m = v1, wmax = 1;
+        if (v2 > m) m = v2, wmax = 2;
+        const double ea = bt_exp((wmax == 0 ? v1 : v0) - m), eb = bt_exp((wmax == 2 ? v1 : v2) - m);   // the two that are not the maximum, in candidate order
+        blk[SB_WORDS * s] = __float_as_uint((float)ea);
+        blk[SB_WORDS * s + 1] = __float_as_uint((float)eb);
+        uint32_t pr = pend[s], pv = pvalid[s];
+        uint32_t pcode = sd_code(pdip[2 * s], pdip[2 * s + 1]);
+        if (pv && pr > 255u) {   // (not produced by this kernel, which drains at the end of every launch that collects)
+            log_collected_run(c, P, s, sd_key(pcode), pr, sc[SC_NSUB_U]);
+            pr = 0;
+            pv = 0;
+        }
+        blk[SB_WORDS * s + 2] = sd_code(dip[2 * s], dip[2 * s + 1]) | (pcode << SP_PDIP) | (wmax << SP_WMAX) | (pr << SP_PEND) | ((uint32_t)evn[s] << SP_EVN) | (pl << SP_PLOIDY) |
+                                ((upd[s] ? 1u : 0u) << SP_UPD) | ((pv ? 1u : 0u) << SP_PVALID);
+    }
+    double p1 = 1.0;
+    if (sc[SC_IS_SPARSE] && n_obs > 0) {
+        // cached simplex-size distribution (FrequencyDistribution.cpp:143-196,211-229) for |plus| = 1 (for |plus| = 2 the size is 2)
+        TPtr<double> vec = c.simplex();
+        const bool cached = d.scache_n && n_obs <= 2 * d.S && 1u <= d.scache_p;
+        const uint32_t ci = cached ? (n_obs - 1) * d.scache_p : 0u;
+        if (cached) vec = c.scache() + ci * d.scache_len;
+        uint32_t len = cached ? (uint32_t)c.sclen()[ci] : 0u;
+        if (len == 0) {
+            len = simplex_prob_vector(c, P, vec, n_obs, 1u);
+            if (cached) c.sclen()[ci] = len;
+        }
+        p1 = vec[0];
+    }
+    return p1;
+}
+
+// chain exit: back to the general representation
+__device__ static __noinline__ void simple_leave(Env env, uint32_t blk_off, double f0, double f1, uint32_t nzmask) {
+    const Tile t = make_tile(env);
+    const Vx c = make_vx(t, 0);
+    const GParams BT_CAS &P = env_params(env);
+    LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
+    SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
+    SPtrF<uint32_t, LANES> pend = c.pend();
+    SPtrF<uint8_t, LANES> pvalid = c.pend_valid(), upd = c.ksc_upd(), evn = c.evn();
+    for (uint32_t s = 0; s < P.S; ++s) {
+        const uint32_t pk = blk[SB_WORDS * s + 2];
+        const uint32_t code = pk & 7u, pcode = (pk >> SP_PDIP) & 7u;
+        dip[2 * s] = (uint16_t)sd_h1(code);
+        dip[2 * s + 1] = (uint16_t)sd_h2(code);
+        pdip[2 * s] = (uint16_t)sd_h1(pcode);
+        pdip[2 * s + 1] = (uint16_t)sd_h2(pcode);
+        pend[s] = (pk >> SP_PEND) & 255u;
+        evn[s] = (uint8_t)((pk >> SP_EVN) & 255u);
+        upd[s] = (uint8_t)((pk >> SP_UPD) & 1u);
+        pvalid[s] = (uint8_t)((pk >> SP_PVALID) & 1u);
+    }
+    // log(frequency) of the non-zero haplotypes: what the general sampler keeps beside the frequencies
+    SPtrF<double, LANES> freq = c.freq(), logf = c.logf();
+    SPtrF<uint8_t, LANES> nz = c.nz();
+    freq[0] = f0;
+    freq[1] = f1;
+    nz[0] = (uint8_t)(nzmask & 1u);
+    nz[1] = (uint8_t)((nzmask >> 1) & 1u);
+    if (nzmask & 1u) logf[0] = bt_log(f0);
+    if (nzmask & 2u) logf[1] = bt_log(f1);
+}
+
+// n_burn sweeps without and then n_collect sweeps with collection of the tile's clusters (one per lane).
+// (One call site per kernel.)
 __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParams BT_CAS &P, uint32_t n_burn, uint32_t n_collect, uint32_t *trace_counter, uint32_t *trace_buf,
                                      uint32_t trace_max, uint32_t tile) {
     const uint32_t n_sweeps = n_burn + n_collect;
     const TileDesc BT_CAS &d = *t.d;
     const Vx c = make_vx(t, 0);   // (general accessors for the arrays that stay in HBM and for the slow paths)
-    const uint32_t S = P.S, Dcm = d.Dcm;
-    LdsArr<uint32_t> sc = lds_arr<uint32_t>(t, A_SC), obs = lds_arr<uint32_t>(t, A_OBS), pend = lds_arr<uint32_t>(t, A_PEND);
-    LdsArr<uint16_t> dip = lds_arr<uint16_t>(t, A_DIP), pdip = lds_arr<uint16_t>(t, A_PENDDIP);
-    LdsArr<uint8_t> nz = lds_arr<uint8_t>(t, A_NZ), upd = lds_arr<uint8_t>(t, A_KSCUPD), pvalid = lds_arr<uint8_t>(t, A_PENDVALID), ploidy = lds_arr<uint8_t>(t, A_NESTPL),
-                    nest_n = lds_arr<uint8_t>(t, A_NESTN);
-    LdsArr<double> freq = lds_arr<double>(t, A_FREQ), logf = lds_arr<double>(t, A_LOGF);
-    const Vx::UCPtr uc = c.ucache();   // LDS when the table is small, else HBM
-    // the group's ploidy per sample is the cluster's (a root cluster without nesting: VariantClusterGroup.cpp:225-231)
+    const uint32_t S = P.S;
+    const uint32_t blk_off = d.sblk;
+    const double p_simplex1 = simple_enter(env, blk_off);
+    LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
+    SPtrF<uint32_t, LANES> sc = c.sc();
+    const bool is_sparse = sc[SC_IS_SPARSE] != 0;
+    Set2 zero{0, 0, 0}, plus{0, 0, 0};
+    if (is_sparse) {
+        zero = set2_load(c.zero_set());
+        plus = set2_load(c.plus_set());
+    }
+    double fnd_saved = c.fnd_saved();
+    uint32_t fnd_avail = sc[SC_FND_AVAIL];
+    double f0, f1;
+    uint32_t nzmask, obs0, obs1;
     {
-        TPtr<uint8_t> gp = t.arr<uint8_t>(A_PLOIDY);
-        for (uint32_t s = 0; s < S; ++s) {
-            ploidy[s] = gp[s];
-            nest_n[s] = 0;
-        }
+        SPtrF<double, LANES> freq = c.freq();
+        SPtrF<uint8_t, LANES> nz = c.nz();
+        SPtrF<uint32_t, LANES> obs = c.obs();
+        nzmask = (nz[0] ? 1u : 0u) | (nz[1] ? 2u : 0u);
+        f0 = (nzmask & 1u) ? (double)freq[0] : 0.0;
+        f1 = (nzmask & 2u) ? (double)freq[1] : 0.0;
+        obs0 = obs[0];
+        obs1 = obs[1];
     }
-    SimpleState st;
-    st.is_sparse = sc[SC_IS_SPARSE];
-    st.zero = Set2{0, 0, 0};
-    st.plus = Set2{0, 0, 0};
-    if (st.is_sparse) {
-        st.zero = set2_load(c.zero_set());
-        st.plus = set2_load(c.plus_set());
-    }
-    st.fnd_saved = c.fnd_saved();
-    st.fnd_avail = sc[SC_FND_AVAIL];
-    st.hap_count = sc[SC_HAP_COUNT];
     typedef MtRingT<LdsArr<uint32_t>> Ring;
     const LdsArr<uint32_t> ring0 = lds_arr<uint32_t>(t, A_RING), ring1 = ring0 + (d.ring_cap[0] + MT_RING_HDR);
     Ring r0 = mt_ring_open_as(c.mt(0), ring0, d.ring_cap[0]), r1 = mt_ring_open_as(c.mt(1), ring1, d.ring_cap[1]);
+    const double BT_GAS *a2tab = P.gamma_a2;
+    const uint32_t a2n = P.gamma_n;
 
     for (uint32_t sweep = 0; sweep < n_sweeps; ++sweep) {
         const bool collect = sweep >= n_burn;
@@ -126,213 +311,154 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
                 tracing = true;
             }
         }
-        if (sc[SC_UC_DIRTY]) {   // chain start / clearCache: the dense table of unique-k-mer sums is rebuilt as a whole
-            fill_unique_cache(env, 0);
-            sc[SC_UC_DIRTY] = 0;
-        }
         PROF_DECL;
-        r0.topup();
-        r1.topup();
+        {   // the visit's words: exactly two per sample from the diplotype generator, the frequency generator's ring full
+            const uint32_t want = 2u * S < r0.cap ? 2u * S : r0.cap;   // (more than 16 samples: the draws top up on the way)
+            r0.generate4(r0.avail < want ? want - r0.avail : 0u);
+            r1.topup4();
+        }
         PROF(11);
         // ---- sampleDiplotypes ----
-        uint32_t nzl[2] = {0, 0}, nnz = 0;
-        if (nz[0]) nzl[nnz++] = 0;
-        if (nz[1]) nzl[nnz++] = 1;
-        const double lf0 = logf[nzl[0]], lf1 = nnz > 1 ? (double)logf[nzl[1]] : 0.0;
+        const double ff00 = f0 * f0, ff01 = 2.0 * f0 * f1, ff11 = f1 * f1;
+        // a frequency so small that a candidate's weight could be lost against another's rounding is left to the exact chain
+        const bool tiny = ((nzmask & 1u) && f0 < 1e-12) || ((nzmask & 2u) && f1 < 1e-12);
         for (uint32_t s = 0; s < S; ++s) {
-            const uint16_t p1 = dip[2 * s], p2 = dip[2 * s + 1];
-            const uint32_t pl = ploidy[s];
-            const uint32_t total = pl == 2 ? nnz * (nnz + 1) / 2 : (pl == 1 ? nnz : 0u);
-            // candidates in the reference's order: diploid (a, b >= a) over the non-zero haplotypes, haploid (a)
-            double lp[3];
-            uint16_t ca[3], cb[3];
-            if (pl == 2) {
-                ca[0] = (uint16_t)nzl[0], cb[0] = (uint16_t)nzl[0];
-                ca[1] = (uint16_t)nzl[0], cb[1] = (uint16_t)nzl[1];
-                ca[2] = (uint16_t)nzl[1], cb[2] = (uint16_t)nzl[1];
-                if (nnz == 1) ca[1] = ca[2] = ca[0], cb[1] = cb[2] = cb[0];
-            } else {
-                ca[0] = (uint16_t)nzl[0], cb[0] = NOHAP;
-                ca[1] = (uint16_t)nzl[nnz > 1 ? 1 : 0], cb[1] = NOHAP;
-                ca[2] = ca[1], cb[2] = NOHAP;
-            }
-            double uv[3];
-#pragma unroll
-            for (uint32_t q = 0; q < 3; ++q) {   // H = 2: dip_index(a, b) = 2a - a(a-1)/2 + (b - a), haploid 3 + a
-                const uint32_t a = ca[q], b = cb[q];
-                const uint32_t idx = cb[q] == NOHAP ? 3u + a : 2u * a - (a * (a - 1u)) / 2u + (b - a);
-                uv[q] = q < total ? (double)uc[s * Dcm + idx] : 0.0;
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < 3; ++q) {
-                const double la = ca[q] == nzl[0] ? lf0 : lf1, lb = cb[q] == nzl[0] ? lf0 : lf1;
-                double v = 0;
-                if (pl != 2) v += la;
-                else if (ca[q] == cb[q]) v += 2 * la;
-                else v += BT_LN2 + la + lb;
-                lp[q] = v + uv[q];
-            }
+            uint32_t pk = blk[SB_WORDS * s + 2];
+            const float wa = __uint_as_float(blk[SB_WORDS * s]), wb = __uint_as_float(blk[SB_WORDS * s + 1]);
             // LogDiscreteSampler: the draw happens even for a single outcome (DiscreteSampler.cpp:120-125)
             const double u01 = rng_canonical(r0);
-            uint32_t pick = 0;
-            if (total == 0) (void)bt_log(u01);
-            else {
-                double cum1 = 0, cum2 = 0;
-                double run = lp[0];
-                if (total > 1) {
-                    run = log_addition(lp[1], run);
-                    cum1 = run;
+            const uint32_t pl = (pk >> SP_PLOIDY) & 3u, wmax = (pk >> SP_WMAX) & 3u, pcode = pk & 7u;
+            uint32_t code = SD_NONE;
+            if (pl != 0) {
+                const double e0 = wmax == 0 ? 1.0 : (double)wa, e1 = wmax == 0 ? (double)wa : (wmax == 1 ? 1.0 : (double)wb), e2 = wmax == 2 ? 1.0 : (double)wb;
+                // candidates in the reference's order over the non-zero haplotypes: diploid (0,0) (0,1) (1,1), haploid (0) (1); a zero frequency
+                // gives a zero weight, i.e. the candidate is absent
+                const double w0 = (pl == 2 ? ff00 : f0) * e0, w1 = (pl == 2 ? ff01 : f1) * e1, w2 = pl == 2 ? ff11 * e2 : 0.0;
+                const double c1 = w0 + w1, tot = c1 + w2, thr = u01 * tot, mg = 1e-5 * tot;
+                const uint32_t pick = thr < w0 ? 0u : (thr < c1 ? 1u : 2u);
+                const double lo = pick == 1 ? w0 : c1, hi = pick == 0 ? w0 : (pick == 1 ? c1 : tot);
+                const bool safe = !tiny && tot > 1e-280 && hi - thr > mg && (pick == 0 || thr - lo > mg);
+                code = pl == 2 ? pick : 3u + pick;
+                if (!safe) {
+                    PROF_CNT(19, 1);
+                    code = simple_exact_code(env, s, pl, nzmask, f0, f1, u01);
                 }
-                if (total > 2) {
-                    run = log_addition(lp[2], run);
-                    cum2 = run;
-                }
-                const double u = bt_log(u01) + run;
-                // upper_bound(cum, u): first index with u < cum[i]; past the end -> last
-                if (u < lp[0]) pick = 0;
-                else if (total > 1 && u < cum1) pick = 1;
-                else if (total > 2 && u < cum2) pick = 2;
-                else pick = total - 1;
             }
-            uint16_t h1 = NOHAP, h2 = NOHAP;
-            if (total != 0) {
-                h1 = ca[pick];
-                h2 = cb[pick];
-            }
-            dip[2 * s] = h1;
-            dip[2 * s + 1] = h2;
-            // HaplotypeFrequencyDistribution::incrementCount (x2)
+            // HaplotypeFrequencyDistribution::incrementCount for the drawn haplotypes, in order
+            {
+                const uint32_t h1 = sd_h1(code), h2 = sd_h2(code);
 #pragma unroll
-            for (uint32_t w = 0; w < 2; ++w) {
-                const uint16_t h = w ? h2 : h1;
-                if (h == NOHAP) continue;
-                st.hap_count += 1;
-                const uint32_t o = obs[h];
-                if (st.is_sparse && o == 0) {
-                    st.zero.erase(h);
-                    st.plus.insert(h);
+                for (uint32_t w = 0; w < 2; ++w) {
+                    const uint32_t h = w ? h2 : h1;
+                    if (h == (uint32_t)NOHAP) continue;
+                    const uint32_t o = h ? obs1 : obs0;
+                    if (is_sparse && o == 0) {
+                        zero.erase(h);
+                        plus.insert(h);
+                    }
+                    if (h) obs1 = o + 1;
+                    else obs0 = o + 1;
                 }
-                obs[h] = o + 1;
             }
-            if (h1 != p1 || h2 != p2) upd[s] = 1;   // update_multicluster_multiplicities without multicluster k-mers
-            if (tracing) trace_row[s] = (uint32_t)h1 | ((uint32_t)h2 << 16);
+            pk = (pk & ~7u) | code;
+            if (code != pcode) pk |= 1u << SP_UPD;   // update_multicluster_multiplicities without multicluster k-mers
+            if (tracing) trace_row[s] = sd_key(code);
+            // ---- collected sweep: diplotype_sampling_frequencies + updateAlleleKmerStats, logged as runs of identical sweeps ----
+            if (collect) {
+                const uint32_t pdc = (pk >> SP_PDIP) & 7u, run = (pk >> SP_PEND) & 255u;
+                const bool pv = (pk >> SP_PVALID) & 1u;
+                if (pv && pdc == code && run < 255u) pk += 1u << SP_PEND;
+                else {
+                    if (pv && run) {
+                        uint32_t n = (pk >> SP_EVN) & 255u;
+                        if (n == EV_CAP) {
+                            simple_apply_full_log(env, s);
+                            n = 0;
+                        }
+                        TPtr<uint32_t> lg = c.evlog(s);
+                        lg[1 + 2 * n] = sd_key(pdc);   // (stores only: nothing waits for HBM while sampling)
+                        lg[2 + 2 * n] = run;
+                        pk = (pk & ~(255u << SP_EVN)) | ((n + 1u) << SP_EVN);
+                    }
+                    pk = (pk & ~((7u << SP_PDIP) | (255u << SP_PEND))) | (code << SP_PDIP) | (1u << SP_PEND) | (1u << SP_PVALID);
+                }
+            }
+            blk[SB_WORDS * s + 2] = pk;
         }
         PROF(2);
-        // ---- collected sweep: diplotype_sampling_frequencies + updateAlleleKmerStats, deferred while nothing changes ----
-        if (collect) {
-            for (uint32_t s = 0; s < S; ++s) {
-                if (pvalid[s] && pdip[2 * s] == dip[2 * s] && pdip[2 * s + 1] == dip[2 * s + 1]) {
-                    pend[s] += 1;
-                    continue;
-                }
-                if (pvalid[s] && pend[s]) log_collected_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], sc[SC_NSUB_U]);
-                pdip[2 * s] = dip[2 * s];
-                pdip[2 * s + 1] = dip[2 * s + 1];
-                pend[s] = 1;
-                pvalid[s] = 1;
-            }
-        }
-        PROF(6);
         // ---- sampleHaplotypeFrequencies ----
-        if (st.hap_count > 0) {
-            double saved = st.fnd_saved;
-            uint32_t avail = st.fnd_avail;
+        const uint32_t n_obs = obs0 + obs1;
+        if (n_obs > 0) {
+            double saved = fnd_saved;
+            uint32_t avail = fnd_avail;
             const NormalState nd{&saved, &avail};
-            if (!st.is_sparse) {
-                double f[2], norm = 0;
-#pragma unroll
-                for (uint32_t h = 0; h < 2; ++h) {
-                    f[h] = rng_gamma(r1, nd, (double)(obs[h] + 1u), 1.0);
-                    norm += f[h];
-                    obs[h] = 0;
-                }
-#pragma unroll
-                for (uint32_t h = 0; h < 2; ++h) {
-                    const double x = f[h] / norm;
-                    freq[h] = x;
-                    logf[h] = bt_log(x);
-                }
-            } else {
-                const uint32_t n_obs = st.hap_count, plus_size = st.plus.n;
-                // cached simplex-size distribution (FrequencyDistribution.cpp:143-196,211-229): at most 3 - plus_size entries
-                TPtr<double> vec = c.simplex();
-                const bool cached = d.scache_n && n_obs <= 2 * d.S && plus_size <= d.scache_p;
-                const uint32_t ci = cached ? (n_obs - 1) * d.scache_p + (plus_size - 1) : 0u;
-                if (cached) vec = c.scache() + ci * d.scache_len;
-                double head[2];
-                head[0] = cached ? (double)vec[0] : 0.0;
-                head[1] = cached ? (double)vec[1] : 0.0;
-                uint32_t len = cached ? (uint32_t)c.sclen()[ci] : 0u;
-                if (len == 0) {
-                    len = simplex_prob_vector(c, P, vec, n_obs, plus_size);
-                    if (cached) c.sclen()[ci] = len;
-                    head[0] = vec[0];
-                    head[1] = len > 1 ? (double)vec[1] : 0.0;
-                }
+            double g0 = 0, g1 = 0, norm = 0;
+            bool sel0 = !is_sparse, sel1 = !is_sparse;
+            uint32_t n_first = 2, n_steps = 2;   // non-sparse: a gamma draw per haplotype, in index order
+            Set2 order0 = plus;
+            if (is_sparse) {
+                // simplex size = |plus| + upper_bound(cached vector, U): with two haplotypes the vector has one entry that is not 1
                 const double u = rng_canonical(r1);
-                uint32_t ub = 0;
-                if (!(u < head[0])) {
-                    ub = 1;
-                    if (len > 1 && !(u < head[1])) ub = 2;
-                }
-                const uint32_t simplex_size = ub + plus_size;
-                double f[2] = {0, 0}, norm = 0;
-                bool sel[2] = {false, false};
-                for (uint32_t i = 0; i < plus_size; ++i) {   // plus in iteration order
-                    const uint32_t e = st.plus.at(i);
-                    const double x = rng_gamma(r1, nd, (double)obs[e] + 1.0, 1.0);
-                    f[e & 1u] = x;
-                    norm += x;
-                    sel[e & 1u] = true;
-                }
-                while (st.plus.n < simplex_size) {
-                    const uint32_t pos = rng_uniform_int(r1, st.zero.n);   // uniform_int(0, |zero| - 1)
-                    const uint32_t e = st.zero.at(pos);
-                    const double x = rng_gamma(r1, nd, 1.0, 1.0);
-                    f[e & 1u] = x;
-                    norm += x;
-                    sel[e & 1u] = true;
-                    st.zero.erase(e);
-                    st.plus.insert(e);
-                }
-#pragma unroll
-                for (uint32_t h = 0; h < 2; ++h) {
-                    if (sel[h]) nz[h] = 1;
+                n_first = plus.n;
+                n_steps = plus.n + ((plus.n == 1 && !(u < p_simplex1)) ? 1u : 0u);
+            }
+            // one gamma draw per step: the observed haplotypes in the plus set's iteration order, then unobserved ones drawn from the zero set
+            for (uint32_t i = 0; bt_wave_any(i < n_steps); ++i) {
+                PROF_CNT(20, 1);
+                if (i < n_steps) {
+                    uint32_t e, o = 0;
+                    if (!is_sparse) e = i;
+                    else if (i < n_first) e = order0.at(i);
                     else {
-                        freq[h] = 0;
-                        nz[h] = 0;
-                        obs[h] = 0;
+                        const uint32_t pos = rng_uniform_int(r1, zero.n);   // uniform_int(0, |zero| - 1)
+                        e = zero.at(pos);
+                        zero.erase(e);
+                        plus.insert(e);
                     }
-                }
-                // "for p in plus: freq /= norm; zero.insert(p); obs = 0", then plus.clear()
-                const Set2 order = st.plus;
-                st.plus.clear();
-                for (uint32_t i = 0; i < order.n; ++i) {
-                    const uint32_t e = order.at(i);
-                    const double x = f[e & 1u] / norm;
-                    freq[e] = x;
-                    logf[e] = bt_log(x);
-                    st.zero.insert(e);
-                    obs[e] = 0;
+                    if (i < n_first) o = e ? obs1 : obs0;
+                    const uint32_t ai = o + 1u;
+                    const double alpha = (double)ai, a1 = alpha - 1.0 / 3.0;
+                    const double a2 = ai < a2n ? (double)a2tab[ai] : 1.0 / sqrt(9.0 * a1);
+                    const double v = rng_gamma_v(r1, nd, a1, a2);
+                    const double x = a1 * v * 1.0;
+                    if (e) g1 = x, sel1 = true;
+                    else g0 = x, sel0 = true;
+                    norm += x;
                 }
             }
-            st.fnd_saved = saved;
-            st.fnd_avail = avail;
+            // "for z in zero: freq = 0"; "for p in plus: freq /= norm; zero.insert(p)" then plus.clear()
+            f0 = sel0 ? g0 / norm : 0.0;
+            f1 = sel1 ? g1 / norm : 0.0;
+            nzmask = (sel0 ? 1u : 0u) | (sel1 ? 2u : 0u);
+            if (is_sparse) {
+                const Set2 order = plus;
+                plus.clear();
+                for (uint32_t i = 0; i < 2; ++i)
+                    if (i < order.n) zero.insert(order.at(i));
+            }
+            obs0 = obs1 = 0;
+            fnd_saved = saved;
+            fnd_avail = avail;
         }
-        st.hap_count = 0;
         PROF(7);
     }
     // ---- back to the general representation ----
     mt_close(r0);
     mt_close(r1);
-    if (st.is_sparse) {
-        set2_store(c.zero_set(), st.zero);
-        set2_store(c.plus_set(), st.plus);
+    if (is_sparse) {
+        set2_store(c.zero_set(), zero);
+        set2_store(c.plus_set(), plus);
     }
-    c.fnd_saved() = st.fnd_saved;
-    sc[SC_FND_AVAIL] = st.fnd_avail;
-    sc[SC_HAP_COUNT] = st.hap_count;
+    c.fnd_saved() = fnd_saved;
+    sc[SC_FND_AVAIL] = fnd_avail;
+    sc[SC_HAP_COUNT] = obs0 + obs1;
     sc[SC_USE_MULTI] = 0;
+    {
+        SPtrF<uint32_t, LANES> obs = c.obs();
+        obs[0] = obs0;
+        obs[1] = obs1;
+    }
+    simple_leave(env, blk_off, f0, f1, nzmask);
 }
 
 }  // namespace bt

@@ -1,18 +1,17 @@
 // libbtgpu: gibbs_simple_kernel — the Gibbs schedule for launch classes made of tiles of two-haplotype clusters only (90 % of the
-// clusters of a whole-genome batch) and the three sampling operations.  Its own translation unit: every device function is compiled
-// again here and inlined into the kernel (BT_NOINLINE is empty in this unit), without the general sweep in the way of the register
-// allocator.  Measured on the 600 320-group batch (S = 3): two-haplotype tiles alone 2.27 -> 2.15 s, the mixture 10.2 -> 9.85 s.  A smaller
-// register budget, which would let these wavefronts sit beside the general kernel's instead of queueing for the same two slots per
-// SIMD, does not pay: at 168 / 128 registers (GIBBS_SIMPLE_WAVES 3 / 4) the sweep spills and the same tiles take 2.9 / 3.8 s.
+// clusters of a whole-genome batch) and the three sampling operations.  Its own translation unit: the sweep (bt_gibbs_simple.hpp) is the
+// kernel body, compiled for GIBBS_SIMPLE_WAVES wavefronts per SIMD; what runs once per chain (chain start, entry / exit of the sweep loop,
+// the drain of the collected runs) and the rare exact paths are out-of-line functions with their own register allocation.
 #define BT_SIMPLE_TU 1
+#define BT_RING_REFILL4 1
 #include "bt_gibbs_kernel.hpp"
 
 namespace {
 using namespace bt;
 #ifndef GIBBS_SIMPLE_WAVES
-#define GIBBS_SIMPLE_WAVES 2
+#define GIBBS_SIMPLE_WAVES 3
 #endif
-__global__ __attribute__((flatten)) __launch_bounds__(LANES, GIBBS_SIMPLE_WAVES) void gibbs_simple_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg,
+__global__ __launch_bounds__(LANES, GIBBS_SIMPLE_WAVES) void gibbs_simple_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg,
                                                                                   int op, uint32_t arg0, uint32_t arg1, unsigned long long *__restrict__ hist, TraceCfg tr,
                                                                                   const uint32_t *__restrict__ tile_list) {
     gibbs_body<true>(tiles, pool, Pg, op, arg0, arg1, hist, tr, tile_list);

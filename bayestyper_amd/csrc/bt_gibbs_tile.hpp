@@ -158,6 +158,7 @@ struct TileDesc {
     uint32_t logged;                // single clusters without multicluster k-mers: collected sweeps are logged as runs and applied at the end of the chain
     uint32_t wsh;                   // log2 of the tile's width W (power of two >= num_lanes): every array of the tile is interleaved over W lanes, in HBM and in LDS
     uint32_t teams;                 // sample_diplotypes: the copies form this many teams that draw as many samples at a time (1: none); A_CUM holds one block per team
+    uint32_t sblk;                  // tiles of two-haplotype clusters: LDS byte offset of the per-sample words of simple_sweeps() (bt_gibbs_simple.hpp), after the rings
 };
 #ifndef BT_EV_CAP
 #define BT_EV_CAP 32
@@ -175,7 +176,8 @@ struct GParams {
     const double BT_GAS *lut_g;        // [S][256][256]
     const double BT_GAS *lut_n;        // [S][256]
     const double BT_GAS *lgamma_int;   // lgamma(n) for integer n in [0, lgamma_n): computed on the host (libm), gathered on the device
-    uint32_t lgamma_n, pad;
+    const double BT_GAS *gamma_a2;     // 1 / sqrt(9 (n - 1/3)) for integer n in [1, gamma_n): Marsaglia-Tsang's a2 for alpha = an observation count + 1
+    uint32_t lgamma_n, gamma_n;
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t bt_lds_raw[];

@@ -32,11 +32,7 @@ namespace bt {
 #else
 #define BT_SWEEPFN static __noinline__
 #endif
-#ifdef BT_SIMPLE_TU
-#define BT_NOINLINE
-#else
 #define BT_NOINLINE static __noinline__   // (internal linkage: the code generator then drops the callee-saved register convention for them)
-#endif
 
 // fp64 transcendental functions.  On the device they are out-of-line: ocml's double-precision log/exp/log1p/pow need many
 // registers; keeping them as separate functions keeps the samplers' own allocation small enough for 2-4 waves per SIMD.
@@ -189,6 +185,13 @@ BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
 // whole wavefront at fixed points (mt_ring_topup at the start of a cluster visit), so the lanes of a wavefront refill together.
 // Ring block of one generator: [cap] tempered words, then {position of the next state word to generate, ring head, words available}.
 constexpr unsigned MT_RING_HDR = 3;
+BT_HD bool bt_wave_any(bool p) {   // true in every lane of the wavefront when p holds in any of them
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#else
+    return p;
+#endif
+}
 template <class RP>   // RP: pointer-like (operator[](uint32_t) -> uint32_t&) to the ring block
 struct MtRingT {
     uint32_t BT_GAS *st;
@@ -222,9 +225,36 @@ struct MtRingT {
         }
     }
     BT_HD void generate(uint32_t n) { generate_t<false>(n); }
+    // the same in bursts of four, the wavefront looping while any of its lanes still wants words (a burst of sixteen costs its sixteen slots whatever
+    // the lanes need; a visit of a two-haplotype cluster draws six + about ten words): bt_gibbs_simple.hpp
+    BT_HD void generate4(uint32_t n) {
+        while (bt_wave_any(n > 0)) {
+            const uint32_t c = n < 4u ? n : 4u, p = pos;
+            uint32_t a[5], b[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 5; ++k) a[k] = st[mt_wrap(p + k)];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) b[k] = st[mt_wrap(mt_wrap(p + k) + MT_M)];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < c) {
+                    const uint32_t z = mt_twist(a[k], a[k + 1], b[k]);
+                    st[mt_wrap(p + k)] = z;
+                    ring[(head + avail + k) & (cap - 1u)] = mt_temper(z);
+                }
+            pos = mt_wrap(p + c);
+            avail += c;
+            n -= c;
+        }
+    }
+    BT_HD void topup4() { generate4(cap - avail); }
     BT_HD void topup() { generate(cap - avail); }
     BT_HD void need(uint32_t n) {
+#ifdef BT_RING_REFILL4   // (the unit of gibbs_simple_kernel: a refill in the middle of a visit is rare there, and sixteen unrolled slots at every draw site are not)
+        if (avail < n) generate4(cap - avail < 16u ? cap - avail : 16u);
+#else
         if (avail < n) generate(cap - avail < 16u ? cap - avail : 16u);
+#endif
     }
     BT_HD uint32_t next() {
         need(1);
@@ -389,11 +419,35 @@ BT_HD double rng_normal(G &st, NormalState nd) {
     return ret;
 }
 
+// single-precision natural logarithm for the screening test below (one hardware instruction on the device)
+BT_HD float bt_fast_logf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __logf(x);
+#else
+    return logf(x);
+#endif
+}
+// Marsaglia-Tsang's second acceptance test, log(u) > 0.5 n^2 + a1 (1 - v + log v), decides nothing but a branch.  It is screened in single
+// precision with an error bound: only when the two sides are closer than the bound (about once in 10^4 evaluations) are the two double-precision
+// logarithms evaluated.  The decision — and with it the draw stream — is the double-precision one in every case: a wavefront evaluates this
+// test in nearly every iteration (some lane fails the cheap first test), so the two out-of-line logarithms were a fifth of a gamma draw.
+// returns true when the candidate is REJECTED by the second test
+BT_HD bool gamma_second_test_rejects(double u, double n, double v, double a1) {
+    const float lu = bt_fast_logf((float)u), lv = bt_fast_logf((float)v);
+    const double diff = (double)lu - (0.5 * n * n + a1 * (1.0 - v + (double)lv));
+    // error of the screen: the rounding of u and v to single precision (relative 6e-8 -> 6e-8 absolute in the logarithm) plus the logarithm's own
+    // (a few units in the last place; near 1 an absolute 1e-6 at most).  Bound taken 8x wider; comparisons are false on NaN / infinities -> exact path.
+    const double err = 4e-5 * ((1.0 + fabs((double)lu)) + a1 * (1.0 + fabs((double)lv)));
+    if (diff > err) return true;
+    if (diff < -err) return false;
+    return bt_log(u) > (0.5 * n * n + a1 * (1.0 - v + bt_log(v)));
+}
+
+// gamma_distribution(alpha, beta) for alpha >= 1 with a2 = 1 / sqrt(9 (alpha - 1/3)) handed in (callers whose alpha is a small integer — an
+// observation count + 1 — read it from a table built with the same two IEEE operations: bt_gibbs.hip, GParams::gamma_a2)
+// the accepted v of Marsaglia-Tsang's loop for a1 = alpha - 1/3 (alpha >= 1), a2 = 1 / sqrt(9 a1)
 template <class G>
-BT_HD double rng_gamma(G &st, NormalState nd, double alpha, double beta) {
-    const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
-    const double a1 = malpha - 1.0 / 3.0;
-    const double a2 = 1.0 / sqrt(9.0 * a1);
+BT_HD double rng_gamma_v(G &st, NormalState nd, double a1, double a2) {
     double u, v, n;
     do {
         do {
@@ -402,8 +456,26 @@ BT_HD double rng_gamma(G &st, NormalState nd, double alpha, double beta) {
         } while (v <= 0.0);
         v = v * v * v;
         u = rng_canonical(st);
-    } while (u > 1.0 - 0.0331 * n * n * n * n && (bt_log(u) > (0.5 * n * n + a1 * (1.0 - v + bt_log(v)))));
+    } while (u > 1.0 - 0.0331 * n * n * n * n && gamma_second_test_rejects(u, n, v, a1));
+    return v;
+}
+// gamma_distribution(alpha, beta) for alpha >= 1 with a2 = 1 / sqrt(9 (alpha - 1/3)) handed in (callers whose alpha is a small integer — an
+// observation count + 1 — read it from a table built with the same two IEEE operations: bt_gibbs.hip, GParams::gamma_a2)
+template <class G>
+BT_HD double rng_gamma_ge1(G &st, NormalState nd, double alpha, double a2, double beta) {
+    const double a1 = alpha - 1.0 / 3.0;
+    const double v = rng_gamma_v(st, nd, a1, a2);
+    return a1 * v * beta;
+}
+
+template <class G>
+BT_HD double rng_gamma(G &st, NormalState nd, double alpha, double beta) {
+    const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
+    const double a1 = malpha - 1.0 / 3.0;
+    const double a2 = 1.0 / sqrt(9.0 * a1);
+    const double v = rng_gamma_v(st, nd, a1, a2);
     if (alpha == malpha) return a1 * v * beta;
+    double u;
     do u = rng_canonical(st);
     while (u == 0.0);
     return bt_pow(u, 1.0 / alpha) * a1 * v * beta;

@@ -1,5 +1,7 @@
 #include "Comm.hpp"
 
+#include <dirent.h>
+#include <iterator>
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -74,18 +76,42 @@ std::unique_ptr<Comm> Comm::fromEnvironment(bt_ctx *ctx) {
     c->ctx = ctx;
     c->rank_ = rank;
     c->world_ = world;
+    c->id_file_ = id_file;
+    // A run's rendezvous carries the run's nonce (BT_COMM_NONCE, the same on every rank: the starting process sets it; an external launcher should): what a
+    // previous run left under the same path — the old communicator id, a "failed" marker — is then never taken for this run's.  Without a nonce rank 0 still
+    // removes the leftovers before it publishes, which covers every order of events except a rank > 0 reading the stale id before rank 0 got that far.
+    const std::string nonce = getenv("BT_COMM_NONCE") ? getenv("BT_COMM_NONCE") : "";
+    if (rank == 0) {
+        std::remove(id_file);
+        std::remove((std::string(id_file) + ".failed").c_str());
+    }
     const char *transport = getenv("BT_COMM_TRANSPORT");
     if (transport && std::strcmp(transport, "files") == 0) {   // tests: ranks sharing one GPU
         c->dir = std::string(id_file) + ".d";
         if (rank == 0) {
             if (mkdir(c->dir.c_str(), 0777) != 0 && errno != EEXIST) throw std::runtime_error("cannot create " + c->dir);
-            std::ofstream f(id_file);   // the other ranks wait for this file like for the communicator id
-            f << "files\n";
+            // (leftovers of an earlier run under this path: its exchange files would be taken for this run's)
+            if (DIR *dh = opendir(c->dir.c_str())) {
+                while (dirent *e = readdir(dh))
+                    if (e->d_name[0] != '.') std::remove((c->dir + "/" + e->d_name).c_str());
+                closedir(dh);
+            }
+            const std::string tmp = std::string(id_file) + ".tmp";
+            {
+                std::ofstream f(tmp);   // the other ranks wait for this file like for the communicator id
+                f << "files " << nonce << "\n";
+            }
+            if (std::rename(tmp.c_str(), id_file) != 0) throw std::runtime_error(std::string("cannot write ") + id_file);
         } else {
             bool got = false;
             for (int tries = 0; tries < 6000 && !got; ++tries) {
-                if (access(id_file, R_OK) == 0) got = true;
-                else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                std::ifstream f(id_file);
+                std::string word, n;
+                if (f && (f >> word) && word == "files") {
+                    f >> n;
+                    got = n == nonce;
+                }
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
             }
             if (!got) throw std::runtime_error(std::string("rank ") + std::to_string(rank) + ": " + id_file + " did not appear");
         }
@@ -114,6 +140,7 @@ std::unique_ptr<Comm> Comm::fromEnvironment(bt_ctx *ctx) {
         {
             std::ofstream f(tmp, std::ios::binary);
             f.write((const char *)id, BT_COMM_ID_BYTES);
+            f.write(nonce.data(), (std::streamsize)nonce.size());
             if (!f) throw std::runtime_error("cannot write " + tmp);
         }
         if (std::rename(tmp.c_str(), id_file) != 0) throw std::runtime_error(std::string("cannot write ") + id_file);   // (appears atomically)
@@ -121,8 +148,11 @@ std::unique_ptr<Comm> Comm::fromEnvironment(bt_ctx *ctx) {
         bool got = false;
         for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to ten minutes: rank 0 may still be reading its inputs
             std::ifstream f(id_file, std::ios::binary);
-            if (f && f.read((char *)id, BT_COMM_ID_BYTES)) got = true;
-            else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            if (f && f.read((char *)id, BT_COMM_ID_BYTES)) {
+                const std::string rest((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+                got = rest == nonce;   // (another run's id: keep waiting for this run's)
+            }
+            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
         if (!got) throw std::runtime_error(std::string("rank ") + std::to_string(rank) + ": no communicator id in " + id_file);
     }
@@ -135,6 +165,9 @@ Comm::Comm() {}
 Comm::~Comm() {
     if (comm && api) api->destroy(comm);
     if (dl) dlclose(dl);
+    // the run is over: rank 0 takes its rendezvous file away (a launcher of one's own does not have to); with RCCL every rank has joined the communicator by
+    // now, with the files transport the directory protocol below waits for all ranks first
+    if (rank_ == 0 && !id_file_.empty() && dir.empty()) std::remove(id_file_.c_str());
     if (!dir.empty()) {
         // A rank's file of the LAST exchange may still be unread by a slower rank, so nobody removes its own: every rank leaves a "done"
         // marker when it is through, and rank 0 clears the directory once all markers are there (or after a while, if a rank died).
@@ -151,6 +184,7 @@ Comm::~Comm() {
                 for (uint64_t s = seq > 2 ? seq - 2 : 0; s <= seq; s++) std::remove((dir + "/" + std::to_string(s) + "." + std::to_string(r)).c_str());
             }
             rmdir(dir.c_str());
+            if (!id_file_.empty()) std::remove(id_file_.c_str());
         }
     }
 }

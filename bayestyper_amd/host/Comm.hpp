@@ -57,6 +57,7 @@ class Comm {
     bt_comm *comm = nullptr;
     void *dl = nullptr;
     int rank_ = 0, world_ = 1;
+    std::string id_file_;   // BT_COMM_ID_FILE: removed by rank 0 when the run is over
     struct Api;
     std::unique_ptr<Api> api;
     // files transport

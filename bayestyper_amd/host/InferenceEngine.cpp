@@ -80,7 +80,11 @@ struct GpuSampler : GibbsSampler {
     }
     bt_noise_model *noise_model = nullptr;
     bool noiseChain(CountDistribution *cd, uint32_t n_iterations, uint32_t first_collect, const DeviceReducer &reduce, std::vector<double> *rows) override {
-        if (getenv("BT_NOISE_ON_HOST")) return false;   // (the per-iteration host loop: draws by libstdc++ itself)
+        // Default: the per-iteration host loop (bt_gibbs_noise_iteration: one synchronisation per iteration) — the rates are drawn by libstdc++'s own
+        // gamma distribution and the Poisson table is built by glibc, bit for bit the reference's, whatever the number of ranks and the transport.
+        // BT_NOISE_ON_DEVICE=1 runs a whole chain on the device instead (ocml log / pow / lgamma: last-bit differences in the rates, which a rejection
+        // test of a later draw can amplify; every rank of a run must then take this path).
+        if (!getenv("BT_NOISE_ON_DEVICE")) return false;
         if (!noise_model) {
             std::vector<float> prior;
             for (auto &p : cd->noiseRatePriors()) {

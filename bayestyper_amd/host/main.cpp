@@ -19,6 +19,7 @@
 // byte for byte the files of a one-GPU run.
 #include <sys/stat.h>
 #include <signal.h>
+#include <fcntl.h>
 #include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -507,6 +508,8 @@ std::vector<pid_t> startRanks(int argc, char *const argv[]) {
     std::remove(id_file.c_str());
     setenv("BT_WORLD", std::to_string(n).c_str(), 1);
     setenv("BT_COMM_ID_FILE", id_file.c_str(), 1);
+    // the run's nonce: every rank only accepts a rendezvous file that carries it (host/Comm.cpp)
+    setenv("BT_COMM_NONCE", (std::to_string((long)getpid()) + "." + std::to_string((long long)std::chrono::steady_clock::now().time_since_epoch().count())).c_str(), 1);
     for (int r = 1; r < n; r++) {
         const pid_t pid = fork();
         if (pid < 0) throw std::runtime_error("cannot start rank " + std::to_string(r));
@@ -514,7 +517,10 @@ std::vector<pid_t> startRanks(int argc, char *const argv[]) {
             prctl(PR_SET_PDEATHSIG, SIGTERM);   // (a rank does not outlive the process that started it)
             setenv("BT_RANK", std::to_string(r).c_str(), 1);
             const std::string log = prefix + ".rank" + std::to_string(r) + ".log";
-            if (!freopen(log.c_str(), "w", stdout) || !freopen(log.c_str(), "a", stderr)) _exit(1);
+            // ONE open file description for both streams (O_APPEND): two independent ones would overwrite each other's output
+            const int fd = open(log.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_APPEND, 0644);
+            if (fd < 0 || dup2(fd, 1) < 0 || dup2(fd, 2) < 0) _exit(1);
+            if (fd > 2) close(fd);
             execv("/proc/self/exe", argv);
             _exit(127);
         }
@@ -546,11 +552,16 @@ int main(int argc, char *const argv[]) {
             if (!children.empty())   // a rank that dies would leave the others waiting in a collective: end the run instead
                 watchdog = std::thread([&]() {
                     while (!finished.load()) {
-                        for (pid_t pid : children) {
+                        for (pid_t &pid : children) {
+                            if (pid <= 0) continue;   // reaped: its pid may belong to somebody else by now
                             int status = 0;
-                            if (waitpid(pid, &status, WNOHANG) == pid && !(WIFEXITED(status) && WEXITSTATUS(status) == 0)) {
+                            const pid_t got = waitpid(pid, &status, WNOHANG);
+                            if (got != pid) continue;
+                            pid = 0;
+                            if (!(WIFEXITED(status) && WEXITSTATUS(status) == 0)) {
                                 std::cerr << "\nERROR: a rank of this run failed (see <output-prefix>.rank<r>.log)\n" << std::endl;
-                                for (pid_t other : children) kill(other, SIGTERM);
+                                for (pid_t other : children)
+                                    if (other > 0) kill(other, SIGTERM);
                                 if (getenv("BT_COMM_ID_FILE")) std::remove(getenv("BT_COMM_ID_FILE"));
                                 _exit(1);
                             }
@@ -570,7 +581,8 @@ int main(int argc, char *const argv[]) {
     }
     finished.store(true);
     if (watchdog.joinable()) watchdog.join();
-    for (pid_t pid : children) {   // the ranks this process started (those the watchdog has reaped already return -1 here: they ended well)
+    for (pid_t pid : children) {   // the ranks this process started (those the watchdog has reaped ended well)
+        if (pid <= 0) continue;
         int status = 0;
         if (rc != 0) kill(pid, SIGTERM);   // rank 0 failed: the others would wait for it forever
         if (waitpid(pid, &status, 0) == pid && !(WIFEXITED(status) && WEXITSTATUS(status) == 0)) {
