@@ -1004,8 +1004,9 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         len[A_SHMULT] = (uint64_t)std::max<uint32_t>(d.NSHm, 1) * S;
         // draw-ahead rings (MtRing): the diplotype generator consumes exactly two words per sample and visit, the frequency generator
         // a few words per non-zero haplotype; both are topped up at the start of a visit
+        // (production is in chunks of four words: a ring of `cap` words can be filled up to cap - 3 ahead)
         d.ring_cap[0] = 8;
-        while (d.ring_cap[0] < 2 * S && d.ring_cap[0] < 32) d.ring_cap[0] *= 2;
+        while (d.ring_cap[0] < 2 * S + 3 && d.ring_cap[0] < 64) d.ring_cap[0] *= 2;
         d.ring_cap[1] = 16;
         if (const char *e = getenv("BT_GIBBS_RING0")) d.ring_cap[0] = (uint32_t)atoi(e);
         if (const char *e = getenv("BT_GIBBS_RING1")) d.ring_cap[1] = (uint32_t)atoi(e);

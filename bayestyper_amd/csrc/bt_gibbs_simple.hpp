@@ -15,7 +15,7 @@
 //    observation total of a cluster is the same in every sweep);
 //  * gamma draws read 1 / sqrt(9 (alpha - 1/3)) from a table (alpha = an observation count + 1) and screen Marsaglia-Tsang's second test in
 //    single precision (bt_rng_device.hpp);
-//  * generator refills in bursts of four (MtRingT::generate4).
+//  * generator refills in aligned chunks of four words, four memory requests per lane and chunk (MtRingT::chunk).
 // LDS per cluster: the two draw-ahead rings + 12 bytes per sample (round 3: 430 bytes at three samples), so that a CU holds twelve and more
 // of these wavefronts instead of six.
 //
@@ -313,9 +313,9 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
         }
         PROF_DECL;
         {   // the visit's words: exactly two per sample from the diplotype generator, the frequency generator's ring full
-            const uint32_t want = 2u * S < r0.cap ? 2u * S : r0.cap;   // (more than 16 samples: the draws top up on the way)
-            r0.generate4(r0.avail < want ? want - r0.avail : 0u);
-            r1.topup4();
+            const uint32_t want = 2u * S < r0.cap - 3u ? 2u * S : r0.cap - 3u;   // (more samples than the ring holds words for: the draws top up on the way)
+            r0.fill_to(want);
+            r1.topup();
         }
         PROF(11);
         // ---- sampleDiplotypes ----

@@ -3,7 +3,6 @@
 // kernel body, compiled for GIBBS_SIMPLE_WAVES wavefronts per SIMD; what runs once per chain (chain start, entry / exit of the sweep loop,
 // the drain of the collected runs) and the rare exact paths are out-of-line functions with their own register allocation.
 #define BT_SIMPLE_TU 1
-#define BT_RING_REFILL4 1
 #include "bt_gibbs_kernel.hpp"
 
 namespace {

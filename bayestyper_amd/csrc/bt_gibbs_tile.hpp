@@ -2020,6 +2020,16 @@ __device__ inline uint32_t simplex_prob_vector(const Vx &c, const GParams BT_CAS
     return n;
 }
 
+// gamma_distribution(count + 1, 1): Marsaglia-Tsang with a2 = 1 / sqrt(9 (alpha - 1/3)) read from the host's table for the small integers alpha takes
+// (the same two IEEE operations; GParams::gamma_a2) instead of a square root and a division per draw
+template <class G>
+__device__ inline double rng_gamma_count(G &rng, NormalState nd, const GParams BT_CAS &P, uint32_t count) {
+    const uint32_t ai = count + 1u;
+    const double a1 = (double)ai - 1.0 / 3.0;
+    const double a2 = ai < P.gamma_n ? (double)P.gamma_a2[ai] : 1.0 / sqrt(9.0 * a1);
+    return a1 * rng_gamma_v(rng, nd, a1, a2) * 1.0;
+}
+
 // ---- sampleHaplotypeFrequencies (VariantClusterGenotyper.cpp:781-785 -> HaplotypeFrequencyDistribution.cpp:127-138
 //      -> FrequencyDistribution.cpp:75-93 / 209-303) ----
 __device__ BT_SWEEPFN void sample_haplotype_frequencies(Env env, uint32_t vtx) {
@@ -2038,7 +2048,7 @@ __device__ BT_SWEEPFN void sample_haplotype_frequencies(Env env, uint32_t vtx) {
         if (!sc[SC_IS_SPARSE]) {
             double norm = 0;
             for (uint32_t h = 0; h < c.H; ++h) {
-                const double f = rng_gamma(rng, nd, (double)(obs[h] + 1u), 1.0);
+                const double f = rng_gamma_count(rng, nd, P, obs[h]);
                 freq[h] = f;
                 norm += f;
                 obs[h] = 0;
@@ -2085,7 +2095,7 @@ __device__ BT_SWEEPFN void sample_haplotype_frequencies(Env env, uint32_t vtx) {
             const uint32_t simplex_size = ub + plus_size;
             double norm = 0;
             for (uint32_t e = uset_begin(plus); e != US_NONE; e = unext[e]) {
-                const double f = rng_gamma(rng, nd, (double)obs[e] + 1.0, 1.0);
+                const double f = rng_gamma_count(rng, nd, P, obs[e]);
                 freq[e] = f;
                 norm += f;
                 nz[e] = 2;   // selected in this call (turned into 1 below)
@@ -2095,7 +2105,7 @@ __device__ BT_SWEEPFN void sample_haplotype_frequencies(Env env, uint32_t vtx) {
                 const uint32_t pos = rng_uniform_int(rng, uset_size(zero));   // uniform_int(0, |zero| - 1)
                 uint32_t e = uset_begin(zero);
                 for (uint32_t i = 0; i < pos; ++i) e = unext[e];
-                const double f = rng_gamma(rng, nd, 1.0, 1.0);
+                const double f = rng_gamma_count(rng, nd, P, 0u);
                 freq[e] = f;
                 norm += f;
                 nz[e] = 2;

@@ -179,12 +179,21 @@ struct Mt {
 BT_HD Mt mt_open(uint32_t *st) { return Mt{(uint32_t BT_GAS *)st, ((uint32_t BT_GAS *)st)[MT_N]}; }
 BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
 
-// DRAW-AHEAD form (the Gibbs kernels): the same stream, but the generator's output is produced in bursts of up to 16 words — all the
-// state loads of a burst are independent, so a burst is ONE memory round trip — into a small ring that lives in LDS, and the sampler's
-// draws read the ring.  A draw then costs an LDS access instead of a dependent HBM round trip per call; bursts are issued for the
-// whole wavefront at fixed points (mt_ring_topup at the start of a cluster visit), so the lanes of a wavefront refill together.
+// DRAW-AHEAD form (the Gibbs kernels): the same stream, but the generator's output is produced in bursts ahead of its use into a small ring that
+// lives in LDS, and the sampler's draws read the ring.  A draw then costs an LDS access instead of a dependent HBM round trip per call; bursts are
+// issued for the whole wavefront at fixed points (topup at the start of a cluster visit), so the lanes of a wavefront refill together.
 // Ring block of one generator: [cap] tempered words, then {position of the next state word to generate, ring head, words available}.
+//
+// Round 4: production in ALIGNED CHUNKS OF FOUR WORDS.  The lanes of a wavefront are at different positions of their own (per-lane contiguous) states,
+// so every state access is 64 separate requests whatever it fetches — the memory pipeline takes them one lane per cycle, and at three single-word
+// loads and one store per generated word the generators alone kept a CU's address unit busy for most of a sweep (profiles/r04: 283 memory
+// instructions per wavefront-sweep of two-haplotype clusters).  A chunk [p, p + 4), p a multiple of four (624 = 4 * 156: a chunk never wraps), is
+// one 16-byte load of the four words, one word x[p + 4], one unaligned 16-byte load of x[p + 397 .. p + 400] and one 16-byte store: four
+// requests per lane for four words.  Two of those reach past the end of the state — x[p + 4] at p = 620 and x[p + 397 ...] at p = 224 .. 226 — and
+// read a MIRROR of words 0 .. 3 kept at [624, 628), rewritten with them (chunk 0).  None of a chunk's new words is an input of another (the recurrence
+// reaches 1 and 397 positions ahead), so loading everything first gives the textbook stream.
 constexpr unsigned MT_RING_HDR = 3;
+constexpr unsigned MT_MIRROR = 4;   // words 0 .. 3 again at [MT_N, MT_N + 4)
 BT_HD bool bt_wave_any(bool p) {   // true in every lane of the wavefront when p holds in any of them
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ballot_w64(p) != 0;
@@ -192,69 +201,44 @@ BT_HD bool bt_wave_any(bool p) {   // true in every lane of the wavefront when p
     return p;
 #endif
 }
+typedef uint32_t MtQuad __attribute__((ext_vector_type(4)));    // four consecutive state words at a 16-byte aligned address (a chunk)
+typedef MtQuad MtQuadU __attribute__((aligned(4)));             // ... at a 4-byte aligned address (x[p + 397 ...])
 template <class RP>   // RP: pointer-like (operator[](uint32_t) -> uint32_t&) to the ring block
 struct MtRingT {
     uint32_t BT_GAS *st;
     RP ring;                   // element i of the ring block at ring[i] (LDS when the cluster's hot arrays are resident, else HBM)
-    uint32_t cap;              // power of two, <= 64
-    uint32_t pos, head, avail;
-    // generate n more words (n <= cap - avail), bursts of 16.  UNIFORM: the caller has checked that n is the same in every lane of the
-    // wavefront; it is then held in a scalar register, and the slots a burst does not need are skipped by scalar branches
-    template <bool UNIFORM>
-    BT_HD void generate_t(uint32_t n) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (UNIFORM) n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
-#endif
-        while (n > 0) {
-            const uint32_t c = n < 16u ? n : 16u, p = pos;
-            uint32_t a[17], b[16];
-#pragma unroll
-            for (uint32_t k = 0; k < 17; ++k) a[k] = k <= c ? st[mt_wrap(p + k)] : 0u;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k) b[k] = k < c ? st[mt_wrap(mt_wrap(p + k) + MT_M)] : 0u;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; ++k)
-                if (k < c) {
-                    const uint32_t z = mt_twist(a[k], a[k + 1], b[k]);
-                    st[mt_wrap(p + k)] = z;
-                    ring[(head + avail + k) & (cap - 1u)] = mt_temper(z);
-                }
-            pos = mt_wrap(p + c);
-            avail += c;
-            n -= c;
+    uint32_t cap;              // power of two, 8 .. 64
+    uint32_t pos, head, avail; // pos: multiple of four
+    // one chunk for the lanes with `go` set
+    BT_HD void chunk(bool go) {
+        if (go) {   // (only the lanes that produce send their four requests)
+            const uint32_t p = pos, q = p + MT_M < MT_N ? p + MT_M : p + MT_M - MT_N;
+            const MtQuad a = *(const MtQuad BT_GAS *)(st + p);
+            const uint32_t a4 = st[p + 4u];
+            const MtQuad b = *(const MtQuadU BT_GAS *)(st + q);
+            MtQuad z;
+            z.x = mt_twist(a.x, a.y, b.x);
+            z.y = mt_twist(a.y, a.z, b.y);
+            z.z = mt_twist(a.z, a.w, b.z);
+            z.w = mt_twist(a.w, a4, b.w);
+            *(MtQuad BT_GAS *)(st + p) = z;
+            if (p == 0) *(MtQuad BT_GAS *)(st + MT_N) = z;
+            const uint32_t w = (head + avail) & (cap - 1u);   // a multiple of four: as many words were produced before
+            ring[w] = mt_temper(z.x);
+            ring[w + 1u] = mt_temper(z.y);
+            ring[w + 2u] = mt_temper(z.z);
+            ring[w + 3u] = mt_temper(z.w);
+            pos = p + 4u == MT_N ? 0u : p + 4u;
+            avail += 4u;
         }
     }
-    BT_HD void generate(uint32_t n) { generate_t<false>(n); }
-    // the same in bursts of four, the wavefront looping while any of its lanes still wants words (a burst of sixteen costs its sixteen slots whatever
-    // the lanes need; a visit of a two-haplotype cluster draws six + about ten words): bt_gibbs_simple.hpp
-    BT_HD void generate4(uint32_t n) {
-        while (bt_wave_any(n > 0)) {
-            const uint32_t c = n < 4u ? n : 4u, p = pos;
-            uint32_t a[5], b[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 5; ++k) a[k] = st[mt_wrap(p + k)];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) b[k] = st[mt_wrap(mt_wrap(p + k) + MT_M)];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                if (k < c) {
-                    const uint32_t z = mt_twist(a[k], a[k + 1], b[k]);
-                    st[mt_wrap(p + k)] = z;
-                    ring[(head + avail + k) & (cap - 1u)] = mt_temper(z);
-                }
-            pos = mt_wrap(p + c);
-            avail += c;
-            n -= c;
-        }
+    // chunks until every lane holds at least `want` words (want <= cap - 3), the wavefront looping while any of its lanes is short
+    BT_HD void fill_to(uint32_t want) {
+        while (bt_wave_any(avail < want)) chunk(avail < want);
     }
-    BT_HD void topup4() { generate4(cap - avail); }
-    BT_HD void topup() { generate(cap - avail); }
-    BT_HD void need(uint32_t n) {
-#ifdef BT_RING_REFILL4   // (the unit of gibbs_simple_kernel: a refill in the middle of a visit is rare there, and sixteen unrolled slots at every draw site are not)
-        if (avail < n) generate4(cap - avail < 16u ? cap - avail : 16u);
-#else
-        if (avail < n) generate(cap - avail < 16u ? cap - avail : 16u);
-#endif
+    BT_HD void topup() { fill_to(cap - 3u); }
+    BT_HD void need(uint32_t n) {   // n <= 4
+        if (avail < n) fill_to(cap - 3u < 16u ? cap - 3u : 16u);
     }
     BT_HD uint32_t next() {
         need(1);
@@ -304,6 +288,7 @@ BT_HD void mt_close(const MtRingT<RP> &m) {
 template <class RP>
 BT_HD void mt_ring_seed(uint32_t *st, RP ring, uint32_t cap, uint32_t seed) {
     mt_seed(st, seed);
+    for (unsigned i = 0; i < MT_MIRROR; ++i) st[MT_N + i] = st[i];   // (a ring generator keeps its position in the ring block, not at st[MT_N])
     ring[cap] = 0;
     ring[cap + 1] = 0;
     ring[cap + 2] = 0;
