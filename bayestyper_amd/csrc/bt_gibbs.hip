@@ -34,6 +34,7 @@ hipError_t launch_gibbs_hot_kernel(unsigned grid, unsigned block, uint32_t lds, 
 hipError_t prepare_gibbs_hot_kernel(int max_lds);
 #ifdef BT_PROF
 hipError_t simple_prof_read(unsigned long long *h_out32, int reset);
+hipError_t hot_prof_read(unsigned long long *h_out32, int reset);
 #endif
 }  // namespace bt
 
@@ -79,6 +80,101 @@ __global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict
         }
         out[((size_t)c * S + s) * 2] = best_key;
         out[((size_t)c * S + s) * 2 + 1] = best;
+    }
+}
+
+// ---- the collected samples of a launch in the flat layout bt_gibbs_result_fetch hands out, built ON THE DEVICE ----------------------------------
+// (round 3 copied three arrays of every tile to the host, one synchronous copy each, and rebuilt the layout cluster by cluster on one host thread)
+__device__ inline Vx result_vx(const TileDesc *tiles, uint8_t *pool, const ClusterLoc &L) {
+    Tile t;
+    t.d = (const TileDesc BT_CAS *)&tiles[L.tile];
+    t.base = (uint8_t BT_GAS *)(pool + t.d->base);
+    t.lane = t.plane = L.lane;   // (no LDS here; pool_lane0 is 0 since the tiles have rows of their own width)
+    t.plane += t.d->pool_lane0;
+    t.wsh = t.d->wsh;
+    t.part = 0;
+    t.copies = 1;
+    t.hot = nullptr;
+    t.resident = 0xFFFFFFFFu;
+    return make_vx(t, L.v);
+}
+// entries of every cluster's diplotype table (VariantClusterGenotyper: diplotype_sampling_frequencies), overflow flag
+__global__ __launch_bounds__(256) void result_count_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const ClusterLoc *__restrict__ loc, uint32_t num_clusters,
+                                                           uint32_t *__restrict__ n_ent, uint32_t *__restrict__ overflow) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= num_clusters) return;
+    const Vx x = result_vx(tiles, pool, loc[c]);
+    SPtrF<uint32_t, LANES> sc = x.sc();
+    n_ent[c] = sc[SC_DIP_ENTRIES];
+    if (sc[SC_DIP_OVERFLOW]) atomicOr(overflow, 1u);
+}
+// one wavefront per cluster: the cluster's diplotype entries ordered by (h1, h2) with their per-sample counts, its allele k-mer statistics
+constexpr uint32_t kPackLds = 2048;   // entries ranked from LDS; larger tables are ranked from the table itself
+__global__ __launch_bounds__(64) void result_pack_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const ClusterLoc *__restrict__ loc, uint32_t S,
+                                                         const uint64_t *__restrict__ dip_off, const uint64_t *__restrict__ cell_off, const uint32_t *__restrict__ alleles,
+                                                         uint16_t *__restrict__ out_h1, uint16_t *__restrict__ out_h2, uint32_t *__restrict__ out_freq, double *__restrict__ out_stats) {
+    __shared__ uint32_t l_key[kPackLds], l_slot[kPackLds];
+    __shared__ uint32_t l_n;
+    const uint32_t c = blockIdx.x;
+    const Vx x = result_vx(tiles, pool, loc[c]);
+    TPtr<uint32_t> keys = x.dip_keys(), freq = x.dip_freq();
+    const uint32_t cap = x.d().dip_cap;
+    const uint64_t e0 = dip_off[c];
+    const uint32_t n = (uint32_t)(dip_off[c + 1] - e0);
+    auto order_key = [](uint32_t tag) {   // (h1, h2) lexicographic: h1 in the upper half
+        const uint32_t key = tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u;
+        return (key << 16) | (key >> 16);
+    };
+    if (out_h1 || out_h2 || out_freq) {
+        if (n <= kPackLds) {
+            if (threadIdx.x == 0) l_n = 0;
+            __syncthreads();
+            for (uint32_t slot = threadIdx.x; slot < cap; slot += 64u) {
+                const uint32_t tag = keys[slot];
+                if (!tag) continue;
+                const uint32_t i = atomicAdd(&l_n, 1u);
+                if (i < kPackLds) {
+                    l_key[i] = order_key(tag);
+                    l_slot[i] = slot;
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += 64u) {
+                const uint32_t kk = l_key[i], slot = l_slot[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n; ++j) rank += l_key[j] < kk ? 1u : 0u;   // (keys are distinct)
+                const uint64_t e = e0 + rank;
+                if (out_h1) out_h1[e] = (uint16_t)(kk >> 16);
+                if (out_h2) out_h2[e] = (uint16_t)(kk & 0xFFFFu);
+                if (out_freq)
+                    for (uint32_t s = 0; s < S; ++s) out_freq[e * S + s] = freq[slot * S + s];
+            }
+        } else {
+            for (uint32_t slot = threadIdx.x; slot < cap; slot += 64u) {
+                const uint32_t tag = keys[slot];
+                if (!tag) continue;
+                const uint32_t kk = order_key(tag);
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < cap; ++j) {
+                    const uint32_t tj = keys[j];
+                    rank += (tj && order_key(tj) < kk) ? 1u : 0u;
+                }
+                const uint64_t e = e0 + rank;
+                if (out_h1) out_h1[e] = (uint16_t)(kk >> 16);
+                if (out_h2) out_h2[e] = (uint16_t)(kk & 0xFFFFu);
+                if (out_freq)
+                    for (uint32_t s = 0; s < S; ++s) out_freq[e * S + s] = freq[slot * S + s];
+            }
+        }
+    }
+    if (out_stats) {
+        const uint32_t A = alleles[c], Am = x.d().Am, row = A * 12u;
+        TPtr<double> as = x.a<double>(A_ASTATS, S * Am * 12u);
+        double *dst = out_stats + cell_off[c] * 12u;
+        for (uint32_t i = threadIdx.x; i < S * row; i += 64u) {
+            const uint32_t s = i / row, r = i - s * row;
+            dst[i] = as[s * Am * 12u + r];
+        }
     }
 }
 
@@ -541,9 +637,16 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
     TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
     const bool fork = g->classes.size() > 1;
     if (fork) BT_HIP(hipEventRecord(g->ev_fork, g->ctx->stream));
+    // BT_GIBBS_ORDER (tuning): "hot_first" = the class of the two-haplotype tiles (gibbs_simple_kernel, on the context's stream) starts when the other classes'
+    // launches are through; unset = all classes start together
+    const char *order_env = getenv("BT_GIBBS_ORDER");
+    const bool hot_first = order_env && std::strcmp(order_env, "hot_first") == 0 && (op == OP_RUN || op == OP_SWEEP);
     for (auto &c : g->classes) {
         hipStream_t st = c.stream ? c.stream : g->ctx->stream;
         if (c.stream) BT_HIP(hipStreamWaitEvent(st, g->ev_fork, 0));
+        if (hot_first && !c.stream)
+            for (auto &o : g->classes)
+                if (o.stream) BT_HIP(hipStreamWaitEvent(st, o.done, 0));
         if (op == OP_SWEEP && g->prefill_armed && c.num_prefill) {
             // one wavefront per (vertex, sample) when there are many of them: between two iterations a vertex has a handful of candidates, and a
             // 256-thread workgroup with one busy wavefront holds four wavefront slots for the length of a subset walk
@@ -1007,7 +1110,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         // (production is in chunks of four words: a ring of `cap` words can be filled up to cap - 3 ahead)
         d.ring_cap[0] = 8;
         while (d.ring_cap[0] < 2 * S + 3 && d.ring_cap[0] < 64) d.ring_cap[0] *= 2;
-        d.ring_cap[1] = 16;
+        d.ring_cap[1] = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 ? 32 : 16;   // (two-haplotype clusters: the LDS block is small, fewer refills in the middle of a visit)
         if (const char *e = getenv("BT_GIBBS_RING0")) d.ring_cap[0] = (uint32_t)atoi(e);
         if (const char *e = getenv("BT_GIBBS_RING1")) d.ring_cap[1] = (uint32_t)atoi(e);
         d.ring_len = d.ring_cap[0] + d.ring_cap[1] + 2 * MT_RING_HDR;
@@ -1601,101 +1704,98 @@ static int fetch_array(bt_gibbs *g, uint32_t ti, int arr, uint64_t elems_per_lan
 
 extern "C" {
 
-int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t *num_allele_cells) {
-    if (!g) return fail("bt_gibbs_result_sizes: null handle");
+// entries per cluster (device count -> host prefix sums); fails when a table overflowed
+static int result_offsets(bt_gibbs *g, std::vector<uint64_t> &dip_off, std::vector<uint64_t> &cell_off) {
     BT_HIP(hipSetDevice(g->ctx->device));
-    BT_HIP(hipStreamSynchronize(g->ctx->stream));
-    uint64_t nd = 0, nc = 0;
-    std::vector<uint32_t> sc;
-    for (uint32_t ti = 0; ti < g->ntiles; ++ti) {
-        const TileDesc &d = g->tiles[ti];
-        int rc = fetch_array<uint32_t>(g, ti, A_SC, (uint64_t)d.nvm * SC_COUNT, sc);
-        if (rc != BT_OK) return rc;
-        for (uint32_t l = 0; l < d.num_lanes; ++l)
-            for (uint32_t v = 0; v < d.nvm; ++v) {
-                if (sc[(((size_t)v * SC_COUNT + SC_DIP_OVERFLOW) << d.wsh) + l]) return fail("bt_gibbs: diplotype frequency table overflowed");
-                nd += sc[(((size_t)v * SC_COUNT + SC_DIP_ENTRIES) << d.wsh) + l];
-            }
+    hipStream_t st = g->ctx->stream;
+    const uint32_t C = g->C;
+    uint32_t *d_n = nullptr;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_n), ((size_t)C + 1) * 4));
+    struct Free {
+        void *p;
+        ~Free() { (void)hipFree(p); }
+    } fr{d_n};
+    BT_HIP(hipMemsetAsync(d_n + C, 0, 4, st));
+    hipLaunchKernelGGL(result_count_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const ClusterLoc *)g->d_loc, C, d_n, d_n + C);
+    BT_CHECK_LAUNCH();
+    std::vector<uint32_t> n((size_t)C + 1);
+    BT_HIP(hipMemcpyAsync(n.data(), d_n, ((size_t)C + 1) * 4, hipMemcpyDeviceToHost, st));
+    BT_HIP(hipStreamSynchronize(st));
+    if (n[C]) return fail("bt_gibbs: diplotype frequency table overflowed");
+    dip_off.resize((size_t)C + 1);
+    cell_off.resize((size_t)C + 1);
+    uint64_t e = 0, cells = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+        dip_off[c] = e;
+        cell_off[c] = cells;
+        e += n[c];
+        cells += (uint64_t)g->S * g->h_A[c];
     }
-    for (uint32_t c = 0; c < g->C; ++c) nc += (uint64_t)g->h_A[c] * g->S;
-    if (num_diplotype_entries) *num_diplotype_entries = nd;
-    if (num_allele_cells) *num_allele_cells = nc;
+    dip_off[C] = e;
+    cell_off[C] = cells;
     return BT_OK;
 }
 
+int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t *num_allele_cells) {
+    if (!g) return fail("bt_gibbs_result_sizes: null handle");
+    std::vector<uint64_t> dip_off, cell_off;
+    const int rc = result_offsets(g, dip_off, cell_off);
+    if (rc != BT_OK) return rc;
+    if (num_diplotype_entries) *num_diplotype_entries = dip_off[g->C];
+    if (num_allele_cells) *num_allele_cells = cell_off[g->C];
+    return BT_OK;
+}
+
+// The flat layout is built by result_pack_kernel (one wavefront per cluster: entries ranked by (h1, h2), statistics gathered from the tile's
+// interleaved rows) and comes back in one copy per output array.
 int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, uint16_t *h_dip_h2, uint32_t *h_dip_freq, uint64_t *h_cell_off,
                           double *h_stats) {
     if (!g || !h_dip_off || !h_cell_off) return fail("bt_gibbs_result_fetch: null argument");
-    BT_HIP(hipSetDevice(g->ctx->device));
-    BT_HIP(hipStreamSynchronize(g->ctx->stream));
-    const uint32_t S = g->S;
-    // clusters grouped by tile so that every tile array is fetched once
-    std::vector<uint32_t> order(g->C);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g->loc[a].tile < g->loc[b].tile; });
-    std::vector<uint32_t> keys, freq;
-    std::vector<double> ast;
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> ents(g->C);   // per cluster: (key, slot) sorted by (h1, h2)
-    uint32_t cur_tile = 0xFFFFFFFFu;
-    for (uint32_t oi = 0; oi < g->C; ++oi) {
-        const uint32_t c = order[oi];
-        const ClusterLoc &L = g->loc[c];
-        const TileDesc &d = g->tiles[L.tile];
-        if (L.tile != cur_tile) {
-            int rc = fetch_array<uint32_t>(g, L.tile, A_DIPKEYS, (uint64_t)d.nvm * d.dip_cap, keys);
-            if (rc != BT_OK) return rc;
-            cur_tile = L.tile;
-        }
-        auto &e = ents[c];
-        for (uint32_t slot = 0; slot < d.dip_cap; ++slot) {
-            const uint32_t tag = keys[(((size_t)L.v * d.dip_cap + slot) << d.wsh) + L.lane];
-            if (!tag) continue;
-            e.emplace_back(tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u, slot);
-        }
-        std::sort(e.begin(), e.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
-            const uint32_t a1 = a.first & 0xFFFF, a2 = a.first >> 16, b1 = b.first & 0xFFFF, b2 = b.first >> 16;
-            return a1 != b1 ? a1 < b1 : a2 < b2;
-        });
+    std::vector<uint64_t> dip_off, cell_off;
+    {
+        const int rc = result_offsets(g, dip_off, cell_off);
+        if (rc != BT_OK) return rc;
     }
-    uint64_t e_acc = 0, cell_acc = 0;
-    for (uint32_t c = 0; c < g->C; ++c) {
-        h_dip_off[c] = e_acc;
-        h_cell_off[c] = cell_acc;
-        e_acc += ents[c].size();
-        cell_acc += (uint64_t)S * g->h_A[c];
-    }
-    h_dip_off[g->C] = e_acc;
-    h_cell_off[g->C] = cell_acc;
-    cur_tile = 0xFFFFFFFFu;
-    for (uint32_t oi = 0; oi < g->C; ++oi) {
-        const uint32_t c = order[oi];
-        const ClusterLoc &L = g->loc[c];
-        const TileDesc &d = g->tiles[L.tile];
-        if (L.tile != cur_tile) {
-            int rc = fetch_array<uint32_t>(g, L.tile, A_DIPFREQ, (uint64_t)d.nvm * d.dip_cap * S, freq);
-            if (rc != BT_OK) return rc;
-            if (h_stats) {
-                rc = fetch_array<double>(g, L.tile, A_ASTATS, (uint64_t)d.nvm * S * d.Am * 12, ast);
-                if (rc != BT_OK) return rc;
-            }
-            cur_tile = L.tile;
+    const uint32_t C = g->C, S = g->S;
+    hipStream_t st = g->ctx->stream;
+    const uint64_t nd = dip_off[C], nc = cell_off[C];
+    std::memcpy(h_dip_off, dip_off.data(), ((size_t)C + 1) * 8);
+    std::memcpy(h_cell_off, cell_off.data(), ((size_t)C + 1) * 8);
+    if (C == 0) return BT_OK;
+    std::vector<void *> tmp;
+    struct FreeAll {
+        std::vector<void *> &v;
+        ~FreeAll() {
+            for (void *p : v) (void)hipFree(p);
         }
-        uint64_t e = h_dip_off[c];
-        for (auto &kv : ents[c]) {
-            if (h_dip_h1) h_dip_h1[e] = (uint16_t)(kv.first & 0xFFFF);
-            if (h_dip_h2) h_dip_h2[e] = (uint16_t)(kv.first >> 16);
-            if (h_dip_freq)
-                for (uint32_t s = 0; s < S; ++s) h_dip_freq[e * S + s] = freq[((((size_t)L.v * d.dip_cap + kv.second) * S + s) << d.wsh) + L.lane];
-            ++e;
-        }
-        if (h_stats) {
-            const uint32_t A = g->h_A[c];
-            for (uint32_t s = 0; s < S; ++s)
-                for (uint32_t a = 0; a < A; ++a)
-                    for (uint32_t q = 0; q < 12; ++q)
-                        h_stats[(h_cell_off[c] + (uint64_t)s * A + a) * 12 + q] = ast[(((((size_t)L.v * S + s) * d.Am + a) * 12 + q) << d.wsh) + L.lane];
-        }
-    }
+    } fr{tmp};
+    auto dev = [&](size_t bytes, void **out) -> hipError_t {
+        hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess) tmp.push_back(*out);
+        return e;
+    };
+    uint64_t *d_dip_off = nullptr, *d_cell_off = nullptr;
+    uint32_t *d_alleles = nullptr, *d_freq = nullptr;
+    uint16_t *d_h1 = nullptr, *d_h2 = nullptr;
+    double *d_stats = nullptr;
+    BT_HIP(dev(((size_t)C + 1) * 8, reinterpret_cast<void **>(&d_dip_off)));
+    BT_HIP(dev(((size_t)C + 1) * 8, reinterpret_cast<void **>(&d_cell_off)));
+    BT_HIP(dev((size_t)C * 4, reinterpret_cast<void **>(&d_alleles)));
+    if (h_dip_h1) BT_HIP(dev(nd * 2, reinterpret_cast<void **>(&d_h1)));
+    if (h_dip_h2) BT_HIP(dev(nd * 2, reinterpret_cast<void **>(&d_h2)));
+    if (h_dip_freq) BT_HIP(dev(nd * S * 4, reinterpret_cast<void **>(&d_freq)));
+    if (h_stats) BT_HIP(dev(nc * 12 * 8, reinterpret_cast<void **>(&d_stats)));
+    BT_HIP(hipMemcpyAsync(d_dip_off, dip_off.data(), ((size_t)C + 1) * 8, hipMemcpyHostToDevice, st));
+    BT_HIP(hipMemcpyAsync(d_cell_off, cell_off.data(), ((size_t)C + 1) * 8, hipMemcpyHostToDevice, st));
+    BT_HIP(hipMemcpyAsync(d_alleles, g->h_A.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(result_pack_kernel, dim3(C), dim3(64), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const ClusterLoc *)g->d_loc, S, (const uint64_t *)d_dip_off,
+                       (const uint64_t *)d_cell_off, (const uint32_t *)d_alleles, d_h1, d_h2, d_freq, d_stats);
+    BT_CHECK_LAUNCH();
+    if (h_dip_h1 && nd) BT_HIP(hipMemcpyAsync(h_dip_h1, d_h1, nd * 2, hipMemcpyDeviceToHost, st));
+    if (h_dip_h2 && nd) BT_HIP(hipMemcpyAsync(h_dip_h2, d_h2, nd * 2, hipMemcpyDeviceToHost, st));
+    if (h_dip_freq && nd) BT_HIP(hipMemcpyAsync(h_dip_freq, d_freq, nd * S * 4, hipMemcpyDeviceToHost, st));
+    if (h_stats && nc) BT_HIP(hipMemcpyAsync(h_stats, d_stats, nc * 12 * 8, hipMemcpyDeviceToHost, st));
+    BT_HIP(hipStreamSynchronize(st));
     return BT_OK;
 }
 
@@ -1796,6 +1896,8 @@ int bt_diag_prof(unsigned long long *h_out16, int reset) {
     }
     unsigned long long more[32];   // + the simple kernel's translation unit
     BT_HIP(bt::simple_prof_read(more, reset));
+    for (int i = 0; i < 32; ++i) h_out16[i] += more[i];
+    BT_HIP(bt::hot_prof_read(more, reset));   // ... and gibbs_hot_kernel's
     for (int i = 0; i < 32; ++i) h_out16[i] += more[i];
     return BT_OK;
 }

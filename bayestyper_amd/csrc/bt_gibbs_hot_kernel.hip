@@ -24,5 +24,15 @@ hipError_t launch_gibbs_hot_kernel(unsigned grid, unsigned block, uint32_t lds, 
     hipLaunchKernelGGL(gibbs_hot_kernel, dim3(grid), dim3(block), lds, st, tiles, pool, P, op, a0, a1, hist, tr, tile_list);
     return hipGetLastError();
 }
+#ifdef BT_PROF
+hipError_t hot_prof_read(unsigned long long *h_out32, int reset) {   // this unit's copy of the phase counters (tools/prof_class.py)
+    hipError_t e = hipMemcpyFromSymbol(h_out32, HIP_SYMBOL(g_bt_prof), 32 * 8);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_bt_prof), z, 32 * 8);
+    }
+    return e;
+}
+#endif
 hipError_t prepare_gibbs_hot_kernel(int max_lds) { return hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_hot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds); }
 }  // namespace bt

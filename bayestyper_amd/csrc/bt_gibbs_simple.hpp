@@ -314,7 +314,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
         PROF_DECL;
         {   // the visit's words: exactly two per sample from the diplotype generator, the frequency generator's ring full
             const uint32_t want = 2u * S < r0.cap - 3u ? 2u * S : r0.cap - 3u;   // (more samples than the ring holds words for: the draws top up on the way)
-            r0.fill_to(want);
+            if (bt_wave_any(r0.avail < want)) r0.topup();   // (a ring that holds two visits' words is filled every other visit)
             r1.topup();
         }
         PROF(11);

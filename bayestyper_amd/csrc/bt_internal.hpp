@@ -102,6 +102,7 @@ struct bt_kmc_scan {
     uint32_t min_count = 0, max_count = 0xFFFFFFFFu;   // bt_kmc_scan_set_count_range
     uint64_t lut_entries = 0;   // 4^p + 1
     uint64_t *d_lut = nullptr;
+    uint32_t *d_hint = nullptr;   // prefix of every 4096th record (bt_table.hip: KmcView::hint)
     // staging of bt_kmc_scan_run_host (created on first use, kept for the life of the handle): two pinned host buffers, two device
     // buffers, a copy stream and the events that order copy and scan
     uint8_t *h_pin[2] = {nullptr, nullptr}, *d_stage[2] = {nullptr, nullptr};

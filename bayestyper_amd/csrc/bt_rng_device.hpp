@@ -194,6 +194,11 @@ BT_HD void mt_close(const Mt &m) { m.st[MT_N] = m.pos; }
 // reaches 1 and 397 positions ahead), so loading everything first gives the textbook stream.
 constexpr unsigned MT_RING_HDR = 3;
 constexpr unsigned MT_MIRROR = 4;   // words 0 .. 3 again at [MT_N, MT_N + 4)
+BT_HD void bt_sched_fence() {   // the instruction scheduler moves nothing across this point
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 BT_HD bool bt_wave_any(bool p) {   // true in every lane of the wavefront when p holds in any of them
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_ballot_w64(p) != 0;
@@ -216,6 +221,7 @@ struct MtRingT {
             const MtQuad a = *(const MtQuad BT_GAS *)(st + p);
             const uint32_t a4 = st[p + 4u];
             const MtQuad b = *(const MtQuadU BT_GAS *)(st + q);
+            bt_sched_fence();   // (all three requests leave before the first word is used: one round trip, not two)
             MtQuad z;
             z.x = mt_twist(a.x, a.y, b.x);
             z.y = mt_twist(a.y, a.z, b.y);
@@ -232,11 +238,58 @@ struct MtRingT {
             avail += 4u;
         }
     }
+    // up to NB chunks per lane with ALL their loads in flight before the first new word is computed: one memory round trip for the batch instead of
+    // one per chunk (chunks at most a few apart never read each other's words: the recurrence reaches 397 words = 99 chunks ahead, and the mirror is
+    // read by chunks 620 and 224 .. 226 only, each 56 or more chunks away from chunk 0 that writes it — or right before it, whose loads come first)
+    template <unsigned NB>
+    BT_HD void batch(uint32_t want) {
+        uint32_t nc = avail < want ? (want - avail + 3u) >> 2 : 0u;
+        nc = nc < NB ? nc : NB;
+        MtQuad a[NB], b[NB];
+        uint32_t a4[NB], pp[NB];
+        uint32_t p = pos;
+#pragma unroll
+        for (unsigned j = 0; j < NB; ++j) {
+            pp[j] = p;
+            if (j < nc) {
+                const uint32_t q = p + MT_M < MT_N ? p + MT_M : p + MT_M - MT_N;
+                a[j] = *(const MtQuad BT_GAS *)(st + p);
+                a4[j] = st[p + 4u];
+                b[j] = *(const MtQuadU BT_GAS *)(st + q);
+            }
+            p = p + 4u == MT_N ? 0u : p + 4u;
+        }
+        bt_sched_fence();
+#pragma unroll
+        for (unsigned j = 0; j < NB; ++j)
+            if (j < nc) {
+                MtQuad z;
+                z.x = mt_twist(a[j].x, a[j].y, b[j].x);
+                z.y = mt_twist(a[j].y, a[j].z, b[j].y);
+                z.z = mt_twist(a[j].z, a[j].w, b[j].z);
+                z.w = mt_twist(a[j].w, a4[j], b[j].w);
+                *(MtQuad BT_GAS *)(st + pp[j]) = z;
+                if (pp[j] == 0) *(MtQuad BT_GAS *)(st + MT_N) = z;
+                const uint32_t w = (head + avail) & (cap - 1u);
+                ring[w] = mt_temper(z.x);
+                ring[w + 1u] = mt_temper(z.y);
+                ring[w + 2u] = mt_temper(z.z);
+                ring[w + 3u] = mt_temper(z.w);
+                avail += 4u;
+                pos = pp[j] + 4u == MT_N ? 0u : pp[j] + 4u;
+            }
+    }
     // chunks until every lane holds at least `want` words (want <= cap - 3), the wavefront looping while any of its lanes is short
     BT_HD void fill_to(uint32_t want) {
         while (bt_wave_any(avail < want)) chunk(avail < want);
     }
-    BT_HD void topup() { fill_to(cap - 3u); }
+    // the same with the first chunks of every lane as one batch (the top-ups at the start of a visit)
+    template <unsigned NB>
+    BT_HD void fill_batched(uint32_t want) {
+        if (bt_wave_any(avail < want)) batch<NB>(want);
+        fill_to(want);
+    }
+    BT_HD void topup() { fill_batched<4>(cap - 3u); }
     BT_HD void need(uint32_t n) {   // n <= 4
         if (avail < n) fill_to(cap - 3u < 16u ? cap - 3u : 16u);
     }

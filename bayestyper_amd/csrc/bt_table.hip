@@ -366,8 +366,10 @@ __global__ __launch_bounds__(BLOCK) void classify_kernel(TableView t, BloomView 
 // k-mer of record n = prefix(n) (p symbols, from the LUT) ++ suffix bytes (4 symbols per byte,
 // first symbol in the top two bits) — kmc_file.cpp:437-474.
 // ---------------------------------------------------------------------------------------------
+constexpr unsigned KMC_HINT_SHIFT = 12;     // one hint per 4096 records
 struct KmcView {
     const uint64_t *lut;     // 4^p + 1 entries
+    const uint32_t *hint;    // hint[j] = prefix of record j << KMC_HINT_SHIFT (+ a terminal entry): a record's prefix is searched between two neighbouring hints
     uint64_t lut_entries;
     uint32_t k, p, counter_size, suffix_bytes, rec_size;
     uint32_t min_count, max_count;   // records whose counter lies outside are skipped (CKMCFile::ReadNextKmer, kmc_file.cpp:496-511)
@@ -379,7 +381,9 @@ constexpr unsigned KMC_MAX_REC = 24;        // max record size in bytes (k<=64: 
 // prefix of record n: largest j with lut[j] <= n  (skips empty prefixes exactly like
 // ReadNextKmer's "while (buf[idx] == buf[idx+1]) idx++", kmc_file.cpp:439-445)
 __device__ inline uint64_t kmc_prefix_of(const KmcView &v, uint64_t n) {
-    uint64_t lo = 0, hi = v.lut_entries - 1;   // invariant: lut[lo] <= n < lut[hi]
+    // (a prefix holds thousands of records: between two hints there are one or two candidates, so the search below is zero or one step
+    // instead of log2(4^p) dependent loads)
+    uint64_t lo = v.hint[n >> KMC_HINT_SHIFT], hi = (uint64_t)v.hint[(n >> KMC_HINT_SHIFT) + 1] + 1;   // invariant: lut[lo] <= n < lut[hi]
     while (hi - lo > 1) {
         uint64_t mid = (lo + hi) >> 1;
         if (v.lut[mid] <= n) lo = mid;
@@ -1261,11 +1265,26 @@ int bt_kmc_scan_create_bins(bt_ctx *ctx, uint32_t k, uint32_t lut_prefix_len, ui
         return fail("bt_kmc_scan_create: prefix LUT must start at 0 and end at total_records");
     }
     hipError_t e = hipSetDevice(ctx->device);
+    // hint[j] = prefix of record j * 4096 = largest i with lut[i] <= j * 4096 (one pass over the table); the terminal entry is the last prefix
+    const uint64_t num_hints = (total_records >> KMC_HINT_SHIFT) + 2;
+    std::vector<uint32_t> hint(num_hints);
+    {
+        uint64_t i = 0;
+        for (uint64_t j = 0; j + 1 < num_hints; ++j) {
+            const uint64_t n = j << KMC_HINT_SHIFT;
+            while (i + 2 < s->lut_entries && h_prefix_lut[i + 1] <= n) ++i;
+            hint[j] = (uint32_t)i;
+        }
+        hint[num_hints - 1] = (uint32_t)(s->lut_entries - 2);
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_lut), s->lut_entries * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_hint), num_hints * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(s->d_lut, h_prefix_lut, s->lut_entries * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->d_hint, hint.data(), num_hints * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         if (s->d_lut) (void)hipFree(s->d_lut);
+        if (s->d_hint) (void)hipFree(s->d_hint);
         delete s;
         return fail(std::string("bt_kmc_scan_create: ") + hipGetErrorString(e));
     }
@@ -1287,6 +1306,7 @@ int bt_kmc_scan_destroy(bt_kmc_scan *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->d_lut) (void)hipFree(s->d_lut);
+    if (s->d_hint) (void)hipFree(s->d_hint);
     free_host_staging(s);
     free_routed(s);
     delete s;
@@ -1296,6 +1316,7 @@ int bt_kmc_scan_destroy(bt_kmc_scan *s) {
 static KmcView make_kmc_view(const bt_kmc_scan *s) {
     KmcView v;
     v.lut = s->d_lut;
+    v.hint = s->d_hint;
     v.lut_entries = s->lut_entries;
     v.k = s->k;
     v.p = s->p;

@@ -39,6 +39,11 @@ std::string variantClusterRegion(const std::string &chrom_name, const std::vecto
 GenotypeWriter::GenotypeWriter(std::vector<std::string> sample_names, const Chromosomes &chromosomes_in) : samples(std::move(sample_names)), chromosomes(chromosomes_in) {}
 
 void GenotypeWriter::addGenotypes(const ClusterAnnotation &where, const VariantInfo &variant_info, const VariantGenotypes &genotypes, const std::string &sample_columns) {
+    append(where.chrom_name, formatGenotypes(where, variant_info, genotypes, sample_columns));
+}
+
+GenotypeWriter::GenotypedVariant GenotypeWriter::formatGenotypes(const ClusterAnnotation &where, const VariantInfo &variant_info, const VariantGenotypes &genotypes,
+                                                                 const std::string &sample_columns) const {
     const int chrom = chromosomes.find(where.chrom_name);
     if (chrom < 0) throw std::runtime_error("GenotypeWriter: unknown chromosome " + where.chrom_name);
     const std::string &chrom_sequence = chromosomes.sequence((size_t)chrom);
@@ -59,7 +64,7 @@ void GenotypeWriter::addGenotypes(const ClusterAnnotation &where, const VariantI
     for (size_t a = 0; a < variant_info.alt_alleles.size(); a++) os << (a ? "," : "") << (variant_info.alt_alleles[a].aco_att.empty() ? "." : variant_info.alt_alleles[a].aco_att);
     if (variant_info.has_dependency) os << ",.";
     os << "\tGT:GQ:GPP:APP:NAK:FAK:MAC:SAF" << sample_columns;
-    genotyped_variants[where.chrom_name].push_back(GenotypedVariant{variant_info.position, max_ref_length, variant_info.id, os.str()});
+    return GenotypedVariant{variant_info.position, max_ref_length, variant_info.id, os.str()};
 }
 
 std::string GenotypeWriter::generateHeader(const std::string &genome_filename, const std::string &graph_options_header, const std::string &genotype_options_header) const {

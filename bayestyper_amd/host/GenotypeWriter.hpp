@@ -37,8 +37,15 @@ struct ClusterAnnotation {   // the Genotypes fields that describe where a varia
 class GenotypeWriter {
   public:
     GenotypeWriter(std::vector<std::string> sample_names, const Chromosomes &chromosomes);
+    struct GenotypedVariant {
+        uint32_t position, max_ref_length;
+        std::string variant_id, genotypes;   // genotypes = everything after the REF column
+    };
     // one genotyped variant (GenotypeWriter::writeGenotypes :84-128); sample_columns = formatSampleColumns(...) of that variant
     void addGenotypes(const ClusterAnnotation &where, const VariantInfo &variant_info, const VariantGenotypes &genotypes, const std::string &sample_columns);
+    // the same in two steps, so that worker threads can format (const, thread-safe) and one thread appends in the order of a one-thread run
+    GenotypedVariant formatGenotypes(const ClusterAnnotation &where, const VariantInfo &variant_info, const VariantGenotypes &genotypes, const std::string &sample_columns) const;
+    void append(const std::string &chrom_name, GenotypedVariant &&variant) { genotyped_variants[chrom_name].push_back(std::move(variant)); }
     std::string generateHeader(const std::string &genome_filename, const std::string &graph_options_header, const std::string &genotype_options_header) const;   // :494-551
     // header + sorted lines (finalise :352-492); the file variant writes <output_prefix>.vcf or .vcf.gz and returns the number of variants
     std::string vcfText(const std::string &genome_filename, const std::string &graph_options_header, const std::string &genotype_options_header);
@@ -46,10 +53,6 @@ class GenotypeWriter {
                       const std::string &genotype_options_header);
 
   private:
-    struct GenotypedVariant {
-        uint32_t position, max_ref_length;
-        std::string variant_id, genotypes;   // genotypes = everything after the REF column
-    };
     std::vector<std::string> samples;
     const Chromosomes &chromosomes;
     std::unordered_map<std::string, std::vector<GenotypedVariant>> genotyped_variants;

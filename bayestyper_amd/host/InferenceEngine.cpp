@@ -1,4 +1,5 @@
 #include "InferenceEngine.hpp"
+#include "StageTimes.hpp"
 
 #include <algorithm>
 #include <fstream>
@@ -70,6 +71,9 @@ struct GpuSampler : GibbsSampler {
     void initChain(uint32_t chain) override { check(bt_gibbs_init_chain(g, chain), "bt_gibbs_init_chain"); }
     void sweep(uint32_t n, bool collect) override { check(bt_gibbs_sweep(g, n, collect ? 1 : 0), "bt_gibbs_sweep"); }
     void run() override { check(bt_gibbs_run(g), "bt_gibbs_run"); }
+    void sync() override {
+        if (getenv("BT_STAGE_TIMES")) check(bt_sync(ctx), "bt_sync");
+    }
     std::vector<uint64_t> noiseCounts() override {   // VariantClusterGroup::getNoiseCounts of every group + clearGenotyperCache (InferenceEngine.cpp:90-92)
         if (!d_hist) check(bt_malloc(ctx, (size_t)S * 256 * 8, (void **)&d_hist), "bt_malloc");
         check(bt_gibbs_noise_counts(g, d_hist, 1), "bt_gibbs_noise_counts");
@@ -305,9 +309,11 @@ void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistrib
         }
     }
     std::unique_ptr<Sampler> sampler;
+    std::unique_ptr<StageScope> stage(new StageScope("Gibbs: sampler construction (tiles)"));
     try {
         sampler = newSampler(0, batch);
     } catch (const std::runtime_error &e) {
+        stage.reset();
         if (batch.numGroups() < 2 || std::string(e.what()).find("state pool") == std::string::npos) throw;
         std::vector<uint32_t> a, b;
         for (uint32_t g = 0; g < batch.numGroups(); g++) (g < batch.numGroups() / 2 ? a : b).push_back(g);
@@ -317,9 +323,13 @@ void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistrib
     }
     num_launches += 1;
     sampler->setLut(cd.genomicTable().data(), cd.noiseTable().data());
+    stage.reset(new StageScope("Gibbs: sampling launch (20 x 350 sweeps)"));
     sampler->run();
+    sampler->sync();
+    stage.reset(new StageScope("Gibbs: result fetch (device pack + copy)"));
     const BatchResults r = sampler->results(batch.numClusters());
     sampler.reset();   // frees the launch's HBM before the next one is built
+    stage.reset();
     collect(batch, r);
 }
 

@@ -1,4 +1,5 @@
 #include "KmerCounter.hpp"
+#include "Parallel.hpp"
 
 #include <algorithm>
 #include <iostream>
@@ -28,20 +29,33 @@ struct DeviceCopy {
 };
 }  // namespace
 
-UnitGraphs::UnitGraphs(const InferenceUnit &unit, const Chromosomes &chromosomes, unsigned kmer_size) {
+UnitGraphs::UnitGraphs(const InferenceUnit &unit, const Chromosomes &chromosomes, unsigned kmer_size, unsigned threads) {
+    std::vector<const VariantCluster *> clusters;
+    std::vector<const std::string *> sequences;
     for (uint32_t g = 0; g < unit.variant_cluster_groups.size(); g++) {
         const ClusterGroup &grp = unit.variant_cluster_groups[g];
-        group_first.push_back((uint32_t)graphs.size());
+        group_first.push_back((uint32_t)clusters.size());
         for (uint32_t v = 0; v < grp.clusters.size(); v++) {
             const VariantCluster &c = grp.clusters[v];
             const int chrom = chromosomes.find(c.chrom_name);
             if (chrom < 0) throw std::runtime_error("chromosome " + c.chrom_name + " of a variant cluster is not in the genome");
-            graphs.emplace_back(c, chromosomes.sequence((size_t)chrom), kmer_size);
+            clusters.push_back(&c);
+            sequences.push_back(&chromosomes.sequence((size_t)chrom));
             cluster_group.push_back(g);
             cluster_vertex.push_back(v);
         }
     }
-    group_first.push_back((uint32_t)graphs.size());
+    group_first.push_back((uint32_t)clusters.size());
+    // every range of clusters into its own vector, the vectors joined in order
+    const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, clusters.size() / 1024 + 1));
+    std::vector<std::vector<VariantClusterGraph>> built(parts);
+    parallelFor(clusters.size(), parts, [&](size_t a, size_t b, unsigned part) {
+        built[part].reserve(b - a);
+        for (size_t i = a; i < b; i++) built[part].emplace_back(*clusters[i], *sequences[i], kmer_size);
+    });
+    graphs.reserve(clusters.size());
+    for (auto &part : built)
+        for (auto &g : part) graphs.push_back(std::move(g));
 }
 
 bt_gibbs_batch GibbsBatchData::view() const {

@@ -34,7 +34,9 @@ struct PathsHandle {
 struct UnitGraphs {
     std::vector<VariantClusterGraph> graphs;
     std::vector<uint32_t> cluster_group, cluster_vertex, group_first;   // group_first[g] = index of group g's first cluster (+ end sentinel)
-    UnitGraphs(const InferenceUnit &unit, const Chromosomes &chromosomes, unsigned kmer_size);
+    // `threads` host threads construct the graphs (the reference threads graph construction too: VariantFileParser.cpp:1044-1106); the result does not
+    // depend on the thread count (every graph is built from its own cluster)
+    UnitGraphs(const InferenceUnit &unit, const Chromosomes &chromosomes, unsigned kmer_size, unsigned threads = 1);
 };
 
 // the flattened VariantClusterHaplotypes bundles of a unit + its group structure: the host copy of bt_gibbs_batch

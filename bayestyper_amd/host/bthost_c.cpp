@@ -13,6 +13,7 @@
 #include "InferenceEngine.hpp"
 #include "KmcFile.hpp"
 #include "KmerHashOrder.hpp"
+#include "Parallel.hpp"
 #include "InferenceUnit.hpp"
 #include "KmerCounter.hpp"
 #include "Sample.hpp"
@@ -639,6 +640,50 @@ long long bth_cluster_output_columns(unsigned S, unsigned H, unsigned V, const u
         for (unsigned v = 0; v < V; v++) all += formatVariantStatsColumns(res[v]) + formatSampleColumns(r, v, res[v]) + "\n";
         if (out && out_len >= all.size()) std::memcpy(out, all.data(), all.size());
         return (long long)all.size();
+    } catch (...) {
+        return -1;
+    }
+}
+
+
+// The genotype collection of a whole launch on `threads` host threads (what `bayesTyper genotype -p` does per launch, main.cpp: getGenotypes + the
+// formatted sample columns of every variant of every cluster; no VCF coordinates, so the synthetic batches of bench.py can be timed): clusters in batch
+// order, group_cluster_off[G + 1] maps groups to their clusters, group_ploidy[G][S].  Returns the number of output bytes formatted (a checksum of the
+// lengths: the work cannot be optimised away) or -1.
+long long bth_batch_output_columns(unsigned S, unsigned long long G, const uint32_t *group_cluster_off, const uint8_t *group_ploidy, const uint32_t *num_haplotypes,
+                                   const uint32_t *num_variants, const uint16_t *hap_allele, const uint16_t *var_num_alleles, const uint8_t *var_has_dependency,
+                                   const uint64_t *dip_off, const uint16_t *h1, const uint16_t *h2, const uint32_t *freq, const uint64_t *cell_off, const double *stats, float min_gpp,
+                                   float min_kmers, const float *min_fraction, unsigned threads) {
+    try {
+        const uint64_t C = group_cluster_off[G];
+        std::vector<uint64_t> hapvar_off(C + 1, 0), var_base(C + 1, 0);
+        for (uint64_t c = 0; c < C; c++) {
+            hapvar_off[c + 1] = hapvar_off[c] + (uint64_t)num_haplotypes[c] * num_variants[c];
+            var_base[c + 1] = var_base[c] + num_variants[c];
+        }
+        Filters f;
+        f.min_genotype_posterior = min_gpp;
+        f.min_number_of_kmers = min_kmers;
+        f.min_fraction_observed_kmers.assign(min_fraction, min_fraction + S);
+        const unsigned T = clampThreads(threads);
+        std::vector<long long> bytes(T, 0);
+        parallelFor((size_t)G, T, [&](size_t g0, size_t g1, unsigned part) {
+            long long n = 0;
+            for (size_t g = g0; g < g1; g++)
+                for (uint64_t c = group_cluster_off[g]; c < group_cluster_off[g + 1]; c++) {
+                    ClusterResults r;
+                    r.S = S; r.H = num_haplotypes[c]; r.V = num_variants[c];
+                    r.hap_allele = hap_allele + hapvar_off[c]; r.var_num_alleles = var_num_alleles + var_base[c]; r.var_has_dependency = var_has_dependency + var_base[c];
+                    r.num_diplotypes = dip_off[c + 1] - dip_off[c]; r.h1 = h1 + dip_off[c]; r.h2 = h2 + dip_off[c]; r.freq = freq + dip_off[c] * S;
+                    r.stats = stats + cell_off[c] * 12; r.ploidy = group_ploidy + g * S;
+                    const auto res = getGenotypes(r, f);
+                    for (unsigned v = 0; v < r.V; v++) n += (long long)(formatVariantStatsColumns(res[v]).size() + formatSampleColumns(r, v, res[v]).size());
+                }
+            bytes[part] = n;
+        });
+        long long total = 0;
+        for (long long b : bytes) total += b;
+        return total;
     } catch (...) {
         return -1;
     }

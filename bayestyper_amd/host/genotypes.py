@@ -92,3 +92,23 @@ def cluster_output_columns(flat, res, c, ploidy, min_fraction, min_gpp=0.99, min
     buf = C.create_string_buffer(int(n) + 1)
     fn(*args, buf, n)
     return buf.raw[:n].decode().split("\n")[:-1]
+
+
+def batch_output_columns(flat, res, min_fraction, threads, min_gpp=0.99, min_kmers=1.0):
+    """the genotype collection of a whole launch on `threads` host threads (bth_batch_output_columns: getGenotypes + the formatted columns of every
+    variant of every cluster, as `bayesTyper genotype -p` does per launch); returns the number of bytes formatted"""
+    from . import dll
+
+    fn = dll.bth_batch_output_columns
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_uint, C.c_ulonglong] + [C.c_void_p] * 13 + [C.c_float, C.c_float, C.c_void_p, C.c_uint]
+    keep = [np.ascontiguousarray(flat["group_cluster_off"], np.uint32), np.ascontiguousarray(flat["group_ploidy"], np.uint8), np.ascontiguousarray(flat["num_haplotypes"], np.uint32),
+            np.ascontiguousarray(flat["num_variants"], np.uint32), np.ascontiguousarray(flat["hap_allele"], np.uint16), np.ascontiguousarray(flat["var_num_alleles"], np.uint16),
+            np.ascontiguousarray(flat["var_has_dependency"], np.uint8), np.ascontiguousarray(res["dip_off"], np.uint64), np.ascontiguousarray(res["h1"], np.uint16),
+            np.ascontiguousarray(res["h2"], np.uint16), np.ascontiguousarray(res["freq"], np.uint32).reshape(-1), np.ascontiguousarray(res["cell_off"], np.uint64),
+            np.ascontiguousarray(res["stats"], np.float64).reshape(-1)]
+    mf = np.ascontiguousarray(min_fraction, np.float32)
+    n = fn(flat["S"], flat["num_groups"], *[_p(a) for a in keep], min_gpp, min_kmers, _p(mf), threads)
+    if n < 0:
+        raise RuntimeError("batch_output_columns failed")
+    return int(n)

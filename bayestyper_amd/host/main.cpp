@@ -45,7 +45,9 @@
 #include "KmerCounter.hpp"
 #include "KmerHashOrder.hpp"
 #include "Options.hpp"
+#include "Parallel.hpp"
 #include "Sample.hpp"
+#include "StageTimes.hpp"
 
 using namespace bthost;
 
@@ -77,6 +79,7 @@ void makeDirectory(const std::string &dir, const char *what) {
 }
 
 Chromosomes readGenome(const OptionsContainer &options) {
+    StageScope stage("read reference genome");
     std::cout << "\n" << stamp() << "Parsing reference genome ..." << std::endl;
     Chromosomes chromosomes;
     chromosomes.addFasta(options.getString("genome-file"), false);
@@ -144,7 +147,9 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
 
     Context ctx;
     KmerCounter kmer_counter(ctx.h, samples, kmer_size, seed);
+    std::unique_ptr<StageScope> st_read(new StageScope("read variant file"));
     VariantFileParser variant_file_parser(VariantFileParser::readVariantFile(options.getString("variant-file")), kmer_size, (uint32_t)options.getUInt("max-allele-length"), cnv_threshold);
+    st_read.reset();
     const uint32_t num_variants = variant_file_parser.getNumberOfVariants();
     const uint32_t num_units = std::max<uint32_t>(1, (uint32_t)std::floor(num_variants / (float)min_unit_variants));
     std::cout << "\n" << stamp() << "Setting the number of inference units to " << num_units << " across " << num_variants << " variants ..." << std::endl;
@@ -164,21 +169,30 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
         unit.index = unit_idx;
         unit.cluster_options_header = options.getHeader();
         const uint32_t parsed_before = variant_file_parser.numParsedVariants(), clusters_before = variant_file_parser.numVariantClusters();
-        variant_file_parsed = variant_file_parser.constructVariantClusterGroups(&unit.variant_cluster_groups, (uint32_t)std::ceil(num_variants / (float)num_units), chromosomes);
+        {
+            StageScope stage("parse variants -> clusters -> groups");
+            variant_file_parsed = variant_file_parser.constructVariantClusterGroups(&unit.variant_cluster_groups, (uint32_t)std::ceil(num_variants / (float)num_units), chromosomes);
+        }
         unit.num_variants = variant_file_parser.numParsedVariants() - parsed_before;
         unit.num_variant_clusters = variant_file_parser.numVariantClusters() - clusters_before;
         std::sort(unit.variant_cluster_groups.begin(), unit.variant_cluster_groups.end(), ClusterGroupCompare);
         std::cout << stamp() << "Parsed unit " << unit_idx << ": " << unit.num_variants << " variants in " << unit.num_variant_clusters << " clusters and "
                   << unit.variant_cluster_groups.size() << " groups\n" << std::endl;
         {
-            const UnitGraphs graphs(unit, chromosomes, kmer_size);
+            std::unique_ptr<StageScope> st(new StageScope("construct variant cluster graphs (host)"));
+            const UnitGraphs graphs(unit, chromosomes, kmer_size, clampThreads(options.getUInt("threads")));
+            st.reset(new StageScope("find sample paths (sample Bloom filters + search)"));
             kmer_counter.findVariantClusterPaths(&unit, graphs, max_sample_haplotypes);
+            st.reset(new StageScope("count path / multigroup k-mers"));
             kmer_counter.countPathMultigroupKmers(multigroup_kmer_hash.h, path_kmer_bloom.h, &unit, graphs);
         }
         num_path_kmers += unit.num_path_kmers;
         const std::string unit_dir = output_prefix + "_unit_" + std::to_string(unit.index);
         makeDirectory(unit_dir, "Unit");
-        unit.write(unit_dir + "/variant_clusters.bin");
+        {
+            StageScope stage("write variant_clusters.bin");
+            unit.write(unit_dir + "/variant_clusters.bin");
+        }
         std::cout << "\n" << stamp() << "Wrote unit " << unit.index << " variant clusters to " << unit_dir << "/variant_clusters.bin" << std::endl;
     }
     if (!variant_file_parsed) throw std::runtime_error("variants remain after the last inference unit");
@@ -188,6 +202,7 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
     const std::string cluster_data_dir = output_prefix + "_cluster_data";
     makeDirectory(cluster_data_dir, "Cluster data");
 
+    std::unique_ptr<StageScope> st_tail(new StageScope("inter-cluster regions, parameter k-mers, multigroup filter"));
     std::cout << "\n\n" << stamp() << "Writing inter-cluster regions ..." << std::endl;
     const std::string intercluster_regions_dir_prefix = cluster_data_dir + "/" + intercluster_regions_file_prefix;
     variant_file_parser.sortInterclusterRegions();
@@ -240,6 +255,8 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
         check(bt_bloom_save(multigroup_kmer_bloom.h, (cluster_data_dir + "/" + multigroup_kmers_file_prefix).c_str()), "bt_bloom_save");
     }
     std::cout << stamp() << "Wrote " << num_multigroup_kmers << " kmers to " << cluster_data_dir << "/" << multigroup_kmers_file_prefix << ".bloom[Meta|Data]" << std::endl;
+    st_tail.reset();
+    StageTimes::get().print("bayesTyper cluster");
     std::cout << "\n\n" << stamp() << "BayesTyper cluster completed succesfully!\n" << std::endl;
     return 0;
 }
@@ -314,7 +331,9 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     const Chromosomes chromosomes = readGenome(options);
 
     std::cout << "\n\n" << stamp() << "Parsing variant clusters ..." << std::endl;
+    std::unique_ptr<StageScope> st(new StageScope("read variant_clusters.bin"));
     InferenceUnit unit = InferenceUnit::read(options.getString("variant-clusters-file"));
+    st.reset();
     std::cout << stamp() << "Parsed " << unit.num_variant_clusters << " variant clusters (" << unit.num_variants << " variants)" << std::endl;
     const std::string cluster_data_dir = options.getString("cluster-data-dir");
     const std::string intercluster_regions_dir_prefix = cluster_data_dir + "/" + intercluster_regions_file_prefix;
@@ -334,6 +353,7 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     std::cout << "\n" << stamp() << "Parsing parameter kmers ..." << std::endl;
     uint64_t num_parameter_kmers = 0;
     {
+        StageScope stage("parameter k-mers");
         std::istringstream in(readGzFile(parameter_kmers_dir_prefix + ".fa.gz"));
         std::string line;
         std::getline(in, line);
@@ -362,15 +382,21 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     std::cout << "\n" << std::endl;
 
     const ChromosomePloidy chrom_ploidy(options.getString("chromosome-ploidy-file"), chromosomes, samples);
-    const UnitGraphs graphs(unit, chromosomes, kmer_size);
+    st.reset(new StageScope("construct variant cluster graphs (host)"));
+    const UnitGraphs graphs(unit, chromosomes, kmer_size, clampThreads(options.getUInt("threads")));
+    st.reset(new StageScope("count path k-mers (enumerate + Bloom insert)"));
     kmer_counter.countPathKmers(path_kmer_bloom->h, unit, graphs);
+    st.reset(new StageScope("count inter-cluster k-mers"));
     kmer_counter.countInterclusterKmers(kmer_hash.h, path_kmer_bloom->h, intercluster_regions_dir_prefix, chromosomes, chrom_ploidy);
     std::cout << std::endl;
+    st.reset(new StageScope("parse sample k-mers (KMC scan incl. H2D)"));
     kmer_counter.parseSampleKmers(kmer_hash.h, path_kmer_bloom->h, comm.get());
     path_kmer_bloom.reset();
     std::cout << std::endl;
+    st.reset(new StageScope("classify path k-mers + haplotype candidates"));
     const GibbsBatchData batch = kmer_counter.classifyPathKmers(kmer_hash.h, unit, graphs, multigroup_kmers_dir_prefix, chrom_ploidy);
     std::cout << "\n" << std::endl;
+    st.reset(new StageScope("k-mer statistics -> count model"));
 
     // (every rank holds the whole table: the same moments, the same count model; only rank 0's files are kept)
     const std::string rank_suffix = rank == 0 ? "" : ".rank" + std::to_string(rank);
@@ -378,6 +404,7 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     setGenomicCountDistributions(&count_distribution, kmer_hash.h, samples, output_prefix + "_genomic_parameters" + rank_suffix);
     bt_table_destroy(kmer_hash.h);   // the bundles hold everything the sampler needs
     kmer_hash.h = nullptr;
+    st.reset();
 
     const bool noise_genotyping = options.getBool("noise-genotyping");
     std::vector<uint8_t> gender(S);
@@ -407,6 +434,7 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     const std::string noise_prefix = output_prefix + "_noise_parameters" + rank_suffix;
     if (!noise_genotyping) {
         std::cout << "\n" << std::endl;
+        StageScope stage("estimate noise (Gibbs, noise driver)");
         inference_engine.estimateNoise(&count_distribution, my_batch, noise_prefix, NoiseGroupSelector::noise_variants_batch_size, comm ? &unit_clusters : nullptr,
                                        comm ? &unit_variants : nullptr);
     }
@@ -419,15 +447,22 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     if (!options.getBool("disable-observed-kmers"))
         for (size_t s = 0; s < S; s++) filters.min_fraction_observed_kmers[s] = Filters::minFractionObservedKmers(count_distribution.getGenomicCountDistributions()[s].mean());
     GenotypeWriter genotype_writer(names, chromosomes);
+    const unsigned host_threads = clampThreads(options.getUInt("threads"));
 
     // collectGenotypes of every cluster of a launch (VariantClusterGenotyper::getGenotypes) -> GenotypeWriter
     const InferenceEngine::Collector collect = [&](const GibbsBatchData &b, const BatchResults &r) {
+        StageScope stage("genotypes (getGenotypes + VCF lines, -p host threads)");
         std::vector<uint64_t> hapvar_off(b.numClusters() + 1, 0), var_base(b.numClusters() + 1, 0);
         for (uint32_t c = 0; c < b.numClusters(); c++) {
             hapvar_off[c + 1] = hapvar_off[c] + (uint64_t)b.num_haplotypes[c] * b.num_variants[c];
             var_base[c + 1] = var_base[c] + b.num_variants[c];
         }
-        for (uint32_t g = 0; g < b.numGroups(); g++) {
+        // the groups are shared out among the host threads (-p; the reference's worker threads collect their own groups' genotypes,
+        // InferenceEngine.cpp:292-310); every thread formats its range's VCF lines, which are appended range after range: the order of one thread
+        std::vector<std::vector<std::pair<const std::string *, GenotypeWriter::GenotypedVariant>>> lines(host_threads);
+        parallelFor(b.numGroups(), host_threads, [&](size_t g_begin, size_t g_end, unsigned part) {
+        auto &mine = lines[part];
+        for (uint32_t g = (uint32_t)g_begin; g < (uint32_t)g_end; g++) {
             const ClusterGroup &grp = unit.variant_cluster_groups[b.group_index[g]];
             for (uint32_t c = b.group_cluster_off[g]; c < b.group_cluster_off[g + 1]; c++) {
                 const VariantCluster &cluster = grp.clusters[c - b.group_cluster_off[g]];
@@ -447,9 +482,13 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
                 cr.ploidy = b.group_ploidy.data() + (uint64_t)g * S;
                 const std::vector<VariantGenotypes> res = getGenotypes(cr, filters);
                 const ClusterAnnotation where{cluster.chrom_name, (uint32_t)info.size(), variantClusterRegion(cluster.chrom_name, info), (uint32_t)grp.clusters.size(), grp.region(), cr.H};
-                for (size_t v = 0; v < info.size(); v++) genotype_writer.addGenotypes(where, info[v], res[v], formatSampleColumns(cr, (uint32_t)v, res[v]));
+                for (size_t v = 0; v < info.size(); v++)
+                    mine.emplace_back(&cluster.chrom_name, genotype_writer.formatGenotypes(where, info[v], res[v], formatSampleColumns(cr, (uint32_t)v, res[v])));
             }
         }
+        });
+        for (auto &part : lines)
+            for (auto &l : part) genotype_writer.append(*l.first, std::move(l.second));
     };
     if (!comm) {
         if (!noise_genotyping) inference_engine.estimateGenotypes(batch, count_distribution, collect);
@@ -484,10 +523,13 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
         return 0;
     }
 
+    st.reset(new StageScope("write VCF (sort + output)"));
     const uint32_t num_genotyped_variants = genotype_writer.finalise(output_prefix, options.getBool("gzip-output"), options.getString("genome-file"), unit.cluster_options_header, options.getHeader());
     std::cout << "\n" << stamp() << "Out of " << unit.num_variants << " variants:\n" << std::endl;
     std::cout << "\t- " << num_genotyped_variants << " were genotyped" << std::endl;
     std::cout << "\t- " << unit.num_variants - num_genotyped_variants << " were skipped (unsupported)" << std::endl;
+    st.reset();
+    StageTimes::get().print("bayesTyper genotype");
     std::cout << "\n\n" << stamp() << "BayesTyper genotype completed succesfully!\n" << std::endl;
     if (comm) comm->barrier();
     return 0;

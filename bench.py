@@ -7,7 +7,9 @@ One "step" = one pass of the hot path over one batch of synthetic input held in 
       matched k-mers (the cold path), the others find them and add their counts — the weighting of a real S-sample run;
   (2) the default-mode Gibbs schedule (20 chains x (100 burn-in + 250 collected) sweeps,
       InferenceEngine::estimateGenotypesCallback) for every variant-cluster group of the batch;
-  (3) the compact posterior summary per (cluster, sample), gathered to rank 0 (RCCL when --gpus > 1).
+  (3) the launch's collected samples in the product's result layout (bt_gibbs_result_fetch: every cluster's diplotype sampling frequencies ordered by
+      (h1, h2) + its allele k-mer statistics, packed on the device, one copy per array to the host), gathered to rank 0 when --gpus > 1 (RCCL,
+      libbtcomm.so) — what `bayesTyper genotype` does per launch before it turns the samples into genotypes (the `results` sub-record times that host step).
 
 Workload at N=1 = BASELINE.json configs[2], the largest single-GPU configuration ("GRCh38 whole genome, CEU trio (3 samples),
 SNV+indel+SV merged candidates"): S=3 and one launch-sized slice of the unit — 600 000 variant-cluster groups (80-140 GB of sampler
@@ -17,10 +19,13 @@ clusters with up to 32 x S haplotype candidates), every structure with its own d
 every group with its own truth genotypes and counts; a whole genome (5-15 x 10^6 groups) is a sequence of such launches.  KMC: a
 2x10^8-record stream per sample (13-byte records, k=55, p=7), 2 % path-k-mer hit rate against a fpr-1e-4 ThreadedKmerBloom of
 5x10^7 path k-mers (SURVEY 8d's stream: 10^9 records per sample).  --samples 10 gives the north star's 10-sample mixture.
-Several GPUs (--gpus N, one rank per GPU): ONE batch is sharded over the ranks (LPT on a cost proxy, every group keeps its unit-wide index) and
-every rank scans its own share of the KMC stream; the posterior summaries are gathered to rank 0 through the product's own exchange library
-(libbtcomm.so: RCCL over xGMI; torch.distributed/gloo only passes the communicator id), and rank 0 then runs the unsharded batch and checks
-that the gathered summaries equal it (config.sharded_equals_unsharded).  --scaling weak gives every rank its own batch of the full size instead.
+Several GPUs (--gpus N, one rank per GPU), default = weak scaling: ONE unit of N x --groups groups — N launch-sized blocks, block r generated and sampled by
+rank r, every group with its unit-wide index (from which its seeds derive, so the samples do not depend on the placement) — and a KMC stream per rank; the
+ranks' results travel to rank 0 through the product's own exchange library (libbtcomm.so: RCCL over xGMI; torch.distributed/gloo only passes the communicator
+id).  Per-rank launch times and the gather time are reported separately (config.per_rank).  A real unit is 5-15 x 10^6 groups, i.e. several launches per GPU:
+per-GPU work stays launch-sized as N grows.  Placement independence is checked on a sample: rank 0 runs its first 4 096 groups again as a batch of their own
+and compares the posterior summaries (config.subset_equals_batch).  --scaling strong shards ONE --groups batch over the ranks instead (LPT on a cost proxy,
+checked against the unsharded batch: config.sharded_equals_unsharded).
 
 Prints ONE JSON line (rank 0).  `value` = variant-cluster Gibbs iterations (cluster-sweeps) per second over the whole job; k-mer
 matches/sec is reported beside it.  `roofline` describes the dominant kernel (the Gibbs sweep kernel); `roofline_kmer_match` the KMC
@@ -75,6 +80,22 @@ def committed_traffic(kind):
     return None, None
 
 
+def committed_issue_profile():
+    """the VALU instruction counts of one Gibbs schedule of the default command (profiles/*_issue.json, tools/issue_profile.py from single-schedule SQ counter
+    passes), when measured on the sources this library was built from"""
+    import glob
+
+    mine = source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("source_hash") == mine and "gibbs" in d:
+            return d, os.path.relpath(f, ROOT)
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,7 +103,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--groups", type=int, default=600_000, help="variant-cluster groups per GPU")
     ap.add_argument("--samples", type=int, default=3)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: strong (one batch sharded over the ranks) when --gpus > 1")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak (default): a unit of N x --groups groups, one launch-sized block per rank; strong: one --groups batch sharded over the ranks")
     ap.add_argument("--no-verify", action="store_true", help="strong scaling: skip the check of the gathered summaries against the unsharded batch (run by rank 0 after the timed region)")
     ap.add_argument("--records", type=int, default=1_000_000_000, help="KMC records per sample per step (whole job under strong scaling: every rank scans its share)")
     ap.add_argument("--path-kmers", type=int, default=50_000_000)
@@ -129,8 +150,6 @@ def main():
         ident = [btcomm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         comm = btcomm.Comm(ctx, ident[0], rank, world)
-    if args.scaling is None:
-        args.scaling = "strong" if world > 1 else "weak"
 
     # ------------------------------------------------------------------ Gibbs batch (this rank's groups)
     from bayestyper_amd import shard
@@ -164,7 +183,14 @@ def main():
         comm.allreduce(c_all.data_ptr(), world)
         torch.cuda.synchronize()
         c_all = [int(x) for x in c_all.tolist()]
-        d_gathered = torch.zeros(sum(c_all) * S * 2 if rank == 0 else 2, dtype=torch.int32, device=dev)
+        d_gathered = torch.zeros(sum(c_all) * S * 2 if rank == 0 else 2, dtype=torch.int32, device=dev)   # (strong scaling's check: posterior summaries)
+    state = {"res": None, "d_words": None, "d_all": None}
+
+    def result_words(res):
+        """a launch's results as one word string (what the host layer's gatherResults ships): entries per cluster, (h1 | h2 << 16), counts, statistics"""
+        n_ent = np.diff(res["dip_off"]).astype(np.uint32)
+        keys = res["h1"].astype(np.uint32) | (res["h2"].astype(np.uint32) << 16)
+        return np.concatenate([np.asarray([C, len(keys)], np.uint32), n_ent, keys, res["freq"].reshape(-1), res["stats"].reshape(-1).view(np.uint32)])
 
     # ------------------------------------------------------------------ KMC stream + path Bloom + count table (in HBM)
     # under strong scaling the job's stream of args.records records per sample is split over the ranks (every rank scans its share against the
@@ -217,12 +243,34 @@ def main():
         gibbs.run()
         if timed:
             t_gibbs.stop()
-        # (3) posterior summaries -> rank 0
-        lib.check(lib.bt_gibbs_posterior_summary(gibbs.h, d_summary.data_ptr()))
-        if world > 1:
-            comm.gather_words(d_summary.data_ptr(), C * S * 2, d_gathered.data_ptr(), d_gathered.numel())
+        # (3) the launch's results in the product's layout -> host (-> rank 0)
         if timed:
-            return [t.elapsed_ms() for t in t_kmc], t_gibbs.elapsed_ms()
+            ctx.sync()   # (the launch is asynchronous: wait for it here so that the fetch is timed by itself; results() would wait anyway)
+        tf = time.perf_counter()
+        res = gibbs.results()
+        fetch_s = time.perf_counter() - tf
+        gather_s = 0.0
+        if world > 1:
+            tg = time.perf_counter()
+            words = torch.from_numpy(result_words(res).view(np.int32)).to(dev)
+            n_all = torch.zeros(world, dtype=torch.int64, device=dev)
+            n_all[rank] = words.numel()
+            comm.allreduce(n_all.data_ptr(), world)
+            torch.cuda.synchronize()
+            total = int(n_all.sum().item())
+            if state["d_all"] is None or state["d_all"].numel() < (total if rank == 0 else 2):
+                state["d_all"] = torch.zeros(total if rank == 0 else 2, dtype=torch.int32, device=dev)
+            comm.gather_words(words.data_ptr(), words.numel(), state["d_all"].data_ptr(), state["d_all"].numel())
+            if rank == 0:
+                state["h_all"] = state["d_all"][:total].cpu()   # rank 0 holds every rank's results on the host, as the executable's rank 0 does
+            torch.cuda.synchronize()
+            gather_s = time.perf_counter() - tg
+            if strong:
+                lib.check(lib.bt_gibbs_posterior_summary(gibbs.h, d_summary.data_ptr()))
+                comm.gather_words(d_summary.data_ptr(), C * S * 2, d_gathered.data_ptr(), d_gathered.numel())
+        state["res"] = res
+        if timed:
+            return [t.elapsed_ms() for t in t_kmc], t_gibbs.elapsed_ms(), fetch_s * 1e3, gather_s * 1e3
         return None
 
     def barrier():
@@ -234,17 +282,24 @@ def main():
         step(i, False)
     barrier()
     t0 = time.perf_counter()
-    kmc_ms, gibbs_ms = [], []
+    kmc_ms, gibbs_ms, fetch_ms, gather_ms = [], [], [], []
     for i in range(args.steps):
-        a, b = step(args.warmup + i, True)
+        a, b, f_ms, g_ms = step(args.warmup + i, True)
         kmc_ms.append(a)
         gibbs_ms.append(b)
+        fetch_ms.append(f_ms)
+        gather_ms.append(g_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = [C, float(np.mean(gibbs_ms)), float(np.mean([sum(x) for x in kmc_ms])), float(np.mean(fetch_ms)), float(np.mean(gather_ms))]
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        per_rank = [{"rank": r, "clusters": int(x[0]), "gibbs_launch_ms": x[1], "kmc_scans_ms": x[2], "result_fetch_ms": x[3], "gather_ms": x[4]} for r, x in enumerate(rows)]
     hits = int(d_hits.item())
     st = table.status()
     if st["overflowed"]:
@@ -266,7 +321,8 @@ def main():
             if verify:
                 gibbs.close()
                 g_all = lib.Gibbs(ctx, unit, lut_g, lut_n, seed=42)
-                g_all.run()
+                for _ in range(args.warmup + args.steps):   # (a further bt_gibbs_run continues every group's chains: as many schedules as the shards have run)
+                    g_all.run()
                 ref_summary = torch.zeros(C_total * S * 2, dtype=torch.int32, device=dev)
                 lib.check(lib.bt_gibbs_posterior_summary(g_all.h, ref_summary.data_ptr()))
                 torch.cuda.synchronize()
@@ -274,6 +330,53 @@ def main():
                 g_all.close()
                 if not verified:
                     raise RuntimeError("bench: the gathered summaries of the sharded run differ from the unsharded run")
+
+    # ------------------------------------------------------------------ placement independence on a sample (rank 0): the first groups of the batch as a batch
+    # of their own (other tiles, other launch classes, other lanes) give the same posterior summaries — what makes a sharded unit equal the unsharded one
+    subset_ok = None
+    if rank == 0 and not strong and not args.no_verify:
+        n_sub = min(4096, G)
+        sub = shard.take_groups(flat, np.arange(n_sub))
+        lib.check(lib.bt_gibbs_posterior_summary(gibbs.h, d_summary.data_ptr()))
+        torch.cuda.synchronize()
+        g_sub = lib.Gibbs(ctx, sub, lut_g, lut_n, seed=42)
+        for _ in range(args.warmup + args.steps):   # (a further bt_gibbs_run continues every group's chains: as many schedules as the batch has run)
+            g_sub.run()
+        d_sub = torch.zeros(sub["num_clusters"] * S * 2, dtype=torch.int32, device=dev)
+        lib.check(lib.bt_gibbs_posterior_summary(g_sub.h, d_sub.data_ptr()))
+        torch.cuda.synchronize()
+        subset_ok = bool(torch.equal(d_sub, d_summary[: d_sub.numel()]))
+        g_sub.close()
+        del d_sub
+        if not subset_ok:
+            raise RuntimeError("bench: a group's samples depend on the batch it is launched in")
+
+    # ------------------------------------------------------------------ the host step that follows a launch (rank 0, outside the timed region):
+    # VariantClusterGenotyper::getGenotypes + the formatted output columns of every variant of every cluster (bayesTyper genotype -p: host threads)
+    results_rec = None
+    if rank == 0 and world == 1 and state["res"] is not None:
+        from bayestyper_amd.host import genotypes as hgt
+
+        mf = hgt.min_fraction_observed_kmers([15.0] * S)
+        cores_ = os.cpu_count() or 1
+        tg_ = time.perf_counter()
+        nbytes = hgt.batch_output_columns(flat, state["res"], mf, cores_)
+        collect_all = time.perf_counter() - tg_
+        n1 = min(G, 20_000)
+        sub1 = shard.take_groups(flat, np.arange(n1))
+        c1 = sub1["num_clusters"]
+        r1 = {"dip_off": state["res"]["dip_off"][: c1 + 1], "h1": state["res"]["h1"], "h2": state["res"]["h2"], "freq": state["res"]["freq"],
+              "cell_off": state["res"]["cell_off"][: c1 + 1], "stats": state["res"]["stats"]}
+        tg_ = time.perf_counter()
+        hgt.batch_output_columns(sub1, r1, mf, 1)
+        collect_one = time.perf_counter() - tg_
+        results_rec = {"clusters": C, "result_fetch_ms": float(np.mean(fetch_ms)),
+                       "result_bytes": int(sum(state["res"][k].nbytes for k in ("dip_off", "h1", "h2", "freq", "cell_off", "stats"))),
+                       "get_genotypes_s": collect_all, "get_genotypes_threads": cores_, "get_genotypes_clusters_per_sec": C / collect_all,
+                       "get_genotypes_one_thread_clusters_per_sec": c1 / collect_one, "formatted_bytes": nbytes,
+                       "note": "result_fetch_ms is inside the timed step (bt_gibbs_result_sizes + bt_gibbs_result_fetch: count, pack on the device, one copy per array); "
+                               "get_genotypes_s = bthost::getGenotypes + the formatted VCF columns of every variant of the batch on the host threads `bayesTyper genotype -p` uses"}
+    state["res"] = None
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only): the oracle on host cores
     cpu = None
@@ -417,7 +520,10 @@ def main():
         S10 = 10
         f10 = synth.make_mixture(100_000, S10, seed=1010)
         lg10, ln10 = count_model.build_luts(S10, mean=15.0, var=30.0, noise_rate=0.05)
-        g10 = lib.Gibbs(ctx, f10, lg10, ln10, seed=42)
+        f10x = synth.concat([f10] * 4)   # the throughput regime: 4 x the batch, every copy with group indices (hence seeds, hence chains) of its own
+        f10x["group_index"] = np.arange(f10x["num_groups"], dtype=np.uint32)
+        f10x["mixture"] = {k: 4 * v for k, v in f10["mixture"].items()}
+        g10 = lib.Gibbs(ctx, f10x, lg10, ln10, seed=42)
         t10 = lib.Timer(ctx)
         ms10 = []
         for _ in range(2):
@@ -425,9 +531,13 @@ def main():
             g10.run()
             t10.stop()
             ms10.append(t10.elapsed_ms())
+        g10_bytes = g10.device_bytes()
         g10.close()
-        rec10 = {"workload": "BASELINE configs[3] shape on one GPU: 100 000 groups of the mixture (%s), S=10, 20 chains x (100+250) sweeps" % f10["mixture"],
-                 "ms_per_schedule": min(ms10), "cluster_sweeps_per_sec": f10["num_clusters"] * sweeps_per_group / (min(ms10) * 1e-3)}
+        rec10 = {"workload": "BASELINE configs[3] shape on one GPU: %d groups of the mixture (%s; 4 copies of 100 352 generated groups, each copy with its own group "
+                             "indices, i.e. its own chains), S=10, 20 chains x (100+250) sweeps" % (f10x["num_groups"], f10x["mixture"]),
+                 "groups": int(f10x["num_groups"]), "ms_per_schedule": min(ms10), "cluster_sweeps_per_sec": f10x["num_clusters"] * sweeps_per_group / (min(ms10) * 1e-3),
+                 "device_bytes": g10_bytes}
+        del f10x
         if not args.no_cpu_baseline:
             c10 = synth.make_mixture(max(2048, 12 * (os.cpu_count() or 1)), S10, seed=1011)
             og = _oracle.OrcGibbs(orc, c10, *_oracle.build_luts(orc, S10), seed=42)
@@ -440,8 +550,8 @@ def main():
             rec10["gpu_over_cpu_allcores"] = rec10["cluster_sweeps_per_sec"] / rec10["cpu_allcores_cluster_sweeps_per_sec"]
         extra["samples10"] = rec10
         # (1b) BASELINE configs[4]: --noise-genotyping (estimateNoiseAndGenotypes) at 30 samples through the C++ InferenceEngine the executable
-        # ships, beside the default mode on the same batch.  The chains run on the device (bt_gibbs_noise_chain: sweep, noise counts, the
-        # rates drawn from the run's generator, the rebuilt table — no host round trip per iteration).
+        # ships, beside the default mode on the same batch.  The drivers iterate on the host (bt_gibbs_noise_iteration: one synchronisation per iteration, the
+        # rates drawn by libstdc++'s own gamma distribution — bit for bit the reference's; BT_NOISE_ON_DEVICE=1 runs a chain without host round trips).
         from bayestyper_amd.host.inference_engine import InferenceEngine
 
         def noise_pair(flat, S_, chains, label):
@@ -471,7 +581,7 @@ def main():
                                  "(100+250) iterations, wall-clock of the whole driver call (sampler construction and result fetch included)" % (f30["mixture"], chains30))
         rec30["note"] = ("in this mode every genotyper's caches are cleared every iteration (InferenceEngine.cpp:92), so every sweep recomputes its per-(sample, diplotype) "
                          "sums over the k-mer subset, and an iteration lasts as long as its slowest group (a 256-candidate cluster at 30 samples) — on the CPU as well: "
-                         "cpu_allcores_* is the oracle's estimateNoiseAndGenotypes on the same batch.  The chain runs on the device without host round trips")
+                         "cpu_allcores_* is the oracle's estimateNoiseAndGenotypes on the same batch")
         if not args.no_cpu_baseline:
             it_cpu = (2, 3)
             og = _oracle.OrcGibbs(orc, f30, *cd30.tables(), noise_seeding=1, seed=42, chains=1, burn=it_cpu[0], iters=it_cpu[1])
@@ -524,6 +634,10 @@ def main():
         kmc_traffic, kmc_traffic_src = committed_traffic("kmc_bytes_per_scan")
         if (args.groups, S, args.records) != (600_000, 3, 1_000_000_000) or world != 1:   # the committed passes are of the default command
             gibbs_traffic = kmc_traffic = gibbs_traffic_src = kmc_traffic_src = None
+        issue, issue_src = committed_issue_profile()
+        if issue is not None and ((issue["groups"], issue["S"]) != (G, S) or world != 1):
+            issue = issue_src = None
+        SIMDS, CLOCK = 1024, 2.4e9
         shape_note = ("BASELINE configs[2] WGS trio" if S == 3 else "BASELINE configs[3] 10-sample mixture" if S == 10 else "mixture") + \
             ": one launch-sized slice of the unit, %d groups/GPU (%s; heterogeneous structures), S=%d, 20 chains x (100+250) sweeps; k-mer matching: %d scans/step of a " \
             "%d-record KMC stream (13 B, k=55, p=7) into an emptied count table, %d path k-mers, hit rate %.3f, ThreadedKmerBloom fpr 1e-4" % (
@@ -545,10 +659,22 @@ def main():
             "dtype": "f64 log-probabilities over u8 k-mer counts (Gibbs); u64/u8 integer (k-mer matching)",
             "data": "synthetic",
             "config": {"workload": shape_note, "groups_per_gpu": G, "clusters_per_gpu": C, "clusters_total": C_total, "samples": S, "kmc_records_per_gpu_per_sample": R,
-                       "sharding": ("one batch sharded over the ranks (LPT on a cost proxy); " if strong else "a batch of the same size per rank; ") +
-                                   "KMC streams per rank; gather of posterior summaries to rank 0", "sharded_equals_unsharded": verified},
+                       "sharding": ("one batch sharded over the ranks (LPT on a cost proxy); " if strong else "one unit of N launch-sized blocks, block r on rank r (unit-wide group indices); ") +
+                                   "KMC streams per rank; gather of every rank's results (diplotype sampling frequencies + allele k-mer statistics) to rank 0",
+                       "sharded_equals_unsharded": verified, "subset_equals_batch": subset_ok, "per_rank": per_rank,
+                       "result_fetch_ms": float(np.mean(fetch_ms)), "gather_ms": float(np.mean(gather_ms)) if world > 1 else None},
+            "results": results_rec,
             "roofline": {"kernel": "gibbs_hot_kernel + gibbs_simple_kernel (the concurrent launches of one schedule; gibbs_kernel for tiles that do not keep every vertex in LDS)", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gibbs_gbs / HBM_PEAK_GBS, "traffic": gibbs_traffic, "traffic_source": gibbs_traffic_src, "algorithmic_bytes": gibbs_bytes, "avg_launch_ms": gibbs_avg_ms,
+                         "limiter": "VALU issue + latency of a sequential sampler (no dense contraction: MFMA busy cycles 0); the HBM fraction is tiny by construction",
+                         "issue_frac": issue["gibbs"]["valu_issue_cycles_per_schedule"] / (SIMDS * CLOCK * gibbs_avg_ms * 1e-3) if issue else None,
+                         "valu_insts_per_cluster_sweep": issue["gibbs"]["valu_insts_per_cluster_sweep"] if issue else None,
+                         "resident_waves_per_simd": issue["gibbs"]["wave_quad_cycles"] * 4 / (CLOCK * issue["launch_ms_under_pmc"][0] * 1e-3) / SIMDS if issue else None,
+                         "waves_per_simd_by_registers": {"gibbs_simple_kernel": 3, "gibbs_hot_kernel": 2},
+                         "issue_source": issue_src,
+                         "issue_note": "issue_frac = (VALU instructions of one schedule, priced 2 cycles for 32-bit, 4 for f64 add/mul/fma and 64-bit integer, 16 / 8 for "
+                                       "f64 / f32 transcendental: MI355X_MICROARCH.md) / (1024 SIMDs x 2.4 GHz x the launch time measured here); counts from single-schedule "
+                                       "rocprofv3 --pmc passes of the same batch (tools/sq_counters.sh, tools/issue_profile.py), used only when made from the same sources",
                          "note": "latency/issue-bound sequential sampler: the HBM floor (inputs + state once per chain, SURVEY 8d) is tiny by construction; "
                                  "avg_launch_ms spans the sampling launches of one schedule; traffic = FETCH_SIZE + WRITE_SIZE of those launches from the committed PMC "
                                  "passes of this command (separate rocprofv3 --pmc runs, KiB -> bytes), filled in only when they were made from the same device sources "

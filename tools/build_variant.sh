@@ -1,17 +1,14 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <name> [extra hipcc flags]  ->  bayestyper_amd/libbtgpu_<name>.so (load it with BTGPU_LIB=...); tuning experiments only
+# libbtgpu_<tag>.so: the library with extra flags for ONE translation unit (tuning experiments; load with BTGPU_LIB=bayestyper_amd/libbtgpu_<tag>.so)
+# usage: tools/build_variant.sh <tag> <unit without .hip> <flags...>
 set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
-name=$1; shift
+tag=$1; unit=$2; shift 2
 src="$root/bayestyper_amd/csrc"
-obj="$root/scratch/var_${name}_obj"
-mkdir -p "$obj"
+mkdir -p "$root/scratch/variant_obj"
+o="$root/scratch/variant_obj/${unit}_$tag.o"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c "$src/$unit.hip" -o "$o"
 objs=()
-for s in "$src"/*.hip; do
-  o="$obj/$(basename "${s%.hip}").o"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -I"$root/include" "$@" -c "$s" -o "$o" &
-  objs+=("$o")
-done
-wait
-hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$root/bayestyper_amd/libbtgpu_${name}.so"
-echo "built $root/bayestyper_amd/libbtgpu_${name}.so"
+for s in "$src"/*.hip; do b="$(basename "${s%.hip}")"; if [ "$b" = "$unit" ]; then objs+=("$o"); else objs+=("$src/$b.o"); fi; done
+hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$root/bayestyper_amd/libbtgpu_$tag.so"
+echo "built libbtgpu_$tag.so"
