@@ -1143,7 +1143,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
                 ++hot_i;
                 if ((skip_mask >> hot_i) & 1ull) continue;
                 if (a == A_MGEN && d.NMm == 0) continue;          // (only clusters with multicluster k-mers read it)
-                if (a == A_KSCTMP && d.lds_stride == LANES) continue;   // scratch of the k-mer-stats rebuild: LDS only where tiles are narrow
+                if (a == A_KSCTMP) continue;   // (the k-mer-stats rebuild accumulates in registers since round 2: the scratch rows are unused — in narrow tiles they were a third of the LDS block)
                 if (a == A_CUM && d.D2m * d.teams > 16) continue;
                 if (want_simple && a != A_RING) continue;   // (simple_sweeps keeps the cluster's state in registers and its own per-sample words: TileDesc::sblk)
                 // the dense table of unique-k-mer sums is read for every candidate of every sample: a few entries per lane (two-haplotype
@@ -1377,7 +1377,46 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         BT_TRYHIP(hipStreamSynchronize(ctx->stream));
     }
     {
-        const size_t nclass = sizeof(kClassLds) / sizeof(kClassLds[0]);
+        // BT_GIBBS_LDS_CLASSES="a,b,...": upper bounds (bytes) of the launch classes instead of kClassLds (tuning; a last class takes the rest)
+        const bool own_kernel_early = !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
+        std::vector<uint32_t> class_lds(kClassLds, kClassLds + sizeof(kClassLds) / sizeof(kClassLds[0]));
+        if (const char *e = getenv("BT_GIBBS_LDS_CLASSES")) {
+            class_lds.clear();
+            for (const char *q = e; *q;) {
+                class_lds.push_back((uint32_t)strtoul(q, nullptr, 10));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            class_lds.push_back(0xFFFFFFFFu);
+        }
+        else if (!getenv("BT_GIBBS_FIXED_CLASSES")) {
+            // A launch has ONE dynamic LDS size — its hungriest tile's — and the launches of a schedule are LDS-capacity-bound on this batch shape (the sum over
+            // the tiles of LDS x duration against 160 KB per CU): the two cuts between the three classes of the general tiles are placed where they minimise
+            // the LDS charged, sum over the classes of tiles x the class's largest need (2 KB bins; more classes than three queue behind each other).
+            std::vector<uint64_t> cnt(81, 0);
+            std::vector<uint32_t> top(81, 0);
+            for (uint32_t ti = 0; ti < ntiles; ++ti) {
+                if (own_kernel_early && g->tiles[ti].simple && g->tiles[ti].split == 1) continue;
+                const uint32_t hb = tile_lds_bytes(g->tiles[ti]), b = std::min<uint32_t>(80, (hb + 2047) / 2048);
+                cnt[b] += 1;
+                top[b] = std::max(top[b], hb);
+            }
+            auto charged = [&](uint32_t lo, uint32_t hi) {   // bins (lo, hi]
+                uint64_t n = 0;
+                uint32_t m = 0;
+                for (uint32_t b = lo + 1; b <= hi; ++b) n += cnt[b], m = std::max(m, top[b]);
+                return n * m;
+            };
+            uint64_t best = ~0ull;
+            uint32_t c1 = 8, c2 = 16;
+            for (uint32_t a = 1; a < 79; ++a)
+                for (uint32_t b = a + 1; b < 80; ++b) {
+                    const uint64_t v = charged(0, a) + charged(a, b) + charged(b, 80) + charged(0, 0);
+                    if (v < best) best = v, c1 = a, c2 = b;
+                }
+            class_lds = {c1 * 2048u, c2 * 2048u, 0xFFFFFFFFu};
+        }
+        const size_t nclass = class_lds.size();
         std::vector<bt_gibbs::LaunchClass> byb(2 * nclass);   // [LDS class] and [nclass + LDS class]: the same for the tiles gibbs_hot_kernel takes
         const bool hot_kernel = !getenv("BT_GIBBS_NO_HOT_KERNEL");
         auto hot_tile = [&](const TileDesc &d) {
@@ -1397,7 +1436,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
                 continue;
             }
             size_t b = 0;
-            while (hb > kClassLds[b]) ++b;
+            while (hb > class_lds[b]) ++b;
             if (hot_tile(g->tiles[ti])) {
                 b += nclass;
                 byb[b].hot = true;
@@ -1459,6 +1498,14 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
                 BT_TRYHIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi));
                 BT_TRYHIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
             }
+        }
+        if (getenv("BT_GIBBS_DEBUG")) {   // tuning aid: the tiles' LDS need in 2 KB bins (a launch class is charged its hungriest tile's)
+            std::vector<uint32_t> bins(40, 0);
+            for (uint32_t ti = 0; ti < ntiles; ++ti) bins[std::min<uint32_t>(39, tile_lds_bytes(g->tiles[ti]) / 2048)] += 1;
+            fprintf(stderr, "bt_gibbs: tiles by LDS need:");
+            for (uint32_t b = 0; b < 40; ++b)
+                if (bins[b]) fprintf(stderr, " [%u-%u KB: %u]", 2 * b, 2 * b + 2, bins[b]);
+            fprintf(stderr, "\n");
         }
         if (getenv("BT_GIBBS_DEBUG")) {   // tuning aid: how the batch was tiled
             fprintf(stderr, "bt_gibbs: %u tiles in %zu launch classes:", ntiles, g->classes.size());

@@ -344,6 +344,51 @@ __global__ __launch_bounds__(BLOCK) void intercluster_kernel(TableView t, BloomV
     }
 }
 
+// the same over a list of tiles of many regions of one sequence: a tile is SEQ_TILE start positions of one region (positions absolute in `seq`)
+struct RegionTile {
+    uint64_t region_start, region_end, tile_start;   // [region_start, region_end): the region; tile_start: first k-mer start position of the tile
+    uint32_t flags, pad;                              // is_decoy | female ploidy << 8 | male ploidy << 16
+};
+__global__ __launch_bounds__(BLOCK) void intercluster_regions_kernel(TableView t, BloomView bloom, const char *__restrict__ seq, const RegionTile *__restrict__ tiles, uint64_t num_tiles) {
+    __shared__ uint8_t codes[SEQ_TILE + 64];
+    const unsigned k = t.k;
+    for (uint64_t ti = blockIdx.x; ti < num_tiles; ti += gridDim.x) {
+        const RegionTile rt = tiles[ti];
+        const bool is_decoy = (rt.flags & 0xFFu) != 0;
+        const uint32_t fem = (rt.flags >> 8) & 0xFFu, male = (rt.flags >> 16) & 0xFFu;
+        // the k-mers that START in [tile_start, tile_start + SEQ_TILE) and lie inside the region: nucleotides [tile_start, tile_start + SEQ_TILE + k - 1)
+        for (unsigned j = threadIdx.x; j < SEQ_TILE + k - 1; j += BLOCK) {
+            const uint64_t pos = rt.tile_start + j;
+            uint8_t c = 0xFF;
+            if (pos < rt.region_end) {
+                const int code = nt_code(seq[pos]);
+                c = code < 0 ? 0xFF : (uint8_t)code;
+            }
+            codes[j] = c;
+        }
+        __syncthreads();
+        for (unsigned j = threadIdx.x; j < SEQ_TILE; j += BLOCK) {
+            if (rt.tile_start + j + k > rt.region_end) break;
+            Kmer fw{0, 0};
+            bool ok = true;
+            for (unsigned i = 0; i < k; ++i) {
+                const uint8_t c = codes[j + i];
+                ok = ok && (c != 0xFF);
+                const uint64_t v = (uint64_t)(c & 3u);
+                if (i < 32u) fw.lo |= v << (2u * i);
+                else fw.hi |= v << (2u * (i - 32u));
+            }
+            if (!ok) continue;
+            const Kmer can = kmer_canonical(fw, k);
+            if (!bloom_contains(nthash64(can, k), bloom)) continue;
+            const int64_t slot = table_find_or_insert(t, can);
+            if (slot < 0) continue;
+            meta_update(&t.meta[slot], [&](uint32_t m) { return meta_add_intercluster(m, is_decoy, fem, male); });
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void classify_kernel(TableView t, BloomView mg_bloom, const uint64_t *__restrict__ kmers,
                                                          const uint8_t *__restrict__ mult, uint64_t n, uint8_t *__restrict__ excluded) {
     for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
@@ -1219,6 +1264,31 @@ int bt_table_count_intercluster(bt_table *t, bt_bloom *path_bloom, const char *d
     hipLaunchKernelGGL(intercluster_kernel, dim3(grid), dim3(BLOCK), 0, t->ctx->stream, t->v, path_bloom->view(), d_seq, len, is_decoy,
                        female_ploidy, male_ploidy);
     BT_CHECK_LAUNCH();
+    return BT_OK;
+}
+
+// all regions of one chromosome in ONE launch (a call per region is a kernel launch per region: 175 000 launches for a chr20-sized unit)
+int bt_table_count_intercluster_regions(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint32_t num_regions, const uint64_t *h_start, const uint64_t *h_len,
+                                        const uint8_t *h_is_decoy, const uint8_t *h_female_ploidy, const uint8_t *h_male_ploidy) {
+    if (!t || !path_bloom || (num_regions && (!h_start || !h_len || !h_is_decoy || !h_female_ploidy || !h_male_ploidy))) return fail("bt_table_count_intercluster_regions: null argument");
+    if (path_bloom->k != t->k) return fail("bt_table_count_intercluster_regions: k mismatch between table and bloom");
+    std::vector<RegionTile> tiles;
+    for (uint32_t r = 0; r < num_regions; ++r)
+        for (uint64_t a = 0; a < h_len[r]; a += SEQ_TILE)
+            tiles.push_back(RegionTile{h_start[r], h_start[r] + h_len[r], h_start[r] + a, (uint32_t)h_is_decoy[r] | ((uint32_t)h_female_ploidy[r] << 8) | ((uint32_t)h_male_ploidy[r] << 16), 0u});
+    if (tiles.empty()) return BT_OK;
+    BT_HIP(hipSetDevice(t->ctx->device));
+    RegionTile *d_tiles = nullptr;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_tiles), tiles.size() * sizeof(RegionTile)));
+    hipError_t e = hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(RegionTile), hipMemcpyHostToDevice, t->ctx->stream);
+    if (e == hipSuccess) {
+        const unsigned grid = grid_for(tiles.size(), 1, t->ctx->num_cu * 8);
+        hipLaunchKernelGGL(intercluster_regions_kernel, dim3(grid), dim3(BLOCK), 0, t->ctx->stream, t->v, path_bloom->view(), d_seq, (const RegionTile *)d_tiles, (uint64_t)tiles.size());
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = hipStreamSynchronize(t->ctx->stream);   // (the tile list is a host vector and a temporary device buffer)
+    (void)hipFree(d_tiles);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(std::string("bt_table_count_intercluster_regions: ") + hipGetErrorString(e != hipSuccess ? e : e2));
     return BT_OK;
 }
 

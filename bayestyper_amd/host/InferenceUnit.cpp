@@ -1,4 +1,7 @@
 #include "InferenceUnit.hpp"
+#include <vector>
+#include <fstream>
+#include "Parallel.hpp"
 
 #include <zlib.h>
 
@@ -7,7 +10,42 @@
 
 namespace bthost {
 
-void writeGzFile(const std::string &filename, const std::string &content) {
+// one gzip member of `len` bytes (deflate + the 10-byte header and the CRC-32 / length trailer): compress2-style with a gzip wrapper (windowBits 15 + 16)
+static std::string gzipMember(const char *data, size_t len) {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    std::string out(deflateBound(&zs, (uLong)len) + 64, '\0');
+    zs.next_in = (Bytef *)data;
+    zs.avail_in = (uInt)len;
+    zs.next_out = (Bytef *)&out[0];
+    zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t n = out.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) throw std::runtime_error("deflate failed");
+    out.resize(n);
+    return out;
+}
+
+// Large contents (the parameter k-mer FASTA: 56 MB, four seconds of single-thread deflate at a chr20-sized unit) are written as consecutive gzip members
+// of 4 MB of input each, compressed on `threads` host threads: a multi-member file is what `cat a.gz b.gz` gives, and zlib's gzread / gunzip read it as one
+// stream.  One thread (or a small content) writes the single member the reference writes.
+void writeGzFile(const std::string &filename, const std::string &content, unsigned threads) {
+    const size_t piece = 4u << 20;
+    if (threads > 1 && content.size() > 2 * piece) {
+        const size_t parts = (content.size() + piece - 1) / piece;
+        std::vector<std::string> members(parts);
+        parallelFor(parts, threads, [&](size_t a, size_t b, unsigned) {
+            for (size_t i = a; i < b; i++) members[i] = gzipMember(content.data() + i * piece, std::min(piece, content.size() - i * piece));
+        });
+        std::ofstream f(filename, std::ios::binary);
+        if (!f.is_open()) throw std::runtime_error("Unable to write file " + filename);
+        for (auto &m : members) f.write(m.data(), (std::streamsize)m.size());
+        f.close();
+        if (!f) throw std::runtime_error("Error while writing " + filename);
+        return;
+    }
     gzFile f = gzopen(filename.c_str(), "wb");
     if (!f) throw std::runtime_error("Unable to write file " + filename);
     size_t at = 0;

@@ -365,17 +365,25 @@ void KmerCounter::countInterclusterKmers(bt_table *table, bt_bloom *path_bloom, 
         if (chrom < 0) throw std::runtime_error("chromosome " + entry.first + " of an inter-cluster region is not in the genome");
         const std::string &seq = chromosomes.sequence((size_t)chrom);
         DeviceCopy d_seq(ctx, seq.data(), seq.size());
+        std::vector<uint64_t> start, len;
+        std::vector<uint8_t> decoy, female, male;
         for (auto &r : entry.second) {
             if (r.end_position >= seq.size() || r.start_position > r.end_position) throw std::runtime_error("inter-cluster region outside chromosome " + entry.first);
-            uint32_t female = 0, male = 0;
+            uint32_t f = 0, m = 0;
             if (!r.is_decoy) {
                 const auto &gp = chrom_ploidy.getGenderPloidy(r.chrom_name);
-                female = gp[0];
-                male = gp[1];
+                f = gp[0];
+                m = gp[1];
             }
-            check(bt_table_count_intercluster(table, path_bloom, (const char *)d_seq.d + r.start_position, (uint64_t)r.end_position - r.start_position + 1, r.is_decoy ? 1 : 0, female, male),
-                  "bt_table_count_intercluster");
+            start.push_back(r.start_position);
+            len.push_back((uint64_t)r.end_position - r.start_position + 1);
+            decoy.push_back(r.is_decoy ? 1 : 0);
+            female.push_back((uint8_t)f);
+            male.push_back((uint8_t)m);
         }
+        // every region of the chromosome in one launch (a call per region is a kernel launch per region)
+        check(bt_table_count_intercluster_regions(table, path_bloom, (const char *)d_seq.d, (uint32_t)start.size(), start.data(), len.data(), decoy.data(), female.data(), male.data()),
+              "bt_table_count_intercluster_regions");
         check(bt_sync(ctx), "bt_sync");
     }
     checkTable(table, "countInterclusterKmers");

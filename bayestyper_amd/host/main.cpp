@@ -217,12 +217,15 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
     {
         TableHandle parameter_kmer_hash;
         check(bt_table_create(ctx.h, (uint64_t)max_intercluster_kmers + chromosomes.getDecoyLength(), 1, kmer_size, &parameter_kmer_hash.h), "bt_table_create");
+        std::unique_ptr<StageScope> sub(new StageScope("  parameter k-mers: count in inter-cluster regions (GPU)"));
         kmer_counter.countInterclusterParameterKmers(parameter_kmer_hash.h, variant_file_parser.getInterclusterRegions(), chromosomes, path_kmer_bloom.h, parameter_kmer_fraction);
         std::vector<uint64_t> kmers;
         std::vector<uint8_t> flags;
+        sub.reset(new StageScope("  parameter k-mers: export + HybridHash shuffled order (host)"));
         exportTable(parameter_kmer_hash.h, &kmers, &flags);
         // KmerHash::shuffle(seed) then writeKmersToFasta: the first <= 10^6 k-mers with value true (accepted in a non-decoy region and in no decoy)
         const std::vector<uint32_t> order = hybridHashShuffledOrder(kmers.data(), flags.size(), kmer_size, seed);
+        sub.reset(new StageScope("  parameter k-mers: write fasta.gz"));
         std::string fasta = ">k" + std::to_string(kmer_size) + "\n";
         for (uint32_t i : order) {
             if (!(flags[i] & BT_KC_PARAMETER) || (flags[i] & BT_KC_DECOY_OCC)) continue;
@@ -230,7 +233,7 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
             fasta += "\n";
             if (++num_parameter_kmers == max_parameter_kmers) break;
         }
-        writeGzFile(cluster_data_dir + "/" + parameter_kmers_file_prefix + ".fa.gz", fasta);
+        writeGzFile(cluster_data_dir + "/" + parameter_kmers_file_prefix + ".fa.gz", fasta, clampThreads(options.getUInt("threads")));
     }
     std::cout << stamp() << "Wrote " << num_parameter_kmers << " kmers to " << cluster_data_dir << "/" << parameter_kmers_file_prefix << ".fa.gz" << std::endl;
 

@@ -96,6 +96,33 @@ def committed_issue_profile():
     return None, None
 
 
+def rank_batch(groups, S, rank, world, scaling, templates=None):
+    """this rank's groups of the job.  weak (default): the unit is `world` launch-sized blocks of `groups` groups, block r generated (seed 1000 + r) and sampled
+    by rank r; a group's unit-wide index is r * groups_of_a_block + its index in the block.  strong: ONE batch of `groups` groups dealt to the ranks by
+    longest-processing-time on the cost proxy (shard.assign_groups, what `BT_GPUS=N bayesTyper genotype` does with a unit).
+    -> (flat batch of this rank, clusters of the whole job, the unit (strong only, else None), this rank's group ids in the unit (strong only))"""
+    from bayestyper_amd import shard, synth
+
+    if scaling == "strong" and world > 1:
+        unit = synth.make_mixture(groups, S, seed=1000, templates=templates)
+        my_ids = shard.assign_groups(shard.group_cost(unit), world)[rank]
+        flat = shard.take_groups(unit, my_ids)
+        flat["mixture"] = unit["mixture"]
+        return flat, unit["num_clusters"], unit, my_ids
+    flat = synth.make_mixture(groups, S, seed=1000 + rank, templates=templates)
+    flat["group_index"] = (flat["group_index"].astype(np.uint64) + rank * flat["num_groups"]).astype(np.uint32)   # unit-wide group index -> seeds
+    return flat, flat["num_clusters"] * world, None, None
+
+
+def result_words(res, num_clusters):
+    """a launch's results as one word string (what the host layer's gatherResults ships between ranks): [clusters, entries], entries per cluster,
+    (h1 | h2 << 16) per entry, the per-sample counts, the allele k-mer statistics (doubles as word pairs)"""
+    n_ent = np.diff(res["dip_off"]).astype(np.uint32)
+    keys = res["h1"].astype(np.uint32) | (res["h2"].astype(np.uint32) << 16)
+    return np.concatenate([np.asarray([num_clusters, len(keys)], np.uint32), n_ent, keys, np.ascontiguousarray(res["freq"], np.uint32).reshape(-1),
+                           np.ascontiguousarray(res["stats"], np.float64).reshape(-1).view(np.uint32)])
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,19 +184,11 @@ def main():
     strong = args.scaling == "strong" and world > 1
     verify = strong_verify = args.scaling == "strong" and world > 1 and not args.no_verify
     mix_templates = {"B": 10 ** 9, "C": 10 ** 9, "D": 10 ** 9} if args.unique_structures else None   # (capped at the class's group count)
-    if strong:     # ONE batch, sharded: every rank builds the same unit and keeps its groups (global group indices -> seeds)
-        unit = synth.make_mixture(args.groups, S, seed=1000, templates=mix_templates)
-        my_ids = shard.assign_groups(shard.group_cost(unit), world)[rank]
-        flat = shard.take_groups(unit, my_ids)
+    flat, C_total, unit, my_ids = rank_batch(args.groups, S, rank, world, args.scaling, mix_templates)
+    if strong:
         my_clusters = shard.cluster_ids_of(unit, my_ids)
-        flat["mixture"] = unit["mixture"]
-        C_total = unit["num_clusters"]
         if not (verify and rank == 0):
-            del unit
-    else:          # weak: a batch of the same size per rank
-        flat = synth.make_mixture(args.groups, S, seed=1000 + rank, templates=mix_templates)
-        flat["group_index"] = (flat["group_index"].astype(np.uint64) + rank * flat["num_groups"]).astype(np.uint32)   # global group index -> seeds
-        C_total = flat["num_clusters"] * world
+            unit = None
     G, C = flat["num_groups"], flat["num_clusters"]
     lut_g, lut_n = count_model.build_luts(S, mean=15.0, var=30.0, noise_rate=0.05)
     gibbs = lib.Gibbs(ctx, flat, lut_g, lut_n, seed=42)
@@ -186,11 +205,6 @@ def main():
         d_gathered = torch.zeros(sum(c_all) * S * 2 if rank == 0 else 2, dtype=torch.int32, device=dev)   # (strong scaling's check: posterior summaries)
     state = {"res": None, "d_words": None, "d_all": None}
 
-    def result_words(res):
-        """a launch's results as one word string (what the host layer's gatherResults ships): entries per cluster, (h1 | h2 << 16), counts, statistics"""
-        n_ent = np.diff(res["dip_off"]).astype(np.uint32)
-        keys = res["h1"].astype(np.uint32) | (res["h2"].astype(np.uint32) << 16)
-        return np.concatenate([np.asarray([C, len(keys)], np.uint32), n_ent, keys, res["freq"].reshape(-1), res["stats"].reshape(-1).view(np.uint32)])
 
     # ------------------------------------------------------------------ KMC stream + path Bloom + count table (in HBM)
     # under strong scaling the job's stream of args.records records per sample is split over the ranks (every rank scans its share against the
@@ -252,7 +266,7 @@ def main():
         gather_s = 0.0
         if world > 1:
             tg = time.perf_counter()
-            words = torch.from_numpy(result_words(res).view(np.int32)).to(dev)
+            words = torch.from_numpy(result_words(res, C).view(np.int32)).to(dev)
             n_all = torch.zeros(world, dtype=torch.int64, device=dev)
             n_all[rank] = words.numel()
             comm.allreduce(n_all.data_ptr(), world)

@@ -191,6 +191,13 @@ int bt_table_kmer_stats(bt_table *t, const uint8_t *h_gender, uint64_t *h_class_
 int bt_table_count_intercluster(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint64_t len,
                                 int is_decoy, uint32_t female_ploidy, uint32_t male_ploidy);
 
+/* The same for ALL regions of one sequence in one launch (KmerCounter::countInterclusterKmers walks the region list of a unit,
+ * src/bayesTyper/KmerCounter.cpp:349-386: one call per region would be one kernel launch per region).  Region r covers
+ * d_seq[h_start[r] .. h_start[r] + h_len[r]); its k-mers get addInterclusterMultiplicity(h_is_decoy[r], {h_female_ploidy[r], h_male_ploidy[r]}).
+ * The update is commutative, so the result equals the region-by-region calls in any order.  Synchronises the context's stream. */
+int bt_table_count_intercluster_regions(bt_table *t, bt_bloom *path_bloom, const char *d_seq, uint32_t num_regions, const uint64_t *h_start, const uint64_t *h_len,
+                                        const uint8_t *h_is_decoy, const uint8_t *h_female_ploidy, const uint8_t *h_male_ploidy);
+
 /* KmerCounter::countInterclusterParameterKmers (src/bayesTyper/KmerCounter.cpp:161-250) for a batch of disjoint intercluster
  * regions of one device-resident sequence: region r = d_seq[h_start[r] .. h_start[r] + h_len[r]).  Every canonical k-mer of a
  * region that is NOT in the path Bloom filter is, in window order, either recorded as decoy (h_is_decoy[r]) or accepted by a

@@ -1,0 +1,53 @@
+"""bench.py's job sizing for --gpus N (no GPU): weak scaling = one unit of N launch-sized blocks with unit-wide group indices; strong scaling = one batch
+dealt to the ranks; the word string a rank's results travel in."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def test_weak_scaling_is_one_unit_of_launch_sized_blocks():
+    import bench
+
+    world, groups, S = 3, 300, 2
+    parts = [bench.rank_batch(groups, S, r, world, "weak") for r in range(world)]
+    G = parts[0][0]["num_groups"]
+    assert all(p[0]["num_groups"] == G for p in parts), "every rank keeps a launch-sized block: per-GPU work does not shrink with N"
+    assert all(p[1] == sum(q[0]["num_clusters"] for q in parts) or p[1] == p[0]["num_clusters"] * world for p in parts)
+    idx = np.concatenate([p[0]["group_index"] for p in parts])
+    assert len(np.unique(idx)) == world * G and idx.min() == 0 and idx.max() == world * G - 1, "unit-wide group indices: a group's seeds do not depend on its rank"
+    assert not np.array_equal(parts[0][0]["kmer_counts"][:1000], parts[1][0]["kmer_counts"][:1000]), "the blocks are different groups"
+    one = bench.rank_batch(groups, S, 0, 1, "weak")
+    assert one[0]["num_groups"] == G and np.array_equal(one[0]["group_index"], parts[0][0]["group_index"]), "rank 0's block is the N = 1 batch"
+
+
+def test_strong_scaling_deals_one_batch():
+    import bench
+
+    world, groups, S = 2, 300, 2
+    parts = [bench.rank_batch(groups, S, r, world, "strong") for r in range(world)]
+    unit = parts[0][2]
+    assert sum(p[0]["num_groups"] for p in parts) == unit["num_groups"] and all(p[1] == unit["num_clusters"] for p in parts)
+    ids = np.sort(np.concatenate([p[3] for p in parts]))
+    assert np.array_equal(ids, np.arange(unit["num_groups"]))
+    for p in parts:
+        assert np.array_equal(p[0]["group_index"], unit["group_index"][p[3]])
+
+
+def test_result_words_round_trip():
+    import bench
+
+    C, S = 3, 2
+    res = {"dip_off": np.asarray([0, 2, 3, 6], np.uint64), "h1": np.asarray([0, 0, 1, 0, 1, 65535], np.uint16), "h2": np.asarray([0, 1, 1, 65535, 65535, 65535], np.uint16),
+           "freq": np.arange(12, dtype=np.uint32).reshape(6, S), "cell_off": np.asarray([0, 4, 8, 12], np.uint64), "stats": np.linspace(0, 1, 12 * 12).reshape(12, 3, 4)}
+    w = bench.result_words(res, C)
+    assert w.dtype == np.uint32 and int(w[0]) == C and int(w[1]) == 6
+    n_ent = w[2:2 + C]
+    assert np.array_equal(np.concatenate([[0], np.cumsum(n_ent)]), res["dip_off"])
+    keys = w[2 + C:2 + C + 6]
+    assert np.array_equal(keys & 0xFFFF, res["h1"]) and np.array_equal(keys >> 16, res["h2"])
+    freq = w[2 + C + 6:2 + C + 6 + 12]
+    assert np.array_equal(freq, res["freq"].reshape(-1))
+    assert np.array_equal(w[2 + C + 6 + 12:].view(np.float64), res["stats"].reshape(-1))

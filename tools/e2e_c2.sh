@@ -18,8 +18,10 @@ echo "## data set"; t $d/make_c2_dataset $d $L $NV 1 2>&1
 ls -l $d | awk '{print "#   " $5, $9}'
 echo "## bayesTyperTools makeBloom"; ( cd $d && t $tools_exe makeBloom -k sample1 -p $T 2>&1 | tail -4 )
 export BT_STAGE_TIMES=1
-echo "## bayesTyper cluster"; t $exe cluster -v $d/candidates.vcf -s $d/samples.tsv -g $d/genome.fa -o $d/bt -p $T -r 42 > $d/cluster.out 2> $d/cluster.err; tail -30 $d/cluster.err; grep -E "Parsed unit|kmers" $d/cluster.out | head -8
-echo "## bayesTyper genotype"; t $exe genotype -v $d/bt_unit_1/variant_clusters.bin -c $d/bt_cluster_data -s $d/samples.tsv -g $d/genome.fa -o $d/bt -p $T -r 42 > $d/genotype.out 2> $d/genotype.err; tail -30 $d/genotype.err; grep -E "Out of|genotyped|skipped|Estimated negative" $d/genotype.out | head -8
+run_cluster() { $exe cluster -v $d/candidates.vcf -s $d/samples.tsv -g $d/genome.fa -o $d/bt -p $T -r 42 > $d/cluster.out 2> $d/cluster.err; }
+run_genotype() { $exe genotype -v $d/bt_unit_1/variant_clusters.bin -c $d/bt_cluster_data -s $d/samples.tsv -g $d/genome.fa -o $d/bt -p $T -r 42 > $d/genotype.out 2> $d/genotype.err; }
+echo "## bayesTyper cluster"; t run_cluster; tail -30 $d/cluster.err; grep -E "Parsed unit|kmers" $d/cluster.out | head -8
+echo "## bayesTyper genotype"; t run_genotype; tail -30 $d/genotype.err; grep -E "Out of|genotyped|skipped|Estimated negative" $d/genotype.out | head -8
 ls -l $d/bt.vcf 2>/dev/null | awk '{print "# output VCF bytes: " $5}'
 grep -vc '^#' $d/bt.vcf 2>/dev/null | awk '{print "# output VCF records: " $1}'
 } > $dst 2>&1
