@@ -36,6 +36,6 @@ out = {"source_hash": bench.source_hash(), "command": f"tools/sq_counters.sh {ta
                  "wait_inst_any_quad_cycles": cnt.get("SQ_WAIT_INST_ANY"), "waves": cnt.get("SQ_WAVES"),
                  "thread_quad_cycles_valu": cnt.get("SQ_THREAD_CYCLES_VALU"), "active_valu_quad_cycles": cnt.get("SQ_ACTIVE_INST_VALU"),
                  "icache_req": cnt.get("SQC_ICACHE_REQ"), "icache_misses": cnt.get("SQC_ICACHE_MISSES")}}
-dst = os.path.join(ROOT, "profiles", f"{tag}_issue.json")
+dst = os.path.join(ROOT, "gpurun_out", "summ_" + tag, f"{tag}_issue.json")   # (copy it to profiles/: gpurun_out is scratch)
 json.dump(out, open(dst, "w"), indent=1)
 print(dst, json.dumps(out["gibbs"])[:400])

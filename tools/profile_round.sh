@@ -41,5 +41,9 @@ PY
   grep -h clusters $d.log | cut -c1-300 >> $out/summ_$tag/${tag}_sq_graph_stages.txt
   rm -rf $d
 done
-for c in A B C D; do bash tools/sq_counters.sh $tag $c > /dev/null 2>&1; done
+# single-schedule SQ + TCC counters per shape class and for the whole mixture at S = 3 (the bench batch) and per class at S = 10 (the 100 352-group batch the
+# ten-sample record replicates), then the issue-side profile bench.py reads (profiles/<tag>_issue.json)
+for c in A B C D +; do bash tools/sq_counters.sh $tag $c 3 600000 > /dev/null 2>&1; done
+python tools/issue_profile.py $tag 3
+for c in A B C D; do bash tools/sq_counters.sh $tag $c 10 100000 > /dev/null 2>&1; done
 ls -la $out/summ_$tag
