@@ -1509,7 +1509,9 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             if (i + 1 < g->classes.size()) {   // the last class runs on the context's stream
                 int prio_lo = 0, prio_hi = 0;   // the hungrier classes (created first) get the higher dispatch priority
                 BT_TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-                BT_TRYHIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi));
+                int prio = getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi;
+                if (const char *e = getenv("BT_GIBBS_CLASS_PRIO")) prio = atoi(e);   // tuning: 0 = the priority of the context's stream (the two-haplotype class)
+                BT_TRYHIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio));
                 BT_TRYHIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
             }
         }

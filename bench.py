@@ -265,8 +265,6 @@ def main():
             if timed:
                 t_kmc[smp].stop()
         # (2) Gibbs: the whole default schedule for every group of the batch
-        if os.environ.get("BT_BENCH_SYNC_BEFORE_GIBBS"):
-            both_sync()
         if timed:
             t_gibbs.start()
         gibbs.run()
@@ -293,8 +291,10 @@ def main():
             both_sync()
             comm.gather_words(words.data_ptr(), words.numel(), state["d_all"].data_ptr(), state["d_all"].numel())
             ctx.sync()
-            if rank == 0:
-                state["h_all"] = state["d_all"][:total].cpu()   # rank 0 holds every rank's results on the host, as the executable's rank 0 does
+            if rank == 0:   # rank 0 holds every rank's results on the host, as the executable's rank 0 does (pinned staging, allocated once)
+                if state.get("h_all") is None or state["h_all"].numel() < total:
+                    state["h_all"] = torch.empty(int(total * 1.25), dtype=torch.int32, pin_memory=True)
+                state["h_all"][:total].copy_(state["d_all"][:total], non_blocking=True)
             both_sync()
             gather_s = time.perf_counter() - tg
             if strong:
