@@ -71,18 +71,28 @@ struct bt_bloom {
 };
 
 namespace bt {
-// Open-addressing table in HBM, structure of arrays.  state: 0 empty, 1 being written, 2 ready.
+// Open-addressing table in HBM, one packed record per slot: a probe touches ONE 64-byte sector (round 3 kept state / key_lo / key_hi / meta /
+// counts in five arrays: four sectors and four address translations per probed slot).  A slot is slot_words 32-bit words, a multiple of four
+// (32 bytes up to 8 samples, 48 up to 20, 64 up to 30), 16-byte aligned:
+//   word 0 state (0 empty, 1 being written, 2 ready) | word 1 meta (byte0 flags, byte1 max_haploid_multiplicity, byte2 female ic, byte3 male ic)
+//   words 2-3 key_lo | words 4-5 key_hi | words 6.. the samples' count bytes (spad bytes, a multiple of 4) | padding
 struct TableView {
-    uint64_t *key_lo;
-    uint64_t *key_hi;
-    uint32_t *state;
-    uint32_t *meta;      // byte0 flags, byte1 max_haploid_multiplicity, byte2 female ic, byte3 male ic
-    uint32_t *counts;    // spad bytes per slot, viewed as words
-    uint64_t mask;       // capacity - 1
-    uint32_t spad;       // bytes of counts per slot (multiple of 4)
+    uint32_t *slots;
+    uint64_t mask;        // capacity - 1
+    uint32_t slot_words;  // words per slot
+    uint32_t spad;        // bytes of counts per slot (multiple of 4)
     uint32_t k;
+    uint32_t flags;       // bit 0: publish a new key with a release store (BT_TABLE_RELEASE_PUBLISH=1) instead of ordered write-through stores
     unsigned long long *num_keys;   // device counter
     uint32_t *overflow;             // device flag
+    __host__ __device__ inline uint32_t *slot(uint64_t i) const { return slots + i * slot_words; }
+    __host__ __device__ inline uint32_t *state(uint64_t i) const { return slot(i); }
+    __host__ __device__ inline uint32_t *meta(uint64_t i) const { return slot(i) + 1; }
+    __host__ __device__ inline uint64_t *key_lo(uint64_t i) const { return reinterpret_cast<uint64_t *>(slot(i) + 2); }
+    __host__ __device__ inline uint64_t *key_hi(uint64_t i) const { return reinterpret_cast<uint64_t *>(slot(i) + 4); }
+    __host__ __device__ inline uint32_t *counts(uint64_t i) const { return slot(i) + 6; }   // spad / 4 words
+    __host__ __device__ inline const uint8_t *count_bytes(uint64_t i) const { return reinterpret_cast<const uint8_t *>(slot(i) + 6); }
+    __host__ __device__ static inline uint32_t slot_words_for(uint32_t spad) { return (6u + spad / 4u + 3u) & ~3u; }
 };
 }  // namespace bt
 
@@ -110,9 +120,8 @@ struct bt_kmc_scan {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, scanned[2] = {nullptr, nullptr};
     unsigned long long *d_host_hits = nullptr;
-    // buffers of the route-bucketed scan (bt_table.hip: kmc_route_kernel / kmc_probe_kernel), created on first use
-    void *d_route_keys[2] = {nullptr, nullptr}, *d_route_vals[2] = {nullptr, nullptr}, *d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    // buffers of the partitioned scan (bt_table.hip: kmc_partition_kernel / kmc_probe_bucket_kernel), created on first use: [0] the stripe regions, [1] the hit list
+    void *d_route_vals[2] = {nullptr, nullptr};
     uint64_t routed_cap = 0;
     unsigned int *d_part_cursor = nullptr;   // partitioned scan: fill of the 256 bucket regions
     uint32_t part_cap = 0;                   // records per bucket region

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void record_kernel(TableView t, const int64_
     for (uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (uint64_t)gridDim.x * BLOCK) {
         uint8_t f = 0;
         if (slots[j] >= 0) {
-            const uint32_t flags = t.meta[slots[j]] & 0xffu;
+            const uint32_t flags = *t.meta((uint64_t)slots[j]) & 0xffu;
             f = 1;
             if (flags & (BT_KC_DECOY_OCC | BT_KC_MAX_MULTIPLICITY | BT_KC_MULTIGROUP_OCC)) f |= 2;   // isExcluded (KmerCounts.cpp:93-96)
             if (flags & BT_KC_MULTICLUSTER_OCC) f |= 4;
@@ -541,8 +541,8 @@ __global__ __launch_bounds__(BLOCK) void rows_kernel(IndexA A, TableView t, cons
         row_key[2 * (uint64_t)row + 1] = A.hi[a];
         row_flags[row] = list_flags[j];
         const int64_t slot = slots[j];
-        for (uint32_t s = 0; s < S; ++s) row_counts[(uint64_t)row * S + s] = slot >= 0 ? reinterpret_cast<const uint8_t *>(t.counts)[(uint64_t)slot * t.spad + s] : (uint8_t)0;
-        const uint32_t meta = slot >= 0 ? t.meta[slot] : 0u;
+        for (uint32_t s = 0; s < S; ++s) row_counts[(uint64_t)row * S + s] = slot >= 0 ? t.count_bytes((uint64_t)slot)[s] : (uint8_t)0;
+        const uint32_t meta = slot >= 0 ? *t.meta((uint64_t)slot) : 0u;
         row_ic[2 * (uint64_t)row] = (uint8_t)((meta >> 16) & 0xffu);
         row_ic[2 * (uint64_t)row + 1] = (uint8_t)((meta >> 24) & 0xffu);
     }

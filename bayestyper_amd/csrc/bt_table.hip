@@ -20,8 +20,6 @@
 
 #include "bt_rng_device.hpp"
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 using namespace bt;
 
 namespace {
@@ -40,21 +38,47 @@ __device__ inline uint64_t mix64(uint64_t x) {   // murmur3 finaliser
 
 __device__ inline uint64_t table_home(Kmer a, const TableView &t) { return mix64(a.lo ^ mix64(a.hi + 0x9e3779b97f4a7c15ULL)) & t.mask; }
 
-// findKmer: slot or -1.  A slot's key words are read only after its state was observed READY with acquire semantics (the writer
-// publishes with a release store); a BUSY slot is polled again — the loop has a single exit, no lane leaves it from inside.
+// State and key of one slot in one burst: the (state, meta) word pair first, then the key words, issued back to back — three loads of one
+// lane into one 32-byte block, served by one channel in issue order.  A slot's key only changes while its state is BUSY, and a writer
+// publishes with a release store, so "READY and equal" is a match; "READY and different" is confirmed with a second look at the key (now
+// certainly after the state was seen READY) before the probe moves on, so a key is never missed — and never inserted twice.
+struct SlotLook {
+    uint32_t st, cw;
+    uint64_t lo, hi;
+};
+constexpr uint32_t NO_COUNT_WORD = 0xFFFFFFFFu;
+// cword: index of a count word of the slot to fetch in the same burst (the caller's saturating add then starts from it instead of loading it), or NO_COUNT_WORD
+__device__ inline SlotLook slot_look(const TableView &t, uint64_t idx, uint32_t cword = NO_COUNT_WORD) {
+    uint32_t *s = t.slot(idx);
+    SlotLook p;
+    const uint64_t sm = __hip_atomic_load(reinterpret_cast<uint64_t *>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    p.lo = __hip_atomic_load(reinterpret_cast<uint64_t *>(s + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.hi = __hip_atomic_load(reinterpret_cast<uint64_t *>(s + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.cw = cword != NO_COUNT_WORD ? __hip_atomic_load(s + 6 + cword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    p.st = (uint32_t)sm;
+    return p;
+}
+__device__ inline bool slot_holds_other_key(const TableView &t, uint64_t idx, const SlotLook &p, Kmer a) {   // p.st == ST_READY, p's key != a
+    (void)p;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // orders the second look after the READY observation
+    const uint64_t lo = __hip_atomic_load(t.key_lo(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t hi = __hip_atomic_load(t.key_hi(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return lo != a.lo || hi != a.hi;
+}
+
+// findKmer: slot or -1.  A BUSY slot is polled again — the loop has a single exit, no lane leaves it from inside.
 __device__ inline int64_t table_find(const TableView &t, Kmer a) {
     uint64_t idx = table_home(a, t);
     int64_t result = -1;
     bool done = false;
     uint64_t probes = 0;
     while (!done) {
-        const uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (st == ST_EMPTY) {
+        const SlotLook p = slot_look(t, idx);
+        if (p.st == ST_EMPTY) {
             done = true;
-        } else if (st == ST_READY) {
-            const uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lo == a.lo && hi == a.hi) {
+        } else if (p.st == ST_READY) {
+            if ((p.lo == a.lo && p.hi == a.hi) || !slot_holds_other_key(t, idx, p, a)) {
                 result = (int64_t)idx;
                 done = true;
             } else {
@@ -70,28 +94,37 @@ __device__ inline int64_t table_find(const TableView &t, Kmer a) {
 // addKmer: slot of the (possibly new) key, -1 if the table is full.  The lane that wins a slot publishes it INSIDE the loop body
 // (key words, then the READY state with release semantics) before the loop's exit condition is evaluated, so lanes of the same
 // wavefront that poll that slot always see it published on a later iteration.
-__device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a) {
+// cword / cw_seen: a count word to fetch along (slot_look) and its value as seen — 0 for a key this lane has just inserted; a hint for sat_add_byte_from.
+__device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a, uint32_t cword = NO_COUNT_WORD, uint32_t *cw_seen = nullptr) {
     uint64_t idx = table_home(a, t);
     int64_t result = -1;
-    bool done = false, inserted = false;
+    bool done = false;
     uint64_t probes = 0;
+    uint32_t seen = 0;
     while (!done) {
-        uint32_t st = __hip_atomic_load(&t.state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (st == ST_EMPTY) {
-            if (atomicCAS(&t.state[idx], ST_EMPTY, ST_BUSY) == ST_EMPTY) {
-                __hip_atomic_store(&t.key_lo[idx], a.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&t.key_hi[idx], a.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&t.state[idx], ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                inserted = true;
+        const SlotLook p = slot_look(t, idx, cword);
+        if (p.st == ST_EMPTY) {
+            if (atomicCAS(t.state(idx), ST_EMPTY, ST_BUSY) == ST_EMPTY) {
+                // The key words are agent-scope atomic stores: they are written through to the point the other XCDs read from.  The READY state must
+                // not overtake them: the lane waits until they have been acknowledged (a workgroup-scope release fence is exactly that wait), then
+                // stores the state the same way.  A full agent-scope release store would in addition write back every dirty line of this XCD's L2
+                // (buffer_wbl2) — once per inserted key — which nothing here needs: the slot's words are the only data the reader relies on.
+                __hip_atomic_store(t.key_lo(idx), a.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(t.key_hi(idx), a.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t.flags & 1u) {
+                    __hip_atomic_store(t.state(idx), ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(t.state(idx), ST_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 result = (int64_t)idx;
                 done = true;
             }
             // lost the race: the slot is BUSY or READY now; look at it again
-        } else if (st == ST_READY) {
-            const uint64_t lo = __hip_atomic_load(&t.key_lo[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t hi = __hip_atomic_load(&t.key_hi[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lo == a.lo && hi == a.hi) {
+        } else if (p.st == ST_READY) {
+            if ((p.lo == a.lo && p.hi == a.hi) || !slot_holds_other_key(t, idx, p, a)) {
                 result = (int64_t)idx;
+                seen = p.cw;
                 done = true;
             } else {
                 idx = (idx + 1) & t.mask;
@@ -104,7 +137,7 @@ __device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a) {
         // ST_BUSY: poll again
     }
     // (no key counter is kept: millions of inserts would serialise on that one word; bt_table_status counts the READY slots)
-    (void)inserted;
+    if (cw_seen) *cw_seen = seen;
     return result;
 }
 
@@ -120,6 +153,27 @@ __device__ inline void sat_add_byte(uint32_t *words, uint64_t byte_idx, uint32_t
         if (nv > 255u) nv = 255u;
         uint32_t desired = (old & ~(0xFFu << sh)) | (nv << sh);
         if (desired == old) return;
+        uint32_t prev = atomicCAS(w, old, desired);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+
+// the same, starting from a value of the word the caller has already seen (a stale value only costs one more round of the loop)
+__device__ inline void sat_add_byte_from(uint32_t *words, uint64_t byte_idx, uint32_t add, uint32_t old) {
+    uint32_t *w = &words[byte_idx >> 2];
+    const unsigned sh = (unsigned)(byte_idx & 3u) * 8u;
+    while (true) {
+        uint32_t cur = (old >> sh) & 0xFFu;
+        uint32_t nv = cur + add;
+        if (nv > 255u) nv = 255u;
+        uint32_t desired = (old & ~(0xFFu << sh)) | (nv << sh);
+        if (desired == old) {   // nothing to add to this value: make sure the value is current before leaving
+            const uint32_t now = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (now == old) return;
+            old = now;
+            continue;
+        }
         uint32_t prev = atomicCAS(w, old, desired);
         if (prev == old) return;
         old = prev;
@@ -172,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void table_insert_kernel(TableView t, const 
     for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
         Kmer a{kmers[2 * i], kmers[2 * i + 1]};
         int64_t slot = table_find_or_insert(t, a);
-        if (slot >= 0 && mark_parameter) atomicOr(&t.meta[slot], (uint32_t)BT_KC_PARAMETER);
+        if (slot >= 0 && mark_parameter) atomicOr(t.meta(slot), (uint32_t)BT_KC_PARAMETER);
     }
 }
 
@@ -186,7 +240,7 @@ __global__ __launch_bounds__(BLOCK) void table_find_kernel(TableView t, const ui
 // bt_table_status: number of stored keys = READY slots
 __global__ __launch_bounds__(BLOCK) void table_count_kernel(TableView t, uint64_t capacity, unsigned long long *__restrict__ out) {
     unsigned long long mine = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) mine += t.state[i] == ST_READY ? 1u : 0u;
+    for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) mine += *t.state(i) == ST_READY ? 1u : 0u;
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
     if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(out, mine);
 }
@@ -195,11 +249,11 @@ __global__ __launch_bounds__(BLOCK) void table_count_kernel(TableView t, uint64_
 __global__ __launch_bounds__(BLOCK) void table_rehash_kernel(TableView src, uint64_t src_capacity, TableView dst) {
     const uint32_t words = src.spad / 4u;
     for (uint64_t i = blockIdx.x * (uint64_t)BLOCK + threadIdx.x; i < src_capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        if (src.state[i] != ST_READY) continue;
-        const int64_t slot = table_find_or_insert(dst, Kmer{src.key_lo[i], src.key_hi[i]});
+        if (*src.state(i) != ST_READY) continue;
+        const int64_t slot = table_find_or_insert(dst, Kmer{*src.key_lo(i), *src.key_hi(i)});
         if (slot < 0) continue;   // cannot happen: dst is larger than src
-        dst.meta[slot] = src.meta[i];
-        for (uint32_t w = 0; w < words; ++w) dst.counts[(uint64_t)slot * words + w] = src.counts[i * words + w];
+        *dst.meta(slot) = *src.meta(i);
+        for (uint32_t w = 0; w < words; ++w) dst.counts(slot)[w] = src.counts(i)[w];
     }
 }
 
@@ -260,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void param_insert_kernel(TableView t, const 
         const bool decoy = regs[r].is_decoy != 0;
         if (!decoy && c != 2) continue;
         const int64_t slot = table_find_or_insert(t, Kmer{kmers[2 * pos], kmers[2 * pos + 1]});
-        if (slot >= 0) atomicOr(&t.meta[slot], decoy ? (uint32_t)BT_KC_DECOY_OCC : (uint32_t)BT_KC_PARAMETER);
+        if (slot >= 0) atomicOr(t.meta(slot), decoy ? (uint32_t)BT_KC_DECOY_OCC : (uint32_t)BT_KC_PARAMETER);
     }
 }
 
@@ -273,8 +327,8 @@ __global__ __launch_bounds__(BLOCK) void kmer_stats_kernel(TableView t, uint64_t
     __syncthreads();
     unsigned long long *n = acc + 7, *sum = n + (size_t)S * 256, *sumsq = sum + (size_t)S * 256, *nonzero = sumsq + (size_t)S * 256;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        if (t.state[i] != ST_READY) continue;
-        const uint32_t meta = t.meta[i];
+        if (*t.state(i) != ST_READY) continue;
+        const uint32_t meta = *t.meta(i);
         const uint32_t flags = meta & 0xffu;
         atomicAdd(&tally[0], 1u);
         if (flags & BT_KC_CLUSTER_OCC) {
@@ -287,7 +341,7 @@ __global__ __launch_bounds__(BLOCK) void kmer_stats_kernel(TableView t, uint64_t
         } else {
             atomicAdd(&tally[6], 1u);
             if (flags & BT_KC_PARAMETER) {
-                const uint8_t *cnt = reinterpret_cast<const uint8_t *>(t.counts) + i * t.spad;
+                const uint8_t *cnt = t.count_bytes(i);
                 for (uint32_t s = 0; s < S; ++s) {
                     const uint32_t m = (gender_mask >> s) & 1u ? (meta >> 24) & 0xffu : (meta >> 16) & 0xffu;   // male : female
                     const unsigned long long c = cnt[s];
@@ -338,7 +392,7 @@ __global__ __launch_bounds__(BLOCK) void intercluster_kernel(TableView t, BloomV
             if (!bloom_contains(nthash64(can, k), bloom)) continue;
             int64_t slot = table_find_or_insert(t, can);
             if (slot < 0) continue;
-            meta_update(&t.meta[slot], [&](uint32_t m) { return meta_add_intercluster(m, is_decoy != 0, fem, male); });
+            meta_update(t.meta(slot), [&](uint32_t m) { return meta_add_intercluster(m, is_decoy != 0, fem, male); });
         }
         __syncthreads();
     }
@@ -383,7 +437,7 @@ __global__ __launch_bounds__(BLOCK) void intercluster_regions_kernel(TableView t
             if (!bloom_contains(nthash64(can, k), bloom)) continue;
             const int64_t slot = table_find_or_insert(t, can);
             if (slot < 0) continue;
-            meta_update(&t.meta[slot], [&](uint32_t m) { return meta_add_intercluster(m, is_decoy, fem, male); });
+            meta_update(t.meta(slot), [&](uint32_t m) { return meta_add_intercluster(m, is_decoy, fem, male); });
         }
         __syncthreads();
     }
@@ -398,7 +452,7 @@ __global__ __launch_bounds__(BLOCK) void classify_kernel(TableView t, BloomView 
         uint8_t ex = 0;
         if (slot >= 0) {
             const bool is_mg = bloom_contains(nthash64(a, t.k), mg_bloom);
-            uint32_t nm = meta_update(&t.meta[slot], [&](uint32_t old) { return meta_add_cluster(old, m, is_mg); });
+            uint32_t nm = meta_update(t.meta(slot), [&](uint32_t old) { return meta_add_cluster(old, m, is_mg); });
             ex = (nm & (BT_KC_DECOY_OCC | BT_KC_MAX_MULTIPLICITY | BT_KC_MULTIGROUP_OCC)) ? 1 : 0;   // isExcluded, KmerCounts.cpp:93-96
         }
         if (excluded) excluded[i] = ex;
@@ -518,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
             } else if (count >= v.min_count && count <= v.max_count && bloom_contains(nthash64(a, v.k), bloom)) {     // KmerCounter.cpp:412
                 my_hit = 1;
                 int64_t slot = table_find_or_insert(t, a);            // addKmer(kmer, false), :416
-                if (slot >= 0) sat_add_byte(t.counts, (uint64_t)slot * t.spad + sample_idx, count > 255u ? 255u : count);   // :419
+                if (slot >= 0) sat_add_byte(t.counts(slot), sample_idx, count > 255u ? 255u : count);   // :419
             }
         }
         if (!DECODE_ONLY && hit_count) {
@@ -533,183 +587,88 @@ __global__ __launch_bounds__(BLOCK) void kmc_scan_kernel(KmcView v, BloomView bl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Route-bucketed scan against a ThreadedKmerBloom (65 536 sub-filters of ~1-40 KB each).  The direct kernel above pays two random
-// 64-byte sectors of the (cache-exceeding) filter per record.  Here the records of a chunk are first bucketed by the sub-filter they
-// route to — pass 1 decodes every record, computes its ntHash and route and emits (route, {hash, record index}); a radix sort on the
-// 16 route bits groups them — and pass 2 gives every sub-filter one workgroup that stages the sub-filter's bytes in LDS once
-// (coalesced) and probes them there for all of its records; the few hits re-read their record and update the count table.
+// Scan against a ThreadedKmerBloom (65 536 sub-filters of ~1-40 KB each).  The direct kernel above pays two random 64-byte sectors of the
+// (cache-exceeding) filter per record.  Here the records of a chunk are first grouped by the sub-filters they route to, so that the filter
+// bytes a group of records probes stay in cache.  Rounds 2-3 also had a sorted form for sub-filters above 4 KB (route keys, a rocPRIM radix
+// sort on the 16 route bits, one workgroup per sub-filter probing from LDS: 102 B of traffic per record); the partitioned form below now
+// takes every sub-filter size — at 36 KB per sub-filter (a ten-sample path filter) the 256 sub-filters of a bucket no longer fit an XCD's L2
+// but the Infinity Cache holds the eight buckets in flight: 2.08 against 1.66 x 10^10 records/s — and the library sort is gone.
 // Same decisions as the direct kernel, so the table contents are identical.
 // ---------------------------------------------------------------------------------------------
 struct RouteRec {
     uint32_t h_lo, h_hi, idx;   // ntHash of the record's k-mer, record index inside the chunk
 };
 
-// records [rec_offset, rec_offset + n) of the call's record buffer (16-byte aligned base, n_total records)
-__global__ __launch_bounds__(BLOCK) void kmc_route_kernel(KmcView v, uint32_t bloom_k, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t rec_offset, uint64_t n,
-                                                          uint64_t n_total, uint16_t *__restrict__ keys, RouteRec *__restrict__ vals) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[KMC_RECS * KMC_MAX_REC + 32];
-    __shared__ uint64_t block_prefix[2];
-    // ntHash four nucleotides at a time: tab[b] = the Horner contribution of the nucleotides c0 c1 c2 c3 packed in byte b (c0 in the low
-    // bits, hashed first), so that h <- rol(h, 4) ^ tab[b] equals four steps of h <- rol(h, 1) ^ seed[c]
-    __shared__ uint64_t tab[256];
-    for (unsigned b = threadIdx.x; b < 256u; b += BLOCK)
-        tab[b] = rol64(nt_seed(b & 3u), 3) ^ rol64(nt_seed((b >> 2) & 3u), 2) ^ rol64(nt_seed((b >> 4) & 3u), 1) ^ nt_seed((b >> 6) & 3u);
-    __syncthreads();
-    const uint64_t num_chunks = (n + KMC_RECS - 1) / KMC_RECS;
-    for (uint64_t chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
-        const uint64_t rec0 = chunk * KMC_RECS;
-        const unsigned nrec = (unsigned)((n - rec0) < KMC_RECS ? (n - rec0) : KMC_RECS);
-        if (threadIdx.x < 2) block_prefix[threadIdx.x] = kmc_prefix_of(v, first_record + rec_offset + rec0 + (threadIdx.x ? nrec - 1 : 0));
-        const uint64_t byte0 = (rec_offset + rec0) * v.rec_size;
-        const unsigned nbytes = nrec * v.rec_size;
-        const uint64_t a0 = byte0 & ~15ULL;
-        const unsigned lead = (unsigned)(byte0 - a0);
-        const unsigned nvec = (lead + nbytes + 15u) / 16u;
-        const uint64_t total_bytes = n_total * (uint64_t)v.rec_size;
-        for (unsigned j = threadIdx.x; j < nvec; j += BLOCK) {
-            const uint64_t off = a0 + (uint64_t)j * 16u;
-            if (off + 16u <= total_bytes) *reinterpret_cast<uint4 *>(&stage[j * 16u]) = *reinterpret_cast<const uint4 *>(records + off);
-            else
-                for (unsigned q = 0; q < 16u; ++q) stage[j * 16u + q] = (off + q < total_bytes) ? records[off + q] : 0;
-        }
-        __syncthreads();
-        if (threadIdx.x < nrec) {
-            Kmer a;
-            uint32_t count;
-            kmc_decode(v, kmc_prefix_in(v, first_record + rec_offset + rec0 + threadIdx.x, block_prefix[0], block_prefix[1]), &stage[lead + threadIdx.x * v.rec_size], a, count);
-            uint64_t h = 0;
-            {
-                uint64_t w = a.lo;
-                unsigned left = v.k;
-                for (unsigned word = 0; word < 2u && left; ++word, w = a.hi) {
-                    unsigned in_word = left < 32u ? left : 32u;
-                    left -= in_word;
-                    for (; in_word >= 4u; in_word -= 4u, w >>= 8) h = rol64(h, 4) ^ tab[w & 0xFFu];
-                    for (; in_word; --in_word, w >>= 2) h = rol64(h, 1) ^ nt_seed((unsigned)(w & 3u));
-                }
-            }
-            const uint64_t i = rec0 + threadIdx.x;
-            keys[i] = (uint16_t)(nthash64_seeded(h, bloom_k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u));
-            vals[i] = RouteRec{(uint32_t)h, (uint32_t)(h >> 32), (uint32_t)i};
-        }
-        __syncthreads();
-    }
-}
-
-// first index in the sorted keys[0..n) that is >= key
-__device__ inline uint32_t route_lower_bound(const uint16_t *__restrict__ keys, uint32_t n, uint32_t key) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (keys[mid] < key) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
-
-// pass 2: one workgroup per sub-filter: the sub-filter's bytes staged in LDS, every record routed to it probed there; the records that
-// pass all probes (path k-mers present in the sample + false positives, a few per cent) are appended to the chunk's hit list
-__global__ __launch_bounds__(BLOCK) void kmc_probe_kernel(BloomView bloom, const uint16_t *__restrict__ keys, const RouteRec *__restrict__ vals, uint32_t n, uint32_t *__restrict__ hits,
-                                                          unsigned int *__restrict__ num_hits) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t slice[];
-    __shared__ uint32_t range[2];
-    const uint32_t route = blockIdx.x;
-    if (threadIdx.x < 2) range[threadIdx.x] = route_lower_bound(keys, n, route + threadIdx.x);
-    __syncthreads();
-    const uint32_t lo = range[0], hi = range[1];
-    if (lo == hi) return;
-    const uint32_t words = (uint32_t)(bloom.stride / 4u);
-    const uint32_t *src = bloom.words + (uint64_t)route * words;
-    for (uint32_t j = threadIdx.x; j < words; j += BLOCK) slice[j] = src[j];
-    __syncthreads();
-    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(slice);
-    // hits are collected in an LDS queue and moved to the chunk's hit list with ONE global atomic per flush (a counter bumped per
-    // wavefront would serialise a million atomics per chunk on one word)
-    constexpr uint32_t QCAP = 4 * BLOCK;
-    __shared__ uint32_t queue[QCAP];
-    __shared__ uint32_t qn, qbase;
-    if (threadIdx.x == 0) qn = 0;
-    __syncthreads();
-    auto flush = [&]() {
-        __syncthreads();
-        const uint32_t n_q = qn;
-        if (threadIdx.x == 0 && n_q) qbase = atomicAdd(num_hits, n_q);
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < n_q; j += BLOCK) hits[qbase + j] = queue[j];
-        __syncthreads();
-        if (threadIdx.x == 0) qn = 0;
-        __syncthreads();
-    };
-    // The flush decision must be the same in every thread (flush() holds barriers): it is taken on a register that bounds the queue
-    // length from above — at most BLOCK entries per iteration — not on the shared counter, which faster wavefronts may already have
-    // advanced when a slower one reads it.
-    uint32_t q_bound = 0;
-    for (uint32_t i0 = lo; i0 < hi; i0 += BLOCK) {
-        if (q_bound + BLOCK > QCAP) {
-            flush();
-            q_bound = 0;
-        }
-        q_bound += BLOCK;
-        const uint32_t i = i0 + threadIdx.x;
-        bool member = i < hi;
-        uint32_t idx = 0;
-        if (member) {
-            const RouteRec r = vals[i];
-            idx = r.idx;
-            const uint64_t h = (uint64_t)r.h_lo | ((uint64_t)r.h_hi << 32);
-            for (unsigned q = 0; q < bloom.num_hashes && member; ++q) {   // BloomFilter::containsF: stop at the first clear bit
-                const uint64_t pos = bloom_probe_pos(h, q, bloom);
-                member = (bytes[pos >> 3] & (1u << (7u - (unsigned)(pos & 7u)))) != 0;
-            }
-        }
-        if (member) queue[atomicAdd(&qn, 1u)] = idx;
-        __syncthreads();
-    }
-    flush();
-}
-
 // ---------------------------------------------------------------------------------------------
-// Partitioned scan (sub-filters of a few KB: 256 consecutive sub-filters fit an XCD's L2).  The sort of the route-bucketed scan moves every
-// 14-byte route record four more times; here ONE kernel decodes, hashes and writes every route record once, grouped by the upper 8 route
-// bits, and the probe reads it once:
-//   kmc_partition_kernel  — a workgroup takes slabs of 4096 records: the slab's bytes into LDS in one coalesced burst, decode + ntHash
-//                           (hashes stay in registers), an LDS histogram over the 256 buckets, one reservation per bucket and slab in the
-//                           bucket's region (atomicAdd on its cursor), a counting sort of the slab in the same LDS, then the runs (about 16
-//                           records = 192 bytes per bucket and slab) are written out coalesced.  Two workgroups per CU: one loads while the
-//                           other sorts.  A bucket's region holds its expected share + 3 % + 1024 records; a record beyond it (hash routes are
-//                           uniform: it does not happen outside the test that forces it) is probed against the filter in HBM on the spot.
-//   kmc_probe_bucket_kernel — workgroups are mapped so that the ones resident on an XCD work on the same few buckets: the 256 sub-filters
-//                           of a bucket (0.5 MB at the WGS shape) stay in that XCD's L2 while its records stream through.
+// Partitioned scan.  ONE kernel hashes and writes every route record once, grouped by the upper 8 route bits, and the probe reads it once:
+//   kmc_partition_kernel  — a workgroup takes slabs of 4096 records: the slab's bytes into LDS in one coalesced burst; the ntHash is computed
+//                           straight from the raw record bytes (a KMC suffix byte holds four symbols, first symbol in the top bits: one 256-entry
+//                           LDS table per four symbols; the prefix's part once per slab) — the k-mer itself is never assembled here —, an LDS
+//                           histogram over the 256 buckets, one reservation per bucket and slab in the bucket's region (atomicAdd on its cursor),
+//                           a counting sort of the slab in the same LDS, then the runs (about 16 records = 192 bytes per bucket and slab) are
+//                           written out coalesced.  Two workgroups per CU: one loads while the other sorts.  Round 4: a bucket's region is cut into
+//                           eight stripes, stripe = workgroup index mod 8 = the XCD the workgroup runs on: the 16 384 reservations a chunk makes on
+//                           a bucket's cursor (returning atomics on one address, served one after the other) become 2 048 per address, and a
+//                           stripe's frontier lines are only ever written from one XCD's L2.  A stripe holds its expected share + 3 % + 512
+//                           records; a record beyond it (hash routes are uniform: it does not happen outside the test that forces it) is probed
+//                           against the filter in HBM on the spot.
+//   kmc_probe_bucket_kernel — persistent workgroups; the ones resident on an XCD walk through the same buckets in the same order (bucket = 8 g + XCD),
+//                           sharing a bucket's records between them: the 256 sub-filters of a bucket (0.5 MB at the WGS shape) stay in that XCD's L2
+//                           while its records stream through.  Hits are queued in LDS and moved to the chunk's hit list with one global atomic
+//                           per workgroup and chunk (round 3: one per short-lived workgroup, 32 768 on one address per chunk).
 // 13 B record + 12 B written + 12 B read per record (+ the filter once per chunk).  Same decisions as the direct kernel.
 // ---------------------------------------------------------------------------------------------
 #ifndef BT_KMC_PSLAB
 #define BT_KMC_PSLAB 4096
 #endif
 constexpr unsigned PBLOCK = 512, PSLAB = BT_KMC_PSLAB, PRPT = PSLAB / PBLOCK;
+constexpr unsigned PSTRIPES = 8;
+#ifndef BT_KMC_PU
+#define BT_KMC_PU 4
+#endif
+constexpr unsigned PU = BT_KMC_PU;   // records per lane and iteration of the probe kernel
 
 __device__ inline uint32_t route_bucket(uint64_t h, uint32_t bloom_k) { return (uint32_t)((nthash64_seeded(h, bloom_k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) >> 8); }
 
-// dynamic LDS: the slab's raw record bytes (read once, coalesced), later overwritten by the slab's route records in bucket order
-static size_t partition_lds_bytes(uint32_t rec_size) { return std::max<size_t>((size_t)PSLAB * rec_size + 48, (size_t)PSLAB * sizeof(RouteRec)); }
+// dynamic LDS: the slab's raw record bytes (read once, coalesced), later overwritten by the slab's route records in bucket order; then one byte
+// per sorted record: its bucket
+static size_t partition_main_bytes(uint32_t rec_size) { return (std::max<size_t>((size_t)PSLAB * rec_size + 48, (size_t)PSLAB * sizeof(RouteRec)) + 15) & ~(size_t)15; }
+static size_t partition_lds_bytes(uint32_t rec_size) { return partition_main_bytes(rec_size) + PSLAB; }
+
+// ntHash state after the p prefix symbols (most significant symbol first)
+__device__ inline uint64_t kmc_prefix_hash(uint64_t prefix, uint32_t p) {
+    uint64_t h = 0;
+    for (uint32_t j = 0; j < p; ++j) h = rol64(h, 1) ^ nt_seed((unsigned)((prefix >> (2u * (p - 1u - j))) & 3u));
+    return h;
+}
 
 __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomView bloom, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t rec_offset, uint64_t n,
-                                                               uint64_t n_total, RouteRec *__restrict__ part, uint32_t cap, unsigned int *__restrict__ cursor, uint32_t *__restrict__ hits,
-                                                               unsigned int *__restrict__ num_hits) {
+                                                               uint64_t n_total, uint32_t main_bytes, RouteRec *__restrict__ part, uint32_t cap, unsigned int *__restrict__ cursor,
+                                                               uint32_t *__restrict__ hits, unsigned int *__restrict__ num_hits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t part_lds[];
     uint8_t *raw = part_lds;
-    RouteRec *sorted = reinterpret_cast<RouteRec *>(part_lds);   // [PSLAB], after the slab has been decoded
-    __shared__ uint64_t block_prefix[2];
+    RouteRec *sorted = reinterpret_cast<RouteRec *>(part_lds);   // [PSLAB], after the slab has been hashed
+    uint8_t *sbucket = part_lds + main_bytes;                   // [PSLAB] bucket of sorted[i]
+    __shared__ uint64_t block_prefix[2], block_phash[2];
     __shared__ uint64_t tab[256];
     __shared__ uint32_t hist[256], lofs[256], gbase[256], lcur[256], wave_tot[4];
+    // four symbols of a suffix byte at a time: tab[b] = the Horner contribution of the symbols c0 c1 c2 c3 packed in byte b with c0 in the TOP two
+    // bits (kmc_file.cpp:437-474), c0 hashed first, so that h <- rol(h, 4) ^ tab[b] equals four steps of h <- rol(h, 1) ^ seed[c]
     for (unsigned b = threadIdx.x; b < 256u; b += PBLOCK)
-        tab[b] = rol64(nt_seed(b & 3u), 3) ^ rol64(nt_seed((b >> 2) & 3u), 2) ^ rol64(nt_seed((b >> 4) & 3u), 1) ^ nt_seed((b >> 6) & 3u);
+        tab[b] = rol64(nt_seed((b >> 6) & 3u), 3) ^ rol64(nt_seed((b >> 4) & 3u), 2) ^ rol64(nt_seed((b >> 2) & 3u), 1) ^ nt_seed(b & 3u);
+    const uint32_t stripe = blockIdx.x % PSTRIPES;
+    unsigned int *my_cursor = cursor + stripe * 256u;
     const uint64_t num_slabs = (n + PSLAB - 1) / PSLAB;
     const uint64_t total_bytes = n_total * (uint64_t)v.rec_size;
     for (uint64_t slab = blockIdx.x; slab < num_slabs; slab += gridDim.x) {
         const uint64_t slab0 = slab * PSLAB;
         const uint32_t slab_n = (uint32_t)((n - slab0) < PSLAB ? (n - slab0) : PSLAB);
         if (threadIdx.x < 256u) hist[threadIdx.x] = 0;
-        if (threadIdx.x < 2) block_prefix[threadIdx.x] = kmc_prefix_of(v, first_record + rec_offset + slab0 + (threadIdx.x ? slab_n - 1 : 0));
+        if (threadIdx.x < 2) {
+            const uint64_t pf = kmc_prefix_of(v, first_record + rec_offset + slab0 + (threadIdx.x ? slab_n - 1 : 0));
+            block_prefix[threadIdx.x] = pf;
+            block_phash[threadIdx.x] = kmc_prefix_hash(pf, v.p);
+        }
         const uint64_t byte0 = (rec_offset + slab0) * v.rec_size;
         const unsigned nbytes = slab_n * v.rec_size;
         const uint64_t a0 = byte0 & ~15ULL;
@@ -722,31 +681,34 @@ __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomV
                 for (unsigned z = 0; z < 16u; ++z) raw[q * 16u + z] = (off + z < total_bytes) ? records[off + z] : 0;
         }
         __syncthreads();
+        const uint64_t p_first = block_prefix[0], p_last = block_prefix[1];
         uint64_t hh[PRPT];
+        uint32_t bk[PRPT / 4];
         uint32_t valid = 0;
+#pragma unroll
+        for (unsigned j = 0; j < PRPT / 4; ++j) bk[j] = 0;
 #pragma unroll
         for (unsigned j = 0; j < PRPT; ++j) {
             hh[j] = 0;
             const uint32_t r = j * PBLOCK + threadIdx.x;
             if (r >= slab_n) continue;
-            Kmer a;
-            uint32_t count;
-            kmc_decode(v, kmc_prefix_in(v, first_record + rec_offset + slab0 + r, block_prefix[0], block_prefix[1]), &raw[lead + r * v.rec_size], a, count);
-            uint64_t h = 0;
-            uint64_t w = a.lo;
-            unsigned left = v.k;
-            for (unsigned word = 0; word < 2u && left; ++word, w = a.hi) {
-                unsigned in_word = left < 32u ? left : 32u;
-                left -= in_word;
-                for (; in_word >= 4u; in_word -= 4u, w >>= 8) h = rol64(h, 4) ^ tab[w & 0xFFu];
-                for (; in_word; --in_word, w >>= 2) h = rol64(h, 1) ^ nt_seed((unsigned)(w & 3u));
+            // the prefix part: nearly every slab lies inside one prefix or two
+            uint64_t h;
+            if (p_first == p_last) h = block_phash[0];
+            else {
+                const uint64_t pf = kmc_prefix_in(v, first_record + rec_offset + slab0 + r, p_first, p_last);
+                h = pf == p_first ? block_phash[0] : (pf == p_last ? block_phash[1] : kmc_prefix_hash(pf, v.p));
             }
+            const uint8_t *rec = &raw[lead + r * v.rec_size];
+            for (unsigned b = 0; b < v.suffix_bytes; ++b) h = rol64(h, 4) ^ tab[rec[b]];   // (k - p is a multiple of four: bt_kmc_scan_create)
             hh[j] = h;
             valid |= 1u << j;
-            atomicAdd(&hist[route_bucket(h, bloom.k)], 1u);
+            const uint32_t bucket = route_bucket(h, bloom.k);
+            bk[j / 4] |= bucket << (8u * (j & 3u));
+            atomicAdd(&hist[bucket], 1u);
         }
         __syncthreads();   // (every raw byte has been read: the region becomes `sorted`)
-        // exclusive scan of the 256 counts (four wavefronts of 64 bins), one reservation per bucket in its region
+        // exclusive scan of the 256 counts (four wavefronts of 64 bins), one reservation per bucket in its stripe's region
         if (threadIdx.x < 256u) {
             const uint32_t c = hist[threadIdx.x];
             uint32_t incl = c;
@@ -756,7 +718,7 @@ __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomV
             }
             lofs[threadIdx.x] = incl - c;
             if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = incl;
-            gbase[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
+            gbase[threadIdx.x] = c ? atomicAdd(&my_cursor[threadIdx.x], c) : 0u;
         }
         __syncthreads();
         if (threadIdx.x < 256u) {
@@ -770,17 +732,18 @@ __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomV
         for (unsigned j = 0; j < PRPT; ++j)
             if (valid & (1u << j)) {
                 const uint64_t h = hh[j];
-                const uint32_t pos = atomicAdd(&lcur[route_bucket(h, bloom.k)], 1u);
+                const uint32_t bucket = (bk[j / 4] >> (8u * (j & 3u))) & 0xFFu;
+                const uint32_t pos = atomicAdd(&lcur[bucket], 1u);
                 sorted[pos] = RouteRec{(uint32_t)h, (uint32_t)(h >> 32), (uint32_t)(slab0 + j * PBLOCK + threadIdx.x)};
+                sbucket[pos] = (uint8_t)bucket;
             }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < slab_n; i += PBLOCK) {
             const RouteRec r = sorted[i];
-            const uint64_t h = (uint64_t)r.h_lo | ((uint64_t)r.h_hi << 32);
-            const uint32_t b = route_bucket(h, bloom.k);
+            const uint32_t b = sbucket[i];
             const uint32_t dest = gbase[b] + (i - lofs[b]);
-            if (dest < cap) part[(uint64_t)b * cap + dest] = r;
-            else if (bloom_contains(h, bloom)) hits[atomicAdd(num_hits, 1u)] = r.idx;
+            if (dest < cap) part[((uint64_t)b * PSTRIPES + stripe) * cap + dest] = r;
+            else if (bloom_contains((uint64_t)r.h_lo | ((uint64_t)r.h_hi << 32), bloom)) hits[atomicAdd(num_hits, 1u)] = r.idx;
         }
         __syncthreads();
     }
@@ -788,11 +751,14 @@ __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomV
 
 __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom, const RouteRec *__restrict__ part, uint32_t cap, const unsigned int *__restrict__ cursor, uint32_t blocks_per_bucket,
                                                                  uint32_t *__restrict__ hits, unsigned int *__restrict__ num_hits) {
-    // workgroups go to the XCDs round-robin: x % 8 picks the XCD, and all blocks_per_bucket workgroups of bucket 8 g + (x % 8) are neighbours in
-    // dispatch order, so an XCD works its way through one bucket (or a few) at a time
-    const uint32_t x = blockIdx.x, xcd = x & 7u, y = x >> 3, sub = y % blocks_per_bucket, bucket = (y / blocks_per_bucket) * 8u + xcd;
-    const uint32_t filled = cursor[bucket], n = filled < cap ? filled : cap;
-    const RouteRec *src = part + (uint64_t)bucket * cap;
+    // workgroups go to the XCDs round-robin: x % 8 picks the XCD.
+    //   blocks_per_bucket == 0: persistent workgroups — the gridDim.x / 8 workgroups of an XCD share the records of bucket 8 g + (x % 8), g = 0, 1, ...,
+    //                           walking the buckets in the same order;
+    //   blocks_per_bucket > 0:  all blocks_per_bucket workgroups of bucket 8 g + (x % 8) are neighbours in dispatch order.
+    // Either way an XCD works its way through one bucket (or a few) at a time.
+    const uint32_t xcd = blockIdx.x & 7u, y = blockIdx.x >> 3;
+    const uint32_t first_bucket = blocks_per_bucket ? (y / blocks_per_bucket) * 8u + xcd : xcd, bucket_step = blocks_per_bucket ? 256u : 8u;
+    const uint32_t sub = blocks_per_bucket ? y % blocks_per_bucket : y, step = (blocks_per_bucket ? blocks_per_bucket : (gridDim.x >> 3)) * BLOCK;
     // hits (a few per cent of the records) are collected in an LDS queue and moved to the chunk's hit list with one global atomic per workgroup; a
     // hit that finds the queue full goes to the list directly — so the record loop holds no barrier and every wavefront keeps several records in flight
     constexpr uint32_t QCAP = 8 * BLOCK;
@@ -801,31 +767,68 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const uint8_t *filter = reinterpret_cast<const uint8_t *>(bloom.words);
-    const uint32_t step = blocks_per_bucket * BLOCK;
-    for (uint32_t i0 = sub * BLOCK + threadIdx.x; i0 < n; i0 += 2u * step) {
-        RouteRec r[2];
-        bool member[2];
+    for (uint32_t bucket = first_bucket; bucket < 256u; bucket += bucket_step) {
+        // the bucket's records: eight stripes, seen as one sequence
+        uint32_t ofs[PSTRIPES + 1];
+        ofs[0] = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < 2u; ++u) {
-            const uint32_t i = i0 + u * step;
-            member[u] = i < n;
-            r[u] = member[u] ? src[i] : RouteRec{0u, 0u, 0u};
+        for (uint32_t s = 0; s < PSTRIPES; ++s) {
+            const uint32_t filled = cursor[s * 256u + bucket];
+            ofs[s + 1] = ofs[s] + (filled < cap ? filled : cap);
         }
+        const uint32_t n = ofs[PSTRIPES];
+        const RouteRec *src = part + (uint64_t)bucket * PSTRIPES * cap;
+        // PU records per lane at a time, and the probes of one round (hash function q) of all of them issued together: a lane's chain of dependent
+        // accesses per PU records is one record load + as many rounds as its longest-surviving record needs (a clear bit ends a record's probes:
+        // BloomFilter::containsF), not the sum over the records
+        for (uint32_t i0 = sub * BLOCK + threadIdx.x; i0 < n; i0 += PU * step) {
+            RouteRec r[PU];
+            bool in[PU];
 #pragma unroll
-        for (uint32_t u = 0; u < 2u; ++u) {
-            if (!member[u]) continue;
-            const uint64_t h = (uint64_t)r[u].h_lo | ((uint64_t)r[u].h_hi << 32);
-            const uint8_t *bytes = filter + (nthash64_seeded(h, bloom.k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) * bloom.stride;
-            bool in = true;
-            for (unsigned q = 0; q < bloom.num_hashes && in; ++q) {   // BloomFilter::containsF: stop at the first clear bit
-                const uint64_t pos = bloom_probe_pos(h, q, bloom);
-                in = (bytes[pos >> 3] & (1u << (7u - (unsigned)(pos & 7u)))) != 0;
+            for (uint32_t u = 0; u < PU; ++u) {
+                const uint32_t i = i0 + u * step;
+                in[u] = i < n;
+                uint32_t s = 0, o = 0;
+#pragma unroll
+                for (uint32_t q = 1; q < PSTRIPES; ++q)
+                    if (i >= ofs[q]) {
+                        s = q;
+                        o = ofs[q];
+                    }
+                r[u] = in[u] ? src[(uint64_t)s * cap + (i - o)] : RouteRec{0u, 0u, 0u};
             }
-            if (in) {
-                const uint32_t p = atomicAdd(&qn, 1u);
-                if (p < QCAP) queue[p] = r[u].idx;
-                else hits[atomicAdd(num_hits, 1u)] = r[u].idx;
+            uint64_t h[PU];
+            const uint8_t *bytes[PU];
+#pragma unroll
+            for (uint32_t u = 0; u < PU; ++u) {
+                h[u] = (uint64_t)r[u].h_lo | ((uint64_t)r[u].h_hi << 32);
+                bytes[u] = filter + (nthash64_seeded(h[u], bloom.k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) * bloom.stride;
             }
+            for (unsigned q = 0; q < bloom.num_hashes; ++q) {
+                bool any = false;
+#pragma unroll
+                for (uint32_t u = 0; u < PU; ++u) any = any || in[u];
+                if (!any) break;
+                uint32_t byte[PU], bit[PU];
+#pragma unroll
+                for (uint32_t u = 0; u < PU; ++u) {
+                    byte[u] = bit[u] = 0;
+                    if (in[u]) {
+                        const uint64_t pos = bloom_probe_pos(h[u], q, bloom);
+                        bit[u] = 1u << (7u - (unsigned)(pos & 7u));
+                        byte[u] = (uint32_t)bytes[u][pos >> 3];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < PU; ++u) in[u] = in[u] && (byte[u] & bit[u]) != 0;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < PU; ++u)
+                if (in[u]) {
+                    const uint32_t p = atomicAdd(&qn, 1u);
+                    if (p < QCAP) queue[p] = r[u].idx;
+                    else hits[atomicAdd(num_hits, 1u)] = r[u].idx;
+                }
         }
     }
     __syncthreads();
@@ -835,24 +838,76 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom
     for (uint32_t j = threadIdx.x; j < n_q; j += BLOCK) hits[qbase + j] = queue[j];
 }
 
+// A record's bytes from HBM as words: the aligned words that cover its (at most 20) bytes, shifted so that the record starts at bit 0 of w[0]
+// (13 single-byte loads of 64 different lines per wavefront before).  `records` is 16-byte aligned.
+__device__ inline void kmc_load_record_words(const uint8_t *__restrict__ records, uint64_t byte_off, uint32_t rec_size, uint64_t total_bytes, uint32_t (&w)[5]) {
+    const uint64_t a0 = byte_off & ~3ULL;
+    const uint32_t *base = reinterpret_cast<const uint32_t *>(records + a0);
+    const uint32_t sh = (uint32_t)(byte_off & 3ULL) * 8u;
+    const uint32_t nw = (rec_size + 3u) / 4u;   // words of the shifted record (uniform)
+    uint32_t x[6];
+#pragma unroll
+    for (uint32_t i = 0; i < 6u; ++i) x[i] = (i <= nw && a0 + 4u * i < total_bytes) ? base[i] : 0u;   // (a word that starts inside the buffer: the last one may reach up to 3 bytes into the allocation's padding)
+#pragma unroll
+    for (uint32_t i = 0; i < 5u; ++i) w[i] = sh ? ((x[i] >> sh) | (x[i + 1] << (32u - sh))) : x[i];
+}
+__device__ inline uint32_t kmc_word_at(const uint32_t (&w)[5], uint32_t i) { return i == 0 ? w[0] : i == 1 ? w[1] : i == 2 ? w[2] : i == 3 ? w[3] : w[4]; }
+__device__ inline uint32_t kmc_byte_at(const uint32_t (&w)[5], uint32_t b) { return (kmc_word_at(w, b >> 2) >> ((b & 3u) * 8u)) & 0xFFu; }
+
+// kmc_decode on the shifted words of a record
+__device__ inline void kmc_decode_words(const KmcView &v, uint64_t prefix, const uint32_t (&w)[5], Kmer &out, uint32_t &count) {
+    uint64_t bhi = 0, blo = 0;   // symbols s_0 .. s_{k-1}, s_0 most significant, right-aligned at bit 0
+    auto push = [&](uint64_t bits, unsigned nbits) {   // 0 < nbits < 64
+        bhi = (bhi << nbits) | (blo >> (64u - nbits));
+        blo = (blo << nbits) | bits;
+    };
+    if (v.p) {
+        const unsigned pb = 2u * v.p;   // <= 30 bits
+        push(prefix & ((1ULL << pb) - 1ULL), pb);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) {   // suffix bytes are a big-endian number: a little-endian word of four of them, byte-swapped, is its next 32 bits
+        if (4u * i >= v.suffix_bytes) break;
+        const uint32_t nb = v.suffix_bytes - 4u * i < 4u ? v.suffix_bytes - 4u * i : 4u;
+        const uint32_t be = __builtin_bswap32(w[i]);
+        push(nb == 4u ? (uint64_t)be : (uint64_t)(be >> (32u - 8u * nb)), 8u * nb);
+    }
+    uint64_t rlo = rev2bit64(bhi), rhi = rev2bit64(blo);
+    unsigned sh = 2u * (64u - v.k);
+    if (sh == 0) { out.lo = rlo; out.hi = rhi; }
+    else if (sh < 64u) { out.lo = (rlo >> sh) | (rhi << (64u - sh)); out.hi = rhi >> sh; }
+    else if (sh == 64u) { out.lo = rhi; out.hi = 0; }
+    else { out.lo = rhi >> (sh - 64u); out.hi = 0; }
+    count = 0;
+    for (unsigned b = 0; b < v.counter_size; ++b) count |= kmc_byte_at(w, v.suffix_bytes + b) << (8u * b);
+}
+
 // pass 3: the hits of a chunk, one per lane: decode the record again, add its count to the table (KmerCounter.cpp:414-419)
 __global__ __launch_bounds__(BLOCK) void kmc_apply_kernel(KmcView v, TableView t, uint32_t sample_idx, const uint8_t *__restrict__ records, uint64_t first_record, uint64_t rec_offset,
-                                                          const uint32_t *__restrict__ hits, const unsigned int *__restrict__ num_hits, unsigned long long *__restrict__ hit_count) {
+                                                          uint64_t n_total, const uint32_t *__restrict__ hits, const unsigned int *__restrict__ num_hits, unsigned long long *__restrict__ hit_count) {
+    __shared__ unsigned block_hits;
+    if (threadIdx.x == 0) block_hits = 0;
+    __syncthreads();
     const uint32_t nh = *num_hits;
     unsigned my_hits = 0;
     for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < nh; j += gridDim.x * BLOCK) {
         const uint64_t ridx = rec_offset + hits[j];
+        uint32_t w[5];
+        kmc_load_record_words(records, ridx * v.rec_size, v.rec_size, n_total * (uint64_t)v.rec_size, w);
         Kmer a;
         uint32_t count;
-        kmc_decode(v, kmc_prefix_of(v, first_record + ridx), records + ridx * v.rec_size, a, count);
+        kmc_decode_words(v, kmc_prefix_of(v, first_record + ridx), w, a, count);
         if (count < v.min_count || count > v.max_count) continue;
         my_hits += 1;
-        const int64_t slot = table_find_or_insert(t, a);
-        if (slot >= 0) sat_add_byte(t.counts, (uint64_t)slot * t.spad + sample_idx, count > 255u ? 255u : count);
+        uint32_t seen;
+        const int64_t slot = table_find_or_insert(t, a, sample_idx >> 2, &seen);
+        if (slot >= 0) sat_add_byte_from(t.counts(slot), sample_idx, count > 255u ? 255u : count, seen);
     }
-    if (hit_count) {   // one atomic per wavefront
+    if (hit_count) {   // one atomic per workgroup
         for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_down(my_hits, off);
-        if ((threadIdx.x & 63u) == 0 && my_hits) atomicAdd(hit_count, (unsigned long long)my_hits);
+        if ((threadIdx.x & 63u) == 0 && my_hits) atomicAdd(&block_hits, my_hits);
+        __syncthreads();
+        if (threadIdx.x == 0 && block_hits) atomicAdd(hit_count, (unsigned long long)block_hits);
     }
 }
 
@@ -860,19 +915,19 @@ __global__ __launch_bounds__(BLOCK) void kmc_apply_kernel(KmcView v, TableView t
 __global__ __launch_bounds__(BLOCK) void export_count_rows_kernel(TableView t, uint64_t cap, uint8_t *__restrict__ rows, uint64_t capacity_rows, unsigned long long *__restrict__ num_rows) {
     const uint32_t words = t.spad / 4u, row_words = 4u + words;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * BLOCK) {
-        if (t.state[i] != ST_READY) continue;
+        if (*t.state(i) != ST_READY) continue;
         uint32_t any = 0;
-        for (uint32_t w = 0; w < words; ++w) any |= t.counts[i * words + w];
+        for (uint32_t w = 0; w < words; ++w) any |= t.counts(i)[w];
         if (!any) continue;
         const unsigned long long at = atomicAdd(num_rows, 1ULL);
         if (at >= capacity_rows) continue;   // (sizing pass, or an undersized buffer: the host compares the counter with the capacity)
         uint32_t *out = reinterpret_cast<uint32_t *>(rows) + at * row_words;
-        const uint64_t lo = t.key_lo[i], hi = t.key_hi[i];
+        const uint64_t lo = *t.key_lo(i), hi = *t.key_hi(i);
         out[0] = (uint32_t)lo;
         out[1] = (uint32_t)(lo >> 32);
         out[2] = (uint32_t)hi;
         out[3] = (uint32_t)(hi >> 32);
-        for (uint32_t w = 0; w < words; ++w) out[4 + w] = t.counts[i * words + w];
+        for (uint32_t w = 0; w < words; ++w) out[4 + w] = t.counts(i)[w];
     }
 }
 __global__ __launch_bounds__(BLOCK) void merge_count_rows_kernel(TableView t, const uint8_t *__restrict__ rows, uint64_t n) {
@@ -888,7 +943,7 @@ __global__ __launch_bounds__(BLOCK) void merge_count_rows_kernel(TableView t, co
             const uint32_t c = in[4 + w];
             for (uint32_t b = 0; b < 4u; ++b) {
                 const uint32_t add = (c >> (8u * b)) & 0xFFu;
-                if (add) sat_add_byte(t.counts, (uint64_t)slot * t.spad + 4u * w + b, add);
+                if (add) sat_add_byte(t.counts(slot), 4u * w + b, add);
             }
         }
     }
@@ -932,34 +987,26 @@ __global__ __launch_bounds__(BLOCK) void kmc_make_bloom_kernel(KmcView v, BloomV
 extern "C" {
 
 static void table_free_arrays(bt::TableView &v) {
-    (void)hipFree(v.key_lo);
-    (void)hipFree(v.key_hi);
-    (void)hipFree(v.state);
-    (void)hipFree(v.meta);
-    (void)hipFree(v.counts);
+    (void)hipFree(v.slots);
     (void)hipFree(v.num_keys);
     (void)hipFree(v.overflow);
-    v.key_lo = v.key_hi = nullptr;
-    v.state = v.meta = v.counts = v.overflow = nullptr;
+    v.slots = v.overflow = nullptr;
     v.num_keys = nullptr;
 }
 
-// allocate and zero the arrays of a table of `cap` slots; everything allocated so far is released on failure
+// allocate and zero the slots of a table of `cap` slots; everything allocated so far is released on failure
 static int table_alloc_arrays(bt_ctx *ctx, uint64_t cap, uint32_t spad, uint32_t k, bt::TableView &v) {
     v = bt::TableView{};
     v.mask = cap - 1;
     v.spad = spad;
+    v.slot_words = bt::TableView::slot_words_for(spad);
     v.k = k;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&v.key_lo), cap * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.key_hi), cap * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.state), cap * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.meta), cap * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.counts), cap * (uint64_t)spad);
+    if (const char *e = getenv("BT_TABLE_RELEASE_PUBLISH")) v.flags = atoi(e) ? 1u : 0u;
+    const uint64_t bytes = cap * (uint64_t)v.slot_words * 4u;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&v.slots), bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.num_keys), 8);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v.overflow), 4);
-    if (e == hipSuccess) e = hipMemsetAsync(v.state, 0, cap * 4, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(v.meta, 0, cap * 4, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(v.counts, 0, cap * (uint64_t)spad, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(v.slots, 0, bytes, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(v.num_keys, 0, 8, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(v.overflow, 0, 4, ctx->stream);
     if (e != hipSuccess) {
@@ -993,9 +1040,7 @@ int bt_table_create(bt_ctx *ctx, uint64_t expected_size, uint32_t num_samples, u
 int bt_table_clear(bt_table *t) {
     if (!t) return fail("bt_table_clear: null table");
     BT_HIP(hipSetDevice(t->ctx->device));
-    BT_HIP(hipMemsetAsync(t->v.state, 0, t->capacity * 4, t->ctx->stream));
-    BT_HIP(hipMemsetAsync(t->v.meta, 0, t->capacity * 4, t->ctx->stream));
-    BT_HIP(hipMemsetAsync(t->v.counts, 0, t->capacity * (uint64_t)t->spad, t->ctx->stream));
+    BT_HIP(hipMemsetAsync(t->v.slots, 0, t->capacity * (uint64_t)t->v.slot_words * 4u, t->ctx->stream));
     BT_HIP(hipMemsetAsync(t->v.num_keys, 0, 8, t->ctx->stream));
     BT_HIP(hipMemsetAsync(t->v.overflow, 0, 4, t->ctx->stream));
     return BT_OK;
@@ -1086,10 +1131,10 @@ int bt_table_read_slots(bt_table *t, const int64_t *h_slots, uint64_t n, uint8_t
             continue;
         }
         if (h_counts) {
-            BT_HIP(hipMemcpy(cbuf.data(), reinterpret_cast<const uint8_t *>(t->v.counts) + (uint64_t)s * t->spad, t->spad, hipMemcpyDeviceToHost));
+            BT_HIP(hipMemcpy(cbuf.data(), t->v.counts((uint64_t)s), t->spad, hipMemcpyDeviceToHost));
             for (uint32_t j = 0; j < t->num_samples; ++j) h_counts[i * t->num_samples + j] = cbuf[j];
         }
-        if (h_meta) BT_HIP(hipMemcpy(h_meta + i * 4, t->v.meta + s, 4, hipMemcpyDeviceToHost));
+        if (h_meta) BT_HIP(hipMemcpy(h_meta + i * 4, t->v.meta((uint64_t)s), 4, hipMemcpyDeviceToHost));
     }
     return BT_OK;
 }
@@ -1099,25 +1144,23 @@ int bt_table_export(bt_table *t, uint64_t *h_kmers, uint8_t *h_counts, uint8_t *
     BT_HIP(hipSetDevice(t->ctx->device));
     BT_HIP(hipStreamSynchronize(t->ctx->stream));
     const uint64_t cap = t->capacity;
-    std::vector<uint64_t> lo(cap), hi(cap);
-    std::vector<uint32_t> st(cap), meta(cap);
-    std::vector<uint8_t> counts(cap * t->spad);
-    BT_HIP(hipMemcpy(lo.data(), t->v.key_lo, cap * 8, hipMemcpyDeviceToHost));
-    BT_HIP(hipMemcpy(hi.data(), t->v.key_hi, cap * 8, hipMemcpyDeviceToHost));
-    BT_HIP(hipMemcpy(st.data(), t->v.state, cap * 4, hipMemcpyDeviceToHost));
-    BT_HIP(hipMemcpy(meta.data(), t->v.meta, cap * 4, hipMemcpyDeviceToHost));
-    BT_HIP(hipMemcpy(counts.data(), t->v.counts, cap * t->spad, hipMemcpyDeviceToHost));
+    // the slots come over in blocks of 2^20 (a whole table can be tens of gigabytes)
+    const uint32_t sw = t->v.slot_words;
+    const uint64_t block = 1ull << 20;
+    std::vector<uint32_t> buf(std::min(cap, block) * sw);
     uint64_t w = 0;
-    for (uint64_t i = 0; i < cap; ++i) {
-        if (st[i] != ST_READY) continue;
-        if (w >= max_records) return fail("bt_table_export: output arrays too small");
-        if (h_kmers) {
-            h_kmers[2 * w] = lo[i];
-            h_kmers[2 * w + 1] = hi[i];
+    for (uint64_t i0 = 0; i0 < cap; i0 += block) {
+        const uint64_t m = std::min(block, cap - i0);
+        BT_HIP(hipMemcpy(buf.data(), t->v.slot(i0), m * sw * 4u, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < m; ++i) {
+            const uint32_t *sl = &buf[i * sw];
+            if (sl[0] != ST_READY) continue;
+            if (w >= max_records) return fail("bt_table_export: output arrays too small");
+            if (h_kmers) std::memcpy(h_kmers + 2 * w, sl + 2, 16);
+            if (h_counts) std::memcpy(h_counts + w * t->num_samples, sl + 6, t->num_samples);
+            if (h_meta) std::memcpy(h_meta + w * 4, sl + 1, 4);
+            ++w;
         }
-        if (h_counts) for (uint32_t j = 0; j < t->num_samples; ++j) h_counts[w * t->num_samples + j] = counts[i * t->spad + j];
-        if (h_meta) std::memcpy(h_meta + w * 4, &meta[i], 4);
-        ++w;
     }
     *num_written = w;
     return BT_OK;
@@ -1400,55 +1443,39 @@ static KmcView make_kmc_view(const bt_kmc_scan *s) {
 
 static void free_routed(bt_kmc_scan *s) {
     for (int b = 0; b < 2; ++b) {
-        if (s->d_route_keys[b]) (void)hipFree(s->d_route_keys[b]);
         if (s->d_route_vals[b]) (void)hipFree(s->d_route_vals[b]);
-        s->d_route_keys[b] = nullptr;
         s->d_route_vals[b] = nullptr;
     }
-    if (s->d_sort_tmp) (void)hipFree(s->d_sort_tmp);
     if (s->d_num_hits) (void)hipFree(s->d_num_hits);
     if (s->d_part_cursor) (void)hipFree(s->d_part_cursor);
     s->d_part_cursor = nullptr;
     s->part_cap = 0;
-    s->d_sort_tmp = nullptr;
     s->d_num_hits = nullptr;
-    s->sort_tmp_bytes = 0;
     s->routed_cap = 0;
 }
 
-// buffers of the route-bucketed scan for chunks of up to `cap` records (kept with the handle)
+// buffers of the partitioned scan for chunks of up to `cap` records (kept with the handle): the 256 x 8 stripe regions (a stripe's expected
+// share + 3 % + 512 records) and the chunk's hit list
 static int ensure_routed(bt_kmc_scan *s, uint64_t cap) {
     if (s->routed_cap >= cap) return BT_OK;
     free_routed(s);
-    hipError_t e = hipSuccess;
-    // (the first value buffer doubles as the 256 bucket regions of the partitioned scan: a bucket's expected share + 3 % + 1024 records)
-    const uint64_t part_cap = cap / 256 + cap / 256 * 3 / 100 + 1024;
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-        e = hipMalloc(reinterpret_cast<void **>(&s->d_route_keys[b]), cap * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals[b]), std::max<uint64_t>(cap, b == 0 ? 256 * part_cap : 0) * sizeof(RouteRec));
-    }
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_part_cursor), 256 * sizeof(unsigned int));
+    const uint64_t part_cap = cap / (256 * PSTRIPES) + cap / (256 * PSTRIPES) * 3 / 100 + 512;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals[0]), 256 * PSTRIPES * part_cap * sizeof(RouteRec));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals[1]), cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_part_cursor), 256 * PSTRIPES * sizeof(unsigned int));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmc_partition_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)partition_lds_bytes(KMC_MAX_REC));
-    size_t tmp = 0;
-    if (e == hipSuccess)
-        e = rocprim::radix_sort_pairs(nullptr, tmp, (uint16_t *)s->d_route_keys[0], (uint16_t *)s->d_route_keys[1], (RouteRec *)s->d_route_vals[0], (RouteRec *)s->d_route_vals[1],
-                                      (size_t)cap, 0, 16, s->ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&s->d_sort_tmp, std::max<size_t>(tmp, 16));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_num_hits), 4);
     if (e != hipSuccess) {
         free_routed(s);
-        return fail(std::string("bt_kmc_scan: buffers of the route-bucketed scan: ") + hipGetErrorString(e));
+        return fail(std::string("bt_kmc_scan: buffers of the partitioned scan: ") + hipGetErrorString(e));
     }
-    s->sort_tmp_bytes = tmp;
     s->routed_cap = cap;
     s->part_cap = (uint32_t)part_cap;
     return BT_OK;
 }
 
-constexpr uint64_t kRoutedChunk = 1ull << 26;      // records per bucketed chunk (14 bytes of keys + values each, double-buffered)
-constexpr uint64_t kRoutedMinRecords = 1ull << 22;  // below this a sub-filter gets too few records per chunk for its staging to pay
-constexpr uint64_t kRoutedMaxSlice = 64000;         // bytes of one sub-filter that fit the LDS of a workgroup
-constexpr uint64_t kPartMaxSlice = 4096;            // partitioned scan: 256 sub-filters of a bucket (<= 1 MB) stay in an XCD's 4 MB L2 next to the streams
+constexpr uint64_t kRoutedChunk = 1ull << 26;      // records per chunk (12 bytes of route record + 4 of hit list each)
+constexpr uint64_t kRoutedMinRecords = 1ull << 22;  // below this the direct kernel is as fast
 
 int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *d_records,
                     uint64_t first_record, uint64_t n, uint64_t *d_hit_count) {
@@ -1459,10 +1486,10 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
     if ((reinterpret_cast<uintptr_t>(d_records) & 15u) != 0) return fail("bt_kmc_scan_run: d_records must be 16-byte aligned");
     if (n == 0) return BT_OK;
     BT_HIP(hipSetDevice(s->ctx->device));
-    // a ThreadedKmerBloom and enough records: bucket by sub-filter, probe in LDS.  BT_KMC_ROUTED=0 / 1 forces the direct / bucketed kernel.
+    // a ThreadedKmerBloom and enough records: the partitioned form.  BT_KMC_ROUTED=0 / 1 forces the direct / partitioned form.
     const char *force = getenv("BT_KMC_ROUTED");
-    bool routed = path_bloom->num_sub == BT_NUM_SUB_BLOOMS && path_bloom->stride <= kRoutedMaxSlice && n >= kRoutedMinRecords;
-    if (force) routed = path_bloom->num_sub == BT_NUM_SUB_BLOOMS && path_bloom->stride <= kRoutedMaxSlice && atoi(force) != 0;
+    bool routed = path_bloom->num_sub == BT_NUM_SUB_BLOOMS && n >= kRoutedMinRecords;
+    if (force) routed = path_bloom->num_sub == BT_NUM_SUB_BLOOMS && atoi(force) != 0;
     if (!routed) {
         unsigned grid = grid_for((n + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8);
         hipLaunchKernelGGL(kmc_scan_kernel<false>, dim3(grid), dim3(BLOCK), 0, s->ctx->stream, make_kmc_view(s), path_bloom->view(), table->v,
@@ -1475,45 +1502,27 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
     if (const char *e = getenv("BT_KMC_ROUTED_CHUNK")) chunk = std::max<uint64_t>(1024, std::min<uint64_t>(chunk, strtoull(e, nullptr, 0)));   // tests: several chunks at small sizes
     if (ensure_routed(s, chunk) != BT_OK) return BT_ERR;
     const KmcView kv = make_kmc_view(s);
-    bool partitioned = path_bloom->stride <= kPartMaxSlice && chunk < (1ull << 32);
-    if (const char *e = getenv("BT_KMC_PARTITIONED")) partitioned = partitioned && atoi(e) != 0;
     uint32_t part_cap = s->part_cap;
-    if (const char *e = getenv("BT_KMC_PART_CAP")) part_cap = std::max<uint32_t>(1, std::min<uint32_t>(part_cap, (uint32_t)strtoul(e, nullptr, 0)));   // tests: records beyond a bucket's region
-    for (uint64_t off = 0; partitioned && off < n; off += chunk) {
+    if (const char *e = getenv("BT_KMC_PART_CAP")) part_cap = std::max<uint32_t>(1, std::min<uint32_t>(part_cap, (uint32_t)strtoul(e, nullptr, 0)));   // tests: records beyond a stripe's region
+    for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = std::min<uint64_t>(chunk, n - off);
         RouteRec *part = (RouteRec *)s->d_route_vals[0];
         uint32_t *hit_list = reinterpret_cast<uint32_t *>(s->d_route_vals[1]);
         BT_HIP(hipMemsetAsync(s->d_num_hits, 0, 4, s->ctx->stream));
-        BT_HIP(hipMemsetAsync(s->d_part_cursor, 0, 256 * sizeof(unsigned int), s->ctx->stream));
+        BT_HIP(hipMemsetAsync(s->d_part_cursor, 0, 256 * PSTRIPES * sizeof(unsigned int), s->ctx->stream));
         const unsigned pgrid = grid_for((m + PSLAB - 1) / PSLAB, 1, s->ctx->num_cu * 4);
-        hipLaunchKernelGGL(kmc_partition_kernel, dim3(pgrid), dim3(PBLOCK), partition_lds_bytes(s->rec_size), s->ctx->stream, kv, path_bloom->view(), d_records, first_record, off, m, n, part, part_cap,
-                           s->d_part_cursor, hit_list, s->d_num_hits);
+        hipLaunchKernelGGL(kmc_partition_kernel, dim3(pgrid), dim3(PBLOCK), partition_lds_bytes(s->rec_size), s->ctx->stream, kv, path_bloom->view(), d_records, first_record, off, m, n,
+                           (uint32_t)partition_main_bytes(s->rec_size), part, part_cap, s->d_part_cursor, hit_list, s->d_num_hits);
         BT_CHECK_LAUNCH();
-        const uint32_t bpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (m / 256 + BLOCK * 8 - 1) / (BLOCK * 8)));
-        hipLaunchKernelGGL(kmc_probe_bucket_kernel, dim3(256 * bpb), dim3(BLOCK), 0, s->ctx->stream, path_bloom->view(), (const RouteRec *)part, part_cap, (const unsigned int *)s->d_part_cursor, bpb,
+        // blocks per bucket: two rounds of PU records per lane; BT_KMC_PROBE_BPB=0 -> persistent workgroups (eight per CU): measured 2.3x slower (71 against
+        // 31 ms per 10^9 records: every wavefront of the chip in the same phase of the same bucket at the same time)
+        uint32_t bpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (m / 256 + BLOCK * 2 * PU - 1) / (BLOCK * 2 * PU)));
+        if (const char *e = getenv("BT_KMC_PROBE_BPB")) bpb = (uint32_t)std::min<uint64_t>(256, strtoul(e, nullptr, 0));
+        const uint32_t pwgs = bpb ? 256u * bpb : 8u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(s->ctx->num_cu, (m / 256 + BLOCK * 16 - 1) / (BLOCK * 16)));
+        hipLaunchKernelGGL(kmc_probe_bucket_kernel, dim3(pwgs), dim3(BLOCK), 0, s->ctx->stream, path_bloom->view(), (const RouteRec *)part, part_cap, (const unsigned int *)s->d_part_cursor, bpb,
                            hit_list, s->d_num_hits);
         BT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(kmc_apply_kernel, dim3(s->ctx->num_cu * 8), dim3(BLOCK), 0, s->ctx->stream, kv, table->v, sample_idx, d_records, first_record, off, (const uint32_t *)hit_list,
-                           (const unsigned int *)s->d_num_hits, reinterpret_cast<unsigned long long *>(d_hit_count));
-        BT_CHECK_LAUNCH();
-    }
-    if (partitioned) return BT_OK;
-    for (uint64_t off = 0; off < n; off += chunk) {
-        const uint64_t m = std::min<uint64_t>(chunk, n - off);
-        uint16_t *k0 = (uint16_t *)s->d_route_keys[0], *k1 = (uint16_t *)s->d_route_keys[1];
-        RouteRec *v0 = (RouteRec *)s->d_route_vals[0], *v1 = (RouteRec *)s->d_route_vals[1];
-        hipLaunchKernelGGL(kmc_route_kernel, dim3(grid_for((m + KMC_RECS - 1) / KMC_RECS, 1, s->ctx->num_cu * 8)), dim3(BLOCK), 0, s->ctx->stream, kv, path_bloom->k, d_records, first_record, off, m,
-                           n, k0, v0);
-        BT_CHECK_LAUNCH();
-        size_t tmp = s->sort_tmp_bytes;
-        BT_HIP(rocprim::radix_sort_pairs(s->d_sort_tmp, tmp, k0, k1, v0, v1, (size_t)m, 0, 16, s->ctx->stream));
-        // the sorted keys are only needed to find the buckets; the unsorted values' buffer is free again: it holds the hit list
-        uint32_t *hit_list = reinterpret_cast<uint32_t *>(v0);
-        BT_HIP(hipMemsetAsync(s->d_num_hits, 0, 4, s->ctx->stream));
-        hipLaunchKernelGGL(kmc_probe_kernel, dim3(BT_NUM_SUB_BLOOMS), dim3(BLOCK), (size_t)path_bloom->stride, s->ctx->stream, path_bloom->view(), (const uint16_t *)k1, (const RouteRec *)v1,
-                           (uint32_t)m, hit_list, s->d_num_hits);
-        BT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(kmc_apply_kernel, dim3(s->ctx->num_cu * 8), dim3(BLOCK), 0, s->ctx->stream, kv, table->v, sample_idx, d_records, first_record, off, (const uint32_t *)hit_list,
+        hipLaunchKernelGGL(kmc_apply_kernel, dim3(s->ctx->num_cu * 8), dim3(BLOCK), 0, s->ctx->stream, kv, table->v, sample_idx, d_records, first_record, off, n, (const uint32_t *)hit_list,
                            (const unsigned int *)s->d_num_hits, reinterpret_cast<unsigned long long *>(d_hit_count));
         BT_CHECK_LAUNCH();
     }

@@ -132,16 +132,15 @@ def test_threaded_bloom_bit_exact(gpu_ctx, oracle):
     gb.close(), ob.close()
 
 
-@pytest.mark.parametrize("routed", ["0", "1", "partitioned"])
+@pytest.mark.parametrize("routed", ["0", "partitioned"])
 def test_kmc_decode_and_scan(gpu_ctx, oracle, tmp_path, monkeypatch, routed):
     """parseSampleKmers: decode -> path-Bloom -> table add; table contents bit-exact incl. Bloom false positives.
-    routed = 1: the route-bucketed scan (records sorted by sub-filter, sub-filters staged in LDS) forced at this small size;
-    partitioned: the one-pass partition by the upper route bits + probe through L2 (what small sub-filters get); routed = 0: the direct kernel"""
+    partitioned: the one-pass partition by the upper route bits + probe through the caches (what a scan of a ThreadedKmerBloom gets from 2^22 records),
+    forced at this small size; routed = 0: the direct kernel"""
     from bayestyper_amd import lib
     from test_oracle_kmer import make_kmc
 
     monkeypatch.setenv("BT_KMC_ROUTED", "0" if routed == "0" else "1")
-    monkeypatch.setenv("BT_KMC_PARTITIONED", "1" if routed == "partitioned" else "0")
 
     rng = np.random.default_rng(14)
     S = 3
@@ -382,9 +381,10 @@ def test_large_scan_properties(gpu_ctx, oracle):
 
 
 def test_routed_scan_equals_direct_at_scale(gpu_ctx, monkeypatch):
-    """6 x 10^6 records (above the size from which bt_kmc_scan_run buckets the records by sub-filter): the sorted scan (sub-filters staged in
-    LDS) and the partitioned scan (one partition pass, probe through L2) — one chunk, several ragged chunks, and chunks so small that the bucket
-    regions' slack matters — leave exactly the table the direct kernel leaves (keys incl. Bloom false positives, counts, hit count)"""
+    """6 x 10^6 records (above the size from which bt_kmc_scan_run partitions the records by sub-filter): the partitioned scan (one partition pass,
+    probe through the caches) — one chunk, several ragged chunks, chunks so small that the stripe regions' slack matters, stripe regions too small
+    for their share (the records beyond them are probed on the spot), and persistent probe workgroups — leaves exactly the table the direct kernel
+    leaves (keys incl. Bloom false positives, counts, hit count)"""
     from bayestyper_amd import lib
 
     rng = np.random.default_rng(23)
@@ -399,17 +399,21 @@ def test_routed_scan_equals_direct_at_scale(gpu_ctx, monkeypatch):
     bloom.insert(mk)
     d_rec = gpu_ctx.to_device(rec.reshape(-1))
     out = []
-    for routed, chunk, partitioned in (("0", None, None), (None, None, "0"), ("1", "1500007", "0"), (None, None, "1"), ("1", "1500007", "1"), ("1", "70001", "1"), ("1", "2000003", "overflow")):
+    for routed, chunk, extra in (("0", None, None), (None, None, None), ("1", "1500007", None), ("1", "70001", None), ("1", "2000003", "overflow"), ("1", "3000001", "persistent")):
         if routed is None:
             monkeypatch.delenv("BT_KMC_ROUTED", raising=False)
         else:
             monkeypatch.setenv("BT_KMC_ROUTED", routed)
         if chunk:
             monkeypatch.setenv("BT_KMC_ROUTED_CHUNK", chunk)
-        if partitioned:     # "0": the sorted form (LDS-staged sub-filters); "1": the partitioned form; "overflow": bucket regions of 3 000 records for ~7 800
-            monkeypatch.setenv("BT_KMC_PARTITIONED", "0" if partitioned == "0" else "1")
-            if partitioned == "overflow":
-                monkeypatch.setenv("BT_KMC_PART_CAP", "3000")
+        if extra == "overflow":     # stripe regions (a bucket's region is cut into eight) of 400 records for ~980
+            monkeypatch.setenv("BT_KMC_PART_CAP", "400")
+        else:
+            monkeypatch.delenv("BT_KMC_PART_CAP", raising=False)
+        if extra == "persistent":
+            monkeypatch.setenv("BT_KMC_PROBE_BPB", "0")
+        else:
+            monkeypatch.delenv("BT_KMC_PROBE_BPB", raising=False)
         table = lib.Table(gpu_ctx, 400_000, 2, K)
         d_hits = gpu_ctx.buffer(8).zero()
         scan.set_count_range(2, 250)
@@ -423,6 +427,49 @@ def test_routed_scan_equals_direct_at_scale(gpu_ctx, monkeypatch):
         assert hits == ref_hits
         for a, b in zip(tab, ref_tab):
             assert np.array_equal(a, b)
+    scan.close(), bloom.close(), d_rec.free()
+
+
+@pytest.mark.parametrize("k,p,cs", [(55, 7, 2), (55, 3, 4), (55, 11, 1), (31, 7, 1), (31, 3, 2), (64, 4, 2), (64, 0, 1), (21, 9, 1)])
+def test_partitioned_scan_other_record_shapes(gpu_ctx, monkeypatch, k, p, cs):
+    """the partition kernel hashes straight from the raw record bytes (prefix part once per slab, then four symbols per suffix byte), the apply
+    kernel decodes from aligned words: every (k, prefix length, counter size) shape leaves the table the direct kernel leaves"""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(1000 * k + 10 * p + cs)
+    n = 300_000
+    sb = (k - p) // 4          # (KMC picks the prefix length so that k - p is a multiple of four)
+    prefixes = np.sort(rng.integers(0, 4 ** p, size=n))
+    rec = rng.integers(0, 256, size=(n, sb + cs), dtype=np.uint8)
+    rec[:, sb:] = 0
+    rec[:, sb] = rng.integers(1, 256, size=n, dtype=np.uint8)
+    if cs > 1:
+        rec[:, sb + 1] = rng.integers(0, 2, size=n, dtype=np.uint8)   # some counts above 255 (saturate) and above the range
+    lut = np.searchsorted(prefixes, np.arange(4 ** p + 1)).astype(np.uint64)
+    scan = lib.KmcScan(gpu_ctx, k, p, cs, n, lut)
+    gk, gc = scan.decode(rec.reshape(-1), 0, n)
+    mk = np.unique(gk[rng.choice(n, 20_000, replace=False)], axis=0)
+    bloom = lib.Bloom.create(gpu_ctx, len(mk) + 10_000, 1e-3, k, threaded=True)
+    bloom.insert(mk)
+    d_rec = gpu_ctx.to_device(rec.reshape(-1))
+    out = []
+    for routed in ("0", "1"):
+        monkeypatch.setenv("BT_KMC_ROUTED", routed)
+        monkeypatch.setenv("BT_KMC_ROUTED_CHUNK", "100003")
+        table = lib.Table(gpu_ctx, 60_000, 2, k)
+        d_hits = gpu_ctx.buffer(8).zero()
+        scan.set_count_range(2, 400)
+        # ragged calls: the second starts at a record whose byte offset is 16-byte aligned but not at a slab boundary
+        first = 16 * 1001
+        scan.run(bloom, table, 1, d_rec.ptr, 0, first, d_hits.ptr)
+        scan.run(bloom, table, 1, d_rec.ptr + first * (sb + cs), first, n - first, d_hits.ptr)
+        gpu_ctx.sync()
+        out.append((_sorted_export(*table.export()), int(d_hits.download(np.uint64, 1)[0])))
+        table.close(), d_hits.free()
+    (ref_tab, ref_hits), (tab, hits) = out
+    assert ref_hits > 15_000 and hits == ref_hits
+    for a, b in zip(tab, ref_tab):
+        assert np.array_equal(a, b)
     scan.close(), bloom.close(), d_rec.free()
 
 

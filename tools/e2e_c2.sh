@@ -23,6 +23,15 @@ run_genotype() { $exe genotype -v $d/bt_unit_1/variant_clusters.bin -c $d/bt_clu
 echo "## bayesTyper cluster"; t run_cluster; tail -30 $d/cluster.err; grep -E "Parsed unit|kmers" $d/cluster.out | head -8
 echo "## bayesTyper genotype"; t run_genotype; tail -30 $d/genotype.err; grep -E "Out of|genotyped|skipped|Estimated negative" $d/genotype.out | head -8
 ls -l $d/bt.vcf 2>/dev/null | awk '{print "# output VCF bytes: " $5}'
+if [ -n "${BT_E2E_TRACE:-}" ]; then   # kernel trace of a second `genotype` run: totals per kernel + a window of the noise driver's loop
+  echo "## bayesTyper genotype under rocprofv3 --kernel-trace --stats"
+  export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- $exe genotype -v $d/bt_unit_1/variant_clusters.bin -c $d/bt_cluster_data -s $d/samples.tsv -g $d/genome.fa -o $d/bt2 -p $T -r 42 > $d/genotype2.out 2> $d/genotype2.err
+  python $root/tools/kstats.py $d/trace | sort -k9 -n -r | head -16
+  python $root/tools/dispatch_timeline.py $d/trace > $d/timeline.txt
+  n=$(grep -n gibbs_noise_kernel $d/timeline.txt | sed -n 2000p | cut -d: -f1)
+  [ -n "$n" ] && sed -n "$((n - 30)),$((n + 10))p" $d/timeline.txt
+fi
 grep -vc '^#' $d/bt.vcf 2>/dev/null | awk '{print "# output VCF records: " $1}'
 } > $dst 2>&1
 cat $dst

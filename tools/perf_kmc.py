@@ -1,4 +1,5 @@
-"""Time the KMC scan alone (bench.py's stream shape) in its three forms.  usage: perf_kmc.py [records] [path_kmers]"""
+"""Time the KMC scan alone (bench.py's stream shape).  usage: perf_kmc.py [records] [path_kmers] ["name:ENV=VAL,ENV=VAL;name2:..."]
+(path_kmers 50 000 000: 1.9 KB sub-filters, the WGS shape; 1 000 000 000: 36 KB sub-filters, a ten-sample path filter)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -29,13 +30,21 @@ absent = torch.randint(-(2 ** 62), 2 ** 62, (max(P - n_hit, 1), 2), dtype=torch.
 lib.check(lib.bt_bloom_insert_batch(bloom.h, absent.data_ptr(), absent.shape[0])); torch.cuda.synchronize()
 del kmers, cnts, absent
 print("sub-filter bytes:", bloom.info()["num_bits"] // 8, flush=True)
-table = lib.Table(ctx, int(n_hit * 1.5), 3, K)
 d_hits = torch.zeros(1, dtype=torch.int64, device=dev)
 t = lib.Timer(ctx)
-for mode in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["1", "0"]):
-    os.environ["BT_KMC_PARTITIONED"] = mode
-    table.clear(); d_hits.zero_()
+# variants: "name:ENV=VAL,ENV=VAL;name2:..." (argv[3]); default: the partitioned form and the direct kernel
+variants = sys.argv[3] if len(sys.argv) > 3 else "partitioned:BT_KMC_ROUTED=1;direct:BT_KMC_ROUTED=0"
+for var in variants.split(";"):
+    name, _, envs = var.partition(":")
+    sets = [e.split("=", 1) for e in envs.split(",") if e]
+    for k, v in sets: os.environ[k] = v
+    table = lib.Table(ctx, int(n_hit * 1.5), 3, K)
+    d_hits.zero_()
     ms = []
-    for smp in range(3):
-        t.start(); scan.run(bloom, table, smp, records.data_ptr(), 0, R, d_hits.data_ptr()); t.stop(); ms.append(t.elapsed_ms())
-    print(f"partitioned={mode}: scans {[round(x, 1) for x in ms]} ms -> {R / (min(ms) * 1e-3):.3e} records/s; hits {int(d_hits.item())} keys {table.status()['num_keys']}", flush=True)
+    for rep in range(2):
+        table.clear(); torch.cuda.synchronize()
+        for smp in range(3):
+            t.start(); scan.run(bloom, table, smp, records.data_ptr(), 0, R, d_hits.data_ptr()); t.stop(); ms.append(t.elapsed_ms())
+    print(f"{name}: scans {[round(x, 1) for x in ms]} ms -> {3 * R / (sum(ms[3:]) * 1e-3):.3e} records/s over the second round's three scans; hits {int(d_hits.item())} keys {table.status()['num_keys']}", flush=True)
+    table.close()
+    for k, v in sets: os.environ.pop(k, None)
