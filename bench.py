@@ -50,18 +50,32 @@ REC = 13                # (55-7)/4 suffix bytes + 1 counter byte
 KMER_MATCH_BYTES_PER_RECORD = 15.9   # 13 B record + E[probes] + hit * table update, pure-algorithmic floor
 
 
-def source_hash():
+_HASH_SETS = {
+    None: ("bt_gibbs", "bt_rng_device", "bt_table", "bt_bloom", "bt_kmer_device", "bt_internal", "bt_ctx"),
+    "gibbs": ("bt_gibbs", "bt_rng_device", "bt_internal", "bt_ctx"),
+    "kmc": ("bt_table", "bt_bloom", "bt_kmer_device", "bt_internal", "bt_ctx"),
+}
+
+
+def source_hash(part=None):
     """hash of the device sources of the kernels a step runs (Gibbs sampler, count table + KMC scan, Bloom filter, their shared headers — not the
-    graph-stage kernels of bt_paths.hip / bt_find_paths.hip, which a step does not launch): profiles/ summaries made from the same sources carry the same hash"""
+    graph-stage kernels of bt_paths.hip / bt_find_paths.hip, which a step does not launch): profiles/ summaries made from the same sources carry the same hash.
+    part = "gibbs" / "kmc": the sources of the Gibbs launch / of the KMC scan alone (a summary of one of them stays valid when only the other's sources change)"""
     import glob
     import hashlib
 
     h = hashlib.sha256()
-    names = ("bt_gibbs", "bt_rng_device", "bt_table", "bt_bloom", "bt_kmer_device", "bt_internal", "bt_ctx")
+    names = _HASH_SETS[part]
     for f in sorted(f for f in glob.glob(os.path.join(ROOT, "bayestyper_amd", "csrc", "*.h*")) if os.path.basename(f).startswith(names)):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def _matches(d, part):
+    """a profiles/ summary was made from this tree's sources of `part` (or, older summaries, from exactly this tree's sources)"""
+    key = "source_hash_" + part
+    return d.get(key) == source_hash(part) if key in d else d.get("source_hash") == source_hash()
 
 
 def committed_traffic(kind):
@@ -69,13 +83,13 @@ def committed_traffic(kind):
     written by tools/pmc_traffic.py on the GPU box), but only when they were measured on the sources this library was built from"""
     import glob
 
-    mine = source_hash()
+    part = "kmc" if kind.startswith("kmc") else "gibbs"
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("source_hash") == mine and kind in d:
+        if kind in d and _matches(d, part):
             return d[kind], os.path.relpath(f, ROOT)
     return None, None
 
@@ -85,13 +99,12 @@ def committed_issue_profile():
     passes), when measured on the sources this library was built from"""
     import glob
 
-    mine = source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("source_hash") == mine and "gibbs" in d:
+        if "gibbs" in d and _matches(d, "gibbs"):
             return d, os.path.relpath(f, ROOT)
     return None, None
 
@@ -722,7 +735,7 @@ def main():
             "graph_stages": paths,
             "kmer_match_from_host_memory": pcie,
             "gibbs_device_bytes": gibbs_device_bytes,
-            "source_hash": source_hash(),
+            "source_hash": source_hash(), "source_hash_gibbs": source_hash("gibbs"), "source_hash_kmc": source_hash("kmc"),
         }
         out.update(extra)
         if cpu:

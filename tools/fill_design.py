@@ -10,19 +10,22 @@ trace = json.load(open(os.path.join(P, f"{tag}_bench_kernel_trace.json")))
 traffic = json.load(open(os.path.join(P, f"{tag}_traffic.json")))
 
 
-def sq(cls):
+def sq(cls, S=3):
+    """counters of one class's single-schedule passes (tools/sq_counters.sh: '<kernel> <counter> <value> dispatches <n>' per kernel, summed over the
+    sampling kernels) + the launch time under --pmc"""
     d = {}
-    p = os.path.join(P, f"{tag}_sq_{cls}.txt")
+    p = os.path.join(P, f"{tag}_sq_{cls}_S{S}.txt")
     if not os.path.exists(p):
         return None
     for line in open(p):
         a = line.split()
-        if len(a) == 2 and a[0].startswith("SQ_"):
-            d[a[0]] = float(a[1])
+        if len(a) == 5 and a[3] == "dispatches":
+            d[a[1]] = d.get(a[1], 0.0) + float(a[2])
         elif line.startswith("{"):
-            d["ms"] = min(json.loads(line)["ms"])
-            d["clusters"] = json.loads(line)["clusters"]
-    return d
+            j = json.loads(line)
+            d["ms"] = min(j["ms"]) if "ms" not in d else min(d["ms"], min(j["ms"]))
+            d["clusters"] = j["clusters"]
+    return d if "SQ_WAVE_CYCLES" in d else None
 
 
 def e(x):

@@ -26,7 +26,7 @@ typed = sum(cnt.get(k, 0.0) for k in CYC)
 other = cnt["SQ_INSTS_VALU"] - typed          # moves, selects, compares, bit operations, lane operations: 2 cycles
 issue = sum(cnt.get(k, 0.0) * c for k, c in CYC.items()) + other * 2
 clusters = runs[0]["clusters"]
-out = {"source_hash": bench.source_hash(), "command": f"tools/sq_counters.sh {tag} + {S} {runs[0]['groups']}", "S": S, "groups": runs[0]["groups"], "clusters": clusters,
+out = {"source_hash": bench.source_hash(), "source_hash_gibbs": bench.source_hash("gibbs"), "source_hash_kmc": bench.source_hash("kmc"), "command": f"tools/sq_counters.sh {tag} + {S} {runs[0]['groups']}", "S": S, "groups": runs[0]["groups"], "clusters": clusters,
        "launch_ms_under_pmc": [r["ms"][0] for r in runs],
        "gibbs": {"valu_insts_per_schedule": cnt["SQ_INSTS_VALU"], "valu_issue_cycles_per_schedule": issue, "valu_insts_per_cluster_sweep": cnt["SQ_INSTS_VALU"] / (clusters * 7000.0),
                  "valu_by_type": {k.replace("SQ_INSTS_VALU_", "").lower(): cnt.get(k, 0.0) for k in CYC} | {"other": other},

@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         tot[grp][c] += r["sum"] * 1024.0   # the counters are in KiB (MI355X_MICROARCH.md); no x2: most accesses here are narrow, not wide coalesced streams
         detail.append({"kernel": k, "grid": r["grid"], "counter": c, "bytes": r["sum"] * 1024.0})
-out = {"source_hash": bench.source_hash(), "command": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-paths --no-pcie --no-extra (one rocprofv3 --pmc pass per counter)",
+out = {"source_hash": bench.source_hash(), "source_hash_gibbs": bench.source_hash("gibbs"), "source_hash_kmc": bench.source_hash("kmc"), "command": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-paths --no-pcie --no-extra (one rocprofv3 --pmc pass per counter)",
        "gibbs_bytes_per_schedule": tot["gibbs"]["FETCH_SIZE"] + tot["gibbs"]["WRITE_SIZE"], "gibbs_fetch_bytes": tot["gibbs"]["FETCH_SIZE"], "gibbs_write_bytes": tot["gibbs"]["WRITE_SIZE"],
        "kmc_bytes_per_scan": (tot["kmc"]["FETCH_SIZE"] + tot["kmc"]["WRITE_SIZE"]) / S, "kmc_fetch_bytes_per_scan": tot["kmc"]["FETCH_SIZE"] / S, "kmc_write_bytes_per_scan": tot["kmc"]["WRITE_SIZE"] / S,
        "samples": S, "detail": detail}
