@@ -1,4 +1,5 @@
 #include "KmerCounter.hpp"
+#include "StageTimes.hpp"
 #include "Parallel.hpp"
 
 #include <algorithm>
@@ -446,12 +447,15 @@ GibbsBatchData KmerCounter::classifyPathKmers(bt_table *table, const InferenceUn
     check(bt_bloom_load(ctx, multigroup_kmers_bloom_prefix.c_str(), kmer_size, &mg.h), "bt_bloom_load");
     std::vector<uint32_t> num_path_kmers(C);
     std::vector<uint8_t> has_excluded(C);
+    std::unique_ptr<StageScope> st(new StageScope("  classify (bt_paths_classify)"));
     check(bt_paths_classify(unit_paths->h, table, mg.h, num_path_kmers.data(), has_excluded.data()), "bt_paths_classify");
     checkTable(table, "classifyPathKmers");
+    st.reset(new StageScope("  candidates (bt_paths_candidates)"));
 
     // ---- getHaplotypeCandidates of every cluster (VariantClusterGraph.cpp:941-1135) ----
     bt_paths_candidates_sizes sz{};
     check(bt_paths_candidates(unit_paths->h, table, &sz), "bt_paths_candidates");
+    st.reset(new StageScope("  candidates: host arrays + fetch"));
     GibbsBatchData b;
     b.S = S;
     std::vector<uint64_t> kmer_key(std::max<uint64_t>(sz.rows * 2, 1));
@@ -511,6 +515,7 @@ GibbsBatchData KmerCounter::classifyPathKmers(bt_table *table, const InferenceUn
     b.nestdep_var.resize(sz.nestdep_var);
 
     // ---- the group structure (VariantClusterGroup.hpp:60-89) around the bundles ----
+    st.reset(new StageScope("  group structure (host)"));
     const uint32_t G = (uint32_t)unit.variant_cluster_groups.size();
     b.kmer_shared.assign(sz.rows, -1);
     b.group_cluster_off.push_back(0);

@@ -51,3 +51,15 @@ def test_result_words_round_trip():
     freq = w[2 + C + 6:2 + C + 6 + 12]
     assert np.array_equal(freq, res["freq"].reshape(-1))
     assert np.array_equal(w[2 + C + 6 + 12:].view(np.float64), res["stats"].reshape(-1))
+
+
+def test_profile_summaries_are_matched_per_part():
+    """a profiles/ summary carries one hash per part (Gibbs launch / KMC scan): bench.py uses it for roofline.traffic / issue_frac only when that
+    part's sources are the ones the library was built from; older summaries (one hash over everything) still match their exact tree"""
+    import bench
+
+    hg, hk, hall = bench.source_hash("gibbs"), bench.source_hash("kmc"), bench.source_hash()
+    assert len({hg, hk, hall}) == 3
+    assert bench._matches({"source_hash_gibbs": hg, "source_hash_kmc": "0" * 16, "source_hash": "0" * 16}, "gibbs")
+    assert not bench._matches({"source_hash_gibbs": hg, "source_hash_kmc": "0" * 16, "source_hash": hall}, "kmc")
+    assert bench._matches({"source_hash": hall}, "kmc") and not bench._matches({"source_hash": "0" * 16}, "gibbs")
