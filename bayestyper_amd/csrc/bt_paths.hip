@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <thread>
 
 using namespace bt;
 
@@ -647,6 +648,25 @@ struct bt_paths {
 
 namespace {
 
+// host threads of the assembly steps: BT_HOST_THREADS (the executable sets it from -p), else up to 16; never more than one per 256 items
+unsigned host_threads(uint64_t items) {
+    unsigned t = 0;
+    if (const char *e = getenv("BT_HOST_THREADS")) t = (unsigned)std::max(1, atoi(e));
+    else t = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(t, items / 256 + 1));
+}
+template <typename F>
+void run_on_threads(unsigned T, F &&fn) {
+    if (T <= 1) {
+        fn(0u);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back([&fn, t]() { fn(t); });
+    fn(0u);
+    for (auto &th : pool) th.join();
+}
+
 // Host half of getHaplotypeCandidates for one path: running-variant intervals in path-nucleotide coordinates
 // (VariantClusterGraph.cpp:984-1011), haplotype allele indices (:990-996,1095-1102), nested cluster list (:1013-1017,1093)
 void walk_path_host(const bt_paths &p, uint32_t c, uint32_t lp, std::vector<Interval> &iv, std::vector<uint16_t> &alleles, std::vector<uint32_t> &nested) {
@@ -1240,75 +1260,110 @@ int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes 
 #undef TRYC
 #undef HIPC
     if (over) return fail("bt_paths_candidates: a path k-mer occurs more than 127 times on one haplotype (the reference asserts <= 127)");
+    // ---- assembly on the host, on several threads: every thread takes a range of clusters (their rows are a contiguous range of rows, their triples a
+    // contiguous range of the sorted triples), builds its pieces of the lists with offsets relative to the piece, and the pieces are concatenated in
+    // cluster order with the offsets rebased.  (One thread did all of this in rounds 1-3: 0.37 s for 175 000 clusters, more than the unit's sampling launch.)
+    struct Piece {
+        std::vector<uint32_t> unique_off, unique_idx, multi_off, multi_idx, kv_off, kv_bits, hapnest_off, hapnest_idx, nestdep_off, nestdep_cluster, nestdep_var_off;
+        std::vector<uint16_t> kv_var, hap_allele, nestdep_var;
+    };
+    const unsigned T = host_threads(C);
+    std::vector<Piece> piece(T);
     p->has_counts.resize(R);
-    for (uint64_t r = 0; r < R; ++r) p->has_counts[r] = row_flags[r] & 1;
-    // unique / multicluster row lists, in row (= first-seen) order
-    p->unique_off.assign(1, 0);
-    p->multi_off.assign(1, 0);
-    p->unique_idx.clear();
-    p->multi_idx.clear();
-    for (uint32_t c = 0; c < C; ++c) {
-        for (uint32_t r = p->kmer_off[c]; r < p->kmer_off[c + 1]; ++r) (row_flags[r] & 4 ? p->multi_idx : p->unique_idx).push_back(r - p->kmer_off[c]);
-        p->unique_off.push_back((uint32_t)p->unique_idx.size());
-        p->multi_off.push_back((uint32_t)p->multi_idx.size());
-    }
-    // variant_haplotype_indices: the triples arrive sorted by (row, variant, path); entries of a row ordered by variant
-    std::vector<uint32_t> row_cluster(R);
-    for (uint32_t c = 0; c < C; ++c)
-        for (uint32_t r = p->kmer_off[c]; r < p->kmer_off[c + 1]; ++r) row_cluster[r] = c;
-    p->kv_off.assign(R + 1, 0);
-    p->kv_var.clear();
-    p->kv_bits.clear();
-    uint64_t ti = 0;
-    for (uint64_t r = 0; r < R; ++r) {
-        const uint32_t HW = (p->num_paths[row_cluster[r]] + 31) / 32;
-        while (ti < ntrip && (trip[ti] >> 32) == r) {
-            const uint16_t var = (uint16_t)((trip[ti] >> 16) & 0xffff);
-            p->kv_var.push_back(var);
-            const size_t w0 = p->kv_bits.size();
-            p->kv_bits.resize(w0 + HW, 0);
-            while (ti < ntrip && (trip[ti] >> 32) == r && (uint16_t)((trip[ti] >> 16) & 0xffff) == var) {
-                const uint32_t path = (uint32_t)(trip[ti] & 0xffff);
-                p->kv_bits[w0 + (path >> 5)] |= 1u << (path & 31);
-                ++ti;
+    auto work = [&](unsigned t) {
+        Piece &q = piece[t];
+        const uint32_t c0 = (uint32_t)((uint64_t)C * t / T), c1 = (uint32_t)((uint64_t)C * (t + 1) / T);
+        const uint64_t r0 = p->kmer_off[c0], r1 = p->kmer_off[c1];
+        for (uint64_t r = r0; r < r1; ++r) p->has_counts[r] = row_flags[r] & 1;
+        // unique / multicluster row lists, in row (= first-seen) order
+        for (uint32_t c = c0; c < c1; ++c) {
+            for (uint32_t r = p->kmer_off[c]; r < p->kmer_off[c + 1]; ++r) (row_flags[r] & 4 ? q.multi_idx : q.unique_idx).push_back(r - p->kmer_off[c]);
+            q.unique_off.push_back((uint32_t)q.unique_idx.size());
+            q.multi_off.push_back((uint32_t)q.multi_idx.size());
+        }
+        // variant_haplotype_indices: the triples arrive sorted by (row, variant, path); entries of a row ordered by variant
+        uint64_t ti = (uint64_t)(std::lower_bound(trip.begin(), trip.end(), r0 << 32) - trip.begin());
+        for (uint32_t c = c0; c < c1; ++c) {
+            const uint32_t HW = (p->num_paths[c] + 31) / 32;
+            for (uint64_t r = p->kmer_off[c]; r < p->kmer_off[c + 1]; ++r) {
+                while (ti < ntrip && (trip[ti] >> 32) == r) {
+                    const uint16_t var = (uint16_t)((trip[ti] >> 16) & 0xffff);
+                    q.kv_var.push_back(var);
+                    const size_t w0 = q.kv_bits.size();
+                    q.kv_bits.resize(w0 + HW, 0);
+                    while (ti < ntrip && (trip[ti] >> 32) == r && (uint16_t)((trip[ti] >> 16) & 0xffff) == var) {
+                        const uint32_t path = (uint32_t)(trip[ti] & 0xffff);
+                        q.kv_bits[w0 + (path >> 5)] |= 1u << (path & 31);
+                        ++ti;
+                    }
+                }
+                q.kv_off.push_back((uint32_t)q.kv_var.size());
             }
         }
-        p->kv_off[r + 1] = (uint32_t)p->kv_var.size();
-    }
-    // haplotypes and the nested dependency map (host: O(paths x vertices))
-    p->hap_allele.clear();
-    p->hapnest_off.assign(1, 0);
-    p->hapnest_idx.clear();
-    p->nestdep_off.assign(1, 0);
-    p->nestdep_cluster.clear();
-    p->nestdep_var_off.assign(1, 0);
-    p->nestdep_var.clear();
-    std::vector<Interval> iv_dummy;
-    std::vector<uint16_t> alleles;
-    std::vector<uint32_t> nested;
-    for (uint32_t c = 0; c < C; ++c) {
-        for (uint32_t lp = 0; lp < p->num_paths[c]; ++lp) {
-            iv_dummy.clear();
-            walk_path_host(*p, c, lp, iv_dummy, alleles, nested);
-            p->hap_allele.insert(p->hap_allele.end(), alleles.begin(), alleles.end());
-            p->hapnest_idx.insert(p->hapnest_idx.end(), nested.begin(), nested.end());
-            p->hapnest_off.push_back((uint32_t)p->hapnest_idx.size());
+        // haplotypes and the nested dependency map (O(paths x vertices))
+        std::vector<Interval> iv_dummy;
+        std::vector<uint16_t> alleles;
+        std::vector<uint32_t> nested;
+        for (uint32_t c = c0; c < c1; ++c) {
+            for (uint32_t lp = 0; lp < p->num_paths[c]; ++lp) {
+                iv_dummy.clear();
+                walk_path_host(*p, c, lp, iv_dummy, alleles, nested);
+                q.hap_allele.insert(q.hap_allele.end(), alleles.begin(), alleles.end());
+                q.hapnest_idx.insert(q.hapnest_idx.end(), nested.begin(), nested.end());
+                q.hapnest_off.push_back((uint32_t)q.hapnest_idx.size());
+            }
+            std::map<uint32_t, std::vector<uint16_t>> dep;   // VariantClusterGraph.cpp:1112-1132
+            for (uint32_t v = p->vertex_off[c]; v < p->vertex_off[c + 1]; ++v) {
+                if (p->vertex_nested[v] == 0xFFFFFFFFu) continue;
+                auto &lst = dep[p->vertex_nested[v]];
+                if (p->vertex_variant[v] != 0xFFFF) lst.push_back(p->vertex_variant[v]);
+                for (uint32_t r = p->refvar_off[v]; r < p->refvar_off[v + 1]; ++r) lst.push_back(p->refvar[r]);
+                std::sort(lst.begin(), lst.end(), std::greater<uint16_t>());
+            }
+            for (auto &e : dep) {
+                q.nestdep_cluster.push_back(e.first);
+                q.nestdep_var.insert(q.nestdep_var.end(), e.second.begin(), e.second.end());
+                q.nestdep_var_off.push_back((uint32_t)q.nestdep_var.size());
+            }
+            q.nestdep_off.push_back((uint32_t)q.nestdep_cluster.size());
         }
-        std::map<uint32_t, std::vector<uint16_t>> dep;   // VariantClusterGraph.cpp:1112-1132
-        for (uint32_t v = p->vertex_off[c]; v < p->vertex_off[c + 1]; ++v) {
-            if (p->vertex_nested[v] == 0xFFFFFFFFu) continue;
-            auto &lst = dep[p->vertex_nested[v]];
-            if (p->vertex_variant[v] != 0xFFFF) lst.push_back(p->vertex_variant[v]);
-            for (uint32_t r = p->refvar_off[v]; r < p->refvar_off[v + 1]; ++r) lst.push_back(p->refvar[r]);
-            std::sort(lst.begin(), lst.end(), std::greater<uint16_t>());
+    };
+    run_on_threads(T, work);
+    // concatenation: `idx` lists appended as they are, `off` lists (cumulative ends, relative to the piece) rebased on what precedes the piece
+    auto cat = [&](auto &dst, auto Piece::*m) {
+        size_t n = 0;
+        for (auto &q : piece) n += (q.*m).size();
+        dst.clear();
+        dst.reserve(n);
+        for (auto &q : piece) dst.insert(dst.end(), (q.*m).begin(), (q.*m).end());
+    };
+    auto cat_off = [&](std::vector<uint32_t> &dst, std::vector<uint32_t> Piece::*off, auto Piece::*idx) {
+        size_t n = 1;
+        for (auto &q : piece) n += (q.*off).size();
+        dst.clear();
+        dst.reserve(n);
+        dst.push_back(0);
+        uint32_t base = 0;
+        for (auto &q : piece) {
+            for (uint32_t v : q.*off) dst.push_back(base + v);
+            base += (uint32_t)(q.*idx).size();
         }
-        for (auto &e : dep) {
-            p->nestdep_cluster.push_back(e.first);
-            p->nestdep_var.insert(p->nestdep_var.end(), e.second.begin(), e.second.end());
-            p->nestdep_var_off.push_back((uint32_t)p->nestdep_var.size());
-        }
-        p->nestdep_off.push_back((uint32_t)p->nestdep_cluster.size());
-    }
+    };
+    cat_off(p->unique_off, &Piece::unique_off, &Piece::unique_idx);
+    cat_off(p->multi_off, &Piece::multi_off, &Piece::multi_idx);
+    cat_off(p->kv_off, &Piece::kv_off, &Piece::kv_var);
+    cat_off(p->hapnest_off, &Piece::hapnest_off, &Piece::hapnest_idx);
+    cat_off(p->nestdep_off, &Piece::nestdep_off, &Piece::nestdep_cluster);
+    cat_off(p->nestdep_var_off, &Piece::nestdep_var_off, &Piece::nestdep_var);
+    cat(p->unique_idx, &Piece::unique_idx);
+    cat(p->multi_idx, &Piece::multi_idx);
+    cat(p->kv_var, &Piece::kv_var);
+    cat(p->kv_bits, &Piece::kv_bits);
+    cat(p->hap_allele, &Piece::hap_allele);
+    cat(p->hapnest_idx, &Piece::hapnest_idx);
+    cat(p->nestdep_cluster, &Piece::nestdep_cluster);
+    cat(p->nestdep_var, &Piece::nestdep_var);
+    piece.clear();
     p->have_candidates = true;
     sizes->rows = R;
     sizes->mult_bytes = p->mult.size();
@@ -1327,8 +1382,16 @@ int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes 
 int bt_paths_candidates_fetch(bt_paths *p, bt_paths_candidates_out *o) {
     if (!p || !o) return fail("bt_paths_candidates_fetch: null argument");
     if (!p->have_candidates) return fail("bt_paths_candidates_fetch: bt_paths_candidates has not run");
-    auto cp = [](const auto &v, auto *dst) {
-        if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0]));
+    auto cp = [](const auto &v, auto *dst) {   // (the large arrays on several threads: one core's memcpy into fresh pages is the slow part)
+        if (!dst || v.empty()) return;
+        const size_t bytes = v.size() * sizeof(v[0]);
+        const unsigned T = host_threads(bytes >> 14);   // at least 4 MB per thread
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(v.data());
+        uint8_t *out = reinterpret_cast<uint8_t *>(dst);
+        run_on_threads(T, [&](unsigned t) {
+            const size_t a = bytes * t / T / 64 * 64, b = t + 1 == T ? bytes : bytes * (t + 1) / T / 64 * 64;
+            if (b > a) std::memcpy(out + a, src + a, b - a);
+        });
     };
     cp(p->kmer_off, o->kmer_off);
     cp(p->mult, o->hap_kmer_mult);

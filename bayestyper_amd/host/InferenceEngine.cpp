@@ -69,6 +69,10 @@ struct GpuSampler : GibbsSampler {
     void setLut(const double *genomic, const double *noise) override { check(bt_gibbs_set_lut(g, genomic, noise), "bt_gibbs_set_lut"); }
     void setNoiseLut(const double *noise) override { check(bt_gibbs_set_noise_lut(g, noise), "bt_gibbs_set_noise_lut"); }
     void initChain(uint32_t chain) override { check(bt_gibbs_init_chain(g, chain), "bt_gibbs_init_chain"); }
+    bool resetGroups() override {
+        check(bt_gibbs_reset_groups(g), "bt_gibbs_reset_groups");
+        return true;
+    }
     void sweep(uint32_t n, bool collect) override { check(bt_gibbs_sweep(g, n, collect ? 1 : 0), "bt_gibbs_sweep"); }
     void run() override { check(bt_gibbs_run(g), "bt_gibbs_run"); }
     void sync() override {
@@ -244,16 +248,29 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
     if (!out.is_open()) throw std::runtime_error("Unable to write file " + output_prefix + ".txt");
     out << noiseParameterHeader(sample_names);
     std::vector<double> mean(S, 0.0);
+    std::unique_ptr<Sampler> sampler;
+    std::vector<uint32_t> sampler_groups;
     for (uint32_t chain = 0; chain < opt.chains; chain++) {
         std::vector<uint32_t> mine;
         for (uint32_t g : selector.nextChain())
             if (local[g] >= 0) mine.push_back((uint32_t)local[g]);
-        std::unique_ptr<Sampler> sampler;
-        if (!mine.empty()) {
-            // a fresh sampler per chain: genotypers are constructed with seed + (i+1)(chain+1) (:70) and deleted afterwards (resetGroupsCallback, :240-251)
-            sampler = newSampler(1, unit.take(mine));
-            sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
+        // The genotypers of a chain are constructed with seed + (i+1)(chain+1) (:70) and deleted afterwards (resetGroupsCallback, :240-251).  A unit
+        // with fewer variants than the batch size selects the same (sorted) groups in every chain: the previous chain's sampler then only has its
+        // groups reset — the reference's own sequence — instead of the subset copy + tile construction per chain (twenty times the whole unit: about
+        // half of this stage at chr20 size).  Otherwise, and for a sampler that cannot reset, a fresh sampler.
+        const bool again = sampler && !mine.empty() && mine == sampler_groups && sampler->resetGroups();
+        if (again) {
+            sampler->setNoiseLut(cd->noiseTable().data());
             sampler->initChain(chain);
+        } else {
+            sampler.reset();
+            sampler_groups.clear();
+            if (!mine.empty()) {
+                sampler = newSampler(1, unit.take(mine));
+                sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
+                sampler->initChain(chain);
+                sampler_groups = mine;
+            }
         }
         pending_noise = false;   // (the chain's sampler starts with the current table)
         logRow(out, chain + 1, 0, cd->getNoiseRates());
@@ -261,9 +278,9 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
             if (opt.burn_in < it)
                 for (size_t s = 0; s < S; s++) mean[s] += rates[s];
         });
-        sampler.reset();
         cd->resetNoiseRates();
     }
+    sampler.reset();
     for (auto &m : mean) m /= (double)opt.samples * opt.chains;
     cd->setNoiseRates(mean);
     logRow(out, 0, 0, cd->getNoiseRates());

@@ -71,6 +71,9 @@ struct GibbsSampler {
     virtual void setLut(const double *genomic, const double *noise) = 0;
     virtual void setNoiseLut(const double *noise) = 0;
     virtual void initChain(uint32_t chain) = 0;
+    // resetGroup of every group (InferenceEngine.cpp:100-113: the genotypers are deleted, the next initChain constructs them anew with the chain's
+    // seeds).  false: not supported — the caller then builds a fresh sampler instead.
+    virtual bool resetGroups() { return false; }
     virtual void sweep(uint32_t n, bool collect) = 0;
     virtual void run() = 0;                                   // the whole default schedule
     virtual void sync() {}                                    // wait for what run() enqueued (stage timing; results() waits anyway)

@@ -131,6 +131,7 @@ void exportTable(bt_table *t, std::vector<uint64_t> *kmers, std::vector<uint8_t>
 int runCluster(int argc, char *const argv[], unsigned kmer_size) {
     OptionsContainer options("cluster", BT_VERSION, getLocalTime(), kmer_size);
     if (options.parse(argc, argv, clusterOptionSpecs(), "## BayesTyper cluster options ##")) return 1;
+    setenv("BT_HOST_THREADS", std::to_string(clampThreads(options.getUInt("threads"))).c_str(), 0);   // the library's host-side assembly steps (bt_paths_candidates) take -p too
     const uint32_t min_unit_variants = (uint32_t)options.getUInt("min-number-of-unit-variants");
     const float cnv_threshold = options.getFloat("copy-number-variant-threshold");
     const uint16_t max_sample_haplotypes = (uint16_t)options.getUInt("max-number-of-sample-haplotypes");
@@ -314,6 +315,7 @@ void setGenomicCountDistributions(CountDistribution *cd, bt_table *table, const 
 int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     OptionsContainer options("genotype", BT_VERSION, getLocalTime(), kmer_size);
     if (options.parse(argc, argv, genotypeOptionSpecs(), "## BayesTyper genotype options ##")) return 1;
+    setenv("BT_HOST_THREADS", std::to_string(clampThreads(options.getUInt("threads"))).c_str(), 0);   // the library's host-side assembly steps (bt_paths_candidates) take -p too
     GibbsOptions gibbs;
     gibbs.seed = (unsigned)options.getUInt("random-seed");
     gibbs.burn_in = (uint32_t)options.getUInt("gibbs-burn-in");

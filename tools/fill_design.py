@@ -35,8 +35,14 @@ def e(x):
 
 SQ = {c: sq(c) for c in "ABCD"}
 g = sorted((r for r in trace if r["kernel"].startswith("gibbs") and r.get("start_ms") is not None and r["dur_ms"] > 500), key=lambda r: r["start_ms"])
-ncls = len({r["grid_x"] for r in g}) or 1
-last = g[-ncls:]   # the launch classes of the last schedule of the run
+# the launch classes of the main step: the grids of the run's first schedule (the sub-records launch other batches later); `last` = its last schedule
+first_grids = []
+for r in g:
+    if r["grid_x"] in first_grids:
+        break
+    first_grids.append(r["grid_x"])
+main = [r for r in g if r["grid_x"] in first_grids]
+last = main[-len(first_grids):] if first_grids else g[-4:]
 classes = ", ".join(f"{int(r['grid_x']) // 64} tiles ({r['kernel']}, scratch {r['scratch']} B/lane): {r['dur_ms'] / 1e3:.2f} s" for r in sorted(last, key=lambda r: -r["dur_ms"]))
 rf, rk, cpu = bench["roofline"], bench["roofline_kmer_match"], bench["cpu_baseline"]
 alg = rf["algorithmic_bytes"]
@@ -129,7 +135,7 @@ Final build, one MI355X (`profiles/{tag}_bench_under_rocprof.json`, i.e. under `
 of at least 0.1 ms): **{e(bench['value'])} cluster-sweeps/s** ({bench['ms_per_step'] / 1e3:.2f} s per step, of which the Gibbs launch {sched_s:.2f} s by HIP events and the three scans
 {rk['launches_per_step'] * rk['avg_launch_ms'] / 1e3:.2f} s), {bench['gpu_over_cpu_allcores']:.0f}× the {cpu['cores']}-thread oracle run and {bench['gibbs_kernel_cluster_sweeps_per_sec'] / cpu['one_core']['value']:.0f}× one core; {e(bench['kmer_matches_per_sec'])} KMC records/s
 ({bench['kmer_matches_per_sec'] / cpu['kmer_matches_per_sec_single_producer']:.0f}× the single-producer scan, {bench['kmer_matches_per_sec'] / cpu['kmer_matches_per_sec_parallel_decode']:.0f}× the parallel one).  Round 2 on this batch: 8.21 s per step.  {bench['gibbs_device_bytes'] / 1e9:.0f} GB of sampler state.
-Sub-records of the same line: **ten samples** (`samples10`: {s10['workload'].split(':')[1].split(',')[0].strip() if s10 else ''}, the north star's sample count): {e(s10['cluster_sweeps_per_sec']) if s10 else 'n/a'} cluster-sweeps/s, {f"{s10['gpu_over_cpu_allcores']:.0f}" if s10 else 'n/a'}× the
+Sub-records of the same line: **ten samples** (`samples10`: {(str(s10['groups']) + ' groups of the mixture') if s10 else ''}, the north star's sample count): {e(s10['cluster_sweeps_per_sec']) if s10 else 'n/a'} cluster-sweeps/s, {f"{s10['gpu_over_cpu_allcores']:.0f}" if s10 else 'n/a'}× the
 {cpu['cores']}-thread oracle run (target ≥ 20×); **thirty samples, `--noise-genotyping`** through the C++ engine (`noise_genotyping`): {f"{e(ng['noise_genotyping_cluster_sweeps_per_sec'])} cluster-sweeps/s against {e(ng['default_mode_cluster_sweeps_per_sec'])} in the default mode on the same batch" + (f" and {e(ng['cpu_allcores_cluster_sweeps_per_sec'])} for the oracle's estimateNoiseAndGenotypes on {cpu['cores']} threads" if 'cpu_allcores_cluster_sweeps_per_sec' in ng else '') if ng else 'n/a'}; the ten-sample batch in that mode (`noise_genotyping_samples10`): {f"{e(ng10['noise_genotyping_cluster_sweeps_per_sec'])} cluster-sweeps/s, {ng10['noise_over_default_time']:.1f}× the default mode's time" if ng10 else 'n/a'};
 **C4-sized sub-filters** (`kmer_match_c4_subfilters`): {e(c4['records_per_sec']) if c4 else 'n/a'} records/s.
 
