@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
@@ -181,8 +182,12 @@ void InferenceEngine::iteration(Sampler *sampler, CountDistribution *cd, bool co
     std::vector<uint64_t> hist(S * 256, 0);
     // the table drawn at the end of the previous iteration travels with this iteration's sweep (pending_noise); the first iteration of a
     // chain finds the table set by the driver
-    if (sampler) hist = sampler->noiseIteration(pending_noise ? cd->noiseTable().data() : nullptr, collect);   // (a rank without groups in this chain still takes part in the reduction)
+    {
+        StageScope stage("  noise iterations: sweep + noise counts (device, one synchronisation each)");
+        if (sampler) hist = sampler->noiseIteration(pending_noise ? cd->noiseTable().data() : nullptr, collect);   // (a rank without groups in this chain still takes part in the reduction)
+    }
     if (reduce_hist) reduce_hist(hist.data(), hist.size());
+    StageScope stage("  noise iterations: rates + Poisson table (host)");
     CountAllocation counts((unsigned short)S);
     for (size_t s = 0; s < S; s++)
         for (size_t c = 0; c < 256; c++) counts.counts()[s][c] = hist[s * 256 + c];
@@ -250,14 +255,21 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
     std::vector<double> mean(S, 0.0);
     std::unique_ptr<Sampler> sampler;
     std::vector<uint32_t> sampler_groups;
-    for (uint32_t chain = 0; chain < opt.chains; chain++) {
+    // this rank's groups of the next chain (the selection depends on the selector's generator only, not on the chains' results)
+    auto select = [&]() {
         std::vector<uint32_t> mine;
         for (uint32_t g : selector.nextChain())
             if (local[g] >= 0) mine.push_back((uint32_t)local[g]);
+        return mine;
+    };
+    std::vector<uint32_t> mine = select();
+    std::future<GibbsBatchData> prepared;   // the subset copy of `mine`, made by a helper thread while the previous chain ran
+    for (uint32_t chain = 0; chain < opt.chains; chain++) {
         // The genotypers of a chain are constructed with seed + (i+1)(chain+1) (:70) and deleted afterwards (resetGroupsCallback, :240-251).  A unit
         // with fewer variants than the batch size selects the same (sorted) groups in every chain: the previous chain's sampler then only has its
-        // groups reset — the reference's own sequence — instead of the subset copy + tile construction per chain (twenty times the whole unit: about
-        // half of this stage at chr20 size).  Otherwise, and for a sampler that cannot reset, a fresh sampler.
+        // groups reset — the reference's own sequence.  Otherwise (a unit of 100 000 variants or more: another random subset per chain), and for a
+        // sampler that cannot reset, a fresh sampler over a copy of the subset; the copy of the NEXT chain's subset is made by a helper thread while
+        // this chain's iterations wait for the device (the twenty copies + constructions were 3.8 of the 7.9 s of this stage at chr20 size).
         const bool again = sampler && !mine.empty() && mine == sampler_groups && sampler->resetGroups();
         if (again) {
             sampler->setNoiseLut(cd->noiseTable().data());
@@ -266,12 +278,17 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
             sampler.reset();
             sampler_groups.clear();
             if (!mine.empty()) {
-                sampler = newSampler(1, unit.take(mine));
+                StageScope stage("  noise chains: subset copy (when not prepared) + sampler construction");
+                const GibbsBatchData subset = prepared.valid() ? prepared.get() : unit.take(mine);
+                sampler = newSampler(1, subset);
                 sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
                 sampler->initChain(chain);
                 sampler_groups = mine;
             }
         }
+        std::vector<uint32_t> next;
+        if (chain + 1 < opt.chains) next = select();
+        if (!next.empty() && next != sampler_groups) prepared = std::async(std::launch::async, [&unit, next]() { return unit.take(next); });
         pending_noise = false;   // (the chain's sampler starts with the current table)
         logRow(out, chain + 1, 0, cd->getNoiseRates());
         runNoiseChain(sampler.get(), cd, chain, opt.burn_in + opt.samples + 1 /* never collects */, out, [&](uint32_t it, const std::vector<double> &rates) {
@@ -279,6 +296,7 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
                 for (size_t s = 0; s < S; s++) mean[s] += rates[s];
         });
         cd->resetNoiseRates();
+        mine = std::move(next);
     }
     sampler.reset();
     for (auto &m : mean) m /= (double)opt.samples * opt.chains;

@@ -180,6 +180,33 @@ GibbsBatchData GibbsBatchData::take(const std::vector<uint32_t> &ids) const {
         var_base[c + 1] = var_base[c] + V;
         kvb_off[c + 1] = kvb_off[c] + (uint64_t)(kv_off[kmer_off[c + 1]] - kv_off[kmer_off[c]]) * ((H + 31) / 32);
     }
+    {   // the large arrays get their final capacity up front (appending slice by slice reallocated — and re-touched — them a dozen times over)
+        uint64_t rows = 0, mult = 0, kv = 0, kvb = 0, uniq = 0, multi = 0, nclus = 0;
+        for (uint32_t g : ids)
+            for (uint32_t c = group_cluster_off[g]; c < group_cluster_off[g + 1]; c++) {
+                rows += kmer_off[c + 1] - kmer_off[c];
+                mult += mult_off[c + 1] - mult_off[c];
+                kv += kv_off[kmer_off[c + 1]] - kv_off[kmer_off[c]];
+                kvb += kvb_off[c + 1] - kvb_off[c];
+                uniq += unique_off[c + 1] - unique_off[c];
+                multi += multi_off[c + 1] - multi_off[c];
+                nclus++;
+            }
+        o.hap_kmer_mult.reserve(mult);
+        o.kmer_has_counts.reserve(rows);
+        o.kmer_counts.reserve(rows * S);
+        o.kmer_ic_mult.reserve(rows * 2);
+        o.kmer_shared.reserve(rows);
+        o.kv_off.reserve(rows + 1);
+        o.kv_var.reserve(kv);
+        o.kv_bits.reserve(kvb);
+        o.unique_idx.reserve(uniq);
+        o.multi_idx.reserve(multi);
+        for (auto *v : {&o.cluster_idx, &o.num_haplotypes, &o.num_variants}) v->reserve(nclus);
+        for (auto *v : {&o.kmer_off, &o.unique_off, &o.multi_off, &o.edge_off, &o.nestdep_off}) v->reserve(nclus + 1);
+        o.group_index.reserve(ids.size());
+        o.group_cluster_off.reserve(ids.size() + 1);
+    }
     o.group_cluster_off.push_back(0);
     o.group_source_off.push_back(0);
     o.edge_off.push_back(0);
