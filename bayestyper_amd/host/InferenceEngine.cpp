@@ -263,13 +263,19 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         return mine;
     };
     std::vector<uint32_t> mine = select();
-    std::future<GibbsBatchData> prepared;   // the subset copy of `mine`, made by a helper thread while the previous chain ran
+    // what a helper thread prepares for the next chain while the current one runs: the subset copy, and — for the product's own (GPU) sampler, whose
+    // construction only enqueues on the context's stream — the sampler itself; a caller-supplied sampler factory is only ever called from this thread
+    struct Prepared {
+        GibbsBatchData subset;
+        std::unique_ptr<Sampler> sampler;
+    };
+    std::future<Prepared> prepared;
     for (uint32_t chain = 0; chain < opt.chains; chain++) {
         // The genotypers of a chain are constructed with seed + (i+1)(chain+1) (:70) and deleted afterwards (resetGroupsCallback, :240-251).  A unit
         // with fewer variants than the batch size selects the same (sorted) groups in every chain: the previous chain's sampler then only has its
         // groups reset — the reference's own sequence.  Otherwise (a unit of 100 000 variants or more: another random subset per chain), and for a
-        // sampler that cannot reset, a fresh sampler over a copy of the subset; the copy of the NEXT chain's subset is made by a helper thread while
-        // this chain's iterations wait for the device (the twenty copies + constructions were 3.8 of the 7.9 s of this stage at chr20 size).
+        // sampler that cannot reset, a fresh sampler over a copy of the subset; the NEXT chain's subset copy and sampler are made by a helper thread
+        // while this chain's iterations wait for the device (the twenty copies + constructions were 3.8 of the 7.9 s of this stage at chr20 size).
         const bool again = sampler && !mine.empty() && mine == sampler_groups && sampler->resetGroups();
         if (again) {
             sampler->setNoiseLut(cd->noiseTable().data());
@@ -278,9 +284,11 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
             sampler.reset();
             sampler_groups.clear();
             if (!mine.empty()) {
-                StageScope stage("  noise chains: subset copy (when not prepared) + sampler construction");
-                const GibbsBatchData subset = prepared.valid() ? prepared.get() : unit.take(mine);
-                sampler = newSampler(1, subset);
+                StageScope stage("  noise chains: what the helper thread had not prepared (first chain: subset copy + sampler construction)");
+                Prepared ready;
+                if (prepared.valid()) ready = prepared.get();
+                else ready.subset = unit.take(mine);
+                sampler = ready.sampler ? std::move(ready.sampler) : newSampler(1, ready.subset);
                 sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
                 sampler->initChain(chain);
                 sampler_groups = mine;
@@ -288,7 +296,13 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         }
         std::vector<uint32_t> next;
         if (chain + 1 < opt.chains) next = select();
-        if (!next.empty() && next != sampler_groups) prepared = std::async(std::launch::async, [&unit, next]() { return unit.take(next); });
+        if (!next.empty() && next != sampler_groups)
+            prepared = std::async(std::launch::async, [this, &unit, next]() {
+                Prepared r;
+                r.subset = unit.take(next);
+                if (!make_sampler && !getenv("BT_NOISE_SAMPLER_ON_MAIN_THREAD")) r.sampler = newSampler(1, r.subset);
+                return r;
+            });
         pending_noise = false;   // (the chain's sampler starts with the current table)
         logRow(out, chain + 1, 0, cd->getNoiseRates());
         runNoiseChain(sampler.get(), cd, chain, opt.burn_in + opt.samples + 1 /* never collects */, out, [&](uint32_t it, const std::vector<double> &rates) {
