@@ -760,13 +760,41 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom
     const uint32_t first_bucket = blocks_per_bucket ? (y / blocks_per_bucket) * 8u + xcd : xcd, bucket_step = blocks_per_bucket ? 256u : 8u;
     const uint32_t sub = blocks_per_bucket ? y % blocks_per_bucket : y, step = (blocks_per_bucket ? blocks_per_bucket : (gridDim.x >> 3)) * BLOCK;
     // hits (a few per cent of the records) are collected in an LDS queue and moved to the chunk's hit list with one global atomic per workgroup; a
-    // hit that finds the queue full goes to the list directly — so the record loop holds no barrier and every wavefront keeps several records in flight
-    constexpr uint32_t QCAP = 8 * BLOCK;
+    // hit that finds the queue full goes to the list directly
+    constexpr uint32_t QCAP = 4 * BLOCK;
     __shared__ uint32_t queue[QCAP];
     __shared__ uint32_t qn, qbase;
-    if (threadIdx.x == 0) qn = 0;
+    // SURVIVOR COMPACTION.  A clear bit ends a record's probes (BloomFilter::containsF), and at 40 % filled only 0.4^q of the records reach round q — but
+    // a wavefront that keeps every record in its lane until the last one has failed executes every round for all 64 lanes (round 4's first form: 596
+    // VALU instructions per record, half of the kernel's wave cycles waiting for issue: profiles/r04_sq_kmc_before_compaction.txt).  So every record gets
+    // PDENSE rounds in its lane; the few that are still alive go to an LDS list, and the workgroup works that list off densely, one survivor per lane.
+#ifndef BT_KMC_PDENSE
+#define BT_KMC_PDENSE 2
+#endif
+    constexpr uint32_t SCAP = 3 * BLOCK, PDENSE = BT_KMC_PDENSE;
+    __shared__ uint32_t surv_lo[SCAP], surv_hi[SCAP], surv_idx[SCAP];
+    __shared__ uint32_t sn;
+    if (threadIdx.x == 0) {
+        qn = 0;
+        sn = 0;
+    }
     __syncthreads();
     const uint8_t *filter = reinterpret_cast<const uint8_t *>(bloom.words);
+    auto push_hit = [&](uint32_t idx) {
+        const uint32_t p = atomicAdd(&qn, 1u);
+        if (p < QCAP) queue[p] = idx;
+        else hits[atomicAdd(num_hits, 1u)] = idx;
+    };
+    auto sub_filter = [&](uint64_t h) { return filter + (nthash64_seeded(h, bloom.k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) * bloom.stride; };
+    // rounds first .. num_hashes - 1 of one record, stopping at the first clear bit
+    auto finish = [&](uint64_t h, const uint8_t *bytes, unsigned first) {
+        bool in = true;
+        for (unsigned q = first; q < bloom.num_hashes && in; ++q) {
+            const uint64_t pos = bloom_probe_pos(h, q, bloom);
+            in = (bytes[pos >> 3] & (1u << (7u - (unsigned)(pos & 7u)))) != 0;
+        }
+        return in;
+    };
     for (uint32_t bucket = first_bucket; bucket < 256u; bucket += bucket_step) {
         // the bucket's records: eight stripes, seen as one sequence
         uint32_t ofs[PSTRIPES + 1];
@@ -778,15 +806,14 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom
         }
         const uint32_t n = ofs[PSTRIPES];
         const RouteRec *src = part + (uint64_t)bucket * PSTRIPES * cap;
-        // PU records per lane at a time, and the probes of one round (hash function q) of all of them issued together: a lane's chain of dependent
-        // accesses per PU records is one record load + as many rounds as its longest-surviving record needs (a clear bit ends a record's probes:
-        // BloomFilter::containsF), not the sum over the records
-        for (uint32_t i0 = sub * BLOCK + threadIdx.x; i0 < n; i0 += PU * step) {
+        // PU records per lane at a time, the probes of one round of all of them issued together.  (The loop variable is the same in every thread of the
+        // workgroup: the loop body holds barriers.)
+        for (uint32_t base = sub * BLOCK; base < n; base += PU * step) {
             RouteRec r[PU];
             bool in[PU];
 #pragma unroll
             for (uint32_t u = 0; u < PU; ++u) {
-                const uint32_t i = i0 + u * step;
+                const uint32_t i = base + threadIdx.x + u * step;
                 in[u] = i < n;
                 uint32_t s = 0, o = 0;
 #pragma unroll
@@ -802,13 +829,10 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom
 #pragma unroll
             for (uint32_t u = 0; u < PU; ++u) {
                 h[u] = (uint64_t)r[u].h_lo | ((uint64_t)r[u].h_hi << 32);
-                bytes[u] = filter + (nthash64_seeded(h[u], bloom.k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) * bloom.stride;
+                bytes[u] = sub_filter(h[u]);
             }
-            for (unsigned q = 0; q < bloom.num_hashes; ++q) {
-                bool any = false;
-#pragma unroll
-                for (uint32_t u = 0; u < PU; ++u) any = any || in[u];
-                if (!any) break;
+            const unsigned dense = bloom.num_hashes < PDENSE ? bloom.num_hashes : PDENSE;
+            for (unsigned q = 0; q < dense; ++q) {
                 uint32_t byte[PU], bit[PU];
 #pragma unroll
                 for (uint32_t u = 0; u < PU; ++u) {
@@ -825,10 +849,25 @@ __global__ __launch_bounds__(BLOCK) void kmc_probe_bucket_kernel(BloomView bloom
 #pragma unroll
             for (uint32_t u = 0; u < PU; ++u)
                 if (in[u]) {
-                    const uint32_t p = atomicAdd(&qn, 1u);
-                    if (p < QCAP) queue[p] = r[u].idx;
-                    else hits[atomicAdd(num_hits, 1u)] = r[u].idx;
+                    if (dense == bloom.num_hashes) push_hit(r[u].idx);
+                    else {
+                        const uint32_t p = atomicAdd(&sn, 1u);
+                        if (p < SCAP) {
+                            surv_lo[p] = r[u].h_lo;
+                            surv_hi[p] = r[u].h_hi;
+                            surv_idx[p] = r[u].idx;
+                        } else if (finish(h[u], bytes[u], dense)) push_hit(r[u].idx);   // (a list that is full: the record is finished in its lane)
+                    }
                 }
+            __syncthreads();
+            const uint32_t ns = sn < SCAP ? sn : SCAP;
+            for (uint32_t e = threadIdx.x; e < ns; e += BLOCK) {
+                const uint64_t hs = (uint64_t)surv_lo[e] | ((uint64_t)surv_hi[e] << 32);
+                if (finish(hs, sub_filter(hs), dense)) push_hit(surv_idx[e]);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) sn = 0;
+            __syncthreads();
         }
     }
     __syncthreads();

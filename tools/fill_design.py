@@ -62,7 +62,7 @@ C = bench["config"]["clusters_per_gpu"]
 
 kernel_table = f"""| Kernel | Work per launch | Bound | Algorithmic bytes (SURVEY §8d) | Measured ({tag}, MI355X, `profiles/`) |
 |---|---|---|---|---|
-| KMC scan = `kmc_partition_kernel` → `kmc_probe_bucket_kernel` → `kmc_apply_kernel`, per chunk of 2^26 records (every sub-filter size; rounds 2–3 sent sub-filters above 4 KB through a rocPRIM radix sort and LDS-staged sub-filters) | R records: a workgroup stages a slab of 4096 records in LDS, computes the ntHash straight from the raw record bytes (one 256-entry LDS table per suffix byte = four symbols, the prefix's part once per slab: 72 VALU instructions per record; round 3 assembled the k-mer first: ≈ 350), counting-sorts the slab's 12-byte route records by the upper 8 route bits and writes every bucket's run into its stripe of the bucket's region (stripe = workgroup mod 8 = XCD: one `atomicAdd` per bucket and slab, 2 048 per cursor and chunk instead of 16 384) → workgroups mapped so that an XCD works through one bucket at a time probe the bucket's 256 sub-filters (0.5 MB at the WGS shape: L2; 9 MB for a ten-sample path filter: Infinity Cache), four records per lane with the probes of a round issued together, hits go through an LDS queue into a dense list → hits only: the record as aligned words, table find-or-insert on the packed slots (§3: one sector, one burst) + saturating count | HBM stream (13 B records in, 12 B route records out and in once) | 15.9 B/record pure (13 B record + E[probes]·1 B + 2 % × 34 B table update); the partitioned form moves 13 + 2×12 B = 37 B/record + the hits' table traffic (round 2's sorted form: 13 + 3×14 B ≈ 55 B, measured 102 B) | SURVEY §8d's stream, {rk['launches_per_step']} scans per step into an emptied table: {e(R)} records in {rk['insert_launch_ms']:.0f} ms (the inserting scan, {e(rk['bloom_hits_per_scan'])} hits) / {rk['find_launch_ms']:.0f} ms (the finding scans) → **{e(bench['kmer_matches_per_sec'])} records/s** = {rk['achieved']:.0f} GB/s algorithmic ({100 * rk['frac']:.1f} % of 8 TB/s); round 3: 74 / 40 ms, 1.94×10^10 records/s.  Counter traffic {kb / 1e9:.0f} GB per scan = {kb / R:.0f} B/record ({kb / R / 15.9:.1f}× the pure floor; round 3: 52 B/record; the sorted form: 102 B/record).  Sub-filters of C4 size ({c4['path_filter'] if c4 else 'n/a'}): {e(c4['records_per_sec']) if c4 else 'n/a'} records/s (a finding scan).  CPU oracle: {e(cpu['kmer_matches_per_sec_single_producer'])} records/s with the reference's single producer, {e(cpu['kmer_matches_per_sec_parallel_decode'])} with every core decoding its own range |
+| KMC scan = `kmc_partition_kernel` → `kmc_probe_bucket_kernel` → `kmc_apply_kernel`, per chunk of 2^26 records (every sub-filter size; rounds 2–3 sent sub-filters above 4 KB through a rocPRIM radix sort and LDS-staged sub-filters) | R records: a workgroup stages a slab of 4096 records in LDS, computes the ntHash straight from the raw record bytes (one 256-entry LDS table per suffix byte = four symbols, the prefix's part once per slab: 72 VALU instructions per record; round 3 assembled the k-mer first: ≈ 350), counting-sorts the slab's 12-byte route records by the upper 8 route bits and writes every bucket's run into its stripe of the bucket's region (stripe = workgroup mod 8 = XCD: one `atomicAdd` per bucket and slab, 2 048 per cursor and chunk instead of 16 384) → workgroups mapped so that an XCD works through one bucket at a time probe the bucket's 256 sub-filters (0.5 MB at the WGS shape: L2; 9 MB for a ten-sample path filter: Infinity Cache), four records per lane with the probes of a round issued together, two rounds per record in its lane and the survivors compacted through an LDS list (one per lane), hits go through an LDS queue into a dense list → hits only: the record as aligned words, table find-or-insert on the packed slots (§3: one sector, one burst) + saturating count | HBM stream (13 B records in, 12 B route records out and in once) | 15.9 B/record pure (13 B record + E[probes]·1 B + 2 % × 34 B table update); the partitioned form moves 13 + 2×12 B = 37 B/record + the hits' table traffic (round 2's sorted form: 13 + 3×14 B ≈ 55 B, measured 102 B) | SURVEY §8d's stream, {rk['launches_per_step']} scans per step into an emptied table: {e(R)} records in {rk['insert_launch_ms']:.0f} ms (the inserting scan, {e(rk['bloom_hits_per_scan'])} hits) / {rk['find_launch_ms']:.0f} ms (the finding scans) → **{e(bench['kmer_matches_per_sec'])} records/s** = {rk['achieved']:.0f} GB/s algorithmic ({100 * rk['frac']:.1f} % of 8 TB/s); round 3: 74 / 40 ms, 1.94×10^10 records/s.  Counter traffic {kb / 1e9:.0f} GB per scan = {kb / R:.0f} B/record ({kb / R / 15.9:.1f}× the pure floor; round 3: 52 B/record; the sorted form: 102 B/record).  Sub-filters of C4 size ({c4['path_filter'] if c4 else 'n/a'}): {e(c4['records_per_sec']) if c4 else 'n/a'} records/s (a finding scan).  CPU oracle: {e(cpu['kmer_matches_per_sec_single_producer'])} records/s with the reference's single producer, {e(cpu['kmer_matches_per_sec_parallel_decode'])} with every core decoding its own range |
 | `gibbs_hot_kernel` (`gibbs_kernel` for tiles that do not keep every vertex in LDS) + `gibbs_simple_kernel` | G groups × 20 chains × 350 sweeps; one launch per LDS class, concurrent | wavefront slots × per-tile latency of a sequential sampler (below); no dense contraction → no MFMA | per (cluster, chain): `K·H + K·(S+4) + 0.1K·4 + 2(13H+4S) + 2·2·2496` B (inputs once, state in/out once): {alg / 1e9:.0f} GB for the bench batch | {bench['config']['groups_per_gpu']} groups / {C} clusters, S = 3: {sched_s:.2f} s per schedule → **{e(bench['gibbs_kernel_cluster_sweeps_per_sec'])} cluster-sweeps/s**, {bench['gpu_over_cpu_allcores']:.0f}× the {cpu['cores']}-thread oracle run ({e(cpu['value'])}; one core {e(cpu['one_core']['value'])}); launches of one step: {classes}.  Algorithmic {rf['achieved']:.0f} GB/s = {100 * rf['frac']:.2f} % of HBM peak — tiny by construction.  Counter traffic **{gb / 1e12:.2f} TB per schedule** ({gr / 1e12:.2f} read, {gw / 1e12:.2f} written) = {gb / alg:.0f}× the algorithmic floor (round 3: 3.58 TB, 20×; round 2: 12.1 TB, 68×), {gb / (C * 7000):.0f} B per cluster-sweep; round 3: 5.63 s per schedule |
 | `build_tiles_kernel` (`bt_gibbs_create`) | one workgroup per cluster scatters the cluster's slices of the flat batch into its tile's rows | HBM stream | the batch once in, once out | 600 320 groups: 0.5 s for the whole `bt_gibbs_create` (planning on the host, upload, build) |
 | `noise_update_kernel` (`bt_gibbs_noise_chain`) | per iteration of a noise driver: S × 256 histogram → S gamma draws (one thread: the stream is sequential) → S × 256 Poisson log-pmf entries | latency (a few µs per iteration; it replaces a host round trip) | 2 KB · S in, 2 KB · S out | thirty samples, 2 000 groups: {f"{ng['iterations_per_sec']:.0f} iterations/s, {ng['noise_over_default_time']:.1f}× the default mode's time on the same batch (the caches are cleared every iteration)" + (f", {ng['gpu_over_cpu_allcores']:.0f}× the oracle's estimateNoiseAndGenotypes on all cores" if 'gpu_over_cpu_allcores' in ng else '') if ng else 'n/a'}; ten samples, 100 000 groups: {f"{ng10['iterations_per_sec']:.0f} iterations/s, {ng10['noise_over_default_time']:.1f}× the default mode's time" if ng10 else 'n/a'} |
