@@ -234,6 +234,28 @@ def test_table_duplicates_in_a_wavefront_clear_reserve_overflow(gpu_ctx, oracle)
     small.close()
 
 
+def test_table_same_keys_from_every_xcd(gpu_ctx):
+    """addKmer when the SAME keys arrive from workgroups all over the chip at the same time (the key set repeated 32 times in one batch: the copies of a
+    key sit megabytes apart, i.e. in workgroups on different XCDs with their own L2): a key is published with ordered write-through stores and probed with
+    agent-scope loads — no key may end up in two slots, none may be lost; repeated on fresh tables because the race is a matter of timing."""
+    from bayestyper_amd import lib
+
+    rng = np.random.default_rng(77)
+    uniq = np.unique(np.stack([rng.integers(0, 2 ** 62, 150_000, dtype=np.uint64), rng.integers(0, 2 ** 46, 150_000, dtype=np.uint64)], axis=1), axis=0)
+    batch = np.ascontiguousarray(np.tile(uniq, (32, 1)))
+    want = uniq[np.lexsort((uniq[:, 0], uniq[:, 1]))]
+    for rep in range(5):
+        t = lib.Table(gpu_ctx, 200_000, 3, K)               # capacity 2^19: load 0.29
+        t.insert(batch[rng.permutation(len(batch))] if rep else batch)
+        st = t.status()
+        assert st["num_keys"] == len(uniq) and not st["overflowed"], (rep, st)
+        k, _, _ = t.export()
+        assert np.array_equal(k[np.lexsort((k[:, 0], k[:, 1]))], want)
+        slots = t.find(uniq)
+        assert (slots >= 0).all() and len(np.unique(slots)) == len(uniq)
+        t.close()
+
+
 def test_kmc_counter_range_filter(gpu_ctx, oracle, tmp_path):
     """CKMCFile::ReadNextKmer skips records whose counter is outside the header's [min_count, max_count] (kmc_file.cpp:496-511):
     a scan with the range set equals a scan of a database that holds only the in-range records; same for makeBloom"""
