@@ -3,6 +3,7 @@
 #include "Parallel.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <sstream>
@@ -485,26 +486,31 @@ GibbsBatchData KmerCounter::classifyPathKmers(bt_table *table, const InferenceUn
     st.reset(new StageScope("  candidates: host arrays + fetch"));
     GibbsBatchData b;
     b.S = S;
-    std::vector<uint64_t> kmer_key(std::max<uint64_t>(sz.rows * 2, 1));
-    b.kmer_off.resize(C + 1);
-    b.hap_kmer_mult.resize(std::max<uint64_t>(sz.mult_bytes, 1));
-    b.kmer_has_counts.resize(std::max<uint64_t>(sz.rows, 1));
-    b.kmer_counts.resize(std::max<uint64_t>(sz.rows * S, 1));
-    b.kmer_ic_mult.resize(std::max<uint64_t>(sz.rows * 2, 1));
-    b.kv_off.resize(sz.rows + 1);
-    b.kv_var.resize(std::max<uint64_t>(sz.nnz, 1));
-    b.kv_bits.resize(std::max<uint64_t>(sz.kv_words, 1));
-    b.unique_off.resize(C + 1);
-    b.unique_idx.resize(std::max<uint64_t>(sz.num_unique, 1));
-    b.multi_off.resize(C + 1);
-    b.multi_idx.resize(std::max<uint64_t>(sz.num_multi, 1));
-    b.hap_allele.resize(std::max<uint64_t>(sz.hap_allele, 1));
-    b.hapnest_off.resize(sz.num_haplotypes + 1);
-    b.hapnest_idx.resize(std::max<uint64_t>(sz.hapnest, 1));
-    b.nestdep_off.resize(C + 1);
-    b.nestdep_cluster.resize(std::max<uint64_t>(sz.nestdep, 1));
-    b.nestdep_var_off.resize(sz.nestdep + 1);
-    b.nestdep_var.resize(std::max<uint64_t>(sz.nestdep_var, 1));
+    // (the arrays are sized — i.e. zero-filled, page by page — on several threads: one thread took 0.17 s for the 0.4 GB of a chr20-sized unit)
+    std::vector<uint64_t> kmer_key;
+    {
+        const std::vector<std::function<void()>> sizing = {
+            [&]() { kmer_key.resize(std::max<uint64_t>(sz.rows * 2, 1)); },
+            [&]() { b.kmer_off.resize(C + 1); b.unique_off.resize(C + 1); b.multi_off.resize(C + 1); b.nestdep_off.resize(C + 1); },
+            [&]() { b.hap_kmer_mult.resize(std::max<uint64_t>(sz.mult_bytes, 1)); },
+            [&]() { b.kmer_has_counts.resize(std::max<uint64_t>(sz.rows, 1)); b.kmer_counts.resize(std::max<uint64_t>(sz.rows * S, 1)); },
+            [&]() { b.kmer_ic_mult.resize(std::max<uint64_t>(sz.rows * 2, 1)); },
+            [&]() { b.kv_off.resize(sz.rows + 1); },
+            [&]() { b.kv_var.resize(std::max<uint64_t>(sz.nnz, 1)); },
+            [&]() { b.kv_bits.resize(std::max<uint64_t>(sz.kv_words, 1)); },
+            [&]() { b.unique_idx.resize(std::max<uint64_t>(sz.num_unique, 1)); b.multi_idx.resize(std::max<uint64_t>(sz.num_multi, 1)); },
+            [&]() {
+                b.hap_allele.resize(std::max<uint64_t>(sz.hap_allele, 1));
+                b.hapnest_off.resize(sz.num_haplotypes + 1);
+                b.hapnest_idx.resize(std::max<uint64_t>(sz.hapnest, 1));
+                b.nestdep_cluster.resize(std::max<uint64_t>(sz.nestdep, 1));
+                b.nestdep_var_off.resize(sz.nestdep + 1);
+                b.nestdep_var.resize(std::max<uint64_t>(sz.nestdep_var, 1));
+            }};
+        parallelFor(sizing.size(), (unsigned)sizing.size(), [&](size_t a, size_t e, unsigned) {
+            for (size_t i = a; i < e; i++) sizing[i]();
+        });
+    }
     bt_paths_candidates_out out{};
     out.kmer_off = b.kmer_off.data();
     out.hap_kmer_mult = b.hap_kmer_mult.data();
