@@ -50,6 +50,18 @@ int bt_ctx_create(int device_id, bt_ctx **out) {
     return BT_OK;
 }
 
+int bt_ctx_clone(bt_ctx *ctx, bt_ctx **out) {
+    if (!ctx || !out) return bt::fail("bt_ctx_clone: null argument");
+    BT_HIP(hipSetDevice(ctx->device));
+    bt_ctx *c = new bt_ctx();
+    c->device = ctx->device;
+    c->num_cu = ctx->num_cu;
+    BT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    *out = c;
+    return BT_OK;
+}
+
 int bt_ctx_destroy(bt_ctx *ctx) {
     if (!ctx) return BT_OK;
     (void)hipSetDevice(ctx->device);

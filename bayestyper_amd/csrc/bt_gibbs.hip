@@ -17,6 +17,7 @@
 #include "bt_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -32,6 +33,10 @@ hipError_t prepare_gibbs_simple_kernel(int max_lds);
 hipError_t launch_gibbs_hot_kernel(unsigned grid, unsigned block, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
                                    unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
 hipError_t prepare_gibbs_hot_kernel(int max_lds);
+// defined in bt_gibbs_chain_kernel.hip
+hipError_t launch_gibbs_chain_kernel(unsigned grid, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, const NoiseChainCtl *ctl, TraceCfg tr);
+hipError_t occupancy_gibbs_chain_kernel(int *blocks_per_cu, uint32_t lds);
+hipError_t prepare_gibbs_chain_kernel(int max_lds);
 #ifdef BT_PROF
 hipError_t simple_prof_read(unsigned long long *h_out32, int reset);
 hipError_t hot_prof_read(unsigned long long *h_out32, int reset);
@@ -465,6 +470,16 @@ struct bt_gibbs {
     // bt_gibbs_noise_iteration: pinned staging of the histogram (device -> host) and of the noise table (host -> device), device histogram
     uint64_t *h_pin_hist = nullptr, *d_iter_hist = nullptr;
     double *h_pin_noise = nullptr;
+    // bt_gibbs_noise_chain_{begin,step,end}: a chain of a noise driver as one resident launch (bt_noise_chain.hpp)
+    std::vector<double> h_lut_n;          // host mirror of d_lut_n
+    struct NoiseChainState {
+        uint8_t *h_mail = nullptr;        // pinned, fine-grained: [S*256] u64 histogram | [S*256] f64 table | hist_seq, table_seq (a cache line each)
+        uint8_t *d_sync = nullptr;        // device: [S*256] u64 histogram | arrived | abort | table_seq copies
+        NoiseChainCtl *d_ctl = nullptr;
+        NoiseChainCtl ctl{};
+        bool active = false;
+        uint32_t n = 0, next = 0;
+    } nc;
 };
 
 namespace {
@@ -631,6 +646,7 @@ __global__ __launch_bounds__(256) void ucache_prefill_kernel(const TileDesc *__r
 
 int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hist) {
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
+    if (g->nc.active) return fail("bt_gibbs: a resident noise chain is in progress (bt_gibbs_noise_chain_end)");
     BT_HIP(hipSetDevice(g->ctx->device));
     if (op == OP_NOISE && !g->wide_fill) a0 = 0;
     if (op == OP_INIT_CHAIN) a1 = g->wide_fill ? 1u : 0u;
@@ -1541,6 +1557,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
 int bt_gibbs_destroy(bt_gibbs *g) {
     if (!g) return BT_OK;
     (void)hipSetDevice(g->ctx->device);
+    if (g->nc.active) (void)bt_gibbs_noise_chain_end(g);   // (releases the resident launch)
     (void)hipStreamSynchronize(g->ctx->stream);
     for (void *p : g->allocs)
         if (p) (void)hipFree(p);
@@ -1549,6 +1566,9 @@ int bt_gibbs_destroy(bt_gibbs *g) {
     if (g->h_pin_hist) (void)hipHostFree(g->h_pin_hist);
     if (g->h_pin_noise) (void)hipHostFree(g->h_pin_noise);
     if (g->d_iter_hist) (void)hipFree(g->d_iter_hist);
+    if (g->nc.h_mail) (void)hipHostFree(g->nc.h_mail);
+    if (g->nc.d_sync) (void)hipFree(g->nc.d_sync);
+    if (g->nc.d_ctl) (void)hipFree(g->nc.d_ctl);
     for (auto &c : g->classes) {
         if (c.stream) {
             (void)hipStreamSynchronize(c.stream);
@@ -1568,6 +1588,7 @@ int bt_gibbs_set_lut(bt_gibbs *g, const double *h_genomic, const double *h_noise
     BT_HIP(hipMemcpyAsync(g->d_lut_g, h_genomic, (size_t)g->S * 65536 * 8, hipMemcpyHostToDevice, g->ctx->stream));
     BT_HIP(hipMemcpyAsync(g->d_lut_n, h_noise, (size_t)g->S * 256 * 8, hipMemcpyHostToDevice, g->ctx->stream));
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
+    g->h_lut_n.assign(h_noise, h_noise + (size_t)g->S * 256);
     g->lut_set = true;
     return BT_OK;
 }
@@ -1577,6 +1598,7 @@ int bt_gibbs_set_noise_lut(bt_gibbs *g, const double *h_noise) {
     BT_HIP(hipSetDevice(g->ctx->device));
     BT_HIP(hipMemcpyAsync(g->d_lut_n, h_noise, (size_t)g->S * 256 * 8, hipMemcpyHostToDevice, g->ctx->stream));
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
+    g->h_lut_n.assign(h_noise, h_noise + (size_t)g->S * 256);
     return BT_OK;
 }
 
@@ -1625,6 +1647,7 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
     }
     hipStream_t st = g->ctx->stream;
     if (h_noise) {   // (the staging buffer is free: the previous call ended with a synchronisation after its upload)
+        g->h_lut_n.assign(h_noise, h_noise + nh);
         std::memcpy(g->h_pin_noise, h_noise, nh * 8);
         BT_HIP(hipMemcpyAsync(g->d_lut_n, g->h_pin_noise, nh * 8, hipMemcpyHostToDevice, st));
     }
@@ -1636,6 +1659,167 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
     BT_HIP(hipMemcpyAsync(g->h_pin_hist, g->d_iter_hist, nh * 8, hipMemcpyDeviceToHost, st));
     BT_HIP(hipStreamSynchronize(st));
     std::memcpy(h_hist, g->h_pin_hist, nh * 8);
+    return BT_OK;
+}
+
+
+// ---- a chain of a noise driver as ONE resident launch (bt_noise_chain.hpp) ----
+namespace {
+inline uint32_t nc_bins_bytes(uint32_t S) { return (S * NC_BINS + 1u) * 4u; }
+constexpr uint32_t kResidentTableEntries = 4096;
+struct NcMail {   // layout of the pinned mailbox
+    uint64_t *hist;
+    double *table;
+    uint32_t *hist_seq, *table_seq;
+};
+inline NcMail nc_mail(bt_gibbs *g) {
+    const size_t nh = (size_t)g->S * 256;
+    uint8_t *b = g->nc.h_mail;
+    return NcMail{reinterpret_cast<uint64_t *>(b), reinterpret_cast<double *>(b + nh * 8), reinterpret_cast<uint32_t *>(b + nh * 16), reinterpret_cast<uint32_t *>(b + nh * 16 + 256)};
+}
+// where a chain that did not finish stood (after the launch has ended): for the error text
+static std::string nc_state_text(bt_gibbs *g, uint32_t it) {
+    uint32_t arrived = 0, aborted = 0, seq = 0;
+    const size_t nh = (size_t)g->S * 256;
+    (void)hipMemcpy(&arrived, g->nc.d_sync + nh * 8, 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&aborted, g->nc.d_sync + nh * 8 + 256, 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&seq, g->nc.d_sync + nh * 8 + 512, 4, hipMemcpyDeviceToHost);
+    const NcMail mail = nc_mail(g);
+    return " [iteration " + std::to_string(it) + " of " + std::to_string(g->nc.n) + ": " + std::to_string(arrived) + " arrivals of " +
+           std::to_string(g->nc.ctl.total_wgs) + " workgroups per iteration, device table_seq " + std::to_string(seq) + ", host hist_seq " +
+           std::to_string(*mail.hist_seq) + ", host table_seq " + std::to_string(*mail.table_seq) + ", device abort flag " + std::to_string(aborted) + "]";
+}
+inline uint32_t nc_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void nc_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+double nc_timeout_seconds() {
+    if (const char *e = getenv("BT_NOISE_CHAIN_TIMEOUT_S")) return std::max(0.001, atof(e));
+    return 60.0;
+}
+}  // namespace
+
+int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t first_collect, int *resident) {
+    if (!g || !resident) return fail("bt_gibbs_noise_chain_begin: null argument");
+    *resident = 0;
+    if (g->nc.active) return fail("bt_gibbs_noise_chain_begin: a chain is already in progress");
+    if (!g->lut_set) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
+    if (num_iterations == 0 || getenv("BT_NOISE_CHAIN_OFF")) return BT_OK;
+    BT_HIP(hipSetDevice(g->ctx->device));
+    // (1) Can every tile have its workgroup resident at the same time?  One launch, one workgroup shape (gibbs_chain_kernel: a wavefront per tile, the LDS
+    // need of the hungriest tile + the bins): tiles <= workgroups per CU x CUs, exactly.  Tiles with large dense tables want the whole-GPU refill between
+    // iterations (nan_fill_kernel / ucache_prefill_kernel), which a resident launch cannot give them: such batches keep the launch-per-iteration path.
+    const double fill_limit = getenv("BT_NOISE_CHAIN_FILL") ? atof(getenv("BT_NOISE_CHAIN_FILL")) : 1.0;
+    uint32_t class_lds = 0;
+    for (const auto &c : g->classes) {
+        class_lds = std::max(class_lds, c.lds);
+        if (c.num_fill || c.num_prefill) {
+            // large dense tables of unique-k-mer sums: up to kResidentTableEntries entries per lane they are invalidated and refilled by the tile's own lanes
+            // (cache_clear's "dirty = 2": what a launch without the wide refill does); above, the launch-per-iteration path with its whole-GPU refill is faster
+            uint32_t biggest = 0;
+            for (uint32_t ti : c.tiles) biggest = std::max(biggest, g->tiles[ti].cache_entries);
+            if (biggest > kResidentTableEntries && !getenv("BT_NOISE_CHAIN_WIDE")) return BT_OK;
+        }
+    }
+    const uint32_t bins_off = (class_lds + 15u) & ~15u, lds = bins_off + nc_bins_bytes(g->S);
+    if (lds > kHotBudget || g->ntiles == 0) return BT_OK;
+    int occ = 0;
+    BT_HIP(occupancy_gibbs_chain_kernel(&occ, lds));
+    if (getenv("BT_GIBBS_DEBUG"))
+        fprintf(stderr, "bt_gibbs_noise_chain_begin: %u tiles, %u B of LDS each: %d workgroups per CU x %d CUs (limit %.2f)\n", g->ntiles, lds, occ, g->ctx->num_cu, fill_limit);
+    if (occ < 1 || (double)g->ntiles > fill_limit * occ * g->ctx->num_cu) return BT_OK;
+    const uint32_t total = g->ntiles;
+    // (2) mailbox + device words
+    const size_t nh = (size_t)g->S * 256;
+    if (!g->nc.h_mail) {
+        BT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->nc.h_mail), nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped));
+        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_sync), nh * 8 + 512 + (size_t)NC_SEQ_COPIES * NC_SEQ_STRIDE * 4));
+        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_ctl), sizeof(NoiseChainCtl)));
+    }
+    int wall_khz = 0;   // rate of wall_clock64() (the deadlines of the device-side waits)
+    if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, g->ctx->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
+    if (getenv("BT_GIBBS_DEBUG")) fprintf(stderr, "bt_gibbs_noise_chain_begin: wall clock %d kHz\n", wall_khz);
+    const NcMail mail = nc_mail(g);
+    std::memset(g->nc.h_mail, 0, nh * 16 + 512);
+    std::memcpy(mail.table, g->h_lut_n.data(), nh * 8);   // (a step without a new table hands the current one over again)
+    hipStream_t st = g->ctx->stream;
+    BT_HIP(hipMemsetAsync(g->nc.d_sync, 0, nh * 8 + 512 + (size_t)NC_SEQ_COPIES * NC_SEQ_STRIDE * 4, st));
+    {
+        NoiseChainCtl &k = g->nc.ctl;
+        k.hist = reinterpret_cast<unsigned long long *>(g->nc.d_sync);
+        k.arrived = reinterpret_cast<uint32_t *>(g->nc.d_sync + nh * 8);
+        k.abort_flag = reinterpret_cast<uint32_t *>(g->nc.d_sync + nh * 8 + 256);
+        k.table_seq = reinterpret_cast<uint32_t *>(g->nc.d_sync + nh * 8 + 512);
+        k.lut_n = g->d_lut_n;
+        k.h_hist = reinterpret_cast<unsigned long long *>(mail.hist);
+        k.h_table = mail.table;
+        k.h_hist_seq = mail.hist_seq;
+        k.h_table_seq = mail.table_seq;
+        k.total_wgs = total;
+        k.bins_off = bins_off;
+        k.n_iterations = num_iterations;
+        k.first_collect = first_collect;
+        k.S = g->S;
+        k.pad = 0;
+        k.timeout_ticks = (unsigned long long)(nc_timeout_seconds() * 1e3 * wall_khz);
+    }
+    BT_HIP(hipMemcpyAsync(g->nc.d_ctl, &g->nc.ctl, sizeof(NoiseChainCtl), hipMemcpyHostToDevice, st));
+    BT_HIP(hipStreamSynchronize(st));   // (the control block is read from pageable memory)
+    BT_HIP(prepare_gibbs_chain_kernel((int)kHotBudget));
+    TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
+    BT_HIP(launch_gibbs_chain_kernel(g->ntiles, lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
+    g->prefill_armed = false;
+    g->nc.active = true;
+    g->nc.n = num_iterations;
+    g->nc.next = 0;
+    *resident = 1;
+    return BT_OK;
+}
+
+int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hist) {
+    if (!g || !h_hist) return fail("bt_gibbs_noise_chain_step: null argument");
+    if (!g->nc.active) return fail("bt_gibbs_noise_chain_step: no chain in progress (bt_gibbs_noise_chain_begin)");
+    const uint32_t it = g->nc.next;
+    if (it >= g->nc.n) return fail("bt_gibbs_noise_chain_step: the chain has no iteration left");
+    if (it == 0 && h_noise) return fail("bt_gibbs_noise_chain_step: the first iteration of a chain runs with the sampler's table (bt_gibbs_set_noise_lut before the chain)");
+    const size_t nh = (size_t)g->S * 256;
+    const NcMail mail = nc_mail(g);
+    if (it > 0) {   // the table of this iteration's sweep: the workgroup that published histogram `it` is waiting for it
+        if (h_noise) {
+            std::memcpy(mail.table, h_noise, nh * 8);
+            g->h_lut_n.assign(h_noise, h_noise + nh);
+        }
+        nc_store(mail.table_seq, it);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = nc_timeout_seconds();
+    uint32_t v = nc_load(mail.hist_seq);
+    for (uint64_t spins = 0; v < it + 1u; ++spins) {
+        __builtin_ia32_pause();
+        v = nc_load(mail.hist_seq);
+        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            nc_store(mail.table_seq, NC_ABORT);
+            (void)bt_gibbs_noise_chain_end(g);
+            return fail("bt_gibbs_noise_chain_step: no histogram from the device within the deadline (BT_NOISE_CHAIN_TIMEOUT_S)" + nc_state_text(g, it));
+        }
+    }
+    if (v == NC_ABORT) {
+        (void)bt_gibbs_noise_chain_end(g);
+        return fail("bt_gibbs_noise_chain_step: the resident launch gave up waiting (workgroups not resident together, or the host too slow: BT_NOISE_CHAIN_TIMEOUT_S)" + nc_state_text(g, it));
+    }
+    std::memcpy(h_hist, mail.hist, nh * 8);
+    g->nc.next = it + 1;
+    return BT_OK;
+}
+
+int bt_gibbs_noise_chain_end(bt_gibbs *g) {
+    if (!g) return fail("bt_gibbs_noise_chain_end: null handle");
+    if (!g->nc.active) return BT_OK;
+    (void)hipSetDevice(g->ctx->device);
+    const NcMail mail = nc_mail(g);
+    const bool complete = g->nc.next >= g->nc.n;
+    if (!complete) nc_store(mail.table_seq, NC_ABORT);   // the launch ends at its next exchange
+    g->nc.active = false;
+    BT_HIP(hipStreamSynchronize(g->ctx->stream));
+    if (complete && nc_load(mail.hist_seq) == NC_ABORT) return fail("bt_gibbs_noise_chain_end: the resident launch was aborted");
     return BT_OK;
 }
 

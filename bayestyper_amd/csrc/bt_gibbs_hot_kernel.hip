@@ -13,7 +13,7 @@ namespace {
 using namespace bt;
 __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_hot_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg, int op, uint32_t arg0,
                                                                            uint32_t arg1, unsigned long long *__restrict__ hist, TraceCfg tr, const uint32_t *__restrict__ tile_list) {
-    if (!(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN)) return;   // (the other operations read the arrays in HBM: gibbs_kernel)
+    if (!(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || op == OP_NOISE_CHAIN)) return;   // (the other operations read the arrays in HBM: gibbs_kernel)
     gibbs_body<false>(tiles, pool, Pg, op, arg0, arg1, hist, tr, tile_list);
 }
 }  // namespace

@@ -3,11 +3,12 @@
 // (gibbs_simple_kernel: tiles of two-haplotype clusters, the three sampling operations; compiled for half the registers).
 #pragma once
 #include "bt_gibbs_tile.hpp"
+#include "bt_noise_chain.hpp"
 #include "bt_gibbs_simple.hpp"
 
 namespace bt {
 
-enum GibbsOp { OP_RUN = 0, OP_INIT_CHAIN = 1, OP_SWEEP = 2, OP_NOISE = 3, OP_RESET = 4, OP_SETUP = 5 };
+enum GibbsOp { OP_RUN = 0, OP_INIT_CHAIN = 1, OP_SWEEP = 2, OP_NOISE = 3, OP_RESET = 4, OP_SETUP = 5, OP_NOISE_CHAIN = 6 };
 
 struct TraceCfg {
     uint32_t max_sweeps;   // 0 = off
@@ -173,6 +174,29 @@ __device__ __forceinline__ void group_sweep(const Env &env, const Tile &t, const
     }
 }
 
+// VariantClusterGenotyper::getNoiseCounts (:757-779) + clearCache (:131-138) for every vertex of the lane's group, inside a resident chain of a noise
+// driver (bt_noise_chain.hpp): the counts go to the workgroup's LDS bins.  The hot arrays are read where they are (LDS for resident groups).
+__device__ BT_NOINLINE void noise_tally_group(Env env, uint32_t nvert, const NoiseChainCtl *nc) {
+    if (env.resident != RESIDENT_ALL) env.resident = 0xFFFFFFFFu;   // swap mode: between visits every vertex's hot arrays are in HBM
+    const Tile t = make_tile(env);
+    const GParams BT_CAS &P = env_params(env);
+    auto *bins = nc_bins(nc);
+    for (uint32_t v = 0; v < nvert; ++v) {
+        const Vx c = make_vx(t, v);
+        const uint32_t nsu = c.sc()[SC_NSUB_U];
+        TPtr<uint32_t> usub = c.usub();
+        for (uint32_t s = 0; s < P.S; ++s) {
+            const uint16_t h1 = c.dip()[2 * s], h2 = c.dip()[2 * s + 1];
+            for (uint32_t i = t.part; i < nsu; i += t.copies) {   // the copies of a narrow tile's group share the k-mers of the subset (a tally: any order)
+                const uint32_t k = usub[i];
+                if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) nc_tally(nc, bins, s, c.has_counts(k) ? c.count(k, s) : 0u);
+            }
+        }
+        if (t.part == 0) cache_clear(c, P, false, false);   // (the other copies read nothing this touches before the next sweep)
+    }
+    if (t.copies > 1u) copies_sync();
+}
+
 struct TraceRow {
     TPtr<uint32_t> row;
     bool on;
@@ -203,14 +227,14 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     Tile t;
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
-    if (!tile_thread_active(t.d->split, t.d->copies)) return;
-    t.lane = tile_lane(t.d->split, t.d->copies);
+    if (!tile_thread_active(tile_split(t.d), t.d->copies)) return;
+    t.lane = tile_lane(tile_split(t.d), t.d->copies);
     t.plane = t.lane + t.d->pool_lane0;
     t.wsh = t.d->wsh;
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     // the extra copies of a narrow tile's groups only take part in the sampling operations (the others tally with atomics)
-    if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || op == OP_NOISE)) return;
+    if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || op == OP_NOISE || op == OP_NOISE_CHAIN)) return;
     t.hot = nullptr;
     t.resident = 0xFFFFFFFFu;
     // Narrow tiles (few groups + lockstep copies) are the launch's critical path: a handful of long sequential programs.  They take
@@ -219,9 +243,13 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     TPtr<uint32_t> gd = t.arr<uint32_t>(A_GDIMS);
     if (!gd[3]) return;   // padding lane of the last tile
     const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
+    // OP_NOISE_CHAIN: a whole chain of a noise driver, the tiles resident (bt_noise_chain.hpp); `hist` carries the launch class's control block.
+    // (Lane 0 of a tile is always a group, so thread 0 and wavefront 0 of the workgroup are still here.)
+    const bool is_nc = op == OP_NOISE_CHAIN;
+    const NoiseChainCtl *nc = is_nc ? (const NoiseChainCtl *)hist : nullptr;
     // groups of ONE cluster keep that cluster's hot arrays in LDS for the whole launch; larger groups swap per vertex visit
     // (and so do multi-cluster groups of narrow tiles, whose LDS rows are interleaved over fewer lanes: TileDesc::lds_all)
-    const bool whole = (t.d->nvm == 1 || t.d->lds_all) && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN);
+    const bool whole = (t.d->nvm == 1 || t.d->lds_all) && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || is_nc);
     if (whole) {
         env.resident = RESIDENT_ALL;
         for (uint32_t v = 0; v < nvert; ++v) hot_swap(env, v, true);
@@ -231,12 +259,18 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     // tiles of two-haplotype clusters run their straight-line sweep in gibbs_simple_kernel only; launched through the general kernel
     // (BT_GIBBS_NO_SIMPLE_KERNEL) they take the general path
     const bool simple = SIMPLE_ONLY;
-    if (op == OP_RUN || op == OP_SWEEP) {
-        // OP_RUN: every chain = init + burn-in + collected sweeps; OP_SWEEP: arg0 sweeps of the chain in progress.  One loop for both,
-        // so that the sweep code (inlined) exists once
+    if (op == OP_RUN || op == OP_SWEEP || is_nc) {
+        // OP_RUN: every chain = init + burn-in + collected sweeps; OP_SWEEP: arg0 sweeps of the chain in progress; OP_NOISE_CHAIN: the iterations of a
+        // noise driver's chain, each sweep followed by the noise tally and the exchange with the host.  One loop for all, so that the sweep code
+        // (inlined) exists once
         const bool is_run = op == OP_RUN;
         const uint32_t nchains = is_run ? P.num_chains : 1u;
-        const uint32_t n_burn = is_run ? P.burn_in : (arg1 != 0 ? 0u : arg0), n_collect = is_run ? P.num_iterations : (arg1 != 0 ? arg0 : 0u);
+        uint32_t n_burn = is_run ? P.burn_in : (arg1 != 0 ? 0u : arg0), n_collect = is_run ? P.num_iterations : (arg1 != 0 ? arg0 : 0u);
+        if (is_nc) {
+            n_burn = nc->first_collect < nc->n_iterations ? nc->first_collect : nc->n_iterations;
+            n_collect = nc->n_iterations - n_burn;
+            nc_begin(nc);
+        }
         for (uint32_t chain = 0; chain < nchains; ++chain) {
             if (is_run) {
                 PROF_DECL;
@@ -244,12 +278,17 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                 PROF(15);
             }
             if constexpr (SIMPLE_ONLY) {
-                simple_sweeps(env, t, P, n_burn, n_collect, tr.counter, tr.buf, tr.max_sweeps, tile);
+                simple_sweeps(env, t, P, n_burn, n_collect, tr.counter, tr.buf, tr.max_sweeps, tile, nc);
                 if (is_run || n_collect) drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
             } else {
                 for (uint32_t i = 0; i < n_burn + n_collect; ++i) {
+                    if (is_nc && i > 0 && !nc_wait_table(nc, i)) break;
                     const TraceRow r = trace_row_for(t, P, tr, tile);
                     group_sweep(env, t, P, i >= n_burn, nvert, nsrc, r.row, r.on);
+                    if (is_nc) {
+                        noise_tally_group(env, nvert, nc);
+                        if (!nc_iteration_end(nc, i)) break;
+                    }
                 }
                 if (is_run && t.d->logged) drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
             }

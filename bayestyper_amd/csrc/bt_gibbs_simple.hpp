@@ -163,6 +163,26 @@ __device__ static __noinline__ void simple_apply_full_log(Env env, uint32_t s) {
     apply_collected_log(c, P, s, c.sc()[SC_NSUB_U]);
 }
 
+// A sample's candidate weights from the table of unique-k-mer sums: exp(sum - max) of the two candidates that are not the maximum, in candidate
+// order, as floats, and which candidate is the maximum (diploid: (0,0) (0,1) (1,1) at table entries 0..2; haploid: (0) (1) at entries 3, 4).
+struct SimpleWeights {
+    float ea, eb;
+    uint32_t wmax;
+};
+template <class UC>
+__device__ inline SimpleWeights simple_weights(const UC &uc, uint32_t Dcm, uint32_t s, uint32_t pl) {
+    const uint32_t i0 = pl == 2 ? 0u : 3u;
+    const double v0 = pl ? (double)uc[s * Dcm + i0] : 0.0, v1 = pl ? (double)uc[s * Dcm + i0 + 1u] : 0.0;
+    const double ninf = -__builtin_huge_val();
+    const double v2 = pl == 2 ? (double)uc[s * Dcm + 2u] : ninf;
+    uint32_t wmax = 0;
+    double m = v0;
+    if (v1 > m) m = v1, wmax = 1;
+    if (v2 > m) m = v2, wmax = 2;
+    const double ea = bt_exp((wmax == 0 ? v1 : v0) - m), eb = bt_exp((wmax == 2 ? v1 : v2) - m);   // the two that are not the maximum, in candidate order
+    return SimpleWeights{(float)ea, (float)eb, wmax};
+}
+
 // Chain entry: the per-sample LDS words from the general arrays, the candidates' weights from the table of unique-k-mer sums (rebuilt when
 // the chain start / clearCache marked it), the sparse distribution's simplex-size probability.  Returns P(simplex size = |plus|) for |plus| = 1.
 __device__ static __noinline__ double simple_enter(Env env, uint32_t blk_off) {
@@ -189,17 +209,10 @@ __device__ static __noinline__ double simple_enter(Env env, uint32_t blk_off) {
         npl[s] = (uint8_t)pl;
         nn[s] = 0;
         n_obs += pl == 2 ? 2u : (pl == 1 ? 1u : 0u);
-        const uint32_t i0 = pl == 2 ? 0u : 3u;
-        const double v0 = pl ? (double)uc[s * Dcm + i0] : 0.0, v1 = pl ? (double)uc[s * Dcm + i0 + 1u] : 0.0;
-        const double ninf = -__builtin_huge_val();
-        const double v2 = pl == 2 ? (double)uc[s * Dcm + 2u] : ninf;
-        uint32_t wmax = 0;
-        double m = v0;
-        if (v1 > m) m = v1, wmax = 1;
-        if (v2 > m) m = v2, wmax = 2;
-        const double ea = bt_exp((wmax == 0 ? v1 : v0) - m), eb = bt_exp((wmax == 2 ? v1 : v2) - m);   // the two that are not the maximum, in candidate order
-        blk[SB_WORDS * s] = __float_as_uint((float)ea);
-        blk[SB_WORDS * s + 1] = __float_as_uint((float)eb);
+        const SimpleWeights w = simple_weights(uc, Dcm, s, pl);
+        const uint32_t wmax = w.wmax;
+        blk[SB_WORDS * s] = __float_as_uint(w.ea);
+        blk[SB_WORDS * s + 1] = __float_as_uint(w.eb);
         uint32_t pr = pend[s], pv = pvalid[s];
         uint32_t pcode = sd_code(pdip[2 * s], pdip[2 * s + 1]);
         if (pv && pr > 255u) {   // (not produced by this kernel, which drains at the end of every launch that collects)
@@ -259,10 +272,52 @@ __device__ static __noinline__ void simple_leave(Env env, uint32_t blk_off, doub
     if (nzmask & 2u) logf[1] = bt_log(f1);
 }
 
+// ---- inside a resident chain of a noise driver (bt_noise_chain.hpp) ----
+// A new noise table has arrived (clearGenotyperCache + the next visit's cache fill): the table of unique-k-mer sums is rebuilt and the samples' weights with it.
+__device__ static __noinline__ void simple_reweight(Env env, uint32_t blk_off) {
+    const Tile t = make_tile(env);
+    const Vx c = make_vx(t, 0);
+    const GParams BT_CAS &P = env_params(env);
+    fill_unique_cache(env, 0);
+    c.sc()[SC_UC_DIRTY] = 0;
+    LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
+    const Vx::UCPtr uc = c.ucache();
+    const uint32_t Dcm = t.d->Dcm;
+    for (uint32_t s = 0; s < P.S; ++s) {
+        const uint32_t pk = blk[SB_WORDS * s + 2];
+        const SimpleWeights w = simple_weights(uc, Dcm, s, (pk >> SP_PLOIDY) & 3u);
+        blk[SB_WORDS * s] = __float_as_uint(w.ea);
+        blk[SB_WORDS * s + 1] = __float_as_uint(w.eb);
+        blk[SB_WORDS * s + 2] = (pk & ~(3u << SP_WMAX)) | (w.wmax << SP_WMAX);
+    }
+}
+// VariantClusterGenotyper::getNoiseCounts (:757-779) for the lane's cluster from the packed sample words, then clearCache (:131-138: the table is
+// rebuilt by simple_reweight when the next table arrives)
+__device__ static __noinline__ void simple_noise_tally(Env env, uint32_t blk_off, const NoiseChainCtl *nc) {
+    const Tile t = make_tile(env);
+    const Vx c = make_vx(t, 0);
+    const GParams BT_CAS &P = env_params(env);
+    LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
+    auto *bins = nc_bins(nc);
+    const uint32_t nsu = c.sc()[SC_NSUB_U];
+    TPtr<uint32_t> usub = c.usub();
+    for (uint32_t s = 0; s < P.S; ++s) {
+        const uint32_t code = blk[SB_WORDS * s + 2] & 7u;
+        const uint16_t h1 = (uint16_t)sd_h1(code), h2 = (uint16_t)sd_h2(code);
+        for (uint32_t i = 0; i < nsu; ++i) {
+            const uint32_t k = usub[i];
+            if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) nc_tally(nc, bins, s, c.has_counts(k) ? c.count(k, s) : 0u);
+        }
+    }
+    c.sc()[SC_UC_DIRTY] = 1;
+}
+
 // n_burn sweeps without and then n_collect sweeps with collection of the tile's clusters (one per lane).
+// nc != nullptr: the sweeps are the iterations of a noise driver's chain — before every sweep but the first the workgroup waits for the new noise table
+// and rebuilds its weights; after every sweep it tallies its noise counts and takes part in the exchange with the host.
 // (One call site per kernel.)
 __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParams BT_CAS &P, uint32_t n_burn, uint32_t n_collect, uint32_t *trace_counter, uint32_t *trace_buf,
-                                     uint32_t trace_max, uint32_t tile) {
+                                     uint32_t trace_max, uint32_t tile, const NoiseChainCtl *nc = nullptr) {
     const uint32_t n_sweeps = n_burn + n_collect;
     const TileDesc BT_CAS &d = *t.d;
     const Vx c = make_vx(t, 0);   // (general accessors for the arrays that stay in HBM and for the slow paths)
@@ -299,6 +354,10 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
 
     for (uint32_t sweep = 0; sweep < n_sweeps; ++sweep) {
         const bool collect = sweep >= n_burn;
+        if (nc && sweep > 0) {
+            if (!nc_wait_table(nc, sweep)) break;
+            simple_reweight(env, blk_off);
+        }
         // ---- trace row of this sweep ----
         bool tracing = false;
         TPtr<uint32_t> trace_row{(uint32_t BT_GAS *)trace_buf, 0u, 6u};
@@ -441,6 +500,10 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
             fnd_avail = avail;
         }
         PROF(7);
+        if (nc) {
+            simple_noise_tally(env, blk_off, nc);
+            if (!nc_iteration_end(nc, sweep)) break;
+        }
     }
     // ---- back to the general representation ----
     mt_close(r0);

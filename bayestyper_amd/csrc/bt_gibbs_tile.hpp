@@ -372,6 +372,12 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
 // consecutive group lanes starting at w * 64/split and runs with only that many active threads; wavefronts of the workgroup
 // beyond `split` exit at once.  The memory layout (HBM pool and LDS hot arrays, both interleaved over 64 group lanes) does not
 // depend on the split: it only trades SIMD width for more wavefronts that each wait on fewer diverging lanes.
+// wavefronts of this launch that work on the tile: the tile's split, or fewer when the workgroup has fewer (gibbs_chain_kernel: ONE wavefront per tile,
+// its 64 lanes the tile's 64 groups)
+__device__ inline uint32_t tile_split(const TileDesc BT_CAS *d) {
+    const uint32_t waves = blockDim.x >> 6;
+    return d->split < waves ? d->split : waves;
+}
 __device__ inline uint32_t tile_lane(uint32_t split, uint32_t copies) { return (threadIdx.x >> 6) * (64u / split) + ((threadIdx.x & 63u) % (64u / copies)); }
 __device__ inline uint32_t tile_part(uint32_t copies) { return (threadIdx.x & 63u) / (64u / copies); }
 __device__ inline bool tile_thread_active(uint32_t split, uint32_t copies) {
@@ -392,7 +398,7 @@ __device__ inline Tile make_tile(const Env &e_in) {
     const uint32_t tile = list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x;
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
-    t.lane = tile_lane(t.d->split, t.d->copies);
+    t.lane = tile_lane(tile_split(t.d), t.d->copies);
     t.plane = t.lane + t.d->pool_lane0;
     t.wsh = t.d->wsh;
     t.part = tile_part(t.d->copies);

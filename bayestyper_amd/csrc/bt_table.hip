@@ -38,10 +38,15 @@ __device__ inline uint64_t mix64(uint64_t x) {   // murmur3 finaliser
 
 __device__ inline uint64_t table_home(Kmer a, const TableView &t) { return mix64(a.lo ^ mix64(a.hi + 0x9e3779b97f4a7c15ULL)) & t.mask; }
 
-// State and key of one slot in one burst: the (state, meta) word pair first, then the key words, issued back to back — three loads of one
-// lane into one 32-byte block, served by one channel in issue order.  A slot's key only changes while its state is BUSY, and a writer
-// publishes with a release store, so "READY and equal" is a match; "READY and different" is confirmed with a second look at the key (now
-// certainly after the state was seen READY) before the probe moves on, so a key is never missed — and never inserted twice.
+// State and key of one slot in one burst: the (state, meta) word pair first, then the key words, issued back to back.  A slot's key words
+// are written exactly once (EMPTY -> BUSY -> READY, no deletion; a cleared / fresh table holds zeros), each with one 64-bit store, and the
+// writer stores READY only after both key stores have been ACKNOWLEDGED (s_waitcnt vmcnt(0) between them, publish_slot below).  The three
+// loads of a look are issued in order but — a 48-byte slot's words may straddle a 64 / 128 / 256-byte boundary, i.e. sit in different
+// channels — are not necessarily SERVED in order, so a look that reads READY may still carry a stale key word, and a stale word is
+// always zero.  Hence: "READY and equal" is taken as a match from the burst only when neither word of the wanted key is zero (a zero
+// word that compares equal could be the stale one: the all-A k-mer, or a k-mer ending in 23 A's); every other READY case — different
+// key, or equal with a zero word — is decided by a second look at the key behind an acquire fence (now certainly served after the
+// state was seen READY).  So a key is never missed, never matched to another key's slot, and never inserted twice.
 struct SlotLook {
     uint32_t st, cw;
     uint64_t lo, hi;
@@ -59,12 +64,34 @@ __device__ inline SlotLook slot_look(const TableView &t, uint64_t idx, uint32_t 
     p.st = (uint32_t)sm;
     return p;
 }
-__device__ inline bool slot_holds_other_key(const TableView &t, uint64_t idx, const SlotLook &p, Kmer a) {   // p.st == ST_READY, p's key != a
+__device__ inline bool burst_match(const SlotLook &p, Kmer a) {   // p.st == ST_READY: is the burst alone proof that the slot holds a?
+    return p.lo == a.lo && p.hi == a.hi && a.lo != 0 && a.hi != 0;
+}
+__device__ inline bool slot_holds_other_key(const TableView &t, uint64_t idx, const SlotLook &p, Kmer a) {   // p.st == ST_READY, !burst_match(p, a)
     (void)p;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // orders the second look after the READY observation
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // s_waitcnt vmcnt(0) + buffer_inv sc1: the second look is served after the READY observation
     const uint64_t lo = __hip_atomic_load(t.key_lo(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t hi = __hip_atomic_load(t.key_hi(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return lo != a.lo || hi != a.hi;
+}
+
+// The lane that won a slot (state BUSY) writes the key and publishes it.  The key words are agent-scope atomic stores (global_store ... sc1):
+// written through to the point the other XCDs read from.  READY must not overtake them, and stores to different channels are not ordered
+// by issue order, so the lane WAITS until both key stores have been acknowledged — an explicit `s_waitcnt vmcnt(0)`: on gfx9 stores count
+// in vmcnt, and a workgroup-scope release fence (round 4) emits no instruction at all — and only then stores the state the same way.
+// A full agent-scope release store (flags & 1, BT_TABLE_RELEASE_PUBLISH) would in addition write back every dirty line of this XCD's
+// L2 (buffer_wbl2) once per inserted key, which nothing here needs: the slot's words are the only data the reader relies on.
+__device__ inline void publish_slot(const TableView &t, uint64_t idx, Kmer a) {
+    __hip_atomic_store(t.key_lo(idx), a.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(t.key_hi(idx), a.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t.flags & 1u) {
+        __hip_atomic_store(t.state(idx), ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) expcnt(7) lgkmcnt(15): gfx9 encoding, vmcnt = bits [3:0] + [15:14]
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __hip_atomic_store(t.state(idx), ST_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // findKmer: slot or -1.  A BUSY slot is polled again — the loop has a single exit, no lane leaves it from inside.
@@ -78,7 +105,7 @@ __device__ inline int64_t table_find(const TableView &t, Kmer a) {
         if (p.st == ST_EMPTY) {
             done = true;
         } else if (p.st == ST_READY) {
-            if ((p.lo == a.lo && p.hi == a.hi) || !slot_holds_other_key(t, idx, p, a)) {
+            if (burst_match(p, a) || !slot_holds_other_key(t, idx, p, a)) {
                 result = (int64_t)idx;
                 done = true;
             } else {
@@ -105,24 +132,13 @@ __device__ inline int64_t table_find_or_insert(const TableView &t, Kmer a, uint3
         const SlotLook p = slot_look(t, idx, cword);
         if (p.st == ST_EMPTY) {
             if (atomicCAS(t.state(idx), ST_EMPTY, ST_BUSY) == ST_EMPTY) {
-                // The key words are agent-scope atomic stores: they are written through to the point the other XCDs read from.  The READY state must
-                // not overtake them: the lane waits until they have been acknowledged (a workgroup-scope release fence is exactly that wait), then
-                // stores the state the same way.  A full agent-scope release store would in addition write back every dirty line of this XCD's L2
-                // (buffer_wbl2) — once per inserted key — which nothing here needs: the slot's words are the only data the reader relies on.
-                __hip_atomic_store(t.key_lo(idx), a.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(t.key_hi(idx), a.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (t.flags & 1u) {
-                    __hip_atomic_store(t.state(idx), ST_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __hip_atomic_store(t.state(idx), ST_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                publish_slot(t, idx, a);
                 result = (int64_t)idx;
                 done = true;
             }
             // lost the race: the slot is BUSY or READY now; look at it again
         } else if (p.st == ST_READY) {
-            if ((p.lo == a.lo && p.hi == a.hi) || !slot_holds_other_key(t, idx, p, a)) {
+            if (burst_match(p, a) || !slot_holds_other_key(t, idx, p, a)) {
                 result = (int64_t)idx;
                 seen = p.cw;
                 done = true;

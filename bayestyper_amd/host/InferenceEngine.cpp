@@ -63,6 +63,7 @@ struct GpuSampler : GibbsSampler {
         check(bt_gibbs_create(ctx, &p, &b, &g), "bt_gibbs_create");
     }
     ~GpuSampler() override {
+        if (resident_chain) bt_gibbs_noise_chain_end(g);
         if (noise_model) bt_noise_model_destroy(noise_model);
         if (d_hist) bt_free(ctx, d_hist);
         bt_gibbs_destroy(g);
@@ -123,9 +124,22 @@ struct GpuSampler : GibbsSampler {
         cd->setNoiseRates(std::vector<double>(rows->end() - S, rows->end()));
         return true;
     }
+    bool resident_chain = false;
+    bool beginResidentChain(uint32_t n_iterations, uint32_t first_collect) override {
+        int resident = 0;
+        check(bt_gibbs_noise_chain_begin(g, n_iterations, first_collect, &resident), "bt_gibbs_noise_chain_begin");
+        resident_chain = resident != 0;
+        return resident_chain;
+    }
+    void endResidentChain() override {
+        if (!resident_chain) return;
+        resident_chain = false;
+        check(bt_gibbs_noise_chain_end(g), "bt_gibbs_noise_chain_end");
+    }
     std::vector<uint64_t> noiseIteration(const double *noise, bool collect) override {
         std::vector<uint64_t> h((size_t)S * 256);
-        check(bt_gibbs_noise_iteration(g, noise, collect ? 1 : 0, h.data()), "bt_gibbs_noise_iteration");
+        if (resident_chain) check(bt_gibbs_noise_chain_step(g, noise, h.data()), "bt_gibbs_noise_chain_step");   // (the chain knows from which iteration on it collects)
+        else check(bt_gibbs_noise_iteration(g, noise, collect ? 1 : 0, h.data()), "bt_gibbs_noise_iteration");
         return h;
     }
     BatchResults results(uint32_t num_clusters) override {
@@ -144,10 +158,10 @@ struct GpuSampler : GibbsSampler {
 };
 }  // namespace
 
-std::unique_ptr<GibbsSampler> InferenceEngine::newSampler(uint32_t noise_seeding, const GibbsBatchData &batch) {
+std::unique_ptr<GibbsSampler> InferenceEngine::newSampler(uint32_t noise_seeding, const GibbsBatchData &batch, bt_ctx *on_ctx) {
     const bt_gibbs_params p = params(noise_seeding);
     if (make_sampler) return make_sampler(p, batch);
-    return std::unique_ptr<GibbsSampler>(new GpuSampler(ctx, p, batch));
+    return std::unique_ptr<GibbsSampler>(new GpuSampler(on_ctx ? on_ctx : ctx, p, batch));
 }
 
 void InferenceEngine::logRow(std::ostream &out, unsigned chain, unsigned iteration, const std::vector<double> &rates) {
@@ -218,10 +232,24 @@ void InferenceEngine::runNoiseChain(Sampler *sampler, CountDistribution *cd, uin
         pending_noise = false;   // (the sampler holds the table of the last rates)
         return;
     }
+    // The iterations: with the sampler's groups resident for the whole chain when it can (one launch per chain; the histogram and the table of an
+    // iteration cross through pinned memory), else a sweep + tally launch and a synchronisation per iteration.  The host side of an iteration — the
+    // reduction over the ranks, the exact draws — is the same either way.
+    struct ResidentGuard {   // (an exception on the host side must not leave the launch waiting for a table)
+        Sampler *s;
+        ~ResidentGuard() {
+            if (s) try { s->endResidentChain(); } catch (...) {}
+        }
+    } guard{nullptr};
+    if (sampler && pending_noise == false && sampler->beginResidentChain(n, first_collect_iteration - 1)) guard.s = sampler;
     for (uint32_t it = 1; it <= n; it++) {
         iteration(sampler, cd, it >= first_collect_iteration);
         logRow(out, chain + 1, it, cd->getNoiseRates());
         if (each) each(it, cd->getNoiseRates());
+    }
+    if (guard.s) {
+        guard.s = nullptr;
+        sampler->endResidentChain();   // (errors of a completed chain are reported)
     }
 }
 
@@ -253,6 +281,15 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
     if (!out.is_open()) throw std::runtime_error("Unable to write file " + output_prefix + ".txt");
     out << noiseParameterHeader(sample_names);
     std::vector<double> mean(S, 0.0);
+    // The helper's sampler is built on a second context of the same GPU (a stream of its own: a chain's launch stays on its stream until the chain ends, and
+    // the construction's copies and kernels must not queue behind it); chains alternate between the two contexts.
+    struct AltCtx {
+        bt_ctx *c = nullptr;
+        ~AltCtx() {
+            if (c) bt_ctx_destroy(c);
+        }
+    } alt;   // (declared before the samplers that may live on it)
+    if (!make_sampler && ctx && !getenv("BT_NOISE_SAMPLER_ON_MAIN_THREAD")) check(bt_ctx_clone(ctx, &alt.c), "bt_ctx_clone");
     std::unique_ptr<Sampler> sampler;
     std::vector<uint32_t> sampler_groups;
     // this rank's groups of the next chain (the selection depends on the selector's generator only, not on the chains' results)
@@ -268,27 +305,34 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
     struct Prepared {
         GibbsBatchData subset;
         std::unique_ptr<Sampler> sampler;
+        std::string why_not;   // the helper could not build the sampler (not enough free HBM next to the running chain's, or an error): the calling thread does, after freeing the previous one
     };
     std::future<Prepared> prepared;
+    bt_ctx *sampler_ctx = ctx;   // the context the current chain's sampler lives on
     for (uint32_t chain = 0; chain < opt.chains; chain++) {
         // The genotypers of a chain are constructed with seed + (i+1)(chain+1) (:70) and deleted afterwards (resetGroupsCallback, :240-251).  A unit
         // with fewer variants than the batch size selects the same (sorted) groups in every chain: the previous chain's sampler then only has its
         // groups reset — the reference's own sequence.  Otherwise (a unit of 100 000 variants or more: another random subset per chain), and for a
         // sampler that cannot reset, a fresh sampler over a copy of the subset; the NEXT chain's subset copy and sampler are made by a helper thread
-        // while this chain's iterations wait for the device (the twenty copies + constructions were 3.8 of the 7.9 s of this stage at chr20 size).
+        // while this chain's iterations run (the twenty copies + constructions were 3.8 of the 7.9 s of this stage at chr20 size).
         const bool again = sampler && !mine.empty() && mine == sampler_groups && sampler->resetGroups();
         if (again) {
             sampler->setNoiseLut(cd->noiseTable().data());
             sampler->initChain(chain);
         } else {
-            sampler.reset();
+            Prepared ready;
+            if (prepared.valid()) {
+                StageScope stage("  noise chains: waiting for the helper thread (next chain's subset copy + sampler)");
+                ready = prepared.get();
+            }
+            sampler.reset();   // (before anything is built on this thread: two samplers' state at once is the helper's privilege, and only when it fits)
             sampler_groups.clear();
             if (!mine.empty()) {
                 StageScope stage("  noise chains: what the helper thread had not prepared (first chain: subset copy + sampler construction)");
-                Prepared ready;
-                if (prepared.valid()) ready = prepared.get();
-                else ready.subset = unit.take(mine);
-                sampler = ready.sampler ? std::move(ready.sampler) : newSampler(1, ready.subset);
+                if (ready.subset.numGroups() == 0) ready.subset = unit.take(mine);
+                if (ready.sampler) sampler_ctx = sampler_ctx == ctx && alt.c ? alt.c : ctx;
+                else ready.sampler = newSampler(1, ready.subset, sampler_ctx);
+                sampler = std::move(ready.sampler);
                 sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
                 sampler->initChain(chain);
                 sampler_groups = mine;
@@ -296,13 +340,27 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         }
         std::vector<uint32_t> next;
         if (chain + 1 < opt.chains) next = select();
-        if (!next.empty() && next != sampler_groups)
-            prepared = std::async(std::launch::async, [this, &unit, next]() {
+        if (!next.empty() && next != sampler_groups) {
+            bt_ctx *helper_ctx = alt.c ? (sampler_ctx == ctx ? alt.c : ctx) : nullptr;
+            prepared = std::async(std::launch::async, [this, &unit, next, helper_ctx]() {
                 Prepared r;
                 r.subset = unit.take(next);
-                if (!make_sampler && !getenv("BT_NOISE_SAMPLER_ON_MAIN_THREAD")) r.sampler = newSampler(1, r.subset);
+                if (!helper_ctx) return r;
+                try {   // next to the running chain's sampler only when its state fits the free HBM with room to spare
+                    const bt_gibbs_params p = params(1);
+                    const bt_gibbs_batch view = r.subset.view();
+                    uint64_t need = 0, total = 0, free_bytes = 0;
+                    int num_cu = 0;
+                    if (bt_gibbs_state_bytes(helper_ctx, &p, &view, &need) != BT_OK || bt_ctx_info(helper_ctx, &num_cu, &total, &free_bytes, nullptr, 0) != BT_OK) r.why_not = bt_last_error();
+                    else if ((double)need > 0.7 * (double)free_bytes) r.why_not = "sampler state does not fit next to the running chain's";
+                    else r.sampler = newSampler(1, r.subset, helper_ctx);
+                } catch (const std::exception &e) {
+                    r.sampler.reset();
+                    r.why_not = e.what();
+                }
                 return r;
             });
+        }
         pending_noise = false;   // (the chain's sampler starts with the current table)
         logRow(out, chain + 1, 0, cd->getNoiseRates());
         runNoiseChain(sampler.get(), cd, chain, opt.burn_in + opt.samples + 1 /* never collects */, out, [&](uint32_t it, const std::vector<double> &rates) {

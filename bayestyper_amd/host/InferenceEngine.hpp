@@ -89,6 +89,11 @@ struct GibbsSampler {
     // (collecting from iteration first_collect on); noise counts; reduction over the ranks (device_reduce, may be empty); the rates drawn
     // from count_distribution's generator; the rebuilt table }.  rows receives the rates of every iteration ([it * S + s]); afterwards
     // count_distribution holds the last rates and the advanced generator.  false: not supported (the driver then iterates itself).
+    // A chain's iterations with the sampler's groups RESIDENT on its side (bt_gibbs_noise_chain_begin / _step / _end: one launch per chain, the
+    // per-iteration exchange through a mailbox in pinned memory): begin returns false when the sampler cannot (the driver then iterates with
+    // noiseIteration as before); while a chain is resident noiseIteration is a step of it.  first_collect is 0-based.
+    virtual bool beginResidentChain(uint32_t /*num_iterations*/, uint32_t /*first_collect*/) { return false; }
+    virtual void endResidentChain() {}
     typedef std::function<void(uint64_t *d_hist, size_t n)> DeviceReducer;   // enqueues the all-reduce of a DEVICE histogram on the context's stream
     virtual bool noiseChain(CountDistribution *, uint32_t, uint32_t, const DeviceReducer &, std::vector<double> *) { return false; }
     virtual BatchResults results(uint32_t num_clusters) = 0;
@@ -124,7 +129,7 @@ class InferenceEngine {
     typedef GibbsSampler Sampler;
     void iteration(Sampler *sampler, CountDistribution *count_distribution, bool collect);
     void logRow(std::ostream &out, unsigned chain, unsigned iteration, const std::vector<double> &rates);
-    std::unique_ptr<Sampler> newSampler(uint32_t noise_seeding, const GibbsBatchData &batch);
+    std::unique_ptr<Sampler> newSampler(uint32_t noise_seeding, const GibbsBatchData &batch, bt_ctx *on_ctx = nullptr);
     void runDefault(const GibbsBatchData &batch, const CountDistribution &count_distribution, const Collector &collect);
     bt_gibbs_params params(uint32_t noise_seeding) const;
 

@@ -490,6 +490,11 @@ bt_gibbs_init_chain = _sig("bt_gibbs_init_chain", [vp, C.c_uint32])
 bt_gibbs_sweep = _sig("bt_gibbs_sweep", [vp, C.c_uint32, C.c_int])
 bt_gibbs_run = _sig("bt_gibbs_run", [vp])
 bt_gibbs_noise_counts = _sig("bt_gibbs_noise_counts", [vp, vp, C.c_int])
+bt_gibbs_noise_iteration = _sig("bt_gibbs_noise_iteration", [vp, vp, C.c_int, vp])
+bt_gibbs_noise_chain_begin = _sig("bt_gibbs_noise_chain_begin", [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_int)])
+bt_gibbs_noise_chain_step = _sig("bt_gibbs_noise_chain_step", [vp, vp, vp])
+bt_gibbs_noise_chain_end = _sig("bt_gibbs_noise_chain_end", [vp])
+bt_ctx_clone = _sig("bt_ctx_clone", [vp, C.POINTER(vp)])
 bt_gibbs_reset_groups = _sig("bt_gibbs_reset_groups", [vp])
 bt_gibbs_result_sizes = _sig("bt_gibbs_result_sizes", [vp, u64p, u64p])
 bt_gibbs_result_fetch = _sig("bt_gibbs_result_fetch", [vp] * 7)
@@ -599,6 +604,30 @@ class Gibbs:
         out = d.download(np.uint64, self.S * 256)
         d.free()
         return out
+
+    def noise_iteration(self, lut_n, collect):
+        """bt_gibbs_noise_iteration: (the table for this iteration's sweep or None;) one sweep; noise counts [S*256] + clearGenotyperCache"""
+        if lut_n is not None:
+            lut_n = np.ascontiguousarray(lut_n, np.float64)
+        h = np.zeros(self.S * 256, np.uint64)
+        check(bt_gibbs_noise_iteration(self.h, _np_ptr(lut_n) if lut_n is not None else None, int(collect), _np_ptr(h)))
+        return h
+
+    def noise_chain_begin(self, num_iterations, first_collect):
+        """bt_gibbs_noise_chain_begin -> True when the chain runs as one resident launch (then noise_chain_step per iteration, noise_chain_end)"""
+        r = C.c_int(0)
+        check(bt_gibbs_noise_chain_begin(self.h, num_iterations, first_collect, C.byref(r)))
+        return bool(r.value)
+
+    def noise_chain_step(self, lut_n):
+        if lut_n is not None:
+            lut_n = np.ascontiguousarray(lut_n, np.float64)
+        h = np.zeros(self.S * 256, np.uint64)
+        check(bt_gibbs_noise_chain_step(self.h, _np_ptr(lut_n) if lut_n is not None else None, _np_ptr(h)))
+        return h
+
+    def noise_chain_end(self):
+        check(bt_gibbs_noise_chain_end(self.h))
 
     def reset_groups(self):
         check(bt_gibbs_reset_groups(self.h))

@@ -47,6 +47,10 @@ int bt_device_count(int *count);
 /* one context = one GPU + one stream (replaces the reference's `-p` thread pool for this path:
  * src/bayesTyper/main.cpp:128,214,467) */
 int bt_ctx_create(int device_id, bt_ctx **out);
+/* a second context on the same GPU with a stream of its own: work a helper thread enqueues (the next noise chain's sampler construction,
+ * InferenceEngine.cpp:191-211 constructs a chain's genotypers while nothing else runs; here it overlaps the previous chain) does not queue behind
+ * the first context's stream.  Handles created on either context live in the same device memory. */
+int bt_ctx_clone(bt_ctx *ctx, bt_ctx **out);
 int bt_ctx_destroy(bt_ctx *ctx);
 /* run all subsequent work of this context on an externally owned hipStream_t (e.g. torch's
  * current stream); NULL restores the context's own stream */
@@ -466,6 +470,21 @@ int bt_gibbs_noise_counts(bt_gibbs *g, uint64_t *d_hist, int zero_first);
  * (+ clearGenotyperCache) lands in h_hist [S*256].  The caller draws the new rates from h_hist (after its all-reduce over the ranks) and
  * hands the rebuilt table to the next call. */
 int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_samples, uint64_t *h_hist);
+/* A whole chain of a noise driver (InferenceEngine.cpp:135-276 estimateNoise, :384-472 estimateNoiseAndGenotypes; one iteration = :77-98) as ONE
+ * resident launch: every tile keeps its workgroup — sampler state in registers / LDS — for the num_iterations iterations (collecting from iteration
+ * first_collect on, 0-based), and the per-iteration exchange (noise-count histogram out, rebuilt noise table in) goes through a mailbox in pinned host
+ * memory instead of a kernel launch + copies + a stream synchronisation per iteration.  The draws stay where they are exact: the caller takes the
+ * histogram of iteration i from step i, reduces it over its ranks, draws the rates (CountDistribution::sampleNoiseParameters, CountDistribution.cpp:173-186:
+ * libstdc++ / glibc) and hands the rebuilt table to step i + 1.
+ *   begin: *resident = 1 when the chain was started this way; 0 (and BT_OK) when this batch cannot be (its workgroups do not fit the GPU together, or
+ *          tiles with large dense tables want the whole-GPU refill between iterations): the caller then iterates with bt_gibbs_noise_iteration.
+ *   step:  h_noise = the table for this iteration's sweep ([S*256]; NULL: unchanged; must be NULL for the first iteration, which runs with the table
+ *          of bt_gibbs_set_lut / bt_gibbs_set_noise_lut); returns when this iteration's histogram is in h_hist [S*256] (caches cleared, :90-92).
+ *   end:   after the last step (or earlier: the launch is told to stop at its next exchange); synchronises.  No other operation on g between begin and end.
+ * Every wait on either side has a deadline (BT_NOISE_CHAIN_TIMEOUT_S, default 60 s): a stall is an error, never a hang. */
+int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t first_collect, int *resident);
+int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hist);
+int bt_gibbs_noise_chain_end(bt_gibbs *g);
 /* resetGroup for every group (InferenceEngine.cpp:100-113): genotypers are rebuilt by the next init_chain */
 int bt_gibbs_reset_groups(bt_gibbs *g);
 

@@ -292,6 +292,68 @@ def test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path):
     assert exact == flat["num_clusters"]
 
 
+@pytest.mark.parametrize("S,parts", [(3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1))), (1, (("A", 200, 8), ("B", 20, 2))), (10, (("A", 70, 4), ("B", 12, 2)))])
+def test_resident_noise_chain_equals_launch_per_iteration(gpu_ctx, oracle, monkeypatch, S, parts):
+    """bt_gibbs_noise_chain_begin / _step / _end (a chain of a noise driver as ONE resident launch: sampler state kept in registers / LDS across the
+    iterations, histogram and table exchanged through pinned memory) against bt_gibbs_noise_iteration (a sweep + a tally launch and a synchronisation per
+    iteration) on two samplers over the same batch — two-haplotype tiles (gibbs_simple_kernel), LDS-resident multi-allelic and many-candidate clusters
+    (gibbs_hot_kernel) and nested groups (gibbs_kernel, hot arrays swapped per visit) — with another noise table every iteration, collecting from the
+    fourth iteration on, two chains with a group reset between them: the histogram of every iteration, every sampled diplotype of every sweep and the
+    collected results are identical."""
+    from bayestyper_amd import lib, synth
+
+    monkeypatch.setenv("BT_NOISE_CHAIN_WIDE", "1")   # (the many-candidate clusters' large tables: refilled by their own lanes inside the resident launch)
+    flat = synth.concat([synth.make_batch(sh, n, S, seed=31 + i, templates=t) for i, (sh, n, t) in enumerate(parts)])
+    flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
+    lut_g, lut_n = _oracle.build_luts(oracle, S)
+    n_it, first_collect = 9, 3
+    tables = [_oracle.build_luts(oracle, S, noise_rate=0.02 + 0.03 * i)[1] for i in range(n_it)]
+    kw = dict(seed=77, chains=2, burn=first_collect, iters=n_it - first_collect, noise_seeding=1)
+    ga, gb = lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, **kw), lib.Gibbs(gpu_ctx, flat, lut_g, lut_n, **kw)
+    ga.trace_enable(2 * n_it)
+    gb.trace_enable(2 * n_it)
+    for chain in range(2):
+        # (one after the other: both samplers enqueue on the context's stream, and a resident launch stays on it until its chain ends)
+        ga.set_noise_lut(lut_n)
+        ga.init_chain(chain)
+        want = [ga.noise_iteration(tables[it] if it else None, it >= first_collect) for it in range(n_it)]
+        gb.set_noise_lut(lut_n)
+        gb.init_chain(chain)
+        assert gb.noise_chain_begin(n_it, first_collect), "the batch should fit the GPU as one resident launch"
+        for it in range(n_it):
+            hb = gb.noise_chain_step(tables[it] if it else None)
+            assert hb.sum() > 0 and np.array_equal(want[it], hb), (chain, it)
+        gb.noise_chain_end()
+        if chain == 0:
+            ga.reset_groups()
+            gb.reset_groups()
+    gpu_ctx.sync()
+    for g, (ta, tb) in enumerate(zip(ga.trace(), gb.trace())):
+        assert np.array_equal(ta, tb), f"group {g}"
+    ra, rb = ga.results(), gb.results()
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
+    assert ra["freq"].sum() > 0
+    # a chain given up half way: the launch stops at its next exchange and the sampler is usable again
+    gb.reset_groups()
+    gb.set_noise_lut(lut_n)
+    gb.init_chain(0)
+    assert gb.noise_chain_begin(50, 50)
+    gb.noise_chain_step(None)
+    gb.noise_chain_end()
+    gb.reset_groups()
+    gb.init_chain(1)
+    gb.sweep(2, False)
+    gpu_ctx.sync()
+    ga.close(), gb.close()
+
+
+def test_noise_drivers_launch_per_iteration_path(gpu_ctx, oracle, tmp_path, monkeypatch):
+    """BT_NOISE_CHAIN_OFF=1: the noise drivers iterate with a launch + synchronisation per iteration (what batches that cannot be resident take): same rows"""
+    monkeypatch.setenv("BT_NOISE_CHAIN_OFF", "1")
+    test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path)
+
+
 def test_noise_drivers_device_chain_opt_in(gpu_ctx, oracle, tmp_path, monkeypatch):
     """BT_NOISE_ON_DEVICE=1: a driver's whole chain runs on the device (bt_gibbs_noise_chain, no host round trip per iteration; the rates drawn with ocml's
     log / pow / sqrt): the rates agree within RATE_RTOL, the collected genotype samples are identical.  (The default — the host loop — is exact.)"""

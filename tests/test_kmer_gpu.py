@@ -234,18 +234,29 @@ def test_table_duplicates_in_a_wavefront_clear_reserve_overflow(gpu_ctx, oracle)
     small.close()
 
 
-def test_table_same_keys_from_every_xcd(gpu_ctx):
+@pytest.mark.parametrize("n_samples", [3, 10, 30])
+def test_table_same_keys_from_every_xcd(gpu_ctx, n_samples):
     """addKmer when the SAME keys arrive from workgroups all over the chip at the same time (the key set repeated 32 times in one batch: the copies of a
-    key sit megabytes apart, i.e. in workgroups on different XCDs with their own L2): a key is published with ordered write-through stores and probed with
-    agent-scope loads — no key may end up in two slots, none may be lost; repeated on fresh tables because the race is a matter of timing."""
+    key sit megabytes apart, i.e. in workgroups on different XCDs with their own L2): a key is published with ordered write-through stores (key words
+    acknowledged before READY is stored) and probed with agent-scope loads — no key may end up in two slots, none may be lost; repeated on fresh tables
+    because the race is a matter of timing.  Three samples = 32-byte slots; ten = 48-byte slots, whose state and key words straddle 64 / 128 / 256-byte
+    boundaries (different channels); thirty = 64-byte slots.  The key set holds the keys a stale (zero) key word could be mistaken for: the all-A k-mer
+    (0, 0), keys with a zero high word (k-mers ending in 23 A's) and keys with a zero low word, next to keys that share the other word with them."""
     from bayestyper_amd import lib
 
-    rng = np.random.default_rng(77)
-    uniq = np.unique(np.stack([rng.integers(0, 2 ** 62, 150_000, dtype=np.uint64), rng.integers(0, 2 ** 46, 150_000, dtype=np.uint64)], axis=1), axis=0)
+    rng = np.random.default_rng(77 + n_samples)
+    lo = rng.integers(1, 2 ** 62, 150_000, dtype=np.uint64)
+    hi = rng.integers(1, 2 ** 46, 150_000, dtype=np.uint64)
+    zero = np.zeros(20_000, dtype=np.uint64)
+    keys = np.concatenate([np.stack([lo, hi], axis=1),
+                           np.stack([lo[:20_000], zero], axis=1),            # (L, 0) next to (L, H)
+                           np.stack([zero, hi[:20_000]], axis=1),            # (0, H) next to (L, H)
+                           np.zeros((1, 2), dtype=np.uint64)])               # poly-A
+    uniq = np.unique(keys, axis=0)
     batch = np.ascontiguousarray(np.tile(uniq, (32, 1)))
     want = uniq[np.lexsort((uniq[:, 0], uniq[:, 1]))]
     for rep in range(5):
-        t = lib.Table(gpu_ctx, 200_000, 3, K)               # capacity 2^19: load 0.29
+        t = lib.Table(gpu_ctx, 260_000, n_samples, K)               # capacity 2^19: load 0.36
         t.insert(batch[rng.permutation(len(batch))] if rep else batch)
         st = t.status()
         assert st["num_keys"] == len(uniq) and not st["overflowed"], (rep, st)
