@@ -477,6 +477,7 @@ struct bt_gibbs {
         uint8_t *d_sync = nullptr;        // device: [S*256] u64 histogram | arrived | abort | table_seq copies
         NoiseChainCtl *d_ctl = nullptr;
         NoiseChainCtl ctl{};
+        unsigned long long *d_busy = nullptr;   // BT_NOISE_CHAIN_PROF: per tile, the ticks its workgroup worked (the rest of a chain it waited for the others / the host)
         bool active = false;
         uint32_t n = 0, next = 0;
     } nc;
@@ -940,6 +941,17 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         while (at < n_y) {
             tile_start.push_back(at);
             at += std::min<uint32_t>(width_y, n_y - at);
+        }
+        // The sampler of a noise driver (noise_seeding): its chains run as ONE resident launch in which every workgroup is charged the LDS of the hungriest
+        // tile and an iteration lasts as long as its slowest tile (bt_gibbs_noise_chain_begin).  Single clusters with 4 or 5 candidates in 64-group tiles
+        // are both (36 - 44 KB of LDS; 190 - 260 us per iteration with their hot arrays pushed out to HBM against 75 us of the others): they get 16 groups
+        // per wavefront (four copies share the table fills), like the clusters with 6..15 candidates above.
+        uint32_t n_z = n_y;
+        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS"))
+            while (n_z < G && shapes[n_z].Hmax >= 4) ++n_z;
+        while (at < n_z) {
+            tile_start.push_back(at);
+            at += std::min<uint32_t>(width_y, n_z - at);
         }
         while (at < G) {
             tile_start.push_back(at);
@@ -1569,6 +1581,7 @@ int bt_gibbs_destroy(bt_gibbs *g) {
     if (g->nc.h_mail) (void)hipHostFree(g->nc.h_mail);
     if (g->nc.d_sync) (void)hipFree(g->nc.d_sync);
     if (g->nc.d_ctl) (void)hipFree(g->nc.d_ctl);
+    if (g->nc.d_busy) (void)hipFree(g->nc.d_busy);
     for (auto &c : g->classes) {
         if (c.stream) {
             (void)hipStreamSynchronize(c.stream);
@@ -1665,7 +1678,7 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
 
 // ---- a chain of a noise driver as ONE resident launch (bt_noise_chain.hpp) ----
 namespace {
-inline uint32_t nc_bins_bytes(uint32_t S) { return (S * NC_BINS + 1u) * 4u; }
+inline uint32_t nc_bins_bytes(uint32_t S) { return (S * NC_BINS + 4u) * 4u; }   // the bins, the flag word, (aligned) the profiling time stamp
 constexpr uint32_t kResidentTableEntries = 4096;
 struct NcMail {   // layout of the pinned mailbox
     uint64_t *hist;
@@ -1708,9 +1721,7 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     // need of the hungriest tile + the bins): tiles <= workgroups per CU x CUs, exactly.  Tiles with large dense tables want the whole-GPU refill between
     // iterations (nan_fill_kernel / ucache_prefill_kernel), which a resident launch cannot give them: such batches keep the launch-per-iteration path.
     const double fill_limit = getenv("BT_NOISE_CHAIN_FILL") ? atof(getenv("BT_NOISE_CHAIN_FILL")) : 1.0;
-    uint32_t class_lds = 0;
     for (const auto &c : g->classes) {
-        class_lds = std::max(class_lds, c.lds);
         if (c.num_fill || c.num_prefill) {
             // large dense tables of unique-k-mer sums: up to kResidentTableEntries entries per lane they are invalidated and refilled by the tile's own lanes
             // (cache_clear's "dirty = 2": what a launch without the wide refill does); above, the launch-per-iteration path with its whole-GPU refill is faster
@@ -1719,13 +1730,42 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
             if (biggest > kResidentTableEntries && !getenv("BT_NOISE_CHAIN_WIDE")) return BT_OK;
         }
     }
-    const uint32_t bins_off = (class_lds + 15u) & ~15u, lds = bins_off + nc_bins_bytes(g->S);
-    if (lds > kHotBudget || g->ntiles == 0) return BT_OK;
+    // LDS per workgroup: every workgroup of the launch is charged the same amount.  The cap is the largest tile need with which all tiles are still resident
+    // together; the (few, many-candidate) tiles above it keep their hot arrays in HBM for the chain (RESIDENT_NEVER); the tiles of two-haplotype clusters
+    // (the bulk, and they cannot do without their block) must fit.
+    if (g->ntiles == 0) return BT_OK;
+    std::vector<uint32_t> needs;
+    uint32_t simple_need = 0;
+    for (const TileDesc &d : g->tiles) {
+        needs.push_back(tile_lds_bytes(d));
+        if (d.simple) simple_need = std::max(simple_need, needs.back());
+    }
+    std::sort(needs.begin(), needs.end());
+    needs.erase(std::unique(needs.begin(), needs.end()), needs.end());
+    const double fits = fill_limit * g->ctx->num_cu;
+    uint32_t lds_cap = 0, bins_off = 0, lds = 0;
     int occ = 0;
-    BT_HIP(occupancy_gibbs_chain_kernel(&occ, lds));
-    if (getenv("BT_GIBBS_DEBUG"))
-        fprintf(stderr, "bt_gibbs_noise_chain_begin: %u tiles, %u B of LDS each: %d workgroups per CU x %d CUs (limit %.2f)\n", g->ntiles, lds, occ, g->ctx->num_cu, fill_limit);
-    if (occ < 1 || (double)g->ntiles > fill_limit * occ * g->ctx->num_cu) return BT_OK;
+    bool found = false;
+    for (size_t lo = 0, hi = needs.size(); lo < hi;) {   // (occupancy is monotone in the LDS need: binary search over the distinct needs)
+        const size_t mid = (lo + hi) / 2;
+        const uint32_t off = (needs[mid] + 15u) & ~15u, bytes = off + nc_bins_bytes(g->S);
+        int o = 0;
+        if (bytes <= kHotBudget) BT_HIP(occupancy_gibbs_chain_kernel(&o, bytes));
+        if (o >= 1 && (double)g->ntiles <= fits * o) {
+            found = true, lds_cap = needs[mid], bins_off = off, lds = bytes, occ = o;
+            lo = mid + 1;
+        } else
+            hi = mid;
+    }
+    if (const char *e = getenv("BT_NOISE_CHAIN_LDS_CAP"))   // (tests: push more tiles out of LDS than residency asks for; the workgroups are still charged `lds`)
+        if (found) lds_cap = std::min(lds_cap, std::max<uint32_t>((uint32_t)strtoul(e, nullptr, 0), simple_need));
+    if (getenv("BT_GIBBS_DEBUG")) {
+        size_t demoted = 0;
+        for (const TileDesc &d : g->tiles) demoted += tile_lds_bytes(d) > lds_cap;
+        fprintf(stderr, "bt_gibbs_noise_chain_begin: %u tiles (LDS needs %u .. %u B, two-haplotype tiles %u B): %s, %u B of LDS per workgroup, %d workgroups per CU x %d CUs, %zu tiles without LDS\n",
+                g->ntiles, needs.front(), needs.back(), simple_need, found && lds_cap >= simple_need ? "resident" : "NOT resident", lds, occ, g->ctx->num_cu, demoted);
+    }
+    if (!found || lds_cap < simple_need) return BT_OK;
     const uint32_t total = g->ntiles;
     // (2) mailbox + device words
     const size_t nh = (size_t)g->S * 256;
@@ -1758,8 +1798,14 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
         k.n_iterations = num_iterations;
         k.first_collect = first_collect;
         k.S = g->S;
-        k.pad = 0;
+        k.lds_cap = lds_cap;
         k.timeout_ticks = (unsigned long long)(nc_timeout_seconds() * 1e3 * wall_khz);
+        k.busy = nullptr;
+        if (getenv("BT_NOISE_CHAIN_PROF")) {
+            if (!g->nc.d_busy) BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_busy), (size_t)g->ntiles * 8));
+            BT_HIP(hipMemsetAsync(g->nc.d_busy, 0, (size_t)g->ntiles * 8, st));
+            k.busy = g->nc.d_busy;
+        }
     }
     BT_HIP(hipMemcpyAsync(g->nc.d_ctl, &g->nc.ctl, sizeof(NoiseChainCtl), hipMemcpyHostToDevice, st));
     BT_HIP(hipStreamSynchronize(st));   // (the control block is read from pageable memory)
@@ -1820,6 +1866,24 @@ int bt_gibbs_noise_chain_end(bt_gibbs *g) {
     g->nc.active = false;
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
     if (complete && nc_load(mail.hist_seq) == NC_ABORT) return fail("bt_gibbs_noise_chain_end: the resident launch was aborted");
+    if (g->nc.d_busy && g->nc.ctl.busy) {   // BT_NOISE_CHAIN_PROF: which tiles an iteration waits for
+        std::vector<unsigned long long> busy(g->ntiles);
+        BT_HIP(hipMemcpy(busy.data(), g->nc.d_busy, busy.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> order(g->ntiles);
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return busy[a] > busy[b]; });
+        const double per_it = 1e-2 / std::max(1u, g->nc.next);   // ticks of 10 ns -> microseconds per iteration
+        fprintf(stderr, "bt_gibbs_noise_chain_end: busy microseconds per iteration and tile (of %u tiles): median %.1f;", g->ntiles, busy[order[g->ntiles / 2]] * per_it);
+        for (uint32_t q = 0; q < std::min<uint32_t>(8, g->ntiles); ++q) {
+            const TileDesc &d = g->tiles[order[q]];
+            fprintf(stderr, " [tile %u: %.1f us, %u lanes, H %u, K %u, NU %u, simple %u, lds %u%s]", order[q], busy[order[q]] * per_it, d.num_lanes, d.Hm, d.Km, d.NUm, d.simple, tile_lds_bytes(d),
+                    tile_lds_bytes(d) > g->nc.ctl.lds_cap ? " (in HBM)" : "");
+        }
+        double simple_sum = 0, other_sum = 0;
+        uint32_t ns = 0, no = 0;
+        for (uint32_t t = 0; t < g->ntiles; ++t) (g->tiles[t].simple ? (simple_sum += busy[t], ++ns) : (other_sum += busy[t], ++no));
+        fprintf(stderr, "; mean two-haplotype tiles %.1f us (%u), others %.1f us (%u)\n", ns ? simple_sum * per_it / ns : 0.0, ns, no ? other_sum * per_it / no : 0.0, no);
+    }
     return BT_OK;
 }
 

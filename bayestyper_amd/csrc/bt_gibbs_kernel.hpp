@@ -47,7 +47,7 @@ __device__ BT_NOINLINE void group_init_chain(Env env, uint32_t chain, uint32_t n
 
 // VariantClusterGenotyper::updateNestedVariantClusterInfo (VariantClusterGenotyper.cpp:140-206): child's info := parent's info, updated
 __device__ BT_NOINLINE void prepare_nested(Env env, uint32_t v_parent, uint32_t v_child) {
-    if (env.resident != RESIDENT_ALL) env.resident = 0xFFFFFFFFu;   // swap mode: between visits every vertex's hot arrays are in HBM
+    if (env.resident != RESIDENT_ALL && env.resident != RESIDENT_NEVER) env.resident = 0xFFFFFFFFu;   // swap mode: between visits every vertex's hot arrays are in HBM
     const Tile t = make_tile(env);
     const GParams BT_CAS &P = env_params(env);
     const Vx c = make_vx(t, v_parent), cc = make_vx(t, v_child);
@@ -177,7 +177,7 @@ __device__ __forceinline__ void group_sweep(const Env &env, const Tile &t, const
 // VariantClusterGenotyper::getNoiseCounts (:757-779) + clearCache (:131-138) for every vertex of the lane's group, inside a resident chain of a noise
 // driver (bt_noise_chain.hpp): the counts go to the workgroup's LDS bins.  The hot arrays are read where they are (LDS for resident groups).
 __device__ BT_NOINLINE void noise_tally_group(Env env, uint32_t nvert, const NoiseChainCtl *nc) {
-    if (env.resident != RESIDENT_ALL) env.resident = 0xFFFFFFFFu;   // swap mode: between visits every vertex's hot arrays are in HBM
+    if (env.resident != RESIDENT_ALL && env.resident != RESIDENT_NEVER) env.resident = 0xFFFFFFFFu;   // swap mode: between visits every vertex's hot arrays are in HBM
     const Tile t = make_tile(env);
     const GParams BT_CAS &P = env_params(env);
     auto *bins = nc_bins(nc);
@@ -249,7 +249,10 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     const NoiseChainCtl *nc = is_nc ? (const NoiseChainCtl *)hist : nullptr;
     // groups of ONE cluster keep that cluster's hot arrays in LDS for the whole launch; larger groups swap per vertex visit
     // (and so do multi-cluster groups of narrow tiles, whose LDS rows are interleaved over fewer lanes: TileDesc::lds_all)
-    const bool whole = (t.d->nvm == 1 || t.d->lds_all) && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || is_nc);
+    // (a resident chain charges every workgroup the same LDS: tiles above its cap keep their hot arrays in HBM for the launch — RESIDENT_NEVER)
+    const bool no_lds = is_nc && (t.d->lds_all ? t.d->hot_bytes * t.d->nvm : t.d->hot_bytes) > nc->lds_cap;
+    if (no_lds) env.resident = t.resident = RESIDENT_NEVER;
+    const bool whole = !no_lds && (t.d->nvm == 1 || t.d->lds_all) && t.d->hot_bytes != 0 && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || is_nc);
     if (whole) {
         env.resident = RESIDENT_ALL;
         for (uint32_t v = 0; v < nvert; ++v) hot_swap(env, v, true);

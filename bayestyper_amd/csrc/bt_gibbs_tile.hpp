@@ -168,6 +168,7 @@ constexpr uint32_t KSC_WAYS = 4;          // recently rebuilt k-mer-stats caches
 constexpr uint32_t KSC_NOKEY = 0xFFFEFFFEu;   // (haplotype indices are < 0xFFFE)
 constexpr uint32_t NOHOT = 0xFFFFFFFFu;
 constexpr uint32_t RESIDENT_ALL = 0xFFFFFFFEu;   // Env/Tile::resident: every vertex of the group has its hot arrays in LDS
+constexpr uint32_t RESIDENT_NEVER = 0xFFFFFFFDu; // Env/Tile::resident: this launch keeps the tile's hot arrays in HBM (gibbs_chain_kernel: a tile whose LDS block would keep the chain's tiles from being resident together)
 
 struct GParams {
     uint32_t S, seed, num_chains, burn_in, num_iterations, max_hvk, noise_seeding;
@@ -404,7 +405,7 @@ __device__ inline Tile make_tile(const Env &e_in) {
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     t.resident = e_in.resident;   // per lane: lanes of a tile may be at different vertices of their groups
-    t.hot = (t.resident != 0xFFFFFFFFu && t.d->hot_bytes) ? lds_block() : nullptr;
+    t.hot = (t.resident != 0xFFFFFFFFu && t.resident != RESIDENT_NEVER && t.d->hot_bytes) ? lds_block() : nullptr;
     return t;
 }
 __device__ inline const GParams BT_CAS &env_params(const Env &e) { return *(const GParams BT_CAS *)uniform_ptr(e.P); }

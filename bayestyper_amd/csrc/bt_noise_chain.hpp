@@ -43,8 +43,10 @@ struct NoiseChainCtl {   // device memory, one per launch class (the pointers ar
     uint32_t total_wgs;                // workgroups of all classes
     uint32_t bins_off;                 // LDS byte offset of this class's bins: [S * NC_BINS] u32 + one flag word
     uint32_t n_iterations, first_collect;
-    uint32_t S, pad;
+    uint32_t S;
+    uint32_t lds_cap;                  // tiles whose hot arrays need more LDS than this keep them in HBM for the chain
     unsigned long long timeout_ticks;  // wall_clock64() ticks (100 MHz) a single wait may last
+    unsigned long long *busy;          // profiling (BT_NOISE_CHAIN_PROF): per workgroup, ticks between the end of its wait and its arrival, summed over the iterations; or null
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -95,6 +97,7 @@ __device__ static __noinline__ void nc_begin(const NoiseChainCtl *ctl) {
     const NcLanes L = nc_lanes();
     if (L.on)
         for (uint32_t i = L.rank; i <= ctl->S * NC_BINS; i += L.count) bins[i] = 0;
+    if (ctl->busy && threadIdx.x == 0) *(unsigned long long NC_LAS *)(bins + ((ctl->S * NC_BINS + 2u) & ~1u)) = (unsigned long long)wall_clock64();
     __syncthreads();
 }
 
@@ -116,6 +119,7 @@ __device__ static __noinline__ bool nc_wait_table(const NoiseChainCtl *ctl, uint
             }
         }
         *flag = v == NC_ABORT ? 1u : 0u;
+        if (ctl->busy) *(unsigned long long NC_LAS *)(bins + ((ctl->S * NC_BINS + 2u) & ~1u)) = (unsigned long long)wall_clock64();
     }
     __syncthreads();
     const bool ok = *flag == 0;
@@ -144,6 +148,7 @@ __device__ static __noinline__ bool nc_iteration_end(const NoiseChainCtl *ctl, u
     nc_wait_vm();      // the adds have been performed at the device's coherence point
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (ctl->busy) ctl->busy[blockIdx.x] += (unsigned long long)wall_clock64() - *(unsigned long long NC_LAS *)(bins + ((S * NC_BINS + 2u) & ~1u));
         const uint32_t old = __hip_atomic_fetch_add(ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *flag = old == (it + 1u) * ctl->total_wgs - 1u ? 1u : 0u;
     }

@@ -344,8 +344,12 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
             bt_ctx *helper_ctx = alt.c ? (sampler_ctx == ctx ? alt.c : ctx) : nullptr;
             prepared = std::async(std::launch::async, [this, &unit, next, helper_ctx]() {
                 Prepared r;
-                r.subset = unit.take(next);
+                {
+                    StageScope stage("  noise chains (helper thread, overlapped): subset copy");
+                    r.subset = unit.take(next);
+                }
                 if (!helper_ctx) return r;
+                StageScope stage("  noise chains (helper thread, overlapped): sampler construction");
                 try {   // next to the running chain's sampler only when its state fits the free HBM with room to spare
                     const bt_gibbs_params p = params(1);
                     const bt_gibbs_batch view = r.subset.view();
