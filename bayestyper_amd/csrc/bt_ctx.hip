@@ -2,6 +2,7 @@
 #include "bt_internal.hpp"
 
 #include <cstring>
+#include <vector>
 
 namespace bt {
 static thread_local std::string g_last_error;
@@ -11,6 +12,22 @@ int fail(const std::string &msg) {
     return BT_ERR;
 }
 }  // namespace bt
+
+namespace {
+// Two single-thread kernels that need each other: each raises its flag and waits (bounded) for the other's.  Both see the other's flag only when the two
+// streams they were launched on run CONCURRENTLY — HIP streams that the runtime has put on the same hardware queue run one after the other.
+__global__ void stream_pair_probe_kernel(uint32_t *flags, int me, unsigned long long timeout_ticks) {
+    __hip_atomic_store(&flags[me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    uint32_t seen = 0;
+    while (!seen && (unsigned long long)wall_clock64() - t0 < timeout_ticks) {
+        seen = __hip_atomic_load(&flags[1 - me], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_sleep(10);
+    }
+    // (a kernel that starts after the other one gave up finds the other's flag raised: only "both overlapped" counts, so each also reports whether it waited to the end)
+    flags[2 + me] = seen && (unsigned long long)wall_clock64() - t0 < timeout_ticks ? 1u : 0u;
+}
+}  // namespace
 
 extern "C" {
 
@@ -53,10 +70,46 @@ int bt_ctx_create(int device_id, bt_ctx **out) {
 int bt_ctx_clone(bt_ctx *ctx, bt_ctx **out) {
     if (!ctx || !out) return bt::fail("bt_ctx_clone: null argument");
     BT_HIP(hipSetDevice(ctx->device));
+    // The new stream must run CONCURRENTLY with the original's: the runtime deals its hardware queues (four by default) to the process's streams round robin,
+    // and two streams on one hardware queue run their kernels one after the other (a sampler built on the clone while a resident noise chain occupies the
+    // original would wait for the chain to end).  Candidates are probed with a pair of kernels that need each other; the first that overlaps is taken.
+    int wall_khz = 0;
+    if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
+    uint32_t *d_flags = nullptr;
+    BT_HIP(hipMalloc(reinterpret_cast<void **>(&d_flags), 16));
+    hipStream_t chosen = nullptr;
+    std::vector<hipStream_t> rejected;
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 12 && !chosen && e == hipSuccess; ++attempt) {
+        hipStream_t cand = nullptr;
+        e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+        if (e != hipSuccess) break;
+        uint32_t h[4] = {0, 0, 0, 0};
+        e = hipMemcpy(d_flags, h, 16, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        const unsigned long long ticks = (unsigned long long)wall_khz * 3;   // 3 ms
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(stream_pair_probe_kernel, dim3(1), dim3(1), 0, ctx->stream, d_flags, 0, ticks);
+            hipLaunchKernelGGL(stream_pair_probe_kernel, dim3(1), dim3(1), 0, cand, d_flags, 1, ticks);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(cand);
+        if (e == hipSuccess) e = hipMemcpy(h, d_flags, 16, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && h[2] && h[3]) chosen = cand;
+        else rejected.push_back(cand);
+    }
+    if (!chosen && !rejected.empty()) {   // no candidate overlapped (a runtime with a single hardware queue): still a stream of its own, in order with the original at worst
+        chosen = rejected.back();
+        rejected.pop_back();
+    }
+    for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+    (void)hipFree(d_flags);
+    if (e != hipSuccess || !chosen) return bt::fail(std::string("bt_ctx_clone: ") + hipGetErrorString(e));
     bt_ctx *c = new bt_ctx();
     c->device = ctx->device;
     c->num_cu = ctx->num_cu;
-    BT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->own_stream = chosen;
     c->stream = c->own_stream;
     *out = c;
     return BT_OK;
@@ -66,6 +119,7 @@ int bt_ctx_destroy(bt_ctx *ctx) {
     if (!ctx) return BT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     delete ctx;
     return BT_OK;
 }

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <numeric>
 
 using namespace bt;
@@ -306,6 +307,16 @@ template <typename T>
 __device__ inline void tput(uint8_t *tile_base, const TileDesc &d, int arr, uint64_t idx, uint32_t lane, T value) {
     reinterpret_cast<T *>(tile_base + d.off[arr])[(idx << d.wsh) + lane] = value;
 }
+// Workgroups of ONE wavefront for everything a sampler's construction launches: a helper thread builds the next noise chain's sampler while the current
+// chain's launch is resident (gibbs_chain_kernel: up to two 256-register wavefronts per SIMD on most SIMDs), and the dispatcher only places a workgroup of
+// several wavefronts on a CU that has room on all its SIMDs — measured: a 256-thread kernel on another stream waited for the chain to end, a 64-thread one
+// ran next to it.  Hence no hipMemsetAsync for the pool either (the runtime's fill kernel has large workgroups).
+__global__ __launch_bounds__(64) void zero_fill_kernel(uint4 *__restrict__ p, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 64u + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 64u) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+__global__ __launch_bounds__(64) void copy_words_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 64u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64u) dst[i] = src[i];
+}
 __global__ __launch_bounds__(256) void build_tiles_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, BuildBatch b, uint32_t S) {
     const BuildCluster x = b.clusters[blockIdx.x];
     const TileDesc &d = tiles[x.tile];
@@ -381,8 +392,8 @@ __global__ __launch_bounds__(256) void build_tiles_kernel(const TileDesc *__rest
     for (uint32_t i = t; i < x.nu; i += NT) tput<uint32_t>(tb, d, A_UNIQ0, v * d.NUm + i, l, b.unique_idx[x.u0 + i]);
     for (uint32_t i = t; i < x.nm; i += NT) tput<uint32_t>(tb, d, A_MULTI0, v * d.NMm + i, l, b.multi_idx[x.m0 + i]);
 }
-__global__ __launch_bounds__(256) void build_groups_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, BuildBatch b, uint32_t G, uint32_t S) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(64) void build_groups_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, BuildBatch b, uint32_t G, uint32_t S) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= G) return;
     const BuildGroup x = b.groups[i];
     const TileDesc &d = tiles[x.tile];
@@ -409,6 +420,50 @@ inline void put(std::vector<uint8_t> &img, const TileDesc &d, int arr, size_t id
 }
 
 }  // namespace
+
+
+// Host -> device copies of a sampler's construction: through the context's pinned arena and copy_words_kernel (one-wavefront workgroups reading host
+// memory), not hipMemcpy — the runtime stages small pageable copies through a shader copy with large workgroups, which cannot be placed while a resident noise
+// chain fills the SIMDs (the "tables" phase of a construction on the helper thread took 55 - 60 ms, i.e. until the running chain ended, instead of 0.5 ms).
+// arena_reserve: at the start of a construction, while the context's stream is idle.  Sizes are multiples of four bytes.
+static hipError_t arena_reserve(bt_ctx *ctx, size_t bytes) {
+    ctx->pin_used = 0;
+    if (ctx->pin_bytes >= bytes) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return e;
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    ctx->pin = nullptr;
+    ctx->pin_bytes = 0;
+    const size_t want = bytes + bytes / 2 + 65536;
+    e = hipHostMalloc(reinterpret_cast<void **>(&ctx->pin), want, hipHostMallocDefault);
+    if (e == hipSuccess) ctx->pin_bytes = want;
+    return e;
+}
+static hipError_t staged_upload(bt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    if ((bytes & 3u) || ctx->pin_used + need > ctx->pin_bytes) return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream);   // (not reserved for: the runtime's copy)
+    uint8_t *p = ctx->pin + ctx->pin_used;
+    ctx->pin_used += need;
+    std::memcpy(p, h_src, bytes);
+    const uint64_t n = bytes / 4;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<uint64_t>((n + 63) / 64, 16384)), dim3(64), 0, ctx->stream, reinterpret_cast<uint32_t *>(d_dst), reinterpret_cast<const uint32_t *>(p), n);
+    return hipGetLastError();
+}
+
+// ---- a batch's flat arrays on the device + what the tile planner needs of it on the host (bt_gibbs_source) ----
+// per cluster: its dimensions and where its slices start in the flat arrays
+struct ClusterDims {
+    uint32_t H, V, K, nnz, nu, nm, nd, ndv, ne, hn, A, cid;
+    uint32_t r0, u0, m0, nd0, e0, hap_base, var_base, pad;
+    uint64_t mult_off, kvb_off, hapvar_off;
+};
+struct GroupDims {
+    uint32_t c0, nv;          // first cluster (index into the ClusterDims array handed to the planner), number of clusters
+    uint32_t src0, nsrc;      // slice of group_sources
+    uint32_t num_shared, group_index;
+    uint32_t g_abs, pad;      // position of the group in the source batch (group_ploidy row)
+};
 
 #ifndef BT_HOT_BUDGET
 #define BT_HOT_BUDGET 155648
@@ -733,28 +788,23 @@ const uint32_t kElemSize[A_COUNT] = {
 
 extern "C" {
 
-static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, bt_gibbs **out, uint64_t *plan_bytes);
+struct bt_gibbs_source {
+    bt_ctx *ctx = nullptr;
+    uint32_t S = 0, G = 0, C = 0;
+    std::vector<ClusterDims> cd;   // every cluster of the batch
+    std::vector<GroupDims> gd;     // every group (c0 = index into cd)
+    BuildBatch dev{};              // the flat arrays on the device (clusters / groups are per sampler)
+    std::vector<void *> allocs;
+    uint64_t device_bytes = 0, flat_bytes = 0;
+    bool uploaded = false;
+};
 
-int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, bt_gibbs **out) {
-    if (!out) return fail("bt_gibbs_create: null argument");
-    return gibbs_create_impl(ctx, params, B, out, nullptr);
-}
-
-int bt_gibbs_state_bytes(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, uint64_t *bytes) {
-    if (!bytes) return fail("bt_gibbs_state_bytes: null argument");
-    return gibbs_create_impl(ctx, params, B, nullptr, bytes);
-}
-
-// plan_bytes != nullptr: validate and lay the batch out only; *plan_bytes = device bytes bt_gibbs_create would allocate for it
-static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, bt_gibbs **out, uint64_t *plan_bytes) {
-    if (!ctx || !params || !B) return fail("bt_gibbs_create: null argument");
-    const uint32_t S = params->num_samples, G = B->num_groups, C = B->num_clusters;
-    if (S < 1 || S > 30) return fail("bt_gibbs_create: number of samples must be in 1..30");   // main.cpp:72
-    if (!params->gender) return fail("bt_gibbs_create: gender array missing");
+// a malformed batch must not make the tile builder read out of bounds: offsets monotone, indices in range
+static int validate_batch(const bt_gibbs_batch *B) {
+    const uint32_t G = B->num_groups, C = B->num_clusters;
     if (G == 0 || C == 0) return fail("bt_gibbs_create: empty batch");
     if (B->group_cluster_off[G] != C) return fail("bt_gibbs_create: group_cluster_off[G] != num_clusters");
     {
-        // a malformed batch must not make the tile builder read out of bounds: offsets monotone, indices in range
         auto monotone = [](const uint32_t *off, uint64_t n) {
             for (uint64_t i = 0; i < n; ++i)
                 if (off[i + 1] < off[i]) return false;
@@ -792,6 +842,209 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             }
         }
     }
+    return BT_OK;
+}
+
+// dimensions + slice starts of every cluster and group of a batch; upload: the flat arrays go to the device (they stay there until the source is destroyed)
+static int source_build(bt_ctx *ctx, uint32_t S, const bt_gibbs_batch *B, bool upload, bt_gibbs_source **out) {
+    const uint32_t G = B->num_groups, C = B->num_clusters;
+    std::unique_ptr<bt_gibbs_source> src(new bt_gibbs_source());
+    src->ctx = ctx;
+    src->S = S;
+    src->G = G;
+    src->C = C;
+    src->cd.resize(C);
+    src->gd.resize(G);
+    uint64_t mult = 0, kvb = 0, hapvar = 0;
+    uint32_t hap = 0, var = 0;
+    for (uint32_t c = 0; c < C; ++c) {
+        ClusterDims &x = src->cd[c];
+        x.H = B->num_haplotypes[c];
+        x.V = B->num_variants[c];
+        x.r0 = B->kmer_off[c];
+        x.K = B->kmer_off[c + 1] - x.r0;
+        if (x.H < 1 || x.H >= 65535 || x.V < 1) return fail("bt_gibbs_create: cluster with no haplotype / variant or too many haplotypes");
+        x.nnz = B->kv_off[B->kmer_off[c + 1]] - B->kv_off[B->kmer_off[c]];
+        x.u0 = B->unique_off[c];
+        x.nu = B->unique_off[c + 1] - x.u0;
+        x.m0 = B->multi_off[c];
+        x.nm = B->multi_off[c + 1] - x.m0;
+        x.nd0 = B->nestdep_off[c];
+        x.nd = B->nestdep_off[c + 1] - x.nd0;
+        x.ndv = B->nestdep_var_off[B->nestdep_off[c + 1]] - B->nestdep_var_off[B->nestdep_off[c]];
+        x.e0 = B->edge_off[c];
+        x.ne = B->edge_off[c + 1] - x.e0;
+        x.cid = B->cluster_idx[c];
+        x.hap_base = hap;
+        x.var_base = var;
+        x.hn = B->hapnest_off[hap + x.H] - B->hapnest_off[hap];
+        x.mult_off = mult;
+        x.kvb_off = kvb;
+        x.hapvar_off = hapvar;
+        x.pad = 0;
+        uint32_t A = 0;
+        for (uint32_t v = 0; v < x.V; ++v) A += B->var_num_alleles[var + v];
+        x.A = A;
+        if (x.V >= 0xFFFFu || A >= 65536u) return fail("bt_gibbs_create: cluster with 65535 or more variants / 65536 or more alleles");   // A_HAPCELL packs a variant index and an allele cell into 16 bits each
+        mult += (uint64_t)x.K * x.H;
+        kvb += (uint64_t)x.nnz * ((x.H + 31) / 32);
+        hapvar += (uint64_t)x.H * x.V;
+        hap += x.H;
+        var += x.V;
+    }
+    for (uint32_t gi = 0; gi < G; ++gi)
+        src->gd[gi] = GroupDims{B->group_cluster_off[gi], B->group_cluster_off[gi + 1] - B->group_cluster_off[gi], B->group_source_off[gi], B->group_source_off[gi + 1] - B->group_source_off[gi],
+                                B->group_num_shared[gi], B->group_index[gi], gi, 0};
+    const uint64_t R = B->kmer_off[C], NNZ = B->kv_off[R], ND = B->nestdep_off[C];
+    src->flat_bytes = (uint64_t)G * S + (uint64_t)B->group_source_off[G] * 4 + (uint64_t)B->edge_off[C] * 4 + mult + R * (S + 11ull) + 4 + NNZ * 2 + kvb * 4 +
+                      ((uint64_t)B->unique_off[C] + B->multi_off[C]) * 4 + hapvar * 2 + ((uint64_t)hap + 1) * 4 + (uint64_t)B->hapnest_off[hap] * 4 + (uint64_t)var * 3 + ND * 8 + 4 +
+                      (uint64_t)B->nestdep_var_off[ND] * 2;
+    if (upload) {
+        BT_HIP(hipSetDevice(ctx->device));
+        hipError_t e = hipSuccess;
+        auto up = [&](const void *h, size_t bytes, const void **d_out) -> hipError_t {
+            void *d = nullptr;
+            hipError_t er = hipMalloc(&d, std::max<size_t>(bytes, 16));
+            if (er != hipSuccess) return er;
+            src->allocs.push_back(d);
+            src->device_bytes += std::max<size_t>(bytes, 16);
+            *d_out = d;
+            return bytes ? hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        };
+        BuildBatch &bb = src->dev;
+#define BT_UP(field, ptr, bytes) \
+    if (e == hipSuccess) e = up(ptr, bytes, reinterpret_cast<const void **>(&bb.field))
+        BT_UP(group_ploidy, B->group_ploidy, (size_t)G * S);
+        BT_UP(group_sources, B->group_sources, (size_t)B->group_source_off[G] * 4);
+        BT_UP(edges, B->edges, (size_t)B->edge_off[C] * 4);
+        BT_UP(hap_kmer_mult, B->hap_kmer_mult, (size_t)mult);
+        BT_UP(kmer_has_counts, B->kmer_has_counts, (size_t)R);
+        BT_UP(kmer_counts, B->kmer_counts, (size_t)R * S);
+        BT_UP(kmer_ic_mult, B->kmer_ic_mult, (size_t)R * 2);
+        BT_UP(kmer_shared, B->kmer_shared, (size_t)R * 4);
+        BT_UP(kv_off, B->kv_off, (size_t)(R + 1) * 4);
+        BT_UP(kv_var, B->kv_var, (size_t)NNZ * 2);
+        BT_UP(kv_bits, B->kv_bits, (size_t)kvb * 4);
+        BT_UP(unique_idx, B->unique_idx, (size_t)B->unique_off[C] * 4);
+        BT_UP(multi_idx, B->multi_idx, (size_t)B->multi_off[C] * 4);
+        BT_UP(hap_allele, B->hap_allele, (size_t)hapvar * 2);
+        BT_UP(hapnest_off, B->hapnest_off, ((size_t)hap + 1) * 4);
+        BT_UP(hapnest_idx, B->hapnest_idx, (size_t)B->hapnest_off[hap] * 4);
+        BT_UP(var_num_alleles, B->var_num_alleles, (size_t)var * 2);
+        BT_UP(var_has_dependency, B->var_has_dependency, (size_t)var);
+        BT_UP(nestdep_cluster, B->nestdep_cluster, (size_t)ND * 4);
+        BT_UP(nestdep_var_off, B->nestdep_var_off, (size_t)(ND + 1) * 4);
+        BT_UP(nestdep_var, B->nestdep_var, (size_t)B->nestdep_var_off[ND] * 2);
+#undef BT_UP
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);   // (the caller's arrays may go away)
+        if (e != hipSuccess || e2 != hipSuccess) {
+            for (void *d : src->allocs) (void)hipFree(d);
+            return fail(std::string("bt_gibbs: uploading the batch: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+        src->uploaded = true;
+    }
+    *out = src.release();
+    return BT_OK;
+}
+
+static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_gibbs_params *params, const uint32_t *group_ids, uint32_t num_ids, bt_gibbs **out, uint64_t *plan_bytes);
+
+int bt_gibbs_source_create(bt_ctx *ctx, uint32_t num_samples, const bt_gibbs_batch *B, bt_gibbs_source **out) {
+    if (!ctx || !B || !out) return fail("bt_gibbs_source_create: null argument");
+    if (num_samples < 1 || num_samples > 30) return fail("bt_gibbs_source_create: number of samples must be in 1..30");
+    const int rc = validate_batch(B);
+    if (rc != BT_OK) return rc;
+    return source_build(ctx, num_samples, B, true, out);
+}
+
+int bt_gibbs_source_destroy(bt_gibbs_source *src) {
+    if (!src) return BT_OK;
+    (void)hipSetDevice(src->ctx->device);
+    for (void *d : src->allocs) (void)hipFree(d);
+    delete src;
+    return BT_OK;
+}
+
+int bt_gibbs_source_device_bytes(bt_gibbs_source *src, uint64_t *bytes) {
+    if (!src || !bytes) return fail("bt_gibbs_source_device_bytes: null argument");
+    *bytes = src->device_bytes;
+    return BT_OK;
+}
+
+int bt_gibbs_create_from_source(bt_gibbs_source *src, bt_ctx *ctx, const bt_gibbs_params *params, const uint32_t *group_ids, uint32_t num_groups, bt_gibbs **out) {
+    if (!src || !params || !out) return fail("bt_gibbs_create_from_source: null argument");
+    if (!src->uploaded) return fail("bt_gibbs_create_from_source: the source holds no device arrays");
+    return gibbs_create_impl(src, ctx, params, group_ids, num_groups, out, nullptr);
+}
+
+int bt_gibbs_state_bytes_from_source(bt_gibbs_source *src, const bt_gibbs_params *params, const uint32_t *group_ids, uint32_t num_groups, uint64_t *bytes) {
+    if (!src || !params || !bytes) return fail("bt_gibbs_state_bytes_from_source: null argument");
+    return gibbs_create_impl(src, nullptr, params, group_ids, num_groups, nullptr, bytes);
+}
+
+int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, bt_gibbs **out) {
+    if (!out) return fail("bt_gibbs_create: null argument");
+    if (!ctx || !params || !B) return fail("bt_gibbs_create: null argument");
+    if (params->num_samples < 1 || params->num_samples > 30) return fail("bt_gibbs_create: number of samples must be in 1..30");   // main.cpp:72
+    int rc = validate_batch(B);
+    if (rc != BT_OK) return rc;
+    bt_gibbs_source *src = nullptr;
+    rc = source_build(ctx, params->num_samples, B, true, &src);
+    if (rc != BT_OK) return rc;
+    rc = gibbs_create_impl(src, nullptr, params, nullptr, 0, out, nullptr);
+    bt_gibbs_source_destroy(src);   // (the sampler holds its tiles; the flat arrays were only the builder's input)
+    return rc;
+}
+
+int bt_gibbs_state_bytes(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *B, uint64_t *bytes) {
+    if (!bytes) return fail("bt_gibbs_state_bytes: null argument");
+    if (!ctx || !params || !B) return fail("bt_gibbs_create: null argument");
+    if (params->num_samples < 1 || params->num_samples > 30) return fail("bt_gibbs_create: number of samples must be in 1..30");
+    int rc = validate_batch(B);
+    if (rc != BT_OK) return rc;
+    bt_gibbs_source *src = nullptr;
+    rc = source_build(ctx, params->num_samples, B, false, &src);
+    if (rc != BT_OK) return rc;
+    rc = gibbs_create_impl(src, nullptr, params, nullptr, 0, nullptr, bytes);
+    bt_gibbs_source_destroy(src);
+    return rc;
+}
+
+// plan_bytes != nullptr: lay the selected groups out only; *plan_bytes = device bytes a sampler over them would allocate.
+// group_ids: the groups of the source the sampler runs (in this order; nullptr: all of them)
+static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_gibbs_params *params, const uint32_t *group_ids, uint32_t num_ids, bt_gibbs **out, uint64_t *plan_bytes) {
+    if (!ctx) ctx = src->ctx;
+    if (ctx->device != src->ctx->device) return fail("bt_gibbs_create_from_source: the context is on another device than the source");
+    const uint32_t S = params->num_samples;
+    if (S != src->S) return fail("bt_gibbs_create: the sampler's number of samples differs from its source's");
+    if (!params->gender) return fail("bt_gibbs_create: gender array missing");
+    // the planner's view: the selected groups and their clusters, compact
+    std::vector<ClusterDims> cd_sel;
+    std::vector<GroupDims> gd_sel;
+    const ClusterDims *cd = src->cd.data();
+    const GroupDims *gd = src->gd.data();
+    uint32_t G = src->G, C = src->C;
+    if (group_ids) {
+        G = num_ids;
+        gd_sel.resize(G);
+        uint32_t nc = 0;
+        for (uint32_t i = 0; i < G; ++i) {
+            if (group_ids[i] >= src->G) return fail("bt_gibbs_create_from_source: group index outside the source");
+            nc += src->gd[group_ids[i]].nv;
+        }
+        cd_sel.reserve(nc);
+        for (uint32_t i = 0; i < G; ++i) {
+            GroupDims x = src->gd[group_ids[i]];
+            const uint32_t c0 = x.c0;
+            x.c0 = (uint32_t)cd_sel.size();
+            for (uint32_t c = 0; c < x.nv; ++c) cd_sel.push_back(src->cd[c0 + c]);
+            gd_sel[i] = x;
+        }
+        C = (uint32_t)cd_sel.size();
+        cd = cd_sel.data();
+        gd = gd_sel.data();
+    }
+    if (G == 0 || C == 0) return fail("bt_gibbs_create: empty batch");
     BT_HIP(hipSetDevice(ctx->device));
     bt_gibbs *g = new bt_gibbs();
     g->ctx = ctx;
@@ -826,41 +1079,36 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         }                                                                \
     } while (0)
 
-    // ---- prefix sums over the flat batch ----
-    std::vector<uint64_t> mult_off(C + 1, 0), kvb_off(C + 1, 0), hapvar_off(C + 1, 0);
-    std::vector<uint32_t> hap_base(C + 1, 0), var_base(C + 1, 0);
     g->h_A.assign(C, 0);
+    uint64_t flat_sel = 0;   // bytes of the selected groups' slices of the flat arrays (bt_gibbs_state_bytes: what a create from a host batch uploads next to the pool)
     for (uint32_t c = 0; c < C; ++c) {
-        const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], K = B->kmer_off[c + 1] - B->kmer_off[c];
-        if (H < 1 || H >= 65535 || V < 1) {
-            bt_gibbs_destroy(g);
-            return fail("bt_gibbs_create: cluster with no haplotype / variant or too many haplotypes");
-        }
-        const uint32_t nnz = B->kv_off[B->kmer_off[c + 1]] - B->kv_off[B->kmer_off[c]];
-        mult_off[c + 1] = mult_off[c] + (uint64_t)K * H;
-        kvb_off[c + 1] = kvb_off[c] + (uint64_t)nnz * ((H + 31) / 32);
-        hapvar_off[c + 1] = hapvar_off[c] + (uint64_t)H * V;
-        hap_base[c + 1] = hap_base[c] + H;
-        var_base[c + 1] = var_base[c] + V;
-        uint32_t A = 0;
-        for (uint32_t v = 0; v < V; ++v) A += B->var_num_alleles[var_base[c] + v];
-        g->h_A[c] = A;
-        if (V >= 0xFFFFu || A >= 65536u) {   // A_HAPCELL packs a variant index and an allele cell into 16 bits each
-            bt_gibbs_destroy(g);
-            return fail("bt_gibbs_create: cluster with 65535 or more variants / 65536 or more alleles");
-        }
+        g->h_A[c] = cd[c].A;
+        flat_sel += (uint64_t)cd[c].K * cd[c].H + (uint64_t)cd[c].K * (S + 11ull) + (uint64_t)cd[c].nnz * (2 + 4 * ((cd[c].H + 31) / 32)) + ((uint64_t)cd[c].nu + cd[c].nm) * 4 +
+                    (uint64_t)cd[c].H * cd[c].V * 2 + (uint64_t)cd[c].H * 4 + (uint64_t)cd[c].hn * 4;
     }
 
+    // BT_GIBBS_DEBUG: where a construction spends its time
+    const bool timing = getenv("BT_GIBBS_DEBUG") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    std::string t_text;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        snprintf(buf, sizeof buf, " %s %.1f ms;", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_text += buf;
+        t_prev = now;
+    };
     // ---- order groups by shape (vertices, haplotypes, k-mers: descending) and cut into tiles of 64 ----
     struct GShape {
         uint32_t nv, Hmax, Kmax, g;
     };
     std::vector<GShape> shapes(G);
     for (uint32_t gi = 0; gi < G; ++gi) {
-        GShape s{B->group_cluster_off[gi + 1] - B->group_cluster_off[gi], 0, 0, gi};
-        for (uint32_t c = B->group_cluster_off[gi]; c < B->group_cluster_off[gi + 1]; ++c) {
-            s.Hmax = std::max(s.Hmax, B->num_haplotypes[c]);
-            s.Kmax = std::max(s.Kmax, B->kmer_off[c + 1] - B->kmer_off[c]);
+        GShape s{gd[gi].nv, 0, 0, gi};
+        for (uint32_t c = gd[gi].c0; c < gd[gi].c0 + gd[gi].nv; ++c) {
+            s.Hmax = std::max(s.Hmax, cd[c].H);
+            s.Kmax = std::max(s.Kmax, cd[c].K);
         }
         shapes[gi] = s;
     }
@@ -1001,21 +1249,21 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         uint32_t Am = 1, NSHm = 0;
         for (uint32_t bl = tile_start[blk_first[ti]]; bl < tile_start[blk_last[ti] + 1]; ++bl) {   // dimensions: maxima over the pool block
             const uint32_t gi = shapes[bl].g;
-            const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
+            const uint32_t c0 = gd[gi].c0, c1 = gd[gi].c0 + gd[gi].nv;
             d.nvm = std::max(d.nvm, c1 - c0);
-            NSHm = std::max(NSHm, B->group_num_shared[gi]);
+            NSHm = std::max(NSHm, gd[gi].num_shared);
             for (uint32_t c = c0; c < c1; ++c) {
-                const uint32_t H = B->num_haplotypes[c], V = B->num_variants[c], K = B->kmer_off[c + 1] - B->kmer_off[c];
+                const uint32_t H = cd[c].H, V = cd[c].V, K = cd[c].K;
                 d.Hm = std::max(d.Hm, H);
                 d.Vm = std::max(d.Vm, V);
                 d.Km = std::max(d.Km, K);
-                d.NUm = std::max(d.NUm, B->unique_off[c + 1] - B->unique_off[c]);
-                d.NMm = std::max(d.NMm, B->multi_off[c + 1] - B->multi_off[c]);
-                d.NNZm = std::max(d.NNZm, B->kv_off[B->kmer_off[c + 1]] - B->kv_off[B->kmer_off[c]]);
-                d.HNm = std::max(d.HNm, B->hapnest_off[hap_base[c + 1]] - B->hapnest_off[hap_base[c]]);
-                d.NDm = std::max(d.NDm, B->nestdep_off[c + 1] - B->nestdep_off[c]);
-                d.NDVm = std::max(d.NDVm, B->nestdep_var_off[B->nestdep_off[c + 1]] - B->nestdep_var_off[B->nestdep_off[c]]);
-                d.NEm = std::max(d.NEm, B->edge_off[c + 1] - B->edge_off[c]);
+                d.NUm = std::max(d.NUm, cd[c].nu);
+                d.NMm = std::max(d.NMm, cd[c].nm);
+                d.NNZm = std::max(d.NNZm, cd[c].nnz);
+                d.HNm = std::max(d.HNm, cd[c].hn);
+                d.NDm = std::max(d.NDm, cd[c].nd);
+                d.NDVm = std::max(d.NDVm, cd[c].ndv);
+                d.NEm = std::max(d.NEm, cd[c].ne);
                 Am = std::max(Am, g->h_A[c]);
             }
         }
@@ -1176,7 +1424,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             // tiles of two-haplotype clusters run simple_sweeps(), which keeps the two haplotype sets and the candidate scratch in
             // registers: those arrays stay in HBM (written once per launch) and the tile's LDS block shrinks by a fifth
             bool want_simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.lds_stride == LANES && !getenv("BT_GIBBS_NO_SIMPLE") && !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
-            for (uint32_t l = 0; l < d.num_lanes && want_simple; ++l) want_simple = B->num_haplotypes[B->group_cluster_off[shapes[tile_start[ti] + l].g]] == 2;
+            for (uint32_t l = 0; l < d.num_lanes && want_simple; ++l) want_simple = cd[gd[shapes[tile_start[ti] + l].g].c0].H == 2;
             // tuning: BT_GIBBS_HOT_SKIP = bit mask over hot_arrs[] of arrays to leave in HBM
             const uint64_t skip_mask = getenv("BT_GIBBS_HOT_SKIP") ? strtoull(getenv("BT_GIBBS_HOT_SKIP"), nullptr, 0) : 0ull;
             int hot_i = -1;
@@ -1223,7 +1471,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         }
         {
             bool simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.copies == 1 && d.split == 1 && d.hot_bytes != 0 && !getenv("BT_GIBBS_NO_SIMPLE");
-            for (uint32_t l = 0; l < d.num_lanes && simple; ++l) simple = B->num_haplotypes[B->group_cluster_off[shapes[tile_start[ti] + l].g]] == 2;
+            for (uint32_t l = 0; l < d.num_lanes && simple; ++l) simple = cd[gd[shapes[tile_start[ti] + l].g].c0].H == 2;
             simple = simple && d.hoff[A_RING] != NOHOT && d.hoff[A_SC] == NOHOT;   // (the LDS block was laid out for simple_sweeps above)
             d.simple = simple ? 1u : 0u;
         }
@@ -1252,10 +1500,12 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             if (relax >= 4 || free_b == 0 || pool + 256 <= (uint64_t)(0.92 * (double)free_b)) break;
         }
     }
+    lap("shape sort + tile plan");
+    if (!plan_bytes)   // the construction's uploads: tile descriptors, cluster / group descriptors, cluster locations, tables, class lists (+ slack for fill lists)
+        BT_TRYHIP(arena_reserve(ctx, (size_t)ntiles * (sizeof(TileDesc) + 64) + (size_t)C * (sizeof(BuildCluster) + sizeof(ClusterLoc) + 32) + (size_t)G * (sizeof(BuildGroup) + 16) + (8u << 20)));
     g->pool_bytes = pool + 256;
     if (plan_bytes) {   // + the count-model tables, descriptors and the transient device copy of the flat batch the tile builder reads
-        uint64_t flat = (uint64_t)C * 160 + (uint64_t)G * (32 + S) + mult_off[C] + (uint64_t)B->kmer_off[C] * (S + 11) + (uint64_t)B->kv_off[B->kmer_off[C]] * 2 + kvb_off[C] * 4 +
-                        ((uint64_t)B->unique_off[C] + B->multi_off[C]) * 4 + hapvar_off[C] * 2 + (uint64_t)hap_base[C] * 4 + (uint64_t)B->hapnest_off[hap_base[C]] * 4;
+        const uint64_t flat = (uint64_t)C * 160 + (uint64_t)G * (32 + S) + flat_sel;
         *plan_bytes = g->pool_bytes + (uint64_t)S * (65536 + 256) * 8 + (uint64_t)ntiles * sizeof(TileDesc) + (uint64_t)C * sizeof(ClusterLoc) + flat;
         bt_gibbs_destroy(g);
         return BT_OK;
@@ -1269,15 +1519,20 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
     }
     g->allocs.push_back(g->d_pool);
     g->device_bytes += g->pool_bytes;
-    BT_TRYHIP(hipMemsetAsync(g->d_pool, 0, g->pool_bytes, ctx->stream));
+    {
+        const uint64_t n16 = (g->pool_bytes + 15) / 16;   // (hipMalloc sizes are multiples of the allocation granule: the tail belongs to the allocation)
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 63) / 64, 65536)), dim3(64), 0, ctx->stream, reinterpret_cast<uint4 *>(g->d_pool), n16);
+        BT_TRYHIP(hipGetLastError());
+    }
 
     // ---- the input arrays of every tile: the flat batch is uploaded as it is and scattered into the tiles' layout ON THE DEVICE
     // (build_tiles_kernel, one workgroup per cluster).  The host only computes where things go: a descriptor per cluster.
+    lap("pool allocation + clear (enqueued)");
     g->tiles.resize(ntiles);
     for (uint32_t ti = 0; ti < ntiles; ++ti) g->tiles[ti] = plans[ti].d;
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_tiles), (size_t)ntiles * sizeof(TileDesc)));
     g->allocs.push_back(g->d_tiles);
-    BT_TRYHIP(hipMemcpyAsync(g->d_tiles, g->tiles.data(), (size_t)ntiles * sizeof(TileDesc), hipMemcpyHostToDevice, ctx->stream));
+    BT_TRYHIP(staged_upload(ctx, g->d_tiles, g->tiles.data(), (size_t)ntiles * sizeof(TileDesc)));
     {
         std::vector<BuildCluster> bc(C);
         std::vector<BuildGroup> bg(G);
@@ -1285,40 +1540,41 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             const TileDesc &d = plans[ti].d;
             for (uint32_t l = 0; l < d.num_lanes; ++l) {
                 const uint32_t gi = shapes[tile_start[ti] + l].g;
-                const uint32_t c0 = B->group_cluster_off[gi], c1 = B->group_cluster_off[gi + 1];
+                const uint32_t c0 = gd[gi].c0, c1 = gd[gi].c0 + gd[gi].nv;
                 g->group_tile[gi] = ti;
                 g->group_lane[gi] = l;
                 g->group_nvert[gi] = c1 - c0;
-                bg[gi] = BuildGroup{ti, l, c1 - c0, B->group_source_off[gi], B->group_source_off[gi + 1] - B->group_source_off[gi], B->group_index[gi], gi, 0};
+                bg[gi] = BuildGroup{ti, l, c1 - c0, gd[gi].src0, gd[gi].nsrc, gd[gi].group_index, gd[gi].g_abs, 0};
                 for (uint32_t c = c0; c < c1; ++c) {
                     g->loc[c] = ClusterLoc{ti, l, c - c0, 0};
                     BuildCluster &x = bc[c];
                     x.tile = ti;
                     x.lane = l;
                     x.v = c - c0;
-                    x.H = B->num_haplotypes[c];
-                    x.V = B->num_variants[c];
-                    x.r0 = B->kmer_off[c];
-                    x.K = B->kmer_off[c + 1] - x.r0;
-                    x.u0 = B->unique_off[c];
-                    x.nu = B->unique_off[c + 1] - x.u0;
-                    x.m0 = B->multi_off[c];
-                    x.nm = B->multi_off[c + 1] - x.m0;
-                    x.nd0 = B->nestdep_off[c];
-                    x.nd = B->nestdep_off[c + 1] - x.nd0;
-                    x.e0 = B->edge_off[c];
-                    x.ne = B->edge_off[c + 1] - x.e0;
-                    x.cid = B->cluster_idx[c];
-                    x.A = g->h_A[c];
-                    x.mult_off = mult_off[c];
-                    x.kvb_off = kvb_off[c];
-                    x.hapvar_off = hapvar_off[c];
-                    x.hap_base = hap_base[c];
-                    x.var_base = var_base[c];
+                    const ClusterDims &q = cd[c];
+                    x.H = q.H;
+                    x.V = q.V;
+                    x.r0 = q.r0;
+                    x.K = q.K;
+                    x.u0 = q.u0;
+                    x.nu = q.nu;
+                    x.m0 = q.m0;
+                    x.nm = q.nm;
+                    x.nd0 = q.nd0;
+                    x.nd = q.nd;
+                    x.e0 = q.e0;
+                    x.ne = q.ne;
+                    x.cid = q.cid;
+                    x.A = q.A;
+                    x.mult_off = q.mult_off;
+                    x.kvb_off = q.kvb_off;
+                    x.hapvar_off = q.hapvar_off;
+                    x.hap_base = q.hap_base;
+                    x.var_base = q.var_base;
                 }
             }
         }
-        // device copies of the flat batch (freed after the build)
+        // the flat batch is on the device already (bt_gibbs_source); the descriptors of this sampler's clusters and groups go up
         std::vector<void *> tmp;
         auto up = [&](const void *h, size_t bytes, const void **d_out) -> hipError_t {
             void *d = nullptr;
@@ -1326,55 +1582,32 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             if (e != hipSuccess) return e;
             tmp.push_back(d);
             *d_out = d;
-            return bytes ? hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+            return staged_upload(ctx, d, h, bytes);
         };
-        const uint64_t R = B->kmer_off[C], NNZ = B->kv_off[R], Hs = hap_base[C], Vs = var_base[C], ND = B->nestdep_off[C];
-        BuildBatch bb{};
-        hipError_t e = hipSuccess;
-#define BT_UP(field, ptr, bytes) \
-    if (e == hipSuccess) e = up(ptr, bytes, reinterpret_cast<const void **>(&bb.field))
-        BT_UP(clusters, bc.data(), (size_t)C * sizeof(BuildCluster));
-        BT_UP(groups, bg.data(), (size_t)G * sizeof(BuildGroup));
-        BT_UP(group_ploidy, B->group_ploidy, (size_t)G * S);
-        BT_UP(group_sources, B->group_sources, (size_t)B->group_source_off[G] * 4);
-        BT_UP(edges, B->edges, (size_t)B->edge_off[C] * 4);
-        BT_UP(hap_kmer_mult, B->hap_kmer_mult, (size_t)mult_off[C]);
-        BT_UP(kmer_has_counts, B->kmer_has_counts, (size_t)R);
-        BT_UP(kmer_counts, B->kmer_counts, (size_t)R * S);
-        BT_UP(kmer_ic_mult, B->kmer_ic_mult, (size_t)R * 2);
-        BT_UP(kmer_shared, B->kmer_shared, (size_t)R * 4);
-        BT_UP(kv_off, B->kv_off, (size_t)(R + 1) * 4);
-        BT_UP(kv_var, B->kv_var, (size_t)NNZ * 2);
-        BT_UP(kv_bits, B->kv_bits, (size_t)kvb_off[C] * 4);
-        BT_UP(unique_idx, B->unique_idx, (size_t)B->unique_off[C] * 4);
-        BT_UP(multi_idx, B->multi_idx, (size_t)B->multi_off[C] * 4);
-        BT_UP(hap_allele, B->hap_allele, (size_t)hapvar_off[C] * 2);
-        BT_UP(hapnest_off, B->hapnest_off, (size_t)(Hs + 1) * 4);
-        BT_UP(hapnest_idx, B->hapnest_idx, (size_t)B->hapnest_off[Hs] * 4);
-        BT_UP(var_num_alleles, B->var_num_alleles, (size_t)Vs * 2);
-        BT_UP(var_has_dependency, B->var_has_dependency, (size_t)Vs);
-        BT_UP(nestdep_cluster, B->nestdep_cluster, (size_t)ND * 4);
-        BT_UP(nestdep_var_off, B->nestdep_var_off, (size_t)(ND + 1) * 4);
-        BT_UP(nestdep_var, B->nestdep_var, (size_t)B->nestdep_var_off[ND] * 2);
-#undef BT_UP
+        BuildBatch bb = src->dev;
+        hipError_t e = up(bc.data(), (size_t)C * sizeof(BuildCluster), reinterpret_cast<const void **>(&bb.clusters));
+        if (e == hipSuccess) e = up(bg.data(), (size_t)G * sizeof(BuildGroup), reinterpret_cast<const void **>(&bb.groups));
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(build_tiles_kernel, dim3(C), dim3(256), 0, ctx->stream, g->d_tiles, g->d_pool, bb, S);
+            hipLaunchKernelGGL(build_tiles_kernel, dim3(C), dim3(64), 0, ctx->stream, g->d_tiles, g->d_pool, bb, S);
             e = hipGetLastError();
         }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(build_groups_kernel, dim3((G + 255) / 256), dim3(256), 0, ctx->stream, g->d_tiles, g->d_pool, bb, G, S);
+            hipLaunchKernelGGL(build_groups_kernel, dim3((G + 63) / 64), dim3(64), 0, ctx->stream, g->d_tiles, g->d_pool, bb, G, S);
             e = hipGetLastError();
         }
-        const hipError_t e2 = hipStreamSynchronize(ctx->stream);   // bc / bg and the temporaries are released below
-        for (void *d : tmp) (void)hipFree(d);
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);   // (bc / bg go out of scope)
+        // the descriptors' device copies stay until the sampler is destroyed: hipFree waits for the whole device to idle — for the chain of a noise driver
+        // that is resident on another stream while a helper thread builds this sampler (82 ms per construction instead of 20)
+        for (void *d : tmp) g->allocs.push_back(d);
         if (e != hipSuccess || e2 != hipSuccess) {
             bt_gibbs_destroy(g);
             return fail(std::string("bt_gibbs_create: building the tiles: ") + hipGetErrorString(e != hipSuccess ? e : e2));
         }
     }
+    lap("descriptors + build kernels (synchronised)");
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_loc), (size_t)C * sizeof(ClusterLoc)));
     g->allocs.push_back(g->d_loc);
-    BT_TRYHIP(hipMemcpyAsync(g->d_loc, g->loc.data(), (size_t)C * sizeof(ClusterLoc), hipMemcpyHostToDevice, ctx->stream));
+    BT_TRYHIP(staged_upload(ctx, g->d_loc, g->loc.data(), (size_t)C * sizeof(ClusterLoc)));
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_lut_g), (size_t)S * 65536 * 8));
     g->allocs.push_back(g->d_lut_g);
     BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_lut_n), (size_t)S * 256 * 8));
@@ -1385,13 +1618,13 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
     {
         // lgamma over the integers the simplex-size distribution touches (FrequencyDistribution.cpp:143-196): <= Hmax + 2S + 1
         uint32_t Hmax = 0;
-        for (uint32_t c = 0; c < C; ++c) Hmax = std::max(Hmax, B->num_haplotypes[c]);
+        for (uint32_t c = 0; c < C; ++c) Hmax = std::max(Hmax, cd[c].H);
         const uint32_t n = Hmax + 2 * S + 8;
         std::vector<double> lg(n, 0.0);
         for (uint32_t i = 1; i < n; ++i) lg[i] = std::lgamma((double)i);
         BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_lgamma), (size_t)n * 8));
         g->allocs.push_back(g->d_lgamma);
-        BT_TRYHIP(hipMemcpyAsync(g->d_lgamma, lg.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        BT_TRYHIP(staged_upload(ctx, g->d_lgamma, lg.data(), (size_t)n * 8));
         BT_TRYHIP(hipStreamSynchronize(ctx->stream));
         g->P.lgamma_int = (const double BT_GAS *)g->d_lgamma;
         g->P.lgamma_n = n;
@@ -1407,17 +1640,18 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             double *d_a2 = nullptr;
             BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&d_a2), (size_t)na * 8));
             g->allocs.push_back(d_a2);
-            BT_TRYHIP(hipMemcpyAsync(d_a2, a2.data(), (size_t)na * 8, hipMemcpyHostToDevice, ctx->stream));
+            BT_TRYHIP(staged_upload(ctx, d_a2, a2.data(), (size_t)na * 8));
             BT_TRYHIP(hipStreamSynchronize(ctx->stream));
             g->P.gamma_a2 = (const double BT_GAS *)d_a2;
             g->P.gamma_n = na;
         }
         BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&g->d_params), sizeof(GParams)));
         g->allocs.push_back(g->d_params);
-        BT_TRYHIP(hipMemcpyAsync(g->d_params, &g->P, sizeof(GParams), hipMemcpyHostToDevice, ctx->stream));
+        BT_TRYHIP(staged_upload(ctx, g->d_params, &g->P, sizeof(GParams)));
         BT_TRYHIP(hipStreamSynchronize(ctx->stream));
     }
     {
+        lap("tables");
         // BT_GIBBS_LDS_CLASSES="a,b,...": upper bounds (bytes) of the launch classes instead of kClassLds (tuning; a last class takes the rest)
         const bool own_kernel_early = !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
         std::vector<uint32_t> class_lds(kClassLds, kClassLds + sizeof(kClassLds) / sizeof(kClassLds[0]));
@@ -1493,16 +1727,19 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_simple_kernel((int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_hot_kernel((int)kHotBudget));
+        lap("class cut");
         BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        lap("event");
         g->wide_fill = !getenv("BT_GIBBS_NO_WIDE_FILL");
         g->noise_in_gibbs_kernel = getenv("BT_GIBBS_NOISE_GLOBAL_ATOMICS") != nullptr;
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_noise_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         if (const char *e = getenv("BT_GIBBS_STEPWISE")) g->stepwise_run = atoi(e) != 0 && g->wide_fill;
+        lap("attributes");
         for (size_t i = 0; i < g->classes.size(); ++i) {
             auto &c = g->classes[i];
             BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_tiles), c.tiles.size() * 4));
             g->allocs.push_back(c.d_tiles);
-            BT_TRYHIP(hipMemcpyAsync(c.d_tiles, c.tiles.data(), c.tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            BT_TRYHIP(staged_upload(ctx, c.d_tiles, c.tiles.data(), c.tiles.size() * 4));
             std::vector<FillChunk> fill;
             for (uint32_t ti : c.tiles) {
                 const TileDesc &d = g->tiles[ti];
@@ -1524,15 +1761,16 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
             if (!pre.empty()) {
                 BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_prefill), pre.size() * sizeof(PrefillItem)));
                 g->allocs.push_back(c.d_prefill);
-                BT_TRYHIP(hipMemcpy(c.d_prefill, pre.data(), pre.size() * sizeof(PrefillItem), hipMemcpyHostToDevice));
+                BT_TRYHIP(staged_upload(ctx, c.d_prefill, pre.data(), pre.size() * sizeof(PrefillItem)));
                 c.num_prefill = (uint32_t)pre.size();
             }
             if (!fill.empty() && !getenv("BT_GIBBS_NO_WIDE_FILL")) {
                 BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_fill), fill.size() * sizeof(FillChunk)));
                 g->allocs.push_back(c.d_fill);
-                BT_TRYHIP(hipMemcpy(c.d_fill, fill.data(), fill.size() * sizeof(FillChunk), hipMemcpyHostToDevice));
+                BT_TRYHIP(staged_upload(ctx, c.d_fill, fill.data(), fill.size() * sizeof(FillChunk)));
                 c.num_fill = (uint32_t)fill.size();
             }
+            lap("class lists");
             BT_TRYHIP(hipEventCreateWithFlags(&c.ready, hipEventDisableTiming));
             if (i + 1 < g->classes.size()) {   // the last class runs on the context's stream
                 int prio_lo = 0, prio_hi = 0;   // the hungrier classes (created first) get the higher dispatch priority
@@ -1542,6 +1780,7 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
                 BT_TRYHIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio));
                 BT_TRYHIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
             }
+            lap("class stream");
         }
         if (getenv("BT_GIBBS_DEBUG")) {   // tuning aid: the tiles' LDS need in 2 KB bins (a launch class is charged its hungriest tile's)
             std::vector<uint32_t> bins(40, 0);
@@ -1558,10 +1797,13 @@ static int gibbs_create_impl(bt_ctx *ctx, const bt_gibbs_params *params, const b
         }
     }
     BT_TRYHIP(hipStreamSynchronize(ctx->stream));
+    lap("tables, launch classes");
     BT_TRY(launch(g, OP_SETUP, 0, 0, nullptr));
     BT_TRYHIP(hipStreamSynchronize(ctx->stream));
 #undef BT_TRY
 #undef BT_TRYHIP
+    lap("set-up launch (synchronised)");
+    if (timing) fprintf(stderr, "bt_gibbs: construction of %u groups in %u tiles, pool %.1f MB:%s\n", G, ntiles, g->pool_bytes / 1048576.0, t_text.c_str());
     *out = g;
     return BT_OK;
 }
@@ -1801,6 +2043,8 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
         k.lds_cap = lds_cap;
         k.timeout_ticks = (unsigned long long)(nc_timeout_seconds() * 1e3 * wall_khz);
         k.busy = nullptr;
+        k.debug_flags = getenv("BT_NOISE_CHAIN_DEBUG_FLAGS") ? (uint32_t)atoi(getenv("BT_NOISE_CHAIN_DEBUG_FLAGS")) : 0u;
+        k.pad2 = 0;
         if (getenv("BT_NOISE_CHAIN_PROF")) {
             if (!g->nc.d_busy) BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_busy), (size_t)g->ntiles * 8));
             BT_HIP(hipMemsetAsync(g->nc.d_busy, 0, (size_t)g->ntiles * 8, st));

@@ -41,6 +41,9 @@ struct bt_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;     // the stream work is submitted to
     int num_cu = 0;
+    // pinned staging arena of this context's small uploads (bt_gibbs.hip: staged_upload), reused from sampler to sampler
+    uint8_t *pin = nullptr;
+    size_t pin_bytes = 0, pin_used = 0;
 };
 
 struct bt_timer {

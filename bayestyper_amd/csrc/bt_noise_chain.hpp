@@ -46,6 +46,7 @@ struct NoiseChainCtl {   // device memory, one per launch class (the pointers ar
     uint32_t S;
     uint32_t lds_cap;                  // tiles whose hot arrays need more LDS than this keep them in HBM for the chain
     unsigned long long timeout_ticks;  // wall_clock64() ticks (100 MHz) a single wait may last
+    uint32_t debug_flags, pad2;        // experiments (BT_NOISE_CHAIN_DEBUG_FLAGS): 1 = no acquire after the wait (wrong results: timing only)
     unsigned long long *busy;          // profiling (BT_NOISE_CHAIN_PROF): per workgroup, ticks between the end of its wait and its arrival, summed over the iterations; or null
 };
 
@@ -123,7 +124,7 @@ __device__ static __noinline__ bool nc_wait_table(const NoiseChainCtl *ctl, uint
     }
     __syncthreads();
     const bool ok = *flag == 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the table (and nothing stale of it in this CU's L1 / this XCD's L2)
+    if (!(ctl->debug_flags & 1u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the table (and nothing stale of it in this CU's L1 / this XCD's L2)
     __syncthreads();                                     // (the flag word is rewritten by the next call)
     return ok;
 }

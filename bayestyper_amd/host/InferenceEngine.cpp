@@ -62,6 +62,11 @@ struct GpuSampler : GibbsSampler {
         const bt_gibbs_batch b = batch.view();
         check(bt_gibbs_create(ctx, &p, &b, &g), "bt_gibbs_create");
     }
+    // over a selection of the groups of a batch that is on the device already
+    GpuSampler(bt_ctx *ctx_in, const bt_gibbs_params &p, bt_gibbs_source *source, const std::vector<uint32_t> &ids) : ctx(ctx_in), S(p.num_samples) {
+        if (!ctx) throw std::runtime_error("InferenceEngine: no GPU context (there is no CPU path)");
+        check(bt_gibbs_create_from_source(source, ctx, &p, ids.data(), (uint32_t)ids.size(), &g), "bt_gibbs_create_from_source");
+    }
     ~GpuSampler() override {
         if (resident_chain) bt_gibbs_noise_chain_end(g);
         if (noise_model) bt_noise_model_destroy(noise_model);
@@ -123,6 +128,11 @@ struct GpuSampler : GibbsSampler {
         cd->importGenerator(rng.mt, rng.mt_pos, rng.saved_available, rng.saved);
         cd->setNoiseRates(std::vector<double>(rows->end() - S, rows->end()));
         return true;
+    }
+    uint64_t deviceBytes() override {
+        uint64_t b = 0;
+        check(bt_gibbs_device_bytes(g, &b), "bt_gibbs_device_bytes");
+        return b;
     }
     bool resident_chain = false;
     bool beginResidentChain(uint32_t n_iterations, uint32_t first_collect) override {
@@ -290,6 +300,24 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         }
     } alt;   // (declared before the samplers that may live on it)
     if (!make_sampler && ctx && !getenv("BT_NOISE_SAMPLER_ON_MAIN_THREAD")) check(bt_ctx_clone(ctx, &alt.c), "bt_ctx_clone");
+    // The unit's flat arrays go to the device ONCE; every chain's sampler is laid out from the per-cluster dimensions and filled on the device from them
+    // (bt_gibbs_create_from_source) — no per-chain subset copy on the host, no per-chain upload.
+    struct Source {
+        bt_gibbs_source *s = nullptr;
+        ~Source() {
+            if (s) bt_gibbs_source_destroy(s);
+        }
+    } source;
+    if (!make_sampler && ctx && unit.numGroups() && !getenv("BT_NOISE_NO_SOURCE")) {
+        StageScope stage("  noise chains: the unit's clusters to the device (once)");
+        const bt_gibbs_batch view = unit.view();
+        check(bt_gibbs_source_create(ctx, (uint32_t)S, &view, &source.s), "bt_gibbs_source_create");
+    }
+    const bt_gibbs_params noise_params = params(1);
+    auto sampler_over = [this, &unit, &source, &noise_params](const std::vector<uint32_t> &ids, bt_ctx *on_ctx) -> std::unique_ptr<Sampler> {
+        if (source.s) return std::unique_ptr<Sampler>(new GpuSampler(on_ctx ? on_ctx : ctx, noise_params, source.s, ids));
+        return newSampler(1, unit.take(ids), on_ctx);
+    };
     std::unique_ptr<Sampler> sampler;
     std::vector<uint32_t> sampler_groups;
     // this rank's groups of the next chain (the selection depends on the selector's generator only, not on the chains' results)
@@ -303,7 +331,6 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
     // what a helper thread prepares for the next chain while the current one runs: the subset copy, and — for the product's own (GPU) sampler, whose
     // construction only enqueues on the context's stream — the sampler itself; a caller-supplied sampler factory is only ever called from this thread
     struct Prepared {
-        GibbsBatchData subset;
         std::unique_ptr<Sampler> sampler;
         std::string why_not;   // the helper could not build the sampler (not enough free HBM next to the running chain's, or an error): the calling thread does, after freeing the previous one
     };
@@ -329,9 +356,8 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
             sampler_groups.clear();
             if (!mine.empty()) {
                 StageScope stage("  noise chains: what the helper thread had not prepared (first chain: subset copy + sampler construction)");
-                if (ready.subset.numGroups() == 0) ready.subset = unit.take(mine);
                 if (ready.sampler) sampler_ctx = sampler_ctx == ctx && alt.c ? alt.c : ctx;
-                else ready.sampler = newSampler(1, ready.subset, sampler_ctx);
+                else ready.sampler = sampler_over(mine, sampler_ctx);
                 sampler = std::move(ready.sampler);
                 sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
                 sampler->initChain(chain);
@@ -342,22 +368,20 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         if (chain + 1 < opt.chains) next = select();
         if (!next.empty() && next != sampler_groups) {
             bt_ctx *helper_ctx = alt.c ? (sampler_ctx == ctx ? alt.c : ctx) : nullptr;
-            prepared = std::async(std::launch::async, [this, &unit, next, helper_ctx]() {
+            const uint64_t like = sampler ? sampler->deviceBytes() : 0;   // the next chain's sampler is over as many groups of the same unit: about as large
+            prepared = std::async(std::launch::async, [this, &source, &noise_params, &sampler_over, next, helper_ctx, like]() {
                 Prepared r;
-                {
-                    StageScope stage("  noise chains (helper thread, overlapped): subset copy");
-                    r.subset = unit.take(next);
-                }
                 if (!helper_ctx) return r;
                 StageScope stage("  noise chains (helper thread, overlapped): sampler construction");
                 try {   // next to the running chain's sampler only when its state fits the free HBM with room to spare
-                    const bt_gibbs_params p = params(1);
-                    const bt_gibbs_batch view = r.subset.view();
                     uint64_t need = 0, total = 0, free_bytes = 0;
                     int num_cu = 0;
-                    if (bt_gibbs_state_bytes(helper_ctx, &p, &view, &need) != BT_OK || bt_ctx_info(helper_ctx, &num_cu, &total, &free_bytes, nullptr, 0) != BT_OK) r.why_not = bt_last_error();
-                    else if ((double)need > 0.7 * (double)free_bytes) r.why_not = "sampler state does not fit next to the running chain's";
-                    else r.sampler = newSampler(1, r.subset, helper_ctx);
+                    need = like + like / 4;
+                    if (source.s && ((need == 0 && bt_gibbs_state_bytes_from_source(source.s, &noise_params, next.data(), (uint32_t)next.size(), &need) != BT_OK) ||
+                                     bt_ctx_info(helper_ctx, &num_cu, &total, &free_bytes, nullptr, 0) != BT_OK))
+                        r.why_not = bt_last_error();
+                    else if (source.s && (double)need > 0.7 * (double)free_bytes) r.why_not = "sampler state does not fit next to the running chain's";
+                    else r.sampler = sampler_over(next, helper_ctx);
                 } catch (const std::exception &e) {
                     r.sampler.reset();
                     r.why_not = e.what();

@@ -76,6 +76,7 @@ struct GibbsSampler {
     virtual bool resetGroups() { return false; }
     virtual void sweep(uint32_t n, bool collect) = 0;
     virtual void run() = 0;                                   // the whole default schedule
+    virtual uint64_t deviceBytes() { return 0; }              // device memory the sampler holds (0: unknown)
     virtual void sync() {}                                    // wait for what run() enqueued (stage timing; results() waits anyway)
     virtual std::vector<uint64_t> noiseCounts() = 0;          // [S*256], VariantClusterGroup::getNoiseCounts of every group + clearGenotyperCache
     // one iteration of the noise drivers: (the noise table drawn in the previous iteration, or nullptr;) one sweep; the noise counts.

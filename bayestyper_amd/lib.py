@@ -141,6 +141,14 @@ class Ctx:
         check(bt_ctx_create(device, C.byref(h)))
         self.h = h.value
 
+    def clone(self):
+        """bt_ctx_clone: a second context on the same GPU whose stream runs concurrently with this one's"""
+        h = vp()
+        check(bt_ctx_clone(self.h, C.byref(h)))
+        c = Ctx.__new__(Ctx)
+        c.h = h.value
+        return c
+
     def sync(self):
         check(bt_sync(self.h))
 

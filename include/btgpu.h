@@ -451,6 +451,20 @@ int bt_gibbs_create(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_b
  * bt_ctx_info's free HBM (InferenceEngine.cpp:335-382 hands groups to its workers in batches; here a batch is what fits the GPU) */
 int bt_gibbs_state_bytes(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gibbs_batch *batch, uint64_t *bytes);
 int bt_gibbs_destroy(bt_gibbs *g);
+/* A batch's flat arrays held ON THE DEVICE, and samplers over any selection of its groups built from them without another pass through the host:
+ * the reference keeps a unit's clusters in memory for the whole genotyping stage and constructs genotypers from them chain after chain
+ * (InferenceEngine.cpp:60-75 initGenotypersCallback over the unit's groups, :172-211 the noise driver's subset per chain, :335-382 the group batches of
+ * the default mode); here the unit goes to the GPU once (bt_gibbs_source_create: validated like bt_gibbs_create, uploaded, the caller's arrays are not
+ * referenced afterwards) and every sampler — a noise chain's random subset, a launch-sized range of the unit — is laid out by the host from the
+ * per-cluster dimensions alone and filled by the device from the resident arrays (bt_gibbs_create_from_source: group_ids = positions in the source
+ * batch, in the order the sampler shall hold them; NULL = all groups; ctx = the context whose stream the sampler works on, NULL = the source's, same device).
+ * bt_gibbs_create(batch) = source + sampler over all groups + source released. */
+typedef struct bt_gibbs_source bt_gibbs_source;
+int bt_gibbs_source_create(bt_ctx *ctx, uint32_t num_samples, const bt_gibbs_batch *batch, bt_gibbs_source **out);
+int bt_gibbs_source_destroy(bt_gibbs_source *src);
+int bt_gibbs_source_device_bytes(bt_gibbs_source *src, uint64_t *bytes);
+int bt_gibbs_create_from_source(bt_gibbs_source *src, bt_ctx *ctx, const bt_gibbs_params *params, const uint32_t *group_ids, uint32_t num_groups, bt_gibbs **out);
+int bt_gibbs_state_bytes_from_source(bt_gibbs_source *src, const bt_gibbs_params *params, const uint32_t *group_ids, uint32_t num_groups, uint64_t *bytes);
 /* upload the count-model LUTs (see above); must be called before the first sweep and after every noise update */
 int bt_gibbs_set_lut(bt_gibbs *g, const double *h_genomic /* [S*256*256] */, const double *h_noise /* [S*256] */);
 int bt_gibbs_set_noise_lut(bt_gibbs *g, const double *h_noise /* [S*256] */);

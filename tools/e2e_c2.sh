@@ -21,7 +21,7 @@ export BT_STAGE_TIMES=1
 run_cluster() { $exe cluster -v $d/candidates.vcf -s $d/samples.tsv -g $d/genome.fa -o $d/bt -p $T -r 42 > $d/cluster.out 2> $d/cluster.err; }
 run_genotype() { $exe genotype -v $d/bt_unit_1/variant_clusters.bin -c $d/bt_cluster_data -s $d/samples.tsv -g $d/genome.fa -o $d/bt -p $T -r 42 > $d/genotype.out 2> $d/genotype.err; }
 echo "## bayesTyper cluster"; t run_cluster; tail -30 $d/cluster.err; grep -E "Parsed unit|kmers" $d/cluster.out | head -8
-echo "## bayesTyper genotype"; t run_genotype; tail -30 $d/genotype.err; grep -E "Out of|genotyped|skipped|Estimated negative" $d/genotype.out | head -8
+echo "## bayesTyper genotype"; t run_genotype; tail -${BT_E2E_TAIL:-30} $d/genotype.err; grep -E "Out of|genotyped|skipped|Estimated negative" $d/genotype.out | head -8
 ls -l $d/bt.vcf 2>/dev/null | awk '{print "# output VCF bytes: " $5}'
 if [ -n "${BT_E2E_TRACE:-}" ]; then   # kernel trace of a second `genotype` run: totals per kernel + a window of the noise driver's loop
   echo "## bayesTyper genotype under rocprofv3 --kernel-trace --stats"
