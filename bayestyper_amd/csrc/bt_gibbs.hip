@@ -1153,6 +1153,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         // 21.3 s at 64 / 64 before the copies worked in teams).  Four per wavefront; single clusters with 6..15 candidates sixteen.
         // `relax` (the batch does not fit the free HBM) doubles both.
         uint32_t width_x = kMinTileWidth, width_y = 16;   // (r02, after the copies' teams: 10.2 s at 4 / 16 against 10.6 s at 8 / 16 and 11.4 s at 8 / 32)
+        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) width_y = 8;   // (a noise chain's iteration waits for its slowest tile: 150 us at 16 groups per tile, eight copies share the table fill)
         width_x = std::min<uint32_t>(LANES, width_x << relax);
         width_y = std::min<uint32_t>(LANES, width_y << relax);
         if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {
@@ -1194,12 +1195,19 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         // tile and an iteration lasts as long as its slowest tile (bt_gibbs_noise_chain_begin).  Single clusters with 4 or 5 candidates in 64-group tiles
         // are both (36 - 44 KB of LDS; 190 - 260 us per iteration with their hot arrays pushed out to HBM against 75 us of the others): they get 16 groups
         // per wavefront (four copies share the table fills), like the clusters with 6..15 candidates above.
-        uint32_t n_z = n_y;
-        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS"))
+        uint32_t n_z = n_y, n_z3 = n_y;
+        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) {
             while (n_z < G && shapes[n_z].Hmax >= 4) ++n_z;
+            n_z3 = n_z;
+            while (n_z3 < G && shapes[n_z3].Hmax >= 3) ++n_z3;   // three candidates: 29 KB at 64 groups per tile, half of that at 32
+        }
         while (at < n_z) {
             tile_start.push_back(at);
             at += std::min<uint32_t>(width_y, n_z - at);
+        }
+        while (at < n_z3) {
+            tile_start.push_back(at);
+            at += std::min<uint32_t>(32u, n_z3 - at);
         }
         while (at < G) {
             tile_start.push_back(at);

@@ -183,13 +183,19 @@ __device__ BT_NOINLINE void noise_tally_group(Env env, uint32_t nvert, const Noi
     auto *bins = nc_bins(nc);
     for (uint32_t v = 0; v < nvert; ++v) {
         const Vx c = make_vx(t, v);
-        const uint32_t nsu = c.sc()[SC_NSUB_U];
-        TPtr<uint32_t> usub = c.usub();
+        // from the compact copies of the subset (sample_kmer_subset: multiplicity rows, intercluster multiplicities and counts — both zero for a k-mer
+        // without counts: what unique_mult and the count test of getNoiseCounts read through the subset's index list)
+        const uint32_t nsu = c.sc()[SC_NSUB_U], Hm = t.d->Hm;
+        const Vx::RPtr<uint8_t> sm = c.subm();
+        TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
         for (uint32_t s = 0; s < P.S; ++s) {
             const uint16_t h1 = c.dip()[2 * s], h2 = c.dip()[2 * s + 1];
+            const uint8_t gender = P.gender[s];
             for (uint32_t i = t.part; i < nsu; i += t.copies) {   // the copies of a narrow tile's group share the k-mers of the subset (a tally: any order)
-                const uint32_t k = usub[i];
-                if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) nc_tally(nc, bins, s, c.has_counts(k) ? c.count(k, s) : 0u);
+                uint8_t m = sic[2 * i + gender];
+                if (h1 != NOHAP) m = (uint8_t)(m + sm[i * Hm + h1]);
+                if (h2 != NOHAP) m = (uint8_t)(m + sm[i * Hm + h2]);
+                if (m == 0) nc_tally(nc, bins, s, scn[i * P.S + s]);
             }
         }
         if (t.part == 0) cache_clear(c, P, false, false);   // (the other copies read nothing this touches before the next sweep)

@@ -183,6 +183,59 @@ __device__ inline SimpleWeights simple_weights(const UC &uc, uint32_t Dcm, uint3
     return SimpleWeights{(float)ea, (float)eb, wmax};
 }
 
+// fill_unique_cache for a two-haplotype cluster: the five entries of a sample — (0,0) (0,1) (1,1) and the haploid (0) (1) — in ONE pass over the k-mer
+// subset (the general fill walks the subset once per block of candidates that share their first haplotype: three passes here), four k-mers per step: the
+// shared operands are read once, the twenty table lookups of a step are independent.  Every entry is the same sum in the same (subset) order as
+// unique_log_prob's, so the values are bit-identical.
+__device__ static __noinline__ void simple_fill_unique(Env env) {
+    const Tile t = make_tile(env);
+    const Vx c = make_vx(t, 0);
+    const GParams BT_CAS &P = env_params(env);
+    const TileDesc BT_CAS &d = *t.d;
+    const uint32_t nsub = c.sc()[SC_NSUB_U], Hm = d.Hm, S = P.S;
+    const Vx::RPtr<uint8_t> sm = c.subm();
+    TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
+    const Vx::UCPtr uc = c.ucache();
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint8_t gender = P.gender[s];
+        double acc[5] = {0, 0, 0, 0, 0};
+        uint32_t i = 0;
+        for (; i + 4 <= nsub; i += 4) {
+            uint8_t m[4][5], cn[4];
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint8_t m0 = sm[(i + r) * Hm], m1 = sm[(i + r) * Hm + 1], icn = sic[2 * (i + r) + gender];
+                cn[r] = scn[(i + r) * S + s];
+                m[r][0] = (uint8_t)((uint8_t)(m0 + m0) + icn);
+                m[r][1] = (uint8_t)((uint8_t)(m0 + m1) + icn);
+                m[r][2] = (uint8_t)((uint8_t)(m1 + m1) + icn);
+                m[r][3] = (uint8_t)(m0 + icn);
+                m[r][4] = (uint8_t)(m1 + icn);
+            }
+            double lp[4][5];
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+                for (uint32_t q = 0; q < 5; ++q) lp[r][q] = count_log_prob(P, s, m[r][q], cn[r]);
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r)
+#pragma unroll
+                for (uint32_t q = 0; q < 5; ++q) acc[q] += lp[r][q];
+        }
+        for (; i < nsub; ++i) {
+            const uint8_t m0 = sm[i * Hm], m1 = sm[i * Hm + 1], icn = sic[2 * i + gender], cn = scn[i * S + s];
+            const uint8_t m[5] = {(uint8_t)((uint8_t)(m0 + m0) + icn), (uint8_t)((uint8_t)(m0 + m1) + icn), (uint8_t)((uint8_t)(m1 + m1) + icn), (uint8_t)(m0 + icn), (uint8_t)(m1 + icn)};
+            double lp[5];
+#pragma unroll
+            for (uint32_t q = 0; q < 5; ++q) lp[q] = count_log_prob(P, s, m[q], cn);
+#pragma unroll
+            for (uint32_t q = 0; q < 5; ++q) acc[q] += lp[q];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 5; ++q) uc[s * d.Dcm + q] = acc[q];
+    }
+}
+
 // Chain entry: the per-sample LDS words from the general arrays, the candidates' weights from the table of unique-k-mer sums (rebuilt when
 // the chain start / clearCache marked it), the sparse distribution's simplex-size probability.  Returns P(simplex size = |plus|) for |plus| = 1.
 __device__ static __noinline__ double simple_enter(Env env, uint32_t blk_off) {
@@ -193,7 +246,7 @@ __device__ static __noinline__ double simple_enter(Env env, uint32_t blk_off) {
     const uint32_t S = P.S, Dcm = d.Dcm;
     SPtrF<uint32_t, LANES> sc = c.sc();
     if (sc[SC_UC_DIRTY]) {   // chain start / clearCache: the dense table of unique-k-mer sums is rebuilt as a whole
-        fill_unique_cache(env, 0);
+        simple_fill_unique(env);
         sc[SC_UC_DIRTY] = 0;
     }
     LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
@@ -278,7 +331,7 @@ __device__ static __noinline__ void simple_reweight(Env env, uint32_t blk_off) {
     const Tile t = make_tile(env);
     const Vx c = make_vx(t, 0);
     const GParams BT_CAS &P = env_params(env);
-    fill_unique_cache(env, 0);
+    simple_fill_unique(env);
     c.sc()[SC_UC_DIRTY] = 0;
     LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
     const Vx::UCPtr uc = c.ucache();
@@ -299,14 +352,35 @@ __device__ static __noinline__ void simple_noise_tally(Env env, uint32_t blk_off
     const GParams BT_CAS &P = env_params(env);
     LdsArr<uint32_t> blk{(uint32_t BT_LAS *)(bt_lds_raw + blk_off) + t.lane};
     auto *bins = nc_bins(nc);
-    const uint32_t nsu = c.sc()[SC_NSUB_U];
-    TPtr<uint32_t> usub = c.usub();
-    for (uint32_t s = 0; s < P.S; ++s) {
-        const uint32_t code = blk[SB_WORDS * s + 2] & 7u;
-        const uint16_t h1 = (uint16_t)sd_h1(code), h2 = (uint16_t)sd_h2(code);
-        for (uint32_t i = 0; i < nsu; ++i) {
-            const uint32_t k = usub[i];
-            if (unique_mult(c, k, h1, h2, P.gender[s]) == 0) nc_tally(nc, bins, s, c.has_counts(k) ? c.count(k, s) : 0u);
+    // from the compact copies of the subset (sample_kmer_subset: rows of the two haplotypes' multiplicities, the intercluster multiplicities and the counts,
+    // both zero for a k-mer without counts — what unique_mult / the count test of getNoiseCounts read through the subset's index list), four k-mers per step
+    const uint32_t nsu = c.sc()[SC_NSUB_U], Hm = t.d->Hm, S = P.S;
+    const Vx::RPtr<uint8_t> sm = c.subm();
+    TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
+    for (uint32_t i = 0; i < nsu; i += 4) {
+        uint8_t m0[4], m1[4], ic0[4], ic1[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = i + r < nsu ? i + r : nsu - 1u;
+            m0[r] = sm[j * Hm];
+            m1[r] = sm[j * Hm + 1];
+            ic0[r] = sic[2 * j];
+            ic1[r] = sic[2 * j + 1];
+        }
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint32_t code = blk[SB_WORDS * s + 2] & 7u, h1 = sd_h1(code), h2 = sd_h2(code);
+            const bool g1 = P.gender[s] != 0;
+            uint8_t cn[4];
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) cn[r] = scn[(i + r < nsu ? i + r : nsu - 1u) * S + s];
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {
+                uint8_t m = 0;
+                if (h1 != (uint32_t)NOHAP) m = (uint8_t)(m + (h1 ? m1[r] : m0[r]));
+                if (h2 != (uint32_t)NOHAP) m = (uint8_t)(m + (h2 ? m1[r] : m0[r]));
+                m = (uint8_t)(m + (g1 ? ic1[r] : ic0[r]));
+                if (i + r < nsu && m == 0) nc_tally(nc, bins, s, cn[r]);
+            }
         }
     }
     c.sc()[SC_UC_DIRTY] = 1;
