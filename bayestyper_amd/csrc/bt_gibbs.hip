@@ -533,8 +533,9 @@ struct bt_gibbs {
         NoiseChainCtl *d_ctl = nullptr;
         NoiseChainCtl ctl{};
         unsigned long long *d_busy = nullptr;   // BT_NOISE_CHAIN_PROF: per tile, the ticks its workgroup worked (the rest of a chain it waited for the others / the host)
-        bool active = false;
+        bool active = false, launched = false;
         uint32_t n = 0, next = 0;
+        uint32_t it_begin = 0, first_collect = 0, lds = 0;   // it_begin = 1: iteration 0 of the chain runs as ordinary launches (whole-GPU table refill), the resident launch starts with iteration 1
     } nc;
 };
 
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(256) void ucache_prefill_kernel(const TileDesc *__r
 
 int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hist) {
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
-    if (g->nc.active) return fail("bt_gibbs: a resident noise chain is in progress (bt_gibbs_noise_chain_end)");
+    if (g->nc.active && g->nc.launched) return fail("bt_gibbs: a resident noise chain is in progress (bt_gibbs_noise_chain_end)");
     BT_HIP(hipSetDevice(g->ctx->device));
     if (op == OP_NOISE && !g->wide_fill) a0 = 0;
     if (op == OP_INIT_CHAIN) a1 = g->wide_fill ? 1u : 0u;
@@ -1929,7 +1930,6 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
 // ---- a chain of a noise driver as ONE resident launch (bt_noise_chain.hpp) ----
 namespace {
 inline uint32_t nc_bins_bytes(uint32_t S) { return (S * NC_BINS + 4u) * 4u; }   // the bins, the flag word, (aligned) the profiling time stamp
-constexpr uint32_t kResidentTableEntries = 4096;
 struct NcMail {   // layout of the pinned mailbox
     uint64_t *hist;
     double *table;
@@ -1971,15 +1971,14 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     // need of the hungriest tile + the bins): tiles <= workgroups per CU x CUs, exactly.  Tiles with large dense tables want the whole-GPU refill between
     // iterations (nan_fill_kernel / ucache_prefill_kernel), which a resident launch cannot give them: such batches keep the launch-per-iteration path.
     const double fill_limit = getenv("BT_NOISE_CHAIN_FILL") ? atof(getenv("BT_NOISE_CHAIN_FILL")) : 1.0;
-    for (const auto &c : g->classes) {
-        if (c.num_fill || c.num_prefill) {
-            // large dense tables of unique-k-mer sums: up to kResidentTableEntries entries per lane they are invalidated and refilled by the tile's own lanes
-            // (cache_clear's "dirty = 2": what a launch without the wide refill does); above, the launch-per-iteration path with its whole-GPU refill is faster
-            uint32_t biggest = 0;
-            for (uint32_t ti : c.tiles) biggest = std::max(biggest, g->tiles[ti].cache_entries);
-            if (biggest > kResidentTableEntries && !getenv("BT_NOISE_CHAIN_WIDE")) return BT_OK;
-        }
-    }
+    // Tiles with large dense tables of unique-k-mer sums: the FIRST sweep of a chain asks for every entry (all haplotypes have a non-zero frequency at a chain
+    // start), which the whole GPU computes far faster than the tile's own lanes (nan_fill_kernel / ucache_prefill_kernel between launches) — so iteration 0 of
+    // such a chain runs as ordinary launches and the resident launch starts with iteration 1, where the sweeps ask for the pairs of the few haplotypes left and
+    // the tile invalidates its table itself (cache_clear's "dirty = 2").  BT_NOISE_CHAIN_WIDE=1: resident from iteration 0 on (tests).
+    bool has_wide = false;
+    for (const auto &c : g->classes) has_wide = has_wide || c.num_fill || c.num_prefill;
+    const uint32_t it_begin = has_wide && !getenv("BT_NOISE_CHAIN_WIDE") ? 1u : 0u;
+    if (num_iterations <= it_begin) return BT_OK;
     // LDS per workgroup: every workgroup of the launch is charged the same amount.  The cap is the largest tile need with which all tiles are still resident
     // together; the (few, many-candidate) tiles above it keep their hot arrays in HBM for the chain (RESIDENT_NEVER); the tiles of two-haplotype clusters
     // (the bulk, and they cannot do without their block) must fit.
@@ -2052,19 +2051,26 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
         k.timeout_ticks = (unsigned long long)(nc_timeout_seconds() * 1e3 * wall_khz);
         k.busy = nullptr;
         k.debug_flags = getenv("BT_NOISE_CHAIN_DEBUG_FLAGS") ? (uint32_t)atoi(getenv("BT_NOISE_CHAIN_DEBUG_FLAGS")) : 0u;
-        k.pad2 = 0;
         if (getenv("BT_NOISE_CHAIN_PROF")) {
             if (!g->nc.d_busy) BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_busy), (size_t)g->ntiles * 8));
             BT_HIP(hipMemsetAsync(g->nc.d_busy, 0, (size_t)g->ntiles * 8, st));
             k.busy = g->nc.d_busy;
         }
     }
+    g->nc.ctl.it_begin = it_begin;
+    g->nc.it_begin = it_begin;
+    g->nc.first_collect = first_collect;
+    g->nc.lds = lds;
+    g->nc.launched = false;
     BT_HIP(hipMemcpyAsync(g->nc.d_ctl, &g->nc.ctl, sizeof(NoiseChainCtl), hipMemcpyHostToDevice, st));
     BT_HIP(hipStreamSynchronize(st));   // (the control block is read from pageable memory)
     BT_HIP(prepare_gibbs_chain_kernel((int)kHotBudget));
-    TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
-    BT_HIP(launch_gibbs_chain_kernel(g->ntiles, lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
-    g->prefill_armed = false;
+    if (it_begin == 0) {
+        TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
+        BT_HIP(launch_gibbs_chain_kernel(g->ntiles, lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
+        g->prefill_armed = false;
+        g->nc.launched = true;
+    }
     g->nc.active = true;
     g->nc.n = num_iterations;
     g->nc.next = 0;
@@ -2080,7 +2086,36 @@ int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hi
     if (it == 0 && h_noise) return fail("bt_gibbs_noise_chain_step: the first iteration of a chain runs with the sampler's table (bt_gibbs_set_noise_lut before the chain)");
     const size_t nh = (size_t)g->S * 256;
     const NcMail mail = nc_mail(g);
-    if (it > 0) {   // the table of this iteration's sweep: the workgroup that published histogram `it` is waiting for it
+    if (!g->nc.launched && it < g->nc.it_begin) {   // iteration 0 of a chain with large tables: ordinary launches (sweep with the whole-GPU refill, tally, one synchronisation)
+        const int rc = bt_gibbs_noise_iteration(g, nullptr, it >= g->nc.first_collect ? 1 : 0, h_hist);
+        if (rc != BT_OK) {
+            g->nc.active = false;
+            return rc;
+        }
+        g->nc.next = it + 1;
+        return BT_OK;
+    }
+    if (!g->nc.launched) {   // it == it_begin > 0: this iteration's table goes up the ordinary way, the large tables are refilled by the whole GPU, then the launch
+        BT_HIP(hipSetDevice(g->ctx->device));
+        hipStream_t st = g->ctx->stream;
+        if (h_noise) {
+            std::memcpy(mail.table, h_noise, nh * 8);
+            g->h_lut_n.assign(h_noise, h_noise + nh);
+        }
+        BT_HIP(hipMemcpyAsync(g->d_lut_n, mail.table, nh * 8, hipMemcpyHostToDevice, st));
+        if (g->prefill_armed)
+            for (auto &c : g->classes)
+                if (c.num_prefill) {
+                    const unsigned threads = (uint64_t)c.num_prefill * g->S >= 4096 ? 64u : 256u;
+                    hipLaunchKernelGGL(ucache_prefill_kernel, dim3(c.num_prefill, g->S), dim3(threads), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const GParams *)g->d_params,
+                                       (const PrefillItem *)c.d_prefill);
+                    BT_CHECK_LAUNCH();
+                }
+        TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
+        BT_HIP(launch_gibbs_chain_kernel(g->ntiles, g->nc.lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
+        g->prefill_armed = false;
+        g->nc.launched = true;
+    } else if (it > 0) {   // the table of this iteration's sweep: the workgroup that published histogram `it` is waiting for it
         if (h_noise) {
             std::memcpy(mail.table, h_noise, nh * 8);
             g->h_lut_n.assign(h_noise, h_noise + nh);
@@ -2116,6 +2151,7 @@ int bt_gibbs_noise_chain_end(bt_gibbs *g) {
     const bool complete = g->nc.next >= g->nc.n;
     if (!complete) nc_store(mail.table_seq, NC_ABORT);   // the launch ends at its next exchange
     g->nc.active = false;
+    g->nc.launched = false;
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
     if (complete && nc_load(mail.hist_seq) == NC_ABORT) return fail("bt_gibbs_noise_chain_end: the resident launch was aborted");
     if (g->nc.d_busy && g->nc.ctl.busy) {   // BT_NOISE_CHAIN_PROF: which tiles an iteration waits for

@@ -290,8 +290,9 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                 simple_sweeps(env, t, P, n_burn, n_collect, tr.counter, tr.buf, tr.max_sweeps, tile, nc);
                 if (is_run || n_collect) drain_collected(env);   // the chain's collected sweeps -> statistics (the next chain has another k-mer subset)
             } else {
-                for (uint32_t i = 0; i < n_burn + n_collect; ++i) {
-                    if (is_nc && i > 0 && !nc_wait_table(nc, i)) break;
+                const uint32_t i0 = is_nc ? nc->it_begin : 0u;
+                for (uint32_t i = i0; i < n_burn + n_collect; ++i) {
+                    if (is_nc && i > i0 && !nc_wait_table(nc, i)) break;
                     const TraceRow r = trace_row_for(t, P, tr, tile);
                     group_sweep(env, t, P, i >= n_burn, nvert, nsrc, r.row, r.on);
                     if (is_nc) {

@@ -426,9 +426,10 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
     const double BT_GAS *a2tab = P.gamma_a2;
     const uint32_t a2n = P.gamma_n;
 
-    for (uint32_t sweep = 0; sweep < n_sweeps; ++sweep) {
+    const uint32_t sweep0 = nc ? nc->it_begin : 0u;
+    for (uint32_t sweep = sweep0; sweep < n_sweeps; ++sweep) {
         const bool collect = sweep >= n_burn;
-        if (nc && sweep > 0) {
+        if (nc && sweep > sweep0) {
             if (!nc_wait_table(nc, sweep)) break;
             simple_reweight(env, blk_off);
         }

@@ -46,7 +46,9 @@ struct NoiseChainCtl {   // device memory, one per launch class (the pointers ar
     uint32_t S;
     uint32_t lds_cap;                  // tiles whose hot arrays need more LDS than this keep them in HBM for the chain
     unsigned long long timeout_ticks;  // wall_clock64() ticks (100 MHz) a single wait may last
-    uint32_t debug_flags, pad2;        // experiments (BT_NOISE_CHAIN_DEBUG_FLAGS): 1 = no acquire after the wait (wrong results: timing only)
+    uint32_t debug_flags;
+    uint32_t it_begin;                 // first iteration of the chain that runs in the resident launch (1: iteration 0 ran as ordinary launches, bt_gibbs_noise_chain_step)
+    //        // experiments (BT_NOISE_CHAIN_DEBUG_FLAGS): 1 = no acquire after the wait (wrong results: timing only)
     unsigned long long *busy;          // profiling (BT_NOISE_CHAIN_PROF): per workgroup, ticks between the end of its wait and its arrival, summed over the iterations; or null
 };
 
@@ -151,7 +153,7 @@ __device__ static __noinline__ bool nc_iteration_end(const NoiseChainCtl *ctl, u
     if (threadIdx.x == 0) {
         if (ctl->busy) ctl->busy[blockIdx.x] += (unsigned long long)wall_clock64() - *(unsigned long long NC_LAS *)(bins + ((S * NC_BINS + 2u) & ~1u));
         const uint32_t old = __hip_atomic_fetch_add(ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = old == (it + 1u) * ctl->total_wgs - 1u ? 1u : 0u;
+        *flag = old == (it + 1u - ctl->it_begin) * ctl->total_wgs - 1u ? 1u : 0u;
     }
     __syncthreads();
     const bool last = *flag != 0;

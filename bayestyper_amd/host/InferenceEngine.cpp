@@ -251,13 +251,17 @@ void InferenceEngine::runNoiseChain(Sampler *sampler, CountDistribution *cd, uin
             if (s) try { s->endResidentChain(); } catch (...) {}
         }
     } guard{nullptr};
-    if (sampler && pending_noise == false && sampler->beginResidentChain(n, first_collect_iteration - 1)) guard.s = sampler;
+    {
+        StageScope stage("  noise chains: resident launch set up");
+        if (sampler && pending_noise == false && sampler->beginResidentChain(n, first_collect_iteration - 1)) guard.s = sampler;
+    }
     for (uint32_t it = 1; it <= n; it++) {
         iteration(sampler, cd, it >= first_collect_iteration);
         logRow(out, chain + 1, it, cd->getNoiseRates());
         if (each) each(it, cd->getNoiseRates());
     }
     if (guard.s) {
+        StageScope stage("  noise chains: resident launch ended");
         guard.s = nullptr;
         sampler->endResidentChain();   // (errors of a completed chain are reported)
     }
@@ -352,13 +356,17 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
                 StageScope stage("  noise chains: waiting for the helper thread (next chain's subset copy + sampler)");
                 ready = prepared.get();
             }
-            sampler.reset();   // (before anything is built on this thread: two samplers' state at once is the helper's privilege, and only when it fits)
+            {
+                StageScope stage("  noise chains: previous sampler released");
+                sampler.reset();   // (before anything is built on this thread: two samplers' state at once is the helper's privilege, and only when it fits)
+            }
             sampler_groups.clear();
             if (!mine.empty()) {
                 StageScope stage("  noise chains: what the helper thread had not prepared (first chain: subset copy + sampler construction)");
                 if (ready.sampler) sampler_ctx = sampler_ctx == ctx && alt.c ? alt.c : ctx;
                 else ready.sampler = sampler_over(mine, sampler_ctx);
                 sampler = std::move(ready.sampler);
+                StageScope stage2("  noise chains: count tables to the sampler + chain start (enqueued)");
                 sampler->setLut(cd->genomicTable().data(), cd->noiseTable().data());
                 sampler->initChain(chain);
                 sampler_groups = mine;

@@ -292,21 +292,25 @@ def test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path):
     assert exact == flat["num_clusters"]
 
 
-@pytest.mark.parametrize("S,parts,lds_cap", [(3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), None), (3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), 1),
-                                             (1, (("A", 200, 8), ("B", 20, 2)), None), (10, (("A", 70, 4), ("B", 12, 2)), None)])
-def test_resident_noise_chain_equals_launch_per_iteration(gpu_ctx, oracle, monkeypatch, S, parts, lds_cap):
+@pytest.mark.parametrize("S,parts,mode", [(3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), "hybrid"), (3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), "all"),
+                                          (3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), "lds_cap"), (1, (("A", 200, 8), ("B", 20, 2)), "hybrid"),
+                                          (10, (("A", 70, 4), ("B", 12, 2)), "hybrid")])
+def test_resident_noise_chain_equals_launch_per_iteration(gpu_ctx, oracle, monkeypatch, S, parts, mode):
     """bt_gibbs_noise_chain_begin / _step / _end (a chain of a noise driver as ONE resident launch: sampler state kept in registers / LDS across the
     iterations, histogram and table exchanged through pinned memory) against bt_gibbs_noise_iteration (a sweep + a tally launch and a synchronisation per
     iteration) on two samplers over the same batch — two-haplotype tiles (gibbs_simple_kernel), LDS-resident multi-allelic and many-candidate clusters
     (gibbs_hot_kernel) and nested groups (gibbs_kernel, hot arrays swapped per visit) — with another noise table every iteration, collecting from the
     fourth iteration on, two chains with a group reset between them: the histogram of every iteration, every sampled diplotype of every sweep and the
-    collected results are identical.  lds_cap: the chain keeps the hot arrays of every tile but the two-haplotype ones in HBM (what it does to the few tiles
-    whose LDS block would keep the chain's workgroups from being resident together)."""
+    collected results are identical.  mode "hybrid" (the default): a batch with large dense tables (the many-candidate clusters) runs iteration 0 of a chain as
+    ordinary launches — the whole GPU fills the tables the first sweep asks for — and the resident launch from iteration 1 on; "all": resident from
+    iteration 0 on, the tables filled by the tiles' own lanes; "lds_cap": the chain keeps the hot arrays of every tile but the two-haplotype ones in HBM (what
+    it does to the few tiles whose LDS block would keep the chain's workgroups from being resident together)."""
     from bayestyper_amd import lib, synth
 
-    monkeypatch.setenv("BT_NOISE_CHAIN_WIDE", "1")   # (the many-candidate clusters' large tables: refilled by their own lanes inside the resident launch)
-    if lds_cap:
-        monkeypatch.setenv("BT_NOISE_CHAIN_LDS_CAP", str(lds_cap))
+    if mode != "hybrid":
+        monkeypatch.setenv("BT_NOISE_CHAIN_WIDE", "1")   # (the many-candidate clusters' large tables: refilled by their own lanes inside the resident launch)
+    if mode == "lds_cap":
+        monkeypatch.setenv("BT_NOISE_CHAIN_LDS_CAP", "1")
     flat = synth.concat([synth.make_batch(sh, n, S, seed=31 + i, templates=t) for i, (sh, n, t) in enumerate(parts)])
     flat["group_index"] = np.arange(flat["num_groups"], dtype=np.uint32)
     lut_g, lut_n = _oracle.build_luts(oracle, S)
