@@ -1929,6 +1929,7 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
 
 // ---- a chain of a noise driver as ONE resident launch (bt_noise_chain.hpp) ----
 namespace {
+constexpr uint32_t kResidentTableEntries = 16384;
 inline uint32_t nc_bins_bytes(uint32_t S) { return (S * NC_BINS + 4u) * 4u; }   // the bins, the flag word, (aligned) the profiling time stamp
 struct NcMail {   // layout of the pinned mailbox
     uint64_t *hist;
@@ -1975,9 +1976,19 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     // start), which the whole GPU computes far faster than the tile's own lanes (nan_fill_kernel / ucache_prefill_kernel between launches) — so iteration 0 of
     // such a chain runs as ordinary launches and the resident launch starts with iteration 1, where the sweeps ask for the pairs of the few haplotypes left and
     // the tile invalidates its table itself (cache_clear's "dirty = 2").  BT_NOISE_CHAIN_WIDE=1: resident from iteration 0 on (tests).
+    // Above kResidentTableEntries entries per group the per-iteration refill wants the whole GPU as well (a 256-candidate cluster at thirty samples keeps some
+    // sixty haplotypes alive: 55 000 sums over the k-mer subset per iteration — 43 ms by the tile's own lanes, 6 ms with ucache_prefill_kernel between
+    // launches): such batches keep the launch-per-iteration path.
     bool has_wide = false;
-    for (const auto &c : g->classes) has_wide = has_wide || c.num_fill || c.num_prefill;
-    const uint32_t it_begin = has_wide && !getenv("BT_NOISE_CHAIN_WIDE") ? 1u : 0u;
+    uint32_t biggest = 0;
+    for (const auto &c : g->classes)
+        if (c.num_fill || c.num_prefill) {
+            has_wide = true;
+            for (uint32_t ti : c.tiles) biggest = std::max(biggest, g->tiles[ti].cache_entries);
+        }
+    const bool forced = getenv("BT_NOISE_CHAIN_WIDE") != nullptr;
+    if (biggest > kResidentTableEntries && !forced) return BT_OK;
+    const uint32_t it_begin = has_wide && !forced ? 1u : 0u;
     if (num_iterations <= it_begin) return BT_OK;
     // LDS per workgroup: every workgroup of the launch is charged the same amount.  The cap is the largest tile need with which all tiles are still resident
     // together; the (few, many-candidate) tiles above it keep their hot arrays in HBM for the chain (RESIDENT_NEVER); the tiles of two-haplotype clusters

@@ -645,6 +645,26 @@ def main():
         cd10, rec10n = noise_pair(f10, S10, 1, "the samples10 batch (100 000 groups, S=10) in --noise-genotyping mode beside the default mode, 1 chain x (100+250) iterations")
         cd10.close()
         extra["noise_genotyping_samples10"] = rec10n
+        # (1c) the noise driver of the default mode (estimateNoise, InferenceEngine.cpp:135-276: 20 chains x 350 iterations on a random 100 000-variant subset of the
+        # unit's single-cluster groups, every iteration = sweep + noise counts + one exact host draw per sample): iterations per second at chr20 size.  A chain is
+        # ONE resident launch (gibbs_chain_kernel + the pinned mailbox); the next chain's sampler is built from the device-resident unit by a helper thread.
+        def estimate_noise_leg(S_, chains_):
+            flat_ = synth.make_mixture(180_000, S_, seed=2020 + S_, fractions={"A": 0.92, "B": 0.08})
+            flat_["group_index"] = np.arange(flat_["num_groups"], dtype=np.uint32)
+            cd_ = count_model.CountDistribution(S_, prior=(1.0, 0.01), seed=42)
+            for s_ in range(S_):
+                cd_.set_genomic(s_, 15.0, 30.0)
+            eng_ = InferenceEngine(ctx, 42, chains=chains_)
+            tn = time.perf_counter()
+            eng_.estimate_noise(cd_, flat_)
+            dt_ = time.perf_counter() - tn
+            cd_.close()
+            return {"groups": int(flat_["num_groups"]), "mixture": flat_["mixture"], "chains": chains_, "iterations": chains_ * 350, "seconds": dt_,
+                    "iterations_per_sec": chains_ * 350 / dt_, "ms_per_iteration": dt_ / (chains_ * 350) * 1e3}
+
+        extra["estimate_noise"] = {"workload": "estimateNoise on a chr20-sized unit (180 000 groups: two-haplotype and ten-candidate single clusters; a random 100 000-variant subset "
+                                               "per chain), wall-clock of the whole driver call: unit upload, sampler constructions, 350 iterations per chain",
+                                   "S1": estimate_noise_leg(1, 20), "S3": estimate_noise_leg(3, 20), "S10": estimate_noise_leg(10, 6)}
         # (2) k-mer matching against sub-filters of BASELINE configs[3] size: a ThreadedKmerBloom of 10^9 path k-mers (~37 KB per sub-filter,
         # 2.4 GB) — the LDS-staged probe at the other end of its range
         big = lib.Bloom.create(ctx, 1_000_000_000, 1e-4, K, threaded=True)

@@ -292,7 +292,7 @@ def test_noise_drivers_match_oracle(gpu_ctx, oracle, tmp_path):
     assert exact == flat["num_clusters"]
 
 
-@pytest.mark.parametrize("S,parts,mode", [(3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), "hybrid"), (3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), "all"),
+@pytest.mark.parametrize("S,parts,mode", [(3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1)), "hybrid"), (3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), "all"),
                                           (3, (("A", 150, 6), ("B", 40, 3), ("C", 6, 1), ("D", 3, 1)), "lds_cap"), (1, (("A", 200, 8), ("B", 20, 2)), "hybrid"),
                                           (10, (("A", 70, 4), ("B", 12, 2)), "hybrid")])
 def test_resident_noise_chain_equals_launch_per_iteration(gpu_ctx, oracle, monkeypatch, S, parts, mode):
