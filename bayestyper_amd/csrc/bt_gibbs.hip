@@ -1154,7 +1154,28 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         // 21.3 s at 64 / 64 before the copies worked in teams).  Four per wavefront; single clusters with 6..15 candidates sixteen.
         // `relax` (the batch does not fit the free HBM) doubles both.
         uint32_t width_x = kMinTileWidth, width_y = 16;   // (r02, after the copies' teams: 10.2 s at 4 / 16 against 10.6 s at 8 / 16 and 11.4 s at 8 / 32)
-        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) width_y = 8;   // (a noise chain's iteration waits for its slowest tile: 150 us at 16 groups per tile, eight copies share the table fill)
+        // The sampler of a noise driver (noise_seeding): a chain's iteration waits for its slowest tile (150 us at 16 groups per tile, 100 at 8: eight copies
+        // share the table fill) — as long as the narrower tiles do not push the tile count over what can be resident together (seven wavefronts of the resident
+        // launch per CU is what its LDS charge leaves at ten samples): the widest level whose tile count fits is taken (below).
+        const bool noise_widths = params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS");
+        uint32_t width_z3 = LANES;
+        if (noise_widths) {
+            auto count_tiles = [&](uint32_t wy, uint32_t wz3) {   // tiles of the single-cluster part of the batch at these widths (X tiles: as below, at most G / 4)
+                uint64_t n = 0, ge6 = 0, ge4 = 0, ge3 = 0;
+                for (uint32_t i = n_x; i < G; ++i) {
+                    ge6 += shapes[i].Hmax >= 6;
+                    ge4 += shapes[i].Hmax >= 4;
+                    ge3 += shapes[i].Hmax >= 3;
+                }
+                n = (ge4 + wy - 1) / wy + (ge3 - ge4 + wz3 - 1) / wz3 + (G - n_x - ge3 + LANES - 1) / LANES + (n_x + kMinTileWidth - 1) / kMinTileWidth;
+                (void)ge6;
+                return n;
+            };
+            const uint64_t room = (uint64_t)7 * ctx->num_cu;
+            if (count_tiles(8, 32) <= room) width_y = 8, width_z3 = 32;
+            else if (count_tiles(16, 32) <= room) width_y = 16, width_z3 = 32;
+            else width_y = 16, width_z3 = LANES;
+        }
         width_x = std::min<uint32_t>(LANES, width_x << relax);
         width_y = std::min<uint32_t>(LANES, width_y << relax);
         if (const char *e = getenv("BT_GIBBS_TAIL_WIDTH")) {
@@ -1197,7 +1218,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         // are both (36 - 44 KB of LDS; 190 - 260 us per iteration with their hot arrays pushed out to HBM against 75 us of the others): they get 16 groups
         // per wavefront (four copies share the table fills), like the clusters with 6..15 candidates above.
         uint32_t n_z = n_y, n_z3 = n_y;
-        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) {
+        if (noise_widths) {
             while (n_z < G && shapes[n_z].Hmax >= 4) ++n_z;
             n_z3 = n_z;
             while (n_z3 < G && shapes[n_z3].Hmax >= 3) ++n_z3;   // three candidates: 29 KB at 64 groups per tile, half of that at 32
@@ -1208,7 +1229,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         }
         while (at < n_z3) {
             tile_start.push_back(at);
-            at += std::min<uint32_t>(32u, n_z3 - at);
+            at += std::min<uint32_t>(width_z3, n_z3 - at);
         }
         while (at < G) {
             tile_start.push_back(at);
@@ -1409,6 +1430,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         d.ring_cap[0] = 8;
         while (d.ring_cap[0] < 2 * S + 3 && d.ring_cap[0] < 64) d.ring_cap[0] *= 2;
         d.ring_cap[1] = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 ? 32 : 16;   // (two-haplotype clusters: the LDS block is small, fewer refills in the middle of a visit)
+        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) d.ring_cap[1] = 16;   // (a noise sampler's LDS block decides how many tiles its resident chain can hold: 4 KB less per two-haplotype tile)
         if (const char *e = getenv("BT_GIBBS_RING0")) d.ring_cap[0] = (uint32_t)atoi(e);
         if (const char *e = getenv("BT_GIBBS_RING1")) d.ring_cap[1] = (uint32_t)atoi(e);
         d.ring_len = d.ring_cap[0] + d.ring_cap[1] + 2 * MT_RING_HDR;
