@@ -532,7 +532,14 @@ struct bt_gibbs {
         uint8_t *d_sync = nullptr;        // device: [S*256] u64 histogram | arrived | abort | table_seq copies
         NoiseChainCtl *d_ctl = nullptr;
         NoiseChainCtl ctl{};
+        HelpItem *d_help_items = nullptr;       // the help phase (bt_noise_help.hpp): every (tile, lane, vertex) with a large table
+        uint32_t *d_help_words = nullptr;       // [0] the unit counter, [64 ..) units finished per tile
+        uint32_t *d_tile_units = nullptr;
+        uint32_t help_units = 0;
+        bool help_built = false;
+        uint32_t *h_phase = nullptr;            // BT_NOISE_CHAIN_DEBUG_FLAGS & 2: where every workgroup is (pinned)
         unsigned long long *d_busy = nullptr;   // BT_NOISE_CHAIN_PROF: per tile, the ticks its workgroup worked (the rest of a chain it waited for the others / the host)
+        uint32_t num_wgs = 0;   // tiles + helpers
         bool active = false, launched = false;
         uint32_t n = 0, next = 0;
         uint32_t it_begin = 0, first_collect = 0, lds = 0;   // it_begin = 1: iteration 0 of the chain runs as ordinary launches (whole-GPU table refill), the resident launch starts with iteration 1
@@ -1855,6 +1862,9 @@ int bt_gibbs_destroy(bt_gibbs *g) {
     if (g->nc.d_sync) (void)hipFree(g->nc.d_sync);
     if (g->nc.d_ctl) (void)hipFree(g->nc.d_ctl);
     if (g->nc.d_busy) (void)hipFree(g->nc.d_busy);
+    if (g->nc.d_help_items) (void)hipFree(g->nc.d_help_items);
+    if (g->nc.d_help_words) (void)hipFree(g->nc.d_help_words);
+    if (g->nc.d_tile_units) (void)hipFree(g->nc.d_tile_units);
     for (auto &c : g->classes) {
         if (c.stream) {
             (void)hipStreamSynchronize(c.stream);
@@ -1951,8 +1961,8 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
 
 // ---- a chain of a noise driver as ONE resident launch (bt_noise_chain.hpp) ----
 namespace {
-constexpr uint32_t kResidentTableEntries = 16384;
-inline uint32_t nc_bins_bytes(uint32_t S) { return (S * NC_BINS + 4u) * 4u; }   // the bins, the flag word, (aligned) the profiling time stamp
+constexpr uint32_t kResidentTableEntries = 1u << 21;
+inline uint32_t nc_bins_bytes(uint32_t S) { return (S * NC_BINS + 8u + NC_HELP_MAXH / 2u) * 4u; }   // the bins, the flag word, (aligned) the profiling time stamp, the help phase's words + haplotype list
 struct NcMail {   // layout of the pinned mailbox
     uint64_t *hist;
     double *table;
@@ -1964,6 +1974,17 @@ inline NcMail nc_mail(bt_gibbs *g) {
     return NcMail{reinterpret_cast<uint64_t *>(b), reinterpret_cast<double *>(b + nh * 8), reinterpret_cast<uint32_t *>(b + nh * 16), reinterpret_cast<uint32_t *>(b + nh * 16 + 256)};
 }
 // where a chain that did not finish stood (after the launch has ended): for the error text
+static std::string nc_state_text(bt_gibbs *g, uint32_t it);
+static std::string nc_phase_text(bt_gibbs *g) {
+    if (!g->nc.h_phase) return "";
+    std::string t = " phases:";
+    for (uint32_t i = 0; i < g->ntiles * 64 && i < 128; ++i) {
+        char b[32];
+        snprintf(b, sizeof b, " %u:%x", i, g->nc.h_phase[i]);
+        t += b;
+    }
+    return t;
+}
 static std::string nc_state_text(bt_gibbs *g, uint32_t it) {
     uint32_t arrived = 0, aborted = 0, seq = 0;
     const size_t nh = (size_t)g->S * 256;
@@ -1998,9 +2019,9 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     // start), which the whole GPU computes far faster than the tile's own lanes (nan_fill_kernel / ucache_prefill_kernel between launches) — so iteration 0 of
     // such a chain runs as ordinary launches and the resident launch starts with iteration 1, where the sweeps ask for the pairs of the few haplotypes left and
     // the tile invalidates its table itself (cache_clear's "dirty = 2").  BT_NOISE_CHAIN_WIDE=1: resident from iteration 0 on (tests).
-    // Above kResidentTableEntries entries per group the per-iteration refill wants the whole GPU as well (a 256-candidate cluster at thirty samples keeps some
-    // sixty haplotypes alive: 55 000 sums over the k-mer subset per iteration — 43 ms by the tile's own lanes, 6 ms with ucache_prefill_kernel between
-    // launches): such batches keep the launch-per-iteration path.
+    // The per-iteration refill of such tables is shared out among ALL workgroups of the chain (bt_noise_help.hpp: a 256-candidate cluster at thirty samples keeps
+    // some sixty haplotypes alive — 55 000 sums over the k-mer subset per iteration, 43 ms by the tile's own lanes).  Above kResidentTableEntries entries per
+    // group (the owner invalidates its table itself every iteration) a batch keeps the launch-per-iteration path.
     bool has_wide = false;
     uint32_t biggest = 0;
     for (const auto &c : g->classes)
@@ -2082,11 +2103,54 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
         k.S = g->S;
         k.lds_cap = lds_cap;
         k.timeout_ticks = (unsigned long long)(nc_timeout_seconds() * 1e3 * wall_khz);
+        // the help phase's work list: once per sampler
+        if (!g->nc.help_built) {
+            std::vector<HelpItem> items;
+            std::vector<uint32_t> units(g->ntiles, 0);
+            for (uint32_t gi = 0; gi < g->G; ++gi) {
+                const TileDesc &d = g->tiles[g->group_tile[gi]];
+                if (!(d.cache_mode == 0 && !d.simple && d.cache_entries > BT_UC_INVALIDATE_MIN && d.hoff[A_UCACHE] == NOHOT)) continue;   // (wide_table())
+                for (uint32_t v = 0; v < g->group_nvert[gi]; ++v) {
+                    items.push_back(HelpItem{g->group_tile[gi], g->group_lane[gi], v, 0u});
+                    units[g->group_tile[gi]] += g->S;
+                }
+            }
+            g->nc.help_units = getenv("BT_NOISE_CHAIN_NO_HELP") ? 0u : (uint32_t)std::min<uint64_t>((uint64_t)items.size() * g->S, 0x7FFFFFFFu);
+            if (g->nc.help_units) {
+                BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_help_items), items.size() * sizeof(HelpItem)));
+                BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_help_words), (64 + (size_t)g->ntiles) * 4));
+                BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_tile_units), (size_t)g->ntiles * 4));
+                BT_HIP(hipMemcpyAsync(g->nc.d_help_items, items.data(), items.size() * sizeof(HelpItem), hipMemcpyHostToDevice, st));
+                BT_HIP(hipMemcpyAsync(g->nc.d_tile_units, units.data(), (size_t)g->ntiles * 4, hipMemcpyHostToDevice, st));
+                BT_HIP(hipStreamSynchronize(st));
+            }
+            g->nc.help_built = true;
+        }
+        k.help_items = g->nc.d_help_items;
+        k.help_units = g->nc.help_units;
+        k.help_next = g->nc.d_help_words;
+        k.help_done = g->nc.d_help_words ? g->nc.d_help_words + 64 : nullptr;
+        k.tile_units = g->nc.d_tile_units;
+        k.num_tiles = g->ntiles;
+        {   // helpers (gibbs_chain_kernel): top the launch up to what can be resident when there is help to give
+            const uint64_t room = (uint64_t)(fits * occ);
+            uint32_t helpers = g->nc.help_units && room > g->ntiles && !getenv("BT_NOISE_CHAIN_NO_HELPERS") ? (uint32_t)std::min<uint64_t>(room - g->ntiles, (uint64_t)g->nc.help_units) : 0u;
+            if (const char *e = getenv("BT_NOISE_CHAIN_HELPERS")) helpers = std::min<uint32_t>(helpers, (uint32_t)atoi(e));
+            g->nc.num_wgs = g->ntiles + helpers;
+            k.total_wgs = g->nc.num_wgs;
+        }
+        if (g->nc.help_units) BT_HIP(hipMemsetAsync(g->nc.d_help_words, 0, (64 + (size_t)g->ntiles) * 4, st));
+        k.h_phase = nullptr;
+        if (getenv("BT_NOISE_CHAIN_DEBUG_FLAGS") && (atoi(getenv("BT_NOISE_CHAIN_DEBUG_FLAGS")) & 2)) {
+            if (!g->nc.h_phase) BT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->nc.h_phase), ((size_t)g->ntiles + 16384) * 256, hipHostMallocCoherent | hipHostMallocMapped));
+            std::memset(g->nc.h_phase, 0, ((size_t)g->ntiles + 16384) * 256);
+            k.h_phase = g->nc.h_phase;
+        }
         k.busy = nullptr;
         k.debug_flags = getenv("BT_NOISE_CHAIN_DEBUG_FLAGS") ? (uint32_t)atoi(getenv("BT_NOISE_CHAIN_DEBUG_FLAGS")) : 0u;
         if (getenv("BT_NOISE_CHAIN_PROF")) {
-            if (!g->nc.d_busy) BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_busy), (size_t)g->ntiles * 8));
-            BT_HIP(hipMemsetAsync(g->nc.d_busy, 0, (size_t)g->ntiles * 8, st));
+            if (!g->nc.d_busy) BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_busy), ((size_t)g->ntiles + 16384) * 8));
+            BT_HIP(hipMemsetAsync(g->nc.d_busy, 0, ((size_t)g->ntiles + 16384) * 8, st));
             k.busy = g->nc.d_busy;
         }
     }
@@ -2100,7 +2164,7 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     BT_HIP(prepare_gibbs_chain_kernel((int)kHotBudget));
     if (it_begin == 0) {
         TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
-        BT_HIP(launch_gibbs_chain_kernel(g->ntiles, lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
+        BT_HIP(launch_gibbs_chain_kernel(g->nc.num_wgs, lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
         g->prefill_armed = false;
         g->nc.launched = true;
     }
@@ -2145,7 +2209,7 @@ int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hi
                     BT_CHECK_LAUNCH();
                 }
         TraceCfg tr{g->trace_sweeps, g->d_trace_counter, g->d_trace};
-        BT_HIP(launch_gibbs_chain_kernel(g->ntiles, g->nc.lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
+        BT_HIP(launch_gibbs_chain_kernel(g->nc.num_wgs, g->nc.lds, st, g->d_tiles, g->d_pool, g->d_params, g->nc.d_ctl, tr));
         g->prefill_armed = false;
         g->nc.launched = true;
     } else if (it > 0) {   // the table of this iteration's sweep: the workgroup that published histogram `it` is waiting for it
@@ -2163,6 +2227,7 @@ int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hi
         v = nc_load(mail.hist_seq);
         if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
             nc_store(mail.table_seq, NC_ABORT);
+            if (g->nc.h_phase) fprintf(stderr, "bt_gibbs_noise_chain_step: deadline passed at iteration %u;%s\n", it, nc_phase_text(g).c_str());
             (void)bt_gibbs_noise_chain_end(g);
             return fail("bt_gibbs_noise_chain_step: no histogram from the device within the deadline (BT_NOISE_CHAIN_TIMEOUT_S)" + nc_state_text(g, it));
         }

@@ -17,6 +17,21 @@ using namespace bt;
 __global__ __launch_bounds__(LANES, 2) void gibbs_chain_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg,
                                                                 const NoiseChainCtl *__restrict__ ctl, TraceCfg tr) {
     unsigned long long *arg = reinterpret_cast<unsigned long long *>(const_cast<NoiseChainCtl *>(ctl));
+    if (blockIdx.x >= ctl->num_tiles) {
+        // A workgroup without a tile: the batch has large tables whose per-iteration refill is shared out among the workgroups of the chain (bt_noise_help.hpp),
+        // but few tiles — a 2 000-group batch at thirty samples is 70 tiles, 70 wavefronts for what ucache_prefill_kernel spreads over the whole GPU between
+        // ordinary launches — so the launch is topped up with helpers: they wait for every table, take work units until there are none, and arrive.
+        Env env{tiles, pool, Pg, nullptr, 0xFFFFFFFFu};
+        nc_begin(ctl);
+        for (uint32_t i = ctl->it_begin; i < ctl->n_iterations; ++i) {
+            if (i > ctl->it_begin) {
+                if (!nc_wait_table(ctl, i)) break;
+                noise_help(env, ctl);
+            }
+            if (!nc_iteration_end(ctl, i)) break;
+        }
+        return;
+    }
     if (((const TileDesc BT_CAS *)tiles)[blockIdx.x].simple) gibbs_body<true>(tiles, pool, Pg, OP_NOISE_CHAIN, 0u, 0u, arg, tr, nullptr);
     else gibbs_body<false>(tiles, pool, Pg, OP_NOISE_CHAIN, 0u, 0u, arg, tr, nullptr);
 }

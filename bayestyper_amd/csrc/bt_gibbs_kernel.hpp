@@ -4,6 +4,7 @@
 #pragma once
 #include "bt_gibbs_tile.hpp"
 #include "bt_noise_chain.hpp"
+#include "bt_noise_help.hpp"
 #include "bt_gibbs_simple.hpp"
 
 namespace bt {
@@ -199,8 +200,13 @@ __device__ BT_NOINLINE void noise_tally_group(Env env, uint32_t nvert, const Noi
             }
         }
         if (t.part == 0) cache_clear(c, P, false, false);   // (the other copies read nothing this touches before the next sweep)
+        if (nc->help_units && wide_table(*t.d)) {   // the next sweep's sums are computed by every workgroup of the chain (bt_noise_help.hpp)
+            if (t.copies > 1u) copies_sync();
+            noise_help_publish(t, c);
+        }
     }
     if (t.copies > 1u) copies_sync();
+    if (nc->help_units && wide_table(*t.d)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the invalidated tables and the published state, before the arrival
 }
 
 struct TraceRow {
@@ -292,11 +298,21 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
             } else {
                 const uint32_t i0 = is_nc ? nc->it_begin : 0u;
                 for (uint32_t i = i0; i < n_burn + n_collect; ++i) {
-                    if (is_nc && i > i0 && !nc_wait_table(nc, i)) break;
+                    if (is_nc && i > i0) {
+                        nc_phase(nc, 0x10000000u | i);
+                        if (!nc_wait_table(nc, i)) break;
+                        if (nc->help_units) {
+                            noise_help(env, nc);
+                            if (!noise_help_wait(nc, tile, i)) break;
+                        }
+                    }
+                    if (is_nc) nc_phase(nc, 0x40000000u | i);
                     const TraceRow r = trace_row_for(t, P, tr, tile);
                     group_sweep(env, t, P, i >= n_burn, nvert, nsrc, r.row, r.on);
                     if (is_nc) {
+                        nc_phase(nc, 0x50000000u | i);
                         noise_tally_group(env, nvert, nc);
+                        nc_phase(nc, 0x60000000u | i);
                         if (!nc_iteration_end(nc, i)) break;
                     }
                 }

@@ -431,6 +431,7 @@ __device__ inline void simple_sweeps(const Env &env, const Tile &t, const GParam
         const bool collect = sweep >= n_burn;
         if (nc && sweep > sweep0) {
             if (!nc_wait_table(nc, sweep)) break;
+            if (nc->help_units) noise_help(env, nc);   // (the other tiles' large tables: bt_noise_help.hpp)
             simple_reweight(env, blk_off);
         }
         // ---- trace row of this sweep ----

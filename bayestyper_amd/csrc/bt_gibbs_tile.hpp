@@ -973,7 +973,7 @@ __device__ inline double unique_log_prob(const Vx &c, const GParams BT_CAS &P, u
 // read once per k-mer, the candidates' multiplicity rows and table lookups are independent loads — instead of one pass per candidate.
 // Every sum still runs in subset order, so the values are those of unique_log_prob; they are stored in the table the same way.
 __device__ inline void unique_log_prob_block(const Vx &c, const GParams BT_CAS &P, uint32_t s, const uint16_t (&ha)[EVB], const uint16_t (&hb)[EVB], const bool (&need)[EVB],
-                                             uint32_t nsub_u, double (&out)[EVB]) {
+                                             uint32_t nsub_u, double (&out)[EVB], bool store = true) {
     const TileDesc BT_CAS &d = c.d();
     const uint32_t Hm = d.Hm, S = P.S;
     const uint8_t gender = P.gender[s];
@@ -1025,7 +1025,7 @@ __device__ inline void unique_log_prob_block(const Vx &c, const GParams BT_CAS &
 #pragma unroll
     for (uint32_t q = 0; q < EVB; ++q) {
         out[q] = acc[q];
-        if (!need[q]) continue;
+        if (!need[q] || !store) continue;
         const uint32_t idx = dip_index(c, ha[q], hb[q]);
         if (d.cache_mode == 0) uc[(uint32_t)s * d.Dcm + idx] = acc[q];
         else if (d.cache_mode == 1) {

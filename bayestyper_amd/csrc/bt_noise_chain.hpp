@@ -47,8 +47,16 @@ struct NoiseChainCtl {   // device memory, one per launch class (the pointers ar
     uint32_t lds_cap;                  // tiles whose hot arrays need more LDS than this keep them in HBM for the chain
     unsigned long long timeout_ticks;  // wall_clock64() ticks (100 MHz) a single wait may last
     uint32_t debug_flags;
+    // the help phase (bt_noise_help.hpp): work units = help_items x S, taken off help_next (reset by the workgroup that hands a table over), counted per tile in help_done
+    const void *help_items;
+    uint32_t *help_next, *help_done;
+    const uint32_t *tile_units;        // per tile: units of one iteration (0: no large table)
+    uint32_t help_units;
+    uint32_t num_tiles;                // workgroups [num_tiles, total_wgs) of the launch have no tile: they only take part in the help phase
+
     uint32_t it_begin;                 // first iteration of the chain that runs in the resident launch (1: iteration 0 ran as ordinary launches, bt_gibbs_noise_chain_step)
     //        // experiments (BT_NOISE_CHAIN_DEBUG_FLAGS): 1 = no acquire after the wait (wrong results: timing only)
+    uint32_t *h_phase;                 // debugging (BT_NOISE_CHAIN_DEBUG_FLAGS & 2): per workgroup, where it is (host-visible), or null
     unsigned long long *busy;          // profiling (BT_NOISE_CHAIN_PROF): per workgroup, ticks between the end of its wait and its arrival, summed over the iterations; or null
 };
 
@@ -80,6 +88,10 @@ __device__ inline NcLanes nc_lanes() {
     r.count = (uint32_t)__popcll(m);
     r.rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
     return r;
+}
+
+__device__ inline void nc_phase(const NoiseChainCtl *ctl, uint32_t code) {
+    if (ctl->h_phase) __hip_atomic_store(&ctl->h_phase[blockIdx.x * 64u + (threadIdx.x & 63u)], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // one noise count of sample s
@@ -124,6 +136,7 @@ __device__ static __noinline__ bool nc_wait_table(const NoiseChainCtl *ctl, uint
         *flag = v == NC_ABORT ? 1u : 0u;
         if (ctl->busy) *(unsigned long long NC_LAS *)(bins + ((ctl->S * NC_BINS + 2u) & ~1u)) = (unsigned long long)wall_clock64();
     }
+    __builtin_amdgcn_wave_barrier();   // (keeps a one-wavefront workgroup's lanes together where its s_barrier is dropped, see bt_noise_help.hpp)
     __syncthreads();
     const bool ok = *flag == 0;
     if (!(ctl->debug_flags & 1u)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the table (and nothing stale of it in this CU's L1 / this XCD's L2)
@@ -155,6 +168,7 @@ __device__ static __noinline__ bool nc_iteration_end(const NoiseChainCtl *ctl, u
         const uint32_t old = __hip_atomic_fetch_add(ctl->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *flag = old == (it + 1u - ctl->it_begin) * ctl->total_wgs - 1u ? 1u : 0u;
     }
+    __builtin_amdgcn_wave_barrier();   // (keeps a one-wavefront workgroup's lanes together where its s_barrier is dropped, see bt_noise_help.hpp)
     __syncthreads();
     const bool last = *flag != 0;
     __syncthreads();
@@ -183,6 +197,7 @@ __device__ static __noinline__ bool nc_iteration_end(const NoiseChainCtl *ctl, u
         if (v == NC_ABORT) nc_abort(ctl);
         *flag = v == NC_ABORT ? 1u : 0u;
     }
+    __builtin_amdgcn_wave_barrier();   // (keeps a one-wavefront workgroup's lanes together where its s_barrier is dropped, see bt_noise_help.hpp)
     __syncthreads();
     const bool ok = *flag == 0;
     __syncthreads();
@@ -190,9 +205,11 @@ __device__ static __noinline__ bool nc_iteration_end(const NoiseChainCtl *ctl, u
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: the table behind the sequence word
     if (L.on)
         for (uint32_t i = L.rank; i < nb; i += L.count) {
-            const double v = __hip_atomic_load(&ctl->h_table[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&ctl->lut_n[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through
+            // (as 64-bit integers: what an atomic access to a double compiles to is the compiler's choice)
+            const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(&ctl->h_table[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(&ctl->lut_n[i]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through
         }
+    if (threadIdx.x == 0 && ctl->help_units) __hip_atomic_store(ctl->help_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     nc_wait_vm();      // acknowledged: the table is where every XCD reads from
     __syncthreads();
     if (L.on)
