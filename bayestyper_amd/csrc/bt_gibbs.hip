@@ -1137,6 +1137,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
     std::vector<TilePlan> plans;
     uint64_t pool = 0;
     uint32_t ntiles = 0;
+    uint32_t noise_level = 0;
     auto plan_tiles = [&](uint32_t relax) {
     tile_start.clear();
     pool = 0;
@@ -1166,21 +1167,9 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         // launch per CU is what its LDS charge leaves at ten samples): the widest level whose tile count fits is taken (below).
         const bool noise_widths = params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS");
         uint32_t width_z3 = LANES;
-        if (noise_widths) {
-            auto count_tiles = [&](uint32_t wy, uint32_t wz3) {   // tiles of the single-cluster part of the batch at these widths (X tiles: as below, at most G / 4)
-                uint64_t n = 0, ge6 = 0, ge4 = 0, ge3 = 0;
-                for (uint32_t i = n_x; i < G; ++i) {
-                    ge6 += shapes[i].Hmax >= 6;
-                    ge4 += shapes[i].Hmax >= 4;
-                    ge3 += shapes[i].Hmax >= 3;
-                }
-                n = (ge4 + wy - 1) / wy + (ge3 - ge4 + wz3 - 1) / wz3 + (G - n_x - ge3 + LANES - 1) / LANES + (n_x + kMinTileWidth - 1) / kMinTileWidth;
-                (void)ge6;
-                return n;
-            };
-            const uint64_t room = (uint64_t)7 * ctx->num_cu;
-            if (count_tiles(8, 32) <= room) width_y = 8, width_z3 = 32;
-            else if (count_tiles(16, 32) <= room) width_y = 16, width_z3 = 32;
+        if (noise_widths) {   // noise_level: 0 = the narrowest widths; raised by the caller of plan_tiles when the tile count does not fit a resident chain
+            if (noise_level == 0) width_y = 8, width_z3 = 32;
+            else if (noise_level == 1) width_y = 16, width_z3 = 32;
             else width_y = 16, width_z3 = LANES;
         }
         width_x = std::min<uint32_t>(LANES, width_x << relax);
@@ -1437,7 +1426,10 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         d.ring_cap[0] = 8;
         while (d.ring_cap[0] < 2 * S + 3 && d.ring_cap[0] < 64) d.ring_cap[0] *= 2;
         d.ring_cap[1] = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 ? 32 : 16;   // (two-haplotype clusters: the LDS block is small, fewer refills in the middle of a visit)
-        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) d.ring_cap[1] = 16;   // (a noise sampler's LDS block decides how many tiles its resident chain can hold: 4 KB less per two-haplotype tile)
+        if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) {   // (a noise sampler's LDS block decides how many tiles its resident chain can hold)
+            d.ring_cap[1] = 16;                                                  // 4 KB less per two-haplotype tile
+            if (d.ring_cap[0] > 16) d.ring_cap[0] = 16;                          // seven samples and more: the diplotype draws of a visit top the ring up on the way (another 4 KB)
+        }
         if (const char *e = getenv("BT_GIBBS_RING0")) d.ring_cap[0] = (uint32_t)atoi(e);
         if (const char *e = getenv("BT_GIBBS_RING1")) d.ring_cap[1] = (uint32_t)atoi(e);
         d.ring_len = d.ring_cap[0] + d.ring_cap[1] + 2 * MT_RING_HDR;
@@ -1536,6 +1528,18 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         for (uint32_t relax = 0;; ++relax) {
             plan_tiles(relax);
             if (relax >= 4 || free_b == 0 || pool + 256 <= (uint64_t)(0.92 * (double)free_b)) break;
+        }
+        // a noise sampler: can its chain be one resident launch?  Every workgroup of that launch is charged the LDS of the two-haplotype tiles (the bulk; hungrier
+        // tiles go without) + the chain's bins, at most eight 256-register wavefronts fit a CU: with more tiles than that the plan is made again with wider tiles
+        // for the few-candidate clusters (fewer tiles; an iteration then waits longer for its slowest tile, but it is not a launch per iteration).
+        while (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS") && noise_level < 2) {
+            uint32_t simple_need = 0;
+            for (uint32_t ti = 0; ti < ntiles; ++ti)
+                if (plans[ti].d.simple) simple_need = std::max(simple_need, tile_lds_bytes(plans[ti].d));
+            const uint64_t per_cu = std::min<uint64_t>(8, 163840 / (((uint64_t)simple_need + 15) / 16 * 16 + (S * NC_BINS + 8u + NC_HELP_MAXH / 2u) * 4u));
+            if ((uint64_t)ntiles <= per_cu * ctx->num_cu) break;
+            ++noise_level;
+            plan_tiles(0);
         }
     }
     lap("shape sort + tile plan");
@@ -2109,7 +2113,7 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
             std::vector<uint32_t> units(g->ntiles, 0);
             for (uint32_t gi = 0; gi < g->G; ++gi) {
                 const TileDesc &d = g->tiles[g->group_tile[gi]];
-                if (!(d.cache_mode == 0 && !d.simple && d.cache_entries > BT_UC_INVALIDATE_MIN && d.hoff[A_UCACHE] == NOHOT)) continue;   // (wide_table())
+                if (!help_table(d.cache_mode, d.simple, d.cache_entries, d.hoff[A_UCACHE], d.Dcm)) continue;
                 for (uint32_t v = 0; v < g->group_nvert[gi]; ++v) {
                     items.push_back(HelpItem{g->group_tile[gi], g->group_lane[gi], v, 0u});
                     units[g->group_tile[gi]] += g->S;

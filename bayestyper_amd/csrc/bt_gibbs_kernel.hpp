@@ -200,13 +200,13 @@ __device__ BT_NOINLINE void noise_tally_group(Env env, uint32_t nvert, const Noi
             }
         }
         if (t.part == 0) cache_clear(c, P, false, false);   // (the other copies read nothing this touches before the next sweep)
-        if (nc->help_units && wide_table(*t.d)) {   // the next sweep's sums are computed by every workgroup of the chain (bt_noise_help.hpp)
+        if (nc->help_units && help_table(t.d->cache_mode, t.d->simple, t.d->cache_entries, t.d->hoff[A_UCACHE], t.d->Dcm)) {   // the next sweep's sums are computed by every workgroup of the chain (bt_noise_help.hpp)
             if (t.copies > 1u) copies_sync();
             noise_help_publish(t, c);
         }
     }
     if (t.copies > 1u) copies_sync();
-    if (nc->help_units && wide_table(*t.d)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the invalidated tables and the published state, before the arrival
+    if (nc->help_units && help_table(t.d->cache_mode, t.d->simple, t.d->cache_entries, t.d->hoff[A_UCACHE], t.d->Dcm)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the invalidated tables and the published state, before the arrival
 }
 
 struct TraceRow {

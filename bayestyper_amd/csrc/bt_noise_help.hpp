@@ -17,6 +17,13 @@
 
 namespace bt {
 
+// Which tables are worth sharing out: large dense tables (wide_table) of clusters with seven candidates and more (36 and more pairs per sample).  A work unit
+// costs a few microseconds whatever it computes (two device-wide atomics, the owner's state scalars and non-zero flags from HBM), and at ten samples every
+// three-candidate cluster has a "large" table (90 entries): 400 000 units per iteration of a chr20-sized chain kept every workgroup busy for 1.6 ms.
+constexpr uint32_t NC_HELP_MIN_D = 32;
+__host__ __device__ inline bool help_table(uint32_t cache_mode, uint32_t simple, uint32_t cache_entries, uint32_t ucache_hoff, uint32_t Dcm) {
+    return cache_mode == 0 && !simple && cache_entries > BT_UC_INVALIDATE_MIN && ucache_hoff == NOHOT && Dcm >= NC_HELP_MIN_D;
+}
 struct HelpItem {
     uint32_t tile, lane, v, pad;
 };

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <sys/resource.h>
 #include <string>
 #include <utility>
 #include <vector>
@@ -32,6 +33,8 @@ class StageTimes {
         std::lock_guard<std::mutex> lock(mu);
         std::fprintf(stderr, "\n## stage times: %s\n", title);
         for (auto &r : rows) std::fprintf(stderr, "%-52s %10.3f s\n", r.first.c_str(), r.second);
+        struct rusage ru;
+        if (getrusage(RUSAGE_SELF, &ru) == 0) std::fprintf(stderr, "%-52s %10.3f GB\n", "peak host memory (resident set)", ru.ru_maxrss / 1048576.0);
         rows.clear();
     }
 

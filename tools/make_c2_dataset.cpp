@@ -9,7 +9,9 @@
 //               plus error_kmers random 55-mers with count 1; KMC1 layout (prefix length 7, one counter byte: 13-byte records)
 //
 // build: g++ -O2 -std=c++17 -fopenmp tools/make_c2_dataset.cpp -o scratch/make_c2_dataset
-// usage: make_c2_dataset <out dir> [genome_len 64000000] [num_variants 200000] [num_samples 1] [error_kmers 140000000]
+//               sv_per_mille > 0: that share of the candidates are deletions of 300..3000 nt; the candidates that follow inside a deleted stretch are nested in it
+//               (a haplotype that carries the deletion carries none of them): groups of several variant clusters, as structural variants make them
+// usage: make_c2_dataset <out dir> [genome_len 64000000] [num_variants 200000] [num_samples 1] [error_kmers 140000000] [sv_per_mille 0]
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -43,7 +45,7 @@ static void kmers_of(const std::vector<uint8_t> &seq, std::vector<u128> *out) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: make_c2_dataset <out dir> [genome_len] [num_variants] [num_samples] [error_kmers]\n");
+        std::fprintf(stderr, "usage: make_c2_dataset <out dir> [genome_len] [num_variants] [num_samples] [error_kmers] [sv_per_mille]\n");
         return 2;
     }
     const std::string dir = argv[1];
@@ -51,6 +53,7 @@ int main(int argc, char **argv) {
     const uint32_t NV = argc > 3 ? (uint32_t)atoi(argv[3]) : 200000u;
     const unsigned NS = argc > 4 ? (unsigned)atoi(argv[4]) : 1u;
     const uint64_t NE = argc > 5 ? strtoull(argv[5], nullptr, 10) : 140000000ull;
+    const unsigned SV_PM = argc > 6 ? (unsigned)atoi(argv[6]) : 0u;
     std::mt19937_64 rng(1);
     std::vector<uint8_t> genome(L);
     for (uint64_t i = 0; i < L; i += 32) {
@@ -81,9 +84,17 @@ int main(int argc, char **argv) {
             if (pos + 200 >= L) break;
             Variant v;
             v.pos = (uint32_t)pos;
-            const unsigned kind = (unsigned)(rng() % 10);
+            unsigned kind = (unsigned)(rng() % 10);
+            if (SV_PM && rng() % 1000 < SV_PM) kind = 10;
             std::string ref(1, "ACGT"[genome[pos]]), alt;
-            if (kind < 8) {   // SNV
+            if (kind == 10) {   // structural variant: a long deletion after the anchor nucleotide (the next candidates fall inside it)
+                const unsigned n = 300 + (unsigned)(rng() % 2701);
+                if (pos + n + 200 >= L) break;
+                v.ref_len = 1 + n;
+                v.alt = {genome[pos]};
+                for (unsigned j = 1; j <= n; j++) ref += "ACGT"[genome[pos + j]];
+                alt = ref.substr(0, 1);
+            } else if (kind < 8) {   // SNV
                 v.ref_len = 1;
                 v.alt = {(uint8_t)((genome[pos] + 1 + rng() % 3) % 4)};
                 alt = std::string(1, "ACGT"[v.alt[0]]);
@@ -123,6 +134,7 @@ int main(int argc, char **argv) {
             uint64_t at = 0;
             for (size_t i = 0; i < vars.size(); i++) {
                 if (!(copies[i] == 2 || (copies[i] == 1 && which[i] == h))) continue;
+                if (vars[i].pos < at) continue;   // inside a deletion this haplotype carries
                 hap.insert(hap.end(), genome.begin() + at, genome.begin() + vars[i].pos);
                 hap.insert(hap.end(), vars[i].alt.begin(), vars[i].alt.end());
                 at = (uint64_t)vars[i].pos + vars[i].ref_len;
