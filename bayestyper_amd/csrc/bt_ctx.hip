@@ -120,6 +120,10 @@ int bt_ctx_destroy(bt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->kmc_pin[b]) (void)hipHostFree(ctx->kmc_pin[b]);
+        if (ctx->kmc_dev[b]) (void)hipFree(ctx->kmc_dev[b]);
+    }
     delete ctx;
     return BT_OK;
 }

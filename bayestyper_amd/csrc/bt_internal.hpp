@@ -44,6 +44,10 @@ struct bt_ctx {
     // pinned staging arena of this context's small uploads (bt_gibbs.hip: staged_upload), reused from sampler to sampler
     uint8_t *pin = nullptr;
     size_t pin_bytes = 0, pin_used = 0;
+    // staging slots of the KMC scans that stream records from the host (bt_table.hip: bt_kmc_scan_run_host / _run_file): kept from scan to scan — a database
+    // per sample means a scan handle per sample, and 2 x 218 MB of pinned memory allocated and released for each of them
+    uint8_t *kmc_pin[2] = {nullptr, nullptr}, *kmc_dev[2] = {nullptr, nullptr};
+    size_t kmc_stage_bytes = 0;
 };
 
 struct bt_timer {

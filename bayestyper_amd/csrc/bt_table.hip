@@ -13,6 +13,8 @@
 #include "bt_internal.hpp"
 
 #include <algorithm>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -1585,14 +1587,24 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
 }
 
 static void free_host_staging(bt_kmc_scan *s) {
+    // the buffers go back to the context (the next sample's scan takes them); what the context held before — smaller ones — is released
+    const bool keep = s->h_pin[0] && s->h_pin[1] && s->d_stage[0] && s->d_stage[1] && s->stage_bytes >= s->ctx->kmc_stage_bytes;
     for (int b = 0; b < 2; ++b) {
-        if (s->h_pin[b]) (void)hipHostFree(s->h_pin[b]);
-        if (s->d_stage[b]) (void)hipFree(s->d_stage[b]);
+        if (keep) {
+            if (s->ctx->kmc_pin[b]) (void)hipHostFree(s->ctx->kmc_pin[b]);
+            if (s->ctx->kmc_dev[b]) (void)hipFree(s->ctx->kmc_dev[b]);
+            s->ctx->kmc_pin[b] = s->h_pin[b];
+            s->ctx->kmc_dev[b] = s->d_stage[b];
+        } else {
+            if (s->h_pin[b]) (void)hipHostFree(s->h_pin[b]);
+            if (s->d_stage[b]) (void)hipFree(s->d_stage[b]);
+        }
         if (s->copied[b]) (void)hipEventDestroy(s->copied[b]);
         if (s->scanned[b]) (void)hipEventDestroy(s->scanned[b]);
         s->h_pin[b] = s->d_stage[b] = nullptr;
         s->copied[b] = s->scanned[b] = nullptr;
     }
+    if (keep) s->ctx->kmc_stage_bytes = s->stage_bytes;
     if (s->d_host_hits) (void)hipFree(s->d_host_hits);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     s->d_host_hits = nullptr;
@@ -1617,9 +1629,55 @@ static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t bytes) {
     for (auto &th : pool) th.join();
 }
 
+// several threads pread() one range of a file into a (pinned) buffer: no page faults (a memory-mapped file costs one per 4 KB — or per fault-around window — of a
+// first pass), the kernel copies from the page cache or reads the device, each thread its own stripe
+static int parallel_pread(int fd, uint8_t *dst, uint64_t offset, size_t bytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t threads = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)(hw ? hw / 2 : 1), bytes >> 21}));
+    const size_t part = (bytes / threads + 4095) / 4096 * 4096;
+    std::vector<int> failed(threads, 0);
+    auto work = [&](size_t t) {
+        size_t lo = std::min(bytes, t * part);
+        const size_t hi = std::min(bytes, lo + part);
+        while (lo < hi) {
+            const ssize_t got = ::pread(fd, dst + lo, hi - lo, (off_t)(offset + lo));
+            if (got <= 0) {
+                failed[t] = 1;
+                return;
+            }
+            lo += (size_t)got;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    for (int f : failed)
+        if (f) return 1;
+    return 0;
+}
+
+static int kmc_scan_stream(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records, int fd, uint64_t file_offset, uint64_t first_record,
+                           uint64_t n, uint64_t chunk_records, uint64_t *h_hit_count);
+
 int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records, uint64_t first_record, uint64_t n,
                          uint64_t chunk_records, uint64_t *h_hit_count) {
     if (!s || !path_bloom || !table || !h_records) return fail("bt_kmc_scan_run_host: null argument");
+    return kmc_scan_stream(s, path_bloom, table, sample_idx, h_records, -1, 0, first_record, n, chunk_records, h_hit_count);
+}
+
+int bt_kmc_scan_run_file(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const char *suf_path, uint64_t payload_offset, uint64_t first_record, uint64_t n,
+                         uint64_t chunk_records, uint64_t *h_hit_count) {
+    if (!s || !path_bloom || !table || !suf_path) return fail("bt_kmc_scan_run_file: null argument");
+    const int fd = ::open(suf_path, O_RDONLY);
+    if (fd < 0) return fail(std::string("bt_kmc_scan_run_file: cannot open ") + suf_path);
+    const int rc = kmc_scan_stream(s, path_bloom, table, sample_idx, nullptr, fd, payload_offset + first_record * s->rec_size, first_record, n, chunk_records, h_hit_count);
+    ::close(fd);
+    return rc;
+}
+
+static int kmc_scan_stream(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records, int fd, uint64_t file_offset, uint64_t first_record,
+                           uint64_t n, uint64_t chunk_records, uint64_t *h_hit_count) {
     if (first_record + n > s->total) return fail("bt_kmc_scan_run_host: record range exceeds the database");
     if (n == 0) {
         if (h_hit_count) *h_hit_count = 0;
@@ -1634,9 +1692,16 @@ int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, 
     if (s->stage_bytes < chunk_bytes) {
         free_host_staging(s);
         e = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking);
+        const bool reuse = s->ctx->kmc_stage_bytes >= chunk_bytes && s->ctx->kmc_pin[0] && s->ctx->kmc_pin[1];   // the previous sample's scan left them with the context
         for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-            e = hipHostMalloc(reinterpret_cast<void **>(&s->h_pin[b]), chunk_bytes, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_stage[b]), chunk_bytes + 16);
+            if (reuse) {
+                s->h_pin[b] = s->ctx->kmc_pin[b];
+                s->d_stage[b] = s->ctx->kmc_dev[b];
+                s->ctx->kmc_pin[b] = s->ctx->kmc_dev[b] = nullptr;
+            } else {
+                e = hipHostMalloc(reinterpret_cast<void **>(&s->h_pin[b]), chunk_bytes, hipHostMallocDefault);
+                if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&s->d_stage[b]), chunk_bytes + 16);
+            }
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->copied[b], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s->scanned[b], hipEventDisableTiming);
         }
@@ -1645,7 +1710,8 @@ int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, 
             free_host_staging(s);
             return fail(std::string("bt_kmc_scan_run_host: staging buffers: ") + hipGetErrorString(e));
         }
-        s->stage_bytes = chunk_bytes;
+        s->stage_bytes = reuse ? s->ctx->kmc_stage_bytes : chunk_bytes;
+        if (reuse) s->ctx->kmc_stage_bytes = 0;
     }
     e = hipMemsetAsync(s->d_host_hits, 0, 8, s->ctx->stream);
     int rc = BT_OK;
@@ -1655,7 +1721,13 @@ int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, 
         const uint64_t m = std::min(chunk_records, n - done);
         if (i >= 2) e = hipEventSynchronize(s->copied[b]);   // the pinned buffer of this slot has been read by its previous copy
         if (e != hipSuccess) break;
-        parallel_copy(s->h_pin[b], h_records + done * rec, m * rec);
+        if (fd >= 0) {
+            if (parallel_pread(fd, s->h_pin[b], file_offset + done * rec, m * rec) != 0) {
+                rc = fail("bt_kmc_scan_run_file: reading the records failed");
+                break;
+            }
+        } else
+            parallel_copy(s->h_pin[b], h_records + done * rec, m * rec);
         if (i >= 2) e = hipStreamWaitEvent(s->copy_stream, s->scanned[b], 0);   // the device buffer of this slot has been scanned
         if (e == hipSuccess) e = hipMemcpyAsync(s->d_stage[b], s->h_pin[b], m * rec, hipMemcpyHostToDevice, s->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(s->copied[b], s->copy_stream);

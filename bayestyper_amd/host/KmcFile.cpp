@@ -1,5 +1,9 @@
 #include "KmcFile.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -70,6 +74,7 @@ KmcFile::KmcFile(const std::string &prefix) {
     lut[lut_entries] = total_kmers;
     // ---- .kmc_suf: "KMCS" | records | "KMCS" ----
     const std::string suf = prefix + ".kmc_suf";
+    suf_path = suf;
     const int fd = ::open(suf.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("cannot open " + suf);
     struct stat st;
@@ -102,14 +107,24 @@ uint64_t parseSampleKmers(bt_ctx *ctx, const KmcFile &db, bt_bloom *path_bloom, 
     if (num_records > db.total_kmers - first_record) num_records = db.total_kmers - first_record;
     if (num_records == 0) return 0;
     bt_kmc_scan *scan = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (bt_kmc_scan_create_bins(ctx, db.kmer_length, db.lut_prefix_length, db.counter_size, db.total_kmers, db.prefix_lut().data(), db.prefix_lut().size(), &scan) != BT_OK)
         throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
     bt_kmc_scan_set_count_range(scan, db.min_count, db.max_count);   // ReadNextKmer's counter filter (kmc_file.cpp:496-511)
     uint64_t hits = 0;
+    const auto t1 = std::chrono::steady_clock::now();
     // copies from the page cache (mmap) into pinned staging, H2D transfers and scan kernels of consecutive chunks overlap inside the library
     const uint64_t rec_bytes = (db.kmer_length - db.lut_prefix_length) / 4 + db.counter_size;
-    const int rc = bt_kmc_scan_run_host(scan, path_bloom, table, sample_idx, db.records() + first_record * rec_bytes, first_record, num_records, chunk_records, &hits);
+    // (the file is read with pread() by several threads straight into the pinned slots; BT_KMC_MMAP=1: copied out of the memory mapping instead)
+    const int rc = getenv("BT_KMC_MMAP") ? bt_kmc_scan_run_host(scan, path_bloom, table, sample_idx, db.records() + first_record * rec_bytes, first_record, num_records, chunk_records, &hits)
+                                         : bt_kmc_scan_run_file(scan, path_bloom, table, sample_idx, db.suffix_file().c_str(), 4, first_record, num_records, chunk_records, &hits);
+    const auto t2 = std::chrono::steady_clock::now();
     bt_kmc_scan_destroy(scan);
+    if (getenv("BT_STAGE_TIMES")) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+        fprintf(stderr, "  parse sample k-mers: scan set-up %.3f s, stream + scan %.3f s, release %.3f s\n", sec(t0, t1), sec(t1, t2), sec(t2, t3));
+    }
     if (rc != BT_OK) throw std::runtime_error(std::string("parseSampleKmers: ") + bt_last_error());
     return hits;
 }

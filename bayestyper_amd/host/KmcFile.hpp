@@ -24,9 +24,11 @@ class KmcFile {
     uint32_t record_size() const { return (kmer_length - lut_prefix_length) / 4 + counter_size; }
     const std::vector<uint64_t> &prefix_lut() const { return lut; }   // bins * 4^p + 1 entries (bins = 1 for KMC1), last = total_kmers
     const uint8_t *records() const { return payload; }                 // total_kmers * record_size() bytes
+    const std::string &suffix_file() const { return suf_path; }        // the .kmc_suf file: records() start 4 bytes into it
 
   private:
     std::vector<uint64_t> lut;
+    std::string suf_path;
     void *map = nullptr;
     size_t map_bytes = 0;
     const uint8_t *payload = nullptr;

@@ -1,4 +1,6 @@
 #include "KmerCounter.hpp"
+
+#include <chrono>
 #include "StageTimes.hpp"
 #include "Parallel.hpp"
 
@@ -427,9 +429,12 @@ void KmerCounter::parseSampleKmers(bt_table *table, bt_bloom *path_bloom, Comm *
         // rank r of w scans records [r * total / w, (r + 1) * total / w): a byte range of the .kmc_suf payload
         const uint64_t first = db.total_kmers / world * rank + std::min<uint64_t>(rank, db.total_kmers % world);
         const uint64_t count = db.total_kmers / world + (rank < db.total_kmers % world ? 1 : 0);
+        const auto t_scan = std::chrono::steady_clock::now();
         uint64_t hits = bthost::parseSampleKmers(ctx, db, path_bloom, table, (uint32_t)s, 1ull << 24, first, count);
+        const double scan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scan).count();
         if (comm) comm->allreduceHist(&hits, 1);
         std::cout << "[" << getLocalTime() << "] Parsed " << db.total_kmers << " kmers (" << hits << " passed the path kmer filter)" << std::endl;
+        if (getenv("BT_STAGE_TIMES")) std::cerr << "  parse sample k-mers: " << samples[s].name << " " << count << " records in " << scan_s << " s = " << (double)count / scan_s << " records/s" << std::endl;
     }
     if (!comm) return;
     // merge: a (k-mer, sample) count comes from ONE KMC record, i.e. from one rank; before the scans the replicas are identical and hold no

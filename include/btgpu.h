@@ -253,6 +253,11 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
  * chunk_records = records per transfer (0: default 2^23); the staging buffers are kept with the handle; *h_hit_count = number of Bloom hits. */
 int bt_kmc_scan_run_host(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const uint8_t *h_records,
                          uint64_t first_record, uint64_t n, uint64_t chunk_records, uint64_t *h_hit_count);
+/* the same from the database's .kmc_suf file: the records [first_record, first_record + n) at payload_offset (4: behind the "KMCS" marker) + first_record x record size
+ * are read by several threads with pread() straight into the pinned staging slots (the reference reads the file through CKMCFile's buffered reader,
+ * kmc_file.cpp:428-515, one producer thread: KmerCounter.cpp:469-505) — no memory mapping, no page fault per 4 KB of a first pass */
+int bt_kmc_scan_run_file(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint32_t sample_idx, const char *suf_path, uint64_t payload_offset,
+                         uint64_t first_record, uint64_t n, uint64_t chunk_records, uint64_t *h_hit_count);
 /* bayesTyperTools makeBloom (src/bayesTyperTools/MakeBloom.cpp:200-295): the k-mers of records [first_record, first_record + n)
  * are added to a sample's KmerBloom (created with bt_bloom_create(ctx, total_kmers, fpr, k, 0, ..), written with bt_bloom_save:
  * byte-identical .bloomMeta / .bloomData, insertion being an order-independent OR) */

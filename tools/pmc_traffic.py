@@ -1,24 +1,64 @@
 """HBM traffic per launch from the two PMC passes of the default bench command (tools/profile_round.sh) -> <dest>/<tag>_traffic.json, the
 file bench.py's roofline.traffic is filled from (matched by the hash of the device sources).
-usage: pmc_traffic.py <dir with <tag>_FETCH_SIZE_pmc.json / <tag>_WRITE_SIZE_pmc.json> <tag> <samples S of the pass>"""
+usage: pmc_traffic.py <dir with <tag>_FETCH_SIZE_pmc.json / <tag>_WRITE_SIZE_pmc.json> <tag> <samples S of the pass> [records per scan]
+
+KMC scan accounting (round 5, after the round-4 verdict):
+  * only the kernels a SCAN runs are counted — kmc_partition_kernel, kmc_probe_bucket_kernel, kmc_apply_kernel (and the direct kmc_scan_kernel<false> of small inputs);
+    kmc_scan_kernel<true> is the bench's set-up decode of the synthetic stream and belongs to no scan;
+  * bytes are reported per kernel;
+  * FETCH_SIZE on gfx950 reports half the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section) and is uncalibrated for other widths: the
+    partition kernel is the calibration — it reads every record of the stream exactly once (13 B per record, coalesced) — so its factor
+    (S scans x records x 13 B) / FETCH_SIZE is measured here (2.0 expected) and applied to that kernel's fetch; the other kernels' accesses (bucketed records re-read in
+    16-byte pieces, sub-filter words, table slots) and every WRITE_SIZE stay as counted, and the file says so."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 d, tag, S = sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 3
-tot = {"gibbs": {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, "kmc": {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}}
+R = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000_000
+REC = 13
+gibbs = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+kmc = {}   # kernel -> counter -> bytes
 detail = []
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in json.load(open(os.path.join(d, f"{tag}_{c}_pmc.json"))):
         k = r["kernel"]
-        grp = "gibbs" if "gibbs" in k else "kmc" if (k.startswith("kmc_") or k.startswith("rocprim")) else None
-        if grp is None or r["counter"] != c:
+        if r["counter"] != c:
             continue
-        tot[grp][c] += r["sum"] * 1024.0   # the counters are in KiB (MI355X_MICROARCH.md); no x2: most accesses here are narrow, not wide coalesced streams
-        detail.append({"kernel": k, "grid": r["grid"], "counter": c, "bytes": r["sum"] * 1024.0})
-out = {"source_hash": bench.source_hash(), "source_hash_gibbs": bench.source_hash("gibbs"), "source_hash_kmc": bench.source_hash("kmc"), "command": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-paths --no-pcie --no-extra (one rocprofv3 --pmc pass per counter)",
-       "gibbs_bytes_per_schedule": tot["gibbs"]["FETCH_SIZE"] + tot["gibbs"]["WRITE_SIZE"], "gibbs_fetch_bytes": tot["gibbs"]["FETCH_SIZE"], "gibbs_write_bytes": tot["gibbs"]["WRITE_SIZE"],
-       "kmc_bytes_per_scan": (tot["kmc"]["FETCH_SIZE"] + tot["kmc"]["WRITE_SIZE"]) / S, "kmc_fetch_bytes_per_scan": tot["kmc"]["FETCH_SIZE"] / S, "kmc_write_bytes_per_scan": tot["kmc"]["WRITE_SIZE"] / S,
-       "samples": S, "detail": detail}
+        b = r["sum"] * 1024.0   # the counters are in KiB (MI355X_MICROARCH.md)
+        if "gibbs" in k:
+            gibbs[c] += b
+        elif k.startswith("kmc_"):
+            name = k.split("(")[0]
+            if "kmc_scan_kernel<true>" in k or "kmc_scan_kernel<(bool)1>" in k:
+                name = "kmc_scan_kernel<true> (set-up decode: not part of a scan)"
+            kmc.setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})[c] += b
+        else:
+            continue
+        detail.append({"kernel": k, "grid": r["grid"], "counter": c, "bytes": b})
+scan_kernels = {k: v for k, v in kmc.items() if "set-up" not in k}
+part = next((k for k in scan_kernels if k.startswith("kmc_partition_kernel")), None)
+factor, calib = 1.0, None
+if part and scan_kernels[part]["FETCH_SIZE"] > 0:
+    expected = float(S) * R * REC
+    factor = expected / scan_kernels[part]["FETCH_SIZE"]
+    calib = {"kernel": part, "expected_fetch_bytes": expected, "counted_fetch_bytes": scan_kernels[part]["FETCH_SIZE"], "factor": factor,
+             "note": "the partition kernel streams every 13-byte record once: (scans x records x 13 B) / FETCH_SIZE; 2.0 = the documented gfx950 half-count of wide coalesced reads"}
+per_kernel = {}
+fetch = write = 0.0
+for k, v in scan_kernels.items():
+    f = v["FETCH_SIZE"] * (factor if k == part and 1.5 < factor < 2.5 else 1.0)
+    per_kernel[k] = {"fetch_bytes_per_record": f / (S * R), "write_bytes_per_record": v["WRITE_SIZE"] / (S * R), "fetch_counted_bytes": v["FETCH_SIZE"], "write_counted_bytes": v["WRITE_SIZE"],
+                     "fetch_corrected": k == part and 1.5 < factor < 2.5}
+    fetch += f
+    write += v["WRITE_SIZE"]
+out = {"source_hash": bench.source_hash(), "source_hash_gibbs": bench.source_hash("gibbs"), "source_hash_kmc": bench.source_hash("kmc"),
+       "command": "python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-paths --no-pcie --no-extra (one rocprofv3 --pmc pass per counter)",
+       "gibbs_bytes_per_schedule": gibbs["FETCH_SIZE"] + gibbs["WRITE_SIZE"], "gibbs_fetch_bytes": gibbs["FETCH_SIZE"], "gibbs_write_bytes": gibbs["WRITE_SIZE"],
+       "kmc_bytes_per_scan": (fetch + write) / S, "kmc_fetch_bytes_per_scan": fetch / S, "kmc_write_bytes_per_scan": write / S, "kmc_bytes_per_record": (fetch + write) / (S * R),
+       "kmc_bytes_per_record_if_every_fetch_were_half_counted": (fetch + write + sum(v["FETCH_SIZE"] for k, v in scan_kernels.items() if k != part)) / (S * R),
+       "kmc_per_kernel": per_kernel, "kmc_calibration": calib, "kmc_excluded": {k: v for k, v in kmc.items() if "set-up" in k},
+       "kmc_note": "scan kernels only; the partition kernel's fetch x the measured calibration factor, everything else as counted (uncalibrated widths: MI355X_MICROARCH.md)",
+       "samples": S, "records_per_scan": R, "detail": detail}
 json.dump(out, open(os.path.join(d, f"{tag}_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "detail"}))
