@@ -13,6 +13,7 @@
 #include "bt_internal.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <fcntl.h>
 #include <unistd.h>
 #include <cstring>
@@ -1633,7 +1634,8 @@ static void parallel_copy(uint8_t *dst, const uint8_t *src, size_t bytes) {
 // first pass), the kernel copies from the page cache or reads the device, each thread its own stripe
 static int parallel_pread(int fd, uint8_t *dst, uint64_t offset, size_t bytes) {
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t threads = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)(hw ? hw / 2 : 1), bytes >> 21}));
+    size_t threads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)(hw ? hw / 2 : 1), bytes >> 21}));
+    if (const char *e = getenv("BT_KMC_READ_THREADS")) threads = std::max<size_t>(1, std::min<size_t>((size_t)atoi(e), bytes >> 16));   // tuning
     const size_t part = (bytes / threads + 4095) / 4096 * 4096;
     std::vector<int> failed(threads, 0);
     auto work = [&](size_t t) {
@@ -1684,6 +1686,7 @@ static int kmc_scan_stream(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table
         return BT_OK;
     }
     BT_HIP(hipSetDevice(s->ctx->device));
+    const auto t_enter = std::chrono::steady_clock::now();
     const uint64_t rec = s->rec_size;
     chunk_records = std::max<uint64_t>(16, std::min<uint64_t>(chunk_records ? chunk_records : (1ull << 23), n + 15) / 16 * 16);   // chunk starts stay 16-byte aligned
     const size_t chunk_bytes = chunk_records * rec;
@@ -1713,14 +1716,20 @@ static int kmc_scan_stream(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table
         s->stage_bytes = reuse ? s->ctx->kmc_stage_bytes : chunk_bytes;
         if (reuse) s->ctx->kmc_stage_bytes = 0;
     }
+    const bool timing = getenv("BT_STAGE_TIMES") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    double read_s = 0, wait_s = 0;
     e = hipMemsetAsync(s->d_host_hits, 0, 8, s->ctx->stream);
     int rc = BT_OK;
     uint64_t done = 0;
     for (uint64_t i = 0; e == hipSuccess && rc == BT_OK && done < n; ++i) {
         const int b = (int)(i & 1);
         const uint64_t m = std::min(chunk_records, n - done);
+        const auto t_w = std::chrono::steady_clock::now();
         if (i >= 2) e = hipEventSynchronize(s->copied[b]);   // the pinned buffer of this slot has been read by its previous copy
         if (e != hipSuccess) break;
+        const auto t_r = std::chrono::steady_clock::now();
+        wait_s += std::chrono::duration<double>(t_r - t_w).count();
         if (fd >= 0) {
             if (parallel_pread(fd, s->h_pin[b], file_offset + done * rec, m * rec) != 0) {
                 rc = fail("bt_kmc_scan_run_file: reading the records failed");
@@ -1728,6 +1737,7 @@ static int kmc_scan_stream(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table
             }
         } else
             parallel_copy(s->h_pin[b], h_records + done * rec, m * rec);
+        read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r).count();
         if (i >= 2) e = hipStreamWaitEvent(s->copy_stream, s->scanned[b], 0);   // the device buffer of this slot has been scanned
         if (e == hipSuccess) e = hipMemcpyAsync(s->d_stage[b], s->h_pin[b], m * rec, hipMemcpyHostToDevice, s->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(s->copied[b], s->copy_stream);
@@ -1739,8 +1749,13 @@ static int kmc_scan_stream(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table
     }
     unsigned long long hits = 0;
     if (e == hipSuccess && rc == BT_OK) e = hipMemcpyAsync(&hits, s->d_host_hits, 8, hipMemcpyDeviceToHost, s->ctx->stream);
+    const auto t_loop = std::chrono::steady_clock::now();
     hipError_t e2 = hipStreamSynchronize(s->ctx->stream);
     (void)hipStreamSynchronize(s->copy_stream);
+    if (timing)
+        fprintf(stderr, "  kmc stream: %.3f s enqueueing (%.3f s reading into the pinned slots, %.3f s waiting for a slot), %.3f s draining; staging set-up before that %.3f s\n",
+                std::chrono::duration<double>(t_loop - t_begin).count(), read_s, wait_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count(),
+                std::chrono::duration<double>(t_begin - t_enter).count());
     if (rc != BT_OK) return rc;
     if (e == hipSuccess) e = e2;
     if (e != hipSuccess) return fail(std::string("bt_kmc_scan_run_host: ") + hipGetErrorString(e));

@@ -430,7 +430,7 @@ void KmerCounter::parseSampleKmers(bt_table *table, bt_bloom *path_bloom, Comm *
         const uint64_t first = db.total_kmers / world * rank + std::min<uint64_t>(rank, db.total_kmers % world);
         const uint64_t count = db.total_kmers / world + (rank < db.total_kmers % world ? 1 : 0);
         const auto t_scan = std::chrono::steady_clock::now();
-        uint64_t hits = bthost::parseSampleKmers(ctx, db, path_bloom, table, (uint32_t)s, 1ull << 24, first, count);
+        uint64_t hits = bthost::parseSampleKmers(ctx, db, path_bloom, table, (uint32_t)s, 1ull << 22, first, count);
         const double scan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scan).count();
         if (comm) comm->allreduceHist(&hits, 1);
         std::cout << "[" << getLocalTime() << "] Parsed " << db.total_kmers << " kmers (" << hits << " passed the path kmer filter)" << std::endl;
