@@ -94,7 +94,7 @@ def committed_traffic(kind):
     return None, None
 
 
-def committed_issue_profile():
+def committed_issue_profile(S=None, groups=None):
     """the VALU instruction counts of one Gibbs schedule of the default command (profiles/*_issue.json, tools/issue_profile.py from single-schedule SQ counter
     passes), when measured on the sources this library was built from"""
     import glob
@@ -104,7 +104,7 @@ def committed_issue_profile():
             d = json.load(open(f))
         except Exception:
             continue
-        if "gibbs" in d and _matches(d, "gibbs"):
+        if "gibbs" in d and _matches(d, "gibbs") and (S is None or (d.get("S") == S and abs(d.get("groups", 0) - groups) <= 0.02 * groups)):
             return d, os.path.relpath(f, ROOT)
     return None, None
 
@@ -595,6 +595,12 @@ def main():
             rec10["cpu_allcores_cluster_sweeps_per_sec"] = c10["num_clusters"] * sweeps_per_group / dt
             rec10["cpu_sample"] = f"{c10['num_groups']} groups, {dt:.1f} s on {os.cpu_count()} threads"
             rec10["gpu_over_cpu_allcores"] = rec10["cluster_sweeps_per_sec"] / rec10["cpu_allcores_cluster_sweeps_per_sec"]
+        issue10, issue10_src = committed_issue_profile(S10, int(rec10["groups"]))
+        if issue10:
+            rec10["issue_frac"] = issue10["gibbs"]["valu_issue_cycles_per_schedule"] / (1024 * 2.4e9 * rec10["ms_per_schedule"] * 1e-3)
+            rec10["valu_insts_per_cluster_sweep"] = issue10["gibbs"]["valu_insts_per_cluster_sweep"]
+            rec10["resident_waves_per_simd"] = issue10["gibbs"]["wave_quad_cycles"] * 4 / (2.4e9 * rec10["ms_per_schedule"] * 1e-3) / 1024
+            rec10["issue_source"] = issue10_src
         extra["samples10"] = rec10
         # (1b) BASELINE configs[4]: --noise-genotyping (estimateNoiseAndGenotypes) at 30 samples through the C++ InferenceEngine the executable
         # ships, beside the default mode on the same batch.  The drivers iterate on the host (bt_gibbs_noise_iteration: one synchronisation per iteration, the
@@ -702,8 +708,8 @@ def main():
         kmc_traffic, kmc_traffic_src = committed_traffic("kmc_bytes_per_scan")
         if (args.groups, S, args.records) != (600_000, 3, 1_000_000_000) or world != 1:   # the committed passes are of the default command
             gibbs_traffic = kmc_traffic = gibbs_traffic_src = kmc_traffic_src = None
-        issue, issue_src = committed_issue_profile()
-        if issue is not None and ((issue["groups"], issue["S"]) != (G, S) or world != 1):
+        issue, issue_src = committed_issue_profile(S, G)
+        if world != 1:
             issue = issue_src = None
         SIMDS, CLOCK = 1024, 2.4e9
         shape_note = ("BASELINE configs[2] WGS trio" if S == 3 else "BASELINE configs[3] 10-sample mixture" if S == 10 else "mixture") + \
@@ -737,7 +743,9 @@ def main():
                          "limiter": "VALU issue + latency of a sequential sampler (no dense contraction: MFMA busy cycles 0); the HBM fraction is tiny by construction",
                          "issue_frac": issue["gibbs"]["valu_issue_cycles_per_schedule"] / (SIMDS * CLOCK * gibbs_avg_ms * 1e-3) if issue else None,
                          "valu_insts_per_cluster_sweep": issue["gibbs"]["valu_insts_per_cluster_sweep"] if issue else None,
-                         "resident_waves_per_simd": issue["gibbs"]["wave_quad_cycles"] * 4 / (CLOCK * issue["launch_ms_under_pmc"][0] * 1e-3) / SIMDS if issue else None,
+                         # wavefront-cycles of the schedule (a count: the same whether its launches ran one after the other, as under the counter passes, or
+                         # together) over the duration of the concurrent launches measured here
+                         "resident_waves_per_simd": issue["gibbs"]["wave_quad_cycles"] * 4 / (CLOCK * gibbs_avg_ms * 1e-3) / SIMDS if issue else None,
                          "waves_per_simd_by_registers": {"gibbs_simple_kernel": 3, "gibbs_hot_kernel": 2},
                          "issue_source": issue_src,
                          "issue_note": "issue_frac = (VALU instructions of one schedule, priced 2 cycles for 32-bit, 4 for f64 add/mul/fma and 64-bit integer, 16 / 8 for "
