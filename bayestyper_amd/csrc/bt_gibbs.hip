@@ -311,8 +311,10 @@ __device__ inline void tput(uint8_t *tile_base, const TileDesc &d, int arr, uint
 // chain's launch is resident (gibbs_chain_kernel: up to two 256-register wavefronts per SIMD on most SIMDs), and the dispatcher only places a workgroup of
 // several wavefronts on a CU that has room on all its SIMDs — measured: a 256-thread kernel on another stream waited for the chain to end, a 64-thread one
 // ran next to it.  Hence no hipMemsetAsync for the pool either (the runtime's fill kernel has large workgroups).
-__global__ __launch_bounds__(64) void zero_fill_kernel(uint4 *__restrict__ p, uint64_t n16) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 64u + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 64u) p[i] = uint4{0u, 0u, 0u, 0u};
+__global__ __launch_bounds__(64) void zero_fill_kernel(uint4 *__restrict__ p, uint64_t n16, uint64_t per_wg) {
+    // a contiguous stretch per workgroup (a grid-stride loop over a 20 GB pool touched another page every iteration: 115 GB/s)
+    const uint64_t a = (uint64_t)blockIdx.x * per_wg, b = a + per_wg < n16 ? a + per_wg : n16;
+    for (uint64_t i = a + threadIdx.x; i < b; i += 64u) p[i] = uint4{0u, 0u, 0u, 0u};
 }
 __global__ __launch_bounds__(64) void copy_words_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * 64u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64u) dst[i] = src[i];
@@ -1502,7 +1504,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         {
             bool simple = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 && d.cache_mode == 0 && d.copies == 1 && d.split == 1 && d.hot_bytes != 0 && !getenv("BT_GIBBS_NO_SIMPLE");
             for (uint32_t l = 0; l < d.num_lanes && simple; ++l) simple = cd[gd[shapes[tile_start[ti] + l].g].c0].H == 2;
-            simple = simple && d.hoff[A_RING] != NOHOT && d.hoff[A_SC] == NOHOT;   // (the LDS block was laid out for simple_sweeps above)
+            simple = simple && d.sblk != 0 && d.hoff[A_RING] != NOHOT && d.hoff[A_SC] == NOHOT;   // (the LDS block was laid out for simple_sweeps above: its per-sample words have their place)
             d.simple = simple ? 1u : 0u;
         }
         d.logged = d.nvm == 1 && d.NMm == 0 && !getenv("BT_GIBBS_NO_LOG") ? 1u : 0u;
@@ -1563,7 +1565,8 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
     g->device_bytes += g->pool_bytes;
     {
         const uint64_t n16 = (g->pool_bytes + 15) / 16;   // (hipMalloc sizes are multiples of the allocation granule: the tail belongs to the allocation)
-        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)std::min<uint64_t>((n16 + 63) / 64, 65536)), dim3(64), 0, ctx->stream, reinterpret_cast<uint4 *>(g->d_pool), n16);
+        const uint64_t per_wg = std::max<uint64_t>(4096, ((n16 + 1048575) / 1048576 + 63) / 64 * 64);   // 64 KB and more per workgroup, at most 2^20 workgroups
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n16 + per_wg - 1) / per_wg)), dim3(64), 0, ctx->stream, reinterpret_cast<uint4 *>(g->d_pool), n16, per_wg);
         BT_TRYHIP(hipGetLastError());
     }
 

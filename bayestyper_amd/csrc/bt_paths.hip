@@ -18,6 +18,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <exception>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -655,16 +656,31 @@ unsigned host_threads(uint64_t items) {
     else t = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(t, items / 256 + 1));
 }
+// fn(t) for t in [0, T) on T threads (the caller's included); the first exception of any of them is rethrown after all have been joined
 template <typename F>
 void run_on_threads(unsigned T, F &&fn) {
     if (T <= 1) {
         fn(0u);
         return;
     }
+    std::vector<std::exception_ptr> err(T);
+    auto guarded = [&](unsigned t) {
+        try {
+            fn(t);
+        } catch (...) {
+            err[t] = std::current_exception();
+        }
+    };
     std::vector<std::thread> pool;
-    for (unsigned t = 1; t < T; ++t) pool.emplace_back([&fn, t]() { fn(t); });
-    fn(0u);
+    try {
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(guarded, t);
+    } catch (...) {   // (a thread could not be started: the ranges of the missing threads are run here)
+        for (unsigned t = (unsigned)pool.size() + 1; t < T; ++t) guarded(t);
+    }
+    guarded(0u);
     for (auto &th : pool) th.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
 }
 
 // Host half of getHaplotypeCandidates for one path: running-variant intervals in path-nucleotide coordinates
@@ -1328,7 +1344,11 @@ int bt_paths_candidates(bt_paths *p, bt_table *table, bt_paths_candidates_sizes 
             q.nestdep_off.push_back((uint32_t)q.nestdep_cluster.size());
         }
     };
-    run_on_threads(T, work);
+    try {
+        if (C) run_on_threads(T, work);
+    } catch (const std::exception &e) {   // (a worker ran out of memory on its pieces: an error of the call, not of the process)
+        return fail(std::string("bt_paths_candidates: ") + e.what());
+    }
     // concatenation: `idx` lists appended as they are, `off` lists (cumulative ends, relative to the piece) rebased on what precedes the piece
     auto cat = [&](auto &dst, auto Piece::*m) {
         size_t n = 0;
@@ -1388,10 +1408,14 @@ int bt_paths_candidates_fetch(bt_paths *p, bt_paths_candidates_out *o) {
         const unsigned T = host_threads(bytes >> 14);   // at least 4 MB per thread
         const uint8_t *src = reinterpret_cast<const uint8_t *>(v.data());
         uint8_t *out = reinterpret_cast<uint8_t *>(dst);
-        run_on_threads(T, [&](unsigned t) {
-            const size_t a = bytes * t / T / 64 * 64, b = t + 1 == T ? bytes : bytes * (t + 1) / T / 64 * 64;
-            if (b > a) std::memcpy(out + a, src + a, b - a);
-        });
+        try {
+            run_on_threads(T, [&](unsigned t) {
+                const size_t a = bytes * t / T / 64 * 64, b = t + 1 == T ? bytes : bytes * (t + 1) / T / 64 * 64;
+                if (b > a) std::memcpy(out + a, src + a, b - a);
+            });
+        } catch (...) {   // (no thread could be started: one copy)
+            std::memcpy(out, src, bytes);
+        }
     };
     cp(p->kmer_off, o->kmer_off);
     cp(p->mult, o->hap_kmer_mult);

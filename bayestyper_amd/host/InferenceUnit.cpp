@@ -5,43 +5,57 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 
 namespace bthost {
 
-// one gzip member of `len` bytes (deflate + the 10-byte header and the CRC-32 / length trailer): compress2-style with a gzip wrapper (windowBits 15 + 16)
-static std::string gzipMember(const char *data, size_t len) {
+// one piece of a raw deflate stream (no gzip wrapper): ended with a sync flush — byte-aligned, not final — or, the last piece, with the final block
+static std::string deflatePiece(const char *data, size_t len, bool last) {
     z_stream zs;
     std::memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
     std::string out(deflateBound(&zs, (uLong)len) + 64, '\0');
     zs.next_in = (Bytef *)data;
     zs.avail_in = (uInt)len;
     zs.next_out = (Bytef *)&out[0];
     zs.avail_out = (uInt)out.size();
-    const int rc = deflate(&zs, Z_FINISH);
+    const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
     const size_t n = out.size() - zs.avail_out;
+    const bool ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0);
     deflateEnd(&zs);
-    if (rc != Z_STREAM_END) throw std::runtime_error("deflate failed");
+    if (!ok) throw std::runtime_error("deflate failed");
     out.resize(n);
     return out;
 }
 
-// Large contents (the parameter k-mer FASTA: 56 MB, four seconds of single-thread deflate at a chr20-sized unit) are written as consecutive gzip members
-// of 4 MB of input each, compressed on `threads` host threads: a multi-member file is what `cat a.gz b.gz` gives, and zlib's gzread / gunzip read it as one
-// stream.  One thread (or a small content) writes the single member the reference writes.
+// Large contents (the parameter k-mer FASTA: 56 MB, four seconds of single-thread deflate at a chr20-sized unit) are compressed in pieces of 4 MB of input on
+// `threads` host threads and written as ONE gzip member: every piece is a stretch of the same raw deflate stream, closed with a sync flush (what pigz does), the
+// CRC-32 of the whole content in the trailer.  Any gzip reader reads it, and the bytes do not depend on the number of threads (the pieces are cut by size).
+// Small contents go through gzwrite like the reference's single stream.
 void writeGzFile(const std::string &filename, const std::string &content, unsigned threads) {
     const size_t piece = 4u << 20;
-    if (threads > 1 && content.size() > 2 * piece) {
+    if (content.size() > 2 * piece) {
         const size_t parts = (content.size() + piece - 1) / piece;
-        std::vector<std::string> members(parts);
-        parallelFor(parts, threads, [&](size_t a, size_t b, unsigned) {
-            for (size_t i = a; i < b; i++) members[i] = gzipMember(content.data() + i * piece, std::min(piece, content.size() - i * piece));
+        std::vector<std::string> blocks(parts);
+        std::vector<uLong> crcs(parts);
+        parallelFor(parts, std::max(1u, threads), [&](size_t a, size_t b, unsigned) {
+            for (size_t i = a; i < b; i++) {
+                const size_t len = std::min(piece, content.size() - i * piece);
+                blocks[i] = deflatePiece(content.data() + i * piece, len, i + 1 == parts);
+                crcs[i] = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)content.data() + i * piece, (uInt)len);
+            }
         });
+        uLong crc = crc32(0L, Z_NULL, 0);
+        for (size_t i = 0; i < parts; i++) crc = crc32_combine(crc, crcs[i], (z_off_t)std::min(piece, content.size() - i * piece));
         std::ofstream f(filename, std::ios::binary);
         if (!f.is_open()) throw std::runtime_error("Unable to write file " + filename);
-        for (auto &m : members) f.write(m.data(), (std::streamsize)m.size());
+        const unsigned char header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};   // deflate, no flags, no time stamp, unix
+        f.write((const char *)header, 10);
+        for (auto &m : blocks) f.write(m.data(), (std::streamsize)m.size());
+        const uint32_t trailer[2] = {(uint32_t)crc, (uint32_t)(content.size() & 0xFFFFFFFFu)};
+        f.write((const char *)trailer, 8);
         f.close();
         if (!f) throw std::runtime_error("Error while writing " + filename);
         return;

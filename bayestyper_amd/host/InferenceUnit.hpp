@@ -28,7 +28,7 @@ struct InferenceUnit {
 };
 
 // gzip text/binary files (the reference's boost::iostreams gzip filters)
-void writeGzFile(const std::string &filename, const std::string &content, unsigned threads = 1);   // threads > 1: large contents as consecutive gzip members
+void writeGzFile(const std::string &filename, const std::string &content, unsigned threads = 1);   // one gzip member whatever the thread count (large contents: 4 MB pieces of one deflate stream, compressed on `threads` threads)
 std::string readGzFile(const std::string &filename);   // also reads uncompressed files
 
 }  // namespace bthost

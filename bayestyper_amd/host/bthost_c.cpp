@@ -24,6 +24,16 @@ using namespace bthost;
 
 extern "C" {
 
+// writeGzFile (the cluster stage's parameter_kmers.fa.gz / intercluster_regions.txt.gz): for the test that the bytes do not depend on the thread count
+int bth_write_gz(const char *filename, const char *data, unsigned long long len, unsigned threads) {
+    try {
+        writeGzFile(filename, std::string(data, (size_t)len), threads);
+    } catch (const std::exception &) {
+        return 1;
+    }
+    return 0;
+}
+
 // LUTs for S samples from per-sample (mean, var, multiplicity) of the parameter k-mers and explicit noise rates
 int bth_build_luts(unsigned S, const double *mean, const double *var, const unsigned *multiplicity, const double *noise_rates, double *genomic, double *noise) {
     try {

@@ -258,3 +258,26 @@ def test_command_lines_arguments(tmp_path):
     assert r.returncode == 1 and "Samples file empty" in r.stderr
     r = run("cluster", "-v", "x.vcf", "-s", _samples(tmp_path), "-g", str(tmp_path / "nogenome.fa"))
     assert r.returncode == 1 and "Unable to open file" in r.stderr and "Parsed information for 2 sample(s)" in r.stdout
+
+
+def test_gz_files_do_not_depend_on_the_thread_count(tmp_path):
+    """writeGzFile (parameter_kmers.fa.gz of the cluster stage): a large content is compressed in pieces on -p threads but written as ONE gzip member — any
+    gzip reader reads it whole — and the bytes are those of a one-thread run (the pieces are cut by size, not by thread)"""
+    from bayestyper_amd.host import dll
+
+    dll.bth_write_gz.argtypes = [C.c_char_p, C.c_char_p, C.c_ulonglong, C.c_uint]
+    rng = np.random.default_rng(3)
+    rec = b">k\n" + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 55)) + b"\n"
+    content = b"".join(b">k%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 55)) + b"\n" for i in range(40_000)) * 8   # 19 MB: five pieces
+    assert len(content) > 3 * (4 << 20) and rec
+    files = []
+    for threads in (1, 7):
+        f = str(tmp_path / f"p{threads}.gz")
+        assert dll.bth_write_gz(f.encode(), content, len(content), threads) == 0
+        files.append(open(f, "rb").read())
+    assert files[0] == files[1]
+    assert gzip.decompress(files[0]) == content            # one member: the standard library reads it in one go
+    assert files[0].count(b"\x1f\x8b\x08") >= 1 and gzip.GzipFile(fileobj=__import__("io").BytesIO(files[0])).read() == content
+    small = b"chr1\t10\t20\n" * 100
+    f = str(tmp_path / "small.gz")
+    assert dll.bth_write_gz(f.encode(), small, len(small), 4) == 0 and gzip.open(f).read() == small
