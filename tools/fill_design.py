@@ -143,7 +143,7 @@ PCIe: `bt_kmc_scan_run` takes device pointers; `bt_kmc_scan_run_host` streams a 
 buffers and a copy stream, overlapping host copy, transfer and scan: **{e(pc['records_per_sec'])} records/s = {pc['host_gbytes_per_sec']:.0f} GB/s** from pageable host memory
 against {e(bench['kmer_matches_per_sec'])} with the stream resident in HBM; reported beside `value`, never as `value`."""
 
-p = os.path.join(ROOT, "DESIGN.md")
+p = os.path.join(ROOT, "docs", "HISTORY.md")   # (the long-form design notes with the measured tables; DESIGN.md is the short current design)
 s = open(p).read()
 for name, text in (("KERNEL_TABLE", kernel_table), ("GIBBS_ANALYSIS", gibbs_analysis), ("MEASUREMENT", measurement)):
     block = f"<!-- measured:{name} -->\n{text}\n<!-- /measured:{name} -->"
