@@ -207,6 +207,15 @@ int bt_memcpy_d2h(bt_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     return BT_OK;
 }
 
+int bt_memcpy_d2d(bt_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return bt::fail("bt_memcpy_d2d: null ctx");
+    if (!bytes) return BT_OK;
+    BT_HIP(hipSetDevice(ctx->device));
+    BT_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    BT_HIP(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
 int bt_timer_create(bt_ctx *ctx, bt_timer **out) {
     if (!ctx || !out) return bt::fail("bt_timer_create: null argument");
     BT_HIP(hipSetDevice(ctx->device));

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void result_count_kernel(const TileDesc *__res
 constexpr uint32_t kPackLds = 2048;   // entries ranked from LDS; larger tables are ranked from the table itself
 __global__ __launch_bounds__(64) void result_pack_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const ClusterLoc *__restrict__ loc, uint32_t S,
                                                          const uint64_t *__restrict__ dip_off, const uint64_t *__restrict__ cell_off, const uint32_t *__restrict__ alleles,
-                                                         uint16_t *__restrict__ out_h1, uint16_t *__restrict__ out_h2, uint32_t *__restrict__ out_freq, double *__restrict__ out_stats) {
+                                                         uint16_t *__restrict__ out_h1, uint16_t *__restrict__ out_h2, uint32_t *__restrict__ out_freq, double *__restrict__ out_stats,
+                                                         uint32_t *__restrict__ out_keys) {   // out_keys: h1 | h2 << 16 per entry (the wire string of bt_gibbs_result_words)
     __shared__ uint32_t l_key[kPackLds], l_slot[kPackLds];
     __shared__ uint32_t l_n;
     const uint32_t c = blockIdx.x;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64) void result_pack_kernel(const TileDesc *__restr
         const uint32_t key = tag == 0xFFFFFFFFu ? 0xFFFFFFFFu : tag - 1u;
         return (key << 16) | (key >> 16);
     };
-    if (out_h1 || out_h2 || out_freq) {
+    if (out_h1 || out_h2 || out_freq || out_keys) {
         if (n <= kPackLds) {
             if (threadIdx.x == 0) l_n = 0;
             __syncthreads();
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(64) void result_pack_kernel(const TileDesc *__restr
                 const uint64_t e = e0 + rank;
                 if (out_h1) out_h1[e] = (uint16_t)(kk >> 16);
                 if (out_h2) out_h2[e] = (uint16_t)(kk & 0xFFFFu);
+                if (out_keys) out_keys[e] = (kk >> 16) | (kk << 16);
                 if (out_freq)
                     for (uint32_t s = 0; s < S; ++s) out_freq[e * S + s] = freq[slot * S + s];
             }
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(64) void result_pack_kernel(const TileDesc *__restr
                 const uint64_t e = e0 + rank;
                 if (out_h1) out_h1[e] = (uint16_t)(kk >> 16);
                 if (out_h2) out_h2[e] = (uint16_t)(kk & 0xFFFFu);
+                if (out_keys) out_keys[e] = (kk >> 16) | (kk << 16);
                 if (out_freq)
                     for (uint32_t s = 0; s < S; ++s) out_freq[e * S + s] = freq[slot * S + s];
             }
@@ -182,6 +185,14 @@ __global__ __launch_bounds__(64) void result_pack_kernel(const TileDesc *__restr
             dst[i] = as[s * Am * 12u + r];
         }
     }
+}
+
+// entries and cells per cluster, interleaved (the size table of the wire string)
+__global__ __launch_bounds__(64) void wire_sizes_kernel(const uint64_t *__restrict__ dip_off, const uint64_t *__restrict__ cell_off, uint32_t num_clusters, uint32_t *__restrict__ sizes) {
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    if (c >= num_clusters) return;
+    sizes[2 * c] = (uint32_t)(dip_off[c + 1] - dip_off[c]);
+    sizes[2 * c + 1] = (uint32_t)(cell_off[c + 1] - cell_off[c]);
 }
 
 // ---- the noise model's update of one iteration (bt_gibbs_noise_chain) ----------------------------------------------------------------
@@ -523,6 +534,8 @@ struct bt_gibbs {
     hipEvent_t ev_fork = nullptr;
     uint32_t trace_sweeps = 0;
     uint32_t *d_trace = nullptr, *d_trace_counter = nullptr;
+    uint32_t *d_wire = nullptr;   // bt_gibbs_result_words' string
+    uint64_t wire_cap = 0;
     uint64_t trace_words = 0;
     // bt_gibbs_noise_iteration: pinned staging of the histogram (device -> host) and of the noise table (host -> device), device histogram
     uint64_t *h_pin_hist = nullptr, *d_iter_hist = nullptr;
@@ -1862,6 +1875,7 @@ int bt_gibbs_destroy(bt_gibbs *g) {
         if (p) (void)hipFree(p);
     if (g->d_trace) (void)hipFree(g->d_trace);
     if (g->d_trace_counter) (void)hipFree(g->d_trace_counter);
+    if (g->d_wire) (void)hipFree(g->d_wire);
     if (g->h_pin_hist) (void)hipHostFree(g->h_pin_hist);
     if (g->h_pin_noise) (void)hipHostFree(g->h_pin_noise);
     if (g->d_iter_hist) (void)hipFree(g->d_iter_hist);
@@ -2494,13 +2508,69 @@ int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, 
     BT_HIP(hipMemcpyAsync(d_cell_off, cell_off.data(), ((size_t)C + 1) * 8, hipMemcpyHostToDevice, st));
     BT_HIP(hipMemcpyAsync(d_alleles, g->h_A.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(result_pack_kernel, dim3(C), dim3(64), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const ClusterLoc *)g->d_loc, S, (const uint64_t *)d_dip_off,
-                       (const uint64_t *)d_cell_off, (const uint32_t *)d_alleles, d_h1, d_h2, d_freq, d_stats);
+                       (const uint64_t *)d_cell_off, (const uint32_t *)d_alleles, d_h1, d_h2, d_freq, d_stats, (uint32_t *)nullptr);
     BT_CHECK_LAUNCH();
     if (h_dip_h1 && nd) BT_HIP(hipMemcpyAsync(h_dip_h1, d_h1, nd * 2, hipMemcpyDeviceToHost, st));
     if (h_dip_h2 && nd) BT_HIP(hipMemcpyAsync(h_dip_h2, d_h2, nd * 2, hipMemcpyDeviceToHost, st));
     if (h_dip_freq && nd) BT_HIP(hipMemcpyAsync(h_dip_freq, d_freq, nd * S * 4, hipMemcpyDeviceToHost, st));
     if (h_stats && nc) BT_HIP(hipMemcpyAsync(h_stats, d_stats, nc * 12 * 8, hipMemcpyDeviceToHost, st));
     BT_HIP(hipStreamSynchronize(st));
+    return BT_OK;
+}
+
+// The same results as ONE word string in device memory — what a rank hands to bt_comm_gather_summaries (InferenceEngine.cpp:335-382: the
+// reference's threads push their genotypes into one queue; with one process per GPU the queue is the gather to rank 0) — without the host
+// round trip of bt_gibbs_result_fetch:  [C, entries, cells, S]  [entries, cells] per cluster  h1 | h2 << 16 per entry  counts [entry][S]
+// (one pad word if the count so far is odd)  statistics [cell][12] doubles.  The buffer belongs to the sampler (valid until the next call
+// or bt_gibbs_destroy) and is complete when the call returns.
+int bt_gibbs_result_words(bt_gibbs *g, const uint32_t **d_words, uint64_t *num_words) {
+    if (!g || !d_words || !num_words) return fail("bt_gibbs_result_words: null argument");
+    std::vector<uint64_t> dip_off, cell_off;
+    {
+        const int rc = result_offsets(g, dip_off, cell_off);
+        if (rc != BT_OK) return rc;
+    }
+    const uint32_t C = g->C, S = g->S;
+    hipStream_t st = g->ctx->stream;
+    const uint64_t nd = dip_off[C], nc = cell_off[C];
+    if (nd >> 32 || nc >> 32) return fail("bt_gibbs_result_words: more than 2^32 entries in one launch");
+    const uint64_t at_sizes = 4, at_keys = at_sizes + 2ull * C, at_freq = at_keys + nd, at_stats = (at_freq + nd * S + 1) & ~1ull, total = at_stats + nc * 24;
+    if (g->wire_cap < total) {
+        if (g->d_wire) BT_HIP(hipFree(g->d_wire));
+        g->d_wire = nullptr;
+        g->wire_cap = 0;
+        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_wire), total * 4));
+        g->wire_cap = total;
+    }
+    uint32_t *w = g->d_wire;
+    const uint32_t head[4] = {C, (uint32_t)nd, (uint32_t)nc, S};
+    BT_HIP(hipMemcpyAsync(w, head, sizeof head, hipMemcpyHostToDevice, st));
+    if (at_stats != at_freq + nd * S) BT_HIP(hipMemsetAsync(w + at_stats - 1, 0, 4, st));
+    void *d_tmp = nullptr;
+    struct Free {
+        void *&p;
+        ~Free() {
+            if (p) (void)hipFree(p);
+        }
+    } fr{d_tmp};
+    if (C) {
+        const size_t off_bytes = ((size_t)C + 1) * 8;
+        BT_HIP(hipMalloc(&d_tmp, 2 * off_bytes + (size_t)C * 4));
+        uint64_t *d_dip_off = (uint64_t *)d_tmp, *d_cell_off = d_dip_off + C + 1;
+        uint32_t *d_alleles = (uint32_t *)(d_cell_off + C + 1);
+        BT_HIP(hipMemcpyAsync(d_dip_off, dip_off.data(), off_bytes, hipMemcpyHostToDevice, st));
+        BT_HIP(hipMemcpyAsync(d_cell_off, cell_off.data(), off_bytes, hipMemcpyHostToDevice, st));
+        BT_HIP(hipMemcpyAsync(d_alleles, g->h_A.data(), (size_t)C * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(wire_sizes_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const uint64_t *)d_dip_off, (const uint64_t *)d_cell_off, C, w + at_sizes);
+        BT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(result_pack_kernel, dim3(C), dim3(64), 0, st, (const TileDesc *)g->d_tiles, g->d_pool, (const ClusterLoc *)g->d_loc, S, (const uint64_t *)d_dip_off,
+                           (const uint64_t *)d_cell_off, (const uint32_t *)d_alleles, (uint16_t *)nullptr, (uint16_t *)nullptr, w + at_freq, reinterpret_cast<double *>(w + at_stats),
+                           w + at_keys);
+        BT_CHECK_LAUNCH();
+    }
+    BT_HIP(hipStreamSynchronize(st));
+    *d_words = w;
+    *num_words = total;
     return BT_OK;
 }
 

@@ -335,6 +335,48 @@ std::vector<uint32_t> Comm::gatherWords(const std::vector<uint32_t> &mine, std::
     return all;
 }
 
+std::vector<uint32_t> Comm::gatherWordsDevice(const uint32_t *d_mine, uint64_t num_words, std::vector<uint64_t> *offsets) {
+    if (!dir.empty()) {   // (files transport: the string leaves the device here, as a rank's part of the exchange)
+        std::vector<uint32_t> mine(num_words);
+        if (num_words) check(bt_memcpy_d2h(ctx, mine.data(), d_mine, num_words * 4), "bt_memcpy_d2h");
+        return gatherWords(mine, offsets);
+    }
+    std::vector<uint64_t> sizes((size_t)world_, 0);
+    sizes[rank_] = num_words;
+    allreduceHist(sizes.data(), sizes.size());
+    const uint64_t total = std::accumulate(sizes.begin(), sizes.end(), (uint64_t)0);
+    DeviceBuffer d_none(ctx, 16), d_out(ctx, rank_ == 0 ? total * 4 : 16);
+    std::vector<uint64_t> off((size_t)world_ + 1);
+    check(api->gather_summaries(comm, num_words ? d_mine : (const uint32_t *)d_none.p, num_words, (uint32_t *)d_out.p, rank_ == 0 ? std::max<uint64_t>(total, 4) : 0, off.data()),
+          "bt_comm_gather_summaries");
+    check(bt_sync(ctx), "bt_sync");
+    std::vector<uint32_t> all;
+    if (rank_ == 0) {
+        all.resize(total);
+        if (total) check(bt_memcpy_d2h(ctx, all.data(), d_out.p, total * 4), "bt_memcpy_d2h");
+    }
+    if (offsets) *offsets = off;
+    return all;
+}
+
+DeviceWords::~DeviceWords() {
+    if (p) bt_free(ctx, p);
+}
+void DeviceWords::append(const uint32_t *d_words, uint64_t num_words) {
+    if (n + num_words > cap) {
+        const uint64_t want = std::max<uint64_t>(n + num_words, cap + cap / 2);
+        void *q = nullptr;
+        check(bt_malloc(ctx, std::max<uint64_t>(want, 4) * 4, &q), "bt_malloc");
+        if (n) check(bt_memcpy_d2d(ctx, q, p, n * 4), "bt_memcpy_d2d");
+        if (p) bt_free(ctx, p);
+        p = q;
+        cap = want;
+    }
+    if (num_words) check(bt_memcpy_d2d(ctx, (uint32_t *)p + n, d_words, num_words * 4), "bt_memcpy_d2d");
+    n += num_words;
+    k += 1;
+}
+
 std::vector<std::vector<uint32_t>> assignGroups(const GibbsBatchData &unit, int world) {
     const uint32_t G = unit.numGroups();
     std::vector<double> cost(G, 0.0);
@@ -355,34 +397,16 @@ std::vector<std::vector<uint32_t>> assignGroups(const GibbsBatchData &unit, int 
     return ids;
 }
 
-// wire format of one rank's BatchResults (32-bit words): C, nd, nc, then per cluster (entries, cells), then h1 | h2 << 16 per entry, the
-// frequencies (nd * S), the statistics (nc * 12 doubles as word pairs)
-BatchResults gatherResults(Comm &comm, const GibbsBatchData &unit, const std::vector<std::vector<uint32_t>> &ids, const BatchResults &mine, uint32_t S) {
-    const uint32_t Cm = mine.dip_off.empty() ? 0u : (uint32_t)mine.dip_off.size() - 1;
-    const uint64_t nd = Cm ? mine.dip_off[Cm] : 0, nc = Cm ? mine.cell_off[Cm] : 0;
-    std::vector<uint32_t> w;
-    w.reserve(3 + 2 * (size_t)Cm + nd * (1 + S) + nc * 24);
-    w.push_back(Cm);
-    w.push_back((uint32_t)nd);
-    w.push_back((uint32_t)nc);
-    if (nd >> 32 || nc >> 32) throw std::runtime_error("gatherResults: more than 2^32 entries on one rank");
-    for (uint32_t c = 0; c < Cm; c++) {
-        w.push_back((uint32_t)(mine.dip_off[c + 1] - mine.dip_off[c]));
-        w.push_back((uint32_t)(mine.cell_off[c + 1] - mine.cell_off[c]));
-    }
-    for (uint64_t e = 0; e < nd; e++) w.push_back((uint32_t)mine.h1[e] | ((uint32_t)mine.h2[e] << 16));
-    for (uint64_t i = 0; i < nd * S; i++) w.push_back(mine.freq[i]);
-    const size_t at = w.size();
-    w.resize(at + nc * 24);
-    if (nc) std::memcpy(w.data() + at, mine.stats.data(), nc * 96);
-    std::vector<uint64_t> off;
-    const std::vector<uint32_t> all = comm.gatherWords(w, &off);
-    BatchResults full;
-    if (comm.rank() != 0) return full;
-    // where every cluster of the unit sits: (rank, local cluster index)
+// wire format of a launch's results (32-bit words; bt_gibbs_result_words builds the same string on the device): C, nd, nc, S, then per cluster
+// (entries, cells), then h1 | h2 << 16 per entry, the frequencies (nd * S), a pad word if the count so far is odd, the statistics (nc * 12
+// doubles as word pairs).  A rank's string is its launches' strings one after the other.
+namespace {
+BatchResults rebuildOnRankZero(const std::vector<uint32_t> &all, const std::vector<uint64_t> &off, int world, const GibbsBatchData &unit, const std::vector<std::vector<uint32_t>> &ids,
+                               uint32_t S) {
+    // where every cluster of the unit sits: (rank, cluster index within the rank's string)
     const uint32_t C = unit.numClusters();
     std::vector<uint32_t> c_rank(C, 0), c_local(C, 0);
-    for (int r = 0; r < comm.world(); r++) {
+    for (int r = 0; r < world; r++) {
         uint32_t local = 0;
         for (uint32_t g : ids[r])
             for (uint32_t c = unit.group_cluster_off[g]; c < unit.group_cluster_off[g + 1]; c++) {
@@ -390,48 +414,110 @@ BatchResults gatherResults(Comm &comm, const GibbsBatchData &unit, const std::ve
                 c_local[c] = local++;
             }
     }
-    struct Part {
+    struct Part {   // one launch of one rank
         const uint32_t *sizes, *keys, *freq;
         const uint8_t *stats;
+        uint32_t first = 0, count = 0;   // the rank-local cluster indices it holds
         std::vector<uint64_t> dip_off, cell_off;
     };
-    std::vector<Part> parts((size_t)comm.world());
-    for (int r = 0; r < comm.world(); r++) {
-        const uint32_t *p = all.data() + off[r];
-        const uint32_t Cr = p[0], ndr = p[1];
-        Part &P = parts[r];
-        P.sizes = p + 3;
-        P.keys = P.sizes + 2 * (size_t)Cr;
-        P.freq = P.keys + ndr;
-        P.stats = (const uint8_t *)(P.freq + (size_t)ndr * S);
-        P.dip_off.assign(Cr + 1, 0);
-        P.cell_off.assign(Cr + 1, 0);
-        for (uint32_t c = 0; c < Cr; c++) {
-            P.dip_off[c + 1] = P.dip_off[c] + P.sizes[2 * c];
-            P.cell_off[c + 1] = P.cell_off[c] + P.sizes[2 * c + 1];
+    std::vector<std::vector<Part>> parts((size_t)world);
+    std::vector<std::vector<uint32_t>> part_of((size_t)world);   // rank-local cluster index -> launch
+    for (int r = 0; r < world; r++) {
+        uint64_t at = off[r];
+        uint32_t first = 0;
+        while (at < off[r + 1]) {
+            if (off[r + 1] - at < 4) throw std::runtime_error("gatherResults: truncated result string from rank " + std::to_string(r));
+            const uint32_t *p = all.data() + at;
+            const uint32_t Cr = p[0], ndr = p[1], ncr = p[2];
+            if (p[3] != S) throw std::runtime_error("gatherResults: rank " + std::to_string(r) + " sampled another number of samples");
+            const uint64_t at_stats = (4 + 2 * (uint64_t)Cr + (uint64_t)ndr * (1 + S) + 1) & ~1ull, words = at_stats + (uint64_t)ncr * 24;
+            if (off[r + 1] - at < words) throw std::runtime_error("gatherResults: truncated result string from rank " + std::to_string(r));
+            Part P;
+            P.sizes = p + 4;
+            P.keys = P.sizes + 2 * (size_t)Cr;
+            P.freq = P.keys + ndr;
+            P.stats = (const uint8_t *)(p + at_stats);
+            P.first = first;
+            P.count = Cr;
+            P.dip_off.assign((size_t)Cr + 1, 0);
+            P.cell_off.assign((size_t)Cr + 1, 0);
+            for (uint32_t c = 0; c < Cr; c++) {
+                P.dip_off[c + 1] = P.dip_off[c] + P.sizes[2 * c];
+                P.cell_off[c + 1] = P.cell_off[c] + P.sizes[2 * c + 1];
+            }
+            if (P.dip_off[Cr] != ndr || P.cell_off[Cr] != ncr) throw std::runtime_error("gatherResults: inconsistent result string from rank " + std::to_string(r));
+            part_of[r].insert(part_of[r].end(), Cr, (uint32_t)parts[r].size());
+            parts[r].push_back(std::move(P));
+            first += Cr;
+            at += words;
         }
     }
-    full.dip_off.assign(C + 1, 0);
-    full.cell_off.assign(C + 1, 0);
+    BatchResults full;
+    full.dip_off.assign((size_t)C + 1, 0);
+    full.cell_off.assign((size_t)C + 1, 0);
+    uint64_t nd = 0, nc = 0;
     for (uint32_t c = 0; c < C; c++) {
-        const Part &P = parts[c_rank[c]];
-        const uint32_t l = c_local[c];
-        const uint64_t e0 = P.dip_off[l], e1 = P.dip_off[l + 1], k0 = P.cell_off[l], k1 = P.cell_off[l + 1];
-        for (uint64_t e = e0; e < e1; e++) {
-            full.h1.push_back((uint16_t)(P.keys[e] & 0xFFFFu));
-            full.h2.push_back((uint16_t)(P.keys[e] >> 16));
-        }
-        full.freq.insert(full.freq.end(), P.freq + e0 * S, P.freq + e1 * S);
-        const size_t sat = full.stats.size();
-        full.stats.resize(sat + (k1 - k0) * 12);
-        if (k1 > k0) std::memcpy(full.stats.data() + sat, P.stats + k0 * 96, (k1 - k0) * 96);
-        full.dip_off[c + 1] = full.dip_off[c] + (e1 - e0);
-        full.cell_off[c + 1] = full.cell_off[c] + (k1 - k0);
+        if (c_local[c] >= part_of[c_rank[c]].size()) throw std::runtime_error("gatherResults: rank " + std::to_string(c_rank[c]) + " did not send all its clusters");
+        const Part &P = parts[c_rank[c]][part_of[c_rank[c]][c_local[c]]];
+        const uint32_t l = c_local[c] - P.first;
+        nd += P.dip_off[l + 1] - P.dip_off[l];
+        nc += P.cell_off[l + 1] - P.cell_off[l];
+        full.dip_off[c + 1] = nd;
+        full.cell_off[c + 1] = nc;
     }
-    if (full.h1.empty()) full.h1.push_back(0), full.h2.push_back(0);
-    if (full.freq.empty()) full.freq.push_back(0);
-    if (full.stats.empty()) full.stats.push_back(0);
+    full.h1.resize(std::max<uint64_t>(nd, 1));
+    full.h2.resize(std::max<uint64_t>(nd, 1));
+    full.freq.resize(std::max<uint64_t>(nd * S, 1));
+    full.stats.resize(std::max<uint64_t>(nc * 12, 1));
+    for (uint32_t c = 0; c < C; c++) {
+        const Part &P = parts[c_rank[c]][part_of[c_rank[c]][c_local[c]]];
+        const uint32_t l = c_local[c] - P.first;
+        const uint64_t e0 = P.dip_off[l], e1 = P.dip_off[l + 1], k0 = P.cell_off[l], k1 = P.cell_off[l + 1];
+        uint64_t to = full.dip_off[c];
+        for (uint64_t e = e0; e < e1; e++, to++) {
+            full.h1[to] = (uint16_t)(P.keys[e] & 0xFFFFu);
+            full.h2[to] = (uint16_t)(P.keys[e] >> 16);
+        }
+        if (e1 > e0) std::memcpy(full.freq.data() + full.dip_off[c] * S, P.freq + e0 * S, (e1 - e0) * S * 4);
+        if (k1 > k0) std::memcpy(full.stats.data() + full.cell_off[c] * 12, P.stats + k0 * 96, (k1 - k0) * 96);
+    }
     return full;
+}
+}  // namespace
+
+BatchResults gatherResults(Comm &comm, const GibbsBatchData &unit, const std::vector<std::vector<uint32_t>> &ids, const BatchResults &mine, uint32_t S) {
+    const uint32_t Cm = mine.dip_off.empty() ? 0u : (uint32_t)mine.dip_off.size() - 1;
+    const uint64_t nd = Cm ? mine.dip_off[Cm] : 0, nc = Cm ? mine.cell_off[Cm] : 0;
+    if (nd >> 32 || nc >> 32) throw std::runtime_error("gatherResults: more than 2^32 entries on one rank");
+    std::vector<uint32_t> w;
+    if (Cm) {   // (a rank without clusters sends nothing)
+        w.reserve(5 + 2 * (size_t)Cm + nd * (1 + S) + nc * 24);
+        w.push_back(Cm);
+        w.push_back((uint32_t)nd);
+        w.push_back((uint32_t)nc);
+        w.push_back(S);
+        for (uint32_t c = 0; c < Cm; c++) {
+            w.push_back((uint32_t)(mine.dip_off[c + 1] - mine.dip_off[c]));
+            w.push_back((uint32_t)(mine.cell_off[c + 1] - mine.cell_off[c]));
+        }
+        for (uint64_t e = 0; e < nd; e++) w.push_back((uint32_t)mine.h1[e] | ((uint32_t)mine.h2[e] << 16));
+        for (uint64_t i = 0; i < nd * S; i++) w.push_back(mine.freq[i]);
+        if (w.size() & 1) w.push_back(0);
+        const size_t at = w.size();
+        w.resize(at + nc * 24);
+        if (nc) std::memcpy(w.data() + at, mine.stats.data(), nc * 96);
+    }
+    std::vector<uint64_t> off;
+    const std::vector<uint32_t> all = comm.gatherWords(w, &off);
+    if (comm.rank() != 0) return BatchResults();
+    return rebuildOnRankZero(all, off, comm.world(), unit, ids, S);
+}
+
+BatchResults gatherResults(Comm &comm, const GibbsBatchData &unit, const std::vector<std::vector<uint32_t>> &ids, const DeviceWords &mine, uint32_t S) {
+    std::vector<uint64_t> off;
+    const std::vector<uint32_t> all = comm.gatherWordsDevice(mine.data(), mine.size(), &off);
+    if (comm.rank() != 0) return BatchResults();
+    return rebuildOnRankZero(all, off, comm.world(), unit, ids, S);
 }
 
 }  // namespace bthost

@@ -49,6 +49,9 @@ class Comm {
     std::vector<uint64_t> allgatherDevice(const uint8_t *d_local, uint64_t local_bytes, uint8_t *d_out, uint64_t capacity);
     // rank 0 receives every rank's words in rank order (offsets[world + 1]); the other ranks get an empty vector
     std::vector<uint32_t> gatherWords(const std::vector<uint32_t> &mine, std::vector<uint64_t> *offsets);
+    // the same for a word string that is already in device memory (bt_gibbs_result_words): nothing is staged through the host on the
+    // sending side, rank 0 copies the gathered string to the host once
+    std::vector<uint32_t> gatherWordsDevice(const uint32_t *d_mine, uint64_t num_words, std::vector<uint64_t> *offsets);
     void barrier();
 
   private:
@@ -70,8 +73,29 @@ class Comm {
 // descending cost dealt in serpentine order): deterministic, identical on every rank.  ids[r] = ascending group indices of rank r.
 std::vector<std::vector<uint32_t>> assignGroups(const GibbsBatchData &unit, int world);
 
+// a rank's launches' result strings (bt_gibbs_result_words), one after the other in device memory in the order of the launches
+class DeviceWords {
+  public:
+    explicit DeviceWords(bt_ctx *c) : ctx(c) {}
+    ~DeviceWords();
+    DeviceWords(const DeviceWords &) = delete;
+    DeviceWords &operator=(const DeviceWords &) = delete;
+    void append(const uint32_t *d_words, uint64_t num_words);
+    const uint32_t *data() const { return (const uint32_t *)p; }
+    uint64_t size() const { return n; }
+    uint32_t parts() const { return k; }
+
+  private:
+    bt_ctx *ctx;
+    void *p = nullptr;
+    uint64_t n = 0, cap = 0;
+    uint32_t k = 0;
+};
+
 // the collected samples of all ranks' groups, rebuilt on rank 0 in the unit's cluster order (so that what follows — getGenotypes,
 // GenotypeWriter — sees exactly what a one-rank run hands it); every rank calls it, the others get an empty result
 BatchResults gatherResults(Comm &comm, const GibbsBatchData &unit, const std::vector<std::vector<uint32_t>> &ids, const BatchResults &mine, uint32_t num_samples);
+// the same from the rank's result strings in device memory (the product's path: the launches' results never visit the sending rank's host)
+BatchResults gatherResults(Comm &comm, const GibbsBatchData &unit, const std::vector<std::vector<uint32_t>> &ids, const DeviceWords &mine, uint32_t num_samples);
 
 }  // namespace bthost

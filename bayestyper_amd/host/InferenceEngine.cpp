@@ -152,6 +152,10 @@ struct GpuSampler : GibbsSampler {
         else check(bt_gibbs_noise_iteration(g, noise, collect ? 1 : 0, h.data()), "bt_gibbs_noise_iteration");
         return h;
     }
+    bool resultWords(const uint32_t **d_words, uint64_t *num_words) override {
+        check(bt_gibbs_result_words(g, d_words, num_words), "bt_gibbs_result_words");
+        return true;
+    }
     BatchResults results(uint32_t num_clusters) override {
         BatchResults r;
         uint64_t nd = 0, nc = 0;
@@ -469,9 +473,25 @@ void InferenceEngine::runDefault(const GibbsBatchData &batch, const CountDistrib
     stage.reset(new StageScope("Gibbs: sampling launch (20 x 350 sweeps)"));
     sampler->run();
     sampler->sync();
-    stage.reset(new StageScope("Gibbs: result fetch (device pack + copy)"));
+    stage.reset();
+    handOver(sampler, batch, collect);
+}
+
+// a finished launch's collected samples -> the caller; the sampler is released (its HBM is free before the next one is built)
+void InferenceEngine::handOver(std::unique_ptr<Sampler> &sampler, const GibbsBatchData &batch, const Collector &collect) {
+    const uint32_t *d_words = nullptr;
+    uint64_t num_words = 0;
+    if (wire_collect) {
+        StageScope stage("Gibbs: result string (device pack, stays on the device)");
+        if (sampler->resultWords(&d_words, &num_words)) {
+            wire_collect(batch, d_words, num_words);
+            sampler.reset();
+            return;
+        }
+    }
+    std::unique_ptr<StageScope> stage(new StageScope("Gibbs: result fetch (device pack + copy)"));
     const BatchResults r = sampler->results(batch.numClusters());
-    sampler.reset();   // frees the launch's HBM before the next one is built
+    sampler.reset();
     stage.reset();
     collect(batch, r);
 }
@@ -512,11 +532,7 @@ void InferenceEngine::estimateNoiseAndGenotypes(const GibbsBatchData &unit, Coun
         runNoiseChain(sampler.get(), cd, chain, opt.burn_in + 1, out, nullptr);
         cd->resetNoiseRates();
     }
-    if (sampler) {
-        const BatchResults r = sampler->results(unit.numClusters());
-        sampler.reset();
-        collect(unit, r);
-    }
+    if (sampler) handOver(sampler, unit, collect);
     if (!quiet) std::cout << "[" << getLocalTime() << "] Wrote noise parameters to " << output_prefix << ".txt" << std::endl;
 }
 

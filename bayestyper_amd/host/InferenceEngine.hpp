@@ -98,6 +98,8 @@ struct GibbsSampler {
     typedef std::function<void(uint64_t *d_hist, size_t n)> DeviceReducer;   // enqueues the all-reduce of a DEVICE histogram on the context's stream
     virtual bool noiseChain(CountDistribution *, uint32_t, uint32_t, const DeviceReducer &, std::vector<double> *) { return false; }
     virtual BatchResults results(uint32_t num_clusters) = 0;
+    // the same results as one word string in the sampler's DEVICE memory (bt_gibbs_result_words; valid while the sampler lives); false: not supported
+    virtual bool resultWords(const uint32_t ** /*d_words*/, uint64_t * /*num_words*/) { return false; }
 };
 typedef std::function<std::unique_ptr<GibbsSampler>(const bt_gibbs_params &, const GibbsBatchData &)> SamplerFactory;
 
@@ -105,6 +107,10 @@ class InferenceEngine {
   public:
     // collected samples of a launch: `batch` holds the launched groups (group_index = index in the unit), results in its cluster order
     typedef std::function<void(const GibbsBatchData &batch, const BatchResults &results)> Collector;
+    // the same hand-over for a run of several ranks: the launch's result string in device memory (GibbsSampler::resultWords), which the caller
+    // keeps on the device for the gather to rank 0.  Used instead of the Collector whenever it is set and the sampler has the string.
+    typedef std::function<void(const GibbsBatchData &batch, const uint32_t *d_words, uint64_t num_words)> WireCollector;
+    void setWireCollector(WireCollector w) { wire_collect = std::move(w); }
     typedef std::function<void(uint64_t *hist, size_t n)> HistReducer;   // sums the S*256 counters over all ranks in place
 
     InferenceEngine(bt_ctx *ctx, std::vector<uint8_t> gender, std::vector<std::string> sample_names, const GibbsOptions &options, HistReducer reduce_hist = nullptr);
@@ -134,6 +140,8 @@ class InferenceEngine {
     void runDefault(const GibbsBatchData &batch, const CountDistribution &count_distribution, const Collector &collect);
     bt_gibbs_params params(uint32_t noise_seeding) const;
 
+    void handOver(std::unique_ptr<Sampler> &sampler, const GibbsBatchData &batch, const Collector &collect);
+    WireCollector wire_collect;
     bt_ctx *ctx;
     std::vector<uint8_t> gender;
     std::vector<std::string> sample_names;

@@ -294,6 +294,51 @@ int bth_comm_selftest(unsigned rounds, char *err, unsigned err_len) {
             } else if (!g.empty())
                 throw std::runtime_error("gather: a rank other than 0 received data");
         }
+        {   // gatherResults: a unit of 11 groups dealt to the ranks by index; cluster c has 1 + c % 3 entries and 2 + c % 2 cells whose values name it
+            const uint32_t S = 2, G = 11;
+            GibbsBatchData unit;
+            unit.group_cluster_off.push_back(0);
+            for (uint32_t g = 0; g < G; g++) {
+                unit.group_index.push_back(g);
+                for (uint32_t k = 0; k < 1 + g % 2; k++) unit.cluster_idx.push_back((uint32_t)unit.cluster_idx.size());
+                unit.group_cluster_off.push_back((uint32_t)unit.cluster_idx.size());
+            }
+            std::vector<std::vector<uint32_t>> ids((size_t)W);
+            for (uint32_t g = 0; g < G; g++)
+                if (W < 3 || g % W != 1 || g % 2) ids[g % W].push_back(g);
+                else ids[0].push_back(g);   // (uneven shares)
+            for (auto &v : ids) std::sort(v.begin(), v.end());
+            auto fill = [&](const std::vector<uint32_t> &clusters) {
+                BatchResults r;
+                r.dip_off.push_back(0);
+                r.cell_off.push_back(0);
+                for (uint32_t cl : clusters) {
+                    for (uint32_t e = 0; e < 1 + cl % 3; e++) {
+                        r.h1.push_back((uint16_t)(cl + e));
+                        r.h2.push_back((uint16_t)(e ? 0xFFFFu : cl));
+                        for (uint32_t smp = 0; smp < S; smp++) r.freq.push_back(1000 * cl + 10 * e + smp);
+                    }
+                    for (uint32_t k = 0; k < 2 + cl % 2; k++)
+                        for (uint32_t j = 0; j < 12; j++) r.stats.push_back(cl + k / 8.0 + j / 1024.0);
+                    r.dip_off.push_back(r.h1.size());
+                    r.cell_off.push_back(r.stats.size() / 12);
+                }
+                return r;
+            };
+            std::vector<uint32_t> my_clusters, all_clusters;
+            for (uint32_t g : ids[R])
+                for (uint32_t cl = unit.group_cluster_off[g]; cl < unit.group_cluster_off[g + 1]; cl++) my_clusters.push_back(cl);
+            for (uint32_t cl = 0; cl < unit.numClusters(); cl++) all_clusters.push_back(cl);
+            const BatchResults got = gatherResults(*c, unit, ids, fill(my_clusters), S), want = fill(all_clusters);
+            if (R == 0) {
+                const uint64_t nd = want.dip_off.back(), nc = want.cell_off.back();
+                if (got.dip_off != want.dip_off || got.cell_off != want.cell_off) throw std::runtime_error("gatherResults: wrong offsets");
+                if (!std::equal(want.h1.begin(), want.h1.end(), got.h1.begin()) || !std::equal(want.h2.begin(), want.h2.end(), got.h2.begin())) throw std::runtime_error("gatherResults: wrong keys");
+                if (!std::equal(want.freq.begin(), want.freq.begin() + nd * S, got.freq.begin())) throw std::runtime_error("gatherResults: wrong counts");
+                if (!std::equal(want.stats.begin(), want.stats.begin() + nc * 12, got.stats.begin())) throw std::runtime_error("gatherResults: wrong statistics");
+            } else if (!got.dip_off.empty())
+                throw std::runtime_error("gatherResults: a rank other than 0 received results");
+        }
         c->barrier();
     } catch (const std::exception &e) {
         Comm::markFailed();

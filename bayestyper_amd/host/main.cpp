@@ -325,6 +325,7 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     gibbs.chains = (uint32_t)options.getUInt("number-of-gibbs-chains");
     gibbs.kmer_subsampling_rate = options.getFloat("kmer-subsampling-rate");
     gibbs.max_haplotype_variant_kmers = (uint32_t)options.getUInt("max-haplotype-variant-kmers");
+    if (const char *e = getenv("BT_MAX_GROUPS_PER_LAUNCH")) gibbs.max_groups_per_launch = (uint32_t)strtoul(e, nullptr, 0);   // (tests: several launches on a small unit)
     if (gibbs.burn_in == 0 || gibbs.samples == 0 || gibbs.chains == 0) throw std::runtime_error("--gibbs-burn-in, --gibbs-samples and --number-of-gibbs-chains must be positive");
     if (!(gibbs.kmer_subsampling_rate > 0) || gibbs.kmer_subsampling_rate > 1) throw std::runtime_error("--kmer-subsampling-rate must be in (0, 1]");
     const std::pair<float, float> noise_rate_prior = options.getFloatPair("noise-rate-prior");
@@ -517,10 +518,25 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
             mine.freq.insert(mine.freq.end(), r.freq.begin(), r.freq.begin() + nd * S);
             mine.stats.insert(mine.stats.end(), r.stats.begin(), r.stats.begin() + nc * 12);
         };
+        // the product's path: every launch's results are packed into one word string ON THE DEVICE (bt_gibbs_result_words), the strings wait in
+        // device memory and go into the gather from there; `keep` only serves a sampler without such a string (BT_GATHER_FROM_HOST=1: the old path)
+        DeviceWords on_device(ctx.h);
+        uint64_t device_clusters = 0;
+        if (!getenv("BT_GATHER_FROM_HOST"))
+            inference_engine.setWireCollector([&](const GibbsBatchData &b, const uint32_t *d_words, uint64_t n) {
+                on_device.append(d_words, n);
+                device_clusters += b.numClusters();
+            });
         if (!noise_genotyping) inference_engine.estimateGenotypes(my_batch, count_distribution, keep);
         else inference_engine.estimateNoiseAndGenotypes(my_batch, &count_distribution, keep, noise_prefix);
-        if (mine.dip_off.size() != (size_t)my_batch.numClusters() + 1) throw std::runtime_error("rank " + std::to_string(rank) + ": collected samples do not cover the rank's clusters");
-        const BatchResults all = gatherResults(*comm, batch, rank_groups, mine, (uint32_t)S);
+        const bool from_host = mine.dip_off.size() > 1;
+        if ((from_host ? mine.dip_off.size() - 1 : device_clusters) != (size_t)my_batch.numClusters() || (from_host && device_clusters))
+            throw std::runtime_error("rank " + std::to_string(rank) + ": collected samples do not cover the rank's clusters");
+        std::unique_ptr<StageScope> gather_stage(new StageScope("gather of the collected samples to rank 0"));
+        const BatchResults all = from_host ? gatherResults(*comm, batch, rank_groups, mine, (uint32_t)S) : gatherResults(*comm, batch, rank_groups, on_device, (uint32_t)S);
+        gather_stage.reset();
+        std::cout << "[" << rank << "] gather: " << (from_host ? "from the host" : "from the device") << ", " << (from_host ? 1u : on_device.parts()) << " launch(es), "
+                  << (from_host ? (uint64_t)0 : on_device.size()) * 4 << " bytes of result strings on this rank" << std::endl;
         if (rank == 0) collect(batch, all);
     }
     if (rank != 0) {   // rank 0 writes the outputs; the other ranks' parameter files are copies of its own

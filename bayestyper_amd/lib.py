@@ -40,6 +40,7 @@ bt_free = _sig("bt_free", [vp, vp])
 bt_memset = _sig("bt_memset", [vp, vp, C.c_int, C.c_size_t])
 bt_memcpy_h2d = _sig("bt_memcpy_h2d", [vp, vp, vp, C.c_size_t])
 bt_memcpy_d2h = _sig("bt_memcpy_d2h", [vp, vp, vp, C.c_size_t])
+bt_memcpy_d2d = _sig("bt_memcpy_d2d", [vp, vp, vp, C.c_size_t])
 bt_timer_create = _sig("bt_timer_create", [vp, C.POINTER(vp)])
 bt_timer_destroy = _sig("bt_timer_destroy", [vp])
 bt_timer_start = _sig("bt_timer_start", [vp])
@@ -506,6 +507,7 @@ bt_ctx_clone = _sig("bt_ctx_clone", [vp, C.POINTER(vp)])
 bt_gibbs_reset_groups = _sig("bt_gibbs_reset_groups", [vp])
 bt_gibbs_result_sizes = _sig("bt_gibbs_result_sizes", [vp, u64p, u64p])
 bt_gibbs_result_fetch = _sig("bt_gibbs_result_fetch", [vp] * 7)
+bt_gibbs_result_words = _sig("bt_gibbs_result_words", [vp, C.POINTER(vp), u64p])
 bt_gibbs_trace_enable = _sig("bt_gibbs_trace_enable", [vp, C.c_uint32])
 bt_gibbs_trace_fetch = _sig("bt_gibbs_trace_fetch", [vp, vp, C.c_uint64, u64p])
 bt_gibbs_posterior_summary = _sig("bt_gibbs_posterior_summary", [vp, vp])
@@ -571,6 +573,23 @@ class NoiseModel:
         if self.h:
             bt_noise_model_destroy(self.h)
             self.h = None
+
+
+def parse_result_words(w):
+    """one launch's word string (bt_gibbs_result_words) -> (the dictionary Gibbs.results() returns, words consumed)"""
+    w = np.ascontiguousarray(w, np.uint32)
+    Cn, nd, nc, S = (int(x) for x in w[:4])
+    sizes = w[4:4 + 2 * Cn].reshape(Cn, 2).astype(np.uint64)
+    at = 4 + 2 * Cn
+    keys = w[at:at + nd]
+    at += nd
+    freq = w[at:at + nd * S].reshape(nd, S)
+    at = (at + nd * S + 1) & ~1
+    stats = w[at:at + nc * 24].copy().view(np.float64).reshape(nc, 3, 4)
+    at += nc * 24
+    dip_off = np.concatenate([[0], np.cumsum(sizes[:, 0])]).astype(np.uint64)
+    cell_off = np.concatenate([[0], np.cumsum(sizes[:, 1])]).astype(np.uint64)
+    return {"dip_off": dip_off, "h1": (keys & 0xFFFF).astype(np.uint16), "h2": (keys >> 16).astype(np.uint16), "freq": freq.copy(), "cell_off": cell_off, "stats": stats}, at
 
 
 class Gibbs:
@@ -686,6 +705,18 @@ class Gibbs:
         check(bt_gibbs_result_fetch(self.h, _np_ptr(dip_off), _np_ptr(h1), _np_ptr(h2), _np_ptr(freq), _np_ptr(cell_off), _np_ptr(stats)))
         return {"dip_off": dip_off, "h1": h1[:nd], "h2": h2[:nd], "freq": freq[: nd * self.S].reshape(nd, self.S), "cell_off": cell_off,
                 "stats": stats[: nc * 12].reshape(nc, 3, 4)}
+
+    def result_words(self):
+        """the results as one word string in DEVICE memory (bt_gibbs_result_words): (device pointer, words); the sampler owns the buffer"""
+        p, n = vp(), C.c_uint64()
+        check(bt_gibbs_result_words(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def result_words_host(self):
+        p, n = self.result_words()
+        out = np.zeros(n, np.uint32)
+        check(bt_memcpy_d2h(self.ctx.h, _np_ptr(out), p, out.nbytes))
+        return out
 
     def close(self):
         if self.h:

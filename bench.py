@@ -127,15 +127,6 @@ def rank_batch(groups, S, rank, world, scaling, templates=None):
     return flat, flat["num_clusters"] * world, None, None
 
 
-def result_words(res, num_clusters):
-    """a launch's results as one word string (what the host layer's gatherResults ships between ranks): [clusters, entries], entries per cluster,
-    (h1 | h2 << 16) per entry, the per-sample counts, the allele k-mer statistics (doubles as word pairs)"""
-    n_ent = np.diff(res["dip_off"]).astype(np.uint32)
-    keys = res["h1"].astype(np.uint32) | (res["h2"].astype(np.uint32) << 16)
-    return np.concatenate([np.asarray([num_clusters, len(keys)], np.uint32), n_ent, keys, np.ascontiguousarray(res["freq"], np.uint32).reshape(-1),
-                           np.ascontiguousarray(res["stats"], np.float64).reshape(-1).view(np.uint32)])
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,18 +274,23 @@ def main():
         gibbs.run()
         if timed:
             t_gibbs.stop()
-        # (3) the launch's results in the product's layout -> host (-> rank 0)
+        # (3) the launch's results: one rank -> host in the product's layout; several ranks -> packed into one word string on the device
+        # (bt_gibbs_result_words), gathered from there to rank 0 (RCCL), which copies the gathered string to pinned host memory once — what
+        # the executable's ranks do (host/main.cpp: DeviceWords + gatherResults); no rank's results visit its own host
         if timed:
             ctx.sync()   # (the launch is asynchronous: wait for it here so that the fetch is timed by itself; results() would wait anyway)
         tf = time.perf_counter()
-        res = gibbs.results()
+        res = None
+        if world == 1:
+            res = gibbs.results()
+        else:
+            d_mine, n_mine = gibbs.result_words()
         fetch_s = time.perf_counter() - tf
         gather_s = 0.0
         if world > 1:
             tg = time.perf_counter()
-            words = torch.from_numpy(result_words(res, C).view(np.int32)).to(dev)
             n_all = torch.zeros(world, dtype=torch.int64, device=dev)
-            n_all[rank] = words.numel()
+            n_all[rank] = n_mine
             both_sync()
             comm.allreduce(n_all.data_ptr(), world)
             both_sync()
@@ -302,7 +298,7 @@ def main():
             if state["d_all"] is None or state["d_all"].numel() < (total if rank == 0 else 2):
                 state["d_all"] = torch.zeros(total if rank == 0 else 2, dtype=torch.int32, device=dev)
             both_sync()
-            comm.gather_words(words.data_ptr(), words.numel(), state["d_all"].data_ptr(), state["d_all"].numel())
+            comm.gather_words(d_mine, n_mine, state["d_all"].data_ptr(), state["d_all"].numel())
             ctx.sync()
             if rank == 0:   # rank 0 holds every rank's results on the host, as the executable's rank 0 does (pinned staging, allocated once)
                 if state.get("h_all") is None or state["h_all"].numel() < total:
@@ -310,6 +306,7 @@ def main():
                 state["h_all"][:total].copy_(state["d_all"][:total], non_blocking=True)
             both_sync()
             gather_s = time.perf_counter() - tg
+            state["gather_words"] = (n_mine, total)
             if strong:
                 lib.check(lib.bt_gibbs_posterior_summary(gibbs.h, d_summary.data_ptr()))
                 comm.gather_words(d_summary.data_ptr(), C * S * 2, d_gathered.data_ptr(), d_gathered.numel())
@@ -344,7 +341,7 @@ def main():
         mine = [C, float(np.mean(gibbs_ms)), float(np.mean([sum(x) for x in kmc_ms])), float(np.mean(fetch_ms)), float(np.mean(gather_ms))]
         rows = [None] * world
         dist.all_gather_object(rows, mine)
-        per_rank = [{"rank": r, "clusters": int(x[0]), "gibbs_launch_ms": x[1], "kmc_scans_ms": x[2], "result_fetch_ms": x[3], "gather_ms": x[4]} for r, x in enumerate(rows)]
+        per_rank = [{"rank": r, "clusters": int(x[0]), "gibbs_launch_ms": x[1], "kmc_scans_ms": x[2], "result_pack_ms": x[3], "gather_ms": x[4]} for r, x in enumerate(rows)]
     hits = int(d_hits.item())
     st = table.status()
     if st["overflowed"]:

@@ -67,6 +67,7 @@ int bt_free(bt_ctx *ctx, void *d_ptr);
 int bt_memset(bt_ctx *ctx, void *d_ptr, int value, size_t bytes);
 int bt_memcpy_h2d(bt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int bt_memcpy_d2h(bt_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int bt_memcpy_d2d(bt_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 
 /* HIP-event timing on the context's stream (bench.py's roofline leg) */
 typedef struct bt_timer bt_timer;
@@ -516,6 +517,12 @@ int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t
  * for stat in {count_stats, fraction_stats, mean_stats} (KmerStats.cpp:107-121); h_cell_off[C+1] */
 int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, uint16_t *h_dip_h2, uint32_t *h_dip_freq,
                           uint64_t *h_cell_off, double *h_stats);
+/* The same results as ONE string of 32-bit words in DEVICE memory, for the gather to rank 0 (bt_comm_gather_summaries) without a
+ * host round trip — the reference's threads push their genotypes into one queue (InferenceEngine.cpp:335-382, 384-399); with
+ * one process per GPU that queue is the gather.  Layout: [C, entries, cells, S], [entries, cells] per cluster, h1 | h2 << 16
+ * per entry (order of bt_gibbs_result_fetch), counts [entry][S], one pad word if the count so far is odd, statistics
+ * [cell][12] doubles.  *d_words belongs to the sampler (valid until the next call or bt_gibbs_destroy); complete on return. */
+int bt_gibbs_result_words(bt_gibbs *g, const uint32_t **d_words, uint64_t *num_words);
 /* compact posterior summary on the DEVICE (input of the cross-GPU gather to rank 0): for cluster c, sample s
  * d_out[(c*S+s)*2] = h1 | h2<<16 of the most frequently sampled diplotype, d_out[(c*S+s)*2+1] = its frequency */
 int bt_gibbs_posterior_summary(bt_gibbs *g, uint32_t *d_out);

@@ -37,20 +37,32 @@ def test_strong_scaling_deals_one_batch():
 
 
 def test_result_words_round_trip():
-    import bench
+    """the wire string of a launch's results (include/btgpu.h: bt_gibbs_result_words; host/Comm.cpp builds the same from host arrays): header,
+    sizes per cluster, keys, counts, pad to an even word count, statistics"""
+    from bayestyper_amd import lib
 
     C, S = 3, 2
     res = {"dip_off": np.asarray([0, 2, 3, 6], np.uint64), "h1": np.asarray([0, 0, 1, 0, 1, 65535], np.uint16), "h2": np.asarray([0, 1, 1, 65535, 65535, 65535], np.uint16),
            "freq": np.arange(12, dtype=np.uint32).reshape(6, S), "cell_off": np.asarray([0, 4, 8, 12], np.uint64), "stats": np.linspace(0, 1, 12 * 12).reshape(12, 3, 4)}
-    w = bench.result_words(res, C)
-    assert w.dtype == np.uint32 and int(w[0]) == C and int(w[1]) == 6
-    n_ent = w[2:2 + C]
-    assert np.array_equal(np.concatenate([[0], np.cumsum(n_ent)]), res["dip_off"])
-    keys = w[2 + C:2 + C + 6]
-    assert np.array_equal(keys & 0xFFFF, res["h1"]) and np.array_equal(keys >> 16, res["h2"])
-    freq = w[2 + C + 6:2 + C + 6 + 12]
-    assert np.array_equal(freq, res["freq"].reshape(-1))
-    assert np.array_equal(w[2 + C + 6 + 12:].view(np.float64), res["stats"].reshape(-1))
+    sizes = np.stack([np.diff(res["dip_off"]), np.diff(res["cell_off"])], axis=1).astype(np.uint32).reshape(-1)
+    keys = res["h1"].astype(np.uint32) | (res["h2"].astype(np.uint32) << 16)
+    head = np.concatenate([np.asarray([C, 6, 12, S], np.uint32), sizes, keys, res["freq"].reshape(-1)])
+    assert len(head) % 2 == 0
+    for pad in (0, 1):   # (an odd count before the statistics gets one pad word: here by way of one more entry)
+        if pad:
+            r2 = dict(res, dip_off=np.asarray([0, 2, 3, 7], np.uint64), h1=np.append(res["h1"], 7).astype(np.uint16), h2=np.append(res["h2"], 9).astype(np.uint16),
+                      freq=np.arange(14, dtype=np.uint32).reshape(7, S))
+            sizes2 = np.stack([np.diff(r2["dip_off"]), np.diff(r2["cell_off"])], axis=1).astype(np.uint32).reshape(-1)
+            k2 = r2["h1"].astype(np.uint32) | (r2["h2"].astype(np.uint32) << 16)
+            h2 = np.concatenate([np.asarray([C, 7, 12, S], np.uint32), sizes2, k2, r2["freq"].reshape(-1)])
+            assert len(h2) % 2 == 1
+            w, want = np.concatenate([h2, np.zeros(1, np.uint32), res["stats"].reshape(-1).view(np.uint32)]), r2
+        else:
+            w, want = np.concatenate([head, res["stats"].reshape(-1).view(np.uint32)]), res
+        got, used = lib.parse_result_words(np.concatenate([w, w]))   # (a rank's string: its launches' strings one after the other)
+        assert used == len(w)
+        for key in want:
+            assert np.array_equal(got[key], want[key]), key
 
 
 def test_profile_summaries_are_matched_per_part():

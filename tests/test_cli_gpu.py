@@ -522,6 +522,15 @@ def _sharded_equals_single(oracle, tmp_path, ranks_env, noise_genotyping):
     many = str(tmp_path / "many")
     out = _genotype(many, unit_prefix, ds["dir"], seed, gibbs, extra, env=ranks_env)
     assert "Rank 0 of " in out and "Merged the sample counts of" in out
+    # the collected samples go into the gather as result strings packed ON THE DEVICE (bt_gibbs_result_words), one per launch, on every rank
+    import re
+
+    lines = [out] + [open(many + f".rank{r_}.log").read() for r_ in range(1, int(ranks_env["BT_GPUS"]))]
+    for r_, text in enumerate(lines):
+        m = re.search(r"\[%d\] gather: from the device, (\d+) launch\(es\), (\d+) bytes" % r_, text)
+        assert m and int(m.group(2)) > 0, text[-800:]
+        if "BT_MAX_GROUPS_PER_LAUNCH" in ranks_env:
+            assert int(m.group(1)) > 1
     a, b = _outputs(one), _outputs(many)
     assert a[0] == b[0] and len(a[0]) > 300
     assert a[1] == b[1] and a[2] == b[2]
@@ -535,7 +544,10 @@ def _sharded_equals_single(oracle, tmp_path, ranks_env, noise_genotyping):
 def test_three_ranks_sharing_one_gpu(oracle, tmp_path, noise_genotyping):
     """three ranks on GPU 0 exchanging through files (BT_COMM_TRANSPORT=files: RCCL forms no communicator over ranks that share a GPU) — the
     sharded run's logic on a one-GPU box"""
-    _sharded_equals_single(oracle, tmp_path, {"BT_GPUS": "3", "BT_COMM_TRANSPORT": "files", "BT_DEVICE": "0"}, noise_genotyping)
+    env = {"BT_GPUS": "3", "BT_COMM_TRANSPORT": "files", "BT_DEVICE": "0"}
+    if not noise_genotyping:
+        env["BT_MAX_GROUPS_PER_LAUNCH"] = "23"   # (several launches per rank: their strings are concatenated on the device)
+    _sharded_equals_single(oracle, tmp_path, env, noise_genotyping)
 
 
 def test_two_ranks_over_rccl_when_two_gpus_are_visible(oracle, tmp_path):

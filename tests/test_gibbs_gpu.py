@@ -25,6 +25,11 @@ def run_both(gpu_ctx, oracle, flat, trace=0, flat_gpu=None, **kw):
     gg.run()
     gpu_ctx.sync()
     ro, rg = og.results(), gg.results()
+    # the same results as the word string a rank hands to the gather (bt_gibbs_result_words, packed on the device)
+    rw, used = lib.parse_result_words(gg.result_words_host())
+    assert used == gg.result_words()[1] and set(rw) == set(rg)
+    for key in rg:
+        assert np.array_equal(rw[key], rg[key], equal_nan=(key == "stats")), key
     tr = None
     if trace:
         goff = flat["group_cluster_off"]
