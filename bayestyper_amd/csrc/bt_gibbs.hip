@@ -1440,13 +1440,23 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         // (production is in chunks of four words: a ring of `cap` words can be filled up to cap - 3 ahead)
         d.ring_cap[0] = 8;
         while (d.ring_cap[0] < 2 * S + 3 && d.ring_cap[0] < 64) d.ring_cap[0] *= 2;
-        d.ring_cap[1] = d.nvm == 1 && d.Hm == 2 && d.NMm == 0 ? 32 : 16;   // (two-haplotype clusters: the LDS block is small, fewer refills in the middle of a visit)
+        // 32 words for the frequency generator: a refill in the middle of a visit happens where the lanes of a wavefront have diverged (every lane pays for
+        // every other lane's refill), the top-up at the start of a visit is one pass for all of them.  Measured (round 5, the bench mixtures): 16 -> 32 words
+        // for the tiles of 4 and 16 groups: S = 3 3.80 -> 3.69 s, S = 10 12.8 -> 11.7 s; 64 words cost more LDS than they save (3.75 s / 12.1 s).
+        d.ring_cap[1] = 32;
         if (params->noise_seeding && !getenv("BT_GIBBS_NO_NOISE_WIDTHS")) {   // (a noise sampler's LDS block decides how many tiles its resident chain can hold)
             d.ring_cap[1] = 16;                                                  // 4 KB less per two-haplotype tile
             if (d.ring_cap[0] > 16) d.ring_cap[0] = 16;                          // seven samples and more: the diplotype draws of a visit top the ring up on the way (another 4 KB)
         }
         if (const char *e = getenv("BT_GIBBS_RING0")) d.ring_cap[0] = (uint32_t)atoi(e);
         if (const char *e = getenv("BT_GIBBS_RING1")) d.ring_cap[1] = (uint32_t)atoi(e);
+        {   // (tuning) per kind of narrow tile: RING1_Y = single clusters in tiles of 8..32 groups, RING1_X = tiles of up to 4 groups; RING1_W = every other non-two-haplotype tile
+            const bool two_hap = d.nvm == 1 && d.Hm == 2 && d.NMm == 0;
+            const char *e = two_hap ? nullptr : (tile_w <= 4 ? getenv("BT_GIBBS_RING1_X") : (tile_w <= 32 ? getenv("BT_GIBBS_RING1_Y") : getenv("BT_GIBBS_RING1_W")));
+            if (e) d.ring_cap[1] = (uint32_t)atoi(e);
+            e = two_hap ? nullptr : (tile_w <= 4 ? getenv("BT_GIBBS_RING0_X") : (tile_w <= 32 ? getenv("BT_GIBBS_RING0_Y") : getenv("BT_GIBBS_RING0_W")));
+            if (e) d.ring_cap[0] = (uint32_t)atoi(e);
+        }
         d.ring_len = d.ring_cap[0] + d.ring_cap[1] + 2 * MT_RING_HDR;
         len[A_RING] = nv * d.ring_len;
         uint64_t off = 0, in_bytes = 0;
