@@ -620,8 +620,8 @@ struct RouteRec {
 
 // ---------------------------------------------------------------------------------------------
 // Partitioned scan.  ONE kernel hashes and writes every route record once, grouped by the upper 8 route bits, and the probe reads it once:
-//   kmc_partition_kernel  — a workgroup takes slabs of 4096 records: the slab's bytes into LDS in one coalesced burst; the ntHash is computed
-//                           straight from the raw record bytes (a KMC suffix byte holds four symbols, first symbol in the top bits: one 256-entry
+//   kmc_partition_kernel  — a workgroup takes slabs of 4096 records: every lane fetches its eight records' dwords (one contiguous run per wavefront); the
+//                           ntHash is computed straight from the raw record bytes (a KMC suffix byte holds four symbols, first symbol in the top bits: one 256-entry
 //                           LDS table per four symbols; the prefix's part once per slab) — the k-mer itself is never assembled here —, an LDS
 //                           histogram over the 256 buckets, one reservation per bucket and slab in the bucket's region (atomicAdd on its cursor),
 //                           a counting sort of the slab in the same LDS, then the runs (about 16 records = 192 bytes per bucket and slab) are
@@ -649,9 +649,9 @@ constexpr unsigned PU = BT_KMC_PU;   // records per lane and iteration of the pr
 
 __device__ inline uint32_t route_bucket(uint64_t h, uint32_t bloom_k) { return (uint32_t)((nthash64_seeded(h, bloom_k, BT_ROUTE_SEED) & (uint64_t)(BT_NUM_SUB_BLOOMS - 1u)) >> 8); }
 
-// dynamic LDS: the slab's raw record bytes (read once, coalesced), later overwritten by the slab's route records in bucket order; then one byte
-// per sorted record: its bucket
-static size_t partition_main_bytes(uint32_t rec_size) { return (std::max<size_t>((size_t)PSLAB * rec_size + 48, (size_t)PSLAB * sizeof(RouteRec)) + 15) & ~(size_t)15; }
+// dynamic LDS: the slab's route records in bucket order; then one byte per sorted record: its bucket  (the raw record bytes no longer pass through
+// LDS: every lane fetches its records' dwords from global memory)
+static size_t partition_main_bytes(uint32_t /*rec_size*/) { return ((size_t)PSLAB * sizeof(RouteRec) + 15) & ~(size_t)15; }
 static size_t partition_lds_bytes(uint32_t rec_size) { return partition_main_bytes(rec_size) + PSLAB; }
 
 // ntHash state after the p prefix symbols (most significant symbol first)
@@ -665,7 +665,6 @@ __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomV
                                                                uint64_t n_total, uint32_t main_bytes, RouteRec *__restrict__ part, uint32_t cap, unsigned int *__restrict__ cursor,
                                                                uint32_t *__restrict__ hits, unsigned int *__restrict__ num_hits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t part_lds[];
-    uint8_t *raw = part_lds;
     RouteRec *sorted = reinterpret_cast<RouteRec *>(part_lds);   // [PSLAB], after the slab has been hashed
     uint8_t *sbucket = part_lds + main_bytes;                   // [PSLAB] bucket of sorted[i]
     __shared__ uint64_t block_prefix[2], block_phash[2];
@@ -689,18 +688,39 @@ __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomV
             block_phash[threadIdx.x] = kmc_prefix_hash(pf, v.p);
         }
         const uint64_t byte0 = (rec_offset + slab0) * v.rec_size;
-        const unsigned nbytes = slab_n * v.rec_size;
-        const uint64_t a0 = byte0 & ~15ULL;
-        const unsigned lead = (unsigned)(byte0 - a0);
-        const unsigned nvec = (lead + nbytes + 15u) / 16u;
-        for (unsigned q = threadIdx.x; q < nvec; q += PBLOCK) {
-            const uint64_t off = a0 + (uint64_t)q * 16u;
-            if (off + 16u <= total_bytes) *reinterpret_cast<uint4 *>(&raw[q * 16u]) = *reinterpret_cast<const uint4 *>(records + off);
-            else
-                for (unsigned z = 0; z < 16u; ++z) raw[q * 16u + z] = (off + z < total_bytes) ? records[off + z] : 0;
-        }
         __syncthreads();
         const uint64_t p_first = block_prefix[0], p_last = block_prefix[1];
+        // Every lane fetches ITS records straight from global memory (round 5; before, the slab's bytes went through LDS and every suffix byte was a
+        // ds_read_u8 at a 13-byte lane stride: four-way bank conflicts on 13 of the 28 LDS instructions per record): the dwords from the 4-byte aligned
+        // address below the record, PRPT records in flight per lane — a wavefront's 64 windows overlap into one contiguous 832-byte run —, then
+        // v_alignbyte shifts the suffix to the front of the window.  (`records` is 16-byte aligned: bt_kmc_scan_run checks it.)
+        constexpr unsigned NW = 4;   // suffix words (k - p <= 64 symbols = 16 bytes)
+        uint32_t win[PRPT][NW + 1];
+        const unsigned sb = v.suffix_bytes, nw = (sb + 3u) / 4u;
+        // (only the slab at the very end of the buffer can hold a dword that reaches past it: that slab reads byte by byte)
+        const bool at_end = byte0 + (uint64_t)slab_n * v.rec_size + 8u > total_bytes;
+        if (!at_end) {
+#pragma unroll
+            for (unsigned j = 0; j < PRPT; ++j) {
+                const uint32_t r = j * PBLOCK + threadIdx.x;
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(records + ((byte0 + (uint64_t)r * v.rec_size) & ~3ULL));
+#pragma unroll
+                for (unsigned i = 0; i <= NW; ++i) win[j][i] = (r < slab_n && i <= nw) ? q[i] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (unsigned j = 0; j < PRPT; ++j) {
+                const uint32_t r = j * PBLOCK + threadIdx.x;
+                const uint64_t w0 = (byte0 + (uint64_t)r * v.rec_size) & ~3ULL;
+#pragma unroll
+                for (unsigned i = 0; i <= NW; ++i) {
+                    uint32_t x = 0;
+                    for (unsigned z = 0; z < 4u; ++z)
+                        if (r < slab_n && w0 + 4u * i + z < total_bytes) x |= (uint32_t)records[w0 + 4u * i + z] << (8u * z);
+                    win[j][i] = x;
+                }
+            }
+        }
         uint64_t hh[PRPT];
         uint32_t bk[PRPT / 4];
         uint32_t valid = 0;
@@ -718,15 +738,20 @@ __global__ __launch_bounds__(PBLOCK) void kmc_partition_kernel(KmcView v, BloomV
                 const uint64_t pf = kmc_prefix_in(v, first_record + rec_offset + slab0 + r, p_first, p_last);
                 h = pf == p_first ? block_phash[0] : (pf == p_last ? block_phash[1] : kmc_prefix_hash(pf, v.p));
             }
-            const uint8_t *rec = &raw[lead + r * v.rec_size];
-            for (unsigned b = 0; b < v.suffix_bytes; ++b) h = rol64(h, 4) ^ tab[rec[b]];   // (k - p is a multiple of four: bt_kmc_scan_create)
+            const uint32_t sh = (uint32_t)((byte0 + (uint64_t)r * v.rec_size) & 3ULL);
+            uint32_t sw[NW];
+#pragma unroll
+            for (unsigned i = 0; i < NW; ++i) sw[i] = __builtin_amdgcn_alignbyte(win[j][i + 1], win[j][i], sh);
+#pragma unroll
+            for (unsigned b = 0; b < 4u * NW; ++b)   // (k - p is a multiple of four: bt_kmc_scan_create)
+                if (b < sb) h = rol64(h, 4) ^ tab[(sw[b >> 2] >> (8u * (b & 3u))) & 0xFFu];
             hh[j] = h;
             valid |= 1u << j;
             const uint32_t bucket = route_bucket(h, bloom.k);
             bk[j / 4] |= bucket << (8u * (j & 3u));
             atomicAdd(&hist[bucket], 1u);
         }
-        __syncthreads();   // (every raw byte has been read: the region becomes `sorted`)
+        __syncthreads();
         // exclusive scan of the 256 counts (four wavefronts of 64 bins), one reservation per bucket in its stripe's region
         if (threadIdx.x < 256u) {
             const uint32_t c = hist[threadIdx.x];
