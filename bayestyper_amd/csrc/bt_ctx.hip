@@ -120,6 +120,11 @@ int bt_ctx_destroy(bt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pool_cache) (void)hipFree(ctx->pool_cache);
+    for (auto &h : ctx->host_cache)
+        if (h.p) (void)hipHostFree(h.p);
+    for (auto &c : ctx->stream_cache)
+        if (c.st) (void)hipStreamDestroy(c.st);
     for (int b = 0; b < 2; ++b) {
         if (ctx->kmc_pin[b]) (void)hipHostFree(ctx->kmc_pin[b]);
         if (ctx->kmc_dev[b]) (void)hipFree(ctx->kmc_dev[b]);
@@ -156,7 +161,7 @@ int bt_ctx_info(bt_ctx *ctx, int *num_cu, uint64_t *hbm_total, uint64_t *hbm_fre
     BT_HIP(hipMemGetInfo(&f, &t));
     if (num_cu) *num_cu = prop.multiProcessorCount;
     if (hbm_total) *hbm_total = t;
-    if (hbm_free) *hbm_free = f;
+    if (hbm_free) *hbm_free = f + ctx->pool_cache_bytes;   // (the cached pool is given back as soon as a sampler needs the room: bt_gibbs.hip)
     if (arch && arch_len) {
         std::strncpy(arch, prop.gcnArchName, arch_len - 1);
         arch[arch_len - 1] = 0;

@@ -498,6 +498,8 @@ struct bt_gibbs {
     uint64_t device_bytes = 0;
     TileDesc *d_tiles = nullptr;
     uint8_t *d_pool = nullptr;
+    uint64_t pool_alloc_bytes = 0;   // size of the allocation behind d_pool (a pool taken over from the context's cache may be larger than pool_bytes)
+    bool keep_pool = false;          // a noise driver's sampler: its pool goes to the context's cache when it is destroyed
     uint64_t pool_bytes = 0;
     ClusterLoc *d_loc = nullptr;
     double *d_lut_g = nullptr, *d_lut_n = nullptr, *d_lgamma = nullptr;
@@ -517,6 +519,7 @@ struct bt_gibbs {
         std::vector<uint32_t> tiles;
         uint32_t *d_tiles = nullptr;
         hipStream_t stream = nullptr;     // nullptr: the context's stream
+        int stream_prio = 0;
         hipEvent_t done = nullptr;
         hipEvent_t ready = nullptr;       // recorded on the class's stream right before its launch: the next class waits for it (launch(): start order)
         // the tiles' large dense tables of unique-k-mer sums in pieces of <= 256 KB: clearGenotyperCache between two iterations of the noise
@@ -1577,14 +1580,26 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         bt_gibbs_destroy(g);
         return BT_OK;
     }
-    {
+    if (ctx->pool_cache && params->noise_seeding && ctx->pool_cache_bytes >= g->pool_bytes && ctx->pool_cache_bytes / 2 <= g->pool_bytes + (64u << 20)) {
+        g->d_pool = static_cast<uint8_t *>(ctx->pool_cache);   // the previous chain's pool (the work queued on it was waited for when its sampler was destroyed)
+        g->pool_alloc_bytes = ctx->pool_cache_bytes;
+        ctx->pool_cache = nullptr;
+        ctx->pool_cache_bytes = 0;
+    } else {
+        if (ctx->pool_cache) {
+            (void)hipFree(ctx->pool_cache);
+            ctx->pool_cache = nullptr;
+            ctx->pool_cache_bytes = 0;
+        }
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&g->d_pool), g->pool_bytes);
+        g->pool_alloc_bytes = g->pool_bytes;
         if (e != hipSuccess) {
             bt_gibbs_destroy(g);
             return fail(std::string("bt_gibbs_create: state pool of ") + std::to_string(g->pool_bytes) + " bytes: " + hipGetErrorString(e));
         }
     }
     g->allocs.push_back(g->d_pool);
+    g->keep_pool = params->noise_seeding != 0 && g->pool_alloc_bytes <= (8ull << 30) && !getenv("BT_GIBBS_NO_POOL_CACHE");   // (a chain's sampler of estimateNoise: 1 - 6 GB)
     g->device_bytes += g->pool_bytes;
     {
         const uint64_t n16 = (g->pool_bytes + 15) / 16;   // (hipMalloc sizes are multiples of the allocation granule: the tail belongs to the allocation)
@@ -1845,7 +1860,8 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
                 BT_TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
                 int prio = getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi;
                 if (const char *e = getenv("BT_GIBBS_CLASS_PRIO")) prio = atoi(e);   // tuning: 0 = the priority of the context's stream (the two-haplotype class)
-                BT_TRYHIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio));
+                BT_TRYHIP(ctx_stream_take(ctx, &c.stream, prio));
+                c.stream_prio = prio;
                 BT_TRYHIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
             }
             lap("class stream");
@@ -1881,30 +1897,52 @@ int bt_gibbs_destroy(bt_gibbs *g) {
     (void)hipSetDevice(g->ctx->device);
     if (g->nc.active) (void)bt_gibbs_noise_chain_end(g);   // (releases the resident launch)
     (void)hipStreamSynchronize(g->ctx->stream);
-    for (void *p : g->allocs)
-        if (p) (void)hipFree(p);
+    const bool dbg_release = getenv("BT_GIBBS_DEBUG") != nullptr;
+    const auto t_rel0 = std::chrono::steady_clock::now();
+    for (void *p : g->allocs) {
+        if (!p) continue;
+        if (p == g->d_pool && g->keep_pool && !g->ctx->pool_cache && g->pool_alloc_bytes) {   // (the stream was waited for above: nothing is in flight on the pool)
+            g->ctx->pool_cache = p;
+            g->ctx->pool_cache_bytes = g->pool_alloc_bytes;
+            continue;
+        }
+        (void)hipFree(p);
+    }
+    const auto t_rel1 = std::chrono::steady_clock::now();
     if (g->d_trace) (void)hipFree(g->d_trace);
     if (g->d_trace_counter) (void)hipFree(g->d_trace_counter);
     if (g->d_wire) (void)hipFree(g->d_wire);
-    if (g->h_pin_hist) (void)hipHostFree(g->h_pin_hist);
-    if (g->h_pin_noise) (void)hipHostFree(g->h_pin_noise);
+    {
+        const size_t nh = (size_t)g->S * 256;
+        ctx_host_give(g->ctx, g->h_pin_hist, nh * 8, hipHostMallocDefault);
+        ctx_host_give(g->ctx, g->h_pin_noise, nh * 8, hipHostMallocDefault);
+        ctx_host_give(g->ctx, g->nc.h_mail, nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped);
+        if (g->nc.h_phase) (void)hipHostFree(g->nc.h_phase);
+    }
+    const auto t_rel1b = std::chrono::steady_clock::now();
     if (g->d_iter_hist) (void)hipFree(g->d_iter_hist);
-    if (g->nc.h_mail) (void)hipHostFree(g->nc.h_mail);
     if (g->nc.d_sync) (void)hipFree(g->nc.d_sync);
     if (g->nc.d_ctl) (void)hipFree(g->nc.d_ctl);
     if (g->nc.d_busy) (void)hipFree(g->nc.d_busy);
     if (g->nc.d_help_items) (void)hipFree(g->nc.d_help_items);
     if (g->nc.d_help_words) (void)hipFree(g->nc.d_help_words);
     if (g->nc.d_tile_units) (void)hipFree(g->nc.d_tile_units);
+    const auto t_rel1c = std::chrono::steady_clock::now();
     for (auto &c : g->classes) {
         if (c.stream) {
             (void)hipStreamSynchronize(c.stream);
-            (void)hipStreamDestroy(c.stream);
+            ctx_stream_give(g->ctx, c.stream, c.stream_prio);
         }
         if (c.done) (void)hipEventDestroy(c.done);
         if (c.ready) (void)hipEventDestroy(c.ready);
     }
     if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (dbg_release) {
+        const auto t_rel2 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "bt_gibbs_destroy: device allocations %.2f ms (pool %s), pinned buffers %.2f ms, the chain's device words %.2f ms, streams + events %.2f ms\n", ms(t_rel0, t_rel1),
+                     g->ctx->pool_cache == g->d_pool ? "kept for the next sampler" : "freed", ms(t_rel1, t_rel1b), ms(t_rel1b, t_rel1c), ms(t_rel1c, t_rel2));
+    }
     delete g;
     return BT_OK;
 }
@@ -1968,8 +2006,8 @@ int bt_gibbs_noise_iteration(bt_gibbs *g, const double *h_noise, int collect_sam
     BT_HIP(hipSetDevice(g->ctx->device));
     const size_t nh = (size_t)g->S * 256;
     if (!g->h_pin_hist) {
-        BT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_pin_hist), nh * 8, hipHostMallocDefault));
-        BT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->h_pin_noise), nh * 8, hipHostMallocDefault));
+        BT_HIP(ctx_host_take(g->ctx, reinterpret_cast<void **>(&g->h_pin_hist), nh * 8, hipHostMallocDefault));
+        BT_HIP(ctx_host_take(g->ctx, reinterpret_cast<void **>(&g->h_pin_noise), nh * 8, hipHostMallocDefault));
         BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_iter_hist), nh * 8));
     }
     hipStream_t st = g->ctx->stream;
@@ -2104,7 +2142,7 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     // (2) mailbox + device words
     const size_t nh = (size_t)g->S * 256;
     if (!g->nc.h_mail) {
-        BT_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->nc.h_mail), nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped));
+        BT_HIP(ctx_host_take(g->ctx, reinterpret_cast<void **>(&g->nc.h_mail), nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped));
         BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_sync), nh * 8 + 512 + (size_t)NC_SEQ_COPIES * NC_SEQ_STRIDE * 4));
         BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_ctl), sizeof(NoiseChainCtl)));
     }

@@ -48,7 +48,64 @@ struct bt_ctx {
     // per sample means a scan handle per sample, and 2 x 218 MB of pinned memory allocated and released for each of them
     uint8_t *kmc_pin[2] = {nullptr, nullptr}, *kmc_dev[2] = {nullptr, nullptr};
     size_t kmc_stage_bytes = 0;
+    // the state pool of the last noise-driver sampler released on this context (bt_gibbs.hip): the next chain's sampler is over as many groups of the same
+    // unit and takes it over instead of a hipFree + hipMalloc of gigabytes per chain; released when it does not fit the next sampler, and with the context
+    void *pool_cache = nullptr;
+    size_t pool_cache_bytes = 0;
+    // pinned host buffers handed back by released samplers (the mailbox of a resident noise chain, the per-iteration staging words): hipHostMalloc /
+    // hipHostFree cost milliseconds each, a noise driver builds a sampler per chain
+    struct HostBuf {
+        void *p;
+        size_t bytes;
+        unsigned flags;
+    };
+    HostBuf host_cache[8] = {};
+    // launch-class streams of released samplers by priority (hipStreamDestroy: about 2 ms each)
+    struct ClassStream {
+        hipStream_t st;
+        int prio;
+    };
+    ClassStream stream_cache[8] = {};
 };
+
+namespace bt {
+// a pinned host buffer of exactly `bytes` with `flags` from the context's cache, or a new one
+inline hipError_t ctx_host_take(bt_ctx *ctx, void **out, size_t bytes, unsigned flags) {
+    for (auto &h : ctx->host_cache)
+        if (h.p && h.bytes == bytes && h.flags == flags) {
+            *out = h.p;
+            h.p = nullptr;
+            return hipSuccess;
+        }
+    return hipHostMalloc(out, bytes, flags);
+}
+inline hipError_t ctx_stream_take(bt_ctx *ctx, hipStream_t *out, int prio) {
+    for (auto &c : ctx->stream_cache)
+        if (c.st && c.prio == prio) {
+            *out = c.st;
+            c.st = nullptr;
+            return hipSuccess;
+        }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+}
+inline void ctx_stream_give(bt_ctx *ctx, hipStream_t st, int prio) {   // (the stream has been waited for)
+    for (auto &c : ctx->stream_cache)
+        if (!c.st) {
+            c = bt_ctx::ClassStream{st, prio};
+            return;
+        }
+    (void)hipStreamDestroy(st);
+}
+inline void ctx_host_give(bt_ctx *ctx, void *p, size_t bytes, unsigned flags) {
+    if (!p) return;
+    for (auto &h : ctx->host_cache)
+        if (!h.p) {
+            h = bt_ctx::HostBuf{p, bytes, flags};
+            return;
+        }
+    (void)hipHostFree(p);
+}
+}  // namespace bt
 
 struct bt_timer {
     bt_ctx *ctx = nullptr;
