@@ -1,6 +1,8 @@
 // libbtgpu: context, device memory, HIP-event timers, error reporting.
 #include "bt_internal.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -28,6 +30,73 @@ __global__ void stream_pair_probe_kernel(uint32_t *flags, int me, unsigned long 
     flags[2 + me] = seen && (unsigned long long)wall_clock64() - t0 < timeout_ticks ? 1u : 0u;
 }
 }  // namespace
+
+namespace bt {
+// do kernels on streams a and b overlap?  (the pair of kernels of bt_ctx_clone; d_flags: 16 bytes of device memory)
+static hipError_t streams_overlap(bt_ctx *ctx, hipStream_t a, hipStream_t b, uint32_t *d_flags, unsigned long long ticks, bool *yes) {
+    uint32_t h[4] = {0, 0, 0, 0};
+    hipError_t e = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = hipStreamSynchronize(b);
+    if (e == hipSuccess) e = hipMemcpy(d_flags, h, 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(stream_pair_probe_kernel, dim3(1), dim3(1), 0, a, d_flags, 0, ticks);
+    hipLaunchKernelGGL(stream_pair_probe_kernel, dim3(1), dim3(1), 0, b, d_flags, 1, ticks);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(a);
+    if (e == hipSuccess) e = hipStreamSynchronize(b);
+    if (e == hipSuccess) e = hipMemcpy(h, d_flags, 16, hipMemcpyDeviceToHost);
+    *yes = e == hipSuccess && h[2] && h[3];
+    return e;
+}
+
+hipError_t ctx_class_streams(bt_ctx *ctx, unsigned n, int prio, hipStream_t *out) {
+    const bool probe = getenv("BT_CLASS_STREAMS_NO_PROBE") == nullptr;
+    if (ctx->class_streams_probed && (ctx->class_streams_for != ctx->stream || ctx->class_streams_prio != prio)) {   // probed against another stream: start over
+        for (hipStream_t st : ctx->class_streams) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+        ctx->class_streams.clear();
+        ctx->class_streams_probed = false;
+    }
+    if (ctx->class_streams.size() < n) {
+        int wall_khz = 0;
+        if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
+        const unsigned long long ticks = (unsigned long long)wall_khz * 2;   // 2 ms
+        uint32_t *d_flags = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_flags), 16);
+        if (e != hipSuccess) return e;
+        std::vector<hipStream_t> rejected;
+        // (the context's stream may be the NULL stream: kernels on it are probed all the same)
+        for (int attempt = 0; attempt < 16 && ctx->class_streams.size() < n && e == hipSuccess; ++attempt) {
+            hipStream_t cand = nullptr;
+            e = hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio);
+            if (e != hipSuccess) break;
+            bool ok = true;
+            if (probe) {
+                e = streams_overlap(ctx, ctx->stream, cand, d_flags, ticks, &ok);
+                for (size_t i = 0; ok && e == hipSuccess && i < ctx->class_streams.size(); ++i) e = streams_overlap(ctx, ctx->class_streams[i], cand, d_flags, ticks, &ok);
+            }
+            if (e == hipSuccess && ok) ctx->class_streams.push_back(cand);
+            else rejected.push_back(cand);
+        }
+        while (e == hipSuccess && ctx->class_streams.size() < n && !rejected.empty()) {   // not enough hardware queues: streams of their own all the same, in order with another one at worst
+            ctx->class_streams.push_back(rejected.back());
+            rejected.pop_back();
+        }
+        for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
+        (void)hipFree(d_flags);
+        if (e != hipSuccess) return e;
+        if (ctx->class_streams.size() < n) return hipErrorOutOfMemory;
+        ctx->class_streams_for = ctx->stream;
+        ctx->class_streams_prio = prio;
+        ctx->class_streams_probed = true;
+        if (getenv("BT_GIBBS_DEBUG")) std::fprintf(stderr, "bt_ctx: %zu launch-class streams probed against the context's stream and each other\n", ctx->class_streams.size());
+    }
+    for (unsigned i = 0; i < n; ++i) out[i] = ctx->class_streams[i];
+    return hipSuccess;
+}
+}  // namespace bt
 
 extern "C" {
 
@@ -123,8 +192,7 @@ int bt_ctx_destroy(bt_ctx *ctx) {
     if (ctx->pool_cache) (void)hipFree(ctx->pool_cache);
     for (auto &h : ctx->host_cache)
         if (h.p) (void)hipHostFree(h.p);
-    for (auto &c : ctx->stream_cache)
-        if (c.st) (void)hipStreamDestroy(c.st);
+    for (hipStream_t st : ctx->class_streams) (void)hipStreamDestroy(st);
     for (int b = 0; b < 2; ++b) {
         if (ctx->kmc_pin[b]) (void)hipHostFree(ctx->kmc_pin[b]);
         if (ctx->kmc_dev[b]) (void)hipFree(ctx->kmc_dev[b]);

@@ -500,6 +500,7 @@ struct bt_gibbs {
     uint8_t *d_pool = nullptr;
     uint64_t pool_alloc_bytes = 0;   // size of the allocation behind d_pool (a pool taken over from the context's cache may be larger than pool_bytes)
     bool keep_pool = false;          // a noise driver's sampler: its pool goes to the context's cache when it is destroyed
+    bool recycles = false;           // ... and so do its pinned words and class streams (gibbs_create_impl)
     uint64_t pool_bytes = 0;
     ClusterLoc *d_loc = nullptr;
     double *d_lut_g = nullptr, *d_lut_n = nullptr, *d_lgamma = nullptr;
@@ -519,7 +520,6 @@ struct bt_gibbs {
         std::vector<uint32_t> tiles;
         uint32_t *d_tiles = nullptr;
         hipStream_t stream = nullptr;     // nullptr: the context's stream
-        int stream_prio = 0;
         hipEvent_t done = nullptr;
         hipEvent_t ready = nullptr;       // recorded on the class's stream right before its launch: the next class waits for it (launch(): start order)
         // the tiles' large dense tables of unique-k-mer sums in pieces of <= 256 KB: clearGenotyperCache between two iterations of the noise
@@ -1039,6 +1039,10 @@ int bt_gibbs_state_bytes(bt_ctx *ctx, const bt_gibbs_params *params, const bt_gi
 // plan_bytes != nullptr: lay the selected groups out only; *plan_bytes = device bytes a sampler over them would allocate.
 // group_ids: the groups of the source the sampler runs (in this order; nullptr: all of them)
 static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_gibbs_params *params, const uint32_t *group_ids, uint32_t num_ids, bt_gibbs **out, uint64_t *plan_bytes) {
+    // A noise driver's chain samplers (bt_gibbs_create_from_source with noise seeding: one sampler per chain over a subset of the same unit) hand their pool,
+    // pinned words and class streams on to the next one through the context.  Every other sampler allocates and releases its own: a default-mode sampler
+    // on class streams taken over from its predecessor ran a ten-sample schedule in 17.1 s instead of 13.1 s (round 5, bench sub-record; not understood).
+    const bool recycles = ctx != nullptr && params->noise_seeding != 0 && !ctx_caches_off() && !getenv("BT_GIBBS_NO_POOL_CACHE");
     if (!ctx) ctx = src->ctx;
     if (ctx->device != src->ctx->device) return fail("bt_gibbs_create_from_source: the context is on another device than the source");
     const uint32_t S = params->num_samples;
@@ -1580,7 +1584,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         bt_gibbs_destroy(g);
         return BT_OK;
     }
-    if (ctx->pool_cache && params->noise_seeding && ctx->pool_cache_bytes >= g->pool_bytes && ctx->pool_cache_bytes / 2 <= g->pool_bytes + (64u << 20)) {
+    if (ctx->pool_cache && recycles && ctx->pool_cache_bytes >= g->pool_bytes && ctx->pool_cache_bytes / 2 <= g->pool_bytes + (64u << 20)) {
         g->d_pool = static_cast<uint8_t *>(ctx->pool_cache);   // the previous chain's pool (the work queued on it was waited for when its sampler was destroyed)
         g->pool_alloc_bytes = ctx->pool_cache_bytes;
         ctx->pool_cache = nullptr;
@@ -1599,7 +1603,8 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         }
     }
     g->allocs.push_back(g->d_pool);
-    g->keep_pool = params->noise_seeding != 0 && g->pool_alloc_bytes <= (8ull << 30) && !getenv("BT_GIBBS_NO_POOL_CACHE");   // (a chain's sampler of estimateNoise: 1 - 6 GB)
+    g->recycles = recycles;
+    g->keep_pool = recycles && g->pool_alloc_bytes <= (8ull << 30);   // (a chain's sampler of estimateNoise: 1 - 6 GB)
     g->device_bytes += g->pool_bytes;
     {
         const uint64_t n16 = (g->pool_bytes + 15) / 16;   // (hipMalloc sizes are multiples of the allocation granule: the tail belongs to the allocation)
@@ -1818,6 +1823,11 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_noise_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         if (const char *e = getenv("BT_GIBBS_STEPWISE")) g->stepwise_run = atoi(e) != 0 && g->wide_fill;
         lap("attributes");
+        hipStream_t class_streams[16] = {};
+        if (g->classes.size() > 16) {
+            bt_gibbs_destroy(g);
+            return fail("bt_gibbs_create: more launch classes than class streams");
+        }
         for (size_t i = 0; i < g->classes.size(); ++i) {
             auto &c = g->classes[i];
             BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_tiles), c.tiles.size() * 4));
@@ -1860,8 +1870,8 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
                 BT_TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
                 int prio = getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi;
                 if (const char *e = getenv("BT_GIBBS_CLASS_PRIO")) prio = atoi(e);   // tuning: 0 = the priority of the context's stream (the two-haplotype class)
-                BT_TRYHIP(ctx_stream_take(ctx, &c.stream, prio));
-                c.stream_prio = prio;
+                BT_TRYHIP(ctx_class_streams(ctx, (unsigned)i + 1, prio, class_streams));   // (the context's: borrowed)
+                c.stream = class_streams[i];
                 BT_TRYHIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
             }
             lap("class stream");
@@ -1914,9 +1924,15 @@ int bt_gibbs_destroy(bt_gibbs *g) {
     if (g->d_wire) (void)hipFree(g->d_wire);
     {
         const size_t nh = (size_t)g->S * 256;
-        ctx_host_give(g->ctx, g->h_pin_hist, nh * 8, hipHostMallocDefault);
-        ctx_host_give(g->ctx, g->h_pin_noise, nh * 8, hipHostMallocDefault);
-        ctx_host_give(g->ctx, g->nc.h_mail, nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped);
+        if (g->recycles) {
+            ctx_host_give(g->ctx, g->h_pin_hist, nh * 8, hipHostMallocDefault);
+            ctx_host_give(g->ctx, g->h_pin_noise, nh * 8, hipHostMallocDefault);
+            ctx_host_give(g->ctx, g->nc.h_mail, nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped);
+        } else {
+            if (g->h_pin_hist) (void)hipHostFree(g->h_pin_hist);
+            if (g->h_pin_noise) (void)hipHostFree(g->h_pin_noise);
+            if (g->nc.h_mail) (void)hipHostFree(g->nc.h_mail);
+        }
         if (g->nc.h_phase) (void)hipHostFree(g->nc.h_phase);
     }
     const auto t_rel1b = std::chrono::steady_clock::now();
@@ -1931,7 +1947,7 @@ int bt_gibbs_destroy(bt_gibbs *g) {
     for (auto &c : g->classes) {
         if (c.stream) {
             (void)hipStreamSynchronize(c.stream);
-            ctx_stream_give(g->ctx, c.stream, c.stream_prio);
+            // (the stream belongs to the context)
         }
         if (c.done) (void)hipEventDestroy(c.done);
         if (c.ready) (void)hipEventDestroy(c.ready);

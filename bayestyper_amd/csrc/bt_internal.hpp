@@ -60,12 +60,14 @@ struct bt_ctx {
         unsigned flags;
     };
     HostBuf host_cache[8] = {};
-    // launch-class streams of released samplers by priority (hipStreamDestroy: about 2 ms each)
-    struct ClassStream {
-        hipStream_t st;
-        int prio;
-    };
-    ClassStream stream_cache[8] = {};
+    // The streams the launch classes of this context's samplers run on (bt_gibbs.hip): created once, each PROBED to run concurrently with the context's
+    // stream and with one another (ctx_class_streams) — the runtime deals a handful of hardware queues to the process's streams round robin, and launch
+    // classes whose streams share a queue run one after the other (the same ten-sample schedule: 12.9 or 17.1 s, a chr20 unit 0.41 or 0.73 s, depending on
+    // which streams a sampler happened to get).  Samplers borrow them; they live as long as the context.
+    std::vector<hipStream_t> class_streams;
+    hipStream_t class_streams_for = nullptr;   // the context stream they were probed against (bt_ctx_set_stream may change it)
+    int class_streams_prio = 0;
+    bool class_streams_probed = false;
 };
 
 namespace bt {
@@ -79,27 +81,16 @@ inline hipError_t ctx_host_take(bt_ctx *ctx, void **out, size_t bytes, unsigned 
         }
     return hipHostMalloc(out, bytes, flags);
 }
-inline hipError_t ctx_stream_take(bt_ctx *ctx, hipStream_t *out, int prio) {
-    for (auto &c : ctx->stream_cache)
-        if (c.st && c.prio == prio) {
-            *out = c.st;
-            c.st = nullptr;
-            return hipSuccess;
-        }
-    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+inline bool ctx_caches_off() {
+    static const bool off = getenv("BT_CTX_NO_CACHE") != nullptr;   // (diagnosis: every sampler allocates and releases its own)
+    return off;
 }
-inline void ctx_stream_give(bt_ctx *ctx, hipStream_t st, int prio) {   // (the stream has been waited for)
-    for (auto &c : ctx->stream_cache)
-        if (!c.st) {
-            c = bt_ctx::ClassStream{st, prio};
-            return;
-        }
-    (void)hipStreamDestroy(st);
-}
+// n streams of priority prio that run concurrently with ctx->stream and with each other (bt_ctx.hip); fewer than n concurrent ones found: the rest share
+hipError_t ctx_class_streams(bt_ctx *ctx, unsigned n, int prio, hipStream_t *out);
 inline void ctx_host_give(bt_ctx *ctx, void *p, size_t bytes, unsigned flags) {
     if (!p) return;
     for (auto &h : ctx->host_cache)
-        if (!h.p) {
+        if (!h.p && !ctx_caches_off()) {
             h = bt_ctx::HostBuf{p, bytes, flags};
             return;
         }

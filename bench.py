@@ -338,10 +338,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = [C, float(np.mean(gibbs_ms)), float(np.mean([sum(x) for x in kmc_ms])), float(np.mean(fetch_ms)), float(np.mean(gather_ms))]
+        gw = state.get("gather_words", (0, 0))
+        mine = [C, float(np.mean(gibbs_ms)), float(np.mean([sum(x) for x in kmc_ms])), float(np.mean(fetch_ms)), float(np.mean(gather_ms)), int(gw[0]) * 4, int(gw[1]) * 4]
         rows = [None] * world
         dist.all_gather_object(rows, mine)
-        per_rank = [{"rank": r, "clusters": int(x[0]), "gibbs_launch_ms": x[1], "kmc_scans_ms": x[2], "result_pack_ms": x[3], "gather_ms": x[4]} for r, x in enumerate(rows)]
+        per_rank = [{"rank": r, "clusters": int(x[0]), "gibbs_launch_ms": x[1], "kmc_scans_ms": x[2], "result_pack_ms": x[3], "gather_ms": x[4],
+                     "result_string_bytes": int(x[5]), "gathered_bytes_all_ranks": int(x[6])} for r, x in enumerate(rows)]
     hits = int(d_hits.item())
     st = table.status()
     if st["overflowed"]:
