@@ -52,10 +52,7 @@ static hipError_t streams_overlap(bt_ctx *ctx, hipStream_t a, hipStream_t b, uin
 hipError_t ctx_class_streams(bt_ctx *ctx, unsigned n, int prio, hipStream_t *out) {
     const bool probe = getenv("BT_CLASS_STREAMS_NO_PROBE") == nullptr;
     if (ctx->class_streams_probed && (ctx->class_streams_for != ctx->stream || ctx->class_streams_prio != prio)) {   // probed against another stream: start over
-        for (hipStream_t st : ctx->class_streams) {
-            (void)hipStreamSynchronize(st);
-            (void)hipStreamDestroy(st);
-        }
+        for (hipStream_t st : ctx->class_streams) ctx->retired_streams.push_back(st);   // (a sampler built before may still launch on them)
         ctx->class_streams.clear();
         ctx->class_streams_probed = false;
     }
@@ -193,6 +190,7 @@ int bt_ctx_destroy(bt_ctx *ctx) {
     for (auto &h : ctx->host_cache)
         if (h.p) (void)hipHostFree(h.p);
     for (hipStream_t st : ctx->class_streams) (void)hipStreamDestroy(st);
+    for (hipStream_t st : ctx->retired_streams) (void)hipStreamDestroy(st);
     for (int b = 0; b < 2; ++b) {
         if (ctx->kmc_pin[b]) (void)hipHostFree(ctx->kmc_pin[b]);
         if (ctx->kmc_dev[b]) (void)hipFree(ctx->kmc_dev[b]);

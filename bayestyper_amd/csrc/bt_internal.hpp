@@ -65,6 +65,7 @@ struct bt_ctx {
     // classes whose streams share a queue run one after the other (the same ten-sample schedule: 12.9 or 17.1 s, a chr20 unit 0.41 or 0.73 s, depending on
     // which streams a sampler happened to get).  Samplers borrow them; they live as long as the context.
     std::vector<hipStream_t> class_streams;
+    std::vector<hipStream_t> retired_streams;   // class streams of an earlier context stream: samplers built then may still hold them
     hipStream_t class_streams_for = nullptr;   // the context stream they were probed against (bt_ctx_set_stream may change it)
     int class_streams_prio = 0;
     bool class_streams_probed = false;
