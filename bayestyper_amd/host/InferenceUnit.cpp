@@ -1,4 +1,5 @@
 #include "InferenceUnit.hpp"
+#include <atomic>
 #include <vector>
 #include <fstream>
 #include "Parallel.hpp"
@@ -70,6 +71,61 @@ void writeGzFile(const std::string &filename, const std::string &content, unsign
         at += n;
     }
     if (gzclose(f) != Z_OK || !ok) throw std::runtime_error("Error while writing " + filename);
+}
+
+std::vector<uint64_t> parseKmerLines(const std::string &text, size_t begin, uint32_t k, unsigned threads) {
+    auto parse = [&](const char *line, size_t len, uint64_t *out) {
+        uint64_t lo = 0, hi = 0;
+        bool ok = len == k;
+        for (size_t i = 0; ok && i < len; i++) {
+            uint64_t c = 0;
+            switch (line[i]) {
+                case 'A': c = 0; break;
+                case 'C': c = 1; break;
+                case 'G': c = 2; break;
+                case 'T': c = 3; break;
+                default: ok = false;
+            }
+            if (i < 32) lo |= c << (2 * i);
+            else hi |= c << (2 * (i - 32));
+        }
+        if (!ok) throw std::runtime_error("malformed kmer line: " + std::string(line, std::min<size_t>(len, 200)));
+        out[0] = lo;
+        out[1] = hi;
+    };
+    std::vector<uint64_t> kmers;
+    if (begin >= text.size()) return kmers;
+    const size_t body = text.size() - begin, w = (size_t)k + 1;
+    // regular: every line k symbols + '\n' (the last newline may be missing)
+    const size_t n_reg = (body + 1) / w;
+    bool regular = k > 0 && (body % w == 0 || body % w == k);
+    if (regular) {
+        std::atomic<bool> all(true);
+        parallelFor(n_reg, std::max(1u, threads), [&](size_t a, size_t b, unsigned) {
+            for (size_t i = a; i < b; i++)
+                if (begin + i * w + k < text.size() && text[begin + i * w + k] != '\n') {
+                    all.store(false);
+                    return;
+                }
+        });
+        regular = all.load();
+    }
+    if (regular) {
+        kmers.resize(2 * n_reg);
+        parallelFor(n_reg, std::max(1u, threads), [&](size_t a, size_t b, unsigned) {
+            for (size_t i = a; i < b; i++) parse(text.data() + begin + i * w, k, &kmers[2 * i]);
+        });
+        return kmers;
+    }
+    size_t at = begin;   // lines of any length: one after the other (the first malformed one is reported)
+    while (at < text.size()) {
+        size_t e = text.find('\n', at);
+        if (e == std::string::npos) e = text.size();
+        kmers.resize(kmers.size() + 2);
+        parse(text.data() + at, e - at, &kmers[kmers.size() - 2]);
+        at = e + 1;
+    }
+    return kmers;
 }
 
 std::string readGzFile(const std::string &filename) {

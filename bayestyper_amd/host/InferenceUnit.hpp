@@ -30,5 +30,9 @@ struct InferenceUnit {
 // gzip text/binary files (the reference's boost::iostreams gzip filters)
 void writeGzFile(const std::string &filename, const std::string &content, unsigned threads = 1);   // one gzip member whatever the thread count (large contents: 4 MB pieces of one deflate stream, compressed on `threads` threads)
 std::string readGzFile(const std::string &filename);   // also reads uncompressed files
+// The k-mers of a text of one k-mer per line from offset `begin` on (parameter_kmers.fa.gz after its header line), [lo, hi] per k-mer in the packing of
+// Nucleotide::ntToBit (symbol i in bits 2i, 2i+1); the lines are cut among `threads` threads when they all have k symbols (what the cluster stage writes).
+// Throws std::runtime_error naming the first malformed line.
+std::vector<uint64_t> parseKmerLines(const std::string &text, size_t begin, uint32_t k, unsigned threads);
 
 }  // namespace bthost

@@ -34,6 +34,24 @@ int bth_write_gz(const char *filename, const char *data, unsigned long long len,
     return 0;
 }
 
+// parseKmerLines (the genotype stage's reading of parameter_kmers.fa.gz): out[2 * i] = lo, out[2 * i + 1] = hi; returns 0, or 1 with the message in err
+int bth_parse_kmer_lines(const char *text, unsigned long long len, unsigned long long begin, unsigned k, unsigned threads, unsigned long long *out, unsigned long long capacity,
+                         unsigned long long *num_kmers, char *err, unsigned err_len) {
+    try {
+        const std::vector<uint64_t> v = parseKmerLines(std::string(text, (size_t)len), (size_t)begin, k, threads);
+        if (v.size() > capacity) throw std::runtime_error("output buffer too small");
+        if (!v.empty()) std::memcpy(out, v.data(), v.size() * 8);
+        *num_kmers = v.size() / 2;
+        return 0;
+    } catch (const std::exception &e) {
+        if (err && err_len) {
+            std::strncpy(err, e.what(), err_len - 1);
+            err[err_len - 1] = 0;
+        }
+        return 1;
+    }
+}
+
 // LUTs for S samples from per-sample (mean, var, multiplicity) of the parameter k-mers and explicit noise rates
 int bth_build_luts(unsigned S, const double *mean, const double *var, const unsigned *multiplicity, const double *noise_rates, double *genomic, double *noise) {
     try {

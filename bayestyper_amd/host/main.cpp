@@ -99,23 +99,6 @@ std::string kmerToString(uint64_t lo, uint64_t hi, unsigned k) {   // Nucleotide
     for (unsigned i = 0; i < k; i++) s[i] = "ACGT"[((i < 32 ? lo >> (2 * i) : hi >> (2 * (i - 32))) & 3u)];
     return s;
 }
-bool stringToKmer(const std::string &s, uint64_t *lo, uint64_t *hi) {   // Nucleotide::ntToBit
-    *lo = *hi = 0;
-    for (size_t i = 0; i < s.size(); i++) {
-        uint64_t c;
-        switch (s[i]) {
-            case 'A': c = 0; break;
-            case 'C': c = 1; break;
-            case 'G': c = 2; break;
-            case 'T': c = 3; break;
-            default: return false;
-        }
-        if (i < 32) *lo |= c << (2 * i);
-        else *hi |= c << (2 * (i - 32));
-    }
-    return true;
-}
-
 // every stored k-mer of a table with its flag byte
 void exportTable(bt_table *t, std::vector<uint64_t> *kmers, std::vector<uint8_t> *flags) {
     uint64_t n = 0;
@@ -362,16 +345,15 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     uint64_t num_parameter_kmers = 0;
     {
         StageScope stage("parameter k-mers");
-        std::istringstream in(readGzFile(parameter_kmers_dir_prefix + ".fa.gz"));
-        std::string line;
-        std::getline(in, line);
-        if (line != ">k" + std::to_string(kmer_size)) throw std::runtime_error(parameter_kmers_dir_prefix + ".fa.gz was written for another kmer size (" + line + ")");
+        const std::string text = readGzFile(parameter_kmers_dir_prefix + ".fa.gz");
+        const size_t header_end = std::min(text.find('\n'), text.size());
+        const std::string header = text.substr(0, header_end);
+        if (header != ">k" + std::to_string(kmer_size)) throw std::runtime_error(parameter_kmers_dir_prefix + ".fa.gz was written for another kmer size (" + header + ")");
         std::vector<uint64_t> kmers;
-        while (std::getline(in, line)) {
-            uint64_t lo, hi;
-            if (line.size() != kmer_size || !stringToKmer(line, &lo, &hi)) throw std::runtime_error("malformed kmer in " + parameter_kmers_dir_prefix + ".fa.gz: " + line);
-            kmers.push_back(lo);
-            kmers.push_back(hi);
+        try {   // (the lines are parsed by the -p host threads: a million k-mers were 0.3 s of a chr20-sized run on one)
+            kmers = parseKmerLines(text, header_end + 1, kmer_size, clampThreads(options.getUInt("threads")));
+        } catch (const std::runtime_error &e) {
+            throw std::runtime_error(std::string(e.what()) + " in " + parameter_kmers_dir_prefix + ".fa.gz");
         }
         num_parameter_kmers = kmers.size() / 2;
         if (num_parameter_kmers > max_parameter_kmers) throw std::runtime_error("more than " + std::to_string(max_parameter_kmers) + " parameter kmers");

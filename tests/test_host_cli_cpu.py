@@ -281,3 +281,40 @@ def test_gz_files_do_not_depend_on_the_thread_count(tmp_path):
     small = b"chr1\t10\t20\n" * 100
     f = str(tmp_path / "small.gz")
     assert dll.bth_write_gz(f.encode(), small, len(small), 4) == 0 and gzip.open(f).read() == small
+
+
+def test_parameter_kmer_lines_parse_the_same_on_any_thread_count():
+    """parseKmerLines (genotype's reading of parameter_kmers.fa.gz; Nucleotide::ntToBit packing: symbol i in bits 2i, 2i+1 of lo / hi): the regular layout is
+    cut among the -p threads, any other layout goes line by line; a malformed line is an error either way"""
+    from bayestyper_amd.host import dll
+
+    dll.bth_parse_kmer_lines.argtypes = [C.c_char_p, C.c_ulonglong, C.c_ulonglong, C.c_uint, C.c_uint, C.c_void_p, C.c_ulonglong, C.POINTER(C.c_ulonglong), C.c_char_p, C.c_uint]
+    rng = np.random.default_rng(11)
+    k, n = 55, 20_001
+    sym = rng.integers(0, 4, (n, k), dtype=np.uint8)
+    lines = [bytes(np.frombuffer(b"ACGT", np.uint8)[row]) for row in sym]
+    w = sym.astype(np.uint64)
+    lo = (w[:, :32] << (2 * np.arange(32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+    hi = (w[:, 32:] << (2 * np.arange(k - 32, dtype=np.uint64))).sum(axis=1, dtype=np.uint64)
+    want = np.stack([lo, hi], axis=1).reshape(-1)
+
+    def parse(text, begin, threads):
+        out = np.zeros(2 * n + 2, np.uint64)
+        got, err = C.c_ulonglong(0), C.create_string_buffer(400)
+        rc = dll.bth_parse_kmer_lines(text, len(text), begin, k, threads, out.ctypes.data, len(out), C.byref(got), err, 400)
+        return rc, out[: 2 * got.value], err.value.decode()
+
+    head = b">k55\n"
+    body = b"\n".join(lines) + b"\n"
+    for text in (head + body, head + body[:-1]):            # with and without the last newline
+        for threads in (1, 5, 64):
+            rc, got, err = parse(text, len(head), threads)
+            assert rc == 0 and np.array_equal(got, want), err
+    rc, got, _ = parse(head, len(head), 4)
+    assert rc == 0 and len(got) == 0                          # no k-mers at all
+    bad = head + body[:56 * 100] + b"ACGN" + body[56 * 100 + 4:]
+    rc, _, err = parse(bad, len(head), 8)
+    assert rc == 1 and "malformed kmer line" in err
+    ragged = head + body[:56 * 3] + b"ACGT\n" + body[56 * 3:]   # a short line: the line-by-line path reports it
+    rc, _, err = parse(ragged, len(head), 8)
+    assert rc == 1 and "malformed kmer line: ACGT" in err
