@@ -1,4 +1,5 @@
 #include "Comm.hpp"
+#include "Parallel.hpp"
 
 #include <dirent.h>
 #include <iterator>
@@ -469,18 +470,23 @@ BatchResults rebuildOnRankZero(const std::vector<uint32_t> &all, const std::vect
     full.h2.resize(std::max<uint64_t>(nd, 1));
     full.freq.resize(std::max<uint64_t>(nd * S, 1));
     full.stats.resize(std::max<uint64_t>(nc * 12, 1));
-    for (uint32_t c = 0; c < C; c++) {
-        const Part &P = parts[c_rank[c]][part_of[c_rank[c]][c_local[c]]];
-        const uint32_t l = c_local[c] - P.first;
-        const uint64_t e0 = P.dip_off[l], e1 = P.dip_off[l + 1], k0 = P.cell_off[l], k1 = P.cell_off[l + 1];
-        uint64_t to = full.dip_off[c];
-        for (uint64_t e = e0; e < e1; e++, to++) {
-            full.h1[to] = (uint16_t)(P.keys[e] & 0xFFFFu);
-            full.h2[to] = (uint16_t)(P.keys[e] >> 16);
+    // (every cluster's rows go to their own place: the -p host threads — BT_HOST_THREADS, set by the executable — share the clusters)
+    unsigned threads = 1;
+    if (const char *e = getenv("BT_HOST_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    parallelFor(C, threads, [&](size_t c_begin, size_t c_end, unsigned) {
+        for (size_t c = c_begin; c < c_end; c++) {
+            const Part &P = parts[c_rank[c]][part_of[c_rank[c]][c_local[c]]];
+            const uint32_t l = c_local[c] - P.first;
+            const uint64_t e0 = P.dip_off[l], e1 = P.dip_off[l + 1], k0 = P.cell_off[l], k1 = P.cell_off[l + 1];
+            uint64_t to = full.dip_off[c];
+            for (uint64_t e = e0; e < e1; e++, to++) {
+                full.h1[to] = (uint16_t)(P.keys[e] & 0xFFFFu);
+                full.h2[to] = (uint16_t)(P.keys[e] >> 16);
+            }
+            if (e1 > e0) std::memcpy(full.freq.data() + full.dip_off[c] * S, P.freq + e0 * S, (e1 - e0) * S * 4);
+            if (k1 > k0) std::memcpy(full.stats.data() + full.cell_off[c] * 12, P.stats + k0 * 96, (k1 - k0) * 96);
         }
-        if (e1 > e0) std::memcpy(full.freq.data() + full.dip_off[c] * S, P.freq + e0 * S, (e1 - e0) * S * 4);
-        if (k1 > k0) std::memcpy(full.stats.data() + full.cell_off[c] * 12, P.stats + k0 * 96, (k1 - k0) * 96);
-    }
+    });
     return full;
 }
 }  // namespace
