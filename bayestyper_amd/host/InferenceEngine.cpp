@@ -339,6 +339,7 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
     // what a helper thread prepares for the next chain while the current one runs: the subset copy, and — for the product's own (GPU) sampler, whose
     // construction only enqueues on the context's stream — the sampler itself; a caller-supplied sampler factory is only ever called from this thread
     struct Prepared {
+        std::vector<uint32_t> groups;   // the next chain's selection (the shuffle + sort of the unit's groups: 6 ms per chain at chr20 size, off the calling thread)
         std::unique_ptr<Sampler> sampler;
         std::string why_not;   // the helper could not build the sampler (not enough free HBM next to the running chain's, or an error): the calling thread does, after freeing the previous one
     };
@@ -350,16 +351,17 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
         // groups reset — the reference's own sequence.  Otherwise (a unit of 100 000 variants or more: another random subset per chain), and for a
         // sampler that cannot reset, a fresh sampler over a copy of the subset; the NEXT chain's subset copy and sampler are made by a helper thread
         // while this chain's iterations run (the twenty copies + constructions were 3.8 of the 7.9 s of this stage at chr20 size).
+        Prepared ready;
+        if (prepared.valid()) {
+            StageScope stage("  noise chains: waiting for the helper thread (next chain's selection + sampler)");
+            ready = prepared.get();
+            mine = std::move(ready.groups);
+        }
         const bool again = sampler && !mine.empty() && mine == sampler_groups && sampler->resetGroups();
         if (again) {
             sampler->setNoiseLut(cd->noiseTable().data());
             sampler->initChain(chain);
         } else {
-            Prepared ready;
-            if (prepared.valid()) {
-                StageScope stage("  noise chains: waiting for the helper thread (next chain's subset copy + sampler)");
-                ready = prepared.get();
-            }
             {
                 StageScope stage("  noise chains: previous sampler released");
                 sampler.reset();   // (before anything is built on this thread: two samplers' state at once is the helper's privilege, and only when it fits)
@@ -376,14 +378,15 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
                 sampler_groups = mine;
             }
         }
-        std::vector<uint32_t> next;
-        if (chain + 1 < opt.chains) next = select();
-        if (!next.empty() && next != sampler_groups) {
+        if (chain + 1 < opt.chains) {
             bt_ctx *helper_ctx = alt.c ? (sampler_ctx == ctx ? alt.c : ctx) : nullptr;
             const uint64_t like = sampler ? sampler->deviceBytes() : 0;   // the next chain's sampler is over as many groups of the same unit: about as large
-            prepared = std::async(std::launch::async, [this, &source, &noise_params, &sampler_over, next, helper_ctx, like]() {
+            // (the selector is touched by one thread at a time: this one before the first chain, then the helper of each chain, whose result is taken before the next is started)
+            prepared = std::async(std::launch::async, [this, &source, &noise_params, &sampler_over, &select, current = sampler_groups, helper_ctx, like]() {
                 Prepared r;
-                if (!helper_ctx) return r;
+                r.groups = select();
+                const std::vector<uint32_t> &next = r.groups;
+                if (!helper_ctx || next.empty() || next == current) return r;
                 StageScope stage("  noise chains (helper thread, overlapped): sampler construction");
                 try {   // next to the running chain's sampler only when its state fits the free HBM with room to spare
                     uint64_t need = 0, total = 0, free_bytes = 0;
@@ -408,7 +411,6 @@ void InferenceEngine::estimateNoise(CountDistribution *cd, const GibbsBatchData 
                 for (size_t s = 0; s < S; s++) mean[s] += rates[s];
         });
         cd->resetNoiseRates();
-        mine = std::move(next);
     }
     sampler.reset();
     for (auto &m : mean) m /= (double)opt.samples * opt.chains;
