@@ -139,6 +139,8 @@ int bt_ctx_clone(bt_ctx *ctx, bt_ctx **out) {
     // The new stream must run CONCURRENTLY with the original's: the runtime deals its hardware queues (four by default) to the process's streams round robin,
     // and two streams on one hardware queue run their kernels one after the other (a sampler built on the clone while a resident noise chain occupies the
     // original would wait for the chain to end).  Candidates are probed with a pair of kernels that need each other; the first that overlaps is taken.
+    // The probe launches on ctx->stream and SYNCHRONISES it (every attempt): a caller-owned stream set with bt_ctx_set_stream must have no work in flight
+    // that depends on the calling thread.
     int wall_khz = 0;
     if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
     uint32_t *d_flags = nullptr;
@@ -171,7 +173,10 @@ int bt_ctx_clone(bt_ctx *ctx, bt_ctx **out) {
     }
     for (hipStream_t st : rejected) (void)hipStreamDestroy(st);
     (void)hipFree(d_flags);
-    if (e != hipSuccess || !chosen) return bt::fail(std::string("bt_ctx_clone: ") + hipGetErrorString(e));
+    if (e != hipSuccess || !chosen) {
+        if (chosen) (void)hipStreamDestroy(chosen);   // (picked from the rejected candidates before the error was looked at)
+        return bt::fail(std::string("bt_ctx_clone: ") + hipGetErrorString(e));
+    }
     bt_ctx *c = new bt_ctx();
     c->device = ctx->device;
     c->num_cu = ctx->num_cu;

@@ -17,6 +17,7 @@
 #include "bt_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -34,6 +35,10 @@ hipError_t prepare_gibbs_simple_kernel(int max_lds);
 hipError_t launch_gibbs_hot_kernel(unsigned grid, unsigned block, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
                                    unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
 hipError_t prepare_gibbs_hot_kernel(int max_lds);
+// defined in bt_gibbs_single_kernel.hip
+hipError_t launch_gibbs_single_kernel(unsigned grid, unsigned block, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
+                                      unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
+hipError_t prepare_gibbs_single_kernel(int max_lds);
 // defined in bt_gibbs_chain_kernel.hip
 hipError_t launch_gibbs_chain_kernel(unsigned grid, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, const NoiseChainCtl *ctl, TraceCfg tr);
 hipError_t occupancy_gibbs_chain_kernel(int *blocks_per_cu, uint32_t lds);
@@ -41,6 +46,7 @@ hipError_t prepare_gibbs_chain_kernel(int max_lds);
 #ifdef BT_PROF
 hipError_t simple_prof_read(unsigned long long *h_out32, int reset);
 hipError_t hot_prof_read(unsigned long long *h_out32, int reset);
+hipError_t single_prof_read(unsigned long long *h_out32, int reset);
 #endif
 }  // namespace bt
 
@@ -517,6 +523,7 @@ struct bt_gibbs {
         uint32_t lds = 0, split = 1;      // dynamic LDS per workgroup, wavefronts per tile (tile_lane())
         bool simple = false;              // every tile runs simple_sweeps(): launched as gibbs_simple_kernel
         bool hot = false;                 // every tile keeps all vertices' hot arrays in LDS for the launch: sampling operations launched as gibbs_hot_kernel
+        bool single = false;              // ... and every group is one cluster without multicluster k-mers: sampling operations launched as gibbs_single_kernel (three wavefronts per SIMD)
         std::vector<uint32_t> tiles;
         uint32_t *d_tiles = nullptr;
         hipStream_t stream = nullptr;     // nullptr: the context's stream
@@ -559,6 +566,7 @@ struct bt_gibbs {
         unsigned long long *d_busy = nullptr;   // BT_NOISE_CHAIN_PROF: per tile, the ticks its workgroup worked (the rest of a chain it waited for the others / the host)
         uint32_t num_wgs = 0;   // tiles + helpers
         bool active = false, launched = false;
+        bool fallback = false;   // the launch's roll call failed (its workgroups were not resident together): the chain's remaining steps are launches per iteration
         uint32_t n = 0, next = 0;
         uint32_t it_begin = 0, first_collect = 0, lds = 0;   // it_begin = 1: iteration 0 of the chain runs as ordinary launches (whole-GPU table refill), the resident launch starts with iteration 1
     } nc;
@@ -726,6 +734,9 @@ __global__ __launch_bounds__(256) void ucache_prefill_kernel(const TileDesc *__r
     }
 }
 
+// every call that enqueues on the sampler's stream would queue behind a resident chain's launch — which is itself waiting for the host
+inline bool chain_in_flight(const bt_gibbs *g) { return g->nc.active && g->nc.launched; }
+
 int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hist) {
     if (!g->lut_set && (op == OP_RUN || op == OP_SWEEP)) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     if (g->nc.active && g->nc.launched) return fail("bt_gibbs: a resident noise chain is in progress (bt_gibbs_noise_chain_end)");
@@ -772,6 +783,8 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
                                (const uint32_t *)c.d_tiles, (uint32_t)c.tiles.size());
         } else if (c.simple && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
             BT_HIP(launch_gibbs_simple_kernel((unsigned)c.tiles.size(), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
+        else if (c.single && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
+            BT_HIP(launch_gibbs_single_kernel((unsigned)c.tiles.size(), LANES * c.split, c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
         else if (c.hot && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
             BT_HIP(launch_gibbs_hot_kernel((unsigned)c.tiles.size(), LANES * c.split, c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
         else
@@ -1740,81 +1753,133 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
     }
     {
         lap("tables");
-        // BT_GIBBS_LDS_CLASSES="a,b,...": upper bounds (bytes) of the launch classes instead of kClassLds (tuning; a last class takes the rest)
-        const bool own_kernel_early = !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
-        std::vector<uint32_t> class_lds(kClassLds, kClassLds + sizeof(kClassLds) / sizeof(kClassLds[0]));
-        if (const char *e = getenv("BT_GIBBS_LDS_CLASSES")) {
-            class_lds.clear();
-            for (const char *q = e; *q;) {
-                class_lds.push_back((uint32_t)strtoul(q, nullptr, 10));
-                while (*q && *q != ',') ++q;
-                if (*q == ',') ++q;
-            }
-            class_lds.push_back(0xFFFFFFFFu);
-        }
-        else if (!getenv("BT_GIBBS_FIXED_CLASSES")) {
-            // A launch has ONE dynamic LDS size — its hungriest tile's — and the launches of a schedule are LDS-capacity-bound on this batch shape (the sum over
-            // the tiles of LDS x duration against 160 KB per CU): the two cuts between the three classes of the general tiles are placed where they minimise
-            // the LDS charged, sum over the classes of tiles x the class's largest need (2 KB bins; more classes than three queue behind each other).
-            std::vector<uint64_t> cnt(81, 0);
-            std::vector<uint32_t> top(81, 0);
-            for (uint32_t ti = 0; ti < ntiles; ++ti) {
-                if (own_kernel_early && g->tiles[ti].simple && g->tiles[ti].split == 1) continue;
-                const uint32_t hb = tile_lds_bytes(g->tiles[ti]), b = std::min<uint32_t>(80, (hb + 2047) / 2048);
-                cnt[b] += 1;
-                top[b] = std::max(top[b], hb);
-            }
-            auto charged = [&](uint32_t lo, uint32_t hi) {   // bins (lo, hi]
-                uint64_t n = 0;
-                uint32_t m = 0;
-                for (uint32_t b = lo + 1; b <= hi; ++b) n += cnt[b], m = std::max(m, top[b]);
-                return n * m;
-            };
-            uint64_t best = ~0ull;
-            uint32_t c1 = 8, c2 = 16;
-            for (uint32_t a = 1; a < 79; ++a)
-                for (uint32_t b = a + 1; b < 80; ++b) {
-                    const uint64_t v = charged(0, a) + charged(a, b) + charged(b, 80) + charged(0, 0);
-                    if (v < best) best = v, c1 = a, c2 = b;
-                }
-            class_lds = {c1 * 2048u, c2 * 2048u, 0xFFFFFFFFu};
-        }
-        const size_t nclass = class_lds.size();
-        std::vector<bt_gibbs::LaunchClass> byb(2 * nclass);   // [LDS class] and [nclass + LDS class]: the same for the tiles gibbs_hot_kernel takes
-        const bool hot_kernel = !getenv("BT_GIBBS_NO_HOT_KERNEL");
+        // Launch classes.  A launch has ONE kernel and ONE dynamic LDS size — its hungriest tile's — so the tiles are classed by the kernel that runs their
+        // sampling operations (KIND: gibbs_kernel / gibbs_hot_kernel / gibbs_single_kernel; the two-haplotype tiles are a class of their own) and, within a kind,
+        // by LDS need.  At most three classes beside the two-haplotype one: more streams than hardware queues run one after another (round 2: ten classes
+        // 5.2 -> 8.9 s).  The schedule is LDS-capacity-bound on whole-genome batch shapes (sum over the tiles of LDS x duration against 160 KB per CU), so the
+        // three are dealt to the kinds, and the cuts inside a kind placed, where they minimise the LDS charged: sum over the classes of tiles x the class's
+        // largest need (2 KB bins).  BT_GIBBS_LDS_CLASSES="a,b,...": upper bounds (bytes) for every kind instead (tuning; a last class takes the rest);
+        // BT_GIBBS_FIXED_CLASSES=1: kClassLds for every kind; BT_GIBBS_KIND_CLASSES="g,h,s": classes per kind instead of the dealt ones.
+        const bool own_kernel = !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
+        const bool hot_kernel = !getenv("BT_GIBBS_NO_HOT_KERNEL"), single_kernel = hot_kernel && !getenv("BT_GIBBS_NO_SINGLE_KERNEL");
         auto hot_tile = [&](const TileDesc &d) {
             bool ok = hot_kernel && !d.simple && d.hot_bytes != 0 && (d.nvm == 1 || d.lds_all);
             for (int a = 0; a < A_COUNT && ok; ++a)
                 if (hot_core(a)) ok = d.hoff[a] != NOHOT;
             return ok;
         };
+        enum { KIND_GENERAL = 0, KIND_HOT = 1, KIND_SINGLE = 2, NKIND = 3 };
+        auto tile_kind = [&](const TileDesc &d) { return !hot_tile(d) ? KIND_GENERAL : (single_kernel && d.logged && d.nvm == 1 && d.NMm == 0 && d.split <= 4 ? KIND_SINGLE : KIND_HOT); };
+        std::vector<int> kind_of(ntiles, -1);   // -1: the two-haplotype class
+        for (uint32_t ti = 0; ti < ntiles; ++ti)
+            if (!(own_kernel && g->tiles[ti].simple && g->tiles[ti].split == 1)) kind_of[ti] = tile_kind(g->tiles[ti]);
+        std::vector<uint32_t> kind_cuts[NKIND];   // per kind: upper LDS bounds of its classes, ascending, the last one unbounded
+        if (getenv("BT_GIBBS_LDS_CLASSES") || getenv("BT_GIBBS_FIXED_CLASSES")) {
+            std::vector<uint32_t> class_lds(kClassLds, kClassLds + sizeof(kClassLds) / sizeof(kClassLds[0]));
+            if (const char *e = getenv("BT_GIBBS_LDS_CLASSES")) {
+                class_lds.clear();
+                for (const char *q = e; *q;) {
+                    class_lds.push_back((uint32_t)strtoul(q, nullptr, 10));
+                    while (*q && *q != ',') ++q;
+                    if (*q == ',') ++q;
+                }
+                class_lds.push_back(0xFFFFFFFFu);
+            }
+            for (auto &kc : kind_cuts) kc = class_lds;
+        } else {
+            constexpr uint32_t NB = 81;   // 2 KB bins
+            std::vector<uint64_t> cnt[NKIND];
+            std::vector<uint32_t> top[NKIND];
+            bool present[NKIND] = {false, false, false};
+            for (int k = 0; k < NKIND; ++k) cnt[k].assign(NB, 0), top[k].assign(NB, 0);
+            for (uint32_t ti = 0; ti < ntiles; ++ti) {
+                const int k = kind_of[ti];
+                if (k < 0) continue;
+                const uint32_t hb = tile_lds_bytes(g->tiles[ti]), b = std::min<uint32_t>(NB - 1, (hb + 2047) / 2048);
+                cnt[k][b] += 1;
+                top[k][b] = std::max(top[k][b], hb);
+                present[k] = true;
+            }
+            // best[k][n]: the least LDS charged to kind k's tiles in n classes, cuts[k][n]: the bins after which it cuts
+            uint64_t best[NKIND][4];
+            std::vector<uint32_t> cuts[NKIND][4];
+            for (int k = 0; k < NKIND; ++k) {
+                auto charged = [&](uint32_t lo, uint32_t hi) {   // bins [lo, hi]
+                    uint64_t n = 0;
+                    uint32_t m = 0;
+                    for (uint32_t b = lo; b <= hi; ++b) n += cnt[k][b], m = std::max(m, top[k][b]);
+                    return n * m;
+                };
+                best[k][0] = present[k] ? ~0ull : 0;
+                best[k][1] = charged(0, NB - 1);
+                best[k][2] = best[k][3] = ~0ull;
+                for (uint32_t a = 0; a + 1 < NB; ++a) {
+                    const uint64_t lo = charged(0, a);
+                    const uint64_t v2 = lo + charged(a + 1, NB - 1);
+                    if (v2 < best[k][2]) best[k][2] = v2, cuts[k][2] = {a};
+                    for (uint32_t b = a + 1; b + 1 < NB; ++b) {
+                        const uint64_t v3 = lo + charged(a + 1, b) + charged(b + 1, NB - 1);
+                        if (v3 < best[k][3]) best[k][3] = v3, cuts[k][3] = {a, b};
+                    }
+                }
+            }
+            int nk[NKIND] = {present[0] ? 1 : 0, present[1] ? 1 : 0, present[2] ? 1 : 0};
+            const int budget = std::max(3, nk[0] + nk[1] + nk[2]);
+            if (const char *e = getenv("BT_GIBBS_KIND_CLASSES")) {
+                int v[NKIND] = {1, 1, 1};
+                sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+                for (int k = 0; k < NKIND; ++k) nk[k] = present[k] ? std::min(3, std::max(1, v[k])) : 0;
+            } else {
+                uint64_t least = ~0ull;
+                int pick[NKIND] = {nk[0], nk[1], nk[2]};
+                for (int a = nk[0]; a <= (present[0] ? 3 : 0); ++a)
+                    for (int b = nk[1]; b <= (present[1] ? 3 : 0); ++b)
+                        for (int c = nk[2]; c <= (present[2] ? 3 : 0); ++c) {
+                            if (a + b + c > budget) continue;
+                            const uint64_t v = best[0][a] + best[1][b] + best[2][c];
+                            if (v < least) least = v, pick[0] = a, pick[1] = b, pick[2] = c;
+                        }
+                for (int k = 0; k < NKIND; ++k) nk[k] = pick[k];
+            }
+            for (int k = 0; k < NKIND; ++k) {
+                for (uint32_t a : cuts[k][nk[k]]) kind_cuts[k].push_back(a * 2048u);
+                kind_cuts[k].push_back(0xFFFFFFFFu);
+            }
+        }
+        std::vector<bt_gibbs::LaunchClass> byb[NKIND];
+        for (int k = 0; k < NKIND; ++k) byb[k].resize(kind_cuts[k].size());
         bt_gibbs::LaunchClass simple_class;
         simple_class.simple = true;
-        const bool own_kernel = !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
         for (uint32_t ti = 0; ti < ntiles; ++ti) {
             const uint32_t hb = tile_lds_bytes(g->tiles[ti]);
-            if (own_kernel && g->tiles[ti].simple && g->tiles[ti].split == 1) {
+            const int k = kind_of[ti];
+            if (k < 0) {
                 simple_class.tiles.push_back(ti);
                 simple_class.lds = std::max(simple_class.lds, hb);
                 continue;
             }
             size_t b = 0;
-            while (hb > class_lds[b]) ++b;
-            if (hot_tile(g->tiles[ti])) {
-                b += nclass;
-                byb[b].hot = true;
-            }
-            byb[b].tiles.push_back(ti);
-            byb[b].lds = std::max(byb[b].lds, hb);
-            byb[b].split = std::max(byb[b].split, g->tiles[ti].split);
+            while (hb > kind_cuts[k][b]) ++b;
+            auto &c = byb[k][b];
+            c.hot = k != KIND_GENERAL;
+            c.single = k == KIND_SINGLE;
+            c.tiles.push_back(ti);
+            c.lds = std::max(c.lds, hb);
+            c.split = std::max(c.split, g->tiles[ti].split);
         }
-        for (size_t b = nclass; b-- > 0;)   // hungriest first: those tiles run longest
-            for (size_t h : {b + nclass, b})
-                if (!byb[h].tiles.empty()) g->classes.push_back(std::move(byb[h]));
+        {   // hungriest first: those tiles run longest
+            std::vector<bt_gibbs::LaunchClass> all;
+            for (int k = 0; k < NKIND; ++k)
+                for (auto &c : byb[k])
+                    if (!c.tiles.empty()) all.push_back(std::move(c));
+            std::stable_sort(all.begin(), all.end(), [](const bt_gibbs::LaunchClass &a, const bt_gibbs::LaunchClass &b) { return a.lds > b.lds; });
+            for (auto &c : all) g->classes.push_back(std::move(c));
+        }
         if (!simple_class.tiles.empty()) g->classes.push_back(std::move(simple_class));
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_simple_kernel((int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_hot_kernel((int)kHotBudget));
+        BT_TRYHIP(prepare_gibbs_single_kernel((int)kHotBudget));
         lap("class cut");
         BT_TRYHIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         lap("event");
@@ -1886,7 +1951,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         }
         if (getenv("BT_GIBBS_DEBUG")) {   // tuning aid: how the batch was tiled
             fprintf(stderr, "bt_gibbs: %u tiles in %zu launch classes:", ntiles, g->classes.size());
-            for (auto &c : g->classes) fprintf(stderr, " [%zu tiles, lds %u B, split %u%s%s]", c.tiles.size(), c.lds, c.split, c.simple ? ", simple" : "", c.hot ? ", hot" : "");
+            for (auto &c : g->classes) fprintf(stderr, " [%zu tiles, lds %u B, split %u%s%s]", c.tiles.size(), c.lds, c.split, c.simple ? ", simple" : "", c.single ? ", single" : (c.hot ? ", hot" : ""));
             fprintf(stderr, "; tile 0: hot_bytes %u lds_stride %u copies %u\n", g->tiles[0].hot_bytes, g->tiles[0].lds_stride, g->tiles[0].copies);
         }
     }
@@ -1965,6 +2030,7 @@ int bt_gibbs_destroy(bt_gibbs *g) {
 
 int bt_gibbs_set_lut(bt_gibbs *g, const double *h_genomic, const double *h_noise) {
     if (!g || !h_genomic || !h_noise) return fail("bt_gibbs_set_lut: null argument");
+    if (chain_in_flight(g)) return fail("bt_gibbs_set_lut: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     BT_HIP(hipSetDevice(g->ctx->device));
     BT_HIP(hipMemcpyAsync(g->d_lut_g, h_genomic, (size_t)g->S * 65536 * 8, hipMemcpyHostToDevice, g->ctx->stream));
     BT_HIP(hipMemcpyAsync(g->d_lut_n, h_noise, (size_t)g->S * 256 * 8, hipMemcpyHostToDevice, g->ctx->stream));
@@ -1976,6 +2042,7 @@ int bt_gibbs_set_lut(bt_gibbs *g, const double *h_genomic, const double *h_noise
 
 int bt_gibbs_set_noise_lut(bt_gibbs *g, const double *h_noise) {
     if (!g || !h_noise) return fail("bt_gibbs_set_noise_lut: null argument");
+    if (chain_in_flight(g)) return fail("bt_gibbs_set_noise_lut: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     BT_HIP(hipSetDevice(g->ctx->device));
     BT_HIP(hipMemcpyAsync(g->d_lut_n, h_noise, (size_t)g->S * 256 * 8, hipMemcpyHostToDevice, g->ctx->stream));
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
@@ -2087,6 +2154,13 @@ double nc_timeout_seconds() {
     if (const char *e = getenv("BT_NOISE_CHAIN_TIMEOUT_S")) return std::max(0.001, atof(e));
     return 60.0;
 }
+double nc_rollcall_seconds() {   // how long the workgroups of a resident launch wait for each other to have STARTED (bt_noise_chain.hpp: roll call)
+    if (const char *e = getenv("BT_NOISE_CHAIN_ROLLCALL_S")) return std::max(0.001, atof(e));
+    return 2.0;
+}
+// a roll call failed on this device: something else holds wavefront slots there (a CU mask, another process, another rank), and it will for the chains to come —
+// the samplers of this process stop asking for resident launches on it instead of paying the roll call's deadline chain after chain
+std::atomic<bool> g_no_resident_chain[64];
 }  // namespace
 
 int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t first_collect, int *resident) {
@@ -2095,6 +2169,7 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     if (g->nc.active) return fail("bt_gibbs_noise_chain_begin: a chain is already in progress");
     if (!g->lut_set) return fail("bt_gibbs: count-model LUTs not set (bt_gibbs_set_lut)");
     if (num_iterations == 0 || getenv("BT_NOISE_CHAIN_OFF")) return BT_OK;
+    if (g->ctx->device >= 0 && g->ctx->device < 64 && g_no_resident_chain[g->ctx->device].load()) return BT_OK;
     BT_HIP(hipSetDevice(g->ctx->device));
     // (1) Can every tile have its workgroup resident at the same time?  One launch, one workgroup shape (gibbs_chain_kernel: a wavefront per tile, the LDS
     // need of the hungriest tile + the bins): tiles <= workgroups per CU x CUs, exactly.  Tiles with large dense tables want the whole-GPU refill between
@@ -2157,11 +2232,10 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
     const uint32_t total = g->ntiles;
     // (2) mailbox + device words
     const size_t nh = (size_t)g->S * 256;
-    if (!g->nc.h_mail) {
-        BT_HIP(ctx_host_take(g->ctx, reinterpret_cast<void **>(&g->nc.h_mail), nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped));
-        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_sync), nh * 8 + 512 + (size_t)NC_SEQ_COPIES * NC_SEQ_STRIDE * 4));
-        BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_ctl), sizeof(NoiseChainCtl)));
-    }
+    // (each pointer on its own: a failed allocation must not leave the next call with a mailbox but no device words)
+    if (!g->nc.h_mail) BT_HIP(ctx_host_take(g->ctx, reinterpret_cast<void **>(&g->nc.h_mail), nh * 16 + 512, hipHostMallocCoherent | hipHostMallocMapped));
+    if (!g->nc.d_sync) BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_sync), nh * 8 + 512 + (size_t)NC_SEQ_COPIES * NC_SEQ_STRIDE * 4));
+    if (!g->nc.d_ctl) BT_HIP(hipMalloc(reinterpret_cast<void **>(&g->nc.d_ctl), sizeof(NoiseChainCtl)));
     int wall_khz = 0;   // rate of wall_clock64() (the deadlines of the device-side waits)
     if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, g->ctx->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
     if (getenv("BT_GIBBS_DEBUG")) fprintf(stderr, "bt_gibbs_noise_chain_begin: wall clock %d kHz\n", wall_khz);
@@ -2175,6 +2249,8 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
         k.hist = reinterpret_cast<unsigned long long *>(g->nc.d_sync);
         k.arrived = reinterpret_cast<uint32_t *>(g->nc.d_sync + nh * 8);
         k.abort_flag = reinterpret_cast<uint32_t *>(g->nc.d_sync + nh * 8 + 256);
+        k.rollcall = reinterpret_cast<uint32_t *>(g->nc.d_sync + nh * 8 + 128);
+        k.rollcall_ticks = (unsigned long long)(std::min(nc_timeout_seconds(), nc_rollcall_seconds()) * 1e3 * wall_khz);
         k.table_seq = reinterpret_cast<uint32_t *>(g->nc.d_sync + nh * 8 + 512);
         k.lut_n = g->d_lut_n;
         k.h_hist = reinterpret_cast<unsigned long long *>(mail.hist);
@@ -2254,6 +2330,7 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
         g->nc.launched = true;
     }
     g->nc.active = true;
+    g->nc.fallback = false;
     g->nc.n = num_iterations;
     g->nc.next = 0;
     *resident = 1;
@@ -2268,6 +2345,15 @@ int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hi
     if (it == 0 && h_noise) return fail("bt_gibbs_noise_chain_step: the first iteration of a chain runs with the sampler's table (bt_gibbs_set_noise_lut before the chain)");
     const size_t nh = (size_t)g->S * 256;
     const NcMail mail = nc_mail(g);
+    if (g->nc.fallback) {   // the resident launch never started its sweeps (roll call): the chain continues launch by launch, the same values
+        const int rc = bt_gibbs_noise_iteration(g, it > 0 ? h_noise : nullptr, it >= g->nc.first_collect ? 1 : 0, h_hist);
+        if (rc != BT_OK) {
+            g->nc.active = g->nc.fallback = false;
+            return rc;
+        }
+        g->nc.next = it + 1;
+        return BT_OK;
+    }
     if (!g->nc.launched && it < g->nc.it_begin) {   // iteration 0 of a chain with large tables: ordinary launches (sweep with the whole-GPU refill, tally, one synchronisation)
         const int rc = bt_gibbs_noise_iteration(g, nullptr, it >= g->nc.first_collect ? 1 : 0, h_hist);
         if (rc != BT_OK) {
@@ -2318,7 +2404,20 @@ int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hi
         }
     }
     if (v == NC_ABORT) {
-        (void)bt_gibbs_noise_chain_end(g);
+        (void)bt_gibbs_noise_chain_end(g);   // (waits for the launch to have ended)
+        uint32_t code = 0;
+        if (it == g->nc.it_begin && hipMemcpy(&code, g->nc.d_sync + nh * 8 + 256, 4, hipMemcpyDeviceToHost) == hipSuccess && code == 2u) {
+            // ROLL CALL FAILED: the launch's workgroups did not all start — this GPU is not this process's alone — and none of them ran a sweep.  This and the
+            // chain's remaining iterations run as launches per iteration; later chains on this device do not try again.
+            if (g->ctx->device >= 0 && g->ctx->device < 64) g_no_resident_chain[g->ctx->device].store(true);
+            if (getenv("BT_GIBBS_DEBUG") || getenv("BT_STAGE_TIMES"))
+                fprintf(stderr, "bt_gibbs_noise_chain_step: the chain's %u workgroups were not resident together within %.1f s (is the GPU shared?): launches per iteration from here on\n",
+                        g->nc.num_wgs, std::min(nc_timeout_seconds(), nc_rollcall_seconds()));
+            g->nc.active = true;
+            g->nc.fallback = true;
+            g->nc.next = it;
+            return bt_gibbs_noise_chain_step(g, h_noise, h_hist);
+        }
         return fail("bt_gibbs_noise_chain_step: the resident launch gave up waiting (workgroups not resident together, or the host too slow: BT_NOISE_CHAIN_TIMEOUT_S)" + nc_state_text(g, it));
     }
     std::memcpy(h_hist, mail.hist, nh * 8);
@@ -2329,6 +2428,10 @@ int bt_gibbs_noise_chain_step(bt_gibbs *g, const double *h_noise, uint64_t *h_hi
 int bt_gibbs_noise_chain_end(bt_gibbs *g) {
     if (!g) return fail("bt_gibbs_noise_chain_end: null handle");
     if (!g->nc.active) return BT_OK;
+    if (g->nc.fallback) {   // (nothing resident)
+        g->nc.active = g->nc.fallback = false;
+        return BT_OK;
+    }
     (void)hipSetDevice(g->ctx->device);
     const NcMail mail = nc_mail(g);
     const bool complete = g->nc.next >= g->nc.n;
@@ -2463,6 +2566,7 @@ int bt_gibbs_reset_groups(bt_gibbs *g) {
 
 int bt_gibbs_posterior_summary(bt_gibbs *g, uint32_t *d_out) {
     if (!g || !d_out) return fail("bt_gibbs_posterior_summary: null argument");
+    if (chain_in_flight(g)) return fail("bt_gibbs_posterior_summary: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     BT_HIP(hipSetDevice(g->ctx->device));
     hipLaunchKernelGGL(summary_kernel, dim3((g->C + 255) / 256), dim3(256), 0, g->ctx->stream, g->d_tiles, g->d_pool, g->d_loc, g->C, g->S, d_out);
     BT_CHECK_LAUNCH();
@@ -2521,6 +2625,7 @@ static int result_offsets(bt_gibbs *g, std::vector<uint64_t> &dip_off, std::vect
 
 int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t *num_allele_cells) {
     if (!g) return fail("bt_gibbs_result_sizes: null handle");
+    if (chain_in_flight(g)) return fail("bt_gibbs_result_sizes: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     std::vector<uint64_t> dip_off, cell_off;
     const int rc = result_offsets(g, dip_off, cell_off);
     if (rc != BT_OK) return rc;
@@ -2534,6 +2639,7 @@ int bt_gibbs_result_sizes(bt_gibbs *g, uint64_t *num_diplotype_entries, uint64_t
 int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, uint16_t *h_dip_h2, uint32_t *h_dip_freq, uint64_t *h_cell_off,
                           double *h_stats) {
     if (!g || !h_dip_off || !h_cell_off) return fail("bt_gibbs_result_fetch: null argument");
+    if (chain_in_flight(g)) return fail("bt_gibbs_result_fetch: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     std::vector<uint64_t> dip_off, cell_off;
     {
         const int rc = result_offsets(g, dip_off, cell_off);
@@ -2589,6 +2695,7 @@ int bt_gibbs_result_fetch(bt_gibbs *g, uint64_t *h_dip_off, uint16_t *h_dip_h1, 
 // or bt_gibbs_destroy) and is complete when the call returns.
 int bt_gibbs_result_words(bt_gibbs *g, const uint32_t **d_words, uint64_t *num_words) {
     if (!g || !d_words || !num_words) return fail("bt_gibbs_result_words: null argument");
+    if (chain_in_flight(g)) return fail("bt_gibbs_result_words: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     std::vector<uint64_t> dip_off, cell_off;
     {
         const int rc = result_offsets(g, dip_off, cell_off);
@@ -2640,6 +2747,7 @@ int bt_gibbs_result_words(bt_gibbs *g, const uint32_t **d_words, uint64_t *num_w
 
 int bt_gibbs_trace_enable(bt_gibbs *g, uint32_t max_sweeps) {
     if (!g) return fail("bt_gibbs_trace_enable: null handle");
+    if (chain_in_flight(g)) return fail("bt_gibbs_trace_enable: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     BT_HIP(hipSetDevice(g->ctx->device));
     BT_HIP(hipStreamSynchronize(g->ctx->stream));
     if (g->d_trace) {
@@ -2670,6 +2778,7 @@ int bt_gibbs_trace_enable(bt_gibbs *g, uint32_t max_sweeps) {
 // h_trace: groups in batch order; group gi contributes [max_sweeps][nvert(gi)][S] words
 int bt_gibbs_trace_fetch(bt_gibbs *g, uint32_t *h_trace, uint64_t max_words, uint64_t *num_sweeps_recorded) {
     if (!g || !h_trace) return fail("bt_gibbs_trace_fetch: null argument");
+    if (chain_in_flight(g)) return fail("bt_gibbs_trace_fetch: a resident noise chain is in progress (bt_gibbs_noise_chain_end): the call would wait behind its launch");
     if (!g->d_trace) return fail("bt_gibbs_trace_fetch: tracing is off");
     uint64_t need = 0;
     for (uint32_t gi = 0; gi < g->G; ++gi) need += (uint64_t)g->trace_sweeps * g->group_nvert[gi] * g->S;
@@ -2737,6 +2846,8 @@ int bt_diag_prof(unsigned long long *h_out16, int reset) {
     BT_HIP(bt::simple_prof_read(more, reset));
     for (int i = 0; i < 32; ++i) h_out16[i] += more[i];
     BT_HIP(bt::hot_prof_read(more, reset));   // ... and gibbs_hot_kernel's
+    for (int i = 0; i < 32; ++i) h_out16[i] += more[i];
+    BT_HIP(bt::single_prof_read(more, reset));   // ... and gibbs_single_kernel's
     for (int i = 0; i < 32; ++i) h_out16[i] += more[i];
     return BT_OK;
 }

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(LANES, 2) void gibbs_chain_kernel(const TileDesc *_
         // but few tiles — a 2 000-group batch at thirty samples is 70 tiles, 70 wavefronts for what ucache_prefill_kernel spreads over the whole GPU between
         // ordinary launches — so the launch is topped up with helpers: they wait for every table, take work units until there are none, and arrive.
         Env env{tiles, pool, Pg, nullptr, 0xFFFFFFFFu};
-        nc_begin(ctl);
+        if (!nc_begin(ctl)) return;
         for (uint32_t i = ctl->it_begin; i < ctl->n_iterations; ++i) {
             if (i > ctl->it_begin) {
                 if (!nc_wait_table(ctl, i)) break;

@@ -4,6 +4,7 @@
 // hot_core) — ds instructions — where the general kernel reaches them through generic pointers that may point to LDS or HBM (flat instructions: both
 // wait counters, and a wait for any of them is a wait for all memory operations in flight).
 #define BT_HOT_ALL 1
+#define BT_NO_NOISE_CHAIN 1
 #ifndef BT_SWEEP_OUTLINE
 #define BT_SWEEP_INLINE
 #endif
@@ -13,7 +14,7 @@ namespace {
 using namespace bt;
 __global__ __launch_bounds__(LANES * 8, GIBBS_WAVES) void gibbs_hot_kernel(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg, int op, uint32_t arg0,
                                                                            uint32_t arg1, unsigned long long *__restrict__ hist, TraceCfg tr, const uint32_t *__restrict__ tile_list) {
-    if (!(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || op == OP_NOISE_CHAIN)) return;   // (the other operations read the arrays in HBM: gibbs_kernel)
+    if (!(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN)) return;   // (the other operations read the arrays in HBM: gibbs_kernel; chains of a noise driver: gibbs_chain_kernel)
     gibbs_body<false>(tiles, pool, Pg, op, arg0, arg1, hist, tr, tile_list);
 }
 }  // namespace

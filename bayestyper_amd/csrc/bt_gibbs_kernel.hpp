@@ -254,10 +254,14 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     if (t.d->prio) __builtin_amdgcn_s_setprio(3);
     TPtr<uint32_t> gd = t.arr<uint32_t>(A_GDIMS);
     if (!gd[3]) return;   // padding lane of the last tile
-    const uint32_t nvert = gd[0], nsrc = gd[1], gindex = gd[2];
+    const uint32_t nvert = kSingle ? 1u : (uint32_t)gd[0], nsrc = kSingle ? 1u : (uint32_t)gd[1], gindex = gd[2];
     // OP_NOISE_CHAIN: a whole chain of a noise driver, the tiles resident (bt_noise_chain.hpp); `hist` carries the launch class's control block.
     // (Lane 0 of a tile is always a group, so thread 0 and wavefront 0 of the workgroup are still here.)
+#ifdef BT_NO_NOISE_CHAIN   // translation units whose kernel is never launched for a resident chain (gibbs_hot_kernel, gibbs_single_kernel: bt_gibbs.hip launch())
+    const bool is_nc = false;
+#else
     const bool is_nc = op == OP_NOISE_CHAIN;
+#endif
     const NoiseChainCtl *nc = is_nc ? (const NoiseChainCtl *)hist : nullptr;
     // groups of ONE cluster keep that cluster's hot arrays in LDS for the whole launch; larger groups swap per vertex visit
     // (and so do multi-cluster groups of narrow tiles, whose LDS rows are interleaved over fewer lanes: TileDesc::lds_all)
@@ -284,7 +288,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
         if (is_nc) {
             n_burn = nc->first_collect < nc->n_iterations ? nc->first_collect : nc->n_iterations;
             n_collect = nc->n_iterations - n_burn;
-            nc_begin(nc);
+            if (!nc_begin(nc)) n_burn = n_collect = 0;   // the launch's workgroups are not resident together: no sweep, the state as it was (bt_noise_chain.hpp: roll call)
         }
         for (uint32_t chain = 0; chain < nchains; ++chain) {
             if (is_run) {
@@ -308,7 +312,18 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
                     }
                     if (is_nc) nc_phase(nc, 0x40000000u | i);
                     const TraceRow r = trace_row_for(t, P, tr, tile);
-                    group_sweep(env, t, P, i >= n_burn, nvert, nsrc, r.row, r.on);
+                    if constexpr (kSingle) {   // VariantClusterGroup::estimateGenotypes of a one-cluster group: the one visit
+                        if (r.on)
+                            for (uint32_t q = 0; q < P.S; ++q) r.row[q] = 0xFFFFFFFFu;
+                        const Vx root = make_vx(t, 0);
+                        TPtr<uint8_t> gploidy = t.arr<uint8_t>(A_PLOIDY);
+                        for (uint32_t q = 0; q < P.S; ++q) {
+                            root.nest_ploidy()[q] = gploidy[q];
+                            root.nest_n()[q] = 0;
+                        }
+                        visit_vertex(env, t, P, 0u, i >= n_burn, r.row, r.on);
+                    } else
+                        group_sweep(env, t, P, i >= n_burn, nvert, nsrc, r.row, r.on);
                     if (is_nc) {
                         nc_phase(nc, 0x50000000u | i);
                         noise_tally_group(env, nvert, nc);

@@ -35,6 +35,14 @@ constexpr double BT_DBL_EPS = 2.220446049250313080847263336181640625e-16;
 #define BT_EVAL_BLOCK 4u        // candidates evaluated per step of sample_diplotypes' blocked evaluation (their cache words are requested together)
 #endif
 constexpr uint32_t EVB = BT_EVAL_BLOCK;
+// BT_SINGLE: the translation unit of gibbs_single_kernel (bt_gibbs_single_kernel.hip) — every group of its tiles is ONE cluster without multicluster
+// k-mers (TileDesc::logged tiles: nvm == 1, NMm == 0).  The nested-group traversal, the multicluster sums and the immediate statistics path are
+// compiled out of the sweep, which then fits three wavefronts per SIMD.
+#ifdef BT_SINGLE
+constexpr bool kSingle = true;
+#else
+constexpr bool kSingle = false;
+#endif
 constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
 
 // scalar slots per vertex (A_SC)
@@ -417,7 +425,7 @@ __device__ inline Vx make_vx(const Tile &t, uint32_t v) {
     SPtrF<uint32_t, LANES> sc = t.harr<uint32_t>(A_SC, v, SC_COUNT);
     x.H = sc[SC_H];
     x.V = sc[SC_V];
-    x.nm = sc[SC_NM];
+    x.nm = kSingle ? 0u : (uint32_t)sc[SC_NM];
     return x;
 }
 __device__ inline uint32_t vx_nd(const Vx &c) { return c.t.arr<uint32_t>(A_VDIMS, c.v * 8)[5]; }
@@ -750,7 +758,7 @@ __device__ inline void cache_clear(const Vx &c, const GParams BT_CAS &P, bool al
         for (uint32_t i = all_copies_run ? c.t.part * sub : 0u, e = i + sub; i < e; ++i) tg[i] = 0;
     }    // ... and the multicluster sums (the reference clears both maps): their entries are stamped with the sample's generation, so a bump
     // invalidates them.  (Without it a sum cached under the previous noise table survived clearGenotyperCache in the noise drivers.)
-    if (d.NMm) {
+    if (!kSingle && d.NMm) {
         SPtrF<uint32_t, LANES> mg = c.mgen();
         for (uint32_t s = 0; s < P.S; ++s) mg[s] += 1;
     }
@@ -1569,16 +1577,23 @@ __device__ inline void apply_collected_log(const Vx &c, const GParams BT_CAS &P,
     }
     c.evn()[s] = 0;
 }
+template <bool ROOM_CHECKED = false>   // ROOM_CHECKED: the caller has applied a full log already (apply_full_log, out of line)
 __device__ inline void log_collected_run(const Vx &c, const GParams BT_CAS &P, uint32_t s, uint32_t key, uint32_t r, uint32_t nsub_u) {
     TPtr<uint32_t> lg = c.evlog(s);
     uint32_t n = c.evn()[s];
-    if (n == EV_CAP) {   // (a sample that keeps changing its diplotype: apply what is logged now)
+    if (!ROOM_CHECKED && n == EV_CAP) {   // (a sample that keeps changing its diplotype: apply what is logged now)
         apply_collected_log(c, P, s, nsub_u);
         n = 0;
     }
     lg[1 + 2 * n] = key;   // (stores only: nothing waits for HBM while sampling)
     lg[2 + 2 * n] = r;
     c.evn()[s] = (uint8_t)(n + 1);
+}
+// gibbs_single_kernel: the early application of a full log as a function of its own (once in thousands of sweeps; inlined, the statistics code would
+// sit in the middle of the sweep's register allocation)
+__device__ BT_NOINLINE void apply_full_log(Env env, uint32_t s) {
+    const Vx c = make_vx(make_tile(env), 0);
+    apply_collected_log(c, env_params(env), s, c.sc()[SC_NSUB_U]);
 }
 // end of a chain / of a launch: the open runs join the log, the log is applied
 __device__ BT_NOINLINE void drain_collected(Env env) {
@@ -1619,7 +1634,7 @@ __device__ BT_SWEEPFN void update_allele_kmer_stats(Env env, uint32_t vtx, uint3
     const GParams BT_CAS &P = env_params(env);
     SPtrF<uint16_t, LANES> dip = c.dip(), pdip = c.pend_dip();
     SPtrF<uint8_t, LANES> upd = c.ksc_upd(), pvalid = c.pend_valid();
-    if (c.d().logged) {   // single cluster, no multicluster k-mers: log the run, apply it with everybody else's at the end of the chain
+    if (kSingle || c.d().logged) {   // single cluster, no multicluster k-mers: log the run, apply it with everybody else's at the end of the chain
         SPtrF<uint32_t, LANES> pend = c.pend();
         for (uint32_t s = 0; s < P.S; ++s) {
             const uint16_t h1 = dip[2 * s], h2 = dip[2 * s + 1];
@@ -1627,7 +1642,13 @@ __device__ BT_SWEEPFN void update_allele_kmer_stats(Env env, uint32_t vtx, uint3
                 pend[s] += 1;
                 continue;
             }
-            if (pvalid[s] && pend[s]) log_collected_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], nsub_u);
+            if (pvalid[s] && pend[s]) {
+                if (kSingle) {
+                    if (c.evn()[s] == EV_CAP) apply_full_log(env, s);
+                    log_collected_run<true>(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], nsub_u);
+                } else
+                    log_collected_run(c, P, s, (uint32_t)pdip[2 * s] | ((uint32_t)pdip[2 * s + 1] << 16), pend[s], nsub_u);
+            }
             pdip[2 * s] = h1;
             pdip[2 * s + 1] = h2;
             pend[s] = 1;
@@ -1670,8 +1691,8 @@ __device__ BT_SWEEPFN void sample_diplotypes(Env env, uint32_t vtx, bool collect
     const GParams BT_CAS &P = env_params(env);
     const TPtr<uint32_t> trace_row{(uint32_t BT_GAS *)uniform_ptr(trace_buf), trace_word, 6u};   // (trace blocks are interleaved over 64 lanes whatever the tile)
     SPtrF<uint32_t, LANES> sc = c.sc();
-    const uint32_t nsub_u = sc[SC_NSUB_U], nsub_m = sc[SC_NSUB_M];
-    const bool use_multi = sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
+    const uint32_t nsub_u = sc[SC_NSUB_U], nsub_m = kSingle ? 0u : (uint32_t)sc[SC_NSUB_M];
+    const bool use_multi = !kSingle && sc[SC_USE_MULTI] != 0, is_sparse = sc[SC_IS_SPARSE] != 0;
     uint32_t hap_count = sc[SC_HAP_COUNT];
     PROF_DECL;
     if (sc[SC_UC_DIRTY] == 2u) {   // invalidate only: NaN marks "not computed" (unique_log_prob fills on demand)
@@ -1967,7 +1988,7 @@ __device__ BT_SWEEPFN void sample_diplotypes(Env env, uint32_t vtx, bool collect
         const uint16_t p1 = dip[2 * ss], p2 = dip[2 * ss + 1];
         dip[2 * ss] = h1;
         dip[2 * ss + 1] = h2;
-        if (c.d().nvm > 1u && (h1 != p1 || h2 != p2)) c.nver()[ss] += 1;
+        if (!kSingle && c.d().nvm > 1u && (h1 != p1 || h2 != p2)) c.nver()[ss] += 1;
         hfd_increment(c, h1, is_sparse, hap_count);
         hfd_increment(c, h2, is_sparse, hap_count);
         PROF(4);

@@ -34,7 +34,9 @@ struct NoiseChainCtl {   // device memory, one per launch class (the pointers ar
     unsigned long long *hist;          // device [S * 256]
     uint32_t *arrived;                 // device: workgroups that finished an iteration, counted over the whole chain
     uint32_t *table_seq;               // device [NC_SEQ_COPIES * NC_SEQ_STRIDE]: tables 1 .. table_seq have been handed to the device
-    uint32_t *abort_flag;              // device: a deadline passed somewhere
+    uint32_t *abort_flag;              // device: a deadline passed somewhere (1), or the roll call at the start of the launch was incomplete (2: no sampler state was touched)
+    uint32_t *rollcall;                // device: workgroups of the launch that have started (nc_begin)
+    unsigned long long rollcall_ticks; // wall_clock64() ticks the roll call may last
     double *lut_n;                     // device [S * 256]: the sampler's noise table (GParams::lut_n)
     unsigned long long *h_hist;        // host mailbox [S * 256]
     double *h_table;                   // host mailbox [S * 256]
@@ -100,20 +102,54 @@ __device__ inline void nc_tally(const NoiseChainCtl *ctl, uint32_t NC_LAS *bins,
     else __hip_atomic_fetch_add(&ctl->hist[s * 256u + cnt], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ inline void nc_abort(const NoiseChainCtl *ctl) {
-    __hip_atomic_store(ctl->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ inline void nc_abort(const NoiseChainCtl *ctl, uint32_t code = 1u) {
+    __hip_atomic_store(ctl->abort_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t c = 0; c < NC_SEQ_COPIES; ++c) __hip_atomic_store(&ctl->table_seq[c * NC_SEQ_STRIDE], NC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(ctl->h_hist_seq, NC_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Start of the workgroup's part of a chain: every thread of the workgroup calls it (no thread has left the kernel).
-__device__ static __noinline__ void nc_begin(const NoiseChainCtl *ctl) {
+// ROLL CALL.  The workgroups of a chain wait for each other every iteration, so all of them must be resident at once.  The host checks that against the
+// whole GPU's capacity (bt_gibbs_noise_chain_begin) — but a CU mask, another process or a second rank on the same GPU take slots the check cannot see.  So
+// before any sampler state is touched every workgroup reports in and waits until all have: a launch whose workgroups are not co-resident fails HERE, within
+// `rollcall_ticks` (a resident launch is complete within milliseconds), with abort code 2, and the host runs the chain launch by launch instead
+// (bt_gibbs_noise_chain_step).  Returns false when the chain was aborted: the caller runs no sweep.
+__device__ static __noinline__ bool nc_begin(const NoiseChainCtl *ctl) {
     uint32_t NC_LAS *bins = nc_bins(ctl);
+    uint32_t NC_LAS *flag = bins + ctl->S * NC_BINS;
     const NcLanes L = nc_lanes();
     if (L.on)
         for (uint32_t i = L.rank; i <= ctl->S * NC_BINS; i += L.count) bins[i] = 0;
     if (ctl->busy && threadIdx.x == 0) *(unsigned long long NC_LAS *)(bins + ((ctl->S * NC_BINS + 2u) & ~1u)) = (unsigned long long)wall_clock64();
+    __builtin_amdgcn_wave_barrier();
     __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctl->rollcall, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        uint32_t bad = 0;
+        while (__hip_atomic_load(ctl->rollcall, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ctl->total_wgs) {
+            if (__hip_atomic_load(ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                bad = 1;
+                break;
+            }
+            if (wall_clock64() - t0 > ctl->rollcall_ticks) {
+                nc_abort(ctl, 2u);
+                bad = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(20);
+        }
+        if (!bad && __hip_atomic_load(ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) bad = 1;   // (someone gave up while the last ones reported in)
+        *flag = bad;
+    }
+    __builtin_amdgcn_wave_barrier();   // (keeps a one-wavefront workgroup's lanes together where its s_barrier is dropped, see bt_noise_help.hpp)
+    __syncthreads();
+    const bool ok = *flag == 0;
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = 0;
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    return ok;
 }
 
 // Before iteration `it` >= 1: wait until the table drawn from iteration it - 1's counts is the sampler's.  Every thread of the workgroup calls it.

@@ -257,7 +257,8 @@ void InferenceEngine::runNoiseChain(Sampler *sampler, CountDistribution *cd, uin
     } guard{nullptr};
     {
         StageScope stage("  noise chains: resident launch set up");
-        if (sampler && pending_noise == false && sampler->beginResidentChain(n, first_collect_iteration - 1)) guard.s = sampler;
+        const bool reducer_blocks = reduce_hist && reduce_on_stream;   // (host <-> device deadlock until the chain's deadline)
+        if (sampler && pending_noise == false && !reducer_blocks && sampler->beginResidentChain(n, first_collect_iteration - 1)) guard.s = sampler;
     }
     for (uint32_t it = 1; it <= n; it++) {
         iteration(sampler, cd, it >= first_collect_iteration);

@@ -124,7 +124,12 @@ class InferenceEngine {
     bool lowNoiseVariantWarning() const { return low_variant_warning; }
     uint32_t numLaunches() const { return num_launches; }   // of the last estimateGenotypes
     void setSamplerFactory(SamplerFactory f) { make_sampler = std::move(f); }
-    void setHistReducer(HistReducer r) { reduce_hist = std::move(r); }
+    // uses_device_stream: the reducer copies / reduces on the context's stream (Comm over RCCL) — it would queue behind a resident chain launch that is itself
+    // waiting for the reduced histogram, so with such a reducer the chains run launch by launch (the files transport and the tests' reducers stay on the host)
+    void setHistReducer(HistReducer r, bool uses_device_stream = false) {
+        reduce_hist = std::move(r);
+        reduce_on_stream = uses_device_stream;
+    }
     // with several ranks the noise chains stay on the device only if the histogram can be reduced there (Comm over RCCL: bt_comm_allreduce_hist)
     void setDeviceHistReducer(GibbsSampler::DeviceReducer r) { device_reduce = std::move(r); }
     // every row of the noise parameter file in full precision: (chain, iteration, rate_0 .. rate_{S-1}) per row (tests compare these, the file has 6 digits)
@@ -147,6 +152,7 @@ class InferenceEngine {
     std::vector<std::string> sample_names;
     GibbsOptions opt;
     HistReducer reduce_hist;
+    bool reduce_on_stream = false;
     bool low_variant_warning = false;
     uint32_t num_launches = 0;
     SamplerFactory make_sampler;

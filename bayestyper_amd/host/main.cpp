@@ -409,7 +409,7 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     std::vector<uint32_t> unit_clusters, unit_variants;   // per group of the WHOLE unit (estimateNoise selects its groups from them on every rank alike)
     GibbsBatchData shard;
     if (comm) {
-        inference_engine.setHistReducer([&](uint64_t *hist, size_t n) { comm->allreduceHist(hist, n); });
+        inference_engine.setHistReducer([&](uint64_t *hist, size_t n) { comm->allreduceHist(hist, n); }, /*uses_device_stream=*/comm->deviceReduction());
         if (comm->deviceReduction()) inference_engine.setDeviceHistReducer([&](uint64_t *d_hist, size_t n) { comm->allreduceDeviceAsync(d_hist, n); });
         rank_groups = assignGroups(batch, world);
         shard = batch.take(rank_groups[rank]);
@@ -511,9 +511,16 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
             });
         if (!noise_genotyping) inference_engine.estimateGenotypes(my_batch, count_distribution, keep);
         else inference_engine.estimateNoiseAndGenotypes(my_batch, &count_distribution, keep, noise_prefix);
-        const bool from_host = mine.dip_off.size() > 1;
-        if ((from_host ? mine.dip_off.size() - 1 : device_clusters) != (size_t)my_batch.numClusters() || (from_host && device_clusters))
-            throw std::runtime_error("rank " + std::to_string(rank) + ": collected samples do not cover the rank's clusters");
+        bool from_host = mine.dip_off.size() > 1;
+        const bool covered = (from_host ? mine.dip_off.size() - 1 : device_clusters) == (size_t)my_batch.numClusters() && !(from_host && device_clusters);
+        {   // the ranks AGREE on the path (and on a failure) before the first collective of the gather: the two paths happen to issue the same collectives
+            // today, but nothing else keeps a rank without clusters — which has neither kind of result — on its peers' path
+            uint64_t votes[3] = {from_host ? 1u : 0u, !from_host && device_clusters ? 1u : 0u, covered ? 0u : 1u};
+            comm->allreduceHist(votes, 3);
+            if (votes[2]) throw std::runtime_error("rank " + std::to_string(rank) + ": collected samples do not cover " + (covered ? "another rank's" : "the rank's") + " clusters");
+            if (votes[0] && votes[1]) throw std::runtime_error("the ranks collected their samples in different ways (BT_GATHER_FROM_HOST set on some ranks only?)");
+            from_host = votes[0] != 0;
+        }
         std::unique_ptr<StageScope> gather_stage(new StageScope("gather of the collected samples to rank 0"));
         const BatchResults all = from_host ? gatherResults(*comm, batch, rank_groups, mine, (uint32_t)S) : gatherResults(*comm, batch, rank_groups, on_device, (uint32_t)S);
         gather_stage.reset();

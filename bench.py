@@ -404,7 +404,9 @@ def main():
         from bayestyper_amd.host import genotypes as hgt
 
         mf = hgt.min_fraction_observed_kmers([15.0] * S)
-        cores_ = os.cpu_count() or 1
+        from bayestyper_amd import hostinfo as _hi
+
+        cores_ = _hi.baseline_threads(_hi.host_facts())   # (host threads as `bayesTyper genotype -p` would be given on this box: two per core of the container's quota)
         tg_ = time.perf_counter()
         nbytes = hgt.batch_output_columns(flat, state["res"], mf, cores_)
         collect_all = time.perf_counter() - tg_
@@ -431,17 +433,25 @@ def main():
         import _oracle
 
         orc = _oracle.load_oracle()
-        cores = os.cpu_count() or 1
+        from bayestyper_amd import hostinfo, shard
+
+        # what the box gives this process: the cgroup quota, not os.cpu_count(), is the number of cores a CPU leg can use (round 5 reported "256 cores" on a
+        # box whose container had a 16-core quota and ran 256 threads on it: 9x one thread where 32 threads give 16.7x, tools/cpu_scaling.py)
+        facts = hostinfo.host_facts()
+        cores = hostinfo.baseline_threads(facts)   # threads of the all-cores legs
         og_lut_g, og_lut_n = _oracle.build_luts(orc, S)
 
-        def cpu_leg(n_groups, threads, seed):
-            cf = synth.make_mixture(n_groups, S, seed=seed)
+        def cpu_run(cf, threads):
             og = _oracle.OrcGibbs(orc, cf, og_lut_g, og_lut_n, seed=42)
             tc = time.perf_counter()
             og.run(threads)
             dt = time.perf_counter() - tc
             og.close()
-            return cf, dt
+            return dt
+
+        def cpu_leg(n_groups, threads, seed):
+            cf = synth.make_mixture(n_groups, S, seed=seed)
+            return cf, cpu_run(cf, threads)
 
         # all cores: a short probe sizes the sample for ~args.cpu_seconds of work (the tail of a small sample — a few long nested groups per
         # thread — would otherwise dominate); one core: a sample of its own, a few seconds
@@ -452,15 +462,23 @@ def main():
         cpu_sweeps = cflat["num_clusters"] * sweeps_per_group
         # one core: a down-scaled copy of the SAME batch — every k-th group of the all-cores sample (its groups are ordered by class, so the class
         # mix is the all-cores leg's; round 4 generated a small mixture of its own, whose rounding gave it another mix)
-        from bayestyper_amd import shard
-
         stride = max(1, int(round(cflat["num_groups"] / max(256, n_cpu / cores * 0.4))))
         one_flat = shard.take_groups(cflat, np.arange(0, cflat["num_groups"], stride))
-        og1 = _oracle.OrcGibbs(orc, one_flat, og_lut_g, og_lut_n, seed=42)
-        tc1 = time.perf_counter()
-        og1.run(1)
-        one_s = time.perf_counter() - tc1
-        og1.close()
+        one_s = cpu_run(one_flat, 1)
+        # thread scaling on every k-th group of that sample (k chosen per thread count so that a point takes a few seconds)
+        scaling = {"1": {"groups": int(one_flat["num_groups"]), "s": one_s, "value": one_flat["num_clusters"] * sweeps_per_group / one_s},
+                   str(cores): {"groups": int(cflat["num_groups"]), "s": cpu_s, "value": cpu_sweeps / cpu_s}}
+        for nthr in (8, 32, 64, facts["affinity"]):
+            if str(nthr) in scaling or nthr > facts["affinity"]:
+                continue
+            per_thread_s = 3.0
+            want = max(256, int(rate * min(nthr, facts["effective_cores"]) / max(1.0, min(cores, facts["effective_cores"])) * per_thread_s / sweeps_per_group))
+            k = max(1, cflat["num_groups"] // want)
+            sf = shard.take_groups(cflat, np.arange(0, cflat["num_groups"], k)) if k > 1 else cflat
+            ds = cpu_run(sf, nthr)
+            scaling[str(nthr)] = {"groups": int(sf["num_groups"]), "s": ds, "value": sf["num_clusters"] * sweeps_per_group / ds}
+        for v_ in scaling.values():
+            v_["over_one_thread"] = v_["value"] / scaling["1"]["value"]
         cpu_one = one_flat["num_clusters"] * sweeps_per_group / one_s
         # k-mer matching: decode -> Bloom lookup for a bounded slice of an equivalent database — the reference's shape (ONE producer thread
         # decoding the KMC records, KmerCounter.cpp:469-505) and the best-effort shape (every core decodes its own record range)
@@ -496,7 +514,8 @@ def main():
                 db.close()
         except Exception:   # the k-mer CPU leg is informative only
             pass
-        cpu = {"value": cpu_sweeps / cpu_s, "unit": "cluster-sweeps/s", "cores": cores, "kind": "port",
+        cpu = {"value": cpu_sweeps / cpu_s, "unit": "cluster-sweeps/s", "cores": facts["effective_cores"], "threads": cores, "kind": "port",
+               "host": facts, "scaling": dict(sorted(scaling.items(), key=lambda kv: int(kv[0]))),
                "sample": f"{cflat['num_groups']} groups of the same shape mixture ({cflat['mixture']}), S={S}, full 20x350 schedule, "
                          f"{cpu_s:.1f} s on {cores} threads (oracle/oracle_gibbs.cpp; threads pull groups from a shared queue, largest first, as InferenceEngine.cpp:335-382)",
                "one_core": {"value": cpu_one, "sample": f"every {stride}th group of the all-cores sample ({one_flat['num_groups']} groups, the same class mix), {one_s:.1f} s on 1 thread"},
@@ -601,14 +620,14 @@ def main():
                  "device_bytes": g10_bytes}
         del f10x
         if not args.no_cpu_baseline:
-            c10 = synth.make_mixture(max(2048, 12 * (os.cpu_count() or 1)), S10, seed=1011)
+            c10 = synth.make_mixture(max(2048, 64 * cores), S10, seed=1011)
             og = _oracle.OrcGibbs(orc, c10, *_oracle.build_luts(orc, S10), seed=42)
             tc = time.perf_counter()
-            og.run(os.cpu_count() or 1)
+            og.run(cores)
             dt = time.perf_counter() - tc
             og.close()
             rec10["cpu_allcores_cluster_sweeps_per_sec"] = c10["num_clusters"] * sweeps_per_group / dt
-            rec10["cpu_sample"] = f"{c10['num_groups']} groups, {dt:.1f} s on {os.cpu_count()} threads"
+            rec10["cpu_sample"] = f"{c10['num_groups']} groups, {dt:.1f} s on {cores} threads ({facts['effective_cores']:.0f} effective cores)"
             rec10["gpu_over_cpu_allcores"] = rec10["cluster_sweeps_per_sec"] / rec10["cpu_allcores_cluster_sweeps_per_sec"]
         issue10, issue10_src = committed_issue_profile(S10, int(rec10["groups"]))
         if issue10:
@@ -654,11 +673,11 @@ def main():
             it_cpu = (2, 3)
             og = _oracle.OrcGibbs(orc, f30, *cd30.tables(), noise_seeding=1, seed=42, chains=1, burn=it_cpu[0], iters=it_cpu[1])
             tc = time.perf_counter()
-            og.estimate_noise_and_genotypes(threads=os.cpu_count() or 1)
+            og.estimate_noise_and_genotypes(threads=cores)
             dt = time.perf_counter() - tc
             og.close()
             rec30["cpu_allcores_cluster_sweeps_per_sec"] = f30["num_clusters"] * sum(it_cpu) / dt
-            rec30["cpu_sample"] = f"the same batch, {sum(it_cpu)} iterations, {dt:.1f} s on {os.cpu_count()} threads (groups of an iteration dealt to the threads)"
+            rec30["cpu_sample"] = f"the same batch, {sum(it_cpu)} iterations, {dt:.1f} s on {cores} threads (groups of an iteration dealt to the threads)"
             rec30["gpu_over_cpu_allcores"] = rec30["noise_genotyping_cluster_sweeps_per_sec"] / rec30["cpu_allcores_cluster_sweeps_per_sec"]
         cd30.close()
         extra["noise_genotyping"] = rec30

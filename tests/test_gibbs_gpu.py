@@ -1,6 +1,8 @@
 """GPU parity tests for the Gibbs genotyping path (through the C ABI) against the oracle on identical inputs and seed.
 Bar (BASELINE.json north_star): genotype posteriors within 1e-4.  The draw streams are reproduced exactly, so the integer
 diplotype sampling frequencies are expected to be identical; the tests assert the 1e-4 bar and report exact equality."""
+import os
+
 import numpy as np
 import pytest
 
@@ -616,3 +618,23 @@ def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatc
         assert all(np.array_equal(a, b) for a, b in zip(h0, h1)), env
         for k in r0:
             assert np.array_equal(r0[k], r1[k]), (env, k)
+
+
+def test_resident_chain_falls_back_when_its_workgroups_are_not_resident_together(tmp_path):
+    """bt_gibbs_noise_chain_begin checks residency against the WHOLE GPU; a CU mask (or another process / rank on the GPU) takes slots that check
+    cannot see.  The launch's roll call (bt_noise_chain.hpp: nc_begin) then fails before any sampler state is touched, and bt_gibbs_noise_chain_step runs the
+    chain launch by launch: same histograms, same results, no 60 s stall, no failed run.  The child runs under a CU mask of 16 compute units with a batch of
+    625 tiles (the full device holds them, 16 CUs do not)."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env.update({"HSA_CU_MASK": "0:0-15", "ROC_GLOBAL_CU_MASK": "0xFFFF", "BT_GIBBS_DEBUG": "1", "BT_NOISE_CHAIN_ROLLCALL_S": "1.0"})
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_rollcall_child.py"), "40000"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().split("\n")[-1])
+    assert out["histograms_equal"] and out["results_equal"], out
+    if "not resident together" not in p.stderr:
+        pytest.skip("the CU mask was not honoured on this box (the chain was resident): the fallback path did not run")
+    assert out["resident"] and not out["resident_again"], out

@@ -1,13 +1,16 @@
 #!/bin/bash
 # End-to-end stage timings of the executables at BASELINE configs[1] size (on the GPU box, from the repo root):
-#   tools/e2e_c2.sh <tag> [genome_len 64000000] [variants 200000] [threads = nproc] [samples 1] [error k-mers per sample 140000000] [SVs per mille 0]
-# (BASELINE configs[2]-shaped: 256000000 800000 256 3 560000000 10; configs[3]-shaped per GPU: 64000000 200000 256 10; BT_E2E_FREE_BYTES = pretend that much free
+#   tools/e2e_c2.sh <tag> [genome_len 64000000] [variants 200000] [threads, 0 = 2 x the container's CPU quota] [samples 1] [error k-mers per sample 140000000] [SVs per mille 0]
+# (BASELINE configs[2]-shaped: 256000000 800000 0 3 560000000 10; configs[3]-shaped per GPU: 64000000 200000 0 10; BT_E2E_FREE_BYTES = pretend that much free
 #  HBM so that the unit is genotyped in several launches)
 # generates the synthetic data set (tools/make_c2_dataset.cpp), runs `bayesTyperTools makeBloom`, `bayesTyper cluster` and `bayesTyper genotype` with
 # BT_STAGE_TIMES=1 and -p <threads>, and writes the stage table to gpurun_out/summ_<tag>/<tag>_e2e_c2.txt (copy it to profiles/).
 set -uo pipefail
-tag=$1; L=${2:-64000000}; NV=${3:-200000}; T=${4:-$(nproc)}; NS=${5:-1}; NE=${6:-140000000}; SV=${7:-0}
 root=$PWD
+# threads: two per core of the container's CPU quota (bayestyper_amd/hostinfo.py; nproc counts the box's logical CPUs, not what the container may use); 0 = that default
+auto_threads=$(python3 -c 'import sys; sys.path.insert(0, sys.argv[1]); from bayestyper_amd import hostinfo as h; print(h.baseline_threads(h.host_facts()))' "$root")
+tag=$1; L=${2:-64000000}; NV=${3:-200000}; T=${4:-0}; NS=${5:-1}; NE=${6:-140000000}; SV=${7:-0}
+if [ "$T" = 0 ]; then T=$auto_threads; fi
 out=$root/gpurun_out/summ_$tag; mkdir -p $out
 d=/tmp/c2_$tag; rm -rf $d; mkdir -p $d
 dst=$out/${tag}_e2e_c2.txt
