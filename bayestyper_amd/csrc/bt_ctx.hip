@@ -55,6 +55,7 @@ hipError_t ctx_class_streams(bt_ctx *ctx, unsigned n, int prio, hipStream_t *out
         for (hipStream_t st : ctx->class_streams) ctx->retired_streams.push_back(st);   // (a sampler built before may still launch on them)
         ctx->class_streams.clear();
         ctx->class_streams_probed = false;
+        ctx->class_streams_concurrent = 0;
     }
     if (ctx->class_streams.size() < n) {
         int wall_khz = 0;
@@ -74,8 +75,12 @@ hipError_t ctx_class_streams(bt_ctx *ctx, unsigned n, int prio, hipStream_t *out
                 e = streams_overlap(ctx, ctx->stream, cand, d_flags, ticks, &ok);
                 for (size_t i = 0; ok && e == hipSuccess && i < ctx->class_streams.size(); ++i) e = streams_overlap(ctx, ctx->class_streams[i], cand, d_flags, ticks, &ok);
             }
-            if (e == hipSuccess && ok) ctx->class_streams.push_back(cand);
-            else rejected.push_back(cand);
+            if (e == hipSuccess && ok) {
+                // (streams accepted after a stand-in had to be taken stay uncounted: the count is of a prefix that is concurrent throughout)
+                if (ctx->class_streams_concurrent == ctx->class_streams.size() && probe) ctx->class_streams_concurrent += 1;
+                ctx->class_streams.push_back(cand);
+            } else
+                rejected.push_back(cand);
         }
         while (e == hipSuccess && ctx->class_streams.size() < n && !rejected.empty()) {   // not enough hardware queues: streams of their own all the same, in order with another one at worst
             ctx->class_streams.push_back(rejected.back());

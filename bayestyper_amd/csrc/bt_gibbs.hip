@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <numeric>
 
@@ -35,10 +36,12 @@ hipError_t prepare_gibbs_simple_kernel(int max_lds);
 hipError_t launch_gibbs_hot_kernel(unsigned grid, unsigned block, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
                                    unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
 hipError_t prepare_gibbs_hot_kernel(int max_lds);
+hipError_t occupancy_gibbs_hot_kernel(int *blocks_per_cu, int block, uint32_t lds);
 // defined in bt_gibbs_single_kernel.hip
 hipError_t launch_gibbs_single_kernel(unsigned grid, unsigned block, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, int op, uint32_t a0, uint32_t a1,
                                       unsigned long long *hist, TraceCfg tr, const uint32_t *tile_list);
 hipError_t prepare_gibbs_single_kernel(int max_lds);
+hipError_t occupancy_gibbs_single_kernel(int *blocks_per_cu, int block, uint32_t lds);
 // defined in bt_gibbs_chain_kernel.hip
 hipError_t launch_gibbs_chain_kernel(unsigned grid, uint32_t lds, hipStream_t st, const TileDesc *tiles, uint8_t *pool, const GParams *P, const NoiseChainCtl *ctl, TraceCfg tr);
 hipError_t occupancy_gibbs_chain_kernel(int *blocks_per_cu, uint32_t lds);
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(256) void summary_kernel(const TileDesc *__restrict
     t.lane = t.plane = loc[c].lane;   // (no LDS here)
     t.wsh = t.d->wsh;
     t.hot = nullptr;
+    t.lds0 = 0;
     t.resident = 0xFFFFFFFFu;
     const Vx x = make_vx(t, loc[c].v);
     TPtr<uint32_t> keys = x.dip_keys(), freq = x.dip_freq();
@@ -107,6 +111,7 @@ __device__ inline Vx result_vx(const TileDesc *tiles, uint8_t *pool, const Clust
     t.part = 0;
     t.copies = 1;
     t.hot = nullptr;
+    t.lds0 = 0;
     t.resident = 0xFFFFFFFFu;
     return make_vx(t, L.v);
 }
@@ -526,6 +531,10 @@ struct bt_gibbs {
         bool single = false;              // ... and every group is one cluster without multicluster k-mers: sampling operations launched as gibbs_single_kernel (three wavefronts per SIMD)
         std::vector<uint32_t> tiles;
         uint32_t *d_tiles = nullptr;
+        // hot / single classes: the PACKED launch of the sampling operations (bt_gibbs_tile.hpp: BT_PACKED) — pack_wgs workgroups of pack_waves wavefronts, each
+        // wavefront a slot (tile, LDS offset) of d_pack, pack_lds bytes of LDS per workgroup
+        uint32_t *d_pack = nullptr;
+        uint32_t pack_wgs = 0, pack_waves = 1, pack_lds = 0;
         hipStream_t stream = nullptr;     // nullptr: the context's stream
         hipEvent_t done = nullptr;
         hipEvent_t ready = nullptr;       // recorded on the class's stream right before its launch: the next class waits for it (launch(): start order)
@@ -614,6 +623,7 @@ __global__ __launch_bounds__(LANES * 8) void gibbs_noise_kernel(const TileDesc *
         t.part = tile_part(t.d->copies);
         t.copies = t.d->copies;
         t.hot = nullptr;
+        t.lds0 = 0;
         t.resident = 0xFFFFFFFFu;
         TPtr<uint32_t> gd = t.arr<uint32_t>(A_GDIMS);
         if (!gd[3]) continue;   // padding lane of the last tile
@@ -671,6 +681,7 @@ __global__ __launch_bounds__(256) void ucache_prefill_kernel(const TileDesc *__r
     t.part = 0;
     t.copies = t.d->copies;
     t.hot = nullptr;
+    t.lds0 = 0;
     t.resident = 0xFFFFFFFFu;
     const Vx c = make_vx(t, it.v);
     SPtrF<uint32_t, LANES> sc = c.sc();
@@ -784,9 +795,9 @@ int launch(bt_gibbs *g, int op, uint32_t a0, uint32_t a1, unsigned long long *hi
         } else if (c.simple && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
             BT_HIP(launch_gibbs_simple_kernel((unsigned)c.tiles.size(), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
         else if (c.single && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
-            BT_HIP(launch_gibbs_single_kernel((unsigned)c.tiles.size(), LANES * c.split, c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
+            BT_HIP(launch_gibbs_single_kernel(c.pack_wgs, LANES * c.pack_waves, c.pack_lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_pack));
         else if (c.hot && (op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN))
-            BT_HIP(launch_gibbs_hot_kernel((unsigned)c.tiles.size(), LANES * c.split, c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_tiles));
+            BT_HIP(launch_gibbs_hot_kernel(c.pack_wgs, LANES * c.pack_waves, c.pack_lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr, (const uint32_t *)c.d_pack));
         else
             hipLaunchKernelGGL(gibbs_kernel, dim3((unsigned)c.tiles.size()), dim3(LANES * c.split), c.lds, st, g->d_tiles, g->d_pool, g->d_params, op, a0, a1, hist, tr,
                                (const uint32_t *)c.d_tiles);
@@ -1761,7 +1772,11 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         // largest need (2 KB bins).  BT_GIBBS_LDS_CLASSES="a,b,...": upper bounds (bytes) for every kind instead (tuning; a last class takes the rest);
         // BT_GIBBS_FIXED_CLASSES=1: kClassLds for every kind; BT_GIBBS_KIND_CLASSES="g,h,s": classes per kind instead of the dealt ones.
         const bool own_kernel = !getenv("BT_GIBBS_NO_SIMPLE_KERNEL");
-        const bool hot_kernel = !getenv("BT_GIBBS_NO_HOT_KERNEL"), single_kernel = hot_kernel && !getenv("BT_GIBBS_NO_SINGLE_KERNEL");
+        const bool hot_kernel = !getenv("BT_GIBBS_NO_HOT_KERNEL");
+        // gibbs_single_kernel (one-cluster tiles at 168 registers, three wavefronts per SIMD) is OPT-IN (BT_GIBBS_SINGLE_KERNEL=1): the multi-variant class alone at
+        // the bench's size runs 1.12 s with two wavefronts per SIMD and 1.13 s with three — its SIMDs are VALU-issue-bound at two (49 % of a wavefront's cycles
+        // issuing, profiles/r06_single_kernel.txt) — and a kind of its own splits the launch classes: the mixture 3.69 -> 3.87 s
+        const bool single_kernel = hot_kernel && getenv("BT_GIBBS_SINGLE_KERNEL") && !getenv("BT_GIBBS_NO_SINGLE_KERNEL");
         auto hot_tile = [&](const TileDesc &d) {
             bool ok = hot_kernel && !d.simple && d.hot_bytes != 0 && (d.nvm == 1 || d.lds_all);
             for (int a = 0; a < A_COUNT && ok; ++a)
@@ -1769,7 +1784,9 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
             return ok;
         };
         enum { KIND_GENERAL = 0, KIND_HOT = 1, KIND_SINGLE = 2, NKIND = 3 };
-        auto tile_kind = [&](const TileDesc &d) { return !hot_tile(d) ? KIND_GENERAL : (single_kernel && d.logged && d.nvm == 1 && d.NMm == 0 && d.split <= 4 ? KIND_SINGLE : KIND_HOT); };
+        // (the hot kinds' launches are PACKED — several one-wavefront tiles per workgroup, bt_gibbs_tile.hpp: BT_PACKED —, so a tile worked on by several wavefronts,
+        // which only a batch squeezed into too little HBM has, goes through gibbs_kernel)
+        auto tile_kind = [&](const TileDesc &d) { return !(hot_tile(d) && d.split == 1) ? KIND_GENERAL : (single_kernel && d.logged && d.nvm == 1 && d.NMm == 0 ? KIND_SINGLE : KIND_HOT); };
         std::vector<int> kind_of(ntiles, -1);   // -1: the two-haplotype class
         for (uint32_t ti = 0; ti < ntiles; ++ti)
             if (!(own_kernel && g->tiles[ti].simple && g->tiles[ti].split == 1)) kind_of[ti] = tile_kind(g->tiles[ti]);
@@ -1800,9 +1817,10 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
                 top[k][b] = std::max(top[k][b], hb);
                 present[k] = true;
             }
-            // best[k][n]: the least LDS charged to kind k's tiles in n classes, cuts[k][n]: the bins after which it cuts
-            uint64_t best[NKIND][4];
-            std::vector<uint32_t> cuts[NKIND][4];
+            // best[k][n]: the least LDS charged to kind k's tiles in n classes (n <= MAXC), cuts[k][n]: the bins after which it cuts — dynamic programme over the bins
+            constexpr int MAXC = 7;
+            uint64_t best[NKIND][MAXC + 1];
+            std::vector<uint32_t> cuts[NKIND][MAXC + 1];
             for (int k = 0; k < NKIND; ++k) {
                 auto charged = [&](uint32_t lo, uint32_t hi) {   // bins [lo, hi]
                     uint64_t n = 0;
@@ -1810,32 +1828,56 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
                     for (uint32_t b = lo; b <= hi; ++b) n += cnt[k][b], m = std::max(m, top[k][b]);
                     return n * m;
                 };
+                // f[n][e]: least charge of bins [0, e] in n classes; from[n][e]: end of the class before the last one
+                std::vector<std::vector<uint64_t>> f(MAXC + 1, std::vector<uint64_t>(NB, ~0ull));
+                std::vector<std::vector<int>> from(MAXC + 1, std::vector<int>(NB, -1));
+                for (uint32_t e = 0; e < NB; ++e) f[1][e] = charged(0, e);
+                for (int n = 2; n <= MAXC; ++n)
+                    for (uint32_t e = (uint32_t)n - 1; e < NB; ++e)
+                        for (uint32_t m = (uint32_t)n - 2; m < e; ++m) {
+                            if (f[n - 1][m] == ~0ull) continue;
+                            const uint64_t v = f[n - 1][m] + charged(m + 1, e);
+                            if (v < f[n][e]) f[n][e] = v, from[n][e] = (int)m;
+                        }
                 best[k][0] = present[k] ? ~0ull : 0;
-                best[k][1] = charged(0, NB - 1);
-                best[k][2] = best[k][3] = ~0ull;
-                for (uint32_t a = 0; a + 1 < NB; ++a) {
-                    const uint64_t lo = charged(0, a);
-                    const uint64_t v2 = lo + charged(a + 1, NB - 1);
-                    if (v2 < best[k][2]) best[k][2] = v2, cuts[k][2] = {a};
-                    for (uint32_t b = a + 1; b + 1 < NB; ++b) {
-                        const uint64_t v3 = lo + charged(a + 1, b) + charged(b + 1, NB - 1);
-                        if (v3 < best[k][3]) best[k][3] = v3, cuts[k][3] = {a, b};
+                for (int n = 1; n <= MAXC; ++n) {
+                    best[k][n] = f[n][NB - 1];
+                    int e = (int)NB - 1;
+                    for (int q = n; q >= 2 && e >= 0; --q) {
+                        e = from[q][e];
+                        if (e >= 0) cuts[k][n].insert(cuts[k][n].begin(), (uint32_t)e);
                     }
                 }
             }
             int nk[NKIND] = {present[0] ? 1 : 0, present[1] ? 1 : 0, present[2] ? 1 : 0};
-            const int budget = std::max(3, nk[0] + nk[1] + nk[2]);
+            // BUDGET: the classes run beside each other only on streams that sit on different hardware queues.  The runtime deals four by default (then three
+            // classes + the two-haplotype one, as since round 2); a process started with GPU_MAX_HW_QUEUES=8 (bench.py and the executables set it) gets up to
+            // seven + one — the context counts the class streams that PROVED to overlap (ctx_class_streams) — and the finer cuts charge 17 % less LDS to the
+            // whole-genome batch: 3.70 -> 3.55 s per schedule (profiles/r06_launch_classes.txt).
+            unsigned concurrent = 3;
+            if (!getenv("BT_GIBBS_MAX_CLASSES")) {
+                int prio_lo = 0, prio_hi = 0;
+                BT_TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+                hipStream_t probe[MAXC];
+                const hipError_t pe = ctx_class_streams(ctx, MAXC, getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi, probe);
+                if (pe == hipSuccess) concurrent = std::max<unsigned>(3, std::min<unsigned>(MAXC, ctx->class_streams_concurrent));
+                else (void)hipGetLastError();
+            } else
+                concurrent = (unsigned)std::max(1, std::min(MAXC, atoi(getenv("BT_GIBBS_MAX_CLASSES"))));
+            const int budget = std::max<int>((int)concurrent, nk[0] + nk[1] + nk[2]);
+            const bool packed_kinds = getenv("BT_GIBBS_PACK") != nullptr;   // a packed launch charges every tile its own LDS need: ONE class per hot kind
             if (const char *e = getenv("BT_GIBBS_KIND_CLASSES")) {
                 int v[NKIND] = {1, 1, 1};
                 sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
-                for (int k = 0; k < NKIND; ++k) nk[k] = present[k] ? std::min(3, std::max(1, v[k])) : 0;
+                for (int k = 0; k < NKIND; ++k) nk[k] = present[k] ? std::min(MAXC, std::max(1, v[k])) : 0;
             } else {
                 uint64_t least = ~0ull;
                 int pick[NKIND] = {nk[0], nk[1], nk[2]};
-                for (int a = nk[0]; a <= (present[0] ? 3 : 0); ++a)
-                    for (int b = nk[1]; b <= (present[1] ? 3 : 0); ++b)
-                        for (int c = nk[2]; c <= (present[2] ? 3 : 0); ++c) {
+                for (int a = nk[0]; a <= (present[0] ? MAXC : 0); ++a)
+                    for (int b = nk[1]; b <= (present[1] ? (packed_kinds ? 1 : MAXC) : 0); ++b)
+                        for (int c = nk[2]; c <= (present[2] ? (packed_kinds ? 1 : MAXC) : 0); ++c) {
                             if (a + b + c > budget) continue;
+                            if (best[0][a] == ~0ull || best[1][b] == ~0ull || best[2][c] == ~0ull) continue;
                             const uint64_t v = best[0][a] + best[1][b] + best[2][c];
                             if (v < least) least = v, pick[0] = a, pick[1] = b, pick[2] = c;
                         }
@@ -1876,6 +1918,103 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
             for (auto &c : all) g->classes.push_back(std::move(c));
         }
         if (!simple_class.tiles.empty()) g->classes.push_back(std::move(simple_class));
+        // PACKED LAUNCHES of the hot kinds (bt_gibbs_tile.hpp: BT_PACKED).  Tiles are bucketed by a duration proxy (haplotype candidates x clusters per group,
+        // in powers of two: a workgroup holds its LDS until its last wavefront ends, so its tiles should run about equally long), longest first, and within a
+        // bucket packed best-fit-decreasing into slabs of T bytes and at most W tiles.  (W, T) = the pair with the most tiles resident per CU: workgroups per CU
+        // (the occupancy calculator: registers, LDS granularity) x tiles per workgroup.  BT_GIBBS_NO_PACK=1: one tile per workgroup, as before round 6.
+        BT_TRYHIP(prepare_gibbs_hot_kernel((int)kHotBudget));
+        BT_TRYHIP(prepare_gibbs_single_kernel((int)kHotBudget));
+        for (auto &c : g->classes) {
+            if (!c.hot || c.simple) continue;
+            // (packing is OPT-IN, BT_GIBBS_PACK="W,T" or "auto": measured slower — a workgroup holds its slab until its last wavefront ends, and a slab needs W free
+            // wavefront slots and T bytes at once: the bench batch 3.69 -> 4.15 s, profiles/r06_single_kernel.txt)
+            const bool no_pack = getenv("BT_GIBBS_PACK") == nullptr || getenv("BT_GIBBS_NO_PACK") != nullptr;
+            struct Item { uint32_t tile, need, bucket; };
+            std::vector<Item> items;
+            uint32_t max_need = 64;
+            for (uint32_t ti : c.tiles) {
+                const TileDesc &d = g->tiles[ti];
+                const uint32_t need = (uint32_t)align_up(std::max<uint32_t>(tile_lds_bytes(d), 16), 64);
+                uint32_t proxy = std::max<uint32_t>(1, d.Hm * d.nvm), bucket = 0;
+                while (proxy >>= 1) ++bucket;
+                items.push_back(Item{ti, need, bucket});
+                max_need = std::max(max_need, need);
+            }
+            std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.bucket != b.bucket ? a.bucket > b.bucket : a.need > b.need; });
+            // slots of a packing: bins in bucket order, every bin W slots
+            auto pack = [&](uint32_t W, uint32_t T, std::vector<uint32_t> *slots, uint32_t *top) {
+                uint32_t nbins = 0, biggest = 0;
+                std::vector<uint32_t> fill, count;   // per bin
+                std::multimap<uint32_t, uint32_t> open;   // room left -> bin (bins of the current bucket that can take another tile)
+                uint32_t bucket = 0xFFFFFFFFu;
+                if (slots) slots->clear();
+                for (const Item &it : items) {
+                    if (it.bucket != bucket) {
+                        open.clear();
+                        bucket = it.bucket;
+                    }
+                    auto at = open.lower_bound(it.need);   // best fit: the open bin with the least room that still takes it
+                    uint32_t b;
+                    if (at == open.end()) {
+                        b = nbins++;
+                        fill.push_back(0);
+                        count.push_back(0);
+                        if (slots) slots->resize((size_t)nbins * W * 2, 0xFFFFFFFFu);
+                    } else {
+                        b = at->second;
+                        open.erase(at);
+                    }
+                    if (slots) {
+                        (*slots)[((size_t)b * W + count[b]) * 2] = it.tile;
+                        (*slots)[((size_t)b * W + count[b]) * 2 + 1] = fill[b];
+                    }
+                    fill[b] += it.need;
+                    count[b] += 1;
+                    biggest = std::max(biggest, fill[b]);
+                    if (count[b] < W && fill[b] < T) open.emplace(T - fill[b], b);
+                }
+                if (top) *top = biggest;
+                return nbins;
+            };
+            auto occupancy = [&](uint32_t W, uint32_t lds, int *occ) { return c.single ? occupancy_gibbs_single_kernel(occ, (int)(LANES * W), lds) : occupancy_gibbs_hot_kernel(occ, (int)(LANES * W), lds); };
+            uint32_t bestW = 1, bestT = max_need;
+            double best_score = -1;
+            const uint32_t widths_single[] = {1, 2, 3, 4}, widths_hot[] = {1, 2, 4, 8};
+            for (uint32_t wi = 0; wi < 4 && !no_pack; ++wi) {
+                const uint32_t W = c.single ? widths_single[wi] : widths_hot[wi];
+                for (uint32_t per_cu = 1; per_cu <= 24; ++per_cu) {
+                    uint32_t T = per_cu == 1 ? kHotBudget : (uint32_t)((163840u / per_cu) & ~255u);
+                    T = std::min(T, kHotBudget);
+                    if (T < max_need) break;
+                    uint32_t top = 0;
+                    const uint32_t nbins = pack(W, T, nullptr, &top);
+                    int occ = 0;
+                    BT_TRYHIP(occupancy(W, top, &occ));
+                    const double score = (double)occ * (double)items.size() / (double)nbins - 1e-3 * W;   // (ties: the fewer wavefronts share a workgroup's lifetime the better)
+                    if (score > best_score) best_score = score, bestW = W, bestT = T;
+                }
+            }
+            if (const char *e = getenv("BT_GIBBS_PACK")) {   // tuning: "W,T"
+                unsigned w = 0, t = 0;
+                if (sscanf(e, "%u,%u", &w, &t) == 2 && w >= 1 && w <= (c.single ? 4u : 8u) && t >= max_need && t <= kHotBudget) bestW = w, bestT = t;
+            }
+            std::vector<uint32_t> slots;
+            uint32_t top = 0;
+            c.pack_wgs = pack(bestW, bestT, &slots, &top);
+            c.pack_waves = bestW;
+            c.pack_lds = top;
+            BT_TRYHIP(hipMalloc(reinterpret_cast<void **>(&c.d_pack), slots.size() * 4));
+            g->allocs.push_back(c.d_pack);
+            BT_TRYHIP(staged_upload(ctx, c.d_pack, slots.data(), slots.size() * 4));
+            if (getenv("BT_GIBBS_DEBUG")) {
+                int occ = 0;
+                (void)occupancy(bestW, top, &occ);
+                uint64_t need_sum = 0;
+                for (const Item &it : items) need_sum += it.need;
+                fprintf(stderr, "bt_gibbs: packed %s class: %zu tiles (%.1f MB of LDS needs) in %u workgroups of %u wavefronts, %u B of LDS each (%.1f MB charged), %d workgroups per CU\n",
+                        c.single ? "single" : "hot", items.size(), need_sum / 1048576.0, c.pack_wgs, bestW, top, (double)c.pack_wgs * top / 1048576.0, occ);
+            }
+        }
         BT_TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_simple_kernel((int)kHotBudget));
         BT_TRYHIP(prepare_gibbs_hot_kernel((int)kHotBudget));

@@ -4,6 +4,7 @@
 // hot_core) — ds instructions — where the general kernel reaches them through generic pointers that may point to LDS or HBM (flat instructions: both
 // wait counters, and a wait for any of them is a wait for all memory operations in flight).
 #define BT_HOT_ALL 1
+#define BT_PACKED 1
 #define BT_NO_NOISE_CHAIN 1
 #ifndef BT_SWEEP_OUTLINE
 #define BT_SWEEP_INLINE
@@ -35,5 +36,8 @@ hipError_t hot_prof_read(unsigned long long *h_out32, int reset) {   // this uni
     return e;
 }
 #endif
+hipError_t occupancy_gibbs_hot_kernel(int *blocks_per_cu, int block, uint32_t lds) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(gibbs_hot_kernel), block, lds);
+}
 hipError_t prepare_gibbs_hot_kernel(int max_lds) { return hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_hot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds); }
 }  // namespace bt

@@ -233,7 +233,8 @@ __device__ inline TraceRow trace_row_for(const Tile &t, const GParams BT_CAS &P,
 template <bool SIMPLE_ONLY>
 __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, uint8_t *__restrict__ pool, const GParams *__restrict__ Pg, int op, uint32_t arg0, uint32_t arg1,
                                            unsigned long long *__restrict__ hist, TraceCfg tr, const uint32_t *__restrict__ tile_list) {
-    const uint32_t tile = tile_list ? tile_list[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = kPacked ? ((const uint32_t BT_CAS *)tile_list)[2u * pack_slot()] : (tile_list ? tile_list[blockIdx.x] : blockIdx.x);
+    if (kPacked && tile == 0xFFFFFFFFu) return;   // a slot of the last workgroups without a tile
     Env env{tiles, pool, Pg, tile_list, 0xFFFFFFFFu};
     const GParams BT_CAS &P = *(const GParams BT_CAS *)Pg;
     Tile t;
@@ -248,6 +249,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
     // the extra copies of a narrow tile's groups only take part in the sampling operations (the others tally with atomics)
     if (t.part != 0 && !(op == OP_RUN || op == OP_SWEEP || op == OP_INIT_CHAIN || op == OP_NOISE || op == OP_NOISE_CHAIN)) return;
     t.hot = nullptr;
+    t.lds0 = kPacked ? ((const uint32_t BT_CAS *)tile_list)[2u * pack_slot() + 1u] : 0u;
     t.resident = 0xFFFFFFFFu;
     // Narrow tiles (few groups + lockstep copies) are the launch's critical path: a handful of long sequential programs.  They take
     // issue priority over the 64-group tiles they share a SIMD with, which have plenty of peers to fill the gaps.
@@ -273,7 +275,7 @@ __device__ __forceinline__ void gibbs_body(const TileDesc *__restrict__ tiles, u
         env.resident = RESIDENT_ALL;
         for (uint32_t v = 0; v < nvert; ++v) hot_swap(env, v, true);
         t.resident = RESIDENT_ALL;
-        t.hot = lds_block();
+        t.hot = lds_block() + t.lds0;
     }
     // tiles of two-haplotype clusters run their straight-line sweep in gibbs_simple_kernel only; launched through the general kernel
     // (BT_GIBBS_NO_SIMPLE_KERNEL) they take the general path

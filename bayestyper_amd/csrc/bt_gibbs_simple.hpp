@@ -196,43 +196,83 @@ __device__ static __noinline__ void simple_fill_unique(Env env) {
     const Vx::RPtr<uint8_t> sm = c.subm();
     TPtr<uint8_t> scn = c.subcnt(), sic = c.subic();
     const Vx::UCPtr uc = c.ucache();
-    for (uint32_t s = 0; s < S; ++s) {
-        const uint8_t gender = P.gender[s];
-        double acc[5] = {0, 0, 0, 0, 0};
-        uint32_t i = 0;
-        for (; i + 4 <= nsub; i += 4) {
-            uint8_t m[4][5], cn[4];
+    // Round 6 (a resident noise chain rebuilds this table every iteration, and its time was the serial chain of S x nsub / 4 x 2 memory round trips): TWO samples per
+    // pass over the subset — the multiplicity rows and intercluster multiplicities of a k-mer are read once for both — and the operands of the NEXT block of four
+    // k-mers are requested before the current block's forty table lookups are waited for: about one round trip per block and pair of samples instead of four.
+    struct Ops {   // one block of four k-mers, a byte per k-mer: the haplotypes' multiplicities, both intercluster multiplicities, the two samples' counts
+        uint32_t m0, m1, i0, i1, ca, cb;   // (packed: the block in flight and the next one would otherwise hold 48 registers)
+    };
+    auto load_ops = [&](uint32_t i, uint32_t sa, uint32_t sb) {
+        uint8_t b[6][4];
 #pragma unroll
-            for (uint32_t r = 0; r < 4; ++r) {
-                const uint8_t m0 = sm[(i + r) * Hm], m1 = sm[(i + r) * Hm + 1], icn = sic[2 * (i + r) + gender];
-                cn[r] = scn[(i + r) * S + s];
-                m[r][0] = (uint8_t)((uint8_t)(m0 + m0) + icn);
-                m[r][1] = (uint8_t)((uint8_t)(m0 + m1) + icn);
-                m[r][2] = (uint8_t)((uint8_t)(m1 + m1) + icn);
-                m[r][3] = (uint8_t)(m0 + icn);
-                m[r][4] = (uint8_t)(m1 + icn);
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = i + r < nsub ? i + r : (nsub ? nsub - 1u : 0u);   // (the tail block re-reads the last k-mer: its lanes are masked below)
+            b[0][r] = sm[j * Hm];
+            b[1][r] = sm[j * Hm + 1];
+            b[2][r] = sic[2 * j];
+            b[3][r] = sic[2 * j + 1];
+            b[4][r] = scn[j * S + sa];
+            b[5][r] = scn[j * S + sb];
+        }
+        uint32_t w[6];
+#pragma unroll
+        for (uint32_t q = 0; q < 6; ++q) w[q] = (uint32_t)b[q][0] | ((uint32_t)b[q][1] << 8) | ((uint32_t)b[q][2] << 16) | ((uint32_t)b[q][3] << 24);
+        return Ops{w[0], w[1], w[2], w[3], w[4], w[5]};
+    };
+    auto byte_of = [](uint32_t w, uint32_t r) { return (uint8_t)(w >> (8u * r)); };
+    for (uint32_t s0 = 0; s0 < S; s0 += 2) {
+        const uint32_t sa = s0, sb = s0 + 1 < S ? s0 + 1 : s0;
+        const bool two = s0 + 1 < S;
+        const bool ga = P.gender[sa] != 0, gb = P.gender[sb] != 0;
+        double acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+        Ops cur = load_ops(0, sa, sb);
+        for (uint32_t i = 0; i < nsub; i += 4) {
+            const Ops nxt = load_ops(i + 4 < nsub ? i + 4 : i, sa, sb);   // (requested before this block's lookups: one round trip, not two)
+            // two k-mers x two samples x five candidates = twenty lookups in flight per half block (forty would need more registers than three wavefronts per SIMD leave)
+#pragma unroll
+            for (uint32_t half = 0; half < 2; ++half) {
+                uint8_t m[2][2][5];
+#pragma unroll
+                for (uint32_t rr = 0; rr < 2; ++rr) {
+                    const uint32_t r = 2 * half + rr;
+                    const uint8_t m0 = byte_of(cur.m0, r), m1 = byte_of(cur.m1, r);
+#pragma unroll
+                    for (uint32_t w = 0; w < 2; ++w) {
+                        const uint8_t icn = (w ? gb : ga) ? byte_of(cur.i1, r) : byte_of(cur.i0, r);
+                        m[w][rr][0] = (uint8_t)((uint8_t)(m0 + m0) + icn);
+                        m[w][rr][1] = (uint8_t)((uint8_t)(m0 + m1) + icn);
+                        m[w][rr][2] = (uint8_t)((uint8_t)(m1 + m1) + icn);
+                        m[w][rr][3] = (uint8_t)(m0 + icn);
+                        m[w][rr][4] = (uint8_t)(m1 + icn);
+                    }
+                }
+                double lp[2][2][5];
+#pragma unroll
+                for (uint32_t rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (uint32_t q = 0; q < 5; ++q) {
+                        lp[0][rr][q] = count_log_prob(P, sa, m[0][rr][q], byte_of(cur.ca, 2 * half + rr));
+                        lp[1][rr][q] = count_log_prob(P, sb, m[1][rr][q], byte_of(cur.cb, 2 * half + rr));
+                    }
+                // every entry's sum in subset order, as unique_log_prob's (the k-mers past the end of a tail block add nothing)
+#pragma unroll
+                for (uint32_t rr = 0; rr < 2; ++rr)
+                    if (i + 2 * half + rr < nsub) {
+#pragma unroll
+                        for (uint32_t q = 0; q < 5; ++q) {
+                            acc[0][q] += lp[0][rr][q];
+                            acc[1][q] += lp[1][rr][q];
+                        }
+                    }
+                bt_sched_fence();   // (the second half's lookups are not started before the first half's registers are free)
             }
-            double lp[4][5];
-#pragma unroll
-            for (uint32_t r = 0; r < 4; ++r)
-#pragma unroll
-                for (uint32_t q = 0; q < 5; ++q) lp[r][q] = count_log_prob(P, s, m[r][q], cn[r]);
-#pragma unroll
-            for (uint32_t r = 0; r < 4; ++r)
-#pragma unroll
-                for (uint32_t q = 0; q < 5; ++q) acc[q] += lp[r][q];
-        }
-        for (; i < nsub; ++i) {
-            const uint8_t m0 = sm[i * Hm], m1 = sm[i * Hm + 1], icn = sic[2 * i + gender], cn = scn[i * S + s];
-            const uint8_t m[5] = {(uint8_t)((uint8_t)(m0 + m0) + icn), (uint8_t)((uint8_t)(m0 + m1) + icn), (uint8_t)((uint8_t)(m1 + m1) + icn), (uint8_t)(m0 + icn), (uint8_t)(m1 + icn)};
-            double lp[5];
-#pragma unroll
-            for (uint32_t q = 0; q < 5; ++q) lp[q] = count_log_prob(P, s, m[q], cn);
-#pragma unroll
-            for (uint32_t q = 0; q < 5; ++q) acc[q] += lp[q];
+            cur = nxt;
         }
 #pragma unroll
-        for (uint32_t q = 0; q < 5; ++q) uc[s * d.Dcm + q] = acc[q];
+        for (uint32_t q = 0; q < 5; ++q) {
+            uc[sa * d.Dcm + q] = acc[0][q];
+            if (two) uc[sb * d.Dcm + q] = acc[1][q];
+        }
     }
 }
 
@@ -367,19 +407,29 @@ __device__ static __noinline__ void simple_noise_tally(Env env, uint32_t blk_off
             ic0[r] = sic[2 * j];
             ic1[r] = sic[2 * j + 1];
         }
-        for (uint32_t s = 0; s < S; ++s) {
-            const uint32_t code = blk[SB_WORDS * s + 2] & 7u, h1 = sd_h1(code), h2 = sd_h2(code);
-            const bool g1 = P.gender[s] != 0;
-            uint8_t cn[4];
+        // four samples at a time: their sixteen counts are requested together (round 6: one memory round trip per four samples and block instead of one per sample)
+        for (uint32_t s0 = 0; s0 < S; s0 += 4) {
+            uint8_t cn[4][4];
 #pragma unroll
-            for (uint32_t r = 0; r < 4; ++r) cn[r] = scn[(i + r < nsu ? i + r : nsu - 1u) * S + s];
+            for (uint32_t w = 0; w < 4; ++w) {
+                const uint32_t s = s0 + w < S ? s0 + w : S - 1u;
 #pragma unroll
-            for (uint32_t r = 0; r < 4; ++r) {
-                uint8_t m = 0;
-                if (h1 != (uint32_t)NOHAP) m = (uint8_t)(m + (h1 ? m1[r] : m0[r]));
-                if (h2 != (uint32_t)NOHAP) m = (uint8_t)(m + (h2 ? m1[r] : m0[r]));
-                m = (uint8_t)(m + (g1 ? ic1[r] : ic0[r]));
-                if (i + r < nsu && m == 0) nc_tally(nc, bins, s, cn[r]);
+                for (uint32_t r = 0; r < 4; ++r) cn[w][r] = scn[(i + r < nsu ? i + r : nsu - 1u) * S + s];
+            }
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                const uint32_t s = s0 + w;
+                if (s >= S) continue;
+                const uint32_t code = blk[SB_WORDS * s + 2] & 7u, h1 = sd_h1(code), h2 = sd_h2(code);
+                const bool g1 = P.gender[s] != 0;
+#pragma unroll
+                for (uint32_t r = 0; r < 4; ++r) {
+                    uint8_t m = 0;
+                    if (h1 != (uint32_t)NOHAP) m = (uint8_t)(m + (h1 ? m1[r] : m0[r]));
+                    if (h2 != (uint32_t)NOHAP) m = (uint8_t)(m + (h2 ? m1[r] : m0[r]));
+                    m = (uint8_t)(m + (g1 ? ic1[r] : ic0[r]));
+                    if (i + r < nsu && m == 0) nc_tally(nc, bins, s, cn[w][r]);
+                }
             }
         }
     }

@@ -4,6 +4,7 @@
 // sums and the immediate statistics path, and with the candidates evaluated two at a time, the sweep fits GIBBS_SINGLE_WAVES = 3 wavefronts per SIMD
 // (gibbs_hot_kernel: 256 registers, two) — VariantClusterGenotyper.cpp:597-785 for nested_variant_cluster_info empty and no multicluster k-mers.
 #define BT_HOT_ALL 1
+#define BT_PACKED 1
 #define BT_NO_NOISE_CHAIN 1
 #define BT_SINGLE 1
 #ifndef BT_EVAL_BLOCK
@@ -41,5 +42,8 @@ hipError_t single_prof_read(unsigned long long *h_out32, int reset) {   // this 
     return e;
 }
 #endif
+hipError_t occupancy_gibbs_single_kernel(int *blocks_per_cu, int block, uint32_t lds) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(gibbs_single_kernel), block, lds);
+}
 hipError_t prepare_gibbs_single_kernel(int max_lds) { return hipFuncSetAttribute(reinterpret_cast<const void *>(gibbs_single_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds); }
 }  // namespace bt

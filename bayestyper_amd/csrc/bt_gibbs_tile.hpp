@@ -43,6 +43,17 @@ constexpr bool kSingle = true;
 #else
 constexpr bool kSingle = false;
 #endif
+// BT_PACKED: the translation units of gibbs_hot_kernel / gibbs_single_kernel.  A launch has ONE dynamic LDS size, and a schedule of a whole-genome batch is
+// LDS-capacity-bound (sum over the tiles of LDS x duration against 160 KB per CU: the model reproduces the measured 3.7 s of the round-5 bench batch to 1 %), so
+// charging every tile of a launch class its hungriest tile's need cost a third of the non-simple tiles' LDS.  In a packed launch a workgroup is a SLAB of LDS
+// shared by up to blockDim.x / 64 wavefronts that each run ANOTHER tile (one-wavefront tiles only): wavefront w of workgroup b takes slot b * waves + w of the
+// launch's slot list — (tile, byte offset of the tile's block in the slab) pairs, 0xFFFFFFFF = no tile — which the host fills by best-fit-decreasing bin
+// packing (bt_gibbs.hip: pack_class).  The wavefronts of a workgroup never synchronise with each other.
+#ifdef BT_PACKED
+constexpr bool kPacked = true;
+#else
+constexpr bool kPacked = false;
+#endif
 constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
 
 // scalar slots per vertex (A_SC)
@@ -191,6 +202,8 @@ struct GParams {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t bt_lds_raw[];
 __device__ inline uint8_t *lds_block() { return (uint8_t *)bt_lds_raw; }
+// packed launches: this wavefront's slot (wave-uniform)
+__device__ inline uint32_t pack_slot() { return blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // The arrays every tile with an LDS block keeps there (bt_gibbs.hip: hot_arrs, minus the ones that depend on the tile's shape).  In the translation
 // unit of gibbs_hot_kernel (BT_HOT_ALL: launch classes whose tiles all keep every vertex resident for the whole launch) an access to one of them is an
@@ -214,12 +227,13 @@ struct Tile {
     uint32_t part, copies;
     uint32_t wsh;        // TileDesc::wsh
     uint8_t *hot;        // this wavefront's LDS block (generic pointer) or nullptr
+    uint32_t lds0;       // byte offset of that block in the workgroup's LDS (packed launches; 0 otherwise)
     uint32_t resident;   // vertex whose hot arrays currently live in LDS (0xFFFFFFFF: none)
     // hot-capable array: LDS when the vertex is resident, HBM otherwise; one code path through generic pointers
     template <typename T>
     __device__ inline SPtrF<T, LANES> harr(int a, uint32_t v, uint32_t len) const {
 #ifdef BT_HOT_ALL
-        if (hot_core(a)) return SPtrF<T, LANES>{(T *)(lds_block() + v * d->hot_bytes + d->hoff[a]), lane, wsh};
+        if (hot_core(a)) return SPtrF<T, LANES>{(T *)(lds_block() + (kPacked ? lds0 : 0u) + v * d->hot_bytes + d->hoff[a]), lane, wsh};
 #endif
         const uint32_t ho = d->hoff[a];
         if (hot != nullptr && ho != NOHOT && (resident == RESIDENT_ALL || v == resident))
@@ -384,12 +398,14 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
 // wavefronts of this launch that work on the tile: the tile's split, or fewer when the workgroup has fewer (gibbs_chain_kernel: ONE wavefront per tile,
 // its 64 lanes the tile's 64 groups)
 __device__ inline uint32_t tile_split(const TileDesc BT_CAS *d) {
+    if (kPacked) return 1u;   // (the wavefronts of a packed workgroup run different tiles)
     const uint32_t waves = blockDim.x >> 6;
     return d->split < waves ? d->split : waves;
 }
-__device__ inline uint32_t tile_lane(uint32_t split, uint32_t copies) { return (threadIdx.x >> 6) * (64u / split) + ((threadIdx.x & 63u) % (64u / copies)); }
+__device__ inline uint32_t tile_lane(uint32_t split, uint32_t copies) { return (kPacked ? 0u : (threadIdx.x >> 6) * (64u / split)) + ((threadIdx.x & 63u) % (64u / copies)); }
 __device__ inline uint32_t tile_part(uint32_t copies) { return (threadIdx.x & 63u) / (64u / copies); }
 __device__ inline bool tile_thread_active(uint32_t split, uint32_t copies) {
+    if (kPacked) return true;   // (one wavefront per tile, all of its lanes)
     return (threadIdx.x >> 6) < split && (copies > 1u || (threadIdx.x & 63u) < 64u / split);
 }
 // make the stores of the sibling copies visible before reading what they produced (same wavefront: program order + L1 write-through)
@@ -404,7 +420,8 @@ __device__ inline Tile make_tile(const Env &e_in) {
     const TileDesc *tiles = uniform_ptr(e_in.tiles);
     uint8_t *pool = uniform_ptr(e_in.pool);
     const uint32_t *list = uniform_ptr(e_in.tile_list);
-    const uint32_t tile = list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = kPacked ? ((const uint32_t BT_CAS *)list)[2u * pack_slot()] : (list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x);
+    t.lds0 = kPacked ? ((const uint32_t BT_CAS *)list)[2u * pack_slot() + 1u] : 0u;
     t.d = (const TileDesc BT_CAS *)&tiles[tile];
     t.base = (uint8_t BT_GAS *)(pool + t.d->base);
     t.lane = tile_lane(tile_split(t.d), t.d->copies);
@@ -413,7 +430,7 @@ __device__ inline Tile make_tile(const Env &e_in) {
     t.part = tile_part(t.d->copies);
     t.copies = t.d->copies;
     t.resident = e_in.resident;   // per lane: lanes of a tile may be at different vertices of their groups
-    t.hot = (t.resident != 0xFFFFFFFFu && t.resident != RESIDENT_NEVER && t.d->hot_bytes) ? lds_block() : nullptr;
+    t.hot = (t.resident != 0xFFFFFFFFu && t.resident != RESIDENT_NEVER && t.d->hot_bytes) ? lds_block() + t.lds0 : nullptr;
     return t;
 }
 __device__ inline const GParams BT_CAS &env_params(const Env &e) { return *(const GParams BT_CAS *)uniform_ptr(e.P); }
@@ -437,7 +454,7 @@ __device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len
     const uint32_t ho = t.d->hoff[arr];
     if (ho == NOHOT) return;
     const uint32_t sh = t.wsh;   // the rows have the tile's width in LDS and in HBM
-    T BT_LAS *l = (T BT_LAS *)(bt_lds_raw + lds_vertex_off + ho) + t.lane;   // explicit LDS pointer: the copies of different arrays can overlap (no aliasing with HBM)
+    T BT_LAS *l = (T BT_LAS *)(bt_lds_raw + (kPacked ? t.lds0 : 0u) + lds_vertex_off + ho) + t.lane;   // explicit LDS pointer: the copies of different arrays can overlap (no aliasing with HBM)
     T BT_GAS *g = (T BT_GAS *)(t.base + t.d->off[arr]) + ((v * len) << sh) + t.plane;
     // eight elements in flight per step (the copy is latency-bound: one wavefront, one memory round trip per step)
     uint32_t i = 0;
@@ -466,7 +483,7 @@ __device__ inline void hot_copy(const Tile &t, int arr, uint32_t v, uint32_t len
 __device__ inline uint32_t uniform_tile_hot_bytes(const Env &e) {
     const TileDesc *tiles = uniform_ptr(e.tiles);
     const uint32_t *list = uniform_ptr(e.tile_list);
-    const uint32_t tile = list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = kPacked ? ((const uint32_t BT_CAS *)list)[2u * pack_slot()] : (list ? ((const uint32_t BT_CAS *)list)[blockIdx.x] : blockIdx.x);
     return ((const TileDesc BT_CAS *)&tiles[tile])->hot_bytes;
 }
 // move every hot array of vertex v between HBM and the wavefront's LDS block (lane-wise, coalesced)
@@ -1622,7 +1639,9 @@ __device__ BT_NOINLINE void flush_vertex(Env env, uint32_t vtx) {
     }
     for (uint32_t s = 0; s < P.S; ++s) flush_sample(c, P, s);
 }
-__device__ BT_SWEEPFN void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
+// (BT_COLLECT_OUTLINE: a function of its own — the pending run's replay, the k-mer-stats rebuild and this sweep's contribution are 4 000 instructions that a
+// sample needs when its diplotype changed in a collected sweep; out of line they stay out of the sweep's register allocation)
+__device__ BT_NOINLINE void collect_sample_slow(Env env, uint32_t vtx, uint32_t s) {
     const Vx c = make_vx(make_tile(env), vtx);
     const GParams BT_CAS &P = env_params(env);
     SPtrF<uint32_t, LANES> sc = c.sc();
@@ -1681,7 +1700,11 @@ __device__ BT_SWEEPFN void update_allele_kmer_stats(Env env, uint32_t vtx, uint3
             }
         }
 #endif
+#ifdef BT_COLLECT_OUTLINE
+        collect_sample_slow(env, vtx, s);
+#else
         collect_sample_body(c, P, s, nsub_u, nsub_m);
+#endif
     }
 }
 

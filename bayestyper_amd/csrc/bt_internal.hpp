@@ -69,6 +69,7 @@ struct bt_ctx {
     hipStream_t class_streams_for = nullptr;   // the context stream they were probed against (bt_ctx_set_stream may change it)
     int class_streams_prio = 0;
     bool class_streams_probed = false;
+    unsigned class_streams_concurrent = 0;   // how many of class_streams proved to run concurrently with the context's stream and with one another (the rest share hardware queues)
 };
 
 namespace bt {
@@ -182,4 +183,9 @@ struct bt_kmc_scan {
     unsigned int *d_part_cursor = nullptr;   // partitioned scan: fill of the 256 bucket regions
     uint32_t part_cap = 0;                   // records per bucket region
     unsigned int *d_num_hits = nullptr;
+    // round 6: a SECOND set of those buffers, so that the partition of chunk i + 1 (LDS-bound) runs on a class stream of the context while chunk i is probed
+    // (VALU-bound) and applied (latency-bound) on the context's stream; absent (single-buffered scan) when the allocation fails
+    void *d_route_vals2[2] = {nullptr, nullptr};
+    unsigned int *d_part_cursor2 = nullptr, *d_num_hits2 = nullptr;
+    hipEvent_t part_done[2] = {nullptr, nullptr}, part_free[2] = {nullptr, nullptr}, scan_begin = nullptr;
 };

@@ -68,6 +68,7 @@ __device__ inline void noise_help_unit(const TileDesc *tiles, uint8_t *pool, con
     t.part = 0;
     t.copies = t.d->copies;
     t.hot = nullptr;   // (the owner's LDS is not ours: everything from HBM)
+    t.lds0 = 0;
     t.resident = 0xFFFFFFFFu;
     const Vx c = make_vx(t, it.v);
     SPtrF<uint32_t, LANES> sc = c.sc();

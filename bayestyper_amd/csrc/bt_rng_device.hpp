@@ -206,6 +206,18 @@ BT_HD bool bt_wave_any(bool p) {   // true in every lane of the wavefront when p
     return p;
 #endif
 }
+#ifdef BT_DIAG_FAKE_MT
+// DIAGNOSTIC BUILD ONLY (tools/traffic_by_array.sh): the generators' words come from a counter hash instead of the mt19937 state, so a launch moves no
+// generator state at all — its FETCH_SIZE / WRITE_SIZE against the product build's is what the states cost.  Results are NOT the reference's.
+BT_HD uint32_t bt_fake_word(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x85ebca6bu;
+    x ^= x >> 13;
+    x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
+}
+#endif
 typedef uint32_t MtQuad __attribute__((ext_vector_type(4)));    // four consecutive state words at a 16-byte aligned address (a chunk)
 typedef MtQuad MtQuadU __attribute__((aligned(4)));             // ... at a 4-byte aligned address (x[p + 397 ...])
 template <class RP>   // RP: pointer-like (operator[](uint32_t) -> uint32_t&) to the ring block
@@ -214,8 +226,22 @@ struct MtRingT {
     RP ring;                   // element i of the ring block at ring[i] (LDS when the cluster's hot arrays are resident, else HBM)
     uint32_t cap;              // power of two, 8 .. 64
     uint32_t pos, head, avail; // pos: multiple of four
+#ifdef BT_DIAG_FAKE_MT
+    uint32_t fake_ctr = 0;
+#endif
     // one chunk for the lanes with `go` set
     BT_HD void chunk(bool go) {
+#ifdef BT_DIAG_FAKE_MT
+        if (go) {
+            const uint32_t salt = (uint32_t)(uintptr_t)st * 2654435761u + fake_ctr;
+            const uint32_t w = (head + avail) & (cap - 1u);
+            for (uint32_t k = 0; k < 4u; ++k) ring[w + k] = bt_fake_word(salt + pos + k);
+            fake_ctr += 0x9e3779b9u;
+            pos = pos + 4u == MT_N ? 0u : pos + 4u;
+            avail += 4u;
+        }
+        return;
+#endif
         if (go) {   // (only the lanes that produce send their four requests)
             const uint32_t p = pos, q = p + MT_M < MT_N ? p + MT_M : p + MT_M - MT_N;
             const MtQuad a = *(const MtQuad BT_GAS *)(st + p);
@@ -243,6 +269,10 @@ struct MtRingT {
     // read by chunks 620 and 224 .. 226 only, each 56 or more chunks away from chunk 0 that writes it — or right before it, whose loads come first)
     template <unsigned NB>
     BT_HD void batch(uint32_t want) {
+#ifdef BT_DIAG_FAKE_MT
+        for (unsigned j = 0; j < NB; ++j) chunk(avail < want);
+        return;
+#endif
         uint32_t nc = avail < want ? (want - avail + 3u) >> 2 : 0u;
         nc = nc < NB ? nc : NB;
         MtQuad a[NB], b[NB];

@@ -1531,6 +1531,18 @@ static void free_routed(bt_kmc_scan *s) {
     }
     if (s->d_num_hits) (void)hipFree(s->d_num_hits);
     if (s->d_part_cursor) (void)hipFree(s->d_part_cursor);
+    for (int b = 0; b < 2; ++b) {
+        if (s->d_route_vals2[b]) (void)hipFree(s->d_route_vals2[b]);
+        s->d_route_vals2[b] = nullptr;
+        if (s->part_done[b]) (void)hipEventDestroy(s->part_done[b]);
+        if (s->part_free[b]) (void)hipEventDestroy(s->part_free[b]);
+        s->part_done[b] = s->part_free[b] = nullptr;
+    }
+    if (s->scan_begin) (void)hipEventDestroy(s->scan_begin);
+    s->scan_begin = nullptr;
+    if (s->d_num_hits2) (void)hipFree(s->d_num_hits2);
+    if (s->d_part_cursor2) (void)hipFree(s->d_part_cursor2);
+    s->d_part_cursor2 = s->d_num_hits2 = nullptr;
     s->d_part_cursor = nullptr;
     s->part_cap = 0;
     s->d_num_hits = nullptr;
@@ -1554,6 +1566,30 @@ static int ensure_routed(bt_kmc_scan *s, uint64_t cap) {
     }
     s->routed_cap = cap;
     s->part_cap = (uint32_t)part_cap;
+    // the second set (a scan of several chunks overlaps the partition of the next chunk with the probe / apply of the current one): BT_KMC_OVERLAP=1.  Measured in
+    // round 6 (profiles/r06_kmc_overlap.txt): 25.6 -> 25.4 ms per 10^9 records at the WGS filter shape, 46.4 -> 46.0 ms at 36 KB sub-filters — the three kernels
+    // stress different units of a CU but share the memory pipeline, and 1.1 GB of HBM for 1 % is not a default
+    if (getenv("BT_KMC_OVERLAP")) {
+        hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals2[0]), 256 * PSTRIPES * part_cap * sizeof(RouteRec));
+        if (e2 == hipSuccess) e2 = hipMalloc(reinterpret_cast<void **>(&s->d_route_vals2[1]), cap * sizeof(uint32_t));
+        if (e2 == hipSuccess) e2 = hipMalloc(reinterpret_cast<void **>(&s->d_part_cursor2), 256 * PSTRIPES * sizeof(unsigned int));
+        if (e2 == hipSuccess) e2 = hipMalloc(reinterpret_cast<void **>(&s->d_num_hits2), 4);
+        for (int b = 0; b < 2 && e2 == hipSuccess; ++b) {
+            e2 = hipEventCreateWithFlags(&s->part_done[b], hipEventDisableTiming);
+            if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&s->part_free[b], hipEventDisableTiming);
+        }
+        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&s->scan_begin, hipEventDisableTiming);
+        if (e2 != hipSuccess) {   // (not enough memory for two sets: the scan runs single-buffered)
+            (void)hipGetLastError();
+            for (int b = 0; b < 2; ++b) {
+                if (s->d_route_vals2[b]) (void)hipFree(s->d_route_vals2[b]);
+                s->d_route_vals2[b] = nullptr;
+            }
+            if (s->d_part_cursor2) (void)hipFree(s->d_part_cursor2);
+            if (s->d_num_hits2) (void)hipFree(s->d_num_hits2);
+            s->d_part_cursor2 = s->d_num_hits2 = nullptr;
+        }
+    }
     return BT_OK;
 }
 
@@ -1587,27 +1623,49 @@ int bt_kmc_scan_run(bt_kmc_scan *s, bt_bloom *path_bloom, bt_table *table, uint3
     const KmcView kv = make_kmc_view(s);
     uint32_t part_cap = s->part_cap;
     if (const char *e = getenv("BT_KMC_PART_CAP")) part_cap = std::max<uint32_t>(1, std::min<uint32_t>(part_cap, (uint32_t)strtoul(e, nullptr, 0)));   // tests: records beyond a stripe's region
-    for (uint64_t off = 0; off < n; off += chunk) {
+    // Two buffer sets: chunk i's partition — LDS-bound (the hash table's random reads, the counting sort) — is enqueued on a class stream of the context (probed
+    // to run concurrently with the context's stream, bt_ctx.hip) and the chunk's probe — VALU-bound — and apply — latency-bound — follow on the context's stream,
+    // so that chunk i + 1 is partitioned while chunk i is probed and applied; a set is reused when the apply kernel that read it has ended (part_free).
+    const bool overlap = s->d_route_vals2[0] != nullptr && n > chunk && getenv("BT_KMC_OVERLAP") != nullptr;
+    hipStream_t main_st = s->ctx->stream, part_st = main_st;
+    if (overlap) {
+        int prio_lo = 0, prio_hi = 0;
+        BT_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        hipStream_t cs[1] = {nullptr};
+        BT_HIP(ctx_class_streams(s->ctx, 1, getenv("BT_GIBBS_NO_PRIO") ? prio_lo : prio_hi, cs));   // (the context's first class stream: the priority the samplers ask for)
+        part_st = cs[0];
+        BT_HIP(hipEventRecord(s->scan_begin, main_st));   // (what precedes the scan on the context's stream — the table's clear, the previous sample's scan)
+        BT_HIP(hipStreamWaitEvent(part_st, s->scan_begin, 0));
+    }
+    uint64_t ci = 0;
+    for (uint64_t off = 0; off < n; off += chunk, ++ci) {
         const uint64_t m = std::min<uint64_t>(chunk, n - off);
-        RouteRec *part = (RouteRec *)s->d_route_vals[0];
-        uint32_t *hit_list = reinterpret_cast<uint32_t *>(s->d_route_vals[1]);
-        BT_HIP(hipMemsetAsync(s->d_num_hits, 0, 4, s->ctx->stream));
-        BT_HIP(hipMemsetAsync(s->d_part_cursor, 0, 256 * PSTRIPES * sizeof(unsigned int), s->ctx->stream));
+        const int b = overlap ? (int)(ci & 1u) : 0;
+        RouteRec *part = (RouteRec *)(b ? s->d_route_vals2[0] : s->d_route_vals[0]);
+        uint32_t *hit_list = reinterpret_cast<uint32_t *>(b ? s->d_route_vals2[1] : s->d_route_vals[1]);
+        unsigned int *num_hits = b ? s->d_num_hits2 : s->d_num_hits, *cursor = b ? s->d_part_cursor2 : s->d_part_cursor;
+        if (overlap && ci >= 2) BT_HIP(hipStreamWaitEvent(part_st, s->part_free[b], 0));
+        BT_HIP(hipMemsetAsync(num_hits, 0, 4, part_st));
+        BT_HIP(hipMemsetAsync(cursor, 0, 256 * PSTRIPES * sizeof(unsigned int), part_st));
         const unsigned pgrid = grid_for((m + PSLAB - 1) / PSLAB, 1, s->ctx->num_cu * 4);
-        hipLaunchKernelGGL(kmc_partition_kernel, dim3(pgrid), dim3(PBLOCK), partition_lds_bytes(s->rec_size), s->ctx->stream, kv, path_bloom->view(), d_records, first_record, off, m, n,
-                           (uint32_t)partition_main_bytes(s->rec_size), part, part_cap, s->d_part_cursor, hit_list, s->d_num_hits);
+        hipLaunchKernelGGL(kmc_partition_kernel, dim3(pgrid), dim3(PBLOCK), partition_lds_bytes(s->rec_size), part_st, kv, path_bloom->view(), d_records, first_record, off, m, n,
+                           (uint32_t)partition_main_bytes(s->rec_size), part, part_cap, cursor, hit_list, num_hits);
         BT_CHECK_LAUNCH();
+        if (overlap) {
+            BT_HIP(hipEventRecord(s->part_done[b], part_st));
+            BT_HIP(hipStreamWaitEvent(main_st, s->part_done[b], 0));
+        }
         // blocks per bucket: two rounds of PU records per lane; BT_KMC_PROBE_BPB=0 -> persistent workgroups (eight per CU): measured 2.3x slower (71 against
         // 31 ms per 10^9 records: every wavefront of the chip in the same phase of the same bucket at the same time)
         uint32_t bpb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (m / 256 + BLOCK * 2 * PU - 1) / (BLOCK * 2 * PU)));
         if (const char *e = getenv("BT_KMC_PROBE_BPB")) bpb = (uint32_t)std::min<uint64_t>(256, strtoul(e, nullptr, 0));
         const uint32_t pwgs = bpb ? 256u * bpb : 8u * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(s->ctx->num_cu, (m / 256 + BLOCK * 16 - 1) / (BLOCK * 16)));
-        hipLaunchKernelGGL(kmc_probe_bucket_kernel, dim3(pwgs), dim3(BLOCK), 0, s->ctx->stream, path_bloom->view(), (const RouteRec *)part, part_cap, (const unsigned int *)s->d_part_cursor, bpb,
-                           hit_list, s->d_num_hits);
+        hipLaunchKernelGGL(kmc_probe_bucket_kernel, dim3(pwgs), dim3(BLOCK), 0, main_st, path_bloom->view(), (const RouteRec *)part, part_cap, (const unsigned int *)cursor, bpb, hit_list, num_hits);
         BT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(kmc_apply_kernel, dim3(s->ctx->num_cu * 8), dim3(BLOCK), 0, s->ctx->stream, kv, table->v, sample_idx, d_records, first_record, off, n, (const uint32_t *)hit_list,
-                           (const unsigned int *)s->d_num_hits, reinterpret_cast<unsigned long long *>(d_hit_count));
+        hipLaunchKernelGGL(kmc_apply_kernel, dim3(s->ctx->num_cu * 8), dim3(BLOCK), 0, main_st, kv, table->v, sample_idx, d_records, first_record, off, n, (const uint32_t *)hit_list,
+                           (const unsigned int *)num_hits, reinterpret_cast<unsigned long long *>(d_hit_count));
         BT_CHECK_LAUNCH();
+        if (overlap) BT_HIP(hipEventRecord(s->part_free[b], main_st));
     }
     return BT_OK;
 }

@@ -32,6 +32,12 @@ matches/sec is reported beside it.  `roofline` describes the dominant kernel (th
 scan kernel (average over the S launches of a step: one inserting, S-1 finding).  `cpu_baseline` times the oracle (a scalar
 restatement of the reference's algorithm, parity-pinned in tests/) on a bounded sample of the same workload on this box's host cores.
 """
+import os as _os
+
+# Eight hardware queues for this process's HIP streams (the runtime's default is four): the Gibbs sampler then cuts its tiles into up to seven launch classes
+# beside the two-haplotype one, each on a stream that runs concurrently with the others (bt_gibbs.hip: BUDGET).  Must be in the environment before the HIP
+# runtime initialises; a value set by the caller wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os
@@ -127,6 +133,61 @@ def rank_batch(groups, S, rank, world, scaling, templates=None):
     return flat, flat["num_clusters"] * world, None, None
 
 
+def sharded_precheck(ctx, comm, dist, torch, dev, rank, world, S):
+    """Before anything is timed on N > 1 GPUs: a 2 000-group unit of the mixture is genotyped (short schedule) SHARDED over the ranks the way
+    `BT_GPUS=N bayesTyper genotype` deals a unit (shard.assign_groups), every rank's posterior summaries are gathered to rank 0 through the product's
+    exchange step (bt_comm_gather_summaries over RCCL), and rank 0 compares them with its own UNSHARDED run of the unit.  Every rank learns the outcome; a
+    difference ends the run on all of them — a scaling run can then not report a number for a wrong result (the first N > 1 RCCL execution this code ever gets
+    is the driver's scaling run).  -> True"""
+    from bayestyper_amd import lib, shard, synth
+    from bayestyper_amd.host import count_model
+
+    unit = synth.make_mixture(2000, S, seed=77)
+    parts = shard.assign_groups(shard.group_cost(unit), world)
+    mine = shard.take_groups(unit, parts[rank])
+    lg, ln = count_model.build_luts(S, mean=15.0, var=30.0, noise_rate=0.05)
+    kw = dict(seed=42, chains=2, burn=10, iters=20)
+
+    def summary(flat):
+        g = lib.Gibbs(ctx, flat, lg, ln, **kw)
+        g.run()
+        d = torch.zeros(max(1, flat["num_clusters"] * S * 2), dtype=torch.int32, device=dev)
+        ctx.sync()
+        torch.cuda.synchronize()
+        lib.check(lib.bt_gibbs_posterior_summary(g.h, d.data_ptr()))
+        ctx.sync()
+        g.close()
+        return d
+
+    d_mine = summary(mine)
+    Cm, Ct = mine["num_clusters"], unit["num_clusters"]
+    c_all = torch.zeros(world, dtype=torch.int64, device=dev)
+    c_all[rank] = Cm
+    torch.cuda.synchronize()
+    comm.allreduce(c_all.data_ptr(), world)
+    ctx.sync()
+    c_all = [int(x) for x in c_all.tolist()]
+    ok = sum(c_all) == Ct
+    d_all = torch.zeros(Ct * S * 2 if rank == 0 else 2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    comm.gather_words(d_mine.data_ptr(), Cm * S * 2, d_all.data_ptr(), d_all.numel())
+    ctx.sync()
+    if rank == 0 and ok:
+        whole = torch.zeros(Ct, S * 2, dtype=torch.int32, device=dev)
+        at = 0
+        for r in range(world):
+            ids_r = torch.from_numpy(np.ascontiguousarray(shard.cluster_ids_of(unit, parts[r])).astype(np.int64)).to(dev)
+            whole[ids_r] = d_all[at * S * 2: (at + c_all[r]) * S * 2].view(c_all[r], S * 2)
+            at += c_all[r]
+        ref = summary(unit)
+        ok = bool(torch.equal(ref.view(Ct, S * 2), whole)) and int(ref.abs().sum().item()) > 0
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    dist.broadcast(flag, src=0)
+    if not int(flag.item()):
+        raise RuntimeError("bench: the sharded pre-check failed — the summaries gathered from %d ranks differ from rank 0's unsharded run of the same unit" % world)
+    return True
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +240,7 @@ def main():
         torch.cuda.synchronize()
     S = args.samples
     comm = None
+    precheck_ok = None
     if world > 1:
         # the exchange steps are the product's (libbtcomm.so: RCCL on the context's stream); the gloo group only carries the communicator id
         from bayestyper_amd import comm as btcomm
@@ -187,6 +249,7 @@ def main():
         ident = [btcomm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         comm = btcomm.Comm(ctx, ident[0], rank, world)
+        precheck_ok = sharded_precheck(ctx, comm, dist, torch, dev, rank, world, S)
 
     # ------------------------------------------------------------------ Gibbs batch (this rank's groups)
     from bayestyper_amd import shard
@@ -339,11 +402,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         gw = state.get("gather_words", (0, 0))
-        mine = [C, float(np.mean(gibbs_ms)), float(np.mean([sum(x) for x in kmc_ms])), float(np.mean(fetch_ms)), float(np.mean(gather_ms)), int(gw[0]) * 4, int(gw[1]) * 4]
+        props = torch.cuda.get_device_properties(dev)
+        mine = [C, float(np.mean(gibbs_ms)), float(np.mean([sum(x) for x in kmc_ms])), float(np.mean(fetch_ms)), float(np.mean(gather_ms)), int(gw[0]) * 4, int(gw[1]) * 4,
+                int(dev.index), "%s, %d CUs, pci %s" % (props.name, props.multi_processor_count, getattr(props, "pci_bus_id", "?")), os.getpid()]
         rows = [None] * world
         dist.all_gather_object(rows, mine)
         per_rank = [{"rank": r, "clusters": int(x[0]), "gibbs_launch_ms": x[1], "kmc_scans_ms": x[2], "result_pack_ms": x[3], "gather_ms": x[4],
-                     "result_string_bytes": int(x[5]), "gathered_bytes_all_ranks": int(x[6])} for r, x in enumerate(rows)]
+                     "result_string_bytes": int(x[5]), "gathered_bytes_all_ranks": int(x[6]), "device": x[7], "device_name": x[8], "pid": x[9]} for r, x in enumerate(rows)]
+        if len({(x[7], x[8]) for x in rows}) != world:
+            raise RuntimeError("bench: two ranks of the job ran on the same GPU: %s" % [(x[7], x[8]) for x in rows])
     hits = int(d_hits.item())
     st = table.status()
     if st["overflowed"]:
@@ -769,7 +836,8 @@ def main():
             "config": {"workload": shape_note, "groups_per_gpu": G, "clusters_per_gpu": C, "clusters_total": C_total, "samples": S, "kmc_records_per_gpu_per_sample": R,
                        "sharding": ("one batch sharded over the ranks (LPT on a cost proxy); " if strong else "one unit of N launch-sized blocks, block r on rank r (unit-wide group indices); ") +
                                    "KMC streams per rank; gather of every rank's results (diplotype sampling frequencies + allele k-mer statistics) to rank 0",
-                       "sharded_equals_unsharded": verified, "subset_equals_batch": subset_ok, "per_rank": per_rank,
+                       "sharded_equals_unsharded": verified if verified is not None else precheck_ok,
+                       "sharded_precheck": precheck_ok, "subset_equals_batch": subset_ok, "per_rank": per_rank,
                        "result_fetch_ms": float(np.mean(fetch_ms)), "gather_ms": float(np.mean(gather_ms)) if world > 1 else None},
             "results": results_rec,
             "roofline": {"kernel": "gibbs_hot_kernel + gibbs_simple_kernel (the concurrent launches of one schedule; gibbs_kernel for tiles that do not keep every vertex in LDS)", "bound": "hbm", "achieved": gibbs_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

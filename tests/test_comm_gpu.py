@@ -184,3 +184,42 @@ def test_noise_chain_on_the_device_with_the_enqueued_all_reduce(gpu_ctx, oracle)
         assert np.allclose(r[it], c2.noise_rates(), rtol=1e-12, atol=0)
     assert np.array_equal(m.get_generator()[0], c2.export_generator()[0])
     m.close(), one.close()
+
+
+def test_bench_sharded_precheck_on_a_one_rank_communicator():
+    """bench.py --gpus N runs sharded_precheck before anything is timed (a 2 000-group unit sharded over the ranks, summaries gathered through
+    bt_comm_gather_summaries, compared with rank 0's unsharded run).  One GPU here: the same code with a one-rank communicator — every step but the exchange
+    between different GPUs — must pass, and must FAIL when the gathered summaries are not the unsharded run's."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from bayestyper_amd import comm as btcomm, lib
+
+    class Dist:   # (the gloo group of a real run only carries rank 0's verdict to the others)
+        @staticmethod
+        def broadcast(t, src):
+            return None
+
+    ctx = lib.Ctx(0)
+    dev = torch.device("cuda", 0)
+    c = btcomm.Comm(ctx, btcomm.unique_id(), 0, 1)
+    assert bench.sharded_precheck(ctx, c, Dist, torch, dev, 0, 1, 3) is True
+
+    class Broken(btcomm.Comm):   # a gather that loses a word must be noticed
+        def gather_words(self, d_local_ptr, local_words, d_out_ptr, out_capacity_words):
+            offs = super().gather_words(d_local_ptr, local_words, d_out_ptr, out_capacity_words)
+            self.ctx.sync()
+            torch.cuda.synchronize()
+            lib.check(lib.bt_memset(self.ctx.h, d_out_ptr, 0, 64))
+            self.ctx.sync()
+            return offs
+
+    c.close()
+    b = Broken(ctx, btcomm.unique_id(), 0, 1)
+    with pytest.raises(RuntimeError, match="pre-check failed"):
+        bench.sharded_precheck(ctx, b, Dist, torch, dev, 0, 1, 3)
+    b.close()
+    ctx.close()

@@ -568,7 +568,8 @@ def test_scale_properties_of_a_mixture_batch(gpu_ctx):
 
 def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatch):
     """The whole-GPU table refill (nan_fill_kernel + ucache_prefill_kernel after a stepwise chain start and after every cache-clearing noise count),
-    bt_gibbs_run chain by chain (BT_GIBBS_STEPWISE) and the choice between gibbs_hot_kernel and gibbs_kernel only move work: every collected statistic is bit-identical to the single-launch schedule,
+    bt_gibbs_run chain by chain (BT_GIBBS_STEPWISE), the choice between gibbs_single_kernel, gibbs_hot_kernel and gibbs_kernel and the packing of several tiles
+    into one workgroup's LDS only move work: every collected statistic is bit-identical to the single-launch schedule,
     and a noise drivers' loop gives the same noise counts and samples with the refill switched off."""
     from bayestyper_amd import lib, synth
 
@@ -579,7 +580,7 @@ def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatc
     kw = dict(seed=97, chains=3, burn=15, iters=30)
 
     def default_run(env):
-        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL", "BT_GIBBS_NO_HOT_KERNEL"):
+        for k in ("BT_GIBBS_STEPWISE", "BT_GIBBS_NO_PREFILL", "BT_GIBBS_NO_WIDE_FILL", "BT_GIBBS_NO_HOT_KERNEL", "BT_GIBBS_SINGLE_KERNEL", "BT_GIBBS_MAX_CLASSES", "BT_GIBBS_PACK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -607,7 +608,10 @@ def test_wide_refill_and_stepwise_run_change_nothing(gpu_ctx, oracle, monkeypatc
 
     base = default_run({})
     # (BT_GIBBS_NO_HOT_KERNEL: the sampling launches through gibbs_kernel's generic pointers instead of gibbs_hot_kernel's LDS accesses)
-    for env in ({"BT_GIBBS_STEPWISE": "1"}, {"BT_GIBBS_STEPWISE": "1", "BT_GIBBS_NO_PREFILL": "1"}, {"BT_GIBBS_NO_HOT_KERNEL": "1"}):
+    # (BT_GIBBS_SINGLE_KERNEL: one-cluster tiles through gibbs_single_kernel instead of gibbs_hot_kernel; BT_GIBBS_PACK: several tiles per workgroup sharing a slab
+    #  of LDS instead of one; BT_GIBBS_MAX_CLASSES: seven launch classes — what a process with eight hardware queues gets — instead of three)
+    for env in ({"BT_GIBBS_STEPWISE": "1"}, {"BT_GIBBS_STEPWISE": "1", "BT_GIBBS_NO_PREFILL": "1"}, {"BT_GIBBS_NO_HOT_KERNEL": "1"}, {"BT_GIBBS_SINGLE_KERNEL": "1"},
+                {"BT_GIBBS_SINGLE_KERNEL": "1", "BT_GIBBS_PACK": "auto"}, {"BT_GIBBS_PACK": "2,65536"}, {"BT_GIBBS_MAX_CLASSES": "7"}):
         got = default_run(env)
         for k in base:
             assert np.array_equal(base[k], got[k]), (env, k)

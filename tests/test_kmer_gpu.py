@@ -417,9 +417,11 @@ def test_routed_scan_equals_direct_at_scale(gpu_ctx, monkeypatch):
     """6 x 10^6 records (above the size from which bt_kmc_scan_run partitions the records by sub-filter): the partitioned scan (one partition pass,
     probe through the caches) — one chunk, several ragged chunks, chunks so small that the stripe regions' slack matters, stripe regions too small
     for their share (the records beyond them are probed on the spot), and persistent probe workgroups — leaves exactly the table the direct kernel
-    leaves (keys incl. Bloom false positives, counts, hit count)"""
+    leaves (keys incl. Bloom false positives, counts, hit count).  The chunked variants run double-buffered here (BT_KMC_OVERLAP=1: the partition of chunk i + 1 on a
+    class stream beside the probe / apply of chunk i; test_partitioned_scan_other_record_shapes covers the single-buffered chunk loop)"""
     from bayestyper_amd import lib
 
+    monkeypatch.setenv("BT_KMC_OVERLAP", "1")
     rng = np.random.default_rng(23)
     n, p = 6_000_000, 7
     prefixes = np.sort(rng.integers(0, 4 ** p, size=n))

@@ -1,6 +1,7 @@
 """Time the default Gibbs schedule of the bench's mixture batch as a whole and per shape class (one MI355X).
 usage: python tools/perf_classes.py [S] [groups] [classes e.g. ABCD+]   ('+' = the whole mixture)
-BT_PERF_RUNS = schedules per class (default 2: the second is the warm one; tools/sq_counters.sh sets 1 so that the counters of a pass cover ONE schedule)"""
+BT_PERF_RUNS = schedules per class (default 2: the second is the warm one; tools/sq_counters.sh sets 1 so that the counters of a pass cover ONE schedule)
+BT_PERF_BURN / BT_PERF_ITERS = burn-in / collected sweeps per chain instead of 100 / 250 (tools/traffic_by_array.py: 0 / 1 isolates the chain starts)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,7 +23,8 @@ for shape in ("D", "C", "B", "A"):
 for w in which:
     f = flat if w == "+" else shard.take_groups(flat, np.arange(*bounds[w]))
     t_create = time.perf_counter()
-    g = lib.Gibbs(ctx, f, lut_g, lut_n, seed=42)
+    sched = {k: int(os.environ[e]) for k, e in (("burn", "BT_PERF_BURN"), ("iters", "BT_PERF_ITERS")) if e in os.environ}
+    g = lib.Gibbs(ctx, f, lut_g, lut_n, seed=42, **sched)
     t_create = time.perf_counter() - t_create
     t = lib.Timer(ctx)
     ms = []

@@ -2,10 +2,10 @@
 import csv, glob, json, os, sys
 src, tag, dest = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dest, exist_ok=True)
-OURS = ("gibbs_kernel", "gibbs_hot_kernel", "summary_kernel", "kmc_", "bloom_", "table_", "kmers_from", "nthash", "intercluster", "classify", "rocprim", "find_paths", "paths", "_kernel")
+OURS = ("gibbs_kernel", "gibbs_hot_kernel", "gibbs_single_kernel", "summary_kernel", "kmc_", "bloom_", "table_", "kmers_from", "nthash", "intercluster", "classify", "rocprim", "find_paths", "paths", "_kernel")
 def ours(name): return any(k in name for k in OURS)
 def short(name):
-    for k in ("gibbs_hot_kernel", "gibbs_simple_kernel", "gibbs_noise_kernel", "gibbs_kernel", "summary_kernel", "kmc_scan_kernel<true>", "kmc_scan_kernel<false>", "kmc_scan_kernel", "kmc_route_kernel", "kmc_probe_kernel<true>", "kmc_probe_kernel<false>", "kmc_probe_kernel",
+    for k in ("gibbs_hot_kernel", "gibbs_single_kernel", "gibbs_simple_kernel", "gibbs_noise_kernel", "gibbs_kernel", "summary_kernel", "kmc_scan_kernel<true>", "kmc_scan_kernel<false>", "kmc_scan_kernel", "kmc_route_kernel", "kmc_probe_kernel<true>", "kmc_probe_kernel<false>", "kmc_probe_kernel",
               "kmc_apply_kernel", "bloom_insert_kernel", "bloom_contains_kernel"):
         if k in name: return k
     if "rocprim" in name: return "rocprim " + ("onesweep" if "onesweep" in name else "histogram" if "histogram" in name else name[-40:])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/sq_counters.sh <tag> <class A|B|C|D|+> [S] [groups]   (on the GPU box, from the repo root)
-# SQ counters of the Gibbs sampling launches (gibbs_kernel / gibbs_hot_kernel / gibbs_simple_kernel) on one shape class of the bench mixture: five --pmc passes
+# SQ counters of the Gibbs sampling launches (gibbs_kernel / gibbs_hot_kernel / gibbs_single_kernel / gibbs_simple_kernel) on one shape class of the bench mixture: five --pmc passes
 # (8 SQ slots each) + one each for FETCH_SIZE and WRITE_SIZE (KiB; TCC slots), every pass ONE schedule (BT_PERF_RUNS=1), counters summed over the dispatches of the sampling kernels and reported with the dispatch count,
 # so that per-schedule figures follow without guessing -> gpurun_out/summ_<tag>/<tag>_sq_<class>_S<S>.txt
 # (round 3's script summed two schedules + the set-up dispatch and the analysis divided by one: every per-sweep figure of that round is 2x too high.)
@@ -25,9 +25,9 @@ agg, disp = {}, {}
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if not any(n in k for n in ("gibbs_kernel", "gibbs_simple_kernel", "gibbs_hot_kernel")): continue
+        if not any(n in k for n in ("gibbs_kernel", "gibbs_simple_kernel", "gibbs_hot_kernel", "gibbs_single_kernel")): continue
         if int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) == 0: continue
-        name = "gibbs_simple_kernel" if "gibbs_simple_kernel" in k else ("gibbs_hot_kernel" if "gibbs_hot_kernel" in k else "gibbs_kernel")
+        name = next((n for n in ("gibbs_simple_kernel", "gibbs_single_kernel", "gibbs_hot_kernel") if n in k), "gibbs_kernel")
         agg[(name, r["Counter_Name"])] = agg.get((name, r["Counter_Name"]), 0.0) + float(r["Counter_Value"])
         disp.setdefault((name, r["Counter_Name"]), set()).add(r["Dispatch_Id"])
 for (k, c), v in sorted(agg.items()): print(k, c, "%.5g" % v, "dispatches", len(disp[(k, c)]))
