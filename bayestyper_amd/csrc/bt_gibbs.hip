@@ -1850,12 +1850,16 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
                 }
             }
             int nk[NKIND] = {present[0] ? 1 : 0, present[1] ? 1 : 0, present[2] ? 1 : 0};
-            // BUDGET: the classes run beside each other only on streams that sit on different hardware queues.  The runtime deals four by default (then three
-            // classes + the two-haplotype one, as since round 2); a process started with GPU_MAX_HW_QUEUES=8 (bench.py and the executables set it) gets up to
-            // seven + one — the context counts the class streams that PROVED to overlap (ctx_class_streams) — and the finer cuts charge 17 % less LDS to the
-            // whole-genome batch: 3.70 -> 3.55 s per schedule (profiles/r06_launch_classes.txt).
+            // BUDGET: the classes run beside each other only on streams that sit on different hardware queues, and the runtime deals a handful to the process's
+            // streams round robin.  The context counts the class streams that PROVED to overlap with its stream and with one another (ctx_class_streams): three
+            // at least (as since round 2), four in a process with the runtime's default queues whose context has a stream of its own — the finer cuts charge
+            // less LDS to a whole-genome batch: 3.70 -> 3.55 s per schedule —, up to seven (no faster, and GPU_MAX_HW_QUEUES=8 slows the same process's KMC
+            // scans down: profiles/r06_launch_classes.txt; bench.py and the executables leave the runtime's default).
             unsigned concurrent = 3;
-            if (!getenv("BT_GIBBS_MAX_CLASSES")) {
+            // (a noise driver's sampler keeps three: its iterations are launches PER CLASS when its chain is not resident — sweep, refill, tally —, and the
+            //  ten-sample batch of the bench took 28 instead of 14 ms per iteration with eight classes; a resident chain is one launch whatever the classes)
+            if (params->noise_seeding && !getenv("BT_GIBBS_MAX_CLASSES")) concurrent = 3;
+            else if (!getenv("BT_GIBBS_MAX_CLASSES")) {
                 int prio_lo = 0, prio_hi = 0;
                 BT_TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
                 hipStream_t probe[MAXC];
@@ -2438,6 +2442,9 @@ int bt_gibbs_noise_chain_begin(bt_gibbs *g, uint32_t num_iterations, uint32_t fi
             if (const char *e = getenv("BT_NOISE_CHAIN_HELPERS")) helpers = std::min<uint32_t>(helpers, (uint32_t)atoi(e));
             g->nc.num_wgs = g->ntiles + helpers;
             k.total_wgs = g->nc.num_wgs;
+            // TEST HOOK (tests/_rollcall_child.py): the roll call expects workgroups that are never launched — what a launch looks like from the inside when a CU
+            // mask or another process keeps some of its workgroups from being resident
+            if (const char *e = getenv("BT_NOISE_CHAIN_TEST_ABSENT_WGS")) k.total_wgs += (uint32_t)std::max(0, atoi(e));
         }
         if (g->nc.help_units) BT_HIP(hipMemsetAsync(g->nc.d_help_words, 0, (64 + (size_t)g->ntiles) * 4, st));
         k.h_phase = nullptr;

@@ -587,9 +587,6 @@ std::vector<pid_t> startRanks(int argc, char *const argv[]) {
 }  // namespace
 
 int main(int argc, char *const argv[]) {
-    // eight hardware queues for the process's HIP streams instead of the runtime's four (before the runtime initialises; the caller's setting wins): the Gibbs
-    // sampler then runs up to seven launch classes beside the two-haplotype one concurrently (csrc/bt_gibbs.hip: BUDGET)
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const unsigned kmer_size = getenv("BT_KMER_SIZE") ? (unsigned)atoi(getenv("BT_KMER_SIZE")) : 55u;
     std::cout << "\n[" << getLocalTime() << "] You are using BayesTyper (" << BT_VERSION << ")\n" << std::endl;
     const std::string command_info = "Usage: bayesTyper <command> [options]\n\nCommands:\n\n\tcluster\t\tcreate variant clusters\n\tgenotype\tgenotype variant clusters\n";

@@ -32,12 +32,6 @@ matches/sec is reported beside it.  `roofline` describes the dominant kernel (th
 scan kernel (average over the S launches of a step: one inserting, S-1 finding).  `cpu_baseline` times the oracle (a scalar
 restatement of the reference's algorithm, parity-pinned in tests/) on a bounded sample of the same workload on this box's host cores.
 """
-import os as _os
-
-# Eight hardware queues for this process's HIP streams (the runtime's default is four): the Gibbs sampler then cuts its tiles into up to seven launch classes
-# beside the two-haplotype one, each on a stream that runs concurrently with the others (bt_gibbs.hip: BUDGET).  Must be in the environment before the HIP
-# runtime initialises; a value set by the caller wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os

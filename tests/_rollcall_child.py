@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _oracle  # noqa: E402
 from bayestyper_amd import lib, synth  # noqa: E402
 
-n_groups = int(sys.argv[1]) if len(sys.argv) > 1 else 40_000
+n_groups = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000
 S = 1
 orc = _oracle.load_oracle()
 ctx = lib.Ctx(0)
