@@ -30,6 +30,7 @@
 #include <thread>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <cstring>
 #include <ctime>
 #include <fstream>
@@ -385,6 +386,32 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     std::cout << std::endl;
     st.reset(new StageScope("classify path k-mers + haplotype candidates"));
     const GibbsBatchData batch = kmer_counter.classifyPathKmers(kmer_hash.h, unit, graphs, multigroup_kmers_dir_prefix, chrom_ploidy);
+    if (getenv("BT_STAGE_TIMES")) {   // the unit's shape beside the stage table: what tools/mixture_shape.py prints for the bench's synthetic mixture
+        std::map<uint32_t, uint64_t> by_h, by_k, by_n, by_v;
+        auto bucket = [](uint32_t x) {   // 1, 2, 3-4, 5-8, 9-16, ...
+            uint32_t b = 1;
+            while (b < x) b *= 2;
+            return b;
+        };
+        uint64_t kh = 0;
+        for (uint32_t c = 0; c + 1 < batch.kmer_off.size(); c++) {
+            by_h[bucket(batch.num_haplotypes[c])] += 1;
+            by_k[bucket(batch.kmer_off[c + 1] - batch.kmer_off[c])] += 1;
+            by_v[bucket(batch.num_variants[c])] += 1;
+            kh += (uint64_t)(batch.kmer_off[c + 1] - batch.kmer_off[c]) * batch.num_haplotypes[c];
+        }
+        for (uint32_t g = 0; g < batch.numGroups(); g++) by_n[bucket(batch.group_cluster_off[g + 1] - batch.group_cluster_off[g])] += 1;
+        auto line = [](const char *what, const std::map<uint32_t, uint64_t> &m) {
+            std::cerr << "unit shape: " << what << " (upper bucket bound: count)";
+            for (auto &kv : m) std::cerr << " " << kv.first << ":" << kv.second;
+            std::cerr << std::endl;
+        };
+        std::cerr << "unit shape: " << batch.numGroups() << " groups, " << batch.kmer_off.size() - 1 << " clusters, sum over clusters of k-mers x haplotype candidates " << kh << std::endl;
+        line("haplotype candidates per cluster", by_h);
+        line("path k-mers per cluster", by_k);
+        line("variants per cluster", by_v);
+        line("clusters per group", by_n);
+    }
     std::cout << "\n" << std::endl;
     st.reset(new StageScope("k-mer statistics -> count model"));
 
