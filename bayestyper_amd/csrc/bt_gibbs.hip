@@ -1401,7 +1401,7 @@ static int gibbs_create_impl(const bt_gibbs_source *src, bt_ctx *ctx, const bt_g
         len[A_GDIMS] = 4;
         len[A_SOURCES0] = nv;
         len[A_PLOIDY] = S;
-        len[A_MT] = nv * 2 * MT_PAD;
+        len[A_MT] = nv * 2 * MT_RING_PAD;
         len[A_FNDSAVED] = nv;
         len[A_SPARSITY] = nv;
         len[A_UNIQ] = len[A_USUB] = nv * d.NUm;

@@ -55,6 +55,11 @@ constexpr bool kPacked = true;
 constexpr bool kPacked = false;
 #endif
 constexpr unsigned MT_PAD = 640;   // words reserved per generator (625 used)
+#ifdef BT_MT_BLOCK
+constexpr unsigned MT_RING_PAD = 2 * MT_BUF;   // a cluster's ring generators keep two state buffers (bt_rng_device.hpp: block form)
+#else
+constexpr unsigned MT_RING_PAD = MT_PAD;
+#endif
 
 // scalar slots per vertex (A_SC)
 // SC_H .. SC_NM: the cluster's dimensions (copied from A_VDIMS by OP_SETUP, never cleared): with the scalars in LDS a sampler function
@@ -306,7 +311,7 @@ struct Vx {   // vertex context: tile + vertex index + the lane's true dimension
     __device__ inline uint8_t var_dep(uint32_t var) const { return a<uint8_t>(A_VARDEP, d().Vm)[var]; }
     __device__ inline uint32_t allele_base(uint32_t var) const { return a<uint32_t>(A_ALBASE, d().Vm + 1)[var]; }
     // state
-    __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)((v * 2 + g) << t.wsh) + t.plane) * MT_PAD; }
+    __device__ inline uint32_t *mt(uint32_t g) const { return (uint32_t *)(t.base + d().off[A_MT]) + ((size_t)((v * 2 + g) << t.wsh) + t.plane) * MT_RING_PAD; }
     __device__ inline SPtrF<uint32_t, LANES> ring(uint32_t g) const { return t.harr<uint32_t>(A_RING, v, d().ring_len) + (g ? d().ring_cap[0] + MT_RING_HDR : 0u); }
     __device__ inline MtRing rng(uint32_t g) const { return mt_ring_open(mt(g), ring(g), d().ring_cap[g]); }
     __device__ inline void rng_seed(uint32_t g, uint32_t seed) const { mt_ring_seed(mt(g), ring(g), d().ring_cap[g], seed); }

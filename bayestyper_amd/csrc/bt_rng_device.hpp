@@ -218,17 +218,179 @@ BT_HD uint32_t bt_fake_word(uint32_t x) {
     return x;
 }
 #endif
+#if !defined(BT_MT_CHUNK) && !defined(BT_MT_BLOCK)
+#define BT_MT_BLOCK 1   // the default since round 6; -DBT_MT_CHUNK builds the chunk form (rounds 4-5) for comparison
+#endif
+// ---- BLOCK form of a ring generator (round 6, BT_MT_BLOCK) ----------------------------------------------------------------------------------------
+// The chunk form regenerates four words in place right before they are read: per lane and chunk a 16-byte load, a word, an unaligned 16-byte load and a
+// 16-byte store — and since the lanes of a wavefront sit at different positions of their own (per-lane contiguous) states, every one of those instructions
+// is 64 separate cache lines to the CU's L1 (5.5e9 such instructions per schedule of the bench batch: the two-haplotype class's bound).
+// Block form: a generator has TWO state buffers (MT_BUF words apart).  The current one holds a block of 624 already twisted words of which [pos, 624) are
+// unread; a refill is ONE aligned 16-byte load per lane and four words.  The NEXT block is twisted AHEAD, out of place, into the other buffer by the whole
+// wavefront: new[i] = f(old[i], old[i + 1], i < 227 ? old[i + 397] : new[i - 227]) (i = 623: f(old[623], new[0], new[396])), so the lane that owns words
+// 4q .. 4q + 3 of the three phases [0, 227), [227, 454), [454, 624) needs, beside old words, only its OWN results of the phase before (and new[0], three old
+// words away): seven loads in flight, three stores, consecutive lanes on consecutive addresses — coalesced — and no exchange between lanes.  The twist-ahead
+// runs at the convergent top-up of a visit once a lane has passed MT_AHEAD words of its block, so that reaching the end of a block — which happens wherever the
+// lane is, usually inside a rejection loop with most of the wavefront masked off — is a flip of the buffer index.  A lane that does reach the end without a
+// next block (chain starts draw hundreds of words between top-ups) gets it from the lanes that are active with it.  The output stream is the textbook's.
+constexpr unsigned MT_BUF = 640;     // words between a ring generator's two state buffers
+constexpr unsigned MT_AHEAD = 312;   // words of a block consumed before the next block is twisted ahead at a top-up
+constexpr uint32_t MT_F_CUR = 1u << 16, MT_F_READY = 1u << 17;   // flags kept with the position word of the ring block: current buffer, next block ready
 typedef uint32_t MtQuad __attribute__((ext_vector_type(4)));    // four consecutive state words at a 16-byte aligned address (a chunk)
 typedef MtQuad MtQuadU __attribute__((aligned(4)));             // ... at a 4-byte aligned address (x[p + 397 ...])
+#if defined(__HIP_DEVICE_COMPILE__)
+// every active lane of the wavefront calls this with the SAME pointers: the block after `old` is written to `nw`
+__device__ inline void mt_twist_block(const uint32_t BT_GAS *old, uint32_t BT_GAS *nw) {
+    const unsigned long long ex = __ballot(1);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rank = (uint32_t)__popcll(ex & ((1ull << lane) - 1ull)), n = (uint32_t)__popcll(ex);
+    for (uint32_t q = rank; q < 57u; q += n) {
+        const uint32_t va = 227u - 4u * q < 4u ? 227u - 4u * q : 4u;                       // words of this quad in phases A and B (3 for the last quad)
+        const uint32_t vc = q <= 42u ? (170u - 4u * q < 4u ? 170u - 4u * q : 4u) : 0u;     // ... in phase C (2 for quad 42, none beyond)
+        const MtQuad a = *(const MtQuad BT_GAS *)(old + 4u * q);
+        const uint32_t a4 = old[4u * q + 4u];
+        const MtQuad b = *(const MtQuadU BT_GAS *)(old + 4u * q + 397u);
+        const MtQuad c = *(const MtQuadU BT_GAS *)(old + 4u * q + 227u);
+        const uint32_t c4 = old[4u * q + 231u];
+        MtQuad d = {0u, 0u, 0u, 0u};
+        uint32_t d4 = 0, o0 = 0, o1 = 0, o397 = 0;
+        if (vc) {
+            d = *(const MtQuadU BT_GAS *)(old + 4u * q + 454u);
+            d4 = old[4u * q + 458u];
+        }
+        if (q == 42u) {   // word 623 reads new[0]
+            o0 = old[0];
+            o1 = old[1];
+            o397 = old[397];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (all requests leave before the first word is used)
+        MtQuad za, zb, zc;
+        za.x = mt_twist(a.x, a.y, b.x);
+        za.y = mt_twist(a.y, a.z, b.y);
+        za.z = mt_twist(a.z, a.w, b.z);
+        za.w = mt_twist(a.w, a4, b.w);
+        zb.x = mt_twist(c.x, c.y, za.x);
+        zb.y = mt_twist(c.y, c.z, za.y);
+        zb.z = mt_twist(c.z, c.w, za.z);
+        zb.w = mt_twist(c.w, c4, za.w);
+        const uint32_t new0 = mt_twist(o0, o1, o397);
+        zc.x = mt_twist(d.x, d.y, zb.x);
+        zc.y = mt_twist(d.y, q == 42u ? new0 : d.z, zb.y);   // quad 42, word 1 is x[623]
+        zc.z = mt_twist(d.z, d.w, zb.z);
+        zc.w = mt_twist(d.w, d4, zb.w);
+        if (va == 4u) {
+            *(MtQuad BT_GAS *)(nw + 4u * q) = za;
+            *(MtQuadU BT_GAS *)(nw + 4u * q + 227u) = zb;
+        } else {   // the last quad: three words
+            nw[4u * q] = za.x, nw[4u * q + 1u] = za.y, nw[4u * q + 2u] = za.z;
+            nw[4u * q + 227u] = zb.x, nw[4u * q + 228u] = zb.y, nw[4u * q + 229u] = zb.z;
+        }
+        if (vc == 4u) *(MtQuadU BT_GAS *)(nw + 4u * q + 454u) = zc;
+        else if (vc == 2u) nw[4u * q + 454u] = zc.x, nw[4u * q + 455u] = zc.y;
+    }
+    // the block's words were written by other lanes than the one that reads them: same CU, same L1 — visible once the stores are acknowledged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// the lanes with `want` set get the block after their current one twisted into their other buffer, one distinct state at a time (the lockstep copies of a
+// narrow tile's group share a state: once for all of them), every active lane helping
+// (a function of its own: it runs once per 624 words of a lane, and its body would otherwise sit at every refill site of the sweep)
+__device__ static __noinline__ void mt_twist_for(bool want, uint32_t BT_GAS *st, uint32_t cur) {
+    unsigned long long todo = __ballot(want);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        const uint64_t p = (uint64_t)(uintptr_t)st;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)p, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(p >> 32), src);
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cur, src);
+        uint32_t BT_GAS *base = (uint32_t BT_GAS *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+        mt_twist_block(base + (c ? MT_BUF : 0u), base + (c ? 0u : MT_BUF));
+        todo &= ~__ballot(want && (uint64_t)(uintptr_t)st == (((uint64_t)hi << 32) | lo));
+    }
+}
+#endif
 template <class RP>   // RP: pointer-like (operator[](uint32_t) -> uint32_t&) to the ring block
 struct MtRingT {
     uint32_t BT_GAS *st;
     RP ring;                   // element i of the ring block at ring[i] (LDS when the cluster's hot arrays are resident, else HBM)
     uint32_t cap;              // power of two, 8 .. 64
     uint32_t pos, head, avail; // pos: multiple of four
+#ifdef BT_MT_BLOCK
+    uint32_t flags = 0;        // MT_F_CUR: the buffer that holds the current block; MT_F_READY: the other buffer holds the next block
+#endif
 #ifdef BT_DIAG_FAKE_MT
     uint32_t fake_ctr = 0;
 #endif
+#if defined(BT_MT_BLOCK) && defined(__HIP_DEVICE_COMPILE__) && !defined(BT_DIAG_FAKE_MT)
+    __device__ inline uint32_t BT_GAS *cur_buf() const { return st + ((flags & MT_F_CUR) ? MT_BUF : 0u); }
+    // lanes with `at_end` set have read their whole block: the next one is made if it was not made ahead, then the buffers change roles
+    __device__ inline void next_block(bool at_end) {
+        mt_twist_for(at_end && !(flags & MT_F_READY), st, (flags & MT_F_CUR) ? 1u : 0u);
+        if (at_end) {
+            flags = (flags ^ MT_F_CUR) & ~MT_F_READY;
+            pos = 0;
+        }
+    }
+    // at a convergent point: lanes past MT_AHEAD words of their block get the next block made now
+    __device__ inline void twist_ahead() {
+        const bool want = pos >= MT_AHEAD && !(flags & MT_F_READY);
+        if (bt_wave_any(want)) {
+            mt_twist_for(want, st, (flags & MT_F_CUR) ? 1u : 0u);
+            if (want) flags |= MT_F_READY;
+        }
+    }
+    __device__ inline void chunk(bool go) {
+        if (bt_wave_any(go && pos == MT_N)) next_block(go && pos == MT_N);
+        if (go) {
+            const MtQuad z = *(const MtQuad BT_GAS *)(cur_buf() + pos);
+            const uint32_t w = (head + avail) & (cap - 1u);   // a multiple of four: as many words were produced before
+            ring[w] = mt_temper(z.x);
+            ring[w + 1u] = mt_temper(z.y);
+            ring[w + 2u] = mt_temper(z.z);
+            ring[w + 3u] = mt_temper(z.w);
+            pos += 4u;
+            avail += 4u;
+        }
+    }
+    template <unsigned NB>
+    __device__ inline void batch(uint32_t want) {
+        // up to NB quads of the current block with all loads in flight (a batch does not cross the end of a block: what is missing follows chunk by chunk)
+        if (bt_wave_any(avail < want && pos == MT_N)) next_block(avail < want && pos == MT_N);
+        uint32_t nc = avail < want ? (want - avail + 3u) >> 2 : 0u;
+        nc = nc < NB ? nc : NB;
+        const uint32_t left = (MT_N - pos) >> 2;
+        nc = nc < left ? nc : left;
+        MtQuad z[NB];
+        const uint32_t BT_GAS *b = cur_buf() + pos;
+#pragma unroll
+        for (unsigned j = 0; j < NB; ++j)
+            if (j < nc) z[j] = *(const MtQuad BT_GAS *)(b + 4u * j);
+        bt_sched_fence();
+#pragma unroll
+        for (unsigned j = 0; j < NB; ++j)
+            if (j < nc) {
+                const uint32_t w = (head + avail) & (cap - 1u);
+                ring[w] = mt_temper(z[j].x);
+                ring[w + 1u] = mt_temper(z[j].y);
+                ring[w + 2u] = mt_temper(z[j].z);
+                ring[w + 3u] = mt_temper(z[j].w);
+                avail += 4u;
+                pos += 4u;
+            }
+    }
+    __device__ inline void fill_to(uint32_t want) {
+        while (bt_wave_any(avail < want)) chunk(avail < want);
+    }
+    template <unsigned NB>
+    __device__ inline void fill_batched(uint32_t want) {
+        if (bt_wave_any(avail < want)) batch<NB>(want);
+        fill_to(want);
+    }
+    __device__ inline void topup() {
+        twist_ahead();
+        fill_batched<4>(cap - 3u);
+    }
+#else
     // one chunk for the lanes with `go` set
     BT_HD void chunk(bool go) {
 #ifdef BT_DIAG_FAKE_MT
@@ -320,6 +482,7 @@ struct MtRingT {
         fill_to(want);
     }
     BT_HD void topup() { fill_batched<4>(cap - 3u); }
+#endif
     BT_HD void need(uint32_t n) {   // n <= 4
         if (avail < n) fill_to(cap - 3u < 16u ? cap - 3u : 16u);
     }
@@ -349,6 +512,10 @@ BT_HD MtRingT<RP> mt_ring_open_as(uint32_t *st, RP ring, uint32_t cap) {
     m.pos = m.ring[cap];
     m.head = m.ring[cap + 1];
     m.avail = m.ring[cap + 2];
+#ifdef BT_MT_BLOCK
+    m.flags = m.pos & (MT_F_CUR | MT_F_READY);
+    m.pos &= 0xFFFFu;
+#endif
     return m;
 }
 template <class RP>
@@ -360,11 +527,19 @@ BT_HD MtRing mt_ring_open(uint32_t *st, RP ring, uint32_t cap) {
     m.pos = m.ring[cap];
     m.head = m.ring[cap + 1];
     m.avail = m.ring[cap + 2];
+#ifdef BT_MT_BLOCK
+    m.flags = m.pos & (MT_F_CUR | MT_F_READY);
+    m.pos &= 0xFFFFu;
+#endif
     return m;
 }
 template <class RP>
 BT_HD void mt_close(const MtRingT<RP> &m) {
+#ifdef BT_MT_BLOCK
+    m.ring[m.cap] = m.pos | m.flags;
+#else
     m.ring[m.cap] = m.pos;
+#endif
     m.ring[m.cap + 1] = m.head;
     m.ring[m.cap + 2] = m.avail;
 }
@@ -372,7 +547,11 @@ template <class RP>
 BT_HD void mt_ring_seed(uint32_t *st, RP ring, uint32_t cap, uint32_t seed) {
     mt_seed(st, seed);
     for (unsigned i = 0; i < MT_MIRROR; ++i) st[MT_N + i] = st[i];   // (a ring generator keeps its position in the ring block, not at st[MT_N])
+#ifdef BT_MT_BLOCK
+    ring[cap] = MT_N;   // the seeded words are the block BEFORE the first one: buffer 0 is "read to the end", the first refill twists (block form)
+#else
     ring[cap] = 0;
+#endif
     ring[cap + 1] = 0;
     ring[cap + 2] = 0;
 }
