@@ -27,5 +27,10 @@ for v in base q8_base single q8_single q8_133 q8_123 q8_132 q8_base33; do echo "
 echo "## r6j  the final tree (class budget = the class streams that proved concurrent, cuts by dynamic programme): q4 = default queues, q8 / q16 = GPU_MAX_HW_QUEUES"
 for v in q4 q8 q16; do echo "-- $v"; rows $o/r6j/S3_+_$v.log; done
 echo "-- q8, two-haplotype class alone (simple_fill_unique: two samples per pass, operands of the next block requested ahead)"; rows $o/r6j/S3_A_q8.log
+echo "## r6q / r6r  ring generators: chunk form (rounds 4-5, -DBT_MT_CHUNK) against block form (two buffers, next block twisted ahead cooperatively; the default), same box per pair;"
+echo "##            ring1_16 / ring0_8 = BT_GIBBS_RING1=16 / BT_GIBBS_RING0=8 with the block form (32 / 16 words stay)"
+for c in A B +; do for v in chunk block; do echo "-- S=3 class $c, $v"; rows $o/r6q/S3_${c}_$v.log; done; done
+for v in block ring1_16 ring1_16_ring0_8; do for c in A +; do echo "-- S=3 class $c, $v"; rows $o/r6r/S3_${c}_$v.log; done; done
+for v in chunk block; do echo "-- S=10, 100 352 groups, whole mixture, $v"; rows $o/r6r/S10_+_$v.log; done
 } > profiles/r06_launch_classes.txt
 wc -l profiles/r06_single_kernel.txt profiles/r06_launch_classes.txt
