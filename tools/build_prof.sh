@@ -3,7 +3,7 @@
 set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
 src="$root/bayestyper_amd/csrc"
-obj="$root/scratch/prof_obj"
+obj="$root/build/prof_obj"
 mkdir -p "$obj"
 objs=()
 for s in "$src"/*.hip; do

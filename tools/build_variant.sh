@@ -5,8 +5,8 @@ set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
 tag=$1; unit=$2; shift 2
 src="$root/bayestyper_amd/csrc"
-mkdir -p "$root/scratch/variant_obj"
-o="$root/scratch/variant_obj/${unit}_$tag.o"
+mkdir -p "$root/build/variant_obj"
+o="$root/build/variant_obj/${unit}_$tag.o"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c "$src/$unit.hip" -o "$o"
 objs=()
 for s in "$src"/*.hip; do b="$(basename "${s%.hip}")"; if [ "$b" = "$unit" ]; then objs+=("$o"); else objs+=("$src/$b.o"); fi; done

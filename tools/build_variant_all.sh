@@ -5,14 +5,14 @@ set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
 tag=$1; shift
 src="$root/bayestyper_amd/csrc"
-mkdir -p "$root/scratch/variant_obj"
+mkdir -p "$root/build/variant_obj"
 objs=()
 pids=()
 for s in "$src"/*.hip; do
   b="$(basename "${s%.hip}")"
   case "$b" in
     bt_gibbs|bt_gibbs_hot_kernel|bt_gibbs_single_kernel|bt_gibbs_simple_kernel|bt_gibbs_chain_kernel)
-      o="$root/scratch/variant_obj/${b}_$tag.o"
+      o="$root/build/variant_obj/${b}_$tag.o"
       hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -c "$s" -o "$o" &
       pids+=($!)
       objs+=("$o");;
