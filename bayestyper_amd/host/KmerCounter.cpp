@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <future>
 #include <iostream>
 #include <map>
 #include <sstream>
@@ -284,15 +285,52 @@ void KmerCounter::findVariantClusterPaths(InferenceUnit *unit, const UnitGraphs 
     check(bt_find_paths_create(ctx, &builder.batch(), kmer_size, max_sample_haplotypes, (uint32_t)samples.size(), &fp), "bt_find_paths_create");
     try {
         std::vector<uint32_t> seeds(C);
+        // The NEXT sample's Bloom filter (KmerBloom<k>(samples[s].file): <file>.bloomMeta / .bloomData — gigabytes read and uploaded) is loaded by a helper thread on
+        // a clone of the context while the current sample's search runs (BT_FIND_PATHS_NO_PREFETCH=1: one after the other, as before round 6).
+        struct CtxClone {
+            bt_ctx *c = nullptr;
+            ~CtxClone() {
+                if (c) bt_ctx_destroy(c);
+            }
+        } loader_ctx;
+        const bool prefetch = samples.size() > 1 && !getenv("BT_FIND_PATHS_NO_PREFETCH");
+        if (prefetch) check(bt_ctx_clone(ctx, &loader_ctx.c), "bt_ctx_clone");
+        auto load = [&](size_t s, bt_ctx *on) {
+            bt_bloom *h = nullptr;
+            check(bt_bloom_load(on, samples[s].file.c_str(), kmer_size, &h), "bt_bloom_load");
+            check(bt_sync(on), "bt_sync");
+            return h;
+        };
+        std::future<bt_bloom *> coming;
+        double load_wait_s = 0, search_s = 0;
         for (size_t s = 0; s < samples.size(); s++) {
-            BloomHandle sample_bloom;   // KmerBloom<k>(samples[s].file): <file>.bloomMeta / .bloomData
-            check(bt_bloom_load(ctx, samples[s].file.c_str(), kmer_size, &sample_bloom.h), "bt_bloom_load");
+            const auto t0 = std::chrono::steady_clock::now();
+            BloomHandle sample_bloom;
+            sample_bloom.h = coming.valid() ? coming.get() : load(s, ctx);
+            if (prefetch && s + 1 < samples.size()) coming = std::async(std::launch::async, load, s + 1, loader_ctx.c);
+            const auto t1 = std::chrono::steady_clock::now();
             // prng_seed + (group index + 1) * (sample index + 1) (KmerCounter.cpp:65) + variant_cluster_idx (VariantClusterGroup.cpp:142)
             for (uint32_t c = 0; c < C; c++)
                 seeds[c] = prng_seed + (ug.cluster_group[c] + 1u) * (uint32_t)(s + 1) + unit->variant_cluster_groups[ug.cluster_group[c]].clusters[ug.cluster_vertex[c]].cluster_idx;
-            check(bt_find_paths_sample(fp, sample_bloom.h, seeds.data()), "bt_find_paths_sample");
-            check(bt_sync(ctx), "bt_sync");
+            try {
+                check(bt_find_paths_sample(fp, sample_bloom.h, seeds.data()), "bt_find_paths_sample");
+                check(bt_sync(ctx), "bt_sync");
+            } catch (...) {
+                if (coming.valid()) {   // (the loader's filter must not outlive the contexts)
+                    try {
+                        BloomHandle drop;
+                        drop.h = coming.get();
+                    } catch (...) {
+                    }
+                }
+                throw;
+            }
+            const auto t2 = std::chrono::steady_clock::now();
+            load_wait_s += std::chrono::duration<double>(t1 - t0).count();
+            search_s += std::chrono::duration<double>(t2 - t1).count();
         }
+        StageTimes::get().add("  sample Bloom filters: load, or wait for the loader thread", load_wait_s);
+        StageTimes::get().add("  best-path search of every sample (device)", search_s);
         std::vector<uint32_t> num_paths(C);
         uint64_t total = 0;
         check(bt_find_paths_sizes(fp, num_paths.data(), &total), "bt_find_paths_sizes");
