@@ -61,6 +61,7 @@ const char *const multigroup_kmers_file_prefix = "multigroup_kmers";
 const char *const parameter_kmers_file_prefix = "parameter_kmers";
 
 std::string stamp() { return "[" + getLocalTime() + "] "; }
+const std::chrono::steady_clock::time_point g_main_start = std::chrono::steady_clock::now();   // (static initialisation: just before main())
 
 void check(int rc, const char *what) {
     if (rc != BT_OK) throw std::runtime_error(std::string(what) + ": " + bt_last_error());
@@ -132,7 +133,9 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
     std::cout << "\n" << stamp() << "Parsed information for " << samples.size() << " sample(s)" << std::endl;
     const Chromosomes chromosomes = readGenome(options);
 
+    std::unique_ptr<StageScope> st_ctx(new StageScope("start-up: HIP runtime + context"));
     Context ctx;
+    st_ctx.reset();
     KmerCounter kmer_counter(ctx.h, samples, kmer_size, seed);
     std::unique_ptr<StageScope> st_read(new StageScope("read variant file"));
     VariantFileParser variant_file_parser(VariantFileParser::readVariantFile(options.getString("variant-file")), kmer_size, (uint32_t)options.getUInt("max-allele-length"), cnv_threshold);
@@ -246,6 +249,7 @@ int runCluster(int argc, char *const argv[], unsigned kmer_size) {
     }
     std::cout << stamp() << "Wrote " << num_multigroup_kmers << " kmers to " << cluster_data_dir << "/" << multigroup_kmers_file_prefix << ".bloom[Meta|Data]" << std::endl;
     st_tail.reset();
+    StageTimes::get().add("wall since main()", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_main_start).count());
     StageTimes::get().print("bayesTyper cluster");
     std::cout << "\n\n" << stamp() << "BayesTyper cluster completed succesfully!\n" << std::endl;
     return 0;
@@ -332,7 +336,9 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     const std::string parameter_kmers_dir_prefix = cluster_data_dir + "/" + parameter_kmers_file_prefix;
     const std::string multigroup_kmers_dir_prefix = cluster_data_dir + "/" + multigroup_kmers_file_prefix;
 
+    std::unique_ptr<StageScope> st_ctx(new StageScope("start-up: HIP runtime + context"));
     Context ctx;
+    st_ctx.reset();
     std::unique_ptr<Comm> comm = Comm::fromEnvironment(ctx.h);   // nullptr: one rank
     const int rank = comm ? comm->rank() : 0, world = comm ? comm->world() : 1;
     if (comm) std::cout << stamp() << "Rank " << rank << " of " << world << " (one GPU per rank)" << std::endl;
@@ -568,6 +574,9 @@ int runGenotype(int argc, char *const argv[], unsigned kmer_size) {
     std::cout << "\t- " << num_genotyped_variants << " were genotyped" << std::endl;
     std::cout << "\t- " << unit.num_variants - num_genotyped_variants << " were skipped (unsupported)" << std::endl;
     st.reset();
+    // (what the table does not list: option / sample parsing before the first stage, and — after this line — the release of the unit's host arrays and of the device
+    //  allocations when the process ends; the caller's wall clock also holds the loading of the executable and its libraries)
+    StageTimes::get().add("wall since main()", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_main_start).count());
     StageTimes::get().print("bayesTyper genotype");
     std::cout << "\n\n" << stamp() << "BayesTyper genotype completed succesfully!\n" << std::endl;
     if (comm) comm->barrier();
