@@ -397,14 +397,28 @@ def main():
         elapsed = float(t.item())
         gw = state.get("gather_words", (0, 0))
         props = torch.cuda.get_device_properties(dev)
+        # what identifies the GPU beyond its index in this process (ranks that are each shown ONE device all call it cuda:0): uuid or PCI bus id when torch has them
+        ident = None
+        for attr in ("uuid", "pci_bus_id"):
+            v = getattr(props, attr, None)
+            if v not in (None, "", 0):
+                ident = f"{attr} {v}"
+                break
+        if ident is None:
+            try:
+                ident = "pci " + torch.cuda.get_device_properties(dev).name + " / " + str(torch.cuda.mem_get_info(dev)[1]) + " B / HIP_VISIBLE_DEVICES=" + os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "all"))
+            except Exception:
+                ident = "unknown"
         mine = [C, float(np.mean(gibbs_ms)), float(np.mean([sum(x) for x in kmc_ms])), float(np.mean(fetch_ms)), float(np.mean(gather_ms)), int(gw[0]) * 4, int(gw[1]) * 4,
-                int(dev.index), "%s, %d CUs, pci %s" % (props.name, props.multi_processor_count, getattr(props, "pci_bus_id", "?")), os.getpid()]
+                int(dev.index), "%s, %d CUs, %s" % (props.name, props.multi_processor_count, ident), os.getpid()]
         rows = [None] * world
         dist.all_gather_object(rows, mine)
         per_rank = [{"rank": r, "clusters": int(x[0]), "gibbs_launch_ms": x[1], "kmc_scans_ms": x[2], "result_pack_ms": x[3], "gather_ms": x[4],
                      "result_string_bytes": int(x[5]), "gathered_bytes_all_ranks": int(x[6]), "device": x[7], "device_name": x[8], "pid": x[9]} for r, x in enumerate(rows)]
-        if len({(x[7], x[8]) for x in rows}) != world:
-            raise RuntimeError("bench: two ranks of the job ran on the same GPU: %s" % [(x[7], x[8]) for x in rows])
+        # two ranks on ONE GPU would halve each other: fatal — but only on positive evidence (the same uuid / PCI id twice), never because the identity is unknown
+        known = [x[8] for x in rows if ("uuid " in x[8] or "pci_bus_id " in x[8])]
+        if len(known) == world and len(set(known)) != world:
+            raise RuntimeError("bench: two ranks of the job ran on the same GPU: %s" % known)
     hits = int(d_hits.item())
     st = table.status()
     if st["overflowed"]:
