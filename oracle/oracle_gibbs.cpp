@@ -600,8 +600,11 @@ struct Genotyper {
         return lp;
     }
     void sampleDiplotype(const std::vector<ushort> &nz, const CountDist &cd, ushort s, uchar ploidy) {   // :707-755
+        const size_t num_expected_diplotypes = (nz.size() * (nz.size() - 1)) / 2 + nz.size();   // :709-713: the sampler and the candidate list are sized up front
         LogDiscreteSampler sampler;
+        sampler.cum_probs.reserve(num_expected_diplotypes);   // (LogDiscreteSampler(size_guess), DiscreteSampler.cpp:39)
         std::vector<Dip> cand;
+        cand.reserve(num_expected_diplotypes);
         if (ploidy == 2) {
             for (size_t a = 0; a < nz.size(); a++)
                 for (size_t b = a; b < nz.size(); b++) {
