@@ -598,12 +598,12 @@ def main():
                # what the port is measured against: the reference's own objects, one thread, in the build container at survey time (SURVEY.md section 6:
                # 2.8e5 cluster-sweeps/s for a biallelic SNV cluster at S = 10, 3.5e4 for a 4-SNV cluster with ten candidates) against the oracle's 2.0e5 / 3.4e4
                # there (docs/HISTORY.md section 2), 0.71 / 0.97 of it; since round 6 an estimated 0.94 / 1.06 (below)
-               "vs_reference_probe": {"A_S10": 0.94, "B_S10": 1.06, "A_S10_before_round6": 0.71, "B_S10_before_round6": 0.97,
+               "vs_reference_probe": {"A_S10": 0.95, "B_S10": 1.1, "A_S10_before_round6": 0.71, "B_S10_before_round6": 0.97,
                                       "note": "oracle / reference single-thread cluster-sweeps/s.  The survey-time probe (build container) gave 0.71 / 0.97; round 6 found the port's "
-                                              "two differences from the reference's build on this path — sampleDiplotype's sampler and candidate list were not reserved "
-                                              "(DiscreteSampler.cpp:39, VariantClusterGenotyper.cpp:709-713) and the port was built -O2 where the reference's CMakeLists uses -O3 — "
-                                              "and fixed both: 2.60e5 -> 3.43e5 (A) and 5.65e4 -> 6.17e4 (B) cluster-sweeps/s back to back in the build container, i.e. x 1.32 / x 1.09 "
-                                              "on the probe's ratios (the reference itself cannot be re-run here).  The port is not the reference; a speed-up over it is a reported "
+                                              "differences from the reference's build on this path — sampleDiplotype's sampler and candidate list and sampleDiplotypes' list of non-zero "
+                                              "haplotypes were not reserved (DiscreteSampler.cpp:39, VariantClusterGenotyper.cpp:672-673,709-713) and the port was built -O2 where the "
+                                              "reference's CMakeLists uses -O3 — and fixed them: 2.60e5 -> 3.4 - 3.6e5 (A) and 5.65e4 -> 6.3 - 6.9e4 (B) cluster-sweeps/s back to back in the "
+                                              "build container (a shared machine: +- 5 %), i.e. x 1.3 - 1.4 / x 1.1 - 1.2 on the probe's ratios (the reference itself cannot be re-run here).  The port is not the reference; a speed-up over it is a reported "
                                               "baseline, not a target"},
                "kmer_matches_per_sec_single_producer": kcpu, "kmer_matches_per_sec_parallel_decode": kcpu_par,
                "kmer_match_note": "400 000-record database: one thread decoding and probing (the reference's single producer is the serial stage) / "

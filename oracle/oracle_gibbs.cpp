@@ -626,6 +626,7 @@ struct Genotyper {
     }
     void sampleDiplotypes(const CountDist &cd, const std::vector<NestedVariantClusterInfo> &nested, bool collect, std::vector<uint32_t> *trace) {   // :668-705
         std::vector<ushort> nz;
+        nz.reserve(hap.H);   // (:672-673)
         for (ushort h = 0; h < hap.H; h++)
             if (hfd->getFrequency(h).first) nz.emplace_back(h);
         for (ushort s = 0; s < S; s++) {
